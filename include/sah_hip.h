@@ -1,0 +1,258 @@
+/* sah_hip.h — C ABI of the MI355X-native deferred lighting + GI + post hot path.
+ *
+ * This is the drop-in boundary.  The reference renderer has no FFI of its
+ * own; each entry point below replaces the GPU work recorded by one of the reference's C++ seams, cited
+ * as `RenderCore/...:line` (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns int: 0 = SAH_OK, < 0 = sah_status; nothing throws across the ABI;
+ *   - one sah_ctx per device; calls on one ctx are serialised by the caller (the reference records all
+ *     passes from one thread, RenderCore/render/scene_renderer.cpp:121-470);
+ *   - all work is enqueued on the ctx's HIP stream and is asynchronous; sah_sync() waits for it;
+ *   - the caller owns every buffer; image pointers are DEVICE pointers to linear row-major storage in
+ *     the VkFormat the reference allocates for that resource (format values are VkFormat enumerants);
+ *   - uniform blocks (sah_view_data, sah_sun_light_constants, cascade tables) are HOST pointers, read
+ *     during the call and passed to the kernels by value, like the reference's UBO uploads;
+ *   - matrices are column-major float[16] (glm / GLSL layout, m[col*4 + row]).
+ */
+#ifndef SAH_HIP_H
+#define SAH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAH_ABI_VERSION 1
+
+typedef enum sah_status {
+    SAH_OK = 0,
+    SAH_ERR_INVALID_ARGUMENT = -1,
+    SAH_ERR_UNSUPPORTED_FORMAT = -2,
+    SAH_ERR_HIP = -3,
+    SAH_ERR_NO_DEVICE = -4,
+    SAH_ERR_COMM = -5,
+    SAH_ERR_UNSUPPORTED = -6
+} sah_status;
+
+/* VkFormat values used on the path (Vulkan 1.4 core enumerants). */
+enum {
+    SAH_FORMAT_R8_UNORM = 9,
+    SAH_FORMAT_R8G8B8A8_UNORM = 37,
+    SAH_FORMAT_R8G8B8A8_SRGB = 43,
+    SAH_FORMAT_R16_SFLOAT = 76,
+    SAH_FORMAT_R16G16_SFLOAT = 83,
+    SAH_FORMAT_R16G16B16A16_SFLOAT = 97,
+    SAH_FORMAT_R32_SFLOAT = 100,
+    SAH_FORMAT_B10G11R11_UFLOAT_PACK32 = 122,
+    SAH_FORMAT_D16_UNORM = 124,
+    SAH_FORMAT_D32_SFLOAT = 126
+};
+
+/* ---- resources ------------------------------------------------------------------------------ */
+
+/* 2D image, linear row-major.  Stands in for the reference's TextureHandle
+ * (RenderCore/render/backend/handles.hpp:3-5). */
+typedef struct sah_plane {
+    void* ptr;
+    uint32_t width, height;
+    uint32_t row_pitch_bytes;
+    uint32_t format;
+} sah_plane;
+
+/* 3D image or 2D array (depth = slices / layers), linear. */
+typedef struct sah_volume {
+    void* ptr;
+    uint32_t width, height, depth;
+    uint32_t row_pitch_bytes, slice_pitch_bytes;
+    uint32_t format;
+} sah_volume;
+
+/* RenderCore/render/gbuffer.hpp:5-11; formats from RenderCore/render/scene_renderer.cpp:580-649. */
+typedef struct sah_gbuffer {
+    sah_plane color;    /* R8G8B8A8_SRGB   */
+    sah_plane normals;  /* R16G16B16A16_SFLOAT, xyz = world normal (not normalised) */
+    sah_plane data;     /* R8G8B8A8_UNORM, g = roughness, b = metalness */
+    sah_plane emission; /* R8G8B8A8_SRGB   */
+    sah_plane depth;    /* D32_SFLOAT, reversed-Z infinite far, 0 = sky */
+} sah_gbuffer;
+
+/* Bloom pyramid (RenderCore/render/bloomer.cpp:268-285): mip 0 = output/2, RGBA16F, tightly packed. */
+#define SAH_MAX_BLOOM_MIPS 8
+typedef struct sah_mipchain {
+    sah_plane mips[SAH_MAX_BLOOM_MIPS];
+    uint32_t num_mips;
+} sah_mipchain;
+
+/* ---- uniform blocks (byte-identical to RenderCore/shared/) ----------------------------------- */
+
+/* RenderCore/shared/view_data.hpp:6-40 — 432 bytes. */
+typedef struct sah_view_data {
+    float view[16];
+    float projection[16];
+    float inverse_view[16];
+    float inverse_projection[16];
+    float last_frame_view[16];
+    float last_frame_projection[16];
+    float frustum[4];
+    float z_near;
+    float material_texture_mip_bias;
+    float render_resolution[2];
+    float jitter[2];
+    float previous_jitter[2];
+} sah_view_data;
+
+#define SAH_SHADOW_MODE_OFF 0
+#define SAH_SHADOW_MODE_CSM 1
+#define SAH_SHADOW_MODE_RT 2
+
+/* RenderCore/shared/sun_light_constants.hpp:10-44 — 640 bytes. */
+typedef struct sah_sun_light_constants {
+    float direction_and_tan_size[4];
+    float color[4];
+    uint32_t csm_resolution[4];
+    float data[4][4]; /* split depth in .x */
+    float cascade_matrices[4][16];
+    float cascade_inverse_matrices[4][16];
+    uint32_t shadow_mode;
+    float num_shadow_samples;
+    uint32_t padding1, padding2;
+} sah_sun_light_constants;
+
+/* RenderCore/shared/lpv.hpp:6-11 — 256 bytes. */
+typedef struct sah_lpv_cascade_matrices {
+    float rsm_vp[16];
+    float inverse_rsm_vp[16];
+    float world_to_cascade[16];
+    float cascade_to_world[16];
+} sah_lpv_cascade_matrices;
+
+/* RenderCore/shared/gi_probe.hpp:5-8 — 16 bytes. */
+typedef struct sah_probe_cascade {
+    float min[3];
+    float probe_spacing;
+} sah_probe_cascade;
+
+/* ---- lighting pass --------------------------------------------------------------------------- */
+
+typedef enum sah_gi_kind { SAH_GI_NONE = 0, SAH_GI_LPV = 1, SAH_GI_CACHE = 2, SAH_GI_RTGI = 3 } sah_gi_kind;
+
+/* What IGlobalIlluminator::render_to_lit_scene binds (RenderCore/render/gi/global_illuminator.hpp:38-40):
+ *   LPV   RenderCore/render/gi/light_propagation_volume.cpp:274-306
+ *   CACHE RenderCore/render/gi/irradiance_cache.cpp:287-306
+ *   RTGI  RenderCore/render/gi/rtgi.cpp:160-188 */
+typedef struct sah_gi {
+    uint32_t kind; /* sah_gi_kind */
+
+    /* LPV: three RGBA16F 3D volumes, (32*num_cascades) x 32 x 32 */
+    sah_volume lpv_red, lpv_green, lpv_blue;
+    const sah_lpv_cascade_matrices* lpv_cascades; /* host, lpv_num_cascades entries (<= 4) */
+    uint32_t lpv_num_cascades;
+    float lpv_exposure; /* r.GI.LPV.Exposure, default pi*10 */
+
+    /* Irradiance cache: 2D arrays with 32 layers */
+    sah_volume probe_irradiance; /* B10G11R11_UFLOAT 224x256x32 */
+    sah_volume probe_depth;      /* R16G16_SFLOAT   384x384x32 */
+    sah_volume probe_validity;   /* R8_UNORM        32x32x32   */
+    sah_probe_cascade probe_cascades[4];
+    uint32_t probe_size[2]; /* push constants, (5,6) in the reference */
+    uint32_t cache_debug_mode;
+
+    /* RTGI reconstruction */
+    sah_plane ray_buffer;     /* RGBA16F: ray direction xyz, distance */
+    sah_plane ray_irradiance; /* RGBA16F */
+    sah_plane noise;          /* RGBA8_UNORM 128x128 blue-noise layer */
+    uint32_t num_extra_rays;  /* r.GI.Reconstruction.NumSamples */
+    float extra_ray_radius;   /* r.GI.Reconstruction.Size */
+} sah_gi;
+
+/* Sky LUTs sampled by the sky fill (RenderCore/render/procedural_sky.cpp:13-42,151-172). */
+typedef struct sah_sky_luts {
+    sah_plane transmittance; /* RGBA16F 256x64  */
+    sah_plane sky_view;      /* RGBA16F 200x200 */
+} sah_sky_luts;
+
+/* Extension (not in the reference): point lights, BASELINE configs 2/3/5.  Spec in DESIGN.md §a9. */
+typedef struct sah_point_light {
+    float position[3];
+    float radius;
+    float color[3];
+    float intensity;
+} sah_point_light;
+
+typedef struct sah_light_list {
+    const sah_point_light* lights; /* device pointer */
+    uint32_t count;
+} sah_light_list;
+
+/* flags */
+#define SAH_LIGHTING_QUIRK_SUN_BLEND (1u << 0) /* reproduce the SRC_COLOR/DST_COLOR sun blend (squares the sun term) */
+#define SAH_LIGHTING_BRUTE_FORCE_LIGHTS (1u << 1) /* shade every light for every pixel (no tile culling) */
+#define SAH_LIGHTING_DEFAULT_FLAGS (SAH_LIGHTING_QUIRK_SUN_BLEND)
+
+/* One "Lighting" pass: RenderCore/render/phase/lighting_phase.cpp:34-134
+ * (clear, sun [CSM], GI overlay, emissive, sky, then sun [RT mode] as a read-modify-write). */
+typedef struct sah_lighting_desc {
+    const sah_gbuffer* gbuffer;
+    const sah_plane* ao;  /* R32_SFLOAT, consumed only by the LPV overlay; may be NULL otherwise */
+    const sah_plane* lit; /* out: R16G16B16A16_SFLOAT */
+    const sah_view_data* view;
+    const sah_sun_light_constants* sun; /* sun->shadow_mode selects off / CSM / RT */
+    const sah_volume* shadowmap;        /* CSM mode: D16_UNORM 2D array, one layer per cascade */
+    const sah_plane* shadow_mask;       /* RT mode: per-pixel visibility fraction (R32_SFLOAT), NULL = 1 */
+    const sah_light_list* lights;       /* may be NULL */
+    const sah_gi* gi;                   /* may be NULL (= no GI) */
+    const sah_sky_luts* sky;            /* NULL = no sky fill */
+    uint32_t flags;
+    uint32_t row_begin, row_end; /* rows [row_begin, row_end) are shaded; 0,0 = whole image */
+} sah_lighting_desc;
+
+/* ---- API ------------------------------------------------------------------------------------- */
+
+typedef struct sah_ctx sah_ctx;
+
+int sah_abi_version(void);
+const char* sah_status_string(int status);
+const char* sah_last_error(const sah_ctx* ctx);
+
+/* comm_id: NULL when world == 1; otherwise the 128-byte ncclUniqueId from sah_comm_unique_id(). */
+int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_id);
+void sah_destroy(sah_ctx* ctx);
+int sah_comm_unique_id(void* out_128_bytes);
+/* Use an externally owned hipStream_t (e.g. the caller's frame stream) for all subsequent work. */
+int sah_set_stream(sah_ctx* ctx, void* hip_stream);
+int sah_sync(sah_ctx* ctx);
+
+/* LightingPhase::render — RenderCore/render/phase/lighting_phase.hpp:33-43 */
+int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* desc);
+
+/* "Copy scene" (AA = None) — RenderCore/render/scene_renderer.cpp:502-527 */
+int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* antialiased);
+
+/* Bloomer::fill_bloom_tex — RenderCore/render/bloomer.hpp:15, bloomer.cpp:38-262 */
+int sah_bloom(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom);
+
+/* UiPhase::draw_scene_image — RenderCore/render/phase/ui_phase.cpp:98-113; out = R8G8B8A8 (sRGB-encoded).
+ * Rows [row_begin,row_end) of the output are written (0,0 = all). */
+int sah_tonemap(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, const sah_plane* out_rgba8,
+                uint32_t row_begin, uint32_t row_end);
+
+/* LightPropagationVolume::clear_volume / propagate_lighting —
+ * RenderCore/render/gi/light_propagation_volume.cpp:839-926, 970-1063.
+ * a_* hold the injected light on entry and the propagated light on return when steps is even
+ * (the reference ping-pongs A->B->A...; with 32 steps the result is in A). */
+int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, const sah_volume* blue,
+                  const sah_volume* geometry, uint32_t num_cascades);
+int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades,
+                      uint32_t steps);
+
+/* Multi-GPU: in-place all-gather of row blocks of `image` (rank r owns rows
+ * [rows_per_rank*r, rows_per_rank*(r+1))) over RCCL. */
+int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAH_HIP_H */
