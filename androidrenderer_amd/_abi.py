@@ -1,0 +1,109 @@
+"""ctypes mirror of include/sah_hip.h (the C ABI). Field order and sizes must match the header exactly;
+tests/test_abi.py checks the struct sizes against the values the library reports."""
+import ctypes as C
+
+SAH_OK = 0
+SAH_ERR_INVALID_ARGUMENT = -1
+SAH_ERR_UNSUPPORTED_FORMAT = -2
+SAH_ERR_HIP = -3
+SAH_ERR_NO_DEVICE = -4
+SAH_ERR_COMM = -5
+SAH_ERR_UNSUPPORTED = -6
+
+FORMAT_R8_UNORM = 9
+FORMAT_R8G8B8A8_UNORM = 37
+FORMAT_R8G8B8A8_SRGB = 43
+FORMAT_R16_SFLOAT = 76
+FORMAT_R16G16_SFLOAT = 83
+FORMAT_R16G16B16A16_SFLOAT = 97
+FORMAT_R32_SFLOAT = 100
+FORMAT_B10G11R11_UFLOAT_PACK32 = 122
+FORMAT_D16_UNORM = 124
+FORMAT_D32_SFLOAT = 126
+
+FORMAT_BPP = {9: 1, 37: 4, 43: 4, 76: 2, 83: 4, 97: 8, 100: 4, 122: 4, 124: 2, 126: 4}
+
+SHADOW_MODE_OFF, SHADOW_MODE_CSM, SHADOW_MODE_RT = 0, 1, 2
+GI_NONE, GI_LPV, GI_CACHE, GI_RTGI = 0, 1, 2, 3
+LIGHTING_QUIRK_SUN_BLEND = 1 << 0
+LIGHTING_BRUTE_FORCE_LIGHTS = 1 << 1
+LIGHTING_DEFAULT_FLAGS = LIGHTING_QUIRK_SUN_BLEND
+MAX_BLOOM_MIPS = 8
+
+
+class Plane(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("row_pitch_bytes", C.c_uint32),
+                ("format", C.c_uint32)]
+
+
+class Volume(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_uint32),
+                ("row_pitch_bytes", C.c_uint32), ("slice_pitch_bytes", C.c_uint32), ("format", C.c_uint32)]
+
+
+class GBuffer(C.Structure):
+    _fields_ = [("color", Plane), ("normals", Plane), ("data", Plane), ("emission", Plane), ("depth", Plane)]
+
+
+class MipChain(C.Structure):
+    _fields_ = [("mips", Plane * MAX_BLOOM_MIPS), ("num_mips", C.c_uint32)]
+
+
+class ViewData(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("projection", C.c_float * 16), ("inverse_view", C.c_float * 16),
+                ("inverse_projection", C.c_float * 16), ("last_frame_view", C.c_float * 16),
+                ("last_frame_projection", C.c_float * 16), ("frustum", C.c_float * 4), ("z_near", C.c_float),
+                ("material_texture_mip_bias", C.c_float), ("render_resolution", C.c_float * 2), ("jitter", C.c_float * 2),
+                ("previous_jitter", C.c_float * 2)]
+
+
+class SunLightConstants(C.Structure):
+    _fields_ = [("direction_and_tan_size", C.c_float * 4), ("color", C.c_float * 4), ("csm_resolution", C.c_uint32 * 4),
+                ("data", (C.c_float * 4) * 4), ("cascade_matrices", (C.c_float * 16) * 4),
+                ("cascade_inverse_matrices", (C.c_float * 16) * 4), ("shadow_mode", C.c_uint32),
+                ("num_shadow_samples", C.c_float), ("padding1", C.c_uint32), ("padding2", C.c_uint32)]
+
+
+class LpvCascadeMatrices(C.Structure):
+    _fields_ = [("rsm_vp", C.c_float * 16), ("inverse_rsm_vp", C.c_float * 16), ("world_to_cascade", C.c_float * 16),
+                ("cascade_to_world", C.c_float * 16)]
+
+
+class ProbeCascade(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("probe_spacing", C.c_float)]
+
+
+class GI(C.Structure):
+    _fields_ = [("kind", C.c_uint32),
+                ("lpv_red", Volume), ("lpv_green", Volume), ("lpv_blue", Volume),
+                ("lpv_cascades", C.POINTER(LpvCascadeMatrices)), ("lpv_num_cascades", C.c_uint32), ("lpv_exposure", C.c_float),
+                ("probe_irradiance", Volume), ("probe_depth", Volume), ("probe_validity", Volume),
+                ("probe_cascades", ProbeCascade * 4), ("probe_size", C.c_uint32 * 2), ("cache_debug_mode", C.c_uint32),
+                ("ray_buffer", Plane), ("ray_irradiance", Plane), ("noise", Plane), ("num_extra_rays", C.c_uint32),
+                ("extra_ray_radius", C.c_float)]
+
+
+class SkyLuts(C.Structure):
+    _fields_ = [("transmittance", Plane), ("sky_view", Plane)]
+
+
+class PointLight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("radius", C.c_float), ("color", C.c_float * 3), ("intensity", C.c_float)]
+
+
+class LightList(C.Structure):
+    _fields_ = [("lights", C.c_void_p), ("count", C.c_uint32)]
+
+
+class LightingDesc(C.Structure):
+    _fields_ = [("gbuffer", C.POINTER(GBuffer)), ("ao", C.POINTER(Plane)), ("lit", C.POINTER(Plane)),
+                ("view", C.POINTER(ViewData)), ("sun", C.POINTER(SunLightConstants)), ("shadowmap", C.POINTER(Volume)),
+                ("shadow_mask", C.POINTER(Plane)), ("lights", C.POINTER(LightList)), ("gi", C.POINTER(GI)),
+                ("sky", C.POINTER(SkyLuts)), ("flags", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32)]
+
+
+assert C.sizeof(ViewData) == 432
+assert C.sizeof(SunLightConstants) == 640
+assert C.sizeof(LpvCascadeMatrices) == 256
+assert C.sizeof(ProbeCascade) == 16
+assert C.sizeof(PointLight) == 32

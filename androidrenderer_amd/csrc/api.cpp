@@ -1,0 +1,337 @@
+// C ABI implementation (include/sah_hip.h): argument validation, host-side digestion of the uniform blocks,
+// kernel launches on the context's HIP stream.  Compiled by hipcc with -ffp-contract=off: the fp32 expressions
+// evaluated here are the uniform sub-expressions of the reference shaders and must round exactly as the
+// per-pixel code would.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/sah_hip.h"
+#include "params.hpp"
+
+namespace sah {
+hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
+                           const SkyArgs& sky, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
+hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+struct TonemapArgs;
+hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
+hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+}  // namespace sah
+
+#include "ctx.hpp"
+#include "post_args.hpp"
+
+namespace {
+
+
+bool vec_ok(const sah_plane* p, uint32_t bytes) { return ((uintptr_t)p->ptr % bytes) == 0 && (p->row_pitch_bytes % bytes) == 0; }
+
+// fp32 helpers that mirror the shader expressions (individually rounded; this TU is built with -ffp-contract=off)
+void normalize3(const float in[3], float out[3]) {
+    const float d = in[0] * in[0] + in[1] * in[1] + in[2] * in[2];
+    const float inv = 1.0f / std::sqrt(d);
+    for (int i = 0; i < 3; i++) out[i] = in[i] * inv;
+}
+void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - b[1] * a[2];
+    o[1] = a[2] * b[0] - b[2] * a[0];
+    o[2] = a[0] * b[1] - b[0] * a[1];
+}
+float round_to_half(float f) { return (float)(_Float16)f; }
+
+}  // namespace
+
+extern "C" {
+
+int sah_abi_version(void) { return SAH_ABI_VERSION; }
+
+const char* sah_status_string(int s) {
+    switch (s) {
+        case SAH_OK: return "ok";
+        case SAH_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case SAH_ERR_UNSUPPORTED_FORMAT: return "unsupported format";
+        case SAH_ERR_HIP: return "HIP error";
+        case SAH_ERR_NO_DEVICE: return "no HIP device";
+        case SAH_ERR_COMM: return "communicator error";
+        case SAH_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown";
+}
+
+const char* sah_last_error(const sah_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int sah_comm_init(sah_ctx* ctx, const void* comm_id);
+void sah_comm_destroy(sah_ctx* ctx);
+
+int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_id) {
+    if (!out || world < 1 || rank < 0 || rank >= world) return SAH_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return SAH_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return SAH_ERR_INVALID_ARGUMENT;
+    sah_ctx* ctx = new sah_ctx();
+    ctx->device = device;
+    ctx->rank = rank;
+    ctx->world = world;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return SAH_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SAH_ERR_HIP; }
+    ctx->own_stream = true;
+    // format tables: sRGB8 -> linear (Vulkan sRGB EOTF, evaluated in double, rounded to fp32) and UNORM8 -> float
+    float host[512];
+    for (int i = 0; i < 256; i++) {
+        const double c = (double)i / 255.0;
+        host[i] = (float)((c <= 0.04045) ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+        host[256 + i] = (float)i / 255.0f;
+    }
+    if (hipMalloc((void**)&ctx->luts, sizeof(host)) != hipSuccess ||
+        hipMemcpy(ctx->luts, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) {
+        sah_destroy(ctx);
+        return SAH_ERR_HIP;
+    }
+    if (world > 1 && comm_id) {
+        int rc = sah_comm_init(ctx, comm_id);
+        if (rc != SAH_OK) { sah_destroy(ctx); return rc; }
+    }
+    const char* ppt = getenv("SAH_FORCE_PPT");
+    if (ppt) ctx->force_ppt = atoi(ppt);
+    *out = ctx;
+    return SAH_OK;
+}
+
+void sah_destroy(sah_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    sah_comm_destroy(ctx);
+    if (ctx->luts) (void)hipFree(ctx->luts);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int sah_set_stream(sah_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return SAH_OK;
+}
+
+void* sah_get_stream(sah_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sah_sync(sah_ctx* ctx) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAH_OK;
+}
+
+int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
+    using namespace sah;
+    if (!ctx || !d) return SAH_ERR_INVALID_ARGUMENT;
+    if (!d->gbuffer || !d->lit || !d->view) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "gbuffer, lit and view are required");
+    const sah_gbuffer& g = *d->gbuffer;
+    const uint32_t W = d->lit->width, H = d->lit->height;
+    if (W == 0 || H == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "empty render target");
+    if (!plane_ok(d->lit, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "lit must be R16G16B16A16_SFLOAT");
+    if (!plane_ok(&g.color, SAH_FORMAT_R8G8B8A8_SRGB, SAH_FORMAT_R8G8B8A8_SRGB, W, H) ||
+        !plane_ok(&g.normals, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H) ||
+        !plane_ok(&g.data, SAH_FORMAT_R8G8B8A8_UNORM, SAH_FORMAT_R8G8B8A8_UNORM, W, H) ||
+        !plane_ok(&g.emission, SAH_FORMAT_R8G8B8A8_SRGB, SAH_FORMAT_R8G8B8A8_SRGB, W, H) ||
+        !plane_ok(&g.depth, SAH_FORMAT_D32_SFLOAT, SAH_FORMAT_R32_SFLOAT, W, H))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "g-buffer planes must match the reference formats and the lit extent");
+    uint32_t r0 = d->row_begin, r1 = d->row_end;
+    if (r0 == 0 && r1 == 0) r1 = H;
+    if (r1 > H || r0 > r1) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "row range [%u,%u) outside image height %u", r0, r1, H);
+
+    const uint32_t sun_mode = d->sun ? d->sun->shadow_mode : SAH_SHADOW_MODE_OFF;
+    if (sun_mode > SAH_SHADOW_MODE_RT) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad shadow_mode %u", sun_mode);
+    const uint32_t gi_kind = d->gi ? d->gi->kind : SAH_GI_NONE;
+    if (gi_kind > SAH_GI_RTGI) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad gi kind %u", gi_kind);
+    if ((d->sky || d->lights) && !d->sun) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sun constants are required with sky");
+
+    LightingArgs a;
+    memset(&a, 0, sizeof(a));
+    a.color = parg(&g.color);
+    a.normals = parg(&g.normals);
+    a.data = parg(&g.data);
+    a.emission = parg(&g.emission);
+    a.depth = parg(&g.depth);
+    a.lit = parg(d->lit);
+    a.width = W;
+    a.height = H;
+    a.row_begin = r0;
+    a.row_end = r1;
+    a.flags = d->flags;
+    a.res[0] = d->view->render_resolution[0];
+    a.res[1] = d->view->render_resolution[1];
+    memcpy(a.inv_proj, d->view->inverse_projection, 64);
+    memcpy(a.inv_view, d->view->inverse_view, 64);
+    for (int i = 0; i < 3; i++) a.view_pos[i] = -d->view->view[12 + i];  // `-view[3].xyz` (directional_light.frag:112)
+    a.luts = ctx->luts;
+    if (d->sun) {
+        const float neg[3] = {-d->sun->direction_and_tan_size[0], -d->sun->direction_and_tan_size[1], -d->sun->direction_and_tan_size[2]};
+        normalize3(neg, a.sun_L);
+        for (int i = 0; i < 3; i++) a.sun_color[i] = d->sun->color[i];
+    }
+    bool vec4ok = (W % 4 == 0) && vec_ok(&g.color, 16) && vec_ok(&g.normals, 16) && vec_ok(&g.data, 16) && vec_ok(&g.emission, 16) &&
+                  vec_ok(&g.depth, 16) && vec_ok(d->lit, 16);
+
+    if (gi_kind == SAH_GI_LPV && d->ao && d->ao->ptr) {
+        if (!plane_ok(d->ao, SAH_FORMAT_R32_SFLOAT, SAH_FORMAT_R32_SFLOAT, W, H)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "ao must be R32_SFLOAT");
+        a.ao = parg(d->ao);
+        a.has_ao = 1;
+        vec4ok = vec4ok && vec_ok(d->ao, 16);
+    }
+    if (sun_mode == SAH_SHADOW_MODE_RT && d->shadow_mask && d->shadow_mask->ptr) {
+        if (!plane_ok(d->shadow_mask, SAH_FORMAT_R32_SFLOAT, SAH_FORMAT_R32_SFLOAT, W, H))
+            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "shadow_mask must be R32_SFLOAT");
+        a.shadow_mask = parg(d->shadow_mask);
+        a.has_mask = 1;
+        vec4ok = vec4ok && vec_ok(d->shadow_mask, 16);
+    }
+
+    CsmArgs csm;
+    memset(&csm, 0, sizeof(csm));
+    if (sun_mode == SAH_SHADOW_MODE_CSM) {
+        if (d->shadowmap && d->shadowmap->ptr) {
+            if (d->shadowmap->format != SAH_FORMAT_D16_UNORM && d->shadowmap->format != SAH_FORMAT_D32_SFLOAT)
+                return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "shadowmap must be D16_UNORM or D32_SFLOAT");
+            if (d->shadowmap->depth < 4) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadowmap needs 4 layers");
+            csm.shadowmap = varg(*d->shadowmap);
+            csm.is_d16 = d->shadowmap->format == SAH_FORMAT_D16_UNORM;
+        }
+        for (int c = 0; c < 4; c++) {
+            csm.splits[c] = d->sun->data[c][0];
+            // biasMat * cascade_matrices[c] (directional_light.frag:55-65), evaluated as the matrix product it is
+            const float* M = d->sun->cascade_matrices[c];
+            for (int col = 0; col < 4; col++) {
+                const float* m = M + col * 4;
+                csm.biased[c][col * 4 + 0] = ((0.5f * m[0] + 0.0f * m[1]) + 0.0f * m[2]) + 0.5f * m[3];
+                csm.biased[c][col * 4 + 1] = ((0.0f * m[0] + 0.5f * m[1]) + 0.0f * m[2]) + 0.5f * m[3];
+                csm.biased[c][col * 4 + 2] = ((0.0f * m[0] + 0.0f * m[1]) + 1.0f * m[2]) + 0.0f * m[3];
+                csm.biased[c][col * 4 + 3] = ((0.0f * m[0] + 0.0f * m[1]) + 0.0f * m[2]) + 1.0f * m[3];
+            }
+        }
+    }
+
+    LpvArgs lpv;
+    memset(&lpv, 0, sizeof(lpv));
+    CacheArgs cache;
+    memset(&cache, 0, sizeof(cache));
+    RtgiArgs rtgi;
+    memset(&rtgi, 0, sizeof(rtgi));
+    if (gi_kind == SAH_GI_LPV) {
+        const sah_gi& gi = *d->gi;
+        if (gi.lpv_num_cascades == 0 || gi.lpv_num_cascades > 4 || !gi.lpv_cascades)
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "LPV needs 1..4 cascades and their matrices");
+        const sah_volume* vols[3] = {&gi.lpv_red, &gi.lpv_green, &gi.lpv_blue};
+        for (const sah_volume* v : vols) {
+            if (!v->ptr || v->format != SAH_FORMAT_R16G16B16A16_SFLOAT) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "LPV volumes must be RGBA16F");
+            if ((uint64_t)v->row_pitch_bytes < (uint64_t)v->width * 8 || (uint64_t)v->slice_pitch_bytes < (uint64_t)v->row_pitch_bytes * v->height)
+                return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "LPV volume pitches too small");
+        }
+        lpv.red = varg(gi.lpv_red);
+        lpv.green = varg(gi.lpv_green);
+        lpv.blue = varg(gi.lpv_blue);
+        for (uint32_t c = 0; c < gi.lpv_num_cascades; c++) memcpy(lpv.world_to_cascade[c], gi.lpv_cascades[c].world_to_cascade, 64);
+        lpv.num_cascades = gi.lpv_num_cascades;
+        lpv.num_cascades_f = (float)gi.lpv_num_cascades;
+        lpv.exposure = gi.lpv_exposure;
+    } else if (gi_kind == SAH_GI_CACHE) {
+        const sah_gi& gi = *d->gi;
+        if (!gi.probe_irradiance.ptr || gi.probe_irradiance.format != SAH_FORMAT_B10G11R11_UFLOAT_PACK32 || !gi.probe_depth.ptr ||
+            gi.probe_depth.format != SAH_FORMAT_R16G16_SFLOAT || !gi.probe_validity.ptr || gi.probe_validity.format != SAH_FORMAT_R8_UNORM)
+            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "probe atlases must be B10G11R11 / R16G16F / R8_UNORM arrays");
+        cache.irradiance = varg(gi.probe_irradiance);
+        cache.depth = varg(gi.probe_depth);
+        cache.validity = varg(gi.probe_validity);
+        for (int c = 0; c < 4; c++) {
+            const float ext[3] = {32.f, 8.f, 32.f};
+            for (int i = 0; i < 3; i++) {
+                cache.cascade_min[c][i] = gi.probe_cascades[c].min[i];
+                cache.cascade_max[c][i] = gi.probe_cascades[c].min[i] + ext[i] * gi.probe_cascades[c].probe_spacing;
+            }
+            cache.spacing[c] = gi.probe_cascades[c].probe_spacing;
+        }
+        cache.probe_size[0] = gi.probe_size[0];
+        cache.probe_size[1] = gi.probe_size[1];
+        cache.debug_mode = gi.cache_debug_mode;
+    } else if (gi_kind == SAH_GI_RTGI) {
+        const sah_gi& gi = *d->gi;
+        if (!plane_ok(&gi.ray_buffer, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H) ||
+            !plane_ok(&gi.ray_irradiance, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H))
+            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "ray_buffer / ray_irradiance must be RGBA16F at render resolution");
+        rtgi.ray_buffer = parg(&gi.ray_buffer);
+        rtgi.ray_irradiance = parg(&gi.ray_irradiance);
+        if (gi.num_extra_rays) {
+            if (!gi.noise.ptr || gi.noise.format != SAH_FORMAT_R8G8B8A8_UNORM || gi.noise.width < 128 || gi.noise.height < 128)
+                return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "noise must be R8G8B8A8_UNORM, at least 128x128");
+            rtgi.noise = parg(&gi.noise);
+            rtgi.noise_w = gi.noise.width;
+            rtgi.noise_h = gi.noise.height;
+        }
+        rtgi.num_extra_rays = gi.num_extra_rays;
+        rtgi.extra_ray_radius = gi.extra_ray_radius;
+    }
+
+    SkyArgs sky;
+    memset(&sky, 0, sizeof(sky));
+    if (d->sky) {
+        const sah_sky_luts& s = *d->sky;
+        if (!s.transmittance.ptr || !s.sky_view.ptr || s.transmittance.format != SAH_FORMAT_R16G16B16A16_SFLOAT ||
+            s.sky_view.format != SAH_FORMAT_R16G16B16A16_SFLOAT)
+            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "sky LUTs must be RGBA16F");
+        sky.enabled = 1;
+        sky.transmittance = parg(&s.transmittance);
+        sky.sky_view = parg(&s.sky_view);
+        sky.t_w = s.transmittance.width;
+        sky.t_h = s.transmittance.height;
+        sky.s_w = s.sky_view.width;
+        sky.s_h = s.sky_view.height;
+        // uniform sub-expressions of sky_unified.slang:80-135,185-206
+        const float sky_pi = 3.14159265358f;
+        const float ground = 6.360f;
+        const float dirn[3] = {d->sun->direction_and_tan_size[0], d->sun->direction_and_tan_size[1], d->sun->direction_and_tan_size[2]};
+        float nd[3];
+        normalize3(dirn, nd);
+        for (int i = 0; i < 3; i++) sky.sun_dir[i] = -nd[i];
+        sky.view_pos_y = 6.360f + 0.0002f;
+        sky.height = std::sqrt((0.0f * 0.0f + sky.view_pos_y * sky.view_pos_y) + 0.0f * 0.0f);
+        sky.up_y = sky.view_pos_y / sky.height;
+        {
+            float q = std::sqrt(sky.height * sky.height - ground * ground) / sky.height;
+            q = std::fmin(std::fmax(q, -1.0f), 1.0f);
+            sky.horizon_angle = (float)std::acos((double)q);
+        }
+        sky.azimuth_limit = 0.5f * sky_pi - .0001f;
+        sky.min_sun_cos = (float)std::cos((double)(0.53f * sky_pi / 180.0f));
+        const float up[3] = {0.0f / sky.height, sky.up_y, 0.0f / sky.height};
+        cross3(sky.sun_dir, up, sky.right);
+        cross3(up, sky.right, sky.forward);
+        sky.smooth_e0 = round_to_half(0.002f);
+    }
+
+    int ppt = vec4ok ? 4 : 1;
+    if (ctx->force_ppt == 1 || ctx->force_ppt == 2 || ctx->force_ppt == 4) {
+        if (ctx->force_ppt == 1 || (vec4ok && W % ctx->force_ppt == 0)) ppt = ctx->force_ppt;
+    }
+    if (d->lights && d->lights->count) {
+        if (!d->lights->lights) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "light list pointer is null");
+        a.lights = d->lights->lights;
+        a.num_lights = d->lights->count;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, (int)sun_mode, (int)gi_kind, ppt,
+                                 (d->flags & SAH_LIGHTING_BRUTE_FORCE_LIGHTS) != 0, ctx->stream));
+    return SAH_OK;
+}
+
+}  // extern "C"

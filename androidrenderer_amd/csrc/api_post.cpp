@@ -1,0 +1,190 @@
+// C ABI: post chain, LPV maintenance and the RCCL row all-gather.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/sah_hip.h"
+#include "ctx.hpp"
+#include "post_args.hpp"
+
+namespace sah {
+hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
+hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+}  // namespace sah
+
+namespace {
+bool rgba16f_ok(const sah_plane* p) {
+    return p && p->ptr && p->format == SAH_FORMAT_R16G16B16A16_SFLOAT && p->width && p->height &&
+           (uint64_t)p->row_pitch_bytes >= (uint64_t)p->width * 8 && ((uintptr_t)p->ptr % 8) == 0 && (p->row_pitch_bytes % 8) == 0;
+}
+bool lpv_vol_ok(const sah_volume* v) {
+    return v && v->ptr && v->format == SAH_FORMAT_R16G16B16A16_SFLOAT && (uint64_t)v->row_pitch_bytes >= (uint64_t)v->width * 8 &&
+           (uint64_t)v->slice_pitch_bytes >= (uint64_t)v->row_pitch_bytes * v->height && ((uintptr_t)v->ptr % 8) == 0 &&
+           (v->row_pitch_bytes % 8) == 0 && (v->slice_pitch_bytes % 8) == 0;
+}
+}  // namespace
+
+extern "C" {
+
+int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!rgba16f_ok(lit) || !rgba16f_ok(out)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "copy_scene needs RGBA16F planes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_copy_scene(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_bloom(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!rgba16f_ok(scene) || !bloom || bloom->num_mips == 0 || bloom->num_mips > SAH_MAX_BLOOM_MIPS)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs an RGBA16F scene and 1..%d mips", SAH_MAX_BLOOM_MIPS);
+    for (uint32_t m = 0; m < bloom->num_mips; m++)
+        if (!rgba16f_ok(&bloom->mips[m])) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "bloom mip %u must be RGBA16F", m);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const sah_plane* src = scene;
+    for (uint32_t m = 0; m < bloom->num_mips; m++) {  // bloomer.cpp:50-151: scene -> mip0, mip i -> mip i+1
+        const sah_plane* dst = &bloom->mips[m];
+        HIP_TRY(ctx, sah::launch_bloom_downsample(parg(src), src->width, src->height, parg(dst), dst->width, dst->height, ctx->stream));
+        src = dst;
+    }
+    return SAH_OK;
+}
+
+int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!rgba16f_ok(scene) || !bloom || bloom->num_mips > SAH_MAX_BLOOM_MIPS || !out || !out->ptr)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "tonemap needs scene, bloom chain and output");
+    if (out->format != SAH_FORMAT_R8G8B8A8_SRGB && out->format != SAH_FORMAT_R8G8B8A8_UNORM)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "tonemap output must be R8G8B8A8");
+    if ((uint64_t)out->row_pitch_bytes < (uint64_t)out->width * 4 || ((uintptr_t)out->ptr % 4) || (out->row_pitch_bytes % 4))
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad output pitch/alignment");
+    if (row_begin == 0 && row_end == 0) row_end = out->height;
+    if (row_end > out->height || row_begin > row_end) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad row range");
+    sah::TonemapArgs t;
+    memset(&t, 0, sizeof(t));
+    t.scene = parg(scene);
+    t.scene_w = scene->width;
+    t.scene_h = scene->height;
+    t.num_mips = bloom->num_mips;
+    for (uint32_t m = 0; m < bloom->num_mips; m++) {
+        if (!rgba16f_ok(&bloom->mips[m])) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "bloom mip %u must be RGBA16F", m);
+        t.mips[m] = parg(&bloom->mips[m]);
+        t.mip_w[m] = bloom->mips[m].width;
+        t.mip_h[m] = bloom->mips[m].height;
+    }
+    t.out = parg(out);
+    t.out_w = out->width;
+    t.out_h = out->height;
+    t.row_begin = row_begin;
+    t.row_end = row_end;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_tonemap(t, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, const sah_volume* blue, const sah_volume* geometry,
+                  uint32_t num_cascades) {
+    if (!ctx || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
+    const sah_volume* in[4] = {red, green, blue, geometry};
+    sah::VolumeArg v[4];
+    int n = 0;
+    for (const sah_volume* p : in) {
+        if (!p || !p->ptr) continue;
+        if (!lpv_vol_ok(p)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "LPV volumes must be RGBA16F, 8-byte aligned");
+        v[n++] = varg(*p);
+    }
+    if (n == 0) return SAH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_lpv_clear(v, n, num_cascades, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades, uint32_t steps) {
+    if (!ctx || !a_rgb || !b_rgb || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
+    sah::VolumeArg a[3], b[3];
+    for (int i = 0; i < 3; i++) {
+        if (!lpv_vol_ok(&a_rgb[i]) || !lpv_vol_ok(&b_rgb[i])) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "LPV volumes must be RGBA16F");
+        if (a_rgb[i].width < 32 * num_cascades || a_rgb[i].height < 32 || a_rgb[i].depth < 32 || b_rgb[i].width < 32 * num_cascades ||
+            b_rgb[i].height < 32 || b_rgb[i].depth < 32)
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "LPV volumes must be at least (32*cascades)x32x32");
+        a[i] = varg(a_rgb[i]);
+        b[i] = varg(b_rgb[i]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (uint32_t s = 0; s < steps; s++) {  // light_propagation_volume.cpp:1016-1034
+        if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, ctx->stream));
+        else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, ctx->stream));
+    }
+    return SAH_OK;
+}
+
+// ---- RCCL (resolved at run time so that a process which already carries an RCCL — e.g. PyTorch's — shares it) ----
+typedef int (*pfn_ncclGetUniqueId)(void*);
+struct sah_nccl_id {  // ncclUniqueId is passed by value: 128 bytes
+    char internal[128];
+};
+typedef int (*pfn_ncclCommInitRank2)(void**, int, sah_nccl_id, int);
+typedef int (*pfn_ncclCommDestroy)(void*);
+typedef int (*pfn_ncclAllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*pfn_ncclGetErrorString)(int);
+
+static void* open_rccl() {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) return h;
+    }
+    return nullptr;
+}
+
+int sah_comm_unique_id(void* out) {
+    if (!out) return SAH_ERR_INVALID_ARGUMENT;
+    void* h = open_rccl();
+    if (!h) return SAH_ERR_COMM;
+    auto f = (pfn_ncclGetUniqueId)dlsym(h, "ncclGetUniqueId");
+    if (!f) return SAH_ERR_COMM;
+    return f(out) == 0 ? SAH_OK : SAH_ERR_COMM;
+}
+
+int sah_comm_init(sah_ctx* ctx, const void* comm_id) {
+    ctx->rccl = open_rccl();
+    if (!ctx->rccl) return fail(ctx, SAH_ERR_COMM, "librccl not found: %s", dlerror());
+    auto init = (pfn_ncclCommInitRank2)dlsym(ctx->rccl, "ncclCommInitRank");
+    if (!init) return fail(ctx, SAH_ERR_COMM, "ncclCommInitRank not found");
+    sah_nccl_id id;
+    memcpy(&id, comm_id, sizeof(id));
+    if (hipSetDevice(ctx->device) != hipSuccess) return SAH_ERR_HIP;
+    int rc = init(&ctx->comm, ctx->world, id, ctx->rank);
+    if (rc != 0) return fail(ctx, SAH_ERR_COMM, "ncclCommInitRank failed: %d", rc);
+    return SAH_OK;
+}
+
+void sah_comm_destroy(sah_ctx* ctx) {
+    if (ctx->comm && ctx->rccl) {
+        auto f = (pfn_ncclCommDestroy)dlsym(ctx->rccl, "ncclCommDestroy");
+        if (f) f(ctx->comm);
+    }
+    ctx->comm = nullptr;
+}
+
+int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank) {
+    if (!ctx || !image || !image->ptr) return SAH_ERR_INVALID_ARGUMENT;
+    if (ctx->world == 1) return SAH_OK;
+    if (!ctx->comm) return fail(ctx, SAH_ERR_COMM, "context was created without a communicator");
+    if ((uint64_t)rows_per_rank * ctx->world > image->height) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rows_per_rank * world > height");
+    auto ag = (pfn_ncclAllGather)dlsym(ctx->rccl, "ncclAllGather");
+    if (!ag) return fail(ctx, SAH_ERR_COMM, "ncclAllGather not found");
+    const size_t bytes = (size_t)rows_per_rank * image->row_pitch_bytes;
+    const uint8_t* send = (const uint8_t*)image->ptr + (size_t)ctx->rank * bytes;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // in place: the send buffer is this rank's slot of the receive buffer; ncclUint8 == 1 (ncclChar == 0)
+    int rc = ag(send, image->ptr, bytes, /*ncclUint8*/ 1, ctx->comm, ctx->stream);
+    if (rc != 0) return fail(ctx, SAH_ERR_COMM, "ncclAllGather failed: %d", rc);
+    return SAH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Context object behind the C ABI and small shared helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/sah_hip.h"
+#include "params.hpp"
+
+struct sah_ctx {
+    int device = 0;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* luts = nullptr;  // device: 256 sRGB->linear + 256 UNORM8->float
+    void* comm = nullptr;   // ncclComm_t
+    void* rccl = nullptr;   // dlopen handle
+    int force_ppt = 0;      // tuning/testing hook: 0 = auto
+    std::string last_error;
+};
+
+inline int fail(sah_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(ctx, SAH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline uint32_t format_bpp(uint32_t f) {
+    switch (f) {
+        case SAH_FORMAT_R8_UNORM: return 1;
+        case SAH_FORMAT_R16_SFLOAT: case SAH_FORMAT_D16_UNORM: return 2;
+        case SAH_FORMAT_R8G8B8A8_UNORM: case SAH_FORMAT_R8G8B8A8_SRGB: case SAH_FORMAT_R16G16_SFLOAT: case SAH_FORMAT_R32_SFLOAT:
+        case SAH_FORMAT_B10G11R11_UFLOAT_PACK32: case SAH_FORMAT_D32_SFLOAT: return 4;
+        case SAH_FORMAT_R16G16B16A16_SFLOAT: return 8;
+    }
+    return 0;
+}
+
+inline bool plane_ok(const sah_plane* p, uint32_t fmt_a, uint32_t fmt_b, uint32_t w, uint32_t h) {
+    if (!p || !p->ptr) return false;
+    if (p->format != fmt_a && p->format != fmt_b) return false;
+    if (p->width != w || p->height != h) return false;
+    return (uint64_t)p->row_pitch_bytes >= (uint64_t)w * format_bpp(p->format);
+}
+
+inline sah::PlaneArg parg(const sah_plane* p) { return sah::PlaneArg{p ? (const uint8_t*)p->ptr : nullptr, p ? p->row_pitch_bytes : 0}; }
+inline sah::VolumeArg varg(const sah_volume& v) {
+    return sah::VolumeArg{(const uint8_t*)v.ptr, v.width, v.height, v.depth, v.row_pitch_bytes, v.slice_pitch_bytes};
+}

@@ -1,0 +1,162 @@
+// LPV maintenance kernels for gfx950:
+//   clear      RenderCore/shaders/gi/lpv/clear_lpv.comp:22-29        (host light_propagation_volume.cpp:839-926)
+//   propagate  RenderCore/shaders/gi/lpv/lpv_propagate.comp.slang:76-156 (host :970-1063), fp16 arithmetic,
+//              use_gv hard-wired to false by the host (:975) => geo_volume_factor == 1.
+// One thread per cell; the three colour volumes are 1 MiB each and stay in the per-XCD L2 between steps.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sah_hip.h"
+#include "numerics.hpp"
+#include "params.hpp"
+
+namespace sah {
+
+struct H4 {
+    Hn x, y, z, w;
+};
+SAH_DEV H4 operator*(Hn s, H4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+SAH_DEV H4 operator*(H4 a, Hn s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+SAH_DEV H4 operator+(H4 a, H4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+SAH_DEV Hn dot4h(H4 a, H4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// spherical_harmonics.slangi:14-32: float literal * half -> float, rounded by the half4 constructor
+SAH_DEV H4 dir_to_sh_h(H3 d) {
+    return {Hn(0.282094792f), Hn(-0.488602512f * tof(d.y)), Hn(0.488602512f * tof(d.z)), Hn(-0.488602512f * tof(d.x))};
+}
+SAH_DEV H4 dir_to_cosine_lobe_h(H3 d) {
+    return {Hn(0.886226925f), Hn(-1.02332671f * tof(d.y)), Hn(1.02332671f * tof(d.z)), Hn(-1.02332671f * tof(d.x))};
+}
+
+__constant__ int8_t kOrient[6][9] = {
+    {1, 0, 0, 0, 1, 0, 0, 0, 1},  {-1, 0, 0, 0, 1, 0, 0, 0, -1}, {0, 0, 1, 0, 1, 0, -1, 0, 0},
+    {0, 0, -1, 0, 1, 0, 1, 0, 0}, {1, 0, 0, 0, 0, 1, 0, -1, 0},  {1, 0, 0, 0, 0, -1, 0, 1, 0},
+};
+__constant__ int8_t kDir[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+__constant__ int8_t kSide[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+
+SAH_DEV H3 mul33(const int8_t* M, H3 v) {
+    H3 r;
+    r.x = Hn((float)M[0]) * v.x + Hn((float)M[1]) * v.y + Hn((float)M[2]) * v.z;
+    r.y = Hn((float)M[3]) * v.x + Hn((float)M[4]) * v.y + Hn((float)M[5]) * v.z;
+    r.z = Hn((float)M[6]) * v.x + Hn((float)M[7]) * v.y + Hn((float)M[8]) * v.z;
+    return r;
+}
+
+struct Q4 {  // trivially constructible LDS image of an H4
+    _Float16 v[4];
+};
+SAH_DEV Q4 to_q(H4 a) { return Q4{{a.x.v, a.y.v, a.z.v, a.w.v}}; }
+SAH_DEV H4 from_q(const Q4& q) { return {Hn::raw(q.v[0]), Hn::raw(q.v[1]), Hn::raw(q.v[2]), Hn::raw(q.v[3])}; }
+struct PropTables {  // 30 direction pairs, built per block into LDS
+    Q4 eval_sh[6][4], reproj_lobe[6][4], cur_lobe[6], cur_sh[6];
+};
+
+SAH_DEV H4 load_h4(const VolumeArg& v, int x, int y, int z) {
+    if ((unsigned)x < v.width && (unsigned)y < v.height && (unsigned)z < v.depth) {
+        const uint2 q = *reinterpret_cast<const uint2*>(v.ptr + (size_t)z * v.slice_pitch + (size_t)y * v.row_pitch + (size_t)x * 8);
+        H4 r;
+        r.x = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.x & 0xffffu)));
+        r.y = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.x >> 16)));
+        r.z = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.y & 0xffffu)));
+        r.w = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.y >> 16)));
+        return r;
+    }
+    return {Hn(0.f), Hn(0.f), Hn(0.f), Hn(0.f)};
+}
+SAH_DEV void store_h4(const VolumeArg& v, int x, int y, int z, H4 c) {
+    uint2 q;
+    q.x = (uint32_t)__builtin_bit_cast(uint16_t, c.x.v) | ((uint32_t)__builtin_bit_cast(uint16_t, c.y.v) << 16);
+    q.y = (uint32_t)__builtin_bit_cast(uint16_t, c.z.v) | ((uint32_t)__builtin_bit_cast(uint16_t, c.w.v) << 16);
+    *reinterpret_cast<uint2*>(const_cast<uint8_t*>(v.ptr) + (size_t)z * v.slice_pitch + (size_t)y * v.row_pitch + (size_t)x * 8) = q;
+}
+
+struct PropArgs {
+    VolumeArg src[3], dst[3];
+    uint32_t num_cascades;
+};
+
+__global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
+    __shared__ PropTables T;
+    if (threadIdx.x < 24) {
+        const int n = threadIdx.x >> 2, s = threadIdx.x & 3;
+        const Hn small = Hn::lit(0.4472135f), big = Hn::lit(0.894427f);
+        const H3 e = mul33(kOrient[n], H3{Hn((float)kSide[s][0]) * small, Hn((float)kSide[s][1]) * small, big});
+        const H3 r = mul33(kOrient[n], H3{Hn((float)kSide[s][0]), Hn((float)kSide[s][1]), Hn(0.f)});
+        T.eval_sh[n][s] = to_q(dir_to_sh_h(e));
+        T.reproj_lobe[n][s] = to_q(dir_to_cosine_lobe_h(r));
+    } else if (threadIdx.x < 30) {
+        const int n = threadIdx.x - 24;
+        const H3 c = {Hn((float)kDir[n][0]), Hn((float)kDir[n][1]), Hn((float)kDir[n][2])};
+        T.cur_lobe[n] = to_q(dir_to_cosine_lobe_h(c));
+        T.cur_sh[n] = to_q(dir_to_sh_h(c));
+    }
+    __syncthreads();
+    const Hn direct_sa = Hn(tof(Hn::lit(0.4006696846f)) / 3.1415927f);
+    const Hn side_sa = Hn(tof(Hn::lit(0.4234413544f)) / 3.1415927f);
+
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.num_cascades * 32768u) return;
+    const int cx = idx & 31, cy = (idx >> 5) & 31, cz = (idx >> 10) & 31, cascade = idx >> 15;
+    const int xoff = cascade * 32;
+    H4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) acc[c] = {Hn(0.f), Hn(0.f), Hn(0.f), Hn(0.f)};
+    for (int n = 0; n < 6; n++) {
+        const int nx = cx - kDir[n][0], ny = cy - kDir[n][1], nz = cz - kDir[n][2];
+        if (nx < -1 || ny < -1 || nz < -1 || nx > 31 || ny > 31 || nz > 31) continue;
+        H4 coef[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) coef[c] = load_h4(a.src[c], nx + xoff, ny, nz);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const Hn m = nmax(Hn(0.f), dot4h(coef[c], from_q(T.eval_sh[n][s])));
+                acc[c] = acc[c] + (side_sa * m) * from_q(T.reproj_lobe[n][s]) * Hn(1.f);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const Hn m = nmax(Hn(0.f), dot4h(coef[c], from_q(T.cur_sh[n])));
+            acc[c] = acc[c] + (direct_sa * m) * from_q(T.cur_lobe[n]) * Hn(1.f);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) store_h4(a.dst[c], cx + xoff, cy, cz, acc[c]);
+}
+
+struct ClearArgs {
+    VolumeArg v[4];
+    int n;
+    uint32_t num_cascades;
+};
+
+__global__ void __launch_bounds__(256) k_lpv_clear(ClearArgs a) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.num_cascades * 32768u) return;
+    const uint32_t x = idx % (32u * a.num_cascades), y = (idx / (32u * a.num_cascades)) & 31u, z = idx / (32u * a.num_cascades * 32u);
+    for (int i = 0; i < a.n; i++) {
+        const VolumeArg& v = a.v[i];
+        if (x < v.width && y < v.height && z < v.depth)
+            *reinterpret_cast<uint2*>(const_cast<uint8_t*>(v.ptr) + (size_t)z * v.slice_pitch + (size_t)y * v.row_pitch + (size_t)x * 8) = make_uint2(0u, 0u);
+    }
+}
+
+hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st) {
+    ClearArgs a;
+    a.n = n;
+    a.num_cascades = num_cascades;
+    for (int i = 0; i < n; i++) a.v[i] = vols[i];
+    hipLaunchKernelGGL(k_lpv_clear, dim3(num_cascades * 128), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st) {
+    PropArgs a;
+    for (int i = 0; i < 3; i++) { a.src[i] = src[i]; a.dst[i] = dst[i]; }
+    a.num_cascades = num_cascades;
+    hipLaunchKernelGGL(k_lpv_propagate, dim3(num_cascades * 128), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace sah

@@ -1,0 +1,185 @@
+// Device-side arithmetic for the gfx950 kernels.
+//
+// Numerics contract (DESIGN.md "Numerics"): the library is compiled with -ffp-contract=off, so every fp32
+// operator below is one individually rounded IEEE operation (v_add/v_mul/v_sub, correctly rounded v_div
+// expansion and v_sqrt); fp16 ("Slang half") expressions round after every operator.  Nothing here may be
+// built with -ffast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sah {
+
+#define SAH_DEV __device__ __forceinline__
+
+// ---- fp16 storage <-> fp32 ----------------------------------------------------------------------
+SAH_DEV float h2f(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+SAH_DEV uint16_t f2h(float f) {  // v_cvt_f16_f32, RNE; the asm keeps LLVM from fusing the producer into v_fma_mixlo_f16
+    asm volatile("" : "+v"(f));
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// ---- number models ------------------------------------------------------------------------------
+// fp32: plain float.  fp16: value kept in a _Float16; + - * are native v_*_f16 (exact result, one rounding),
+// divide and sqrt go through fp32 (correctly rounded there; the second rounding to fp16 is innocuous because
+// 24 >= 2*11 + 2).
+struct Fn {
+    float v;
+    SAH_DEV Fn() : v(0.f) {}
+    SAH_DEV Fn(float x) : v(x) {}
+    static SAH_DEV Fn lit(float x) { return Fn(x); }
+};
+SAH_DEV Fn operator+(Fn a, Fn b) { return Fn(a.v + b.v); }
+SAH_DEV Fn operator-(Fn a, Fn b) { return Fn(a.v - b.v); }
+SAH_DEV Fn operator*(Fn a, Fn b) { return Fn(a.v * b.v); }
+SAH_DEV Fn operator/(Fn a, Fn b) { return Fn(a.v / b.v); }
+SAH_DEV Fn operator-(Fn a) { return Fn(-a.v); }
+SAH_DEV Fn nsqrt(Fn a) { return Fn(__builtin_sqrtf(a.v)); }
+SAH_DEV Fn npow5(Fn a) {
+    double d = (double)a.v;
+    return Fn((float)(d * d * d * d * d));
+}
+SAH_DEV float tof(Fn a) { return a.v; }
+
+// An fp32 value is hidden from the optimiser before it is rounded to fp16.  Without this LLVM (a) narrows
+// fptrunc(fdiv(fpext, fpext)) to a half fdiv whose v_rcp_f16 expansion is not correctly rounded, and (b) fuses
+// fptrunc(fmul/fadd) into v_fma_mixlo_f16, i.e. ONE rounding of the exact result, where the contract (and the
+// RGBA16F blend emulation) is "round to fp32, then to fp16".
+SAH_DEV float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+struct Hn {
+    _Float16 v;
+    SAH_DEV Hn() : v((_Float16)0.f) {}
+    SAH_DEV explicit Hn(float x) : v((_Float16)opaque(x)) {}
+    static SAH_DEV Hn lit(float x) { Hn r; r.v = (_Float16)x; return r; }
+    static SAH_DEV Hn raw(_Float16 h) { Hn r; r.v = h; return r; }
+};
+SAH_DEV Hn operator+(Hn a, Hn b) { return Hn::raw(a.v + b.v); }
+SAH_DEV Hn operator-(Hn a, Hn b) { return Hn::raw(a.v - b.v); }
+SAH_DEV Hn operator*(Hn a, Hn b) { return Hn::raw(a.v * b.v); }
+SAH_DEV Hn operator/(Hn a, Hn b) { return Hn((float)a.v / (float)b.v); }
+SAH_DEV Hn operator-(Hn a) { return Hn::raw(-a.v); }
+SAH_DEV Hn nsqrt(Hn a) { return Hn(__builtin_sqrtf((float)a.v)); }
+SAH_DEV Hn npow5(Hn a) {
+    double d = (double)(float)a.v;
+    return Hn((float)(d * d * d * d * d));
+}
+SAH_DEV float tof(Hn a) { return (float)a.v; }
+
+template <class T> SAH_DEV T nabs(T a) { T r = a; r.v = a.v < 0 ? -a.v : a.v; return r; }
+template <> SAH_DEV Fn nabs<Fn>(Fn a) { return Fn(__builtin_fabsf(a.v)); }
+template <> SAH_DEV Hn nabs<Hn>(Hn a) { return Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(__builtin_bit_cast(uint16_t, a.v) & 0x7fffu))); }
+// max/min with fmax/fmin NaN semantics (the non-NaN operand wins), as the oracle defines clamp().
+SAH_DEV Fn nmax(Fn a, Fn b) { return Fn(__builtin_fmaxf(a.v, b.v)); }
+SAH_DEV Fn nmin(Fn a, Fn b) { return Fn(__builtin_fminf(a.v, b.v)); }
+SAH_DEV Hn nmax(Hn a, Hn b) { return Hn(__builtin_fmaxf((float)a.v, (float)b.v)); }
+SAH_DEV Hn nmin(Hn a, Hn b) { return Hn(__builtin_fminf((float)a.v, (float)b.v)); }
+template <class T> SAH_DEV T nclamp(T x, T lo, T hi) { return nmin(nmax(x, lo), hi); }
+SAH_DEV bool isnan_f(float x) { return x != x; }
+
+// ---- small vectors ------------------------------------------------------------------------------
+template <class T> struct V3 {
+    T x, y, z;
+    SAH_DEV V3() {}
+    SAH_DEV V3(T a, T b, T c) : x(a), y(b), z(c) {}
+    SAH_DEV explicit V3(T a) : x(a), y(a), z(a) {}
+};
+template <class T> SAH_DEV V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> SAH_DEV V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> SAH_DEV V3<T> operator*(V3<T> a, V3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <class T> SAH_DEV V3<T> operator*(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T> SAH_DEV V3<T> operator*(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class T> SAH_DEV V3<T> operator/(V3<T> a, T s) { return {a.x / s, a.y / s, a.z / s}; }
+template <class T> SAH_DEV V3<T> operator-(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <class T> SAH_DEV T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> SAH_DEV T inversesqrt(T x) { return T::lit(1.0f) / nsqrt(x); }
+template <class T> SAH_DEV V3<T> normalize(V3<T> a) { return a * inversesqrt(dot(a, a)); }
+template <class T> SAH_DEV T length(V3<T> a) { return nsqrt(dot(a, a)); }
+template <class T> SAH_DEV V3<T> cross(V3<T> a, V3<T> b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+template <class T> SAH_DEV T mix(T x, T y, T a) { return x * (T::lit(1.0f) - a) + y * a; }
+template <class T> SAH_DEV V3<T> mix(V3<T> x, V3<T> y, T a) { return {mix(x.x, y.x, a), mix(x.y, y.y, a), mix(x.z, y.z, a)}; }
+template <class T> SAH_DEV bool any_nan(V3<T> a) { return isnan_f(tof(a.x)) || isnan_f(tof(a.y)) || isnan_f(tof(a.z)); }
+
+using F3 = V3<Fn>;
+using H3 = V3<Hn>;
+SAH_DEV H3 to_h(F3 a) { return {Hn(a.x.v), Hn(a.y.v), Hn(a.z.v)}; }
+SAH_DEV F3 to_f(H3 a) { return {Fn((float)a.x.v), Fn((float)a.y.v), Fn((float)a.z.v)}; }
+
+struct F4 {
+    Fn x, y, z, w;
+};
+// column-major mat4 * vec4, summed left to right (GLSL `M * v`, Slang `mul(M, v)`)
+SAH_DEV F4 mul44(const float* m, F4 v) {
+    F4 r;
+    r.x = Fn(m[0]) * v.x + Fn(m[4]) * v.y + Fn(m[8]) * v.z + Fn(m[12]) * v.w;
+    r.y = Fn(m[1]) * v.x + Fn(m[5]) * v.y + Fn(m[9]) * v.z + Fn(m[13]) * v.w;
+    r.z = Fn(m[2]) * v.x + Fn(m[6]) * v.y + Fn(m[10]) * v.z + Fn(m[14]) * v.w;
+    r.w = Fn(m[3]) * v.x + Fn(m[7]) * v.y + Fn(m[11]) * v.z + Fn(m[15]) * v.w;
+    return r;
+}
+
+// ---- BRDF: RenderCore/shaders/common/brdf.glsl:29-121 (T = Fn) / brdf.slangi:22-114 (T = Hn) -------
+template <class T> struct Surface {
+    V3<T> base_color;
+    V3<T> normal;
+    T metalness;
+    T roughness;
+};
+
+template <class T> SAH_DEV T brdf_pi() { return T::lit(3.1415927f); }
+
+template <class T> SAH_DEV T D_GGX(T NoH, T roughness) {
+    T k = roughness / (T::lit(1.0f) - NoH * NoH + roughness * roughness);
+    return k * k * (T::lit(1.0f) / brdf_pi<T>());
+}
+template <class T> SAH_DEV V3<T> F_Schlick(T u, V3<T> f0, T f90) {
+    T p = npow5(nclamp(T::lit(1.0f) - u, T::lit(0.0f), T::lit(1.0f)));
+    return {f0.x + (f90 - f0.x) * p, f0.y + (f90 - f0.y) * p, f0.z + (f90 - f0.z) * p};
+}
+template <class T> SAH_DEV T V_SmithGGXCorrelated(T NoV, T NoL, T a) {
+    T a2 = a * a;
+    T GGXL = NoV * nsqrt((-NoL * a2 + NoL) * NoL + a2);
+    T GGXV = NoL * nsqrt((-NoV * a2 + NoV) * NoV + a2);
+    return T::lit(0.5f) / (GGXV + GGXL);
+}
+template <class T> SAH_DEV V3<T> Fd_Burley(T NoV, T NoL, T LoH, T roughness) {
+    T f90 = T::lit(0.5f) + T::lit(2.0f) * roughness * LoH * LoH;
+    V3<T> one(T::lit(1.0f));
+    V3<T> lightScatter = F_Schlick(NoL, one, f90);
+    V3<T> viewScatter = F_Schlick(NoV, one, f90);
+    return lightScatter * viewScatter * (T::lit(1.0f) / brdf_pi<T>());
+}
+template <class T> SAH_DEV V3<T> Fd(const Surface<T>& s, V3<T> l, V3<T> v) {
+    const T dielectric_f0 = T::lit(0.04f);
+    const V3<T> diffuse_color = s.base_color * (T::lit(1.0f) - dielectric_f0) * (T::lit(1.0f) - s.metalness);
+    const V3<T> h = normalize(v + l);
+    T NoV = dot(s.normal, v) + T::lit(1e-5f);
+    T NoL = dot(s.normal, l);
+    if (tof(NoL) <= 0.f) return V3<T>(T::lit(0.0f));  // false for NaN: NaN flows on, as in the shader
+    NoV = nabs(NoV);
+    NoL = nclamp(NoL, T::lit(0.0f), T::lit(1.0f));
+    const T LoH = nclamp(dot(l, h), T::lit(0.0f), T::lit(1.0f));
+    return diffuse_color * Fd_Burley(NoV, NoL, LoH, s.roughness);
+}
+template <class T> SAH_DEV V3<T> Fr(const Surface<T>& s, V3<T> l, V3<T> v) {
+    const T dielectric_f0 = T::lit(0.04f);
+    const V3<T> f0 = mix(V3<T>(dielectric_f0), s.base_color, s.metalness);
+    const V3<T> h = normalize(v + l);
+    T NoV = dot(s.normal, v) + T::lit(1e-5f);
+    T NoL = dot(s.normal, l);
+    const T NoH = nclamp(dot(s.normal, h), T::lit(0.0f), T::lit(1.0f));
+    const T VoH = nclamp(dot(v, h), T::lit(0.0f), T::lit(1.0f));
+    if (tof(NoL) <= 0.f) return V3<T>(T::lit(0.0f));
+    NoV = nabs(NoV);
+    NoL = nclamp(NoL, T::lit(0.0f), T::lit(1.0f));
+    const T D = D_GGX(NoH, s.roughness);
+    const V3<T> Fv = F_Schlick(VoH, f0, T::lit(1.0f));
+    const T V = V_SmithGGXCorrelated(NoV, NoL, s.roughness);
+    return (D * V) * Fv;
+}
+
+}  // namespace sah

@@ -1,0 +1,83 @@
+// Kernel-argument blocks: the reference's UBOs / push constants, flattened and pre-digested on the host
+// (uniform sub-expressions are evaluated once on the CPU with the same individually rounded fp32 operators
+// the per-pixel code would use — IEEE makes that bit-identical).
+#pragma once
+#include <stdint.h>
+
+namespace sah {
+
+struct PlaneArg {
+    const uint8_t* ptr;
+    uint32_t pitch;
+};
+struct VolumeArg {
+    const uint8_t* ptr;
+    uint32_t width, height, depth;
+    uint32_t row_pitch, slice_pitch;
+};
+
+struct LpvArgs {
+    VolumeArg red, green, blue;
+    float world_to_cascade[4][16];
+    uint32_t num_cascades;
+    float num_cascades_f;
+    float exposure;
+};
+
+struct CacheArgs {
+    VolumeArg irradiance, depth, validity;
+    float cascade_min[4][3];
+    float cascade_max[4][3];  // min + (32,8,32) * spacing
+    float spacing[4];
+    uint32_t probe_size[2];
+    uint32_t debug_mode;
+};
+
+struct RtgiArgs {
+    PlaneArg ray_buffer, ray_irradiance, noise;
+    uint32_t noise_w, noise_h;
+    uint32_t num_extra_rays;
+    float extra_ray_radius;
+};
+
+struct CsmArgs {
+    VolumeArg shadowmap;
+    uint32_t is_d16;
+    float splits[4];
+    float biased[4][16];  // biasMat * cascade_matrices[i]
+};
+
+struct SkyArgs {
+    PlaneArg transmittance, sky_view;
+    uint32_t t_w, t_h, s_w, s_h;
+    float sun_dir[3];       // -normalize(direction)
+    float height;           // length(viewPos)
+    float up_y;             // viewPos.y / height
+    float view_pos_y;       // groundRadiusMM + 0.0002
+    float horizon_angle;    // safeacos(sqrt(h*h - g*g) / h)
+    float azimuth_limit;    // 0.5 * PI - .0001
+    float min_sun_cos;      // cos(0.53 * PI / 180)
+    float right[3];         // cross(sunDir, up)
+    float forward[3];       // cross(up, right)
+    float tlut_rgb[3];      // getValFromTLUT(viewPos, sunDir): uniform over the frame
+    float smooth_e0;        // 0.002h as float
+    uint32_t enabled;
+};
+
+struct LightingArgs {
+    PlaneArg color, normals, data, emission, depth, ao, shadow_mask, lit;
+    uint32_t width, height, row_begin, row_end;
+    uint32_t flags;
+    float res[2];
+    float inv_proj[16];
+    float inv_view[16];
+    float view_pos[3];   // -view[3].xyz
+    float sun_L[3];      // normalize(-direction)
+    float sun_color[3];
+    uint32_t has_ao, has_mask;
+    const float* luts;   // [0..255] sRGB8->linear, [256..511] UNORM8->float
+    const void* lights;  // sah_point_light[count]
+    uint32_t num_lights;
+};
+
+}  // namespace sah

@@ -1,0 +1,19 @@
+#pragma once
+#include <stdint.h>
+
+#include "params.hpp"
+
+namespace sah {
+
+struct TonemapArgs {
+    PlaneArg scene;
+    uint32_t scene_w, scene_h;
+    PlaneArg mips[8];
+    uint32_t mip_w[8], mip_h[8];
+    uint32_t num_mips;
+    PlaneArg out;
+    uint32_t out_w, out_h;
+    uint32_t row_begin, row_end;
+};
+
+}  // namespace sah

@@ -1,0 +1,129 @@
+"""ctypes binding of libsah_hip.so (the C ABI in include/sah_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises, and every
+entry point raises SahError on a non-zero status."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsah_hip.so")
+
+
+class SahError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"sah status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+# every symbol include/sah_hip.h declares
+EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_allgather_rows"]
+
+
+def load():
+    """Loads the library (building is a separate, explicit step: python -m androidrenderer_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found — build it with `python -m androidrenderer_amd.build` (needs hipcc); "
+                          "there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    lib.sah_abi_version.restype = C.c_int
+    lib.sah_status_string.restype = C.c_char_p
+    lib.sah_status_string.argtypes = [C.c_int]
+    lib.sah_last_error.restype = C.c_char_p
+    lib.sah_last_error.argtypes = [C.c_void_p]
+    lib.sah_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.sah_destroy.argtypes = [C.c_void_p]
+    lib.sah_destroy.restype = None
+    lib.sah_comm_unique_id.argtypes = [C.c_void_p]
+    lib.sah_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sah_sync.argtypes = [C.c_void_p]
+    lib.sah_lighting.argtypes = [C.c_void_p, C.POINTER(_abi.LightingDesc)]
+    lib.sah_copy_scene.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
+    lib.sah_bloom.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
+    lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
+    lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
+    lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
+    lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32]
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One sah_ctx: a device, a stream, optionally an RCCL communicator."""
+
+    def __init__(self, device=0, rank=0, world=1, comm_id=None, stream=None):
+        self.lib = load()
+        h = C.c_void_p()
+        idbuf = None
+        if comm_id is not None:
+            idbuf = C.create_string_buffer(bytes(comm_id), 128)
+        rc = self.lib.sah_create(C.byref(h), device, rank, world, idbuf)
+        if rc != _abi.SAH_OK:
+            raise SahError(rc, self.lib.sah_status_string(rc).decode())
+        self.handle = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def _check(self, rc):
+        if rc != _abi.SAH_OK:
+            msg = self.lib.sah_last_error(self.handle).decode() or self.lib.sah_status_string(rc).decode()
+            raise SahError(rc, msg)
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self.lib.sah_set_stream(self.handle, C.c_void_p(hip_stream_handle)))
+
+    def sync(self):
+        self._check(self.lib.sah_sync(self.handle))
+
+    def lighting(self, desc):
+        self._check(self.lib.sah_lighting(self.handle, C.byref(desc)))
+
+    def copy_scene(self, lit, out):
+        self._check(self.lib.sah_copy_scene(self.handle, C.byref(lit), C.byref(out)))
+
+    def bloom(self, scene, chain):
+        self._check(self.lib.sah_bloom(self.handle, C.byref(scene), C.byref(chain)))
+
+    def tonemap(self, scene, chain, out, row_begin=0, row_end=0):
+        self._check(self.lib.sah_tonemap(self.handle, C.byref(scene), C.byref(chain), C.byref(out), row_begin, row_end))
+
+    def lpv_clear(self, red, green, blue, geometry, num_cascades):
+        null = C.POINTER(_abi.Volume)()
+        args = [C.byref(v) if v is not None else null for v in (red, green, blue, geometry)]
+        self._check(self.lib.sah_lpv_clear(self.handle, *args, num_cascades))
+
+    def lpv_propagate(self, a_rgb, b_rgb, num_cascades, steps):
+        a = (_abi.Volume * 3)(*a_rgb)
+        b = (_abi.Volume * 3)(*b_rgb)
+        self._check(self.lib.sah_lpv_propagate(self.handle, a, b, num_cascades, steps))
+
+    def allgather_rows(self, image, rows_per_rank):
+        self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sah_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    lib = load()
+    buf = C.create_string_buffer(128)
+    rc = lib.sah_comm_unique_id(buf)
+    if rc != _abi.SAH_OK:
+        raise SahError(rc, lib.sah_status_string(rc).decode())
+    return buf.raw

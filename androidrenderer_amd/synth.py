@@ -1,0 +1,252 @@
+"""Synthetic inputs for the hot path. Everything is generated with numpy's counter-based Philox
+generator from a fixed seed, on the host, in the exact storage formats the reference allocates
+(RenderCore/render/scene_renderer.cpp:580-649).
+
+Two G-buffer flavours:
+  random_gbuffer   independent random texels (BASELINE config "synthetic random G-buffer")
+  atrium_gbuffer   a procedural Sponza-like atrium (floor, walls, two rows of box columns, open roof) ray-cast
+                   analytically; the Sponza asset itself is absent from the reference tree (.MISSING_LARGE_BLOBS), so
+                   the "Sponza" configs run on this stand-in.  Reports must say which flavour was used.
+"""
+import math
+
+import numpy as np
+
+from . import _abi
+
+SEED_BASE = 0x5A48
+
+
+def rng(seed):
+    return np.random.Generator(np.random.Philox(SEED_BASE + seed))
+
+
+def _srgb_encode_u8(lin):
+    lin = np.clip(lin, 0.0, 1.0)
+    s = np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(lin, 1.0 / 2.4) - 0.055)
+    return np.clip(np.rint(s * 255.0), 0, 255).astype(np.uint8)
+
+
+def random_gbuffer(width, height, seed=1, sky_fraction=0.10, z_near=0.05):
+    """10 % sky, depth = z_near/d with d log-uniform in [0.5,100] m, normals uniform on the sphere times
+    U[0.5,1.5] (fp16), uniform colour/data/emission bytes with data.r = data.a = 0, emission non-zero on 1 % of pixels."""
+    g = rng(seed)
+    n = width * height
+    d = np.exp(g.uniform(math.log(0.5), math.log(100.0), n)).astype(np.float32)
+    depth = (np.float32(z_near) / d).astype(np.float32)
+    depth[g.random(n) < sky_fraction] = 0.0
+    v = g.standard_normal((n, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v *= g.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
+    normals = np.zeros((n, 4), dtype=np.float16)
+    normals[:, :3] = v.astype(np.float16)
+    color = g.integers(0, 256, (n, 4), dtype=np.uint8)
+    data = g.integers(0, 256, (n, 4), dtype=np.uint8)
+    data[:, 0] = 0
+    data[:, 3] = 0
+    emission = g.integers(0, 256, (n, 4), dtype=np.uint8)
+    emission[g.random(n) >= 0.01] = 0
+    return {
+        "color": color.reshape(height, width, 4),
+        "normals": normals.reshape(height, width, 4),
+        "data": data.reshape(height, width, 4),
+        "emission": emission.reshape(height, width, 4),
+        "depth": depth.reshape(height, width),
+    }
+
+
+def _ray_box(o, d, bmin, bmax):
+    """Slab test; returns (t_hit or inf, face normal)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        t0 = (bmin - o) * inv
+        t1 = (bmax - o) * inv
+    tn = np.minimum(t0, t1)
+    tf = np.maximum(t0, t1)
+    tnear = tn.max(axis=-1)
+    tfar = tf.min(axis=-1)
+    hit = (tnear <= tfar) & (tnear > 1e-3)
+    axis = tn.argmax(axis=-1)
+    nrm = np.zeros(d.shape, dtype=np.float32)
+    sign = -np.sign(np.take_along_axis(d, axis[..., None], axis=-1))[..., 0]
+    np.put_along_axis(nrm, axis[..., None], sign[..., None], axis=-1)
+    return np.where(hit, tnear, np.inf), nrm
+
+
+def atrium_gbuffer(width, height, view, seed=2):
+    """Procedural atrium seen from `view` (a scene.SceneView): floor y=0, long walls z=+-4.5, end walls x=+-14,
+    open roof above y=11 (sky), two rows of 0.7 m box columns at z=+-2.6 every 3.5 m, a gallery slab at y=5.
+    Materials vary per surface with low-amplitude per-pixel noise; ~1 % of pixels (lamp boxes) are emissive."""
+    g = rng(seed)
+    H, W = height, width
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    ndc_x = (xs + 0.5) / np.float32(W) * 2.0 - 1.0
+    ndc_y = (ys + 0.5) / np.float32(H) * 2.0 - 1.0
+    proj = np.array(view.gpu_data.projection[:], dtype=np.float32).reshape(4, 4)  # [col,row]
+    inv_view = np.array(view.gpu_data.inverse_view[:], dtype=np.float32).reshape(4, 4)
+    dv = np.stack([ndc_x / proj[0, 0], ndc_y / proj[1, 1], -np.ones_like(ndc_x)], axis=-1)  # view space, z_view = -t
+    rot = inv_view[:3, :3]  # columns of the rotation
+    d = (dv[..., 0:1] * rot[0] + dv[..., 1:2] * rot[1] + dv[..., 2:3] * rot[2]).astype(np.float32)
+    o = inv_view[3, :3].astype(np.float32)
+    o = np.broadcast_to(o, d.shape)
+
+    boxes = []  # (min, max, material id)
+    boxes.append(((-14.5, -1.0, -5.0), (14.5, 0.0, 5.0), 0))     # floor
+    boxes.append(((-14.5, 0.0, 4.5), (14.5, 11.0, 5.5), 1))      # wall +z
+    boxes.append(((-14.5, 0.0, -5.5), (14.5, 11.0, -4.5), 1))    # wall -z
+    boxes.append(((14.0, 0.0, -5.0), (15.0, 11.0, 5.0), 2))      # end wall +x
+    boxes.append(((-15.0, 0.0, -5.0), (-14.0, 11.0, 5.0), 2))    # end wall -x
+    boxes.append(((-14.0, 5.0, 2.95), (14.0, 5.3, 4.5), 3))      # gallery slabs
+    boxes.append(((-14.0, 5.0, -4.5), (14.0, 5.3, -2.95), 3))
+    for i in range(8):
+        cx = -12.25 + 3.5 * i
+        for cz in (-2.6, 2.6):
+            boxes.append(((cx - 0.35, 0.0, cz - 0.35), (cx + 0.35, 5.0, cz + 0.35), 4))   # columns
+        boxes.append(((cx - 0.15, 3.2, -4.5), (cx + 0.15, 3.5, -4.3), 5))                 # lamps (emissive)
+    t_best = np.full((H, W), np.inf, dtype=np.float32)
+    n_best = np.zeros((H, W, 3), dtype=np.float32)
+    m_best = np.full((H, W), -1, dtype=np.int32)
+    for bmin, bmax, mat in boxes:
+        t, nrm = _ray_box(o, d, np.array(bmin, dtype=np.float32), np.array(bmax, dtype=np.float32))
+        closer = t < t_best
+        t_best = np.where(closer, t, t_best)
+        n_best = np.where(closer[..., None], nrm, n_best)
+        m_best = np.where(closer, mat, m_best)
+    hit = np.isfinite(t_best)
+    depth = np.where(hit, np.float32(view.near_value) / np.where(hit, t_best, 1.0), 0.0).astype(np.float32)
+
+    pos = o + d * np.where(hit, t_best, 0.0)[..., None]
+    base_lin = np.array([[0.45, 0.40, 0.33], [0.60, 0.52, 0.42], [0.50, 0.30, 0.22], [0.55, 0.55, 0.50], [0.62, 0.58, 0.50],
+                         [0.9, 0.8, 0.6]], dtype=np.float32)
+    rough = np.array([0.65, 0.8, 0.7, 0.5, 0.4, 0.3], dtype=np.float32)
+    metal = np.array([0.0, 0.0, 0.0, 0.1, 0.0, 0.9], dtype=np.float32)
+    mi = np.clip(m_best, 0, 5)
+    checker = ((np.floor(pos[..., 0] * 2.0) + np.floor(pos[..., 1] * 2.0) + np.floor(pos[..., 2] * 2.0)) % 2).astype(np.float32)
+    col = base_lin[mi] * (0.8 + 0.2 * checker)[..., None] + g.uniform(-0.02, 0.02, (H, W, 3)).astype(np.float32)
+    color = np.zeros((H, W, 4), dtype=np.uint8)
+    color[..., :3] = _srgb_encode_u8(col)
+    color[..., 3] = 255
+    data = np.zeros((H, W, 4), dtype=np.uint8)
+    data[..., 1] = np.clip(np.rint((rough[mi] + g.uniform(-0.03, 0.03, (H, W))) * 255.0), 1, 255).astype(np.uint8)
+    data[..., 2] = np.clip(np.rint(metal[mi] * 255.0), 0, 255).astype(np.uint8)
+    nrm = n_best + g.uniform(-0.04, 0.04, (H, W, 3)).astype(np.float32)
+    normals = np.zeros((H, W, 4), dtype=np.float16)
+    normals[..., :3] = nrm.astype(np.float16)
+    emission = np.zeros((H, W, 4), dtype=np.uint8)
+    lamp = (m_best == 5)
+    emission[lamp, 0], emission[lamp, 1], emission[lamp, 2] = 255, 214, 170
+    for a in (color, data, normals, emission):
+        a[~hit] = 0
+    return {"color": color, "normals": normals, "data": data, "emission": emission, "depth": depth}
+
+
+def ao_plane(width, height, seed=3):
+    return rng(seed).random((height, width), dtype=np.float32)
+
+
+def shadow_mask(width, height, seed=4, samples=8):
+    """RT-mode sun visibility: k/samples, as `shadow / num_shadow_samples` produces
+    (RenderCore/shaders/lighting/directional_light.rt.slang:93-125)."""
+    k = rng(seed).integers(0, samples + 1, (height, width))
+    return (k.astype(np.float32) / np.float32(samples)).astype(np.float32)
+
+
+def lpv_volumes(num_cascades=4, seed=5, zero_fraction=0.7):
+    """Three RGBA16F volumes (32*n) x 32 x 32, fp16 U[0,2] with ~70 % zero cells."""
+    g = rng(seed)
+    vols = []
+    for _ in range(3):
+        v = g.uniform(0.0, 2.0, (32, 32, 32 * num_cascades, 4)).astype(np.float16)
+        v[g.random((32, 32, 32 * num_cascades)) < zero_fraction] = 0
+        # signed directional bands so the SH dot can cancel, as real propagated light does
+        v[..., 1:] *= np.where(g.random((32, 32, 32 * num_cascades, 3)) < 0.5, -0.5, 0.5).astype(np.float16)
+        vols.append(v)
+    return vols  # indexed [z][y][x][c]
+
+
+def shadowmap(resolution=1024, cascades=4, seed=6):
+    """D16_UNORM array, values in [0.3, 0.7] (reduced from 4096^2 to keep fixtures bounded)."""
+    g = rng(seed)
+    return g.integers(int(0.3 * 65535), int(0.7 * 65535), (cascades, resolution, resolution), dtype=np.uint16)
+
+
+def sky_luts(seed=7):
+    """Stand-in LUT contents (the LUT generators are a 'next' row): smooth positive RGBA16F fields."""
+    g = rng(seed)
+
+    def smooth(h, w, scale):
+        y, x = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32), np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
+        out = np.zeros((h, w, 4), dtype=np.float32)
+        for c in range(3):
+            a, b, p = g.uniform(0.5, 3.0), g.uniform(0.5, 3.0), g.uniform(0, 6.28)
+            out[..., c] = scale * (0.55 + 0.45 * np.sin(a * 6.28 * x + p) * np.cos(b * 3.14 * y))
+        out[..., 3] = 1.0
+        return out.astype(np.float16)
+
+    return {"transmittance": smooth(64, 256, 1.0), "sky_view": smooth(200, 200, 0.3)}
+
+
+def point_lights(view, count, radius, seed=8):
+    """SURVEY §8-d lights: positions uniform in the view-frustum slab d in [1,60] m, colour U[0,1]^3, intensity
+    log-uniform [1e3,1e5]. Returns a (count, 8) float32 array laid out as sah_point_light."""
+    g = rng(seed)
+    proj = np.array(view.gpu_data.projection[:], dtype=np.float32).reshape(4, 4)
+    inv_view = np.array(view.gpu_data.inverse_view[:], dtype=np.float32).reshape(4, 4)
+    d = g.uniform(1.0, 60.0, count).astype(np.float32)
+    nx = g.uniform(-1.0, 1.0, count).astype(np.float32)
+    ny = g.uniform(-1.0, 1.0, count).astype(np.float32)
+    pv = np.stack([nx / proj[0, 0] * d, ny / proj[1, 1] * d, -d, np.ones_like(d)], axis=-1)
+    pw = np.einsum("ki,nk->ni", inv_view, pv)[:, :3]
+    out = np.zeros((count, 8), dtype=np.float32)
+    out[:, 0:3] = pw
+    out[:, 3] = radius
+    out[:, 4:7] = g.random((count, 3), dtype=np.float32)
+    out[:, 7] = np.exp(g.uniform(math.log(1e3), math.log(1e5), count)).astype(np.float32)
+    return out
+
+
+def pack_r11g11b10(rgb):
+    """fp32 (...,3) >= 0 -> B10G11R11_UFLOAT_PACK32 words, truncating (round toward zero)."""
+    h = np.clip(rgb, 0.0, 65024.0).astype(np.float16)  # exact path through fp16 bit patterns
+    hb = h.view(np.uint16).astype(np.uint32)
+    r = (hb[..., 0] >> 4) & 0x7FF
+    gch = (hb[..., 1] >> 4) & 0x7FF
+    b = (hb[..., 2] >> 5) & 0x3FF
+    return (r | (gch << 11) | (b << 22)).astype(np.uint32)
+
+
+def probe_atlases(seed=9):
+    """Irradiance cache atlases (RenderCore/render/gi/irradiance_cache.cpp:94-183): irradiance U[0,4] packed R11G11B10
+    224x256x32, depth moments RG16F 384x384x32 with y >= x^2, validity R8 32x32x32 with 90 % ones."""
+    g = rng(seed)
+    irr = pack_r11g11b10(g.uniform(0.0, 4.0, (32, 256, 224, 3)).astype(np.float32))
+    dx = g.uniform(0.2, 6.0, (32, 384, 384)).astype(np.float32)
+    dy = dx * dx + g.uniform(0.0, 1.0, (32, 384, 384)).astype(np.float32)
+    depth = np.stack([dx, dy], axis=-1).astype(np.float16)
+    validity = np.where(g.random((32, 32, 32)) < 0.9, 255, 0).astype(np.uint8)
+    return {"irradiance": irr, "depth": depth, "validity": validity}
+
+
+def rtgi_planes(width, height, seed=10):
+    g = rng(seed)
+    v = g.standard_normal((height, width, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    ray = np.zeros((height, width, 4), dtype=np.float16)
+    ray[..., :3] = v.astype(np.float16)
+    ray[..., 3] = g.uniform(0.1, 30.0, (height, width)).astype(np.float16)
+    irr = np.zeros((height, width, 4), dtype=np.float16)
+    irr[..., :3] = g.uniform(0.0, 8.0, (height, width, 3)).astype(np.float16)
+    noise = g.integers(0, 256, (128, 128, 4), dtype=np.uint8)
+    return {"ray_buffer": ray, "ray_irradiance": irr, "noise": noise}
+
+
+def hdr_scene(width, height, seed=11):
+    """An RGBA16F lit-scene stand-in for the post-chain tests: mostly < 4 with sparse bright highlights."""
+    g = rng(seed)
+    c = g.gamma(1.2, 0.5, (height, width, 3)).astype(np.float32)
+    hot = g.random((height, width)) < 0.002
+    c[hot] *= 200.0
+    out = np.zeros((height, width, 4), dtype=np.float16)
+    out[..., :3] = np.minimum(c, 60000.0).astype(np.float16)
+    out[..., 3] = 1.0
+    return out

@@ -1,0 +1,113 @@
+"""GPU parity for the post chain (copy scene, bloom pyramid, tonemap) and LPV propagate/clear vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _mips_np(w, h, n=6):
+    return [np.zeros((mh, mw, 4), dtype=np.uint16) for (mw, mh) in images.bloom_mip_sizes(w, h, n)]
+
+
+def _run_post_oracle(scene, w, h):
+    o = util.oracle()
+    mips = _mips_np(w, h)
+    chain = images.mipchain(mips)
+    sp = images.plane(scene, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_bloom(C.byref(sp), C.byref(chain)) == 0
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    assert o.orc_tonemap(C.byref(sp), C.byref(chain), C.byref(op), 0, 0) == 0
+    return mips, out
+
+
+def _run_post_hip(ctx, scene, w, h, rows=None):
+    import torch
+    sc = util.to_torch(scene.view(np.uint16))
+    mips = [torch.zeros(m.shape, dtype=torch.int16, device="cuda") for m in _mips_np(w, h)]
+    chain = images.mipchain(mips)
+    sp = images.plane(sc, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    ctx.bloom(sp, chain)
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    if rows is None:
+        ctx.tonemap(sp, chain, op)
+    else:
+        for r0, r1 in rows:
+            ctx.tonemap(sp, chain, op, r0, r1)
+    torch.cuda.synchronize()
+    return [util.from_torch(m, np.uint16) for m in mips], out.cpu().numpy()
+
+
+@pytest.mark.parametrize("size", [(256, 144), (250, 130)])
+def test_bloom_and_tonemap(hip_ctx, size):
+    w, h = size
+    scene = synth.hdr_scene(w, h, seed=21)
+    ref_mips, ref_out = _run_post_oracle(scene.view(np.uint16), w, h)
+    got_mips, got_out = _run_post_hip(hip_ctx, scene, w, h)
+    for i, (a, b) in enumerate(zip(got_mips, ref_mips)):
+        d = util.f16_ulp_diff(a, b)
+        print(util.report_ulp(f"bloom mip {i} {a.shape}", d))
+        assert d.max() <= 1
+    dc = np.abs(got_out.astype(np.int32) - ref_out.astype(np.int32))
+    print(f"tonemap: max code diff {dc.max()}, {int((dc > 0).sum())}/{dc.size} differ")
+    assert dc.max() <= 1  # UNORM8 codes within +-1 (1 ULP of the stored format)
+
+
+def test_tonemap_row_shards(hip_ctx):
+    w, h = 192, 108
+    scene = synth.hdr_scene(w, h, seed=22)
+    _, full = _run_post_hip(hip_ctx, scene, w, h)
+    _, parts = _run_post_hip(hip_ctx, scene, w, h, rows=[(0, 27), (27, 54), (54, 81), (81, 108)])
+    assert np.array_equal(full, parts)
+
+
+def test_copy_scene(hip_ctx):
+    import torch
+    o = util.oracle()
+    w, h = 160, 90
+    scene = synth.hdr_scene(w, h, seed=23).view(np.uint16)
+    for (ow, oh) in ((160, 90), (320, 180), (200, 100)):
+        ref = np.zeros((oh, ow, 4), dtype=np.uint16)
+        sp, rp = images.plane(scene, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(ref, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        assert o.orc_copy_scene(C.byref(sp), C.byref(rp)) == 0
+        sc = util.to_torch(scene)
+        out = torch.zeros((oh, ow, 4), dtype=torch.int16, device="cuda")
+        hip_ctx.copy_scene(images.plane(sc, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(out, _abi.FORMAT_R16G16B16A16_SFLOAT))
+        torch.cuda.synchronize()
+        got = util.from_torch(out, np.uint16)
+        d = util.f16_ulp_diff(got, ref)
+        print(util.report_ulp(f"copy {ow}x{oh}", d))
+        assert d.max() <= 1
+        if (ow, oh) == (w, h):
+            assert np.array_equal(got, scene)  # same resolution: identity copy
+
+
+def test_lpv_propagate_and_clear(hip_ctx):
+    import torch
+    o = util.oracle()
+    vols = synth.lpv_volumes(4, seed=31)
+    a_np = [v.view(np.uint16).copy() for v in vols]
+    b_np = [np.full_like(v, 0x3C00) for v in a_np]  # garbage in B: every cell is overwritten
+    a_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in a_np])
+    b_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in b_np])
+    steps = 4
+    assert o.orc_lpv_propagate(a_v, b_v, 4, steps) == 0
+    a_t = [util.to_torch(v.view(np.uint16).copy()) for v in vols]
+    b_t = [torch.full_like(t, 0x3C00) for t in a_t]
+    hip_ctx.lpv_propagate([images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in a_t],
+                          [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in b_t], 4, steps)
+    torch.cuda.synchronize()
+    for name, ts, ns in (("A", a_t, a_np), ("B", b_t, b_np)):
+        for c in range(3):
+            got = util.from_torch(ts[c], np.uint16)
+            assert np.array_equal(got, ns[c]), f"LPV {name}[{c}] differs: {util.report_ulp('lpv', util.f16_ulp_diff(got, ns[c]))}"
+    # clear
+    hip_ctx.lpv_clear(*[images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in a_t], images.volume(b_t[0], _abi.FORMAT_R16G16B16A16_SFLOAT), 4)
+    torch.cuda.synchronize()
+    assert all(int(t.abs().max()) == 0 for t in a_t) and int(b_t[0].abs().max()) == 0
