@@ -15,7 +15,7 @@
 
 namespace sah {
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
-                           const SkyArgs& sky, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
+                           const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
 struct TonemapArgs;
@@ -44,6 +44,62 @@ void cross3(const float a[3], const float b[3], float o[3]) {
     o[2] = a[0] * b[1] - b[0] * a[1];
 }
 float round_to_half(float f) { return (float)(_Float16)f; }
+
+bool is_zero(float x) { return x == 0.0f; }
+bool all_finite(const float* m, int n) {
+    for (int i = 0; i < n; i++)
+        if (!std::isfinite(m[i])) return false;
+    return true;
+}
+
+// Decides whether the uniform blocks have the structure the fast kernel assumes (DESIGN.md "Fast path proofs").
+// Column-major m[col*4 + row].
+bool detect_fast_path(const sah_lighting_desc* d, uint32_t sun_mode, uint32_t gi_kind, const sah::CsmArgs& csm, sah::FastArgs* f) {
+    const float* P = d->view->inverse_projection;
+    const float* V = d->view->inverse_view;
+    if (!all_finite(P, 16) || !all_finite(V, 16)) return false;
+    if (!std::isfinite(d->view->render_resolution[0]) || !std::isfinite(d->view->render_resolution[1])) return false;
+    // inverse_projection: row 0 depends on X only, row 1 on Y only, rows 2-3 on depth only
+    if (!(is_zero(P[4]) && is_zero(P[8]) && is_zero(P[1]) && is_zero(P[9]) && is_zero(P[2]) && is_zero(P[6]) && is_zero(P[3]) && is_zero(P[7])))
+        return false;
+    // inverse_view: affine
+    if (!(is_zero(V[3]) && is_zero(V[7]) && is_zero(V[11]) && V[15] == 1.0f)) return false;
+    f->p0 = P[0]; f->p12 = P[12]; f->p5 = P[5]; f->p13 = P[13];
+    f->p10 = P[10]; f->p14 = P[14]; f->p11 = P[11]; f->p15 = P[15];
+    if (sun_mode == SAH_SHADOW_MODE_CSM) {
+        if (!csm.shadowmap.ptr || (uint64_t)csm.shadowmap.slice_pitch * csm.shadowmap.depth >= (1ull << 32)) return false;
+        if (!csm.is_d16 || !csm.d16_recip_ok) return false;
+        for (int c = 0; c < 4; c++) {
+            const float* b = csm.biased[c];
+            if (!all_finite(b, 16)) return false;
+            if (!(is_zero(b[3]) && is_zero(b[7]) && is_zero(b[11]) && b[15] == 1.0f)) return false;
+        }
+    }
+    if (gi_kind == SAH_GI_LPV) {
+        const sah_gi& gi = *d->gi;
+        if (gi.lpv_red.width != gi.lpv_green.width || gi.lpv_red.width != gi.lpv_blue.width || gi.lpv_red.height != gi.lpv_green.height ||
+            gi.lpv_red.height != gi.lpv_blue.height || gi.lpv_red.depth != gi.lpv_green.depth || gi.lpv_red.depth != gi.lpv_blue.depth ||
+            gi.lpv_red.row_pitch_bytes != gi.lpv_green.row_pitch_bytes || gi.lpv_red.row_pitch_bytes != gi.lpv_blue.row_pitch_bytes ||
+            gi.lpv_red.slice_pitch_bytes != gi.lpv_green.slice_pitch_bytes || gi.lpv_red.slice_pitch_bytes != gi.lpv_blue.slice_pitch_bytes ||
+            (uint64_t)gi.lpv_red.slice_pitch_bytes * gi.lpv_red.depth >= (1ull << 32))
+            return false;
+        for (uint32_t c = 0; c < gi.lpv_num_cascades; c++) {
+            const float* m = gi.lpv_cascades[c].world_to_cascade;
+            if (!all_finite(m, 16)) return false;
+            if (!(is_zero(m[1]) && is_zero(m[2]) && is_zero(m[3]) && is_zero(m[4]) && is_zero(m[6]) && is_zero(m[7]) && is_zero(m[8]) &&
+                  is_zero(m[9]) && is_zero(m[11]) && m[15] == 1.0f))
+                return false;
+            if (is_zero(m[0]) || is_zero(m[5]) || is_zero(m[10])) return false;
+            f->lpv_s[c][0] = m[0]; f->lpv_s[c][1] = m[5]; f->lpv_s[c][2] = m[10];
+            f->lpv_t[c][0] = m[12]; f->lpv_t[c][1] = m[13]; f->lpv_t[c][2] = m[14];
+        }
+        const uint32_t n = gi.lpv_num_cascades;
+        f->ncasc_pow2 = (n & (n - 1)) == 0;
+        f->inv_ncasc = 1.0f / (float)n;
+        if (!std::isfinite(gi.lpv_exposure)) return false;
+    }
+    return true;
+}
 
 }  // namespace
 
@@ -98,8 +154,15 @@ int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_
         int rc = sah_comm_init(ctx, comm_id);
         if (rc != SAH_OK) { sah_destroy(ctx); return rc; }
     }
+    if (hipMalloc((void**)&ctx->state, sizeof(sah::FrameState)) != hipSuccess ||
+        hipMemset(ctx->state, 0, sizeof(sah::FrameState)) != hipSuccess) {
+        sah_destroy(ctx);
+        return SAH_ERR_HIP;
+    }
     const char* ppt = getenv("SAH_FORCE_PPT");
     if (ppt) ctx->force_ppt = atoi(ppt);
+    const char* gen = getenv("SAH_FORCE_GENERAL");
+    if (gen) ctx->force_general = atoi(gen) != 0;
     *out = ctx;
     return SAH_OK;
 }
@@ -109,6 +172,8 @@ void sah_destroy(sah_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     sah_comm_destroy(ctx);
     if (ctx->luts) (void)hipFree(ctx->luts);
+    if (ctx->state) (void)hipFree(ctx->state);
+    if (ctx->list) (void)hipFree(ctx->list);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -125,6 +190,14 @@ int sah_set_stream(sah_ctx* ctx, void* hip_stream) {
 }
 
 void* sah_get_stream(sah_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// Testing / tuning hooks (not part of the reference-facing ABI): force the general kernel, force pixels-per-thread.
+int sah_debug_set(sah_ctx* ctx, int force_general, int force_ppt) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    ctx->force_general = force_general != 0;
+    ctx->force_ppt = force_ppt;
+    return SAH_OK;
+}
 
 int sah_sync(sah_ctx* ctx) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
@@ -207,6 +280,18 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             if (d->shadowmap->depth < 4) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadowmap needs 4 layers");
             csm.shadowmap = varg(*d->shadowmap);
             csm.is_d16 = d->shadowmap->format == SAH_FORMAT_D16_UNORM;
+            csm.d16_recip = 1.0f / 65535.0f;
+            static const bool recip_ok = [] {  // exhaustive check of the reciprocal sequence used by shadow_pcf()
+                const float y = 1.0f / 65535.0f;
+                for (uint32_t i = 0; i < 65536; i++) {
+                    const float v = (float)i;
+                    const float q = v * y;
+                    const float q2 = std::fmaf(std::fmaf(-q, 65535.0f, v), y, q);
+                    if (q2 != v / 65535.0f) return false;
+                }
+                return true;
+            }();
+            csm.d16_recip_ok = recip_ok;
         }
         for (int c = 0; c < 4; c++) {
             csm.splits[c] = d->sun->data[c][0];
@@ -329,8 +414,29 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         a.num_lights = d->lights->count;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, (int)sun_mode, (int)gi_kind, ppt,
+    FastArgs fast;
+    memset(&fast, 0, sizeof(fast));
+    const bool fast_kind = (gi_kind == SAH_GI_NONE || gi_kind == SAH_GI_LPV) && a.num_lights == 0;
+    const bool use_fast = fast_kind && !ctx->force_general && detect_fast_path(d, sun_mode, gi_kind, csm, &fast);
+    if (use_fast) {
+        const size_t need = (size_t)W * H * sizeof(uint32_t);
+        if (ctx->list_bytes < need) {  // grow-only workspace for the deferred-pixel list
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->list) (void)hipFree(ctx->list);
+            ctx->list = nullptr;
+            ctx->list_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->list, need));
+            ctx->list_bytes = need;
+        }
+        fast.sky_enabled = sky.enabled;
+        fast.parity = ctx->parity;
+        fast.state = ctx->state;
+        fast.list = ctx->list;
+        fast.fixup_blocks = 1024;
+    }
+    HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, use_fast ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,
                                  (d->flags & SAH_LIGHTING_BRUTE_FORCE_LIGHTS) != 0, ctx->stream));
+    if (use_fast) ctx->parity ^= 1u;
     return SAH_OK;
 }
 

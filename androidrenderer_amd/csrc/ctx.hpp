@@ -18,6 +18,11 @@ struct sah_ctx {
     void* comm = nullptr;   // ncclComm_t
     void* rccl = nullptr;   // dlopen handle
     int force_ppt = 0;      // tuning/testing hook: 0 = auto
+    bool force_general = false;  // testing hook: always run the general kernel
+    sah::FrameState* state = nullptr;  // device
+    uint32_t* list = nullptr;          // device: deferred-pixel list
+    size_t list_bytes = 0;
+    uint32_t parity = 0;
     std::string last_error;
 };
 

@@ -1,479 +1,30 @@
-// Fused "Lighting" pass for gfx950 (MI355X): one kernel replaces the reference's clear + sun + GI overlay +
-// emissive + sky draws and the RT-mode sun dispatch (RenderCore/render/phase/lighting_phase.cpp:99-134), reading
-// each G-buffer plane once and writing lit_scene once, while reproducing the intermediate RGBA16F blend roundings
-// (DESIGN.md "a0").
+// Fused "Lighting" pass for gfx950 (MI355X): one pass over the G-buffer replaces the reference's clear + sun + GI overlay
+// + emissive + sky draws and the RT-mode sun dispatch (RenderCore/render/phase/lighting_phase.cpp:99-134), reading each
+// plane once and writing lit_scene once, while reproducing the intermediate RGBA16F blend roundings (DESIGN.md "a0").
 //
-// Mapping: one thread shades PPT horizontally adjacent pixels so that every plane is read with PPT*4-byte
-// (PPT=4: 16 B/lane, 1 KiB per wave instruction) coalesced loads and lit_scene is written with 16 B/lane stores.
-// HBM-bound for the deferred-only path; the GI gathers are served from the per-XCD L2 (LPV: 3 MiB).
+// Three kernels:
+//   k_lighting_fast     the hot kernel.  One thread shades PPT horizontally adjacent pixels (PPT=4: 16 B/lane plane loads,
+//                       16 B/lane lit stores).  It exploits what the host verified about the uniform blocks (projection
+//                       inverse separable in x/y/depth, affine view inverse, scale+translate LPV cascades, affine shadow
+//                       matrices) and skips sub-expressions that are provably inert for the pixel at hand (DESIGN.md "Fast
+//                       path proofs").  Pixels it cannot prove anything about (sky, non-finite inputs, roughness 0 under
+//                       LPV GI, ...) are appended to a per-frame list with one wave-aggregated atomic.
+//   k_lighting_fixup    shades the listed pixels with the general restatement (lighting_common.hpp).
+//   k_lighting_general  the general restatement over the whole image: used when the uniform blocks do not have the
+//                       structure the fast kernel needs, and as the in-library cross-check of the fast path.
 #include <hip/hip_runtime.h>
 
 #include "../../include/sah_hip.h"
+#include "lighting_common.hpp"
+#include "lighting_fast.hpp"
 #include "numerics.hpp"
 #include "params.hpp"
 
 namespace sah {
 
-// ---- helpers ------------------------------------------------------------------------------------
-template <int NW> SAH_DEV void load_words(const uint8_t* p, uint32_t (&w)[NW]) {
-    if constexpr (NW == 1) {
-        w[0] = *reinterpret_cast<const uint32_t*>(p);
-    } else if constexpr (NW == 2) {
-        uint2 v = *reinterpret_cast<const uint2*>(p);
-        w[0] = v.x; w[1] = v.y;
-    } else if constexpr (NW == 4) {
-        uint4 v = *reinterpret_cast<const uint4*>(p);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-        static_assert(NW == 8, "unsupported width");
-        uint4 v0 = *reinterpret_cast<const uint4*>(p);
-        uint4 v1 = *reinterpret_cast<const uint4*>(p + 16);
-        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
-        w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
-    }
-}
-template <int NW> SAH_DEV void store_words(uint8_t* p, const uint32_t (&w)[NW]) {
-    if constexpr (NW == 2) {
-        *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
-    } else if constexpr (NW == 4) {
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        static_assert(NW == 8, "unsupported width");
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
-    }
-}
-
-struct Px {  // one pixel's G-buffer texels, still packed
-    uint32_t color, data, emission, n01, n23;
-    float depth, ao, mask;
-};
-
-SAH_DEV int clamp_to_int(float f) { return (int)__builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f); }
-
-// RGBA16F texel fetch with "transparent black" outside the volume.
-SAH_DEV void load_rgba16f_border(const VolumeArg& v, int x, int y, int z, float (&c)[4]) {
-    if ((unsigned)x < v.width && (unsigned)y < v.height && (unsigned)z < v.depth) {
-        const uint2 t = *reinterpret_cast<const uint2*>(v.ptr + (size_t)z * v.slice_pitch + (size_t)y * v.row_pitch + (size_t)x * 8);
-        c[0] = h2f((uint16_t)(t.x & 0xffffu));
-        c[1] = h2f((uint16_t)(t.x >> 16));
-        c[2] = h2f((uint16_t)(t.y & 0xffffu));
-        c[3] = h2f((uint16_t)(t.y >> 16));
-    } else {
-        c[0] = c[1] = c[2] = c[3] = 0.f;
-    }
-}
-
-// Trilinear, CLAMP_TO_BORDER (transparent black), full fp32 weights:
-//   ((t000*(1-fx) + t100*fx)*(1-fy) + (t010*(1-fx) + t110*fx)*fy)*(1-fz) + (... z+1 ...)*fz
-SAH_DEV void sample_trilinear_border(const VolumeArg& v, float u, float vv, float w, float (&out)[4]) {
-    const float px = u * (float)v.width - 0.5f;
-    const float py = vv * (float)v.height - 0.5f;
-    const float pz = w * (float)v.depth - 0.5f;
-    if (isnan_f(px) || isnan_f(py) || isnan_f(pz)) {
-        out[0] = out[1] = out[2] = out[3] = __builtin_nanf("");
-        return;
-    }
-    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py), fz0 = __builtin_floorf(pz);
-    const float fx = px - fx0, fy = py - fy0, fz = pz - fz0;
-    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy, wz0 = 1.0f - fz;
-    const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0), z0 = clamp_to_int(fz0);
-    float t[8][4];
-#pragma unroll
-    for (int k = 0; k < 8; k++) load_rgba16f_border(v, x0 + (k & 1), y0 + ((k >> 1) & 1), z0 + (k >> 2), t[k]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float a0 = t[0][i] * wx0 + t[1][i] * fx;
-        const float b0 = t[2][i] * wx0 + t[3][i] * fx;
-        const float a1 = t[4][i] * wx0 + t[5][i] * fx;
-        const float b1 = t[6][i] * wx0 + t[7][i] * fx;
-        const float c0 = a0 * wy0 + b0 * fy;
-        const float c1 = a1 * wy0 + b1 * fy;
-        out[i] = c0 * wz0 + c1 * fz;
-    }
-}
-
-// Bilinear RGBA16F with REPEAT addressing (sky LUTs: RenderCore/render/procedural_sky.cpp:62-68).
-SAH_DEV void sample_bilinear_repeat_rgba16f(const PlaneArg& p, uint32_t W, uint32_t H, float u, float v, float (&out)[4]) {
-    const float px = u * (float)W - 0.5f, py = v * (float)H - 0.5f;
-    if (isnan_f(px) || isnan_f(py)) {
-        out[0] = out[1] = out[2] = out[3] = __builtin_nanf("");
-        return;
-    }
-    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-    const float fx = px - fx0, fy = py - fy0;
-    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    int x0 = clamp_to_int(fx0) % (int)W, y0 = clamp_to_int(fy0) % (int)H;
-    if (x0 < 0) x0 += (int)W;
-    if (y0 < 0) y0 += (int)H;
-    int x1 = x0 + 1 == (int)W ? 0 : x0 + 1, y1 = y0 + 1 == (int)H ? 0 : y0 + 1;
-    float t[4][4];
-    const int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint2 q = *reinterpret_cast<const uint2*>(p.ptr + (size_t)ys[k] * p.pitch + (size_t)xs[k] * 8);
-        t[k][0] = h2f((uint16_t)(q.x & 0xffffu));
-        t[k][1] = h2f((uint16_t)(q.x >> 16));
-        t[k][2] = h2f((uint16_t)(q.y & 0xffffu));
-        t[k][3] = h2f((uint16_t)(q.y >> 16));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float a = t[0][i] * wx0 + t[1][i] * fx;
-        const float b = t[2][i] * wx0 + t[3][i] * fx;
-        out[i] = a * wy0 + b * fy;
-    }
-}
-
-// directional_light.frag:45-53 / gi/lpv/overlay.frag:43-51: texcoord = (gl_FragCoord + 0.5) / res = (x + 1) / W (quirk)
-SAH_DEV F3 viewspace_position_glsl(const LightingArgs& a, uint32_t x, uint32_t y, float depth) {
-    const Fn fx = Fn((float)x + 0.5f) + Fn(0.5f), fy = Fn((float)y + 0.5f) + Fn(0.5f);
-    const Fn tx = fx / Fn(a.res[0]), ty = fy / Fn(a.res[1]);
-    const F4 ndc = {tx * Fn(2.0f) - Fn(1.0f), ty * Fn(2.0f) - Fn(1.0f), Fn(depth), Fn(1.0f)};
-    const F4 vs = mul44(a.inv_proj, ndc);
-    return {vs.x / vs.w, vs.y / vs.w, vs.z / vs.w};
-}
-
-// directional_light.rt.slang:39-48 / gi/cache/overlay.frag.slang:35-44 (correct pixel centre)
-SAH_DEV F3 worldspace_location_slang(const LightingArgs& a, float px, float py, float depth) {
-    const Fn tx = (Fn(px) + Fn(0.5f)) / Fn(a.res[0]);
-    const Fn ty = (Fn(py) + Fn(0.5f)) / Fn(a.res[1]);
-    const F4 ndc = {tx * Fn(2.0f) - Fn(1.0f), ty * Fn(2.0f) - Fn(1.0f), Fn(depth), Fn(1.0f)};
-    F4 vs = mul44(a.inv_proj, ndc);
-    vs = {vs.x / vs.w, vs.y / vs.w, vs.z / vs.w, vs.w / vs.w};
-    const F4 ws = mul44(a.inv_view, vs);
-    return {ws.x, ws.y, ws.z};
-}
-
-struct SurfIn {  // unpacked texels
-    float color[3];
-    float normal[3];
-    float rough, metal;
-};
-
-SAH_DEV SurfIn unpack_surface(const Px& p, const float* lut) {
-    SurfIn s;
-    s.color[0] = lut[p.color & 0xffu];
-    s.color[1] = lut[(p.color >> 8) & 0xffu];
-    s.color[2] = lut[(p.color >> 16) & 0xffu];
-    s.normal[0] = h2f((uint16_t)(p.n01 & 0xffffu));
-    s.normal[1] = h2f((uint16_t)(p.n01 >> 16));
-    s.normal[2] = h2f((uint16_t)(p.n23 & 0xffffu));
-    s.rough = lut[256 + ((p.data >> 8) & 0xffu)];
-    s.metal = lut[256 + ((p.data >> 16) & 0xffu)];
-    return s;
-}
-
-// ---- a1: directional_light.frag:96-149 (CSM-mode sun) -------------------------------------------------
-SAH_DEV float shadow_pcf(const CsmArgs& c, float u, float v, uint32_t layer, float ref) {
-    const VolumeArg& sm = c.shadowmap;
-    const float px = u * (float)sm.width - 0.5f, py = v * (float)sm.height - 0.5f;
-    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-    const float fx = px - fx0, fy = py - fy0;
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    float cmp[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int x = x0 + (k & 1), y = y0 + (k >> 1);
-        x = x < 0 ? 0 : (x > (int)sm.width - 1 ? (int)sm.width - 1 : x);  // CLAMP_TO_EDGE
-        y = y < 0 ? 0 : (y > (int)sm.height - 1 ? (int)sm.height - 1 : y);
-        const uint8_t* t = sm.ptr + (size_t)layer * sm.slice_pitch + (size_t)y * sm.row_pitch;
-        float d;
-        if (c.is_d16) d = (float)reinterpret_cast<const uint16_t*>(t)[x] / 65535.0f;
-        else d = reinterpret_cast<const float*>(t)[x];
-        cmp[k] = (ref < d) ? 1.0f : 0.0f;  // compare op LESS, then filter
-    }
-    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    const float a = cmp[0] * wx0 + cmp[1] * fx;
-    const float b = cmp[2] * wx0 + cmp[3] * fx;
-    return a * wy0 + b * fy;
-}
-
-SAH_DEV Fn sample_csm(const CsmArgs& c, F3 ws, Fn viewspace_depth, Fn ndotl) {
-    uint32_t cascade = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-        if (viewspace_depth.v < c.splits[i]) cascade = i + 1;
-    }
-    if (cascade > 3) return Fn(0.0f);
-    const Fn bias = Fn(0.0005f) * nsqrt(Fn(1.0f) - ndotl * ndotl) / ndotl;
-    F4 sp = mul44(c.biased[cascade], F4{ws.x, ws.y, ws.z, Fn(1.0f)});
-    sp = {sp.x / sp.w, sp.y / sp.w, sp.z / sp.w, sp.w / sp.w};
-    if (sp.x.v < 0.f || sp.y.v < 0.f || sp.z.v < 0.f || sp.x.v > 1.f || sp.y.v > 1.f || sp.z.v > 1.f) return Fn(1.0f);
-    if (c.shadowmap.ptr == nullptr) return Fn(1.0f);
-    if (isnan_f(sp.x.v) || isnan_f(sp.y.v)) return Fn(__builtin_nanf(""));
-    float ref = (sp.z - bias).v;
-    if (c.is_d16) ref = ref < 0.f ? 0.f : (ref > 1.f ? 1.f : ref);
-    return Fn(shadow_pcf(c, sp.x.v, sp.y.v, cascade, ref));
-}
-
-SAH_DEV void sun_frag(const LightingArgs& a, const CsmArgs& csm, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, Fn (&out)[4]) {
-    Surface<Fn> s;
-    s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
-    s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});
-    s.roughness = Fn(si.rough);
-    s.metalness = Fn(si.metal);
-    const F3 vs = viewspace_position_glsl(a, x, y, p.depth);
-    const F4 ws4 = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(1.0f)});
-    const F3 ws = {ws4.x, ws4.y, ws4.z};
-    const F3 V = normalize(ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])});
-    const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
-    const Fn ndotl = nclamp(dot(s.normal, L), Fn(0.f), Fn(1.f));
-    Fn shadow = Fn(1.0f);
-    if (ndotl.v > 0.f) shadow = sample_csm(csm, ws, vs.z, ndotl);
-    const F3 b = Fd(s, L, V) + Fr(s, L, V);
-    F3 direct = ndotl * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * shadow;
-    if (any_nan(direct)) direct = F3(Fn(0.f));
-    const Fn exposure = Fn(0.00031415927f);
-    out[0] = direct.x * exposure;
-    out[1] = direct.y * exposure;
-    out[2] = direct.z * exposure;
-    out[3] = Fn(1.0f);
-}
-
-// ---- a1b: directional_light.rt.slang:58-139 with the ray query replaced by the shadow-mask plane --------
-SAH_DEV void sun_rt(const LightingArgs& a, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, float (&add)[3]) {
-    Surface<Hn> s;
-    s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
-    s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
-    s.roughness = Hn(si.rough);
-    s.metalness = Hn(si.metal);
-    const F3 location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
-    const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
-    const Hn ndotl = Hn(nclamp(dot(L, to_f(s.normal)), Fn(0.f), Fn(1.f)).v);
-    const H3 V = to_h(normalize(location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
-    const H3 Lh = to_h(L);
-    const H3 b = Fd(s, Lh, V) + Fr(s, Lh, V);
-    const H3 nb = ndotl * b;
-    F3 radiance = to_f(nb) * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])};
-    if (tof(ndotl) > 0.f) radiance = radiance * Fn(p.mask);
-    const Fn exposure = Fn(0.00031415927f);
-    add[0] = (radiance.x * exposure).v;
-    add[1] = (radiance.y * exposure).v;
-    add[2] = (radiance.z * exposure).v;
-}
-
-// ---- a3: gi/lpv/overlay.frag:70-164 ---------------------------------------------------------------------
-SAH_DEV void dir_to_sh(F3 d, Fn (&o)[4]) {
-    const Fn c0 = Fn(0.282094792f), c1 = Fn(0.488602512f);
-    o[0] = c0;
-    o[1] = -c1 * d.y;
-    o[2] = c1 * d.z;
-    o[3] = -c1 * d.x;
-}
-SAH_DEV Fn dot4(const float (&t)[4], const Fn (&n)[4]) { return Fn(t[0]) * n[0] + Fn(t[1]) * n[1] + Fn(t[2]) * n[2] + Fn(t[3]) * n[3]; }
-
-SAH_DEV void lpv_fetch(const LpvArgs& L, F4 p, const Fn (&n)[4], Fn (&out)[3]) {
-    float r[4], g[4], b[4];
-    sample_trilinear_border(L.red, p.x.v, p.y.v, p.z.v, r);
-    sample_trilinear_border(L.green, p.x.v, p.y.v, p.z.v, g);
-    sample_trilinear_border(L.blue, p.x.v, p.y.v, p.z.v, b);
-    out[0] = dot4(r, n);
-    out[1] = dot4(g, n);
-    out[2] = dot4(b, n);
-}
-
-SAH_DEV void gi_lpv_frag(const LightingArgs& a, const LpvArgs& L, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, Fn (&out)[4]) {
-    Surface<Fn> s;
-    s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
-    s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});
-    s.roughness = Fn(si.rough);
-    s.metalness = Fn(si.metal);
-    const F3 vs = viewspace_position_glsl(a, x, y, p.depth);
-    const F4 ws = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(1.0f)});
-    const F3 V = normalize(F3{ws.x, ws.y, ws.z} - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])});
-
-    uint32_t selected = 0;
-    for (int i = (int)L.num_cascades - 1; i >= 0; i--) {
-        const F4 cp = mul44(L.world_to_cascade[i], ws);
-        if (cp.x.v > 0.f && cp.y.v > 0.f && cp.z.v > 0.f && cp.x.v < 1.f && cp.y.v < 1.f && cp.z.v < 1.f) selected = (uint32_t)i;
-    }
-    F3 lpv_normal = -s.normal;
-    lpv_normal.x = lpv_normal.x * Fn(-1.0f);
-    Fn nc[4];
-    dir_to_sh(lpv_normal, nc);
-
-    Fn indirect[3];
-    {
-        const F4 pos = {ws.x + s.normal.x, ws.y + s.normal.y, ws.z + s.normal.z, ws.w + Fn(0.f)};
-        F4 cp = mul44(L.world_to_cascade[selected], pos);
-        cp.x = cp.x + Fn((float)selected);
-        cp.x = cp.x / Fn(L.num_cascades_f);
-        lpv_fetch(L, cp, nc, indirect);
-    }
-    const F3 I = -V;
-    const F3 refl = I - s.normal * (Fn(2.0f) * dot(s.normal, I));
-    Fn spec[3] = {Fn(0.f), Fn(0.f), Fn(0.f)};
-    if (selected == 0) {
-        const F4 cp = mul44(L.world_to_cascade[0], ws);
-        Fn rc[4];
-        dir_to_sh(refl, rc);
-        lpv_fetch(L, cp, rc, spec);
-        const F3 loc = F3{ws.x, ws.y, ws.z} + refl * Fn(1.0f);
-        const F4 cp1 = mul44(L.world_to_cascade[0], F4{loc.x, loc.y, loc.z, Fn(1.f)});
-        Fn more[3];
-        lpv_fetch(L, cp1, rc, more);
-#pragma unroll
-        for (int i = 0; i < 3; i++) spec[i] = (spec[i] + more[i]) / Fn(2.0f);
-    }
-    const F3 diffuse_factor = Fd(s, s.normal, s.normal);
-    const F3 fr = Fr(s, s.normal, refl);
-    const F3 specular_factor = {fr.x * Fn(0.f), fr.y * Fn(0.f), fr.z * Fn(0.f)};
-    const Fn ao = Fn(p.ao);
-    F3 total = {indirect[0] * diffuse_factor.x * ao + spec[0] * specular_factor.x,
-                indirect[1] * diffuse_factor.y * ao + spec[1] * specular_factor.y,
-                indirect[2] * diffuse_factor.z * ao + spec[2] * specular_factor.z};
-    if (any_nan(total)) total = F3(Fn(0.f));
-    const Fn exposure = Fn(L.exposure);
-    out[0] = total.x * exposure;
-    out[1] = total.y * exposure;
-    out[2] = total.z * exposure;
-    out[3] = Fn(1.0f);
-}
-
-// ---- a6: sky/sky_unified.slang:54-206 ---------------------------------------------------------------------
-// acos / atan / exp are evaluated in fp64 and rounded to fp32 (the oracle defines them as correctly rounded).
-SAH_DEV Fn cr_acos(Fn x) { return Fn((float)acos((double)x.v)); }
-SAH_DEV Fn cr_atan(Fn x) { return Fn((float)atan((double)x.v)); }
-SAH_DEV Fn cr_exp(Fn x) { return Fn((float)exp((double)x.v)); }
-SAH_DEV Fn fsign(Fn x) { return Fn(x.v > 0.f ? 1.0f : (x.v < 0.f ? -1.0f : 0.0f)); }
-
-SAH_DEV Fn ray_intersect_sphere(F3 ro, F3 rd, Fn rad) {
-    const Fn b = dot(ro, rd);
-    const Fn c = dot(ro, ro) - rad * rad;
-    if (c.v > 0.0f && b.v > 0.0f) return Fn(-1.0f);
-    const Fn discr = b * b - c;
-    if (discr.v < 0.0f) return Fn(-1.0f);
-    if (discr.v > (b * b).v) return (-b + nsqrt(discr));
-    return -b - nsqrt(discr);
-}
-
-SAH_DEV void sky_frag(const LightingArgs& a, const SkyArgs& k, uint32_t x, uint32_t y, Hn (&out)[4]) {
-    const Fn sky_pi = Fn(3.14159265358f);
-    const Fn sx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]);
-    const Fn sy = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
-    F4 vs = mul44(a.inv_proj, F4{sx, sy, Fn(1.f), Fn(1.f)});
-    vs = {vs.x / vs.w, vs.y / vs.w, vs.z / vs.w, vs.w / vs.w};
-    const F4 wv = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(0.f)});
-    F3 rayDir = -normalize(F3{wv.x, wv.y, wv.z});
-    rayDir.y = rayDir.y * Fn(-1.0f);
-    const F3 sunDir = {Fn(k.sun_dir[0]), Fn(k.sun_dir[1]), Fn(k.sun_dir[2])};
-    const F3 up = {Fn(0.0f) / Fn(k.height), Fn(k.up_y), Fn(0.0f) / Fn(k.height)};
-    const F3 view_pos = {Fn(0.f), Fn(k.view_pos_y), Fn(0.f)};
-
-    // getValFromSkyLUT :80-109
-    const Fn altitudeAngle = Fn(k.horizon_angle) - cr_acos(dot(rayDir, up));
-    Fn azimuthAngle;
-    if (__builtin_fabsf(altitudeAngle.v) > k.azimuth_limit) {
-        azimuthAngle = Fn(0.0f);
-    } else {
-        const F3 right = {Fn(k.right[0]), Fn(k.right[1]), Fn(k.right[2])};
-        const F3 forward = {Fn(k.forward[0]), Fn(k.forward[1]), Fn(k.forward[2])};
-        const F3 projectedDir = normalize(rayDir - up * (dot(rayDir, up)));
-        const Fn sinTheta = dot(projectedDir, right);
-        const Fn cosTheta = dot(projectedDir, forward);
-        azimuthAngle = cr_atan(cosTheta / sinTheta) + sky_pi;
-    }
-    const Fn v = Fn(0.5f) + Fn(0.5f) * fsign(altitudeAngle) * nsqrt(nabs(altitudeAngle) * Fn(2.0f) / sky_pi);
-    const Fn u = azimuthAngle / (Fn(2.0f) * sky_pi);
-    float lut[4];
-    sample_bilinear_repeat_rgba16f(k.sky_view, k.s_w, k.s_h, u.v, v.v, lut);
-    F3 lum = {Fn(lut[0]), Fn(lut[1]), Fn(lut[2])};
-
-    // sunWithBloom :120-135
-    Fn sun;
-    {
-        const Fn cosTheta = dot(rayDir, sunDir);
-        if (cosTheta.v >= k.min_sun_cos) {
-            sun = Fn(1.f);
-        } else {
-            const Fn offset = Fn(k.min_sun_cos) - cosTheta;
-            const Fn gaussianBloom = cr_exp(-offset * Fn(50000.0f)) * Fn(0.5f);
-            const Fn invBloom = Fn(1.0f) / (Fn(0.02f) + offset * Fn(300.0f)) * Fn(0.01f);
-            sun = gaussianBloom + invBloom;
-        }
-    }
-    // smoothstep(0.002h, 1.0h, sunLum)
-    Fn t = nclamp((sun - Fn(k.smooth_e0)) / (Fn(1.0f) - Fn(k.smooth_e0)), Fn(0.0f), Fn(1.0f));
-    const Fn s = t * t * (Fn(3.0f) - Fn(2.0f) * t);
-    F3 sunLum = F3(s);
-    if (length(sunLum).v > 0.0f) {
-        if (ray_intersect_sphere(view_pos, rayDir, Fn(6.360f)).v >= 0.0f) {
-            sunLum = F3(Fn(0.f));
-        } else {
-            // getValFromTLUT(transmittance_lut, viewPos, sunDir) :111-118
-            const Fn sunCosZenithAngle = dot(sunDir, up);
-            const Fn tu = nclamp(Fn(0.5f) + Fn(0.5f) * sunCosZenithAngle, Fn(0.0f), Fn(1.0f));
-            const Fn tv = nmax(Fn(0.0f), nmin(Fn(1.0f), (Fn(k.height) - Fn(6.360f)) / (Fn(6.460f) - Fn(6.360f))));
-            float tl[4];
-            sample_bilinear_repeat_rgba16f(k.transmittance, k.t_w, k.t_h, tu.v, tv.v, tl);
-            sunLum = sunLum * F3{Fn(tl[0]), Fn(tl[1]), Fn(tl[2])};
-        }
-    }
-    lum = lum + sunLum;
-    lum = lum * Fn(20.0f);
-    lum = lum * Fn(1.0f);
-    out[0] = Hn(lum.x.v);
-    out[1] = Hn(lum.y.v);
-    out[2] = Hn(lum.z.v);
-    out[3] = Hn(1.0f);
-}
-
-// ---- a0: per-pixel composition ------------------------------------------------------------------------------
-template <int SUN, int GI>
-SAH_DEV uint2 shade_pixel(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, uint32_t x, uint32_t y,
-                          const Px& p, const float* lut) {
-    Hn lit[4] = {Hn(0.f), Hn(0.f), Hn(0.f), Hn(0.f)};
-    const bool surface = p.depth != 0.f;  // every lighting shader discards on depth == 0
-    SurfIn si;
-    if (surface) si = unpack_surface(p, lut);
-
-    if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
-        if (surface) {
-            Fn s[4];
-            sun_frag(a, csm, x, y, p, si, s);
-            if (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) {
-#pragma unroll
-                for (int i = 0; i < 3; i++) lit[i] = Hn((s[i] * s[i] + Fn(tof(lit[i])) * Fn(tof(lit[i]))).v);
-                lit[3] = Hn((s[3] * Fn(0.f) + Fn(tof(lit[3])) * Fn(0.f)).v);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
-            }
-        }
-    }
-    if constexpr (GI == SAH_GI_LPV) {
-        if (surface) {
-            Fn s[4];
-            gi_lpv_frag(a, lpv, x, y, p, si, s);
-#pragma unroll
-            for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
-        }
-    }
-    {  // emissive.frag:15-22 — no discard
-        const Fn e = Fn(3.1415927f);
-        lit[0] = Hn(tof(lit[0]) + (Fn(lut[p.emission & 0xffu]) * e).v);
-        lit[1] = Hn(tof(lit[1]) + (Fn(lut[(p.emission >> 8) & 0xffu]) * e).v);
-        lit[2] = Hn(tof(lit[2]) + (Fn(lut[(p.emission >> 16) & 0xffu]) * e).v);
-        lit[3] = Hn(tof(lit[3]) + 1.0f);
-    }
-    if (sky.enabled && !surface) sky_frag(a, sky, x, y, lit);
-    if constexpr (SUN == SAH_SHADOW_MODE_RT) {
-        if (surface) {
-            float add[3];
-            sun_rt(a, x, y, p, si, add);
-#pragma unroll
-            for (int i = 0; i < 3; i++) lit[i] = Hn(tof(lit[i]) + add[i]);
-        }
-    }
-    uint2 r;
-    r.x = (uint32_t)__builtin_bit_cast(uint16_t, lit[0].v) | ((uint32_t)__builtin_bit_cast(uint16_t, lit[1].v) << 16);
-    r.y = (uint32_t)__builtin_bit_cast(uint16_t, lit[2].v) | ((uint32_t)__builtin_bit_cast(uint16_t, lit[3].v) << 16);
-    return r;
-}
-
+// ---- general kernel -------------------------------------------------------------------------------------------
 template <int SUN, int GI, int PPT>
-__global__ void __launch_bounds__(256) k_lighting(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky) {
+__global__ void __launch_bounds__(256) k_lighting_general(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky) {
     __shared__ float s_lut[512];
     s_lut[threadIdx.x] = a.luts[threadIdx.x];
     s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
@@ -508,7 +59,7 @@ __global__ void __launch_bounds__(256) k_lighting(const LightingArgs a, const Cs
         p.depth = __uint_as_float(wz[i]);
         p.ao = (GI == SAH_GI_LPV && a.has_ao) ? __uint_as_float(wao[i]) : 1.0f;
         p.mask = (SUN == SAH_SHADOW_MODE_RT && a.has_mask) ? __uint_as_float(wm[i]) : 1.0f;
-        const uint2 r = shade_pixel<SUN, GI>(a, csm, lpv, sky, x0 + i, y, p, s_lut);
+        const uint2 r = shade_pixel_general<SUN, GI>(a, csm, lpv, sky, x0 + i, y, p, s_lut);
         out[2 * i] = r.x;
         out[2 * i + 1] = r.y;
     }
@@ -520,35 +71,206 @@ __global__ void __launch_bounds__(256) k_lighting(const LightingArgs a, const Cs
     }
 }
 
-// ---- launcher ------------------------------------------------------------------------------------------------
+// ---- fix-up kernel: general restatement over the deferred-pixel list ------------------------------------------------
 template <int SUN, int GI>
-static hipError_t launch_ppt(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, int ppt, hipStream_t st) {
+__global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
+                                                        const FastArgs f) {
+    __shared__ float s_lut[512];
+    s_lut[threadIdx.x] = a.luts[threadIdx.x];
+    s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
+    __syncthreads();
+    const uint32_t count = f.state->count[f.parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // arm the other parity for the next call
+        f.state->count[f.parity ^ 1u] = 0u;
+        f.state->nonfinite[f.parity ^ 1u] = 0u;
+    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t idx = f.list[i];
+        const uint32_t y = idx / a.width, x = idx - y * a.width;
+        Px p;
+        p.color = *reinterpret_cast<const uint32_t*>(a.color.ptr + (size_t)y * a.color.pitch + (size_t)x * 4);
+        p.data = *reinterpret_cast<const uint32_t*>(a.data.ptr + (size_t)y * a.data.pitch + (size_t)x * 4);
+        p.emission = *reinterpret_cast<const uint32_t*>(a.emission.ptr + (size_t)y * a.emission.pitch + (size_t)x * 4);
+        p.depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+        const uint2 n = *reinterpret_cast<const uint2*>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x * 8);
+        p.n01 = n.x;
+        p.n23 = n.y;
+        p.ao = (GI == SAH_GI_LPV && a.has_ao) ? *reinterpret_cast<const float*>(a.ao.ptr + (size_t)y * a.ao.pitch + (size_t)x * 4) : 1.0f;
+        p.mask = (SUN == SAH_SHADOW_MODE_RT && a.has_mask)
+                     ? *reinterpret_cast<const float*>(a.shadow_mask.ptr + (size_t)y * a.shadow_mask.pitch + (size_t)x * 4)
+                     : 1.0f;
+        const uint2 r = shade_pixel_general<SUN, GI>(a, csm, lpv, sky, x, y, p, s_lut);
+        *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x * 8) = r;
+    }
+}
+
+// ---- LPV finiteness scan (feeds the "specular quirk is inert" proof) ---------------------------------------------------
+__global__ void __launch_bounds__(256) k_lpv_scan(const VolumeArg r, const VolumeArg g, const VolumeArg b, FrameState* state, uint32_t parity) {
+    const uint32_t row = blockIdx.x;  // one block per (z, y) row of the three volumes
+    const uint32_t z = row / r.height, y = row - z * r.height;
+    uint32_t bad = 0;
+    const VolumeArg* vols[3] = {&r, &g, &b};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const uint8_t* base = vols[c]->ptr + (size_t)z * vols[c]->slice_pitch + (size_t)y * vols[c]->row_pitch;
+        for (uint32_t x = threadIdx.x; x < vols[c]->width; x += 256) {
+            const uint2 t = *reinterpret_cast<const uint2*>(base + (size_t)x * 8);
+            // fp16 exponent all ones <=> inf or NaN
+            bad |= ((t.x & 0x7c00u) == 0x7c00u) | ((t.x & 0x7c000000u) == 0x7c000000u) | ((t.y & 0x7c00u) == 0x7c00u) |
+                   ((t.y & 0x7c000000u) == 0x7c000000u);
+        }
+    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&state->nonfinite[parity], 1u);
+}
+
+// ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
+template <int SUN, int GI, int PPT>
+__global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const FastArgs f) {
+    __shared__ __attribute__((aligned(16))) float s_lut[TAB_SIZE];
+    s_lut[threadIdx.x] = a.luts[threadIdx.x];
+    s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
+    if (SUN == SAH_SHADOW_MODE_CSM && threadIdx.x < 48) {  // [cascade][row x,y,z][col 0..3] of biasMat * cascade_matrices
+        const uint32_t c = threadIdx.x / 12u, j = threadIdx.x % 12u;
+        s_lut[TAB_CSM + threadIdx.x] = csm.biased[c][(j & 3u) * 4u + (j >> 2)];
+    }
+    if (GI == SAH_GI_LPV && threadIdx.x >= 64 && threadIdx.x < 96) {  // [cascade][sx sy sz - tx ty tz -]
+        const uint32_t t = threadIdx.x - 64u, c = t >> 3, j = t & 7u;
+        s_lut[TAB_LPV + t] = (j & 3u) == 3u ? 0.f : (j < 4u ? f.lpv_s[c][j] : f.lpv_t[c][j - 4u]);
+    }
+    __syncthreads();
+
+    const uint32_t groups_per_row = a.width / PPT;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t rows = a.row_end - a.row_begin;
+    const bool active = gid < groups_per_row * rows;
+    const uint32_t ry = active ? gid / groups_per_row : 0u;
+    const uint32_t y = a.row_begin + ry;
+    const uint32_t x0 = active ? (gid - ry * groups_per_row) * PPT : 0u;
+    const bool lpv_bad = (GI == SAH_GI_LPV) ? (f.state->nonfinite[f.parity] != 0u) : false;
+
+    uint32_t wc[PPT], wd[PPT], we[PPT], wz[PPT], wn[2 * PPT], wao[PPT], wm[PPT];
+    if (active) {
+        load_words<PPT>(a.color.ptr + (size_t)y * a.color.pitch + (size_t)x0 * 4, wc);
+        load_words<PPT>(a.data.ptr + (size_t)y * a.data.pitch + (size_t)x0 * 4, wd);
+        load_words<PPT>(a.emission.ptr + (size_t)y * a.emission.pitch + (size_t)x0 * 4, we);
+        load_words<PPT>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x0 * 4, wz);
+        load_words<2 * PPT>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x0 * 8, wn);
+        if (GI == SAH_GI_LPV && a.has_ao) load_words<PPT>(a.ao.ptr + (size_t)y * a.ao.pitch + (size_t)x0 * 4, wao);
+        if (SUN == SAH_SHADOW_MODE_RT && a.has_mask) load_words<PPT>(a.shadow_mask.ptr + (size_t)y * a.shadow_mask.pitch + (size_t)x0 * 4, wm);
+    }
+    // per-row / per-column terms of the view-space position (two texcoord conventions, see lighting_common.hpp)
+    const Fn ty_g = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
+    const float rowy_glsl = (Fn(f.p5) * (ty_g * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+    const Fn ty_s = (Fn((float)y) + Fn(0.5f)) / Fn(a.res[1]);
+    const float rowy_slang = (Fn(f.p5) * (ty_s * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+
+    uint32_t out[2 * PPT];
+    uint32_t deferred_mask = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        if (!active) break;
+        Px p;
+        p.color = wc[i];
+        p.data = wd[i];
+        p.emission = we[i];
+        p.n01 = wn[2 * i];
+        p.n23 = wn[2 * i + 1];
+        p.depth = __uint_as_float(wz[i]);
+        p.ao = (GI == SAH_GI_LPV && a.has_ao) ? __uint_as_float(wao[i]) : 1.0f;
+        p.mask = (SUN == SAH_SHADOW_MODE_RT && a.has_mask) ? __uint_as_float(wm[i]) : 1.0f;
+        const uint32_t x = x0 + i;
+        float colx_glsl = 0.f, colx_slang = 0.f;
+        if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) {
+            const Fn tx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]);
+            colx_glsl = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+        }
+        if (SUN == SAH_SHADOW_MODE_RT) {
+            const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]);
+            colx_slang = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+        }
+        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
+        out[2 * i] = r.lit.x;
+        out[2 * i + 1] = r.lit.y;
+        if (r.deferred) deferred_mask |= 1u << i;
+    }
+    if (active) {
+        uint8_t* dst = const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x0 * 8;
+        if constexpr (PPT == 1) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(out[0], out[1]);
+        } else {
+            store_words<2 * PPT>(dst, out);
+        }
+    }
+    // wave-aggregated append of the deferred pixels: one atomic per wave
+    const uint32_t n_mine = __builtin_popcount(deferred_mask);
+    uint32_t prefix = n_mine;  // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(prefix, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) prefix += t;
+    }
+    const uint32_t total = __shfl(prefix, 63, 64);
+    if (total) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 63) base = atomicAdd(&f.state->count[f.parity], total);
+        base = __shfl(base, 63, 64);
+        uint32_t slot = base + prefix - n_mine;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            if (deferred_mask & (1u << i)) f.list[slot++] = y * a.width + x0 + i;
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------
+template <int SUN, int GI>
+static hipError_t launch_general_ppt(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, int ppt, hipStream_t st) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint64_t groups = (uint64_t)(a.width / ppt) * rows;
     if (groups == 0) return hipSuccess;
     const dim3 grid((uint32_t)((groups + 255) / 256)), block(256);
-    if (ppt == 4) hipLaunchKernelGGL((k_lighting<SUN, GI, 4>), grid, block, 0, st, a, csm, lpv, sky);
-    else if (ppt == 2) hipLaunchKernelGGL((k_lighting<SUN, GI, 2>), grid, block, 0, st, a, csm, lpv, sky);
-    else hipLaunchKernelGGL((k_lighting<SUN, GI, 1>), grid, block, 0, st, a, csm, lpv, sky);
+    if (ppt == 4) hipLaunchKernelGGL((k_lighting_general<SUN, GI, 4>), grid, block, 0, st, a, csm, lpv, sky);
+    else if (ppt == 2) hipLaunchKernelGGL((k_lighting_general<SUN, GI, 2>), grid, block, 0, st, a, csm, lpv, sky);
+    else hipLaunchKernelGGL((k_lighting_general<SUN, GI, 1>), grid, block, 0, st, a, csm, lpv, sky);
+    return hipGetLastError();
+}
+
+template <int SUN, int GI>
+static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, const FastArgs& f, int ppt,
+                                  hipStream_t st) {
+    const uint32_t rows = a.row_end - a.row_begin;
+    const uint64_t groups = (uint64_t)(a.width / ppt) * rows;
+    if (groups == 0) return hipSuccess;
+    if (GI == SAH_GI_LPV) {
+        hipLaunchKernelGGL(k_lpv_scan, dim3(lpv.red.height * lpv.red.depth), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, f.state, f.parity);
+    }
+    const dim3 grid((uint32_t)((groups + 255) / 256)), block(256);
+    if (ppt == 4) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4>), grid, block, 0, st, a, csm, lpv, f);
+    else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 2>), grid, block, 0, st, a, csm, lpv, f);
+    else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 1>), grid, block, 0, st, a, csm, lpv, f);
+    hipLaunchKernelGGL((k_lighting_fixup<SUN, GI>), dim3(f.fixup_blocks), block, 0, st, a, csm, lpv, sky, f);
     return hipGetLastError();
 }
 
 template <int SUN>
-static hipError_t launch_gi(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, int gi, int ppt, hipStream_t st) {
+static hipError_t launch_gi(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, const FastArgs* f, int gi, int ppt,
+                            hipStream_t st) {
     switch (gi) {
-        case SAH_GI_NONE: return launch_ppt<SUN, SAH_GI_NONE>(a, csm, lpv, sky, ppt, st);
-        case SAH_GI_LPV: return launch_ppt<SUN, SAH_GI_LPV>(a, csm, lpv, sky, ppt, st);
+        case SAH_GI_NONE:
+            return f ? launch_fast_ppt<SUN, SAH_GI_NONE>(a, csm, lpv, sky, *f, ppt, st) : launch_general_ppt<SUN, SAH_GI_NONE>(a, csm, lpv, sky, ppt, st);
+        case SAH_GI_LPV:
+            return f ? launch_fast_ppt<SUN, SAH_GI_LPV>(a, csm, lpv, sky, *f, ppt, st) : launch_general_ppt<SUN, SAH_GI_LPV>(a, csm, lpv, sky, ppt, st);
         default: return hipErrorNotSupported;
     }
 }
 
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
-                           const SkyArgs& sky, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st) {
+                           const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st) {
     if (a.num_lights) return hipErrorNotSupported;
     switch (sun_mode) {
-        case SAH_SHADOW_MODE_OFF: return launch_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, sky, gi, ppt, st);
-        case SAH_SHADOW_MODE_CSM: return launch_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, sky, gi, ppt, st);
-        case SAH_SHADOW_MODE_RT: return launch_gi<SAH_SHADOW_MODE_RT>(a, csm, lpv, sky, gi, ppt, st);
+        case SAH_SHADOW_MODE_OFF: return launch_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, sky, fast, gi, ppt, st);
+        case SAH_SHADOW_MODE_CSM: return launch_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, sky, fast, gi, ppt, st);
+        case SAH_SHADOW_MODE_RT: return launch_gi<SAH_SHADOW_MODE_RT>(a, csm, lpv, sky, fast, gi, ppt, st);
         default: return hipErrorInvalidValue;
     }
 }

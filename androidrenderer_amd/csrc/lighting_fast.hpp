@@ -1,0 +1,272 @@
+// Straight-line (branch-free) per-pixel body of the fast Lighting kernel.
+//
+// Everything is evaluated unconditionally and merged with selects so that the whole PPT-unrolled kernel body is ONE basic
+// block: the scheduler can then issue the shadow-map and LPV gathers early and overlap their latency with the BRDF
+// arithmetic (with divergent branches every region waited for its own loads: 43 % of wave cycles in s_waitcnt).
+// Pixels whose inputs fall outside what the proofs cover are flagged `deferred`; whatever was computed for them is
+// discarded and the fix-up kernel shades them with the general restatement.  All gathers use clamped (in-bounds)
+// addresses, so evaluating garbage for a deferred pixel is harmless.
+#pragma once
+#include "lighting_common.hpp"
+
+namespace sah {
+
+SAH_DEV bool finite_f(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
+
+// LDS table of the fast kernel: [0,512) format LUTs, then the per-cascade rows that are indexed per lane
+enum : uint32_t { TAB_CSM = 512, TAB_LPV = 512 + 48, TAB_SIZE = 512 + 48 + 32 };
+
+// brdf() = Fd() + Fr() (brdf.glsl:65-121 / brdf.slangi:58-114) with the shared sub-expressions written once and the
+// `NoL <= 0 -> 0` early-outs turned into one select (both halves return 0 together, and 0 + 0 == +0).
+template <class T> SAH_DEV V3<T> brdf_sl(const Surface<T>& s, V3<T> l, V3<T> v) {
+    const T one = T::lit(1.0f), zero = T::lit(0.0f);
+    const T dielectric_f0 = T::lit(0.04f);
+    const V3<T> f0 = mix(V3<T>(dielectric_f0), s.base_color, s.metalness);
+    const V3<T> diffuse_color = s.base_color * (one - dielectric_f0) * (one - s.metalness);
+    const V3<T> h = normalize(v + l);
+    T NoV = dot(s.normal, v) + T::lit(1e-5f);
+    T NoL = dot(s.normal, l);
+    const T NoH = nclamp(dot(s.normal, h), zero, one);
+    const T VoH = nclamp(dot(v, h), zero, one);
+    const bool dark = tof(NoL) <= 0.f;
+    NoV = nabs(NoV);
+    NoL = nclamp(NoL, zero, one);
+    const T LoH = nclamp(dot(l, h), zero, one);
+    const V3<T> fd = diffuse_color * Fd_Burley(NoV, NoL, LoH, s.roughness);
+    const T D = D_GGX(NoH, s.roughness);
+    const V3<T> Fv = F_Schlick(VoH, f0, one);
+    const T Vis = V_SmithGGXCorrelated(NoV, NoL, s.roughness);
+    const V3<T> fr = (D * Vis) * Fv;
+    const V3<T> sum = fd + fr;
+    return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
+}
+
+struct FastPixelOut {
+    uint2 lit;
+    bool deferred;
+};
+
+template <int SUN, int GI>
+SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const FastArgs& f, float colx_glsl,
+                                         float rowy_glsl, float colx_slang, float rowy_slang, const Px& p, const float* tab,
+                                         bool lpv_has_nonfinite) {
+    const float* lut = tab;
+    const float D = p.depth;
+    const bool sky_px = D == 0.f;
+    const uint32_t rough_byte = (p.data >> 8) & 0xffu;
+    const SurfIn si = unpack_surface(p, lut);
+    const float dn = (si.normal[0] * si.normal[0] + si.normal[1] * si.normal[1]) + si.normal[2] * si.normal[2];
+    bool ok = finite_f(D) && dn > 0.f && finite_f(dn);
+    if (GI == SAH_GI_LPV) ok = ok && rough_byte != 0u && !lpv_has_nonfinite;
+
+    Hn lit[4] = {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
+
+    // ---------------- fp32 ("GLSL") geometry shared by the CSM sun and the LPV overlay ----------------
+    F3 N, ws, V;
+    Fn vsz;
+    if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) {
+        const Fn inv = Fn(1.0f) / nsqrt(Fn(dn));
+        N = F3{Fn(si.normal[0]) * inv, Fn(si.normal[1]) * inv, Fn(si.normal[2]) * inv};
+        // inverse_projection separable: vs = ((p0*X)+p12, (p5*Y)+p13, (p10*D)+p14, (p11*D)+p15)
+        const Fn vw = Fn(f.p11) * Fn(D) + Fn(f.p15);
+        const Fn vx = Fn(colx_glsl) / vw, vy = Fn(rowy_glsl) / vw;
+        vsz = (Fn(f.p10) * Fn(D) + Fn(f.p14)) / vw;
+        // inverse_view affine: ws_i = ((v0i*x + v1i*y) + v2i*z) + v3i
+        const float* m = a.inv_view;
+        ws.x = Fn(m[0]) * vx + Fn(m[4]) * vy + Fn(m[8]) * vsz + Fn(m[12]);
+        ws.y = Fn(m[1]) * vx + Fn(m[5]) * vy + Fn(m[9]) * vsz + Fn(m[13]);
+        ws.z = Fn(m[2]) * vx + Fn(m[6]) * vy + Fn(m[10]) * vsz + Fn(m[14]);
+        const F3 d = ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])};
+        const Fn d2 = dot(d, d);
+        ok = ok && finite_f(ws.x.v) && finite_f(ws.y.v) && finite_f(ws.z.v) && d2.v > 0.f && finite_f(d2.v);
+        V = d * (Fn(1.0f) / nsqrt(d2));
+    }
+
+    Surface<Fn> s;
+    s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
+    s.normal = N;
+    s.roughness = Fn(si.rough);
+    s.metalness = Fn(si.metal);
+
+    // ---------------- gather set-up (addresses only; the loads are independent of the BRDF arithmetic) ----------------
+    // CSM: cascade, shadow-space position, PCF taps
+    Fn ndotl_sun;
+    uint32_t cascade = 0;
+    bool sp_inside = false;
+    float pcf_ref = 0.f, pcf_fx = 0.f, pcf_fy = 0.f;
+    uint32_t pcf_off[4] = {0u, 0u, 0u, 0u};
+    const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
+    if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
+        ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
+        const uint32_t cc = cascade > 3u ? 3u : cascade;  // cascade 4 means "no shadow map": keep the address legal
+        const Fn bias = Fn(0.0005f) * nsqrt(Fn(1.0f) - ndotl_sun * ndotl_sun) / ndotl_sun;
+        // affine shadow matrix: sp.w == 1, so the perspective divide is the identity; rows come from the LDS table
+        const float4 rx = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u);
+        const float4 ry = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 4u);
+        const float4 rz = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 8u);
+        const Fn spx = Fn(rx.x) * ws.x + Fn(rx.y) * ws.y + Fn(rx.z) * ws.z + Fn(rx.w);
+        const Fn spy = Fn(ry.x) * ws.x + Fn(ry.y) * ws.y + Fn(ry.z) * ws.z + Fn(ry.w);
+        const Fn spz = Fn(rz.x) * ws.x + Fn(rz.y) * ws.y + Fn(rz.z) * ws.z + Fn(rz.w);
+        sp_inside = !(spx.v < 0.f || spy.v < 0.f || spz.v < 0.f || spx.v > 1.f || spy.v > 1.f || spz.v > 1.f);
+        pcf_ref = (spz - bias).v;
+        pcf_ref = pcf_ref < 0.f ? 0.f : (pcf_ref > 1.f ? 1.f : pcf_ref);  // D16: D_ref clamped to [0,1]
+        const VolumeArg& sm = csm.shadowmap;
+        const float px = spx.v * (float)sm.width - 0.5f, py = spy.v * (float)sm.height - 0.5f;
+        const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+        pcf_fx = px - fx0;
+        pcf_fy = py - fy0;
+        const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0);
+        const int wm1 = (int)sm.width - 1, hm1 = (int)sm.height - 1;
+        const uint32_t bpp = 2u;
+        const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * bpp, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * bpp;
+        const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
+        const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
+        pcf_off[0] = lo + ra + xa;
+        pcf_off[1] = lo + ra + xb;
+        pcf_off[2] = lo + rb + xa;
+        pcf_off[3] = lo + rb + xb;
+    }
+    // LPV: cascade selection and the gather coordinate
+    Fn nc[4];
+    float lpv_u = 0.f, lpv_v = 0.f, lpv_w = 0.f;
+    if constexpr (GI == SAH_GI_LPV) {
+        uint32_t selected = 0;
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {
+            if (i < (int)lpv.num_cascades) {
+                const Fn cx = Fn(f.lpv_s[i][0]) * ws.x + Fn(f.lpv_t[i][0]);
+                const Fn cy = Fn(f.lpv_s[i][1]) * ws.y + Fn(f.lpv_t[i][1]);
+                const Fn cz = Fn(f.lpv_s[i][2]) * ws.z + Fn(f.lpv_t[i][2]);
+                const bool in = cx.v > 0.f && cy.v > 0.f && cz.v > 0.f && cx.v < 1.f && cy.v < 1.f && cz.v < 1.f;
+                selected = in ? (uint32_t)i : selected;
+            }
+        }
+        F3 lpv_normal = -N;
+        lpv_normal.x = lpv_normal.x * Fn(-1.0f);
+        dir_to_sh(lpv_normal, nc);
+        // scale+translate cascade: cp_i = (s_i * (ws_i + N_i)) + t_i   (pos.w == 1)
+        const float4 cs = *reinterpret_cast<const float4*>(tab + TAB_LPV + selected * 8u);
+        const float4 ct = *reinterpret_cast<const float4*>(tab + TAB_LPV + selected * 8u + 4u);
+        Fn cpx = Fn(cs.x) * (ws.x + N.x) + Fn(ct.x);
+        const Fn cpy = Fn(cs.y) * (ws.y + N.y) + Fn(ct.y);
+        const Fn cpz = Fn(cs.z) * (ws.z + N.z) + Fn(ct.z);
+        cpx = cpx + Fn((float)selected);
+        cpx = f.ncasc_pow2 ? cpx * Fn(f.inv_ncasc) : cpx / Fn(lpv.num_cascades_f);
+        lpv_u = cpx.v;
+        lpv_v = cpy.v;
+        lpv_w = cpz.v;
+    }
+
+    // ---------------- a1: sun, CSM mode ----------------
+    if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
+        // PCF taps (compare LESS, then filter)
+        float dtap[4];
+        const uint8_t* smp = csm.shadowmap.ptr;
+        {   // the fast path is D16_UNORM only (the reference's format; the host sends anything else to the general kernel)
+            uint16_t raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint16_t*>(smp + pcf_off[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float v = (float)raw[k];
+                const float q = v * csm.d16_recip;  // host-verified 3-flop v / 65535 (see shadow_pcf)
+                dtap[k] = __builtin_fmaf(__builtin_fmaf(-q, 65535.0f, v), csm.d16_recip, q);
+            }
+        }
+        const float wx0 = 1.0f - pcf_fx, wy0 = 1.0f - pcf_fy;
+        float pcf = __builtin_fmaf(wx0 * wy0, (pcf_ref < dtap[0]) ? 1.0f : 0.0f, 0.0f);
+        pcf = __builtin_fmaf(pcf_fx * wy0, (pcf_ref < dtap[1]) ? 1.0f : 0.0f, pcf);
+        pcf = __builtin_fmaf(wx0 * pcf_fy, (pcf_ref < dtap[2]) ? 1.0f : 0.0f, pcf);
+        pcf = __builtin_fmaf(pcf_fx * pcf_fy, (pcf_ref < dtap[3]) ? 1.0f : 0.0f, pcf);
+        // ndotl > 0 ? (cascade > 3 ? 0 : (outside ? 1 : pcf)) : 1
+        float shadow = sp_inside ? pcf : 1.0f;
+        shadow = cascade > 3u ? 0.0f : shadow;
+        shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
+
+        const F3 b = brdf_sl(s, L, V);
+        F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
+        const bool bad = any_nan(direct);
+        direct = {bad ? Fn(0.f) : direct.x, bad ? Fn(0.f) : direct.y, bad ? Fn(0.f) : direct.z};
+        const Fn exposure = Fn(0.00031415927f);
+        const Fn sc[3] = {direct.x * exposure, direct.y * exposure, direct.z * exposure};
+        const bool quirk = (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) != 0;
+        // quirk: dst is the cleared target, s*s + 0*0 == s*s, alpha 1*0 + 0*0 == 0; otherwise plain additive
+#pragma unroll
+        for (int i = 0; i < 3; i++) lit[i] = Hn(quirk ? (sc[i] * sc[i]).v : sc[i].v);
+        lit[3] = quirk ? Hn::lit(0.0f) : Hn::lit(1.0f);
+    }
+
+    // ---------------- a3: LPV overlay ----------------
+    if constexpr (GI == SAH_GI_LPV) {
+        Fn indirect[3];
+        lpv_fetch_fast(lpv, lpv_u, lpv_v, lpv_w, nc, indirect);
+        // Fd(surface, N, N) == diffuse_color * (1/pi) exactly when N is a finite normalised vector, and the specular term
+        // is (finite) * (finite * 0) == +-0 when roughness > 0 and the volumes are finite (DESIGN.md "Fast path proofs").
+        const Fn dielectric_f0 = Fn(0.04f);
+        const F3 diffuse_color = s.base_color * (Fn(1.0f) - dielectric_f0) * (Fn(1.0f) - s.metalness);
+        const Fn inv_pi = (Fn(1.0f) * Fn(1.0f)) * (Fn(1.0f) / Fn(3.1415927f));
+        const F3 diffuse_factor = diffuse_color * inv_pi;
+        const Fn ao = Fn(p.ao);
+        F3 total = {indirect[0] * diffuse_factor.x * ao, indirect[1] * diffuse_factor.y * ao, indirect[2] * diffuse_factor.z * ao};
+        const bool bad = any_nan(total);
+        total = {bad ? Fn(0.f) : total.x, bad ? Fn(0.f) : total.y, bad ? Fn(0.f) : total.z};
+        const Fn exposure = Fn(lpv.exposure);
+        lit[0] = Hn(tof(lit[0]) + (total.x * exposure).v);
+        lit[1] = Hn(tof(lit[1]) + (total.y * exposure).v);
+        lit[2] = Hn(tof(lit[2]) + (total.z * exposure).v);
+        lit[3] = Hn(tof(lit[3]) + 1.0f);
+    }
+
+    // ---------------- a2: emissive (also the only pass that touches depth == 0 pixels when there is no sky) --------------
+    const Fn e = Fn(3.1415927f);
+    const float er = (Fn(lut[p.emission & 0xffu]) * e).v;
+    const float eg = (Fn(lut[(p.emission >> 8) & 0xffu]) * e).v;
+    const float eb = (Fn(lut[(p.emission >> 16) & 0xffu]) * e).v;
+    lit[0] = Hn(tof(lit[0]) + er);
+    lit[1] = Hn(tof(lit[1]) + eg);
+    lit[2] = Hn(tof(lit[2]) + eb);
+    lit[3] = Hn(tof(lit[3]) + 1.0f);
+
+    // ---------------- a1b: sun, RT mode (Slang half flavour) ----------------
+    if constexpr (SUN == SAH_SHADOW_MODE_RT) {
+        Surface<Hn> sh;
+        sh.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
+        sh.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
+        sh.roughness = Hn(si.rough);
+        sh.metalness = Hn(si.metal);
+        const Fn vw = Fn(f.p11) * Fn(D) + Fn(f.p15);
+        const Fn vx = Fn(colx_slang) / vw, vy = Fn(rowy_slang) / vw, vz = (Fn(f.p10) * Fn(D) + Fn(f.p14)) / vw;
+        const Fn vww = vw / vw;  // == 1 for finite non-zero vw; NaN otherwise, which then poisons the location as in the shader
+        const float* m = a.inv_view;
+        F3 loc;
+        loc.x = Fn(m[0]) * vx + Fn(m[4]) * vy + Fn(m[8]) * vz + Fn(m[12]) * vww;
+        loc.y = Fn(m[1]) * vx + Fn(m[5]) * vy + Fn(m[9]) * vz + Fn(m[13]) * vww;
+        loc.z = Fn(m[2]) * vx + Fn(m[6]) * vy + Fn(m[10]) * vz + Fn(m[14]) * vww;
+        const Hn ndotl = Hn(nclamp(dot(L, to_f(sh.normal)), Fn(0.f), Fn(1.f)).v);
+        const H3 Vh = to_h(normalize(loc - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+        const H3 Lh = to_h(L);
+        const H3 b = brdf_sl(sh, Lh, Vh);
+        const H3 nb = ndotl * b;
+        F3 radiance = to_f(nb) * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])};
+        const F3 masked = radiance * Fn(p.mask);
+        const bool lit_side = tof(ndotl) > 0.f;
+        radiance = {lit_side ? masked.x : radiance.x, lit_side ? masked.y : radiance.y, lit_side ? masked.z : radiance.z};
+        const Fn exposure = Fn(0.00031415927f);
+        lit[0] = Hn(tof(lit[0]) + (radiance.x * exposure).v);
+        lit[1] = Hn(tof(lit[1]) + (radiance.y * exposure).v);
+        lit[2] = Hn(tof(lit[2]) + (radiance.z * exposure).v);
+    }
+
+    FastPixelOut o;
+    // depth == 0: only the emissive term exists (sky pixels are shaded by the fix-up kernel when a sky is bound)
+    Hn sky_lit[4] = {Hn(er), Hn(eg), Hn(eb), Hn::lit(1.0f)};
+    const uint2 surf = pack_lit(lit), bare = pack_lit(sky_lit);
+    o.lit.x = sky_px ? bare.x : surf.x;
+    o.lit.y = sky_px ? bare.y : surf.y;
+    o.deferred = sky_px ? (f.sky_enabled != 0u) : !ok;
+    return o;
+}
+
+}  // namespace sah

@@ -43,6 +43,8 @@ struct RtgiArgs {
 struct CsmArgs {
     VolumeArg shadowmap;
     uint32_t is_d16;
+    uint32_t d16_recip_ok;  // host verified: the 3-flop reciprocal sequence equals v / 65535 for every 16-bit v
+    float d16_recip;        // RN(1 / 65535)
     float splits[4];
     float biased[4][16];  // biasMat * cascade_matrices[i]
 };
@@ -62,6 +64,28 @@ struct SkyArgs {
     float tlut_rgb[3];      // getValFromTLUT(viewPos, sunDir): uniform over the frame
     float smooth_e0;        // 0.002h as float
     uint32_t enabled;
+};
+
+// Per-context device state shared by consecutive Lighting calls (double-buffered by call parity so that no memset
+// is needed between calls: the fix-up kernel of call k zeroes the slots call k+1 will use).
+struct FrameState {
+    uint32_t count[2];      // number of deferred pixels in `list`
+    uint32_t nonfinite[2];  // != 0 when an LPV volume holds an inf/NaN texel
+};
+
+// What the fast kernel may assume, established by the host (api.cpp: detect_fast_path):
+//   inverse_projection separable:  vs = ((p0*X)+p12, (p5*Y)+p13, (p10*D)+p14, (p11*D)+p15)
+//   inverse_view affine (row 3 = 0,0,0,1), LPV world_to_cascade = scale + translate, CSM matrices affine.
+struct FastArgs {
+    float p0, p12, p5, p13, p10, p14, p11, p15;
+    float lpv_s[4][3], lpv_t[4][3];
+    float inv_ncasc;
+    uint32_t ncasc_pow2;
+    uint32_t sky_enabled;
+    uint32_t parity;
+    uint32_t fixup_blocks;
+    FrameState* state;
+    uint32_t* list;  // deferred pixel indices (y * width + x), capacity width * height
 };
 
 struct LightingArgs {

@@ -45,12 +45,16 @@ template <int MODE> SAH_DEV Rgba bilinear(const PlaneArg& p, uint32_t W, uint32_
     const int xa = wrap<MODE>(x0, (int)W), xb = wrap<MODE>(x0 + 1, (int)W);
     const int ya = wrap<MODE>(y0, (int)H), yb = wrap<MODE>(y0 + 1, (int)H);
     const Rgba t00 = load_rgba16f(p, xa, ya), t10 = load_rgba16f(p, xb, ya), t01 = load_rgba16f(p, xa, yb), t11 = load_rgba16f(p, xb, yb);
+    // Vulkan weighted-sum formula, fma chain in tap order (DESIGN.md "Sampling")
+    const float w00 = wx0 * wy0, w10 = fx * wy0, w01 = wx0 * fy, w11 = fx * fy;
     Rgba r;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float a = t00.c[i] * wx0 + t10.c[i] * fx;
-        const float b = t01.c[i] * wx0 + t11.c[i] * fx;
-        r.c[i] = a * wy0 + b * fy;
+        float a = __builtin_fmaf(w00, t00.c[i], 0.0f);
+        a = __builtin_fmaf(w10, t10.c[i], a);
+        a = __builtin_fmaf(w01, t01.c[i], a);
+        a = __builtin_fmaf(w11, t11.c[i], a);
+        r.c[i] = a;
     }
     return r;
 }

@@ -52,6 +52,7 @@ def load():
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
     lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32]
+    lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
 
@@ -79,6 +80,10 @@ class Context:
 
     def set_stream(self, hip_stream_handle):
         self._check(self.lib.sah_set_stream(self.handle, C.c_void_p(hip_stream_handle)))
+
+    def debug_set(self, force_general=False, force_ppt=0):
+        """Testing hook: run the general kernel instead of the fast one / force pixels-per-thread."""
+        self._check(self.lib.sah_debug_set(self.handle, int(force_general), int(force_ppt)))
 
     def sync(self):
         self._check(self.lib.sah_sync(self.handle))

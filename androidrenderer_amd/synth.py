@@ -55,89 +55,93 @@ def random_gbuffer(width, height, seed=1, sky_fraction=0.10, z_near=0.05):
     }
 
 
-def _ray_box(o, d, bmin, bmax):
-    """Slab test; returns (t_hit or inf, face normal)."""
-    with np.errstate(divide="ignore", invalid="ignore"):
-        inv = 1.0 / d
-        t0 = (bmin - o) * inv
-        t1 = (bmax - o) * inv
-    tn = np.minimum(t0, t1)
-    tf = np.maximum(t0, t1)
-    tnear = tn.max(axis=-1)
-    tfar = tf.min(axis=-1)
-    hit = (tnear <= tfar) & (tnear > 1e-3)
-    axis = tn.argmax(axis=-1)
-    nrm = np.zeros(d.shape, dtype=np.float32)
-    sign = -np.sign(np.take_along_axis(d, axis[..., None], axis=-1))[..., 0]
-    np.put_along_axis(nrm, axis[..., None], sign[..., None], axis=-1)
-    return np.where(hit, tnear, np.inf), nrm
+_ATRIUM_BOXES = None
 
 
-def atrium_gbuffer(width, height, view, seed=2):
-    """Procedural atrium seen from `view` (a scene.SceneView): floor y=0, long walls z=+-4.5, end walls x=+-14,
-    open roof above y=11 (sky), two rows of 0.7 m box columns at z=+-2.6 every 3.5 m, a gallery slab at y=5.
-    Materials vary per surface with low-amplitude per-pixel noise; ~1 % of pixels (lamp boxes) are emissive."""
+def _atrium_boxes():
+    """(min, max, material) of every box in the atrium: floor y=0, long walls z=+-4.5, end walls x=+-14, open roof above
+    y=11 (sky), gallery slabs at y=5, two rows of 0.7 m columns at z=+-2.6 every 3.5 m, small emissive lamp boxes."""
+    global _ATRIUM_BOXES
+    if _ATRIUM_BOXES is None:
+        boxes = [((-14.5, -1.0, -5.0), (14.5, 0.0, 5.0), 0), ((-14.5, 0.0, 4.5), (14.5, 11.0, 5.5), 1),
+                 ((-14.5, 0.0, -5.5), (14.5, 11.0, -4.5), 1), ((14.0, 0.0, -5.0), (15.0, 11.0, 5.0), 2),
+                 ((-15.0, 0.0, -5.0), (-14.0, 11.0, 5.0), 2), ((-14.0, 5.0, 2.95), (14.0, 5.3, 4.5), 3),
+                 ((-14.0, 5.0, -4.5), (14.0, 5.3, -2.95), 3)]
+        for i in range(8):
+            cx = -12.25 + 3.5 * i
+            for cz in (-2.6, 2.6):
+                boxes.append(((cx - 0.35, 0.0, cz - 0.35), (cx + 0.35, 5.0, cz + 0.35), 4))
+            boxes.append(((cx - 0.15, 3.2, -4.5), (cx + 0.15, 3.5, -4.3), 5))
+        _ATRIUM_BOXES = boxes
+    return _ATRIUM_BOXES
+
+
+def atrium_gbuffer(width, height, view, seed=2, device="cpu"):
+    """Procedural Sponza-like atrium seen from `view` (a scene.SceneView), ray-cast analytically with torch on `device`
+    (the arithmetic is a few hundred ops per pixel, so 4K takes well under a second on the GPU). Materials vary per
+    surface with low-amplitude per-pixel noise (numpy Philox, so the noise is device independent); the lamp boxes are
+    emissive. Returns numpy arrays in the reference's storage formats."""
+    import torch
     g = rng(seed)
     H, W = height, width
-    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
-    ndc_x = (xs + 0.5) / np.float32(W) * 2.0 - 1.0
-    ndc_y = (ys + 0.5) / np.float32(H) * 2.0 - 1.0
+    dev = torch.device(device)
+    f32 = torch.float32
+    ys = (torch.arange(H, dtype=f32, device=dev) + 0.5) / H * 2.0 - 1.0
+    xs = (torch.arange(W, dtype=f32, device=dev) + 0.5) / W * 2.0 - 1.0
     proj = np.array(view.gpu_data.projection[:], dtype=np.float32).reshape(4, 4)  # [col,row]
     inv_view = np.array(view.gpu_data.inverse_view[:], dtype=np.float32).reshape(4, 4)
-    dv = np.stack([ndc_x / proj[0, 0], ndc_y / proj[1, 1], -np.ones_like(ndc_x)], axis=-1)  # view space, z_view = -t
-    rot = inv_view[:3, :3]  # columns of the rotation
-    d = (dv[..., 0:1] * rot[0] + dv[..., 1:2] * rot[1] + dv[..., 2:3] * rot[2]).astype(np.float32)
-    o = inv_view[3, :3].astype(np.float32)
-    o = np.broadcast_to(o, d.shape)
-
-    boxes = []  # (min, max, material id)
-    boxes.append(((-14.5, -1.0, -5.0), (14.5, 0.0, 5.0), 0))     # floor
-    boxes.append(((-14.5, 0.0, 4.5), (14.5, 11.0, 5.5), 1))      # wall +z
-    boxes.append(((-14.5, 0.0, -5.5), (14.5, 11.0, -4.5), 1))    # wall -z
-    boxes.append(((14.0, 0.0, -5.0), (15.0, 11.0, 5.0), 2))      # end wall +x
-    boxes.append(((-15.0, 0.0, -5.0), (-14.0, 11.0, 5.0), 2))    # end wall -x
-    boxes.append(((-14.0, 5.0, 2.95), (14.0, 5.3, 4.5), 3))      # gallery slabs
-    boxes.append(((-14.0, 5.0, -4.5), (14.0, 5.3, -2.95), 3))
-    for i in range(8):
-        cx = -12.25 + 3.5 * i
-        for cz in (-2.6, 2.6):
-            boxes.append(((cx - 0.35, 0.0, cz - 0.35), (cx + 0.35, 5.0, cz + 0.35), 4))   # columns
-        boxes.append(((cx - 0.15, 3.2, -4.5), (cx + 0.15, 3.5, -4.3), 5))                 # lamps (emissive)
-    t_best = np.full((H, W), np.inf, dtype=np.float32)
-    n_best = np.zeros((H, W, 3), dtype=np.float32)
-    m_best = np.full((H, W), -1, dtype=np.int32)
-    for bmin, bmax, mat in boxes:
-        t, nrm = _ray_box(o, d, np.array(bmin, dtype=np.float32), np.array(bmax, dtype=np.float32))
-        closer = t < t_best
-        t_best = np.where(closer, t, t_best)
-        n_best = np.where(closer[..., None], nrm, n_best)
-        m_best = np.where(closer, mat, m_best)
-    hit = np.isfinite(t_best)
-    depth = np.where(hit, np.float32(view.near_value) / np.where(hit, t_best, 1.0), 0.0).astype(np.float32)
-
-    pos = o + d * np.where(hit, t_best, 0.0)[..., None]
-    base_lin = np.array([[0.45, 0.40, 0.33], [0.60, 0.52, 0.42], [0.50, 0.30, 0.22], [0.55, 0.55, 0.50], [0.62, 0.58, 0.50],
-                         [0.9, 0.8, 0.6]], dtype=np.float32)
-    rough = np.array([0.65, 0.8, 0.7, 0.5, 0.4, 0.3], dtype=np.float32)
-    metal = np.array([0.0, 0.0, 0.0, 0.1, 0.0, 0.9], dtype=np.float32)
-    mi = np.clip(m_best, 0, 5)
-    checker = ((np.floor(pos[..., 0] * 2.0) + np.floor(pos[..., 1] * 2.0) + np.floor(pos[..., 2] * 2.0)) % 2).astype(np.float32)
-    col = base_lin[mi] * (0.8 + 0.2 * checker)[..., None] + g.uniform(-0.02, 0.02, (H, W, 3)).astype(np.float32)
-    color = np.zeros((H, W, 4), dtype=np.uint8)
-    color[..., :3] = _srgb_encode_u8(col)
+    dvx = (xs / float(proj[0, 0])).view(1, W).expand(H, W)
+    dvy = (ys / float(proj[1, 1])).view(H, 1).expand(H, W)
+    rot = torch.tensor(inv_view[:3, :3], device=dev)  # rows = rotation columns
+    d = dvx.unsqueeze(-1) * rot[0] + dvy.unsqueeze(-1) * rot[1] - rot[2]  # view-space ray (x, y, -1): z_view = -t
+    o = torch.tensor(inv_view[3, :3], device=dev)
+    inv = 1.0 / d
+    t_best = torch.full((H, W), float("inf"), dtype=f32, device=dev)
+    axis_best = torch.zeros((H, W), dtype=torch.int64, device=dev)
+    m_best = torch.full((H, W), -1, dtype=torch.int64, device=dev)
+    for bmin, bmax, mat in _atrium_boxes():
+        t0 = (torch.tensor(bmin, device=dev) - o) * inv
+        t1 = (torch.tensor(bmax, device=dev) - o) * inv
+        tn = torch.minimum(t0, t1)
+        tf = torch.maximum(t0, t1)
+        tnear, axis = tn.max(dim=-1)
+        tfar = tf.min(dim=-1).values
+        closer = (tnear <= tfar) & (tnear > 1e-3) & (tnear < t_best)
+        t_best = torch.where(closer, tnear, t_best)
+        axis_best = torch.where(closer, axis, axis_best)
+        m_best = torch.where(closer, torch.full_like(m_best, mat), m_best)
+    hit = torch.isfinite(t_best)
+    t_hit = torch.where(hit, t_best, torch.ones_like(t_best))
+    depth = torch.where(hit, float(view.near_value) / t_hit, torch.zeros_like(t_best))
+    nrm = torch.zeros((H, W, 3), dtype=f32, device=dev)
+    nrm.scatter_(-1, axis_best.unsqueeze(-1), -torch.sign(torch.gather(d, -1, axis_best.unsqueeze(-1))))
+    pos = o + d * torch.where(hit, t_best, torch.zeros_like(t_best)).unsqueeze(-1)
+    base_lin = torch.tensor([[0.45, 0.40, 0.33], [0.60, 0.52, 0.42], [0.50, 0.30, 0.22], [0.55, 0.55, 0.50], [0.62, 0.58, 0.50],
+                             [0.9, 0.8, 0.6]], dtype=f32, device=dev)
+    rough = torch.tensor([0.65, 0.8, 0.7, 0.5, 0.4, 0.3], dtype=f32, device=dev)
+    metal = torch.tensor([0.0, 0.0, 0.0, 0.1, 0.0, 0.9], dtype=f32, device=dev)
+    mi = m_best.clamp(0, 5)
+    checker = torch.floor(pos * 2.0).sum(dim=-1).remainder(2.0)
+    noise = torch.from_numpy(g.uniform(-1.0, 1.0, (H, W, 7)).astype(np.float32)).to(dev)
+    col = base_lin[mi] * (0.8 + 0.2 * checker).unsqueeze(-1) + 0.02 * noise[..., 0:3]
+    col = col.clamp(0.0, 1.0)
+    srgb = torch.where(col <= 0.0031308, col * 12.92, 1.055 * col.clamp_min(1e-12).pow(1.0 / 2.4) - 0.055)
+    color = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    color[..., :3] = torch.round(srgb * 255.0).clamp(0, 255).to(torch.uint8)
     color[..., 3] = 255
-    data = np.zeros((H, W, 4), dtype=np.uint8)
-    data[..., 1] = np.clip(np.rint((rough[mi] + g.uniform(-0.03, 0.03, (H, W))) * 255.0), 1, 255).astype(np.uint8)
-    data[..., 2] = np.clip(np.rint(metal[mi] * 255.0), 0, 255).astype(np.uint8)
-    nrm = n_best + g.uniform(-0.04, 0.04, (H, W, 3)).astype(np.float32)
-    normals = np.zeros((H, W, 4), dtype=np.float16)
-    normals[..., :3] = nrm.astype(np.float16)
-    emission = np.zeros((H, W, 4), dtype=np.uint8)
-    lamp = (m_best == 5)
-    emission[lamp, 0], emission[lamp, 1], emission[lamp, 2] = 255, 214, 170
+    data = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    data[..., 1] = torch.round((rough[mi] + 0.03 * noise[..., 3]) * 255.0).clamp(1, 255).to(torch.uint8)
+    data[..., 2] = torch.round(metal[mi] * 255.0).clamp(0, 255).to(torch.uint8)
+    normals = torch.zeros((H, W, 4), dtype=torch.float16, device=dev)
+    normals[..., :3] = (nrm + 0.04 * noise[..., 4:7]).to(torch.float16)
+    emission = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    lamp = m_best == 5
+    emission[lamp] = torch.tensor([255, 214, 170, 0], dtype=torch.uint8, device=dev)
+    miss = ~hit
     for a in (color, data, normals, emission):
-        a[~hit] = 0
-    return {"color": color, "normals": normals, "data": data, "emission": emission, "depth": depth}
+        a[miss] = 0
+    return {"color": color.cpu().numpy(), "normals": normals.cpu().numpy(), "data": data.cpu().numpy(),
+            "emission": emission.cpu().numpy(), "depth": depth.cpu().numpy()}
 
 
 def ao_plane(width, height, seed=3):

@@ -93,24 +93,35 @@ static inline Texel load_texel_addr(const Image& im, int x, int y, int z, Addres
     return load_texel(im, x, y, z);
 }
 
-// Bilinear sample of layer `layer` at normalised (u, v).
-//   result = (t00*(1-fx) + t10*fx)*(1-fy) + (t01*(1-fx) + t11*fx)*fy   — every operator rounded to fp32.
+// Linear filtering follows the Vulkan spec's weighted-sum formula (Vulkan 1.4 "Texel Filtering"):
+//   tau_2D = (1-a)(1-b) t_ij + a(1-b) t_i1j + (1-a) b t_ij1 + a b t_i1j1
+//   tau_3D = the same with (1-g) / g on the third axis, taps ordered x fastest, then y, then z.
+// Weights are fp32 products formed left to right; the sum is an fma chain in the listed tap order starting from
+// +0.0f (acc = fma(w_k, t_k, acc)).  DESIGN.md "Sampling".
 static inline Texel sample_bilinear(const Image& im, float u, float v, int layer, AddressMode mode) {
     float px = u * (float)im.width - 0.5f;
     float py = v * (float)im.height - 0.5f;
+    Texel r;
+    if (std::isnan(px) || std::isnan(py)) {
+        for (int i = 0; i < 4; i++) r.c[i] = NAN;
+        return r;
+    }
     float fx0 = std::floor(px), fy0 = std::floor(py);
     float fx = px - fx0, fy = py - fy0;
-    int x0 = (int)fx0, y0 = (int)fy0;
+    auto toi = [](float f) { return f < -1e9f ? -1000000000 : (f > 1e9f ? 1000000000 : (int)f); };
+    int x0 = toi(fx0), y0 = toi(fy0);
     Texel t00 = load_texel_addr(im, x0, y0, layer, mode, false);
     Texel t10 = load_texel_addr(im, x0 + 1, y0, layer, mode, false);
     Texel t01 = load_texel_addr(im, x0, y0 + 1, layer, mode, false);
     Texel t11 = load_texel_addr(im, x0 + 1, y0 + 1, layer, mode, false);
     float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    Texel r;
+    float w00 = wx0 * wy0, w10 = fx * wy0, w01 = wx0 * fy, w11 = fx * fy;
     for (int i = 0; i < 4; i++) {
-        float a = t00.c[i] * wx0 + t10.c[i] * fx;
-        float b = t01.c[i] * wx0 + t11.c[i] * fx;
-        r.c[i] = a * wy0 + b * fy;
+        float a = std::fmaf(w00, t00.c[i], 0.0f);
+        a = std::fmaf(w10, t10.c[i], a);
+        a = std::fmaf(w01, t01.c[i], a);
+        a = std::fmaf(w11, t11.c[i], a);
+        r.c[i] = a;
     }
     return r;
 }
@@ -134,14 +145,13 @@ static inline Texel sample_trilinear(const Image& im, float u, float v, float w,
     auto toi = [](float f) { return f < -1e9f ? -1000000000 : (f > 1e9f ? 1000000000 : (int)f); };
     int x0 = toi(fx0), y0 = toi(fy0), z0 = toi(fz0);
     for (int k = 0; k < 8; k++) t[k] = load_texel_addr(im, x0 + (k & 1), y0 + ((k >> 1) & 1), z0 + (k >> 2), mode, true);
+    const float wxy[4] = {wx0 * wy0, fx * wy0, wx0 * fy, fx * fy};
+    float wt[8];
+    for (int k = 0; k < 8; k++) wt[k] = wxy[k & 3] * ((k >> 2) ? fz : wz0);
     for (int i = 0; i < 4; i++) {
-        float a0 = t[0].c[i] * wx0 + t[1].c[i] * fx;
-        float b0 = t[2].c[i] * wx0 + t[3].c[i] * fx;
-        float a1 = t[4].c[i] * wx0 + t[5].c[i] * fx;
-        float b1 = t[6].c[i] * wx0 + t[7].c[i] * fx;
-        float c0 = a0 * wy0 + b0 * fy;
-        float c1 = a1 * wy0 + b1 * fy;
-        r.c[i] = c0 * wz0 + c1 * fz;
+        float a = 0.0f;
+        for (int k = 0; k < 8; k++) a = std::fmaf(wt[k], t[k].c[i], a);
+        r.c[i] = a;
     }
     return r;
 }
@@ -159,9 +169,11 @@ static inline float sample_shadow_pcf(const Image& im, float u, float v, int lay
         c[k] = (ref < t.c[0]) ? 1.0f : 0.0f;
     }
     float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    float a = c[0] * wx0 + c[1] * fx;
-    float b = c[2] * wx0 + c[3] * fx;
-    return a * wy0 + b * fy;
+    float a = std::fmaf(wx0 * wy0, c[0], 0.0f);
+    a = std::fmaf(fx * wy0, c[1], a);
+    a = std::fmaf(wx0 * fy, c[2], a);
+    a = std::fmaf(fx * fy, c[3], a);
+    return a;
 }
 
 }  // namespace orc

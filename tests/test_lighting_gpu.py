@@ -12,12 +12,19 @@ MAX_ULP = 1  # tolerance stated by BASELINE.json north_star: within 1 ULP per ch
 
 
 def _check(frame, hip_ctx, name):
+    """Both device paths (fast kernel + fix-up, and the general kernel) against the oracle, and against each other."""
     ref = frame.run_oracle()
-    got = frame.run_hip(hip_ctx)
-    d = util.f16_ulp_diff(got, ref)
-    print(util.report_ulp(name, d))
-    assert d.max() <= MAX_ULP, util.report_ulp(name, d)
-    return d
+    dev = frame.device_arrays()
+    outs = {}
+    for path, general in (("fast", False), ("general", True)):
+        hip_ctx.debug_set(force_general=general)
+        got = frame.run_hip(hip_ctx, dev)
+        outs[path] = got
+        d = util.f16_ulp_diff(got, ref)
+        print(util.report_ulp(f"{name} [{path}]", d))
+        assert d.max() <= MAX_ULP, util.report_ulp(f"{name} [{path}]", d)
+    hip_ctx.debug_set(force_general=False)
+    assert np.array_equal(outs["fast"], outs["general"]), "fast and general kernels disagree"
 
 
 @pytest.mark.parametrize("sun_mode", [_abi.SHADOW_MODE_OFF, _abi.SHADOW_MODE_CSM, _abi.SHADOW_MODE_RT])
@@ -52,3 +59,57 @@ def test_row_shard_equals_full(hip_ctx):
         hip_ctx.lighting(d)
     torch.cuda.synchronize()
     assert np.array_equal(util.from_torch(lit, np.uint16), full)
+
+
+def _poison(g, rng):
+    """Adversarial texels: zero / huge / inf / NaN normals, roughness 0, denormal / inf / NaN / negative depth."""
+    h, w = g["depth"].shape
+    n = g["normals"].view(np.uint16)
+    d = g["depth"].view(np.uint32)
+    for k, (nb, db) in enumerate([((0, 0, 0), None), ((0x7BFF, 0x7BFF, 0x7BFF), None), ((0x7C00, 0x3C00, 0), None),
+                                  ((0x7E00, 0x3C00, 0x3C00), None), (None, 0x00000001), (None, 0x7F800000), (None, 0x7FC00000),
+                                  (None, 0xBF000000), ((0x0001, 0, 0), None), (None, 0x00800000), ((0x8000, 0x8000, 0x3C00), 0x3F7FFFFF)]):
+        ys, xs = rng.integers(0, h, 40), rng.integers(0, w, 40)
+        if nb is not None:
+            for c in range(3):
+                n[ys, xs, c] = nb[c]
+        if db is not None:
+            d[ys, xs] = db
+    ys, xs = rng.integers(0, h, 300), rng.integers(0, w, 300)
+    g["data"][ys, xs, 1] = 0  # roughness 0: the NaN-producing corner of D_GGX
+    ys, xs = rng.integers(0, h, 100), rng.integers(0, w, 100)
+    g["data"][ys, xs, 1] = 0
+    g["normals"][ys, xs, :3] = g["normals"][ys, xs, :3]  # keep
+
+
+@pytest.mark.parametrize("sun_mode", [_abi.SHADOW_MODE_CSM, _abi.SHADOW_MODE_RT])
+@pytest.mark.parametrize("gi", [_abi.GI_NONE, _abi.GI_LPV])
+def test_lighting_adversarial_inputs(hip_ctx, sun_mode, gi):
+    from androidrenderer_amd import synth
+    g = synth.random_gbuffer(192, 96, seed=77)
+    _poison(g, np.random.default_rng(5))
+    f = util.LightingFrame(192, 96, gbuffer=g, seed=78, sun_mode=sun_mode, gi=gi)
+    f.arrays["ao"][3, 5] = np.nan
+    f.arrays["ao"][7, 9] = np.inf
+    _check(f, hip_ctx, f"adversarial sun={sun_mode} gi={gi}")
+
+
+def test_lighting_nonfinite_lpv_volume(hip_ctx):
+    """An inf / NaN texel in an LPV volume disables the 'specular quirk is inert' shortcut for the whole frame."""
+    f = util.LightingFrame(160, 90, seed=31, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    v = f.arrays["lpv_g"].view(np.uint16)
+    v[5, 7, 9, 1] = 0x7C00
+    v[20, 11, 40, 2] = 0x7E00
+    _check(f, hip_ctx, "lpv with inf/nan texels")
+    f2 = util.LightingFrame(160, 90, seed=31, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    _check(f2, hip_ctx, "lpv finite again (state flag re-armed)")
+
+
+def test_lighting_no_quirk_flag(hip_ctx):
+    f = util.LightingFrame(128, 72, seed=13, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flags=0)
+    _check(f, hip_ctx, "additive sun blend (quirk off)")
+
+
+def test_lighting_no_sky(hip_ctx):
+    f = util.LightingFrame(128, 72, seed=14, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_NONE, sky=False)
+    _check(f, hip_ctx, "no sky")

@@ -1,0 +1,18 @@
+"""Summarise rocprofv3 --pmc CSV output per kernel: usage pmc_summary.py <dir> [kernel-substring]"""
+import collections
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if flt in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in acc.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print(f"   {c:28s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
