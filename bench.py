@@ -95,7 +95,12 @@ def main():
         return torch.from_numpy(a).to(dev)
 
     d_arr = {k: up(v) for k, v in host.items()}
-    lit = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+    # row shard of this rank: ceil(H / world) rows per gather slot, clipped to the image (tests/test_dist_cpu.py)
+    rows_per = -(-H // world)
+    r0 = min(rank * rows_per, H)
+    r1 = min(r0 + rows_per, H)
+    lit_full = torch.zeros((rows_per * world, W, 4), dtype=torch.int16, device=dev)  # equal slots for the all-gather
+    lit = lit_full[:H]
 
     gb = images.gbuffer(d_arr)
     lit_p = images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)
@@ -122,27 +127,20 @@ def main():
     desc.sky = C.pointer(sky)
     desc.gi = C.pointer(gi)
     desc.flags = _abi.LIGHTING_DEFAULT_FLAGS
-    # row shard of this rank: contiguous blocks, last rank takes the remainder
-    rows_per = H // world
-    r0 = rank * rows_per
-    r1 = H if rank == world - 1 else r0 + rows_per
     desc.row_begin, desc.row_end = (r0, r1) if world > 1 else (0, 0)
 
     ctx = lib.Context(device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     gather = world > 1 and not args.no_gather
-    even = (H % world == 0)
-    lit_flat = lit.view(-1)
-    shard_elems = rows_per * W * 4
+    lit_bytes = lit_full.view(torch.uint8).view(-1)  # RCCL has no int16: the rows travel as bytes
+    shard_bytes = rows_per * W * 8
+    my_slot = lit_bytes[rank * shard_bytes:(rank + 1) * shard_bytes]
 
     def step():
-        ctx.lighting(desc)
+        if r1 > r0:
+            ctx.lighting(desc)
         if gather:
-            if even:
-                dist.all_gather_into_tensor(lit_flat, lit_flat[rank * shard_elems:(rank + 1) * shard_elems])
-            else:
-                parts = [lit[i * rows_per:(H if i == world - 1 else (i + 1) * rows_per)] for i in range(world)]
-                dist.all_gather(parts, parts[rank])
+            dist.all_gather_into_tensor(lit_bytes, my_slot)  # in place: the input is this rank's slot of the output
 
     for _ in range(args.warmup):
         step()
@@ -154,14 +152,11 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        ctx.lighting(desc)
+        if r1 > r0:
+            ctx.lighting(desc)
         ev[i][1].record()
         if gather:
-            if even:
-                dist.all_gather_into_tensor(lit_flat, lit_flat[rank * shard_elems:(rank + 1) * shard_elems])
-            else:
-                parts = [lit[j * rows_per:(H if j == world - 1 else (j + 1) * rows_per)] for j in range(world)]
-                dist.all_gather(parts, parts[rank])
+            dist.all_gather_into_tensor(lit_bytes, my_slot)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1,0 +1,68 @@
+"""CPU-only, world_size 2 over gloo: the N>1 path of bench.py — contiguous row shards, each rank shades its rows, an
+all-gather re-assembles the frame on every rank — must equal the unsharded frame bit for bit.
+The per-rank compute stand-in is the oracle (there is no GPU here); the shard arithmetic and the gather are the code under
+test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def shard_rows(height, world, rank):
+    """Row block of `rank`: ceil(height / world) rows each, clipped to the image (same rule as bench.py): equal-sized
+    gather slots, the last ones possibly short or empty."""
+    per = -(-height // world)
+    r0 = min(rank * per, height)
+    return r0, min(r0 + per, height)
+
+
+def _worker(rank, world, port, height, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from androidrenderer_amd import _abi
+    from tests import util
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = util.LightingFrame(64, height, seed=17, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    r0, r1 = shard_rows(height, world, rank)
+    f.row_begin, f.row_end = r0, r1
+    per = -(-height // world)
+    shaded = f.run_oracle().view(np.uint8)  # bytes, as the gather moves them; only rows [r0, r1) are written
+    padded = torch.zeros((per * world,) + shaded.shape[1:], dtype=torch.uint8)  # equal slots; the tail slot may be short
+    padded[r0:r1] = torch.from_numpy(shaded[r0:r1])
+    parts = [padded[i * per:(i + 1) * per] for i in range(world)]
+    dist.all_gather(parts, parts[rank].clone())
+    full = padded[:height].numpy().view(np.uint16)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [36, 37])  # even split and a remainder row
+def test_row_shards_allgather_equals_unsharded(tmp_path, height):
+    import torch.multiprocessing as mp
+    from androidrenderer_amd import _abi
+    from tests import util
+
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + height
+    mp.spawn(_worker, args=(world, port, height, str(tmp_path)), nprocs=world, join=True)
+    ref = util.LightingFrame(64, height, seed=17, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium").run_oracle()
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert np.array_equal(got, ref), f"rank {r}: gathered frame differs from the unsharded frame"
+
+
+def test_shard_rows_partition():
+    for h in (1, 7, 270, 2160, 2161):
+        for w in (1, 2, 4, 8):
+            rows = [shard_rows(h, w, r) for r in range(w)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            assert all(0 <= b - a <= -(-h // w) for a, b in rows)

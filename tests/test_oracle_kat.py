@@ -1,0 +1,192 @@
+"""CPU-only known-answer tests that pin the oracle's building blocks (SURVEY.md §8-c fixtures (i) and (iii)):
+format codecs, sampler emulation, BRDF points computed by hand, and the reference's quirks. The reference ships no
+golden vectors (parity unpinned), so these are analytic: every expected value below is derived from the format /
+shader definitions, not from running the oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images
+from tests import util
+
+
+# ---- codecs ------------------------------------------------------------------------------------------
+def test_f16_codec_matches_numpy_for_every_bit_pattern(oracle):
+    bits = np.arange(65536, dtype=np.uint16)
+    ref = bits.view(np.float16).astype(np.float32)
+    for b in list(range(0, 65536, 257)) + [0, 1, 0x3FF, 0x400, 0x7BFF, 0x7C00, 0x8000, 0xFBFF, 0xFC00]:
+        got = oracle.orc_f16_to_f32(b)
+        assert (math.isnan(got) and math.isnan(ref[b])) or got == ref[b]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 20000),
+                         np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e-8, 5.9604645e-08, 2.9802322e-08, 2.98023224e-08 * 1.0001,
+                                   6.1035156e-05, 6.0975552e-05, np.inf, -np.inf], dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        ref = xs.astype(np.float16).view(np.uint16)
+    got = np.array([oracle.orc_f32_to_f16(float(x)) for x in xs], dtype=np.uint16)
+    assert np.array_equal(got, ref)  # round-to-nearest-even, overflow to inf, denormals kept
+
+
+def test_srgb_table_endpoints_and_monotone(oracle):
+    v = [oracle.orc_srgb8_to_linear(i) for i in range(256)]
+    assert v[0] == 0.0 and v[255] == 1.0
+    assert all(b > a for a, b in zip(v, v[1:]))
+    # below the 0.04045 knee the curve is c / 12.92
+    assert v[10] == np.float32((10 / 255.0) / 12.92)
+    assert v[128] == np.float32(((128 / 255.0 + 0.055) / 1.055) ** 2.4)
+    # round trip through the OETF reproduces every code
+    assert [oracle.orc_linear_to_srgb8(x) for x in v] == list(range(256))
+
+
+def test_r11g11b10_decode_known_words(oracle):
+    out = (C.c_float * 3)()
+    # 1.0 = exponent 15, mantissa 0 in all three fields
+    one = (15 << 6) | ((15 << 6) << 11) | ((15 << 5) << 22)
+    oracle.orc_r11g11b10_decode(one, out)
+    assert list(out) == [1.0, 1.0, 1.0]
+    # R = 1.5 (mantissa 0b100000), G = 2^-14 * (1/64) denormal, B = 0.5
+    w = ((15 << 6) | 32) | ((1) << 11) | ((14 << 5) << 22)
+    oracle.orc_r11g11b10_decode(w, out)
+    assert list(out) == [1.5, 2.0 ** -20, 0.5]
+    # encode truncates (round toward zero) and clamps negatives
+    arr = (C.c_float * 3)(1.99, -3.0, 0.7)
+    e = oracle.orc_r11g11b10_encode(arr)
+    oracle.orc_r11g11b10_decode(e, out)
+    assert out[0] == 1.984375 and out[1] == 0.0 and out[2] == 0.6875
+
+
+# ---- samplers ------------------------------------------------------------------------------------------
+def _plane_rgba16f(a):
+    return images.plane(a, _abi.FORMAT_R16G16B16A16_SFLOAT)
+
+
+def test_bilinear_texel_centres_and_midpoints(oracle):
+    img = np.zeros((2, 2, 4), dtype=np.float16)
+    img[0, 0, 0], img[0, 1, 0], img[1, 0, 0], img[1, 1, 0] = 1.0, 3.0, 5.0, 9.0
+    p = _plane_rgba16f(img)
+    out = (C.c_float * 4)()
+    oracle.orc_sample_bilinear(C.byref(p), 0.25, 0.25, 2, out)  # centre of texel (0,0)
+    assert out[0] == 1.0
+    oracle.orc_sample_bilinear(C.byref(p), 0.5, 0.5, 2, out)  # equidistant: mean of the four
+    assert out[0] == 4.5
+    oracle.orc_sample_bilinear(C.byref(p), 0.0, 0.25, 2, out)  # clamp-to-edge: left of the first centre
+    assert out[0] == 1.0
+    oracle.orc_sample_bilinear(C.byref(p), 0.0, 0.25, 0, out)  # repeat: halfway between texel 1 and texel 0
+    assert out[0] == 2.0
+
+
+def test_trilinear_border_is_transparent_black(oracle):
+    vol = np.ones((2, 2, 2, 4), dtype=np.float16)
+    v = images.volume(vol, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    out = (C.c_float * 4)()
+    oracle.orc_sample_trilinear(C.byref(v), 0.5, 0.5, 0.5, 3, out)
+    assert list(out) == [1.0, 1.0, 1.0, 1.0]
+    oracle.orc_sample_trilinear(C.byref(v), 0.0, 0.5, 0.5, 3, out)  # on the x=0 face: half border, half texel
+    assert list(out) == [0.5, 0.5, 0.5, 0.5]
+    oracle.orc_sample_trilinear(C.byref(v), -1.0, 0.5, 0.5, 3, out)
+    assert list(out) == [0.0, 0.0, 0.0, 0.0]
+    oracle.orc_sample_trilinear(C.byref(v), float("nan"), 0.5, 0.5, 3, out)
+    assert all(math.isnan(x) for x in out)
+
+
+def test_pcf_compares_then_filters(oracle):
+    sm = np.zeros((1, 2, 2), dtype=np.uint16)
+    sm[0, 0, 0], sm[0, 0, 1], sm[0, 1, 0], sm[0, 1, 1] = 65535, 0, 0, 65535
+    v = images.volume(sm, _abi.FORMAT_D16_UNORM)
+    # ref 0.5 < 1.0 passes on two of the four taps, weights 1/4 each at the image centre
+    assert oracle.orc_sample_shadow(C.byref(v), 0.5, 0.5, 0, 0.5) == 0.5
+    assert oracle.orc_sample_shadow(C.byref(v), 0.25, 0.25, 0, 0.5) == 1.0
+    assert oracle.orc_sample_shadow(C.byref(v), 0.25, 0.25, 0, 1.0) == 0.0  # LESS is strict
+
+
+# ---- BRDF ------------------------------------------------------------------------------------------------
+def _brdf(oracle, fn, base, n, rough, metal, l, v):
+    out = (C.c_float * 3)()
+    fn((C.c_float * 3)(*base), (C.c_float * 3)(*n), rough, metal, (C.c_float * 3)(*l), (C.c_float * 3)(*v), out)
+    return list(out)
+
+
+def test_brdf_head_on_dielectric(oracle):
+    """N = L = V = +z, roughness 1, metalness 0, white base colour (brdf.glsl:29-121 by hand, in float64)."""
+    got = _brdf(oracle, oracle.orc_brdf_f32, (1, 1, 1), (0, 0, 1), 1.0, 0.0, (0, 0, 1), (0, 0, 1))
+    pi = float(np.float32(3.1415927))
+    # h = N, every dot = 1 (+1e-5 on NoV): D = (1/(1-1+1))^2/pi, V = 0.5/(NoL*sqrt(..)+NoV*sqrt(..)), F = f0 + (1-f0)*0
+    nov = 1.0 + 1e-5
+    d = 1.0 / pi
+    vis = 0.5 / (1.0 * math.sqrt((-nov * 1 + nov) * nov + 1.0) + nov * math.sqrt((-1.0 + 1.0) * 1.0 + 1.0))
+    fr = d * vis * 0.04
+    fd = 0.96 * (1.0 / pi)  # Schlick terms are 1 at u = 1
+    for c in got:
+        assert c == pytest.approx(fd + fr, rel=3e-6)
+
+
+def test_brdf_backfacing_is_zero_and_roughness_zero_is_nan(oracle):
+    assert _brdf(oracle, oracle.orc_brdf_f32, (1, 1, 1), (0, 0, 1), 0.5, 0.0, (0, 0, -1), (0, 0, 1)) == [0.0, 0.0, 0.0]
+    # roughness 0 and N.H == 1: D_GGX = (0 / 0)^2 -> NaN (the corner directional_light.frag:145-147 guards against)
+    r = _brdf(oracle, oracle.orc_brdf_f32, (1, 1, 1), (0, 0, 1), 0.0, 0.0, (0, 0, 1), (0, 0, 1))
+    assert all(math.isnan(c) for c in r)
+
+
+def test_half_brdf_rounds_after_every_operator(oracle):
+    a = _brdf(oracle, oracle.orc_brdf_f16, (0.8, 0.5, 0.3), (0, 0, 1), 0.5, 0.25, (0.6, 0, 0.8), (0, 0.6, 0.8))
+    b = _brdf(oracle, oracle.orc_brdf_f32, (0.8, 0.5, 0.3), (0, 0, 1), 0.5, 0.25, (0.6, 0, 0.8), (0, 0.6, 0.8))
+    for x, y in zip(a, b):
+        assert np.float32(x) == np.float16(x)  # fp16-representable
+        assert x == pytest.approx(y, rel=2e-2) and x != y
+
+
+# ---- quirks (SURVEY §8-c fixture iii) -----------------------------------------------------------------------
+def _tiny_frame(**kw):
+    f = util.LightingFrame(16, 8, seed=5, sky=False, **kw)
+    return f
+
+
+def test_quirk_sun_blend_squares_the_sun_term():
+    f = _tiny_frame(sun_mode=_abi.SHADOW_MODE_CSM)
+    f.arrays["emission"][:] = 0
+    del f.arrays["shadowmap"]  # no shadow map bound: shadow factor 1
+    squared = f.run_oracle().view(np.float16).astype(np.float64)
+    f.flags = 0
+    plain = f.run_oracle().view(np.float16).astype(np.float64)
+    m = f.arrays["depth"] != 0
+    s = plain[m][:, :3]
+    sq = squared[m][:, :3]
+    big = s > 1e-2
+    assert np.allclose(sq[big], s[big] ** 2, rtol=4e-3)
+    assert np.all(squared[m][:, 3] == 1.0) and np.all(plain[m][:, 3] == 2.0)  # alpha: 1*0 + 0*0, then +1 emissive
+
+
+def test_quirk_shadow_mode_off_means_no_sun_at_all():
+    f = _tiny_frame(sun_mode=_abi.SHADOW_MODE_OFF)
+    f.arrays["emission"][:] = 0
+    lit = f.run_oracle().view(np.float16)
+    assert np.all(lit[..., :3] == 0) and np.all(lit[..., 3] == 1.0)
+
+
+def test_quirk_emissive_ignores_depth_and_is_scaled_by_pi():
+    f = _tiny_frame(sun_mode=_abi.SHADOW_MODE_OFF)
+    f.arrays["depth"][:] = 0.0
+    f.arrays["emission"][:] = 0
+    f.arrays["emission"][2, 3] = (255, 128, 0, 9)
+    lit = f.run_oracle().view(np.float16)
+    assert lit[2, 3, 0] == np.float16(np.float32(1.0) * np.float32(3.1415927))
+    assert lit[2, 3, 1] == np.float16(util.oracle().orc_srgb8_to_linear(128) * np.float32(3.1415927))
+    assert lit[2, 3, 2] == 0 and lit[2, 3, 3] == 1.0
+
+
+def test_quirk_tonemap_vflip_and_double_gamma(oracle):
+    w, h = 8, 4
+    scene = np.zeros((h, w, 4), dtype=np.float16)
+    scene[0, :, :3] = 1.0  # top row bright
+    mips = [np.zeros((mh, mw, 4), dtype=np.uint16) for (mw, mh) in images.bloom_mip_sizes(w, h, 6)]
+    chain = images.mipchain(mips)
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    sp, op = _plane_rgba16f(scene), images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    assert oracle.orc_tonemap(C.byref(sp), C.byref(chain), C.byref(op), 0, 0) == 0
+    assert out[0, :, :3].max() == 0 and out[h - 1, :, 0].min() > 0  # v = 1 - (y+0.5)/H: the image comes out upside down
+    # c = 1 -> luma 1 -> c * 0.5 -> pow(., 1/2.2) -> sRGB OETF on top -> UNORM8
+    c = 0.5 ** (1 / 2.2)
+    expect = round((1.055 * c ** (1 / 2.4) - 0.055) * 255.0)
+    assert out[h - 1, 2, 0] == expect and out[h - 1, 2, 3] == 255
