@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsah_hip.so")
-SOURCES = ["api.cpp", "api_post.cpp", "lighting.hip", "post.hip", "lpv.hip"]
+SOURCES = ["api.cpp", "api_post.cpp", "lighting.hip", "lighting_tiled.hip", "post.hip", "lpv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
 

@@ -1,0 +1,289 @@
+// Device restatement of the irradiance-cache overlay (a4) and the RTGI reconstruction overlay (a5).
+//   a4: RenderCore/shaders/gi/cache/overlay.frag.slang:46-118, probe_sampling.slangi:6-106, common/octahedral.slangi:56-74
+//   a5: RenderCore/shaders/gi/rtgi/overlay.frag.slang:68-117
+// Same operator sequence as the CPU oracle (oracle/gi.cpp); used by the general / tiled kernels.
+#pragma once
+#include "lighting_common.hpp"
+
+namespace sah {
+
+// ---- format decode ---------------------------------------------------------------------------------------------
+SAH_DEV float uf11_to_f32(uint32_t v) {
+    const uint32_t e = (v >> 6) & 0x1fu, m = v & 0x3fu;
+    if (e == 0) return (float)m * (1.0f / 64.0f) * 6.103515625e-5f;
+    if (e == 31) return m ? __builtin_nanf("") : __builtin_inff();
+    return __uint_as_float(((e + 112u) << 23) | (m << 17));
+}
+SAH_DEV float uf10_to_f32(uint32_t v) {
+    const uint32_t e = (v >> 5) & 0x1fu, m = v & 0x1fu;
+    if (e == 0) return (float)m * (1.0f / 32.0f) * 6.103515625e-5f;
+    if (e == 31) return m ? __builtin_nanf("") : __builtin_inff();
+    return __uint_as_float(((e + 112u) << 23) | (m << 18));
+}
+
+SAH_DEV int wrap_repeat(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+SAH_DEV int array_layer(float l, uint32_t layers) {  // round to nearest even, clamp to [0, layers-1]
+    const float r = __builtin_rintf(l);
+    if (!(r > 0.f)) return 0;
+    if (r > (float)(layers - 1)) return (int)layers - 1;
+    return (int)r;
+}
+
+// 2D-array bilinear, REPEAT (irradiance_cache.cpp:205-217), weighted-sum fma chain; NCH channels decoded by `fetch`
+template <int NCH, class Fetch>
+SAH_DEV void bilinear_repeat_array(const VolumeArg& v, float u, float vv, int layer, float (&out)[NCH], Fetch fetch) {
+    const float px = u * (float)v.width - 0.5f, py = vv * (float)v.height - 0.5f;
+    if (isnan_f(px) || isnan_f(py)) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) out[c] = __builtin_nanf("");
+        return;
+    }
+    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    const float fx = px - fx0, fy = py - fy0;
+    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    const int x0 = wrap_repeat(clamp_to_int(fx0), (int)v.width), y0 = wrap_repeat(clamp_to_int(fy0), (int)v.height);
+    const int x1 = x0 + 1 == (int)v.width ? 0 : x0 + 1, y1 = y0 + 1 == (int)v.height ? 0 : y0 + 1;
+    const int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+    const float w[4] = {wx0 * wy0, fx * wy0, wx0 * fy, fx * fy};
+    const uint8_t* base = v.ptr + (size_t)layer * v.slice_pitch;
+    float t[4][NCH];
+#pragma unroll
+    for (int k = 0; k < 4; k++) fetch(*reinterpret_cast<const uint32_t*>(base + (size_t)ys[k] * v.row_pitch + (size_t)xs[k] * 4), t[k]);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) a = __builtin_fmaf(w[k], t[k][c], a);
+        out[c] = a;
+    }
+}
+
+struct F2 {
+    Fn x, y;
+};
+
+// octahedral.slangi:56-63
+SAH_DEV F2 octahedral_coordinates(F3 dir) {
+    const Fn l1 = nabs(dir.x) + nabs(dir.y) + nabs(dir.z);
+    const Fn inv = Fn(1.f) / l1;
+    F2 uv = {dir.x * inv, dir.y * inv};
+    if (dir.z.v < 0.f) {
+        const Fn sx = Fn(uv.x.v >= 0.f ? 1.f : -1.f), sy = Fn(uv.y.v >= 0.f ? 1.f : -1.f);
+        const F2 r = {(Fn(1.f) - nabs(uv.y)) * sx, (Fn(1.f) - nabs(uv.x)) * sy};
+        uv = r;
+    }
+    return uv;
+}
+// octahedral.slangi:65-74
+SAH_DEV void probe_uv(const uint32_t (&idx)[3], F2 oct, uint32_t n0, uint32_t n1, Fn (&uv)[2]) {
+    const uint32_t n[2] = {n0, n1};
+    const Fn o[2] = {oct.x, oct.y};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const Fn total = Fn((float)n[i]) + Fn(2.f);
+        const Fn tex_size = total * Fn(32.f);
+        Fn u = Fn((float)idx[i]) * total + total * Fn(0.5f);
+        u = u + o[i] * (Fn((float)n[i]) * Fn(0.5f));
+        uv[i] = u / tex_size;
+    }
+}
+SAH_DEV uint32_t f2uint(float f) {  // hardware float -> uint: NaN / negatives -> 0, saturating
+    if (!(f > 0.f)) return 0u;
+    if (f >= 4294967296.f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+// probe_sampling.slangi:6-106
+SAH_DEV F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index) {
+    const Fn spacing = Fn(c.spacing[cascade_index]);
+    const F3 rel = location - F3{Fn(c.cascade_min[cascade_index][0]), Fn(c.cascade_min[cascade_index][1]), Fn(c.cascade_min[cascade_index][2])};
+    const F3 ps = rel / spacing;
+    const F3 min_probe = {Fn(__builtin_floorf(ps.x.v)), Fn(__builtin_floorf(ps.y.v)), Fn(__builtin_floorf(ps.z.v))};
+    const F3 alpha = {nclamp(ps.x - min_probe.x, Fn(0.f), Fn(1.f)), nclamp(ps.y - min_probe.y, Fn(0.f), Fn(1.f)),
+                      nclamp(ps.z - min_probe.z, Fn(0.f), Fn(1.f))};
+    F3 irradiance = F3(Fn(0.f));
+    Fn weight = Fn(0.f);
+    for (uint32_t i = 0; i < 8; i++) {
+        const F3 off = {Fn((float)(i & 1u)), Fn((float)((i >> 1) & 1u)), Fn((float)((i >> 2) & 1u))};
+        const F3 probe_location = min_probe + off;
+        const F3 dir_to_probe = probe_location - ps;
+        const Fn dist = length(dir_to_probe) * spacing;
+        const F3 pidx_f = probe_location + F3{Fn(0.f), Fn((float)cascade_index) * Fn(8.f), Fn(0.f)};
+        const uint32_t pidx[3] = {f2uint(pidx_f.x.v), f2uint(pidx_f.y.v), f2uint(pidx_f.z.v)};
+        float validity = 0.f;  // Texture2DArray<half>[uint3]: out-of-range loads return 0
+        if (pidx[0] < c.validity.width && pidx[1] < c.validity.height && pidx[2] < c.validity.depth) {
+            const uint8_t b = c.validity.ptr[(size_t)pidx[2] * c.validity.slice_pitch + (size_t)pidx[1] * c.validity.row_pitch + pidx[0]];
+            validity = rh((float)b / 255.0f);
+        }
+        if (validity == 0.f) continue;
+        const F3 tri = {nmax(Fn(0.001f), mix(Fn(1.f) - alpha.x, alpha.x, off.x)), nmax(Fn(0.001f), mix(Fn(1.f) - alpha.y, alpha.y, off.y)),
+                        nmax(Fn(0.001f), mix(Fn(1.f) - alpha.z, alpha.z, off.z))};
+        const Fn trilinear_weight = tri.x * tri.y * tri.z;
+        Fn probe_weight = Fn(1.f);
+
+        const F2 depth_oct = octahedral_coordinates(-dir_to_probe);
+        Fn duv[2];
+        probe_uv(pidx, depth_oct, 10u, 10u, duv);
+        float dt[2];
+        bilinear_repeat_array<2>(c.depth, duv[0].v, duv[1].v, array_layer((float)pidx[2], c.depth.depth), dt, [](uint32_t w, float (&o)[2]) {
+            o[0] = (float)hbits(w & 0xffffu);
+            o[1] = (float)hbits(w >> 16);
+        });
+        const Hn dx = Hn(dt[0]), dy = Hn(dt[1]);  // Sampler2DArray<half2>
+        const Fn variance = Fn(tof(nabs(dx * dx - dy)));
+        Fn cheb = Fn(1.f);
+        if (dist.v > tof(dx)) {
+            const Fn v = dist - Fn(tof(dx));
+            cheb = variance / (variance + (v * v));
+            cheb = nmax(cheb * cheb * cheb, Fn(0.f));
+        }
+        probe_weight = probe_weight * nmax(Fn(0.05f), cheb);
+        probe_weight = nmax(Fn(0.000001f), probe_weight);
+        const Fn crush = Fn(0.2f);
+        if (probe_weight.v < crush.v) probe_weight = probe_weight * ((probe_weight * probe_weight) * (Fn(1.f) / (crush * crush)));
+        probe_weight = probe_weight * trilinear_weight;
+
+        const F2 irr_oct = octahedral_coordinates(direction);
+        Fn iuv[2];
+        probe_uv(pidx, irr_oct, c.probe_size[0], c.probe_size[1], iuv);
+        float it[3];
+        bilinear_repeat_array<3>(c.irradiance, iuv[0].v, iuv[1].v, array_layer((float)pidx[2], c.irradiance.depth), it,
+                                 [](uint32_t w, float (&o)[3]) {
+                                     o[0] = uf11_to_f32(w & 0x7ffu);
+                                     o[1] = uf11_to_f32((w >> 11) & 0x7ffu);
+                                     o[2] = uf10_to_f32((w >> 22) & 0x3ffu);
+                                 });
+        const H3 pi = {Hn(it[0]), Hn(it[1]), Hn(it[2])};  // Sampler2DArray<half3>
+        irradiance = irradiance + to_f(pi) * probe_weight;
+        weight = weight + probe_weight;
+    }
+    if (weight.v == 0.f) return F3(Fn(0.f));
+    irradiance = irradiance / weight;
+    return irradiance * Fn(2.f) * Fn(rh(3.1415927f));  // PI = 3.1415927h (brdf.slangi wins the #ifndef race)
+}
+
+SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, Fn (&out)[4]) {
+    Surface<Hn> s;
+    s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
+    s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
+    s.roughness = Hn(si.rough);
+    s.metalness = Hn(si.metal);
+    const F3 location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
+    const H3 V = to_h(normalize(location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+    uint32_t cascade_index = 5;
+    for (uint32_t i = 0; i < 4; i++) {
+        if (location.x.v > c.cascade_min[i][0] && location.y.v > c.cascade_min[i][1] && location.z.v > c.cascade_min[i][2] &&
+            location.x.v < c.cascade_max[i][0] && location.y.v < c.cascade_max[i][1] && location.z.v < c.cascade_max[i][2]) {
+            cascade_index = i;
+            break;
+        }
+    }
+    if (cascade_index > 3) {  // returns (half4)0 and is still blended (overlay.frag.slang:79-81)
+        out[0] = out[1] = out[2] = out[3] = Fn(0.f);
+        return;
+    }
+    const H3 irradiance = to_h(sample_cascade(c, location, to_f(s.normal), cascade_index));
+    const H3 b = Fd(s, s.normal, V) + Fr(s, s.normal, V);
+    const Hn exposure = Hn::lit(0.314159f);
+    H3 col = b * irradiance * exposure;
+    if (c.debug_mode == 1) {
+        const float dbg[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}};
+        col = {Hn(dbg[cascade_index][0]), Hn(dbg[cascade_index][1]), Hn(dbg[cascade_index][2])};
+    }
+    if (any_nan(col)) col = H3(Hn::lit(0.f));
+    out[0] = Fn(tof(col.x));
+    out[1] = Fn(tof(col.y));
+    out[2] = Fn(tof(col.z));
+    out[3] = Fn(1.f);
+}
+
+// ---- a5 ------------------------------------------------------------------------------------------------------------------
+SAH_DEV H3 rtgi_contribution(const Surface<Hn>& s, H3 V, H3 dir, H3 irr) {
+    const H3 b = Fd(s, dir, V) + Fr(s, dir, V);
+    const Hn ndotl = Hn(nclamp(Fn(tof(dot(dir, s.normal))), Fn(0.f), Fn(1.f)).v);
+    return b * irr * ndotl;
+}
+SAH_DEV void load_path(const LightingArgs& a, const RtgiArgs& r, uint32_t px, uint32_t py, H3& dir, H3& irr) {
+    if (px < a.width && py < a.height) {  // out-of-range image loads return 0
+        const half4_t d = *reinterpret_cast<const half4_t*>(r.ray_buffer.ptr + (size_t)py * r.ray_buffer.pitch + (size_t)px * 8);
+        const half4_t i = *reinterpret_cast<const half4_t*>(r.ray_irradiance.ptr + (size_t)py * r.ray_irradiance.pitch + (size_t)px * 8);
+        dir = {Hn::raw(d[0]), Hn::raw(d[1]), Hn::raw(d[2])};
+        irr = {Hn::raw(i[0]), Hn::raw(i[1]), Hn::raw(i[2])};
+    } else {
+        dir = H3(Hn::lit(0.f));
+        irr = H3(Hn::lit(0.f));
+    }
+}
+
+SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, const float* lut,
+                          Fn (&out)[4]) {
+    Surface<Hn> s;
+    s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
+    s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
+    s.roughness = Hn(si.rough);
+    s.metalness = Hn(si.metal);
+    const F3 location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
+    const H3 V = to_h(normalize(location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+    H3 dir, irr;
+    load_path(a, r, x, y, dir, irr);
+    H3 radiance = rtgi_contribution(s, V, dir, irr);
+    uint32_t num_samples = 1;
+    for (uint32_t ray = 0; ray < r.num_extra_rays; ray++) {
+        const Fn phi = Fn(1.618033988749895f);  // r1(n): overlay.frag.slang:30-36
+        const Fn q = Fn((float)ray) / phi;
+        Fn r1x = Fn(2.f) + q, r1y = Fn(3.f) + q;
+        r1x = r1x - Fn(__builtin_floorf(r1x.v));
+        r1y = r1y - Fn(__builtin_floorf(r1y.v));
+        const uint32_t nox = f2uint((r1x * Fn(128.f)).v), noy = f2uint((r1y * Fn(128.f)).v);
+        const uint32_t nxp = (x + nox) % 128u, nyp = (y + noy) % 128u;
+        float n0 = 0.f, n1 = 0.f;
+        if (r.noise.ptr && nxp < r.noise_w && nyp < r.noise_h) {
+            const uint32_t nw = *reinterpret_cast<const uint32_t*>(r.noise.ptr + (size_t)nyp * r.noise.pitch + (size_t)nxp * 4);
+            n0 = lut[256 + (nw & 0xffu)];
+            n1 = lut[256 + ((nw >> 8) & 0xffu)];
+        }
+        const Hn nsx = Hn(n0) * Hn::lit(2.f) - Hn::lit(1.f), nsy = Hn(n1) * Hn::lit(2.f) - Hn::lit(1.f);
+        const Fn ox = Fn((float)x) + Fn(tof(nsx)) * Fn(r.extra_ray_radius), oy = Fn((float)y) + Fn(tof(nsy)) * Fn(r.extra_ray_radius);
+        const uint32_t opx = f2uint(__builtin_rintf(ox.v)), opy = f2uint(__builtin_rintf(oy.v));
+        float odepth = 0.f;
+        if (opx < a.width && opy < a.height) odepth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)opy * a.depth.pitch + (size_t)opx * 4);
+        const F3 other = worldspace_location_slang(a, (float)opx, (float)opy, odepth);
+        if (length(location - other).v > 2.f) continue;  // NaN compares false: not skipped, as in the shader
+        H3 d2, i2;
+        load_path(a, r, opx, opy, d2, i2);
+        radiance = radiance + rtgi_contribution(s, V, d2, i2);
+        num_samples++;
+    }
+    if (any_nan(radiance)) radiance = H3(Hn::lit(0.f));
+    const Hn n = Hn((float)num_samples);
+    out[0] = Fn(tof(radiance.x / n));
+    out[1] = Fn(tof(radiance.y / n));
+    out[2] = Fn(tof(radiance.z / n));
+    out[3] = Fn(1.f);
+}
+
+// ---- a9 (extension): one point light, DESIGN.md / oracle/post.cpp:point_lights_frag ------------------------------------
+struct PointLightDev {
+    float px, py, pz, radius, cr, cg, cb, intensity;
+};
+SAH_DEV F3 point_light_contribution(const Surface<Fn>& s, F3 ws, F3 V, const PointLightDev& pl) {
+    const F3 lv = F3{Fn(pl.px), Fn(pl.py), Fn(pl.pz)} - ws;
+    const Fn d2 = dot(lv, lv);
+    const F3 L = lv * inversesqrt(d2);
+    const Fn dist = nsqrt(d2);
+    const Fn ndotl = nclamp(dot(s.normal, L), Fn(0.f), Fn(1.f));
+    const Fn xr = dist / Fn(pl.radius);
+    const Fn x2 = xr * xr;
+    const Fn x4 = x2 * x2;
+    const Fn w = nclamp(Fn(1.f) - x4, Fn(0.f), Fn(1.f));
+    const Fn att = (w * w) / nmax(d2, Fn(1e-4f));
+    const F3 b = Fd(s, L, V) + Fr(s, L, V);
+    F3 c = ndotl * b * F3{Fn(pl.cr), Fn(pl.cg), Fn(pl.cb)} * (Fn(pl.intensity) * att);
+    if (any_nan(c)) c = F3(Fn(0.f));
+    return c;
+}
+
+}  // namespace sah

@@ -1,0 +1,259 @@
+// Tiled Lighting kernel for gfx950: one 256-thread workgroup shades one 16x16 screen tile.
+//
+// Used for (a) the point-light extension (BASELINE configs 2/3/5): per-tile light culling with the light
+// list in LDS, built with wavefront ballot + prefix so that the list keeps light-index order (the sum over the culled
+// list is then bit-identical to brute force), and (b) the GI overlays that have no fast path yet (irradiance cache a4,
+// RTGI reconstruction a5).  The per-pixel arithmetic is the general restatement of lighting_common.hpp /
+// lighting_gi_ext.hpp.
+//
+// Culling: the tile's bound is the axis-aligned box of the WORLD-SPACE positions the shading itself reconstructs for the
+// tile's surface pixels (min/max by wave shuffles, then across the four waves through LDS); a light survives if its
+// sphere, inflated by 1e-4 relative, touches the box.  A culled light has d >= r for every pixel of the tile, hence
+// attenuation exactly 0 and contribution exactly +-0 (or NaN -> 0 by the guard): skipping it cannot change the sum.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sah_hip.h"
+#include "lighting_common.hpp"
+#include "lighting_gi_ext.hpp"
+#include "numerics.hpp"
+#include "params.hpp"
+
+namespace sah {
+
+constexpr uint32_t kMaxTileLights = 1024;
+
+SAH_DEV float wave_min(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = __builtin_fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+SAH_DEV float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+template <int SUN, int GI, bool LIGHTS>
+__global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const CacheArgs cache,
+                                                        const RtgiArgs rtgi, const SkyArgs sky, const uint32_t brute_force) {
+    __shared__ float s_lut[512];
+    __shared__ float s_box[4][6];
+    __shared__ uint32_t s_wave_count[4];
+    __shared__ uint16_t s_list[kMaxTileLights];
+    s_lut[threadIdx.x] = a.luts[threadIdx.x];
+    s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+    const uint32_t y = a.row_begin + blockIdx.y * 16u + (threadIdx.x >> 4);
+    const bool inside = x < a.width && y < a.row_end;
+
+    Px p;
+    p.color = p.data = p.emission = p.n01 = p.n23 = 0u;
+    p.depth = 0.f;
+    p.ao = 1.f;
+    p.mask = 1.f;
+    if (inside) {
+        p.color = *reinterpret_cast<const uint32_t*>(a.color.ptr + (size_t)y * a.color.pitch + (size_t)x * 4);
+        p.data = *reinterpret_cast<const uint32_t*>(a.data.ptr + (size_t)y * a.data.pitch + (size_t)x * 4);
+        p.emission = *reinterpret_cast<const uint32_t*>(a.emission.ptr + (size_t)y * a.emission.pitch + (size_t)x * 4);
+        p.depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+        const uint2 n = *reinterpret_cast<const uint2*>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x * 8);
+        p.n01 = n.x;
+        p.n23 = n.y;
+        if (GI == SAH_GI_LPV && a.has_ao) p.ao = *reinterpret_cast<const float*>(a.ao.ptr + (size_t)y * a.ao.pitch + (size_t)x * 4);
+        if (SUN == SAH_SHADOW_MODE_RT && a.has_mask)
+            p.mask = *reinterpret_cast<const float*>(a.shadow_mask.ptr + (size_t)y * a.shadow_mask.pitch + (size_t)x * 4);
+    }
+    const bool surface = inside && p.depth != 0.f;
+    SurfIn si = unpack_surface(p, s_lut);
+
+    Hn lit[4] = {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
+
+    // (2) sun, CSM mode
+    if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
+        if (surface) {
+            Fn s[4];
+            sun_frag(a, csm, x, y, p, si, s);
+            if (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) lit[i] = Hn((s[i] * s[i] + Fn(tof(lit[i])) * Fn(tof(lit[i]))).v);
+                lit[3] = Hn((s[3] * Fn(0.f) + Fn(tof(lit[3])) * Fn(0.f)).v);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
+            }
+        }
+    }
+
+    // (2b) point lights
+    if constexpr (LIGHTS) {
+        // shading inputs exactly as oracle/post.cpp:point_lights_frag builds them
+        Surface<Fn> s;
+        s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
+        s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});
+        s.roughness = Fn(si.rough);
+        s.metalness = Fn(si.metal);
+        const F3 vs = viewspace_position_glsl(a, x, y, p.depth);
+        const F4 ws4 = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(1.0f)});
+        const F3 ws = {ws4.x, ws4.y, ws4.z};
+        const F3 V = normalize(ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])});
+        const PointLightDev* lights = reinterpret_cast<const PointLightDev*>(a.lights);
+
+        // tile bound: box of the positions of the surface pixels (non-finite positions get 0 from every light anyway)
+        const float inf = __builtin_inff();
+        const bool bounded = surface && __builtin_fabsf(ws.x.v) < inf && __builtin_fabsf(ws.y.v) < inf && __builtin_fabsf(ws.z.v) < inf;
+        float lo[3] = {bounded ? ws.x.v : inf, bounded ? ws.y.v : inf, bounded ? ws.z.v : inf};
+        float hi[3] = {bounded ? ws.x.v : -inf, bounded ? ws.y.v : -inf, bounded ? ws.z.v : -inf};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            lo[i] = wave_min(lo[i]);
+            hi[i] = wave_max(hi[i]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                s_box[wave][i] = lo[i];
+                s_box[wave][3 + i] = hi[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            lo[i] = __builtin_fminf(__builtin_fminf(s_box[0][i], s_box[1][i]), __builtin_fminf(s_box[2][i], s_box[3][i]));
+            hi[i] = __builtin_fmaxf(__builtin_fmaxf(s_box[0][3 + i], s_box[1][3 + i]), __builtin_fmaxf(s_box[2][3 + i], s_box[3][3 + i]));
+        }
+
+        F3 sum = F3(Fn(0.f));
+        for (uint32_t batch = 0; batch < a.num_lights; batch += kMaxTileLights) {
+            const uint32_t batch_n = min(kMaxTileLights, a.num_lights - batch);
+            uint32_t count = 0;  // lights kept so far in this batch (uniform)
+            if (brute_force) {
+                count = batch_n;
+            } else {
+                for (uint32_t base = 0; base < batch_n; base += 256u) {
+                    const uint32_t i = base + threadIdx.x;
+                    bool keep = false;
+                    if (i < batch_n) {
+                        const PointLightDev pl = lights[batch + i];
+                        const float c[3] = {pl.px, pl.py, pl.pz};
+                        float d2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const float d = __builtin_fmaxf(__builtin_fmaxf(lo[k] - c[k], c[k] - hi[k]), 0.f);
+                            d2 += d * d;
+                        }
+                        const float rr = pl.radius * 1.0001f + 1e-6f;
+                        keep = d2 <= rr * rr;  // empty box (lo = +inf) gives d2 = inf: nothing kept; NaN light data: kept
+                        keep = keep || !(d2 == d2) || !(rr == rr);
+                    }
+                    // order-preserving compaction: ballot + prefix inside the wave, wave totals through LDS
+                    const unsigned long long ballot = __ballot(keep);
+                    const uint32_t before = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+                    if (lane == 0) s_wave_count[wave] = (uint32_t)__builtin_popcountll(ballot);
+                    __syncthreads();
+                    uint32_t offset = count, total = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; w++) {
+                        const uint32_t c = s_wave_count[w];
+                        offset += w < wave ? c : 0u;
+                        total += c;
+                    }
+                    if (keep) s_list[offset + before] = (uint16_t)i;
+                    count += total;
+                    __syncthreads();
+                }
+            }
+            // shade the (ordered) list
+            for (uint32_t j = 0; j < count; j++) {
+                const uint32_t idx = batch + (brute_force ? j : (uint32_t)s_list[j]);
+                const PointLightDev pl = lights[idx];
+                if (surface) sum = sum + point_light_contribution(s, ws, V, pl);
+            }
+            __syncthreads();  // s_list is rewritten by the next batch
+        }
+        if (surface) {
+            const Fn exposure = Fn(0.00031415927f);
+            lit[0] = Hn(tof(lit[0]) + (sum.x * exposure).v);
+            lit[1] = Hn(tof(lit[1]) + (sum.y * exposure).v);
+            lit[2] = Hn(tof(lit[2]) + (sum.z * exposure).v);
+            lit[3] = Hn(tof(lit[3]) + 1.0f);
+        }
+    }
+
+    // (3) GI overlay
+    if (surface) {
+        Fn s[4];
+        bool drawn = false;
+        if constexpr (GI == SAH_GI_LPV) {
+            gi_lpv_frag(a, lpv, x, y, p, si, s);
+            drawn = true;
+        } else if constexpr (GI == SAH_GI_CACHE) {
+            gi_cache_frag(a, cache, x, y, p, si, s);
+            drawn = true;
+        } else if constexpr (GI == SAH_GI_RTGI) {
+            gi_rtgi_frag(a, rtgi, x, y, p, si, s_lut, s);
+            drawn = true;
+        }
+        if (drawn) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
+        }
+    }
+    // (4) emissive
+    {
+        const Fn e = Fn(3.1415927f);
+        lit[0] = Hn(tof(lit[0]) + (Fn(s_lut[p.emission & 0xffu]) * e).v);
+        lit[1] = Hn(tof(lit[1]) + (Fn(s_lut[(p.emission >> 8) & 0xffu]) * e).v);
+        lit[2] = Hn(tof(lit[2]) + (Fn(s_lut[(p.emission >> 16) & 0xffu]) * e).v);
+        lit[3] = Hn(tof(lit[3]) + 1.0f);
+    }
+    // (5) sky
+    if (sky.enabled && inside && !surface) sky_frag(a, sky, x, y, lit);
+    // (6) sun, RT mode
+    if constexpr (SUN == SAH_SHADOW_MODE_RT) {
+        if (surface) {
+            float add[3];
+            sun_rt(a, x, y, p, si, add);
+#pragma unroll
+            for (int i = 0; i < 3; i++) lit[i] = Hn(tof(lit[i]) + add[i]);
+        }
+    }
+    if (inside) *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x * 8) = pack_lit(lit);
+}
+
+template <int SUN, int GI>
+static hipError_t launch_tiled_lights(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
+                                      const SkyArgs& sky, bool brute, hipStream_t st) {
+    const uint32_t rows = a.row_end - a.row_begin;
+    if (rows == 0 || a.width == 0) return hipSuccess;
+    const dim3 grid((a.width + 15) / 16, (rows + 15) / 16), block(256);
+    if (a.num_lights) hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, true>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, brute ? 1u : 0u);
+    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, 0u);
+    return hipGetLastError();
+}
+
+template <int SUN>
+static hipError_t launch_tiled_gi(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
+                                  const SkyArgs& sky, int gi, bool brute, hipStream_t st) {
+    switch (gi) {
+        case SAH_GI_NONE: return launch_tiled_lights<SUN, SAH_GI_NONE>(a, csm, lpv, cache, rtgi, sky, brute, st);
+        case SAH_GI_LPV: return launch_tiled_lights<SUN, SAH_GI_LPV>(a, csm, lpv, cache, rtgi, sky, brute, st);
+        case SAH_GI_CACHE: return launch_tiled_lights<SUN, SAH_GI_CACHE>(a, csm, lpv, cache, rtgi, sky, brute, st);
+        case SAH_GI_RTGI: return launch_tiled_lights<SUN, SAH_GI_RTGI>(a, csm, lpv, cache, rtgi, sky, brute, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_lighting_tiled(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
+                                 const SkyArgs& sky, int sun_mode, int gi, bool brute_force_lights, hipStream_t st) {
+    switch (sun_mode) {
+        case SAH_SHADOW_MODE_OFF: return launch_tiled_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, st);
+        case SAH_SHADOW_MODE_CSM: return launch_tiled_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, st);
+        case SAH_SHADOW_MODE_RT: return launch_tiled_gi<SAH_SHADOW_MODE_RT>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace sah

@@ -49,6 +49,7 @@ SAH_DEV float opaque(float x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+SAH_DEV float rh(float f) { return (float)(_Float16)opaque(f); }  // round to the nearest fp16-representable value
 struct Hn {
     _Float16 v;
     SAH_DEV Hn() : v((_Float16)0.f) {}
