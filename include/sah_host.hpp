@@ -1,0 +1,410 @@
+// sah_host.hpp — C++17 host façade above the C ABI (sah_hip.h).
+//
+// Mirrors the reference's pass / render-graph surface for the hot path so that host code reads like
+// RenderCore/render/scene_renderer.cpp:365-449:
+//     RenderGraph graph{backend};
+//     gi->post_render(graph, view, scene, gbuffer, noise);                 // LPV: propagate
+//     lighting.render(graph, view, gbuffer, lit_scene, ao, gi, ...);       // -> sah_lighting
+//     bloomer.fill_bloom_tex(graph, antialiased);                          // -> sah_bloom
+//     ui.render(graph, view, bloomer.get_bloom_tex());                     // -> sah_tonemap
+//     graph.finish();
+// Names, argument meaning and error behaviour follow the reference (file:line cited per class); resources are linear
+// device allocations instead of VkImages.  Header-only; link libsah_hip.so and the HIP runtime.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sah_hip.h"
+
+namespace sah {
+
+// ---- resources (RenderCore/render/backend/handles.hpp:3-5, resource_allocator.hpp) ---------------------------------
+struct Texture {
+    std::string name;
+    sah_volume desc{};  // depth == 1 for plain 2D textures
+    sah_plane plane() const { return sah_plane{desc.ptr, desc.width, desc.height, desc.row_pitch_bytes, desc.format}; }
+};
+using TextureHandle = Texture*;
+
+inline uint32_t format_bytes(uint32_t f) {
+    switch (f) {
+        case SAH_FORMAT_R8_UNORM: return 1;
+        case SAH_FORMAT_R16_SFLOAT: case SAH_FORMAT_D16_UNORM: return 2;
+        case SAH_FORMAT_R16G16B16A16_SFLOAT: return 8;
+        default: return 4;
+    }
+}
+
+// Creation failures throw std::runtime_error, as ResourceAllocator::create_texture does (resource_allocator.cpp:110-112).
+class ResourceAllocator {
+public:
+    ~ResourceAllocator() {
+        for (auto& t : textures) (void)hipFree(t->desc.ptr);
+    }
+    TextureHandle create_texture(const std::string& name, uint32_t format, uint32_t w, uint32_t h, uint32_t layers = 1) {
+        auto t = std::make_unique<Texture>();
+        t->name = name;
+        const uint32_t pitch = ((w * format_bytes(format) + 255u) / 256u) * 256u;  // 256-byte aligned rows
+        t->desc = sah_volume{nullptr, w, h, layers, pitch, pitch * h, format};
+        if (hipMalloc(&t->desc.ptr, (size_t)pitch * h * layers) != hipSuccess) throw std::runtime_error("Could not create texture " + name);
+        (void)hipMemset(t->desc.ptr, 0, (size_t)pitch * h * layers);
+        textures.push_back(std::move(t));
+        return textures.back().get();
+    }
+    TextureHandle create_volume_texture(const std::string& name, uint32_t format, uint32_t w, uint32_t h, uint32_t d) {
+        return create_texture(name, format, w, h, d);
+    }
+    // tightly packed host rows -> device texture
+    void upload(TextureHandle t, const void* src, uint32_t src_row_bytes) {
+        const size_t rows = (size_t)t->desc.height * t->desc.depth;
+        if (hipMemcpy2D(t->desc.ptr, t->desc.row_pitch_bytes, src, src_row_bytes, src_row_bytes, rows, hipMemcpyHostToDevice) != hipSuccess)
+            throw std::runtime_error("upload failed: " + t->name);
+    }
+    void download(TextureHandle t, void* dst, uint32_t dst_row_bytes) {
+        const size_t rows = (size_t)t->desc.height * t->desc.depth;
+        if (hipMemcpy2D(dst, dst_row_bytes, t->desc.ptr, t->desc.row_pitch_bytes, dst_row_bytes, rows, hipMemcpyDeviceToHost) != hipSuccess)
+            throw std::runtime_error("download failed: " + t->name);
+    }
+
+private:
+    std::vector<std::unique_ptr<Texture>> textures;
+};
+
+// RenderCore/render/gbuffer.hpp:5-11
+struct GBuffer {
+    TextureHandle color = nullptr, normals = nullptr, data = nullptr, emission = nullptr, depth = nullptr;
+};
+
+// ---- backend + immediate render graph (RenderCore/render/backend/render_graph.hpp:24-106) --------------------------
+class RenderBackend {
+public:
+    explicit RenderBackend(int device = 0) {
+        if (int rc = sah_create(&ctx, device, 0, 1, nullptr); rc != SAH_OK) throw std::runtime_error(std::string("sah_create: ") + sah_status_string(rc));
+    }
+    ~RenderBackend() { sah_destroy(ctx); }
+    RenderBackend(const RenderBackend&) = delete;
+    ResourceAllocator& get_global_allocator() { return allocator; }
+    sah_ctx* get_context() const { return ctx; }
+
+private:
+    sah_ctx* ctx = nullptr;
+    ResourceAllocator allocator;
+};
+
+struct ComputePass {
+    std::string name;
+    std::function<int(sah_ctx*)> execute;  // returns a sah_status
+};
+
+// Passes execute immediately, in the order they are added (render_graph.cpp:85-111); a failing pass is logged and the
+// frame continues, which is how the reference treats pipeline failures (pipeline_cache.cpp:166-170).
+class RenderGraph {
+public:
+    explicit RenderGraph(RenderBackend& backend_in) : backend(backend_in) {}
+    void add_pass(ComputePass pass) {
+        const int rc = pass.execute(backend.get_context());
+        if (rc != SAH_OK) errors.push_back(pass.name + ": " + sah_status_string(rc) + " (" + sah_last_error(backend.get_context()) + ")");
+    }
+    void begin_label(const std::string&) {}
+    void end_label() {}
+    void finish() {
+        if (int rc = sah_sync(backend.get_context()); rc != SAH_OK) errors.push_back(std::string("finish: ") + sah_status_string(rc));
+    }
+    const std::vector<std::string>& get_errors() const { return errors; }
+
+private:
+    RenderBackend& backend;
+    std::vector<std::string> errors;
+};
+
+// ---- small column-major matrix helpers (glm stand-ins; inputs to the path, SURVEY §8 "types") -------------------------
+using Mat4 = std::array<float, 16>;  // m[col*4 + row]
+using Vec3 = std::array<float, 3>;
+
+inline Mat4 mat_identity() { return Mat4{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; }
+inline Mat4 mat_mul(const Mat4& a, const Mat4& b) {
+    Mat4 r{};
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            float s = 0.f;
+            for (int k = 0; k < 4; k++) s += a[k * 4 + i] * b[j * 4 + k];
+            r[j * 4 + i] = s;
+        }
+    return r;
+}
+inline Mat4 mat_inverse(const Mat4& m) {  // Gauss-Jordan in double, rounded to fp32
+    double a[4][8];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            a[i][j] = m[j * 4 + i];
+            a[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 4; r++)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        for (int j = 0; j < 8; j++) std::swap(a[c][j], a[piv][j]);
+        const double d = a[c][c];
+        for (int j = 0; j < 8; j++) a[c][j] /= d;
+        for (int r = 0; r < 4; r++)
+            if (r != c) {
+                const double f = a[r][c];
+                for (int j = 0; j < 8; j++) a[r][j] -= f * a[c][j];
+            }
+    }
+    Mat4 r{};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) r[j * 4 + i] = (float)a[i][4 + j];
+    return r;
+}
+inline Vec3 v_sub(Vec3 a, Vec3 b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+inline Vec3 v_cross(Vec3 a, Vec3 b) { return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; }
+inline float v_dot(Vec3 a, Vec3 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline Vec3 v_normalize(Vec3 a) {
+    const float inv = 1.0f / std::sqrt(v_dot(a, a));
+    return {a[0] * inv, a[1] * inv, a[2] * inv};
+}
+inline Mat4 look_at(Vec3 eye, Vec3 center, Vec3 up) {  // glm::lookAt, right-handed
+    const Vec3 f = v_normalize(v_sub(center, eye)), s = v_normalize(v_cross(f, up)), u = v_cross(s, f);
+    Mat4 m = mat_identity();
+    m[0] = s[0]; m[4] = s[1]; m[8] = s[2];
+    m[1] = u[0]; m[5] = u[1]; m[9] = u[2];
+    m[2] = -f[0]; m[6] = -f[1]; m[10] = -f[2];
+    m[12] = -v_dot(s, eye); m[13] = -v_dot(u, eye); m[14] = v_dot(f, eye);
+    return m;
+}
+
+// ---- SceneView (RenderCore/render/scene_view.cpp:13-27,138-187) --------------------------------------------------------
+class SceneView {
+public:
+    void set_render_resolution(uint32_t w, uint32_t h) { gpu_data.render_resolution[0] = (float)w; gpu_data.render_resolution[1] = (float)h; }
+    void set_position(Vec3 p) { position = p; }
+    void rotate(float delta_pitch, float delta_yaw) { pitch += delta_pitch; yaw += delta_yaw; }
+    void set_perspective_projection(float fov_in, float aspect_in, float near_in) { fov = fov_in; aspect = aspect_in; near_value = near_in; }
+    Vec3 get_position() const { return position; }
+    Vec3 get_forward() const { return forward; }
+    float get_near() const { return near_value; }
+    const sah_view_data& get_gpu_data() const { return gpu_data; }
+    void update_transforms() {
+        forward = {std::cos(pitch) * std::sin(yaw), std::sin(pitch), std::cos(pitch) * std::cos(yaw)};
+        const float half_pi = 3.14159265358979f / 2.0f;
+        const Vec3 right = {std::sin(yaw - half_pi), 0.f, std::cos(yaw - half_pi)};
+        const Vec3 up = v_cross(right, forward);
+        const Mat4 view = look_at(position, {position[0] + forward[0], position[1] + forward[1], position[2] + forward[2]}, up);
+        std::memcpy(gpu_data.last_frame_view, gpu_data.view, 64);
+        std::memcpy(gpu_data.view, view.data(), 64);
+        std::memcpy(gpu_data.inverse_view, mat_inverse(view).data(), 64);
+        // inf_depth_reverse_z_perspective, scene_view.cpp:13-27
+        const float t = 1.0f / std::tan(fov * 3.14159265358979f / 180.0f * 0.5f);
+        Mat4 proj{};
+        proj[0] = t / aspect; proj[5] = t; proj[11] = -1.0f; proj[14] = near_value;
+        std::memcpy(gpu_data.last_frame_projection, gpu_data.projection, 64);
+        std::memcpy(gpu_data.projection, proj.data(), 64);
+        std::memcpy(gpu_data.inverse_projection, mat_inverse(proj).data(), 64);
+        gpu_data.z_near = near_value;
+    }
+
+private:
+    float fov = 75.f, aspect = 16.f / 9.f, near_value = 0.05f, pitch = 0.f, yaw = 0.f;
+    Vec3 position{}, forward{};
+    sah_view_data gpu_data{};
+};
+
+// ---- DirectionalLight (RenderCore/render/directional_light.cpp:232-260, render_scene.cpp:25-27) ------------------------
+enum class SunShadowMode : uint32_t { Off = 0, CascadedShadowMaps = 1, RayTracing = 2 };
+class DirectionalLight {
+public:
+    DirectionalLight() {
+        set_direction({0.1f, -1.f, -1.f});
+        constants.color[0] = constants.color[1] = constants.color[2] = 80000.f;
+        constants.shadow_mode = (uint32_t)SunShadowMode::RayTracing;  // r.Shadow.SunShadowMode default
+        constants.num_shadow_samples = 8.f;
+    }
+    void set_direction(Vec3 d) {
+        const Vec3 n = v_normalize(d);
+        for (int i = 0; i < 3; i++) constants.direction_and_tan_size[i] = n[i];
+        constants.direction_and_tan_size[3] = std::tan(0.545f * 3.14159265358979f / 180.0f);
+    }
+    void set_shadow_mode(SunShadowMode m) { constants.shadow_mode = (uint32_t)m; }
+    SunShadowMode get_shadow_mode() const { return (SunShadowMode)constants.shadow_mode; }
+    sah_sun_light_constants& get_constants() { return constants; }
+    const sah_sun_light_constants& get_constants() const { return constants; }
+    TextureHandle shadowmap_handle = nullptr;  // D16 array, CSM mode
+    TextureHandle shadow_mask = nullptr;       // RT mode: visibility fraction written by the (external) ray query
+
+private:
+    sah_sun_light_constants constants{};
+};
+
+struct ProceduralSky {  // RenderCore/render/procedural_sky.hpp — only what the sky fill reads
+    TextureHandle transmittance_lut = nullptr, sky_view_lut = nullptr;
+};
+
+struct RenderScene {  // the slice of RenderCore/render/render_scene.hpp the hot path touches
+    DirectionalLight sun;
+    ProceduralSky sky;
+    DirectionalLight& get_sun_light() { return sun; }
+    ProceduralSky& get_sky() { return sky; }
+};
+
+// ---- GI plugin seam (RenderCore/render/gi/global_illuminator.hpp:18-45) ------------------------------------------------
+class IGlobalIlluminator {
+public:
+    virtual ~IGlobalIlluminator() = default;
+    virtual void pre_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, TextureHandle noise_tex) = 0;
+    virtual void post_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, const GBuffer& gbuffer, TextureHandle noise_tex) = 0;
+    // Stands in for render_to_lit_scene(): describes what the overlay binds; the Lighting pass draws it.
+    virtual void render_to_lit_scene(sah_gi& gi, TextureHandle ao_tex, TextureHandle noise_tex) const = 0;
+};
+
+// RenderCore/render/gi/light_propagation_volume.{hpp,cpp}: volumes :321-378, cascades :455-546, clear :839-926,
+// propagate :970-1063, overlay :274-306.  RSM raster / VPL injection are outside the hot path: inject() is the seam.
+class LightPropagationVolume : public IGlobalIlluminator {
+public:
+    explicit LightPropagationVolume(RenderBackend& backend, uint32_t cascades = 4, uint32_t steps = 32) : num_cascades(cascades), num_steps(steps) {
+        auto& alloc = backend.get_global_allocator();
+        const char* names[7] = {"LPV Red A", "LPV Green A", "LPV Blue A", "LPV Red B", "LPV Green B", "LPV Blue B", "Geometry Volume"};
+        for (int i = 0; i < 7; i++) vol[i] = alloc.create_volume_texture(names[i], SAH_FORMAT_R16G16B16A16_SFLOAT, 32 * cascades, 32, 32);
+    }
+    void update_cascade_transforms(const SceneView& view, const DirectionalLight&) {
+        for (uint32_t c = 0; c < num_cascades; c++) {
+            const float cell = 0.25f * std::pow(2.f, (float)c), size = 32.f * cell;
+            const Vec3 p = view.get_position(), f = view.get_forward();
+            Mat4 m = mat_identity();
+            for (int i = 0; i < 3; i++) {
+                const float off = p[i] + f[i] * (size * (0.5f - 0.1f));
+                const float snapped = std::round(off / (cell * 2.f)) * cell * 2.f;
+                m[i * 5] = 0.5f * (1.0f / size);                          // bias(0.5) * scale(1/size)
+                m[12 + i] = 0.5f * ((1.0f / size) * -snapped) + 0.5f;     // bias * scale * translate(-snapped) + 0.5
+            }
+            std::memcpy(cascades[c].world_to_cascade, m.data(), 64);
+            std::memcpy(cascades[c].cascade_to_world, mat_inverse(m).data(), 64);
+        }
+    }
+    void pre_render(RenderGraph& graph, const SceneView&, const RenderScene&, TextureHandle) override {
+        graph.add_pass({"LPV clear", [this](sah_ctx* ctx) {
+                            return sah_lpv_clear(ctx, &vol[0]->desc, &vol[1]->desc, &vol[2]->desc, &vol[6]->desc, num_cascades);
+                        }});
+    }
+    void post_render(RenderGraph& graph, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {
+        graph.add_pass({"LPV Propagation", [this](sah_ctx* ctx) {
+                            const sah_volume a[3] = {vol[0]->desc, vol[1]->desc, vol[2]->desc}, b[3] = {vol[3]->desc, vol[4]->desc, vol[5]->desc};
+                            return sah_lpv_propagate(ctx, a, b, num_cascades, num_steps);
+                        }});
+    }
+    void render_to_lit_scene(sah_gi& gi, TextureHandle, TextureHandle) const override {
+        gi.kind = SAH_GI_LPV;
+        gi.lpv_red = vol[0]->desc; gi.lpv_green = vol[1]->desc; gi.lpv_blue = vol[2]->desc;
+        gi.lpv_cascades = cascades.data();
+        gi.lpv_num_cascades = num_cascades;
+        gi.lpv_exposure = 3.1415927f * 10.f;  // r.GI.LPV.Exposure
+    }
+    TextureHandle get_volume(int channel, bool b = false) const { return vol[channel + (b ? 3 : 0)]; }
+
+private:
+    uint32_t num_cascades, num_steps;
+    TextureHandle vol[7]{};
+    std::array<sah_lpv_cascade_matrices, 4> cascades{};
+};
+
+// ---- LightingPhase (RenderCore/render/phase/lighting_phase.hpp:17-57, .cpp:34-134) -------------------------------------
+class LightingPhase {
+public:
+    void set_scene(RenderScene& scene_in) { scene = &scene_in; }
+    void render(RenderGraph& graph, const SceneView& view, const GBuffer& gbuffer, TextureHandle lit_scene_texture, TextureHandle ao_texture,
+                const IGlobalIlluminator* gi, std::optional<TextureHandle> /*vrsaa_shading_rate_image*/ = std::nullopt, TextureHandle noise_2d = nullptr) {
+        if (scene == nullptr) return;  // silent no-op, lighting_phase.cpp:47-49
+        graph.add_pass({"Lighting", [&, lit_scene_texture, ao_texture, gi, noise_2d](sah_ctx* ctx) {
+                            const sah_gbuffer g = {gbuffer.color->plane(), gbuffer.normals->plane(), gbuffer.data->plane(), gbuffer.emission->plane(),
+                                                   gbuffer.depth->plane()};
+                            const sah_plane lit = lit_scene_texture->plane();
+                            sah_plane ao{}, mask{};
+                            sah_gi gi_desc{};
+                            sah_sky_luts sky{};
+                            sah_lighting_desc d{};
+                            d.gbuffer = &g;
+                            d.lit = &lit;
+                            if (ao_texture) { ao = ao_texture->plane(); d.ao = &ao; }
+                            d.view = &view.get_gpu_data();
+                            auto& sun = scene->get_sun_light();
+                            d.sun = &sun.get_constants();
+                            if (sun.shadowmap_handle) d.shadowmap = &sun.shadowmap_handle->desc;
+                            if (sun.shadow_mask) { mask = sun.shadow_mask->plane(); d.shadow_mask = &mask; }
+                            if (gi) { gi->render_to_lit_scene(gi_desc, ao_texture, noise_2d); d.gi = &gi_desc; }
+                            if (scene->get_sky().sky_view_lut && scene->get_sky().transmittance_lut) {
+                                sky = {scene->get_sky().transmittance_lut->plane(), scene->get_sky().sky_view_lut->plane()};
+                                d.sky = &sky;
+                            }
+                            d.flags = SAH_LIGHTING_DEFAULT_FLAGS;
+                            return sah_lighting(ctx, &d);
+                        }});
+    }
+
+private:
+    RenderScene* scene = nullptr;
+};
+
+// ---- Bloomer (RenderCore/render/bloomer.hpp:15-17, .cpp:38-285) -----------------------------------------------------------
+class Bloomer {
+public:
+    explicit Bloomer(RenderBackend& backend_in) : backend(backend_in) {}
+    void fill_bloom_tex(RenderGraph& graph, TextureHandle scene_color) {
+        if (mips.empty()) create_bloom_tex(scene_color);
+        graph.add_pass({"Bloom", [this, scene_color](sah_ctx* ctx) {
+                            const sah_plane s = scene_color->plane();
+                            return sah_bloom(ctx, &s, &chain);
+                        }});
+    }
+    const sah_mipchain& get_bloom_tex() const { return chain; }
+
+private:
+    void create_bloom_tex(TextureHandle scene_color) {  // bloomer.cpp:268-285: scene/2, six mips, scene format
+        uint32_t w = scene_color->desc.width / 2, h = scene_color->desc.height / 2;
+        chain.num_mips = 6;  // r.bloom.NumMips
+        for (uint32_t m = 0; m < chain.num_mips; m++) {
+            mips.push_back(backend.get_global_allocator().create_texture("Bloom texture mip " + std::to_string(m), SAH_FORMAT_R16G16B16A16_SFLOAT,
+                                                                          w ? w : 1, h ? h : 1));
+            chain.mips[m] = mips.back()->plane();
+            w = w / 2 ? w / 2 : 1;
+            h = h / 2 ? h / 2 : 1;
+        }
+    }
+    RenderBackend& backend;
+    std::vector<TextureHandle> mips;
+    sah_mipchain chain{};
+};
+
+// ---- UiPhase::draw_scene_image (RenderCore/render/phase/ui_phase.hpp:27, .cpp:98-113) -------------------------------------
+class UiPhase {
+public:
+    void set_resources(TextureHandle scene_color_in, TextureHandle swapchain_in) { scene_color = scene_color_in; swapchain = swapchain_in; }
+    void render(RenderGraph& graph, const SceneView&, const sah_mipchain& bloom_texture) const {
+        graph.add_pass({"UI", [this, &bloom_texture](sah_ctx* ctx) {
+                            const sah_plane s = scene_color->plane(), o = swapchain->plane();
+                            return sah_tonemap(ctx, &s, &bloom_texture, &o, 0, 0);
+                        }});
+    }
+
+private:
+    TextureHandle scene_color = nullptr, swapchain = nullptr;
+};
+
+// "Copy scene" (AA = None), RenderCore/render/scene_renderer.cpp:502-527
+inline void evaluate_antialiasing_none(RenderGraph& graph, TextureHandle lit_scene, TextureHandle antialiased_scene) {
+    graph.add_pass({"Copy scene", [lit_scene, antialiased_scene](sah_ctx* ctx) {
+                        const sah_plane a = lit_scene->plane(), b = antialiased_scene->plane();
+                        return sah_copy_scene(ctx, &a, &b);
+                    }});
+}
+
+}  // namespace sah

@@ -1,0 +1,104 @@
+// Renders one frame through the C++ host façade (include/sah_host.hpp), the way SceneRenderer::render drives the
+// reference's phases (RenderCore/render/scene_renderer.cpp:365-449): GI post_render -> lighting -> copy scene -> bloom
+// -> UI/tonemap.  Inputs come from a file written by tests/test_host_facade_gpu.py; the uniform blocks this program
+// builds are written back with the images so that the test can feed the very same blocks to the oracle.
+//
+//   host_frame <in.bin> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "sah_host.hpp"
+
+static std::vector<unsigned char> read_blob(FILE* f, size_t n) {
+    std::vector<unsigned char> v(n);
+    if (fread(v.data(), 1, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) { fprintf(stderr, "usage: host_frame in.bin out.bin\n"); return 2; }
+    FILE* in = fopen(argv[1], "rb");
+    if (!in) { perror("open input"); return 2; }
+    uint32_t hdr[4];
+    if (fread(hdr, 4, 4, in) != 4) return 2;
+    const uint32_t W = hdr[0], H = hdr[1], sun_mode = hdr[2], lpv_steps = hdr[3];
+
+    using namespace sah;
+    RenderBackend backend(0);
+    auto& alloc = backend.get_global_allocator();
+
+    GBuffer gbuffer;
+    gbuffer.color = alloc.create_texture("gbuffer_color", SAH_FORMAT_R8G8B8A8_SRGB, W, H);
+    gbuffer.normals = alloc.create_texture("gbuffer_normals", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    gbuffer.data = alloc.create_texture("gbuffer_data", SAH_FORMAT_R8G8B8A8_UNORM, W, H);
+    gbuffer.emission = alloc.create_texture("gbuffer_emission", SAH_FORMAT_R8G8B8A8_SRGB, W, H);
+    gbuffer.depth = alloc.create_texture("gbuffer_depth", SAH_FORMAT_D32_SFLOAT, W, H);
+    TextureHandle ao = alloc.create_texture("ao", SAH_FORMAT_R32_SFLOAT, W, H);
+    TextureHandle mask = alloc.create_texture("sun shadow mask", SAH_FORMAT_R32_SFLOAT, W, H);
+    TextureHandle lit_scene = alloc.create_texture("lit_scene", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    TextureHandle antialiased = alloc.create_texture("antialiased_scene", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    TextureHandle swapchain = alloc.create_texture("swapchain", SAH_FORMAT_R8G8B8A8_SRGB, W, H);
+
+    RenderScene scene;
+    scene.sky.transmittance_lut = alloc.create_texture("Transmittance LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 256, 64);
+    scene.sky.sky_view_lut = alloc.create_texture("Sky view LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 200, 200);
+    scene.sun.set_shadow_mode((SunShadowMode)sun_mode);
+    scene.sun.shadow_mask = mask;
+
+    auto up = [&](TextureHandle t, uint32_t bpp) {
+        auto blob = read_blob(in, (size_t)t->desc.width * t->desc.height * t->desc.depth * bpp);
+        alloc.upload(t, blob.data(), t->desc.width * bpp);
+    };
+    up(gbuffer.color, 4); up(gbuffer.normals, 8); up(gbuffer.data, 4); up(gbuffer.emission, 4); up(gbuffer.depth, 4);
+    up(ao, 4); up(mask, 4);
+    up(scene.sky.transmittance_lut, 8); up(scene.sky.sky_view_lut, 8);
+
+    SceneView view;  // start-up camera of the reference: scene_renderer.cpp:53-54,105-116
+    view.rotate(0.f, 90.f * 3.14159265358979f / 180.f);
+    view.set_position({-7.f, 1.f, 0.f});
+    view.set_render_resolution(W, H);
+    view.set_perspective_projection(75.f, (float)W / (float)H, 0.05f);
+    view.update_transforms();
+
+    LightPropagationVolume lpv(backend, 4, lpv_steps);
+    lpv.update_cascade_transforms(view, scene.sun);
+    for (int c = 0; c < 3; c++) up(lpv.get_volume(c), 8);  // stands in for RSM/VPL injection (raster, out of scope)
+
+    LightingPhase lighting;
+    lighting.set_scene(scene);
+    Bloomer bloomer(backend);
+    UiPhase ui;
+    ui.set_resources(antialiased, swapchain);
+
+    RenderGraph graph{backend};
+    const IGlobalIlluminator* gi = &lpv;
+    lpv.post_render(graph, view, scene, gbuffer, nullptr);
+    lighting.render(graph, view, gbuffer, lit_scene, ao, gi);
+    evaluate_antialiasing_none(graph, lit_scene, antialiased);
+    bloomer.fill_bloom_tex(graph, antialiased);
+    ui.render(graph, view, bloomer.get_bloom_tex());
+    graph.finish();
+    for (const auto& e : graph.get_errors()) fprintf(stderr, "pass failed: %s\n", e.c_str());
+    if (!graph.get_errors().empty()) return 1;
+
+    FILE* out = fopen(argv[2], "wb");
+    if (!out) { perror("open output"); return 2; }
+    sah_gi gi_desc{};
+    lpv.render_to_lit_scene(gi_desc, ao, nullptr);
+    fwrite(&view.get_gpu_data(), sizeof(sah_view_data), 1, out);
+    fwrite(&scene.sun.get_constants(), sizeof(sah_sun_light_constants), 1, out);
+    fwrite(gi_desc.lpv_cascades, sizeof(sah_lpv_cascade_matrices), 4, out);
+    std::vector<unsigned char> buf((size_t)W * H * 8);
+    for (int c = 0; c < 3; c++) {  // propagated LPV (A volumes)
+        std::vector<unsigned char> v((size_t)128 * 32 * 32 * 8);
+        alloc.download(lpv.get_volume(c), v.data(), 128 * 8);
+        fwrite(v.data(), 1, v.size(), out);
+    }
+    alloc.download(lit_scene, buf.data(), W * 8);
+    fwrite(buf.data(), 1, (size_t)W * H * 8, out);
+    alloc.download(swapchain, buf.data(), W * 4);
+    fwrite(buf.data(), 1, (size_t)W * H * 4, out);
+    fclose(out);
+    return 0;
+}

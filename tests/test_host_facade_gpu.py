@@ -1,0 +1,98 @@
+"""GPU: one frame through the C++ host façade (include/sah_host.hpp, tests/cpp/host_frame.cpp) — LPV propagate →
+lighting → copy scene → bloom → tonemap — compared with the oracle running the same chain on the uniform blocks the
+C++ program produced."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, scene, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "host_frame")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "cpp", "host_frame.cpp")
+    if os.path.exists(EXE) and os.path.getmtime(EXE) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "sah_host.hpp"))):
+        return
+    libdir = os.path.join(ROOT, "androidrenderer_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", EXE, "-L", libdir,
+                           "-lsah_hip", f"-Wl,-rpath,{libdir}"])
+
+
+@pytest.mark.parametrize("sun_mode", [_abi.SHADOW_MODE_RT])
+def test_frame_through_cpp_facade(tmp_path, sun_mode):
+    _build()
+    W, H, steps = 192, 108, 4
+    view = scene.SceneView.default(W, H)
+    g = synth.atrium_gbuffer(W, H, view, seed=2)
+    ao = synth.ao_plane(W, H, 3)
+    mask = synth.shadow_mask(W, H, 4)
+    luts = synth.sky_luts(7)
+    vols = [v.view(np.uint16) for v in synth.lpv_volumes(4, 5)]
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(np.array([W, H, sun_mode, steps], dtype=np.uint32).tobytes())
+        for a in (g["color"], g["normals"], g["data"], g["emission"], g["depth"], ao, mask, luts["transmittance"], luts["sky_view"], *vols):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([EXE, str(inp), str(outp)])
+    blob = open(outp, "rb").read()
+    off = 0
+
+    def take(n):
+        nonlocal off
+        b = blob[off:off + n]
+        off += n
+        return b
+
+    view_c = _abi.ViewData.from_buffer_copy(take(432))
+    sun_c = _abi.SunLightConstants.from_buffer_copy(take(640))
+    casc = (_abi.LpvCascadeMatrices * 4).from_buffer_copy(take(1024))
+    lpv_out = [np.frombuffer(take(128 * 32 * 32 * 8), dtype=np.uint16).reshape(32, 32, 128, 4) for _ in range(3)]
+    lit = np.frombuffer(take(W * H * 8), dtype=np.uint16).reshape(H, W, 4)
+    final = np.frombuffer(take(W * H * 4), dtype=np.uint8).reshape(H, W, 4)
+
+    o = util.oracle()
+    # 1. LPV propagation
+    a_np = [v.copy() for v in vols]
+    b_np = [np.zeros_like(v) for v in vols]
+    a_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in a_np])
+    b_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in b_np])
+    assert o.orc_lpv_propagate(a_v, b_v, 4, steps) == 0
+    for c in range(3):
+        assert np.array_equal(lpv_out[c], a_np[c])
+    # 2. lighting with the blocks the C++ façade built
+    fr = util.LightingFrame(W, H, gbuffer=g, seed=0, sun_mode=sun_mode, gi=_abi.GI_LPV)
+    fr.arrays["ao"], fr.arrays["shadow_mask"] = ao, mask
+    fr.arrays["sky_t"], fr.arrays["sky_v"] = luts["transmittance"], luts["sky_view"]
+    fr.arrays["lpv_r"], fr.arrays["lpv_g"], fr.arrays["lpv_b"] = a_np
+    fr.view.gpu_data = view_c
+    fr.sun.constants = sun_c
+    fr.lpv.matrices = casc
+    ref_lit = fr.run_oracle()
+    d = util.f16_ulp_diff(lit, ref_lit)
+    print(util.report_ulp("façade lit_scene", d))
+    assert d.max() <= 1
+    # 3. post chain
+    aa = np.zeros_like(ref_lit)
+    sp, ap = images.plane(ref_lit, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_copy_scene(C.byref(sp), C.byref(ap)) == 0
+    mips = [np.zeros((mh, mw, 4), dtype=np.uint16) for (mw, mh) in images.bloom_mip_sizes(W, H, 6)]
+    chain = images.mipchain(mips)
+    assert o.orc_bloom(C.byref(ap), C.byref(chain)) == 0
+    out = np.zeros((H, W, 4), dtype=np.uint8)
+    op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    assert o.orc_tonemap(C.byref(ap), C.byref(chain), C.byref(op), 0, 0) == 0
+    dc = np.abs(final.astype(np.int32) - out.astype(np.int32))
+    print(f"façade final image: max code diff {dc.max()}, {int((dc > 0).sum())} differ")
+    assert dc.max() <= 1
+    # the camera the C++ SceneView builds is the reference's start-up camera, like scene.py's
+    assert np.allclose(np.array(view_c.view[:]), np.array(view.gpu_data.view[:]), atol=1e-5)
+    assert math.isclose(view_c.inverse_projection[0], view.gpu_data.inverse_projection[0], rel_tol=1e-5)
