@@ -174,6 +174,7 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->luts) (void)hipFree(ctx->luts);
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);
+    if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -21,6 +21,35 @@ bool rgba16f_ok(const sah_plane* p) {
     return p && p->ptr && p->format == SAH_FORMAT_R16G16B16A16_SFLOAT && p->width && p->height &&
            (uint64_t)p->row_pitch_bytes >= (uint64_t)p->width * 8 && ((uintptr_t)p->ptr % 8) == 0 && (p->row_pitch_bytes % 8) == 0;
 }
+// Output code of the tonemap tail for one channel value x = colour * luma/(luma+1):
+// pow(x, 1/2.2) (fp32 result of the fp64 libm value), then the sRGB OETF the swap chain applies, then UNORM8
+// (scene_upsample.frag:66-72 + hardware sRGB write; DESIGN.md "Numerics").  Monotone non-decreasing in x.
+uint32_t tonemap_code(float x) {
+    if (!(x > 0.0f)) return 0u;
+    const float g = (float)std::pow((double)x, (double)(1.f / 2.2f));
+    if (!(g > 0.0f)) return 0u;
+    if (g >= 1.0f) return 255u;
+    const double d = (double)g;
+    const float s = (float)((d <= 0.0031308) ? 12.92 * d : 1.055 * std::pow(d, 1.0 / 2.4) - 0.055);
+    if (!(s > 0.0f)) return 0u;
+    if (s >= 1.0f) return 255u;
+    return (uint32_t)(s * 255.0f + 0.5f);
+}
+// thr[k] = smallest positive float whose code is >= k, found by bisection on the bit pattern (positive floats order like
+// their bits); thr[0] is never read.
+void build_tonemap_thresholds(float thr[256]) {
+    thr[0] = 0.0f;
+    for (uint32_t k = 1; k < 256; k++) {
+        uint32_t lo = 0u, hi = 0x7f800000u;  // code(+0) = 0 < k <= 255 = code(+inf)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            float f;
+            memcpy(&f, &mid, 4);
+            if (tonemap_code(f) >= k) hi = mid; else lo = mid;
+        }
+        memcpy(&thr[k], &hi, 4);
+    }
+}
 bool lpv_vol_ok(const sah_volume* v) {
     return v && v->ptr && v->format == SAH_FORMAT_R16G16B16A16_SFLOAT && (uint64_t)v->row_pitch_bytes >= (uint64_t)v->width * 8 &&
            (uint64_t)v->slice_pitch_bytes >= (uint64_t)v->row_pitch_bytes * v->height && ((uintptr_t)v->ptr % 8) == 0 &&
@@ -76,6 +105,14 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom,
         t.mip_w[m] = bloom->mips[m].width;
         t.mip_h[m] = bloom->mips[m].height;
     }
+    if (!ctx->tm_thresholds) {  // built once per context (~15k libm pow calls)
+        float thr[256];
+        build_tonemap_thresholds(thr);
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_thresholds, sizeof(thr)));
+        HIP_TRY(ctx, hipMemcpy(ctx->tm_thresholds, thr, sizeof(thr), hipMemcpyHostToDevice));
+    }
+    t.thresholds = ctx->tm_thresholds;
     t.out = parg(out);
     t.out_w = out->width;
     t.out_h = out->height;

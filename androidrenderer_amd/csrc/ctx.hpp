@@ -23,6 +23,7 @@ struct sah_ctx {
     uint32_t* list = nullptr;          // device: deferred-pixel list
     size_t list_bytes = 0;
     uint32_t parity = 0;
+    float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds (api_post.cpp)
     std::string last_error;
 };
 

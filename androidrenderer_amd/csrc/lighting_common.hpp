@@ -326,19 +326,21 @@ SAH_DEV void lpv_fetch_fast(const LpvArgs& L, float u, float v, float w, const F
         off[k] = zo[k >> 2] + yo[(k >> 1) & 1] + xo[k & 1];
     }
     const uint8_t* vols[3] = {L.red.ptr, L.green.ptr, L.blue.ptr};
-    half4_t t[3][8];
+    uint2 t[3][8];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[c][k] = *reinterpret_cast<const half4_t*>(vols[c] + off[k]);
+        for (int k = 0; k < 8; k++) t[c][k] = *reinterpret_cast<const uint2*>(vols[c] + off[k]);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = __builtin_fmaf(wt[k], (float)t[c][k][j], a[j]);
+            a[0] = fma_mix_lo(wt[k], t[c][k].x, a[0]);
+            a[1] = fma_mix_hi(wt[k], t[c][k].x, a[1]);
+            a[2] = fma_mix_lo(wt[k], t[c][k].y, a[2]);
+            a[3] = fma_mix_hi(wt[k], t[c][k].y, a[3]);
         }
         out[c] = dot4(a, n);
     }

@@ -19,6 +19,21 @@ SAH_DEV uint16_t f2h(float f) {  // v_cvt_f16_f32, RNE; the asm keeps LLVM from 
     return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
+// fma(w, (float)half, acc) with the fp16 operand read straight from the low / high half of a packed dword:
+// v_fma_mix_f32 (VOP3P; op_sel_hi marks src1 as f16, op_sel picks its half).  One instruction per tap and channel —
+// hipcc otherwise emits v_cvt_f32_f16 pairs feeding v_pk_fma_f32 (1.5 issue slots per fma).  Same arithmetic as
+// __builtin_fmaf(w, (float)h, acc): the conversion is exact and the fma is IEEE fp32.
+SAH_DEV float fma_mix_lo(float w, uint32_t packed, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(acc));
+    return r;
+}
+SAH_DEV float fma_mix_hi(float w, uint32_t packed, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(acc));
+    return r;
+}
+
 // ---- number models ------------------------------------------------------------------------------
 // fp32: plain float.  fp16: value kept in a _Float16; + - * are native v_*_f16 (exact result, one rounding),
 // divide and sqrt go through fp32 (correctly rounded there; the second rounding to fp16 is innocuous because

@@ -129,21 +129,129 @@ SAH_DEV uint32_t encode_srgb8(float c) {
     return (uint32_t)(s * 255.0f + 0.5f);
 }
 
+// One axis of a CLAMP_TO_EDGE bilinear tap: clamped texel indices and the two weights (1-f, f).
+struct Axis {
+    int i0, i1;
+    float w0, w1;
+};
+SAH_DEV Axis axis_setup(float coord, uint32_t size) {
+    const float p = coord * (float)size - 0.5f;
+    const float f0 = __builtin_floorf(p);
+    const float f = p - f0;
+    const int i = (int)__builtin_fminf(__builtin_fmaxf(f0, -1.0e9f), 1.0e9f);
+    Axis a;
+    a.i0 = min(max(i, 0), (int)size - 1);
+    a.i1 = min(max(i + 1, 0), (int)size - 1);
+    a.w0 = 1.0f - f;
+    a.w1 = f;
+    return a;
+}
+
+// One tent tap = one bilinear sample from texels held in LDS (8 bytes each, row stride `stride` texels):
+// acc = fma(w_k, t_k, acc) from +0 in tap order (t00, t10, t01, t11), conversions folded into v_fma_mix_f32.
+SAH_DEV C3 tap_lds(const uint2* tile, int stride, int x_org, int y_org, const Axis& ax, const Axis& ay) {
+    const uint2* r0 = tile + (ay.i0 - y_org) * stride - x_org;
+    const uint2* r1 = tile + (ay.i1 - y_org) * stride - x_org;
+    const uint2 t00 = r0[ax.i0], t10 = r0[ax.i1], t01 = r1[ax.i0], t11 = r1[ax.i1];
+    const float w00 = ax.w0 * ay.w0, w10 = ax.w1 * ay.w0, w01 = ax.w0 * ay.w1, w11 = ax.w1 * ay.w1;
+    C3 c;
+    c.r = fma_mix_lo(w11, t11.x, fma_mix_lo(w01, t01.x, fma_mix_lo(w10, t10.x, fma_mix_lo(w00, t00.x, 0.0f))));
+    c.g = fma_mix_hi(w11, t11.x, fma_mix_hi(w01, t01.x, fma_mix_hi(w10, t10.x, fma_mix_hi(w00, t00.x, 0.0f))));
+    c.b = fma_mix_lo(w11, t11.y, fma_mix_lo(w01, t01.y, fma_mix_lo(w10, t10.y, fma_mix_lo(w00, t00.y, 0.0f))));
+    return c;
+}
+
+// Tonemap composite, LDS-staged.  A 256-thread workgroup produces a 32x8 output tile.  For every bloom mip the texel
+// rectangle the tile can touch (tile bounds mapped into the mip, plus the reach of the tent offsets — which are -ix, -iy
+// and +ix in x and +ix, +-iy in y because scene_upsample.frag:29-32 mixes the components of `o`) is copied into LDS once;
+// every thread then evaluates its 9 taps x 6 mips from LDS with the 4+4 distinct axis set-ups per mip computed once.
+// A thread whose indices fall outside the staged rectangle (never for in-range tiles; kept as a guarantee) takes the
+// global-memory path for that mip.  Same operator sequence per tap as tent_blur(): results are bit-identical.
+constexpr int kTmTileW = 32, kTmTileH = 8;
+constexpr int kTmMip0Texels = 640, kTmMipTexels = 224, kTmLdsTexels = kTmMip0Texels + 5 * kTmMipTexels;
+
 __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = t.row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ uint2 s_tex[kTmLdsTexels];
+    __shared__ int s_rect[6][5];  // x0, y0, w, h, lds offset (w == 0: not staged)
+    __shared__ float s_thr[256];  // s_thr[k] = smallest x whose output code is >= k (k = 1..255); s_thr[0] unused
+    s_thr[threadIdx.x] = t.thresholds[threadIdx.x];
+    const uint32_t bx = blockIdx.x * kTmTileW, by = t.row_begin + blockIdx.y * kTmTileH;
+    if (threadIdx.x < 6) {
+        const uint32_t m = threadIdx.x;
+        int* r = s_rect[m];
+        r[0] = r[1] = r[2] = r[3] = 0;
+        r[4] = m == 0 ? 0 : kTmMip0Texels + (int)(m - 1) * kTmMipTexels;
+        if (m < t.num_mips) {
+            const float W = (float)t.mip_w[m], H = (float)t.mip_h[m];
+            const uint32_t x_last = min(bx + kTmTileW - 1, t.out_w - 1), y_last = min(by + kTmTileH - 1, t.row_end - 1);
+            // conservative texel bounds: tile extent in mip texels, widened by the largest tap offset (in texels) + 2
+            const float reach_x = __builtin_fmaxf(1.0f, W / H) + 2.0f, reach_y = __builtin_fmaxf(1.0f, H / W) + 2.0f;
+            const float pu0 = ((float)bx + 0.5f) / (float)t.out_w * W - 0.5f, pu1 = ((float)x_last + 0.5f) / (float)t.out_w * W - 0.5f;
+            const float pv0 = (1.0f - ((float)y_last + 0.5f) / (float)t.out_h) * H - 0.5f, pv1 = (1.0f - ((float)by + 0.5f) / (float)t.out_h) * H - 0.5f;
+            const int x0 = max((int)__builtin_floorf(pu0 - reach_x), 0), x1 = min((int)__builtin_floorf(pu1 + reach_x) + 1, (int)t.mip_w[m] - 1);
+            const int y0 = max((int)__builtin_floorf(pv0 - reach_y), 0), y1 = min((int)__builtin_floorf(pv1 + reach_y) + 1, (int)t.mip_h[m] - 1);
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            if (w > 0 && h > 0 && w * h <= (m == 0 ? kTmMip0Texels : kTmMipTexels)) {
+                r[0] = x0; r[1] = y0; r[2] = w; r[3] = h;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) {
+        const int x0 = s_rect[m][0], y0 = s_rect[m][1], w = s_rect[m][2], h = s_rect[m][3], off = s_rect[m][4];
+        for (int i = threadIdx.x; i < w * h; i += 256) {
+            const int ty = i / w, tx = i - ty * w;
+            s_tex[off + i] = *reinterpret_cast<const uint2*>(t.mips[m].ptr + (size_t)(y0 + ty) * t.mips[m].pitch + (size_t)(x0 + tx) * 8);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t x = bx + (threadIdx.x & (kTmTileW - 1)), y = by + threadIdx.x / kTmTileW;
     if (x >= t.out_w || y >= t.row_end) return;
     const float u = ((float)x + 0.5f) / (float)t.out_w;
     const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
     C3 bloom = {0.f, 0.f, 0.f};
-    for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) bloom = bloom + tent_blur(t.mips[m], t.mip_w[m], t.mip_h[m], u, v);
+    for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) {
+        const uint32_t W = t.mip_w[m], H = t.mip_h[m];
+        const float ix = 1.0f / (float)W, iy = 1.0f / (float)H;
+        const float ox = ix * -1.0f, oy = iy * -1.0f, oz = ix * 1.0f, ow = iy * 1.0f;
+        // distinct coordinates of the nine taps (scene_upsample.frag:28-36): x in {u, u+ox, u+oy, u+oz}, y in {v, v+oz, v+ow, v+oy}
+        const Axis xa = axis_setup(u, W), xb = axis_setup(u + ox, W), xc = axis_setup(u + oy, W), xd = axis_setup(u + oz, W);
+        const Axis ya = axis_setup(v + 0.f, H), yb = axis_setup(v + oz, H), yc = axis_setup(v + ow, H), yd = axis_setup(v + oy, H);
+        const int rx0 = s_rect[m][0], ry0 = s_rect[m][1], rw = s_rect[m][2], rh_ = s_rect[m][3];
+        const int xmin = min(min(xa.i0, xb.i0), min(xc.i0, xd.i0)), xmax = max(max(xa.i1, xb.i1), max(xc.i1, xd.i1));
+        const int ymin = min(min(ya.i0, yb.i0), min(yc.i0, yd.i0)), ymax = max(max(ya.i1, yb.i1), max(yc.i1, yd.i1));
+        C3 s;
+        if (rw > 0 && xmin >= rx0 && xmax < rx0 + rw && ymin >= ry0 && ymax < ry0 + rh_) {
+            const uint2* tile = s_tex + s_rect[m][4];
+            // (u + 0.f is u; the centre column re-uses xa, the centre row re-uses ya)
+            s = tap_lds(tile, rw, rx0, ry0, xa, ya) * 4.0f + tap_lds(tile, rw, rx0, ry0, xb, ya) * 2.0f + tap_lds(tile, rw, rx0, ry0, xc, ya) * 2.0f +
+                tap_lds(tile, rw, rx0, ry0, xa, yb) * 2.0f + tap_lds(tile, rw, rx0, ry0, xa, yc) * 2.0f + tap_lds(tile, rw, rx0, ry0, xb, yd) * 1.0f +
+                tap_lds(tile, rw, rx0, ry0, xd, yd) * 1.0f + tap_lds(tile, rw, rx0, ry0, xb, yc) * 1.0f + tap_lds(tile, rw, rx0, ry0, xd, yc) * 1.0f;
+            s = {s.r / 16.f, s.g / 16.f, s.b / 16.f};
+        } else {
+            s = tent_blur(t.mips[m], W, H, u, v);
+        }
+        bloom = bloom + s;
+    }
     const Rgba sc = bilinear<ADDR_CLAMP>(t.scene, t.scene_w, t.scene_h, u, v);
     const C3 c = {sc.c[0] + bloom.r * 0.014159f, sc.c[1] + bloom.g * 0.014159f, sc.c[2] + bloom.b * 0.014159f};
     const float luma = c.r * 0.2126f + c.g * 0.7152f + c.b * 0.0722f;
     const float factor = luma / (luma + 1.f);
     const C3 mapped = c * factor;
-    const double e = (double)(1.f / 2.2f);
-    const float rgb[3] = {(float)pow((double)mapped.r, e), (float)pow((double)mapped.g, e), (float)pow((double)mapped.b, e)};
-    const uint32_t px = encode_srgb8(rgb[0]) | (encode_srgb8(rgb[1]) << 8) | (encode_srgb8(rgb[2]) << 16) | (255u << 24);
+    // pow(x, 1/2.2) -> sRGB OETF -> UNORM8 is a monotone map from fp32 to 256 codes: the host tabulates, by bisection on the
+    // exact composite (api_post.cpp: tonemap_code), the smallest input that reaches each code; the device counts thresholds.
+    // Two fp64 pow() per channel (~600 issue slots) become an 8-step binary search in LDS.
+    const float rgb[3] = {mapped.r, mapped.g, mapped.b};
+    uint32_t code[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        uint32_t lo = 0;  // invariant: threshold[lo] <= x, with threshold[0] = -inf; NaN compares false everywhere -> code 0
+#pragma unroll
+        for (uint32_t step = 128; step >= 1; step >>= 1) lo = (rgb[ch] >= s_thr[lo + step]) ? lo + step : lo;
+        code[ch] = lo;
+    }
+    const uint32_t px = code[0] | (code[1] << 8) | (code[2] << 16) | (255u << 24);
     *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(t.out.ptr) + (size_t)y * t.out.pitch + (size_t)x * 4) = px;
 }
 
@@ -161,7 +269,7 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st) {
     const uint32_t rows = t.row_end - t.row_begin;
     if (rows == 0) return hipSuccess;
-    const dim3 grid((t.out_w + 63) / 64, (rows + 3) / 4);
+    const dim3 grid((t.out_w + kTmTileW - 1) / kTmTileW, (rows + kTmTileH - 1) / kTmTileH);
     hipLaunchKernelGGL(k_tonemap, grid, dim3(256), 0, st, t);
     return hipGetLastError();
 }

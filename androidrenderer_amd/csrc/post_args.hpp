@@ -14,6 +14,7 @@ struct TonemapArgs {
     PlaneArg out;
     uint32_t out_w, out_h;
     uint32_t row_begin, row_end;
+    const float* thresholds;  // device, 256 floats: see api_post.cpp tonemap_code()
 };
 
 }  // namespace sah

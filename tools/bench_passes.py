@@ -1,0 +1,102 @@
+"""Times every C-ABI pass at a given resolution on one GPU (HIP events on the launch stream) and prints achieved
+algorithmic GB/s next to the 8 TB/s HBM roofline.  Diagnostic companion of bench.py (which owns the headline number).
+
+    python tools/bench_passes.py [--width 3840 --height 2160 --iters 50]
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--lights", type=int, default=256)
+    ap.add_argument("--light-radius", type=float, default=4.0)
+    args = ap.parse_args()
+    import torch
+
+    from androidrenderer_amd import _abi, images, lib, synth
+    from tests import util
+
+    W, H = args.width, args.height
+    ctx = lib.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    px = W * H
+    results = {}
+
+    def timeit(name, fn, bytes_per_call):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        results[name] = {"ms": round(ms, 4), "Mpx_s": round(px / ms / 1e3, 1), "GB_s": round(bytes_per_call / ms / 1e6, 1),
+                         "hbm_frac": round(bytes_per_call / ms / 1e6 / 8000.0, 4)}
+        print(f"{name:34s} {ms:9.4f} ms  {px / ms / 1e3:10.1f} Mpx/s  {bytes_per_call / ms / 1e6:8.1f} GB/s ({bytes_per_call / ms / 1e6 / 80.0:5.1f} % of 8 TB/s)", flush=True)
+
+    # ---- lighting variants ----------------------------------------------------------------------------
+    def lighting_case(name, sun, gi, flavour, bpp, lights=None, flags=_abi.LIGHTING_DEFAULT_FLAGS, general=False):
+        f = util.LightingFrame(W, H, seed=2, sun_mode=sun, gi=gi, flavour=flavour, shadowmap_res=4096, lights=lights, flags=flags)
+        dev = f.device_arrays()
+        lit = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+        d, keep = f.describe(dev, lit)
+        ctx.debug_set(force_general=general)
+        timeit(name, lambda: ctx.lighting(d), bpp * px)
+        ctx.debug_set(force_general=False)
+        return lit
+
+    lighting_case("lighting CSM+LPV atrium (fast)", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, "atrium", 36)
+    lighting_case("lighting CSM+LPV random (fast)", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, "random", 36)
+    lighting_case("lighting CSM only atrium (fast)", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, "atrium", 32)
+    lighting_case("lighting RT only atrium (fast)", _abi.SHADOW_MODE_RT, _abi.GI_NONE, "atrium", 36)
+    lighting_case("lighting RT+LPV atrium (fast)", _abi.SHADOW_MODE_RT, _abi.GI_LPV, "atrium", 40)
+    lighting_case("lighting off/none atrium (fast)", _abi.SHADOW_MODE_OFF, _abi.GI_NONE, "atrium", 32)
+    lighting_case("lighting RT+cache atrium (tiled)", _abi.SHADOW_MODE_RT, _abi.GI_CACHE, "atrium", 36)
+    lighting_case("lighting RT+rtgi atrium (tiled)", _abi.SHADOW_MODE_RT, _abi.GI_RTGI, "atrium", 52)
+    from androidrenderer_amd import scene
+    view = scene.SceneView.default(W, H)
+    pl = synth.point_lights(view, args.lights, args.light_radius, seed=8)
+    lighting_case(f"lighting CSM + {args.lights} lights (tiled)", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, "atrium", 32, lights=pl)
+
+    # ---- post chain -------------------------------------------------------------------------------------
+    scene_img = util.to_torch(synth.hdr_scene(W, H, seed=11).view(np.uint16))
+    sp = images.plane(scene_img, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    aa = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    ap_ = images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    timeit("copy scene", lambda: ctx.copy_scene(sp, ap_), 16 * px)
+    mips = [torch.zeros((mh, mw, 4), dtype=torch.int16, device="cuda") for (mw, mh) in images.bloom_mip_sizes(W, H, 6)]
+    chain = images.mipchain(mips)
+    timeit("bloom chain (6 mips)", lambda: ctx.bloom(sp, chain), int((8 + 2.667 + 2.667) * px))
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    timeit("tonemap composite", lambda: ctx.tonemap(sp, chain, op), int((8 + 4 + 2.667) * px))
+
+    # ---- LPV maintenance ----------------------------------------------------------------------------------
+    vols = synth.lpv_volumes(4, 5)
+    a_t = [util.to_torch(v.view(np.uint16)) for v in vols]
+    b_t = [torch.zeros_like(t) for t in a_t]
+    av = [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in a_t]
+    bv = [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in b_t]
+    timeit("lpv propagate x32", lambda: ctx.lpv_propagate(av, bv, 4, 32), 32 * 6 * 1024 * 1024)
+    timeit("lpv clear", lambda: ctx.lpv_clear(av[0], av[1], av[2], bv[0], 4), 4 * 1024 * 1024)
+    print(json.dumps(results))
+
+
+if __name__ == "__main__":
+    main()
