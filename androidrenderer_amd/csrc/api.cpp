@@ -405,7 +405,9 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         sky.smooth_e0 = round_to_half(0.002f);
     }
 
-    int ppt = vec4ok ? 4 : 1;
+    // pixels per thread: 4 (16 B/lane loads) for the deferred-only variants; 2 when the LPV gather is fused in (measured on
+    // MI355X: the 4-pixel body needs 125+ VGPRs and spills)
+    int ppt = vec4ok ? (gi_kind == SAH_GI_LPV ? 2 : 4) : 1;
     if (ctx->force_ppt == 1 || ctx->force_ppt == 2 || ctx->force_ppt == 4) {
         if (ctx->force_ppt == 1 || (vec4ok && W % ctx->force_ppt == 0)) ppt = ctx->force_ppt;
     }

@@ -88,46 +88,7 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     s.roughness = Fn(si.rough);
     s.metalness = Fn(si.metal);
 
-    // ---------------- gather set-up (addresses only; the loads are independent of the BRDF arithmetic) ----------------
-    // CSM: cascade, shadow-space position, PCF taps
-    Fn ndotl_sun;
-    uint32_t cascade = 0;
-    bool sp_inside = false;
-    float pcf_ref = 0.f, pcf_fx = 0.f, pcf_fy = 0.f;
-    uint32_t pcf_off[4] = {0u, 0u, 0u, 0u};
     const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
-    if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
-        ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
-        const uint32_t cc = cascade > 3u ? 3u : cascade;  // cascade 4 means "no shadow map": keep the address legal
-        const Fn bias = Fn(0.0005f) * nsqrt(Fn(1.0f) - ndotl_sun * ndotl_sun) / ndotl_sun;
-        // affine shadow matrix: sp.w == 1, so the perspective divide is the identity; rows come from the LDS table
-        const float4 rx = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u);
-        const float4 ry = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 4u);
-        const float4 rz = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 8u);
-        const Fn spx = Fn(rx.x) * ws.x + Fn(rx.y) * ws.y + Fn(rx.z) * ws.z + Fn(rx.w);
-        const Fn spy = Fn(ry.x) * ws.x + Fn(ry.y) * ws.y + Fn(ry.z) * ws.z + Fn(ry.w);
-        const Fn spz = Fn(rz.x) * ws.x + Fn(rz.y) * ws.y + Fn(rz.z) * ws.z + Fn(rz.w);
-        sp_inside = !(spx.v < 0.f || spy.v < 0.f || spz.v < 0.f || spx.v > 1.f || spy.v > 1.f || spz.v > 1.f);
-        pcf_ref = (spz - bias).v;
-        pcf_ref = pcf_ref < 0.f ? 0.f : (pcf_ref > 1.f ? 1.f : pcf_ref);  // D16: D_ref clamped to [0,1]
-        const VolumeArg& sm = csm.shadowmap;
-        const float px = spx.v * (float)sm.width - 0.5f, py = spy.v * (float)sm.height - 0.5f;
-        const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-        pcf_fx = px - fx0;
-        pcf_fy = py - fy0;
-        const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0);
-        const int wm1 = (int)sm.width - 1, hm1 = (int)sm.height - 1;
-        const uint32_t bpp = 2u;
-        const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * bpp, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * bpp;
-        const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
-        const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
-        pcf_off[0] = lo + ra + xa;
-        pcf_off[1] = lo + ra + xb;
-        pcf_off[2] = lo + rb + xa;
-        pcf_off[3] = lo + rb + xb;
-    }
     // LPV: cascade selection and the gather coordinate
     Fn nc[4];
     float lpv_u = 0.f, lpv_v = 0.f, lpv_w = 0.f;
@@ -160,41 +121,73 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     }
 
     // ---------------- a1: sun, CSM mode ----------------
+    // direct = ((ndotl * brdf) * colour) * shadow is exactly 0 (or NaN, which the shader's guard turns into 0) whenever
+    // ndotl == 0 or shadow == 0, so both the PCF lookup and the BRDF are skipped when no lane of the wave needs them.
+    // The votes are wave-uniform: the body stays free of divergent branches.
     if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
-        // PCF taps (compare LESS, then filter)
-        float dtap[4];
-        const uint8_t* smp = csm.shadowmap.ptr;
-        {   // the fast path is D16_UNORM only (the reference's format; the host sends anything else to the general kernel)
+        const Fn ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
+        Fn sc[3] = {Fn(0.f), Fn(0.f), Fn(0.f)};
+        if (__any(ok && !sky_px && ndotl_sun.v > 0.f)) {
+            uint32_t cascade = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
+            const uint32_t cc = cascade > 3u ? 3u : cascade;  // cascade 4 means "no shadow map": keep the address legal
+            const Fn bias = Fn(0.0005f) * nsqrt(Fn(1.0f) - ndotl_sun * ndotl_sun) / ndotl_sun;
+            // affine shadow matrix: sp.w == 1, so the perspective divide is the identity; rows come from the LDS table
+            const float4 rx = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u);
+            const float4 ry = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 4u);
+            const float4 rz = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 8u);
+            const Fn spx = Fn(rx.x) * ws.x + Fn(rx.y) * ws.y + Fn(rx.z) * ws.z + Fn(rx.w);
+            const Fn spy = Fn(ry.x) * ws.x + Fn(ry.y) * ws.y + Fn(ry.z) * ws.z + Fn(ry.w);
+            const Fn spz = Fn(rz.x) * ws.x + Fn(rz.y) * ws.y + Fn(rz.z) * ws.z + Fn(rz.w);
+            const bool sp_inside = !(spx.v < 0.f || spy.v < 0.f || spz.v < 0.f || spx.v > 1.f || spy.v > 1.f || spz.v > 1.f);
+            float pcf_ref = (spz - bias).v;
+            pcf_ref = pcf_ref < 0.f ? 0.f : (pcf_ref > 1.f ? 1.f : pcf_ref);  // D16: D_ref clamped to [0,1]
+            const VolumeArg& sm = csm.shadowmap;
+            const float px = spx.v * (float)sm.width - 0.5f, py = spy.v * (float)sm.height - 0.5f;
+            const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+            const float pcf_fx = px - fx0, pcf_fy = py - fy0;
+            const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0);
+            const int wm1 = (int)sm.width - 1, hm1 = (int)sm.height - 1;
+            const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * 2u, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * 2u;
+            const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
+            const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
+            const uint32_t pcf_off[4] = {lo + ra + xa, lo + ra + xb, lo + rb + xa, lo + rb + xb};
+            // PCF taps (compare LESS, then filter); the fast path is D16_UNORM only (anything else: general kernel)
+            float dtap[4];
             uint16_t raw[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint16_t*>(smp + pcf_off[k]);
+            for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint16_t*>(sm.ptr + pcf_off[k]);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float v = (float)raw[k];
                 const float q = v * csm.d16_recip;  // host-verified 3-flop v / 65535 (see shadow_pcf)
                 dtap[k] = __builtin_fmaf(__builtin_fmaf(-q, 65535.0f, v), csm.d16_recip, q);
             }
+            const float wx0 = 1.0f - pcf_fx, wy0 = 1.0f - pcf_fy;
+            float pcf = __builtin_fmaf(wx0 * wy0, (pcf_ref < dtap[0]) ? 1.0f : 0.0f, 0.0f);
+            pcf = __builtin_fmaf(pcf_fx * wy0, (pcf_ref < dtap[1]) ? 1.0f : 0.0f, pcf);
+            pcf = __builtin_fmaf(wx0 * pcf_fy, (pcf_ref < dtap[2]) ? 1.0f : 0.0f, pcf);
+            pcf = __builtin_fmaf(pcf_fx * pcf_fy, (pcf_ref < dtap[3]) ? 1.0f : 0.0f, pcf);
+            // ndotl > 0 ? (cascade > 3 ? 0 : (outside ? 1 : pcf)) : 1
+            float shadow = sp_inside ? pcf : 1.0f;
+            shadow = cascade > 3u ? 0.0f : shadow;
+            shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
+            if (__any(ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f)) {
+                const F3 b = brdf_sl(s, L, V);
+                F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
+                const bool bad = any_nan(direct);
+                direct = {bad ? Fn(0.f) : direct.x, bad ? Fn(0.f) : direct.y, bad ? Fn(0.f) : direct.z};
+                const Fn exposure = Fn(0.00031415927f);
+                sc[0] = direct.x * exposure;
+                sc[1] = direct.y * exposure;
+                sc[2] = direct.z * exposure;
+            }
         }
-        const float wx0 = 1.0f - pcf_fx, wy0 = 1.0f - pcf_fy;
-        float pcf = __builtin_fmaf(wx0 * wy0, (pcf_ref < dtap[0]) ? 1.0f : 0.0f, 0.0f);
-        pcf = __builtin_fmaf(pcf_fx * wy0, (pcf_ref < dtap[1]) ? 1.0f : 0.0f, pcf);
-        pcf = __builtin_fmaf(wx0 * pcf_fy, (pcf_ref < dtap[2]) ? 1.0f : 0.0f, pcf);
-        pcf = __builtin_fmaf(pcf_fx * pcf_fy, (pcf_ref < dtap[3]) ? 1.0f : 0.0f, pcf);
-        // ndotl > 0 ? (cascade > 3 ? 0 : (outside ? 1 : pcf)) : 1
-        float shadow = sp_inside ? pcf : 1.0f;
-        shadow = cascade > 3u ? 0.0f : shadow;
-        shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
-
-        const F3 b = brdf_sl(s, L, V);
-        F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
-        const bool bad = any_nan(direct);
-        direct = {bad ? Fn(0.f) : direct.x, bad ? Fn(0.f) : direct.y, bad ? Fn(0.f) : direct.z};
-        const Fn exposure = Fn(0.00031415927f);
-        const Fn sc[3] = {direct.x * exposure, direct.y * exposure, direct.z * exposure};
         const bool quirk = (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) != 0;
         // quirk: dst is the cleared target, s*s + 0*0 == s*s, alpha 1*0 + 0*0 == 0; otherwise plain additive
 #pragma unroll
-        for (int i = 0; i < 3; i++) lit[i] = Hn(quirk ? (sc[i] * sc[i]).v : sc[i].v);
+        for (int i = 0; i < 3; i++) lit[i] = Hn(quirk ? (sc[i] * sc[i]).v : (Fn(0.f) + sc[i]).v);  // 0 + s: a -0 source blends to +0
         lit[3] = quirk ? Hn::lit(0.0f) : Hn::lit(1.0f);
     }
 
