@@ -137,6 +137,10 @@ __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, con
         const uint32_t t = threadIdx.x - 64u, c = t >> 3, j = t & 7u;
         s_lut[TAB_LPV + t] = (j & 3u) == 3u ? 0.f : (j < 4u ? f.lpv_s[c][j] : f.lpv_t[c][j - 4u]);
     }
+    if (threadIdx.x >= 128 && threadIdx.x < 140) {  // rows x,y,z of the (affine) inverse view matrix: (m[i], m[4+i], m[8+i], m[12+i])
+        const uint32_t t = threadIdx.x - 128u;
+        s_lut[TAB_VIEW + t] = a.inv_view[(t & 3u) * 4u + (t >> 2)];
+    }
     __syncthreads();
 
     const uint32_t groups_per_row = a.width / PPT;

@@ -14,7 +14,7 @@ namespace sah {
 SAH_DEV bool finite_f(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 
 // LDS table of the fast kernel: [0,512) format LUTs, then the per-cascade rows that are indexed per lane
-enum : uint32_t { TAB_CSM = 512, TAB_LPV = 512 + 48, TAB_SIZE = 512 + 48 + 32 };
+enum : uint32_t { TAB_CSM = 512, TAB_LPV = 512 + 48, TAB_VIEW = 512 + 48 + 32, TAB_SIZE = 512 + 48 + 32 + 12 };
 
 // brdf() = Fd() + Fr() (brdf.glsl:65-121 / brdf.slangi:58-114) with the shared sub-expressions written once and the
 // `NoL <= 0 -> 0` early-outs turned into one select (both halves return 0 together, and 0 + 0 == +0).
@@ -72,10 +72,11 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         const Fn vx = Fn(colx_glsl) / vw, vy = Fn(rowy_glsl) / vw;
         vsz = (Fn(f.p10) * Fn(D) + Fn(f.p14)) / vw;
         // inverse_view affine: ws_i = ((v0i*x + v1i*y) + v2i*z) + v3i
-        const float* m = a.inv_view;
-        ws.x = Fn(m[0]) * vx + Fn(m[4]) * vy + Fn(m[8]) * vsz + Fn(m[12]);
-        ws.y = Fn(m[1]) * vx + Fn(m[5]) * vy + Fn(m[9]) * vsz + Fn(m[13]);
-        ws.z = Fn(m[2]) * vx + Fn(m[6]) * vy + Fn(m[10]) * vsz + Fn(m[14]);
+        const float4 mx = *reinterpret_cast<const float4*>(tab + TAB_VIEW), my = *reinterpret_cast<const float4*>(tab + TAB_VIEW + 4u),
+                     mz = *reinterpret_cast<const float4*>(tab + TAB_VIEW + 8u);  // rows of inverse_view (LDS broadcast reads)
+        ws.x = Fn(mx.x) * vx + Fn(mx.y) * vy + Fn(mx.z) * vsz + Fn(mx.w);
+        ws.y = Fn(my.x) * vx + Fn(my.y) * vy + Fn(my.z) * vsz + Fn(my.w);
+        ws.z = Fn(mz.x) * vx + Fn(mz.y) * vy + Fn(mz.z) * vsz + Fn(mz.w);
         const F3 d = ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])};
         const Fn d2 = dot(d, d);
         ok = ok && finite_f(ws.x.v) && finite_f(ws.y.v) && finite_f(ws.z.v) && d2.v > 0.f && finite_f(d2.v);
@@ -93,16 +94,26 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     Fn nc[4];
     float lpv_u = 0.f, lpv_v = 0.f, lpv_w = 0.f;
     if constexpr (GI == SAH_GI_LPV) {
+        // selected = smallest i whose unit box contains the point (overlay.frag:97-103 scans down and overwrites; 0 if none).
+        // Cascade 0 is tested first: when every lane of the wave is inside it (coherent near-field pixels) the other
+        // cascades cannot change the answer and are skipped.  Scale / translate rows come from the LDS table (uniform
+        // addresses: broadcast reads) so that they do not occupy SGPRs.
+        auto inside = [&](uint32_t i) {
+            const float4 cs_ = *reinterpret_cast<const float4*>(tab + TAB_LPV + i * 8u);
+            const float4 ct_ = *reinterpret_cast<const float4*>(tab + TAB_LPV + i * 8u + 4u);
+            const Fn cx = Fn(cs_.x) * ws.x + Fn(ct_.x);
+            const Fn cy = Fn(cs_.y) * ws.y + Fn(ct_.y);
+            const Fn cz = Fn(cs_.z) * ws.z + Fn(ct_.z);
+            return cx.v > 0.f && cy.v > 0.f && cz.v > 0.f && cx.v < 1.f && cy.v < 1.f && cz.v < 1.f;
+        };
         uint32_t selected = 0;
+        const bool in0 = inside(0u);
+        if (!__all(in0 || !ok || sky_px)) {
 #pragma unroll
-        for (int i = 3; i >= 0; i--) {
-            if (i < (int)lpv.num_cascades) {
-                const Fn cx = Fn(f.lpv_s[i][0]) * ws.x + Fn(f.lpv_t[i][0]);
-                const Fn cy = Fn(f.lpv_s[i][1]) * ws.y + Fn(f.lpv_t[i][1]);
-                const Fn cz = Fn(f.lpv_s[i][2]) * ws.z + Fn(f.lpv_t[i][2]);
-                const bool in = cx.v > 0.f && cy.v > 0.f && cz.v > 0.f && cx.v < 1.f && cy.v < 1.f && cz.v < 1.f;
-                selected = in ? (uint32_t)i : selected;
+            for (int i = 3; i >= 1; i--) {
+                if (i < (int)lpv.num_cascades) selected = inside((uint32_t)i) ? (uint32_t)i : selected;
             }
+            selected = in0 ? 0u : selected;
         }
         F3 lpv_normal = -N;
         lpv_normal.x = lpv_normal.x * Fn(-1.0f);

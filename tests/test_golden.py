@@ -1,0 +1,85 @@
+"""Golden images (tests/golden/, made by tools/gen_golden.py — an independent vectorised-numpy restatement of the shader
+text) against the oracle on the CPU and against the HIP library on the GPU.  The reference holds no golden images of its own
+(SURVEY.md §8-c), so this is a two-implementations-agree check, not a pin to reference output: parity stays "unpinned"."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, synth
+from tests import util
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LIGHTING = ("lighting_csm_lpv", "lighting_rt", "lighting_csm")
+
+
+def _frame(name):
+    g = np.load(os.path.join(GOLDEN, f"{name}_64x36.npz"))
+    f = util.golden_lighting_frame(64, 36, int(g["seed"]), int(g["sun_mode"]), int(g["gi"]))
+    assert f.inputs_sha256() == str(g["inputs_sha256"]), "synthetic input generators drifted: re-run tools/gen_golden.py"
+    return f, g["lit"]
+
+
+def _post_inputs():
+    g = np.load(os.path.join(GOLDEN, "post_64x36.npz"))
+    scene_img = synth.hdr_scene(64, 36, seed=int(g["seed"])).view(np.uint16)
+    return scene_img, [g[f"mip{i}"] for i in range(6)], g["final"]
+
+
+@pytest.mark.parametrize("name", LIGHTING)
+def test_oracle_matches_golden_lighting(name):
+    f, want = _frame(name)
+    got = f.run_oracle()
+    d = util.f16_ulp_diff(got, want)
+    assert d.max() == 0, util.report_ulp(name, d)
+    assert (want[..., :3] != 0).mean() > 0.5  # the image is not trivially black
+
+
+def test_oracle_matches_golden_post():
+    scene_img, mips_want, final_want = _post_inputs()
+    o = util.oracle()
+    mips = [np.zeros((h, w, 4), np.uint16) for (w, h) in images.bloom_mip_sizes(64, 36, 6)]
+    sp = images.plane(scene_img, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    mc = images.mipchain(mips)
+    assert o.orc_bloom(C.byref(sp), C.byref(mc)) == 0
+    for i, (m, w) in enumerate(zip(mips, mips_want)):
+        d = util.f16_ulp_diff(m[..., :3], w[..., :3])
+        assert d.max() == 0, util.report_ulp(f"mip{i}", d)
+    out = np.zeros((36, 64, 4), np.uint8)
+    op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    assert o.orc_tonemap(C.byref(sp), C.byref(mc), C.byref(op), 0, 0) == 0
+    assert np.array_equal(out, final_want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LIGHTING)
+@pytest.mark.parametrize("force_general", [0, 1])
+def test_hip_matches_golden_lighting(hip_ctx, name, force_general):
+    f, want = _frame(name)
+    hip_ctx.debug_set(force_general=force_general, force_ppt=0)
+    try:
+        got = f.run_hip(hip_ctx)
+    finally:
+        hip_ctx.debug_set(force_general=0, force_ppt=0)
+    d = util.f16_ulp_diff(got, want)
+    assert d.max() == 0, util.report_ulp(name, d)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_post(hip_ctx):
+    import torch
+    scene_img, mips_want, final_want = _post_inputs()
+    dev_scene = util.to_torch(scene_img)
+    mips = [torch.zeros((h, w, 4), dtype=torch.int16, device="cuda") for (w, h) in images.bloom_mip_sizes(64, 36, 6)]
+    sp = images.plane(dev_scene, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    mc = images.mipchain(mips)
+    hip_ctx.bloom(sp, mc)
+    out = torch.zeros((36, 64, 4), dtype=torch.uint8, device="cuda")
+    op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+    hip_ctx.tonemap(sp, mc, op, 0, 0)
+    torch.cuda.synchronize()
+    for i, (m, w) in enumerate(zip(mips, mips_want)):
+        d = util.f16_ulp_diff(util.from_torch(m, np.uint16)[..., :3], w[..., :3])
+        assert d.max() == 0, util.report_ulp(f"mip{i}", d)
+    assert np.array_equal(out.cpu().numpy(), final_want)

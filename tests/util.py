@@ -213,6 +213,14 @@ class LightingFrame:
         keep.append(arrays)
         return d, keep
 
+    def inputs_sha256(self):
+        import hashlib
+        m = hashlib.sha256()
+        for k in sorted(self.arrays):
+            m.update(k.encode())
+            m.update(np.ascontiguousarray(self.arrays[k]).tobytes())
+        return m.hexdigest()
+
     def run_oracle(self):
         lit = np.zeros((self.height, self.width, 4), dtype=np.uint16)
         d, keep = self.describe(self.arrays, lit)
@@ -231,3 +239,12 @@ class LightingFrame:
         ctx.lighting(d)
         torch.cuda.synchronize()
         return from_torch(lit, np.uint16)
+
+
+def golden_lighting_frame(width, height, seed, sun_mode, gi):
+    """The inputs behind tests/golden/lighting_*.npz (tools/gen_golden.py): atrium G-buffer, no sky LUTs, a 128² CSM, and
+    roughness bytes >= 1 so the LPV specular quirk term is exactly zero (the golden generator does not model it)."""
+    f = LightingFrame(width, height, seed=seed, sun_mode=sun_mode, gi=gi, flavour="atrium", sky=False, shadowmap_res=128)
+    f.arrays["data"] = f.arrays["data"].copy()
+    f.arrays["data"][..., 1] = np.maximum(f.arrays["data"][..., 1], 1)
+    return f

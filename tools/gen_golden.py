@@ -1,0 +1,420 @@
+"""Independent numpy restatement of the reference shaders on the hot path, used ONLY to generate the golden images under
+tests/golden/ (SURVEY.md §7 step 1, §8-c fixture ii).  It is a second implementation — vectorised numpy, written from
+the shader text (file:line cited per function), not from oracle/ — so that a misreading would have to be made twice to
+go unnoticed.  The reference itself cannot run here and ships no golden images (parity unpinned).
+
+    python tools/gen_golden.py          # rewrites tests/golden/*.npz
+
+Arithmetic model: np.float32 per-operator rounding (numpy never fuses), fp16 steps via astype(float16), fp64 only where
+the contract says so (pow5 product chain, libm transcendentals), and fma(a,b,c) emulated as float32(float64(a)*b + c)
+(the product is exact in fp64; the one extra rounding is below 2^-29 relative and irrelevant for these image sizes).
+"""
+import hashlib
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from androidrenderer_amd import _abi, images, scene, synth  # noqa: E402
+
+f32 = np.float32
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def F(x):
+    return np.asarray(x, dtype=f32)
+
+
+def h(x):  # round to fp16, keep as fp32
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=f32).astype(np.float16).astype(f32)
+
+
+def fma(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+
+
+def srgb_lut():
+    c = np.arange(256, dtype=np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4).astype(f32)
+
+
+def dot3(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def normalize3(v, rnd=F):
+    d = rnd(rnd(rnd(v[0] * v[0]) + rnd(v[1] * v[1])) + rnd(v[2] * v[2]))
+    inv = rnd(f32(1.0) / rnd(np.sqrt(d)))
+    return [rnd(v[0] * inv), rnd(v[1] * inv), rnd(v[2] * inv)]
+
+
+def clamp01(x):
+    return np.minimum(np.maximum(x, f32(0)), f32(1))  # fmax/fmin semantics are irrelevant here: inputs are finite
+
+
+def pow5(x, rnd=F):
+    d = np.asarray(x, np.float64)
+    return rnd((d * d * d * d * d).astype(f32))
+
+
+def mat_vec(m, v):  # column-major flat[16], left-to-right sum (GLSL M * v)
+    return [F(F(F(m[0 + i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2]) + m[12 + i] * v[3]) for i in range(4)]
+
+
+# ---- brdf.glsl:29-121 (rnd = F) / brdf.slangi:22-114 (rnd = h) ------------------------------------------------------
+def brdf(base, n, rough, metal, l, v, rnd=F):
+    r = rnd
+    one, pi = r(f32(1.0)), r(f32(3.1415927))
+    f0d = r(f32(0.04))
+    f0 = [r(r(f0d * r(one - metal)) + r(base[i] * metal)) for i in range(3)]                       # mix(x,y,a) = x(1-a) + ya
+    diff = [r(r(base[i] * r(one - f0d)) * r(one - metal)) for i in range(3)]
+    hv = normalize3([r(v[i] + l[i]) for i in range(3)], r)
+    dn = lambda a, b: r(r(r(a[0] * b[0]) + r(a[1] * b[1])) + r(a[2] * b[2]))
+    NoV = r(dn(n, v) + r(f32(1e-5)))
+    NoL = dn(n, l)
+    NoH = clamp01(dn(n, hv))
+    VoH = clamp01(dn(v, hv))
+    dark = NoL <= 0
+    NoV = np.abs(NoV)
+    NoL = clamp01(NoL)
+    LoH = clamp01(dn(l, hv))
+    # Fd_Burley :46-52
+    f90 = r(r(f32(0.5)) + r(r(r(r(f32(2.0)) * rough) * LoH) * LoH))
+    schlick1 = lambda u: r(one + r(r(f90 - one) * pow5(clamp01(r(one - u)), r)))
+    fdv = r(r(schlick1(NoL) * schlick1(NoV)) * r(one / pi))
+    fd = [r(diff[i] * fdv) for i in range(3)]
+    # D_GGX :29-32, V_SmithGGXCorrelated :36-42, F_Schlick :34
+    k = r(rough / r(r(one - r(NoH * NoH)) + r(rough * rough)))
+    D = r(r(k * k) * r(one / pi))
+    a2 = r(rough * rough)
+    GGXL = r(NoV * r(np.sqrt(r(r(r(r(r(-NoL) * a2) + NoL) * NoL) + a2))))
+    GGXV = r(NoL * r(np.sqrt(r(r(r(r(r(-NoV) * a2) + NoV) * NoV) + a2))))
+    Vis = r(r(f32(0.5)) / r(GGXV + GGXL))
+    p = pow5(clamp01(r(one - VoH)), r)
+    Fv = [r(f0[i] + r(r(one - f0[i]) * p)) for i in range(3)]
+    DV = r(D * Vis)
+    out = [r(fd[i] + r(DV * Fv[i])) for i in range(3)]
+    return [np.where(dark, f32(0), o) for o in out]
+
+
+# ---- samplers (Vulkan weighted sum, fma chain from +0) -------------------------------------------------------------------
+def axis(coord, size):
+    p = F(F(coord * f32(size)) - f32(0.5))
+    f0 = np.floor(p)
+    fr = F(p - f0)
+    return f0.astype(np.int64), F(f32(1.0) - fr), fr
+
+
+def bilinear_clamp(img, u, v):
+    """img (H, W, C) fp32; CLAMP_TO_EDGE."""
+    H, W = img.shape[:2]
+    x0, wx0, fx = axis(u, W)
+    y0, wy0, fy = axis(v, H)
+    xa, xb = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+    ya, yb = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+    acc = np.zeros(u.shape + (img.shape[2],), dtype=f32)
+    for (yy, xx, w) in ((ya, xa, F(wx0 * wy0)), (ya, xb, F(fx * wy0)), (yb, xa, F(wx0 * fy)), (yb, xb, F(fx * fy))):
+        acc = fma(w[..., None], img[yy, xx], acc)
+    return acc
+
+
+def trilinear_border(vol, u, v, w):
+    """vol (D, H, W, 4) fp32; CLAMP_TO_BORDER transparent black."""
+    D, H, W = vol.shape[:3]
+    x0, wx0, fx = axis(u, W)
+    y0, wy0, fy = axis(v, H)
+    z0, wz0, fz = axis(w, D)
+    acc = np.zeros(u.shape + (4,), dtype=f32)
+    wxy = [F(wx0 * wy0), F(fx * wy0), F(wx0 * fy), F(fx * fy)]
+    for k in range(8):
+        xx, yy, zz = x0 + (k & 1), y0 + ((k >> 1) & 1), z0 + (k >> 2)
+        wt = F(wxy[k & 3] * (fz if (k >> 2) else wz0))
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H) & (zz >= 0) & (zz < D)
+        t = np.where(ok[..., None], vol[np.clip(zz, 0, D - 1), np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], f32(0))
+        acc = fma(wt[..., None], t, acc)
+    return acc
+
+
+# ---- the Lighting pass, per sub-pass --------------------------------------------------------------------------------------
+class Frame:
+    def __init__(self, W, Hh, seed, sun_mode, gi):
+        self.W, self.H = W, Hh
+        from tests import util  # only its input builder is used here, never the oracle
+        self.f = util.golden_lighting_frame(W, Hh, seed, sun_mode, gi)
+        a = self.f.arrays
+        self.view, self.sun = self.f.view.gpu_data, self.f.sun.constants
+        lut = srgb_lut()
+        self.base = [lut[a["color"][..., i]] for i in range(3)]
+        self.emis = [lut[a["emission"][..., i]] for i in range(3)]
+        self.nrm = [a["normals"][..., i].astype(f32) for i in range(3)]
+        self.rough = F(a["data"][..., 1].astype(f32) / f32(255.0))
+        self.metal = F(a["data"][..., 2].astype(f32) / f32(255.0))
+        self.depth = a["depth"]
+        ys, xs = np.meshgrid(np.arange(Hh, dtype=f32), np.arange(W, dtype=f32), indexing="ij")
+        self.xs, self.ys = xs, ys
+
+    def position(self, glsl):
+        """directional_light.frag:45-53 (gl_FragCoord + 0.5 quirk) or directional_light.rt.slang:39-48."""
+        v = self.view
+        res = (f32(v.render_resolution[0]), f32(v.render_resolution[1]))
+        if glsl:
+            tx, ty = F(F(F(self.xs + f32(0.5)) + f32(0.5)) / res[0]), F(F(F(self.ys + f32(0.5)) + f32(0.5)) / res[1])
+        else:
+            tx, ty = F(F(self.xs + f32(0.5)) / res[0]), F(F(self.ys + f32(0.5)) / res[1])
+        ndc = [F(F(tx * f32(2)) - f32(1)), F(F(ty * f32(2)) - f32(1)), self.depth, np.ones_like(self.depth)]
+        ip = np.array(v.inverse_projection[:], dtype=f32)
+        iv = np.array(v.inverse_view[:], dtype=f32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            vs = mat_vec(ip, ndc)
+            vsd = [F(vs[i] / vs[3]) for i in range(4)]
+            ws = mat_vec(iv, [vsd[0], vsd[1], vsd[2], np.ones_like(self.depth) if glsl else vsd[3]])
+        return vsd, ws
+
+    def sun_csm(self):
+        """directional_light.frag:96-149; returns the fragment colour (rgb) before blending."""
+        vs, ws = self.position(True)
+        view = np.array(self.view.view[:], dtype=f32)
+        cam = [F(-view[12 + i]) for i in range(3)]
+        N = normalize3(self.nrm)
+        with np.errstate(invalid="ignore"):
+            V = normalize3([F(ws[i] - cam[i]) for i in range(3)])
+        sd = np.array(self.sun.direction_and_tan_size[:3], dtype=f32)
+        L = normalize3([F(-sd[i]) for i in range(3)])
+        ndotl = clamp01(dot3_r(N, L))
+        # sample_csm :80-94
+        cascade = np.zeros(self.depth.shape, dtype=np.int64)
+        for i in range(4):
+            cascade = np.where(vs[2] < f32(self.sun.data[i][0]), i + 1, cascade)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            bias = F(F(f32(0.0005) * np.sqrt(F(f32(1) - F(ndotl * ndotl)))) / ndotl)
+        shadow = np.ones(self.depth.shape, dtype=f32)
+        sm = self.f.arrays["shadowmap"].astype(f32) / f32(65535.0)
+        for c in range(4):
+            M = np.array(self.sun.cascade_matrices[c][:], dtype=f32)
+            B = np.zeros(16, dtype=f32)  # biasMat * M (matrix product first: GLSL is left-associative)
+            for col in range(4):
+                m = M[col * 4:col * 4 + 4]
+                B[col * 4 + 0] = F(F(F(f32(0.5) * m[0] + f32(0) * m[1]) + f32(0) * m[2]) + f32(0.5) * m[3])
+                B[col * 4 + 1] = F(F(F(f32(0) * m[0] + f32(0.5) * m[1]) + f32(0) * m[2]) + f32(0.5) * m[3])
+                B[col * 4 + 2] = F(F(F(f32(0) * m[0] + f32(0) * m[1]) + f32(1) * m[2]) + f32(0) * m[3])
+                B[col * 4 + 3] = F(F(F(f32(0) * m[0] + f32(0) * m[1]) + f32(0) * m[2]) + f32(1) * m[3])
+            sp = mat_vec(B, [ws[0], ws[1], ws[2], np.ones_like(self.depth)])
+            with np.errstate(invalid="ignore", divide="ignore"):
+                sp = [F(sp[i] / sp[3]) for i in range(4)]
+            inside = ~((sp[0] < 0) | (sp[1] < 0) | (sp[2] < 0) | (sp[0] > 1) | (sp[1] > 1) | (sp[2] > 1))
+            ref = np.clip(F(sp[2] - bias), f32(0), f32(1))
+            # PCF :338-352: compare LESS per tap, then filter
+            Hs, Ws = sm.shape[1:]
+            x0, wx0, fx = axis(np.where(inside, sp[0], f32(0.5)), Ws)
+            y0, wy0, fy = axis(np.where(inside, sp[1], f32(0.5)), Hs)
+            acc = np.zeros_like(ref)
+            for (dy, dx, w) in ((0, 0, F(wx0 * wy0)), (0, 1, F(fx * wy0)), (1, 0, F(wx0 * fy)), (1, 1, F(fx * fy))):
+                t = sm[c][np.clip(y0 + dy, 0, Hs - 1), np.clip(x0 + dx, 0, Ws - 1)]
+                acc = fma(w, (ref < t).astype(f32), acc)
+            s_c = np.where(inside, acc, f32(1))
+            shadow = np.where(cascade == c, s_c, shadow)
+        shadow = np.where(cascade > 3, f32(0), shadow)
+        shadow = np.where(ndotl > 0, shadow, f32(1))
+        b = brdf(self.base, N, self.rough, self.metal, L, V)
+        col = np.array(self.sun.color[:3], dtype=f32)
+        with np.errstate(invalid="ignore"):
+            direct = [F(F(F(ndotl * b[i]) * col[i]) * shadow) for i in range(3)]
+        bad = np.isnan(direct[0]) | np.isnan(direct[1]) | np.isnan(direct[2])
+        return [np.where(bad, f32(0), F(d * f32(0.00031415927))) for d in direct]
+
+    def lpv_overlay(self):
+        """gi/lpv/overlay.frag:70-164 for finite volumes and roughness > 0 (specular term == 0)."""
+        _, ws = self.position(True)
+        N = normalize3(self.nrm)
+        gi = self.f
+        mats = [np.array(gi.lpv.matrices[c].world_to_cascade[:], dtype=f32) for c in range(4)]
+        selected = np.zeros(self.depth.shape, dtype=np.int64)
+        for i in (3, 2, 1, 0):
+            cp = mat_vec(mats[i], ws)
+            inside = (cp[0] > 0) & (cp[1] > 0) & (cp[2] > 0) & (cp[0] < 1) & (cp[1] < 1) & (cp[2] < 1)
+            selected = np.where(inside, i, selected)
+        nc = [np.full(self.depth.shape, f32(0.282094792)), F(f32(-0.488602512) * F(-N[1])), F(f32(0.488602512) * F(-N[2])),
+              F(f32(-0.488602512) * F(F(-N[0]) * f32(-1)))]
+        pos = [F(ws[0] + N[0]), F(ws[1] + N[1]), F(ws[2] + N[2]), F(ws[3] + f32(0))]
+        cp = [np.zeros_like(self.depth) for _ in range(3)]
+        for i in range(4):
+            c = mat_vec(mats[i], pos)
+            for k in range(3):
+                cp[k] = np.where(selected == i, c[k], cp[k])
+        cp[0] = F(F(cp[0] + selected.astype(f32)) / f32(4.0))
+        vols = [gi.arrays[k].astype(f32) for k in ("lpv_r", "lpv_g", "lpv_b")]
+        ind = []
+        for vol in vols:
+            t = trilinear_border(vol, cp[0], cp[1], cp[2])
+            ind.append(F(F(F(t[..., 0] * nc[0] + t[..., 1] * nc[1]) + t[..., 2] * nc[2]) + t[..., 3] * nc[3]))
+        fdv = brdf_fd_nn(self.base, N, self.rough, self.metal)
+        ao = gi.arrays["ao"]
+        total = [F(F(F(ind[i] * fdv[i]) * ao) + f32(0)) for i in range(3)]  # "+ specular_light * (Fr * 0)" == + 0 here
+        bad = np.isnan(total[0]) | np.isnan(total[1]) | np.isnan(total[2])
+        ex = f32(np.float32(math.pi) * np.float32(10.0))
+        return [np.where(bad, f32(0), F(t * ex)) for t in total]
+
+    def sun_rt(self):
+        """directional_light.rt.slang:58-139 with shadow / num_samples taken from the mask plane; returns the fp32 addend."""
+        _, ws = self.position(False)
+        view = np.array(self.view.view[:], dtype=f32)
+        cam = [F(-view[12 + i]) for i in range(3)]
+        Nh = normalize3([h(n) for n in self.nrm], h)
+        sd = np.array(self.sun.direction_and_tan_size[:3], dtype=f32)
+        L = normalize3([F(-sd[i]) for i in range(3)])
+        ndotl = h(clamp01(F(F(L[0] * Nh[0] + L[1] * Nh[1]) + L[2] * Nh[2])))
+        with np.errstate(invalid="ignore"):
+            V = [h(x) for x in normalize3([F(ws[i] - cam[i]) for i in range(3)])]
+        b = brdf([h(c) for c in self.base], Nh, h(self.rough), h(self.metal), [h(x) for x in L], V, h)
+        col = np.array(self.sun.color[:3], dtype=f32)
+        rad = [F(h(ndotl * b[i]) * col[i]) for i in range(3)]
+        mask = self.f.arrays["shadow_mask"]
+        rad = [np.where(ndotl > 0, F(r * mask), r) for r in rad]
+        return [F(r * f32(0.00031415927)) for r in rad]
+
+    def emissive(self):
+        return [F(e * f32(3.1415927)) for e in self.emis]
+
+
+def dot3_r(a, b):
+    return F(F(F(a[0] * b[0]) + F(a[1] * b[1])) + F(a[2] * b[2]))
+
+
+def brdf_fd_nn(base, n, rough, metal):
+    """Fd(surface, N, N) (overlay.frag:149) through the full formula."""
+    one = f32(1.0)
+    diff = [F(F(base[i] * F(one - f32(0.04))) * F(one - metal)) for i in range(3)]
+    hv = normalize3([F(n[i] + n[i]) for i in range(3)])
+    NoV = np.abs(F(dot3_r(n, n) + f32(1e-5)))
+    NoL = clamp01(dot3_r(n, n))
+    LoH = clamp01(dot3_r(n, hv))
+    f90 = F(f32(0.5) + F(F(F(f32(2.0) * rough) * LoH) * LoH))
+    s = lambda u: F(one + F(F(f90 - one) * pow5(clamp01(F(one - u)))))
+    fdv = F(F(s(NoL) * s(NoV)) * F(one / f32(3.1415927)))
+    return [F(d * fdv) for d in diff]
+
+
+def compose(fr, sun_mode, gi):
+    """lighting_phase.cpp:99-134 with the RGBA16F blend roundings."""
+    surf = fr.depth != 0
+    lit = [np.zeros(fr.depth.shape, dtype=f32) for _ in range(4)]
+    if sun_mode == _abi.SHADOW_MODE_CSM:
+        s = fr.sun_csm()
+        for i in range(3):
+            lit[i] = np.where(surf, h(F(F(s[i] * s[i]) + F(lit[i] * lit[i]))), lit[i])  # SRC_COLOR / DST_COLOR blend
+        # alpha factors ZERO/ZERO: stays 0
+    if gi == _abi.GI_LPV:
+        g = fr.lpv_overlay()
+        for i in range(3):
+            lit[i] = np.where(surf, h(F(lit[i] + g[i])), lit[i])
+        lit[3] = np.where(surf, h(F(lit[3] + f32(1))), lit[3])
+    e = fr.emissive()
+    for i in range(3):
+        lit[i] = h(F(lit[i] + e[i]))
+    lit[3] = h(F(lit[3] + f32(1)))
+    if sun_mode == _abi.SHADOW_MODE_RT:
+        a = fr.sun_rt()
+        for i in range(3):
+            lit[i] = np.where(surf, h(F(lit[i] + a[i])), lit[i])
+    with np.errstate(over="ignore"):
+        return np.stack(lit, axis=-1).astype(np.float16).view(np.uint16)
+
+
+# ---- post chain ---------------------------------------------------------------------------------------------------------------
+def bloom_downsample(src, dw, dh):
+    """bloom_downsample.comp:16-52; src (H, W, 4) fp16 bits -> (dh, dw, 4) fp16 bits."""
+    img = src.view(np.float16).astype(f32)[..., :3]
+    Hs, Ws = img.shape[:2]
+    ys, xs = np.meshgrid(np.arange(dh, dtype=f32), np.arange(dw, dtype=f32), indexing="ij")
+    u, v = F(F(xs + f32(0.5)) / f32(dw)), F(F(ys + f32(0.5)) / f32(dh))
+    ix, iy = F(f32(1) / f32(Ws)), F(f32(1) / f32(Hs))
+    o = [F(ix * f32(-1)), F(iy * f32(-1)), F(ix * f32(1)), F(iy * f32(1))]
+
+    def box(uu, vv):
+        s = bilinear_clamp(img, F(uu + o[0]), F(vv + o[1]))
+        s = F(s + bilinear_clamp(img, F(uu + o[2]), F(vv + o[1])))
+        s = F(s + bilinear_clamp(img, F(uu + o[0]), F(vv + o[3])))
+        s = F(s + bilinear_clamp(img, F(uu + o[2]), F(vv + o[3])))
+        return F(s * f32(0.25))
+
+    s = F(box(u, v) * f32(0.5))
+    for (a, b) in ((0, 1), (2, 1), (0, 3), (2, 3)):
+        s = F(s + F(box(F(u + o[a]), F(v + o[b])) * f32(0.125)))
+    out = np.zeros((dh, dw, 4), dtype=np.float16)
+    with np.errstate(over="ignore"):
+        out[..., :3] = s.astype(np.float16)
+    return out.view(np.uint16)
+
+
+def tonemap(scene_bits, mips_bits, ow, oh):
+    """scene_upsample.frag:20-72 + sRGB swap-chain write."""
+    scene_img = scene_bits.view(np.float16).astype(f32)
+    ys, xs = np.meshgrid(np.arange(oh, dtype=f32), np.arange(ow, dtype=f32), indexing="ij")
+    u = F(F(xs + f32(0.5)) / f32(ow))
+    v = F(f32(1) - F(F(ys + f32(0.5)) / f32(oh)))
+    bloom = np.zeros((oh, ow, 3), dtype=f32)
+    for mb in mips_bits[:6]:
+        img = mb.view(np.float16).astype(f32)[..., :3]
+        Hm, Wm = img.shape[:2]
+        ix, iy = F(f32(1) / f32(Wm)), F(f32(1) / f32(Hm))
+        o = [F(ix * f32(-1)), F(iy * f32(-1)), F(ix * f32(1)), F(iy * f32(1))]
+        z = f32(0)
+        taps = [((z, z), 4.0), ((o[0], z), 2.0), ((o[1], z), 2.0), ((z, o[2]), 2.0), ((z, o[3]), 2.0), ((o[0], o[1]), 1.0), ((o[2], o[1]), 1.0),
+                ((o[0], o[3]), 1.0), ((o[2], o[3]), 1.0)]
+        s = None
+        for k, ((du, dv), wgt) in enumerate(taps):
+            uu = u if (k == 0) else F(u + du)
+            vv = v if (k == 0) else F(v + dv)
+            t = F(bilinear_clamp(img, uu, vv) * f32(wgt))
+            s = t if s is None else F(s + t)
+        bloom = F(bloom + F(s / f32(16.0)))
+    sc = bilinear_clamp(scene_img, u, v)[..., :3]
+    c = F(sc + F(bloom * f32(0.014159)))
+    luma = F(F(F(c[..., 0] * f32(0.2126)) + F(c[..., 1] * f32(0.7152))) + F(c[..., 2] * f32(0.0722)))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        factor = F(luma / F(luma + f32(1)))
+        mapped = F(c * factor[..., None])
+        g = np.power(mapped.astype(np.float64), np.float64(f32(1.0) / f32(2.2))).astype(f32)
+        d = g.astype(np.float64)
+        s = np.where(d <= 0.0031308, 12.92 * d, 1.055 * np.power(d, 1.0 / 2.4) - 0.055).astype(f32)
+    s = np.where(g >= 1, f32(1), np.where(g > 0, s, f32(0)))
+    code = np.where(s >= 1, 255, np.where(s > 0, (F(F(s * f32(255)) + f32(0.5))).astype(np.int64), 0)).astype(np.uint8)
+    out = np.full((oh, ow, 4), 255, dtype=np.uint8)
+    out[..., :3] = code
+    return out
+
+
+def inputs_digest(arrays):
+    m = hashlib.sha256()
+    for k in sorted(arrays):
+        m.update(k.encode())
+        m.update(np.ascontiguousarray(arrays[k]).tobytes())
+    return m.hexdigest()
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    W, Hh = 64, 36
+    for name, sun_mode, gi, seed in (("lighting_csm_lpv", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, 101), ("lighting_rt", _abi.SHADOW_MODE_RT, _abi.GI_NONE, 102),
+                                     ("lighting_csm", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, 103)):
+        fr = Frame(W, Hh, seed, sun_mode, gi)
+        lit = compose(fr, sun_mode, gi)
+        np.savez_compressed(os.path.join(GOLDEN, f"{name}_{W}x{Hh}.npz"), lit=lit, seed=seed, sun_mode=sun_mode, gi=gi,
+                            inputs_sha256=inputs_digest(fr.f.arrays))
+        print(name, "ok", lit.shape)
+    scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
+    mips, src = [], scene_img
+    for (mw, mh) in images.bloom_mip_sizes(W, Hh, 6):
+        src = bloom_downsample(src, mw, mh)
+        mips.append(src)
+    out = tonemap(scene_img, mips, W, Hh)
+    np.savez_compressed(os.path.join(GOLDEN, f"post_{W}x{Hh}.npz"), seed=104, final=out, **{f"mip{i}": m for i, m in enumerate(mips)})
+    print("post ok")
+
+
+if __name__ == "__main__":
+    main()
