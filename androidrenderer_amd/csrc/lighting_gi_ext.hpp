@@ -1,7 +1,7 @@
 // Device restatement of the irradiance-cache overlay (a4) and the RTGI reconstruction overlay (a5).
 //   a4: RenderCore/shaders/gi/cache/overlay.frag.slang:46-118, probe_sampling.slangi:6-106, common/octahedral.slangi:56-74
 //   a5: RenderCore/shaders/gi/rtgi/overlay.frag.slang:68-117
-// Same operator sequence as the CPU oracle (oracle/gi.cpp); used by the general / tiled kernels.
+// Operator order and rounding per DESIGN.md §3; used by the general / tiled kernels.
 #pragma once
 #include "lighting_common.hpp"
 
@@ -265,7 +265,7 @@ SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, 
     out[3] = Fn(1.f);
 }
 
-// ---- a9 (extension): one point light, DESIGN.md / oracle/post.cpp:point_lights_frag ------------------------------------
+// ---- a9 (extension): one point light, spec in DESIGN.md §5b and include/sah_hip.h ---------------------------------------
 struct PointLightDev {
     float px, py, pz, radius, cr, cg, cb, intensity;
 };

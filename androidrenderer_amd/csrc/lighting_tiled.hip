@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
 
     // (2b) point lights
     if constexpr (LIGHTS) {
-        // shading inputs exactly as oracle/post.cpp:point_lights_frag builds them
+        // shading inputs as the a9 spec builds them: the sun fragment's fp32 surface, N, V and position
         Surface<Fn> s;
         s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
         s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: lit Mpixels/s of the fused deferred-lighting + GI pass at 4K on MI355X (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-A step = one Lighting pass (sun CSM + LPV GI gather + AO + emissive + sky, SURVEY.md §8 a0-a3,a6) over one synthetic
-3840x2160 G-buffer already resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is
-sharded by contiguous row blocks, each rank shades its rows, and the lit rows are re-assembled on every rank with an RCCL
-all-gather (the exchange step BASELINE.json's north_star names); total work is fixed => "scaling": "strong".
+A step = one Lighting pass (default workload: sun CSM + LPV GI gather + AO + emissive + sky, SURVEY.md §8 a0-a3,a6) over one
+synthetic 3840x2160 G-buffer already resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
+frame is sharded by contiguous row blocks, each rank shades its rows, and the lit rows are re-assembled on every rank with
+an RCCL all-gather (the exchange step BASELINE.json's north_star names); total work is fixed => "scaling": "strong".
+The `*_chain` workloads add the post chain to the step: copy scene + bloom pyramid on the gathered frame (replicated),
+tonemap composite on this rank's rows, all-gather of the final RGBA8 rows.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` (dominant kernel vs HBM peak,
 kernel time measured with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle, OpenMP, timed
@@ -15,7 +17,6 @@ on a bounded row band of the same frame).
 import argparse
 import ctypes as C
 import json
-import math
 import os
 import sys
 import time
@@ -26,16 +27,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_PIXEL = 36   # colour 4 + normals 8 + data 4 + emission 4 + depth 4 + AO 4 read, lit 8 written
 
+# BASELINE.json configs[1..4] plus diagnostics.  The headline (`metric`) is 4k_deferred_gi.
 WORKLOADS = {
-    # name: (width, height, flavour, sun_mode, gi)
-    "4k_deferred_gi": (3840, 2160, "atrium", "csm", "lpv"),
-    "4k_deferred_gi_random": (3840, 2160, "random", "csm", "lpv"),
-    "4k_deferred_only": (3840, 2160, "atrium", "csm", "none"),
-    "1080p_deferred_gi": (1920, 1080, "atrium", "csm", "lpv"),
-    "8k_deferred_gi": (7680, 4320, "atrium", "csm", "lpv"),
+    "4k_deferred_gi": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv"),
+    "4k_deferred_gi_random": dict(res=(3840, 2160), gbuffer="random", sun="csm", gi="lpv"),
+    "4k_deferred_only": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none"),
+    "1080p_deferred_gi": dict(res=(1920, 1080), gbuffer="atrium", sun="csm", gi="lpv"),
+    "8k_deferred_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv"),
+    "1080p_64_lights": dict(res=(1920, 1080), gbuffer="random", sun="csm", gi="none", lights=64),            # configs[1]
+    "4k_256_lights": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none", lights=256),             # configs[2]
+    "4k_probe_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True),         # configs[3]
+    "4k_lpv_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", chain=True),
+    "8k_1024_lights_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv", lights=1024),         # configs[4]
 }
+LIGHT_RADIUS = 4.0
 
 
 def main():
@@ -52,7 +58,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from androidrenderer_amd import _abi, images, lib, scene, synth
+    from androidrenderer_amd import _abi, frame, images, lib, scene, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -68,66 +74,31 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    W, H, flavour, sun_name, gi_name = WORKLOADS[args.workload]
-    sun_mode = {"off": _abi.SHADOW_MODE_OFF, "csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}[sun_name]
-    gi_kind = {"none": _abi.GI_NONE, "lpv": _abi.GI_LPV}[gi_name]
+    wl = WORKLOADS[args.workload]
+    W, H = wl["res"]
+    sun_mode = {"off": _abi.SHADOW_MODE_OFF, "csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}[wl["sun"]]
+    gi_kind = {"none": _abi.GI_NONE, "lpv": _abi.GI_LPV, "cache": _abi.GI_CACHE, "rtgi": _abi.GI_RTGI}[wl["gi"]]
+    n_lights = wl.get("lights", 0)
+    chain = bool(wl.get("chain"))
 
     # ---- inputs (identical on every rank: generated from fixed seeds) ----------------------------------------------
-    view = scene.SceneView.default(W, H)
-    sun = scene.DirectionalLight(shadow_mode=sun_mode)
-    sun.update_shadow_cascades(view, resolution=4096)
-    if flavour == "atrium":
-        g_np = synth.atrium_gbuffer(W, H, view, seed=2, device=str(dev))
-    else:
-        g_np = synth.random_gbuffer(W, H, seed=1)
-    host = dict(g_np)
-    host["ao"] = synth.ao_plane(W, H, 3)
-    luts = synth.sky_luts(7)
-    host["sky_t"], host["sky_v"] = luts["transmittance"], luts["sky_view"]
-    host["shadowmap"] = synth.shadowmap(4096, 4, 6)
-    lpv = scene.LpvCascades()
-    lpv.update_cascade_transforms(view, sun)
-    host["lpv_r"], host["lpv_g"], host["lpv_b"] = synth.lpv_volumes(4, 5)
+    lights = None
+    if n_lights:
+        lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, LIGHT_RADIUS, seed=8)
+    fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
+                              synth_device=str(dev))
+    d_arr = fr.device_arrays(dev)
+    bytes_per_pixel = fr.bytes_per_pixel()
 
-    def up(a):
-        if a.dtype == np.uint16:
-            return torch.from_numpy(a.view(np.int16)).to(dev)
-        return torch.from_numpy(a).to(dev)
-
-    d_arr = {k: up(v) for k, v in host.items()}
     # row shard of this rank: ceil(H / world) rows per gather slot, clipped to the image (tests/test_dist_cpu.py)
     rows_per = -(-H // world)
     r0 = min(rank * rows_per, H)
     r1 = min(r0 + rows_per, H)
     lit_full = torch.zeros((rows_per * world, W, 4), dtype=torch.int16, device=dev)  # equal slots for the all-gather
     lit = lit_full[:H]
-
-    gb = images.gbuffer(d_arr)
-    lit_p = images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)
-    ao_p = images.plane(d_arr["ao"], _abi.FORMAT_R32_SFLOAT)
-    sm_v = images.volume(d_arr["shadowmap"], _abi.FORMAT_D16_UNORM)
-    sky = _abi.SkyLuts(images.plane(d_arr["sky_t"], _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(d_arr["sky_v"], _abi.FORMAT_R16G16B16A16_SFLOAT))
-    gi = _abi.GI()
-    gi.kind = gi_kind
-    if gi_kind == _abi.GI_LPV:
-        gi.lpv_red = images.volume(d_arr["lpv_r"], _abi.FORMAT_R16G16B16A16_SFLOAT)
-        gi.lpv_green = images.volume(d_arr["lpv_g"], _abi.FORMAT_R16G16B16A16_SFLOAT)
-        gi.lpv_blue = images.volume(d_arr["lpv_b"], _abi.FORMAT_R16G16B16A16_SFLOAT)
-        gi.lpv_cascades = C.cast(lpv.matrices, C.POINTER(_abi.LpvCascadeMatrices))
-        gi.lpv_num_cascades = 4
-        gi.lpv_exposure = float(np.float32(math.pi) * np.float32(10.0))
-
-    desc = _abi.LightingDesc()
-    desc.gbuffer = C.pointer(gb)
-    desc.lit = C.pointer(lit_p)
-    desc.ao = C.pointer(ao_p)
-    desc.view = C.pointer(view.gpu_data)
-    desc.sun = C.pointer(sun.constants)
-    desc.shadowmap = C.pointer(sm_v)
-    desc.sky = C.pointer(sky)
-    desc.gi = C.pointer(gi)
-    desc.flags = _abi.LIGHTING_DEFAULT_FLAGS
-    desc.row_begin, desc.row_end = (r0, r1) if world > 1 else (0, 0)
+    if world > 1:
+        fr.row_begin, fr.row_end = r0, r1
+    desc, keep = fr.describe(d_arr, lit)
 
     ctx = lib.Context(device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -136,11 +107,37 @@ def main():
     shard_bytes = rows_per * W * 8
     my_slot = lit_bytes[rank * shard_bytes:(rank + 1) * shard_bytes]
 
-    def step():
+    if chain:
+        aa = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+        mips = [torch.zeros((mh, mw, 4), dtype=torch.int16, device=dev) for (mw, mh) in images.bloom_mip_sizes(W, H, 6)]
+        final_full = torch.zeros((rows_per * world, W, 4), dtype=torch.uint8, device=dev)
+        lit_p = images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        aa_p = images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        mc = images.mipchain(mips)
+        final_p = images.plane(final_full[:H], _abi.FORMAT_R8G8B8A8_SRGB)
+        final_bytes = final_full.view(-1)
+        fshard = rows_per * W * 4
+        final_slot = final_bytes[rank * fshard:(rank + 1) * fshard]
+
+    def post():
+        ctx.copy_scene(lit_p, aa_p)
+        ctx.bloom(aa_p, mc)
+        if r1 > r0:
+            ctx.tonemap(aa_p, mc, final_p, *((r0, r1) if world > 1 else (0, 0)))
+        if gather:
+            dist.all_gather_into_tensor(final_bytes, final_slot)
+
+    def step(e0=None, e1=None):
+        if e0 is not None:
+            e0.record()
         if r1 > r0:
             ctx.lighting(desc)
+        if e1 is not None:
+            e1.record()
         if gather:
             dist.all_gather_into_tensor(lit_bytes, my_slot)  # in place: the input is this rank's slot of the output
+        if chain:
+            post()
 
     for _ in range(args.warmup):
         step()
@@ -151,12 +148,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        if r1 > r0:
-            ctx.lighting(desc)
-        ev[i][1].record()
-        if gather:
-            dist.all_gather_into_tensor(lit_bytes, my_slot)
+        step(ev[i][0], ev[i][1])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -173,7 +165,7 @@ def main():
         px = W * H
         value = px * args.steps / elapsed / 1e6
         my_px = W * (r1 - r0) if world > 1 else px
-        achieved = BYTES_PER_PIXEL * my_px / (kernel_ms_mean * 1e-3) / 1e9
+        achieved = bytes_per_pixel * my_px / (kernel_ms_mean * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -181,6 +173,14 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload)
             except Exception:
                 traffic = None
+        sun_txt = {"csm": "sun CSM 4x4096^2 D16 PCF", "rt": "sun RT (shadow-mask plane, half-precision BRDF)", "off": "sun off"}[wl["sun"]]
+        gi_txt = {"none": "no GI", "lpv": "LPV GI gather + AO", "cache": "irradiance-cache probe gather", "rtgi": "RTGI reconstruction"}[wl["gi"]]
+        parts = [sun_txt, gi_txt, "emissive", "sky"]
+        if n_lights:
+            parts.insert(1, f"{n_lights} point lights (r={LIGHT_RADIUS} m) with LDS tile culling")
+        what = "fused deferred lighting (" + " + ".join(parts) + ")"
+        if chain:
+            what += " + copy scene + bloom pyramid + tonemap composite"
         out = {
             "metric": "lit Mpixels/sec (deferred+GI pass) at 4K",
             "value": round(value, 1),
@@ -195,10 +195,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {W}x{H} fused deferred lighting (sun {sun_name.upper()} 4x4096^2 D16 PCF + "
-                            f"{gi_name.upper()} GI gather + AO + emissive + sky), {flavour} G-buffer",
+                "workload": f"{args.workload}: {W}x{H} {what}, {wl['gbuffer']} G-buffer",
                 "resolution": [W, H],
-                "gbuffer": flavour,
+                "gbuffer": wl["gbuffer"],
                 "parallelism": "row-shard x%d + RCCL all-gather of lit rows" % world if world > 1 else "single GPU",
                 "gather": bool(gather),
             },
@@ -209,48 +208,31 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "sah::k_lighting",
+                "kernel": "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast",
                 "kernel_ms_mean": round(kernel_ms_mean, 5),
                 "kernel_ms_min": round(kernel_ms[0], 5),
-                "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * my_px,
+                "algorithmic_bytes_per_launch": bytes_per_pixel * my_px,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, view, sun, lpv, W, H, sun_mode, gi_kind, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(host, view, sun, lpv, W, H, sun_mode, gi_kind, target_s):
-    """Times the CPU oracle (a port, OpenMP over rows) on a bounded band of rows of the same frame."""
-    from androidrenderer_amd import _abi, images
+def cpu_baseline(fr, target_s):
+    """Times the CPU oracle (a port, OpenMP over rows) on a bounded band of rows of the same frame (lighting pass only)."""
     try:
         from tests import util
         o = util.oracle()
     except Exception as e:  # oracle .so missing and no compiler: report, don't fail the bench
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    W, H = fr.width, fr.height
     lit = np.zeros((H, W, 4), dtype=np.uint16)
-    gb = images.gbuffer(host)
-    lit_p = images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)
-    ao_p = images.plane(host["ao"], _abi.FORMAT_R32_SFLOAT)
-    sm_v = images.volume(host["shadowmap"], _abi.FORMAT_D16_UNORM)
-    sky = _abi.SkyLuts(images.plane(host["sky_t"], _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(host["sky_v"], _abi.FORMAT_R16G16B16A16_SFLOAT))
-    gi = _abi.GI()
-    gi.kind = gi_kind
-    if gi_kind == _abi.GI_LPV:
-        gi.lpv_red = images.volume(host["lpv_r"], _abi.FORMAT_R16G16B16A16_SFLOAT)
-        gi.lpv_green = images.volume(host["lpv_g"], _abi.FORMAT_R16G16B16A16_SFLOAT)
-        gi.lpv_blue = images.volume(host["lpv_b"], _abi.FORMAT_R16G16B16A16_SFLOAT)
-        gi.lpv_cascades = C.cast(lpv.matrices, C.POINTER(_abi.LpvCascadeMatrices))
-        gi.lpv_num_cascades = 4
-        gi.lpv_exposure = float(np.float32(math.pi) * np.float32(10.0))
-    d = _abi.LightingDesc()
-    d.gbuffer, d.lit, d.ao = C.pointer(gb), C.pointer(lit_p), C.pointer(ao_p)
-    d.view, d.sun = C.pointer(view.gpu_data), C.pointer(sun.constants)
-    d.shadowmap, d.sky, d.gi = C.pointer(sm_v), C.pointer(sky), C.pointer(gi)
-    d.flags = _abi.LIGHTING_DEFAULT_FLAGS
+    fr.row_begin = fr.row_end = 0
+    d, keep = fr.describe(fr.arrays, lit)
     cores = os.cpu_count() or 1
     mid = H // 2
     # calibrate on 16 rows, then size the band for ~target_s seconds

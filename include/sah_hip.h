@@ -174,7 +174,7 @@ typedef struct sah_sky_luts {
     sah_plane sky_view;      /* RGBA16F 200x200 */
 } sah_sky_luts;
 
-/* Extension (not in the reference): point lights, BASELINE configs 2/3/5.  Spec in DESIGN.md §a9. */
+/* Extension (not in the reference): point lights, BASELINE configs 2/3/5.  Spec in DESIGN.md §5b. */
 typedef struct sah_point_light {
     float position[3];
     float radius;
