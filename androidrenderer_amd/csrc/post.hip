@@ -147,12 +147,19 @@ SAH_DEV Axis axis_setup(float coord, uint32_t size) {
     return a;
 }
 
-// One tent tap = one bilinear sample from texels held in LDS (8 bytes each, row stride `stride` texels):
+// Axis set-up as the LDS tap loop consumes it: byte offsets of the two (clamped) texel columns / rows inside the staged
+// rectangle and the two weights.  Built once per workgroup for the 32 columns x 4 x-variants and 8 rows x 4 y-variants of
+// every mip (tile-shared), instead of 8 set-ups per mip per pixel.
+struct AxisE {
+    int o0, o1;
+    float w0, w1;
+};
+
+// One tent tap = one bilinear sample from texels held in LDS (8 bytes each):
 // acc = fma(w_k, t_k, acc) from +0 in tap order (t00, t10, t01, t11), conversions folded into v_fma_mix_f32.
-SAH_DEV C3 tap_lds(const uint2* tile, int stride, int x_org, int y_org, const Axis& ax, const Axis& ay) {
-    const uint2* r0 = tile + (ay.i0 - y_org) * stride - x_org;
-    const uint2* r1 = tile + (ay.i1 - y_org) * stride - x_org;
-    const uint2 t00 = r0[ax.i0], t10 = r0[ax.i1], t01 = r1[ax.i0], t11 = r1[ax.i1];
+SAH_DEV C3 tap_lds(const char* tex, const AxisE& ax, const AxisE& ay) {
+    const uint2 t00 = *reinterpret_cast<const uint2*>(tex + (ay.o0 + ax.o0)), t10 = *reinterpret_cast<const uint2*>(tex + (ay.o0 + ax.o1));
+    const uint2 t01 = *reinterpret_cast<const uint2*>(tex + (ay.o1 + ax.o0)), t11 = *reinterpret_cast<const uint2*>(tex + (ay.o1 + ax.o1));
     const float w00 = ax.w0 * ay.w0, w10 = ax.w1 * ay.w0, w01 = ax.w0 * ay.w1, w11 = ax.w1 * ay.w1;
     C3 c;
     c.r = fma_mix_lo(w11, t11.x, fma_mix_lo(w01, t01.x, fma_mix_lo(w10, t10.x, fma_mix_lo(w00, t00.x, 0.0f))));
@@ -163,19 +170,24 @@ SAH_DEV C3 tap_lds(const uint2* tile, int stride, int x_org, int y_org, const Ax
 
 // Tonemap composite, LDS-staged.  A 256-thread workgroup produces a 32x8 output tile.  For every bloom mip the texel
 // rectangle the tile can touch (tile bounds mapped into the mip, plus the reach of the tent offsets — which are -ix, -iy
-// and +ix in x and +ix, +-iy in y because scene_upsample.frag:29-32 mixes the components of `o`) is copied into LDS once;
-// every thread then evaluates its 9 taps x 6 mips from LDS with the 4+4 distinct axis set-ups per mip computed once.
-// A thread whose indices fall outside the staged rectangle (never for in-range tiles; kept as a guarantee) takes the
-// global-memory path for that mip.  Same operator sequence per tap as tent_blur(): results are bit-identical.
+// and +ix in x and +ix, +-iy in y because scene_upsample.frag:29-32 mixes the components of `o`) is copied into LDS once,
+// and the 4 + 4 distinct axis set-ups of every column / row of the tile are tabulated in LDS once (they depend on x or on y
+// only); every thread then evaluates its 9 taps x 6 mips from those tables.  If any set-up of a mip indexes outside the
+// staged rectangle (never for in-range tiles; kept as a guarantee) the whole workgroup takes the global-memory path for
+// that mip.  Same operator sequence per tap as tent_blur(): results are bit-identical.
 constexpr int kTmTileW = 32, kTmTileH = 8;
 constexpr int kTmMip0Texels = 640, kTmMipTexels = 224, kTmLdsTexels = kTmMip0Texels + 5 * kTmMipTexels;
+constexpr int kTmAxisPerMip = 4 * kTmTileW + 4 * kTmTileH;
 
 __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
     __shared__ uint2 s_tex[kTmLdsTexels];
-    __shared__ int s_rect[6][5];  // x0, y0, w, h, lds offset (w == 0: not staged)
-    __shared__ float s_thr[256];  // s_thr[k] = smallest x whose output code is >= k (k = 1..255); s_thr[0] unused
+    __shared__ AxisE s_ax[6][kTmAxisPerMip];  // [m][k*32 + column] (x variants k = 0..3), [m][128 + k*8 + row] (y variants)
+    __shared__ int s_rect[6][5];              // x0, y0, w, h, lds offset (w == 0: not staged)
+    __shared__ int s_bad[6];                  // 1: some set-up of mip m leaves the staged rectangle -> global path
+    __shared__ float s_thr[256];              // s_thr[k] = smallest x whose output code is >= k (k = 1..255); s_thr[0] unused
     s_thr[threadIdx.x] = t.thresholds[threadIdx.x];
     const uint32_t bx = blockIdx.x * kTmTileW, by = t.row_begin + blockIdx.y * kTmTileH;
+    const uint32_t x_last = min(bx + kTmTileW - 1, t.out_w - 1), y_last = min(by + kTmTileH - 1, t.row_end - 1);
     if (threadIdx.x < 6) {
         const uint32_t m = threadIdx.x;
         int* r = s_rect[m];
@@ -183,7 +195,6 @@ __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
         r[4] = m == 0 ? 0 : kTmMip0Texels + (int)(m - 1) * kTmMipTexels;
         if (m < t.num_mips) {
             const float W = (float)t.mip_w[m], H = (float)t.mip_h[m];
-            const uint32_t x_last = min(bx + kTmTileW - 1, t.out_w - 1), y_last = min(by + kTmTileH - 1, t.row_end - 1);
             // conservative texel bounds: tile extent in mip texels, widened by the largest tap offset (in texels) + 2
             const float reach_x = __builtin_fmaxf(1.0f, W / H) + 2.0f, reach_y = __builtin_fmaxf(1.0f, H / W) + 2.0f;
             const float pu0 = ((float)bx + 0.5f) / (float)t.out_w * W - 0.5f, pu1 = ((float)x_last + 0.5f) / (float)t.out_w * W - 0.5f;
@@ -195,6 +206,7 @@ __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
                 r[0] = x0; r[1] = y0; r[2] = w; r[3] = h;
             }
         }
+        s_bad[m] = r[2] == 0;
     }
     __syncthreads();
     for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) {
@@ -204,33 +216,58 @@ __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
             s_tex[off + i] = *reinterpret_cast<const uint2*>(t.mips[m].ptr + (size_t)(y0 + ty) * t.mips[m].pitch + (size_t)(x0 + tx) * 8);
         }
     }
-    __syncthreads();
-
-    const uint32_t x = bx + (threadIdx.x & (kTmTileW - 1)), y = by + threadIdx.x / kTmTileW;
-    if (x >= t.out_w || y >= t.row_end) return;
-    const float u = ((float)x + 0.5f) / (float)t.out_w;
-    const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
-    C3 bloom = {0.f, 0.f, 0.f};
-    for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) {
+    // axis tables: entry e of mip m; columns / rows past the image edge re-use the last valid one (those threads exit below)
+    for (uint32_t e = threadIdx.x; e < 6u * kTmAxisPerMip; e += 256) {
+        const uint32_t m = e / kTmAxisPerMip, i = e - m * kTmAxisPerMip;
+        if (m >= t.num_mips) break;
         const uint32_t W = t.mip_w[m], H = t.mip_h[m];
         const float ix = 1.0f / (float)W, iy = 1.0f / (float)H;
         const float ox = ix * -1.0f, oy = iy * -1.0f, oz = ix * 1.0f, ow = iy * 1.0f;
-        // distinct coordinates of the nine taps (scene_upsample.frag:28-36): x in {u, u+ox, u+oy, u+oz}, y in {v, v+oz, v+ow, v+oy}
-        const Axis xa = axis_setup(u, W), xb = axis_setup(u + ox, W), xc = axis_setup(u + oy, W), xd = axis_setup(u + oz, W);
-        const Axis ya = axis_setup(v + 0.f, H), yb = axis_setup(v + oz, H), yc = axis_setup(v + ow, H), yd = axis_setup(v + oy, H);
-        const int rx0 = s_rect[m][0], ry0 = s_rect[m][1], rw = s_rect[m][2], rh_ = s_rect[m][3];
-        const int xmin = min(min(xa.i0, xb.i0), min(xc.i0, xd.i0)), xmax = max(max(xa.i1, xb.i1), max(xc.i1, xd.i1));
-        const int ymin = min(min(ya.i0, yb.i0), min(yc.i0, yd.i0)), ymax = max(max(ya.i1, yb.i1), max(yc.i1, yd.i1));
+        const int rx0 = s_rect[m][0], ry0 = s_rect[m][1], rw = s_rect[m][2], rh_ = s_rect[m][3], off = s_rect[m][4];
+        AxisE en;
+        bool inside;
+        if (i < 4u * kTmTileW) {
+            // x variants (scene_upsample.frag:28-36): u, u + o.x, u + o.y, u + o.z
+            const uint32_t k = i / kTmTileW, x = min(bx + (i & (kTmTileW - 1)), x_last);
+            const float u = ((float)x + 0.5f) / (float)t.out_w;
+            const float c = k == 0 ? u : u + (k == 1 ? ox : k == 2 ? oy : oz);
+            const Axis a = axis_setup(c, W);
+            en = {(a.i0 - rx0) * 8, (a.i1 - rx0) * 8, a.w0, a.w1};
+            inside = a.i0 >= rx0 && a.i1 < rx0 + rw;
+        } else {
+            // y variants: v (+ 0.f), v + o.z, v + o.w, v + o.y
+            const uint32_t j = i - 4u * kTmTileW, k = j / kTmTileH, y = min(by + (j & (kTmTileH - 1)), y_last);
+            const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
+            const float c = v + (k == 0 ? 0.f : k == 1 ? oz : k == 2 ? ow : oy);
+            const Axis a = axis_setup(c, H);
+            en = {((a.i0 - ry0) * rw + off) * 8, ((a.i1 - ry0) * rw + off) * 8, a.w0, a.w1};
+            inside = a.i0 >= ry0 && a.i1 < ry0 + rh_;
+        }
+        s_ax[m][i] = en;
+        if (!inside) s_bad[m] = 1;
+    }
+    __syncthreads();
+
+    const uint32_t col = threadIdx.x & (kTmTileW - 1), row = threadIdx.x / kTmTileW;
+    const uint32_t x = bx + col, y = by + row;
+    if (x >= t.out_w || y >= t.row_end) return;
+    const float u = ((float)x + 0.5f) / (float)t.out_w;
+    const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
+    const char* tex = reinterpret_cast<const char*>(s_tex);
+    C3 bloom = {0.f, 0.f, 0.f};
+    for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) {
         C3 s;
-        if (rw > 0 && xmin >= rx0 && xmax < rx0 + rw && ymin >= ry0 && ymax < ry0 + rh_) {
-            const uint2* tile = s_tex + s_rect[m][4];
-            // (u + 0.f is u; the centre column re-uses xa, the centre row re-uses ya)
-            s = tap_lds(tile, rw, rx0, ry0, xa, ya) * 4.0f + tap_lds(tile, rw, rx0, ry0, xb, ya) * 2.0f + tap_lds(tile, rw, rx0, ry0, xc, ya) * 2.0f +
-                tap_lds(tile, rw, rx0, ry0, xa, yb) * 2.0f + tap_lds(tile, rw, rx0, ry0, xa, yc) * 2.0f + tap_lds(tile, rw, rx0, ry0, xb, yd) * 1.0f +
-                tap_lds(tile, rw, rx0, ry0, xd, yd) * 1.0f + tap_lds(tile, rw, rx0, ry0, xb, yc) * 1.0f + tap_lds(tile, rw, rx0, ry0, xd, yc) * 1.0f;
+        if (!s_bad[m]) {
+            const AxisE* ax = s_ax[m];
+            const AxisE xa = ax[col], xb = ax[kTmTileW + col], xc = ax[2 * kTmTileW + col], xd = ax[3 * kTmTileW + col];
+            const AxisE* ayp = ax + 4 * kTmTileW + row;
+            const AxisE ya = ayp[0], yb = ayp[kTmTileH], yc = ayp[2 * kTmTileH], yd = ayp[3 * kTmTileH];
+            s = tap_lds(tex, xa, ya) * 4.0f + tap_lds(tex, xb, ya) * 2.0f + tap_lds(tex, xc, ya) * 2.0f + tap_lds(tex, xa, yb) * 2.0f +
+                tap_lds(tex, xa, yc) * 2.0f + tap_lds(tex, xb, yd) * 1.0f + tap_lds(tex, xd, yd) * 1.0f + tap_lds(tex, xb, yc) * 1.0f +
+                tap_lds(tex, xd, yc) * 1.0f;
             s = {s.r / 16.f, s.g / 16.f, s.b / 16.f};
         } else {
-            s = tent_blur(t.mips[m], W, H, u, v);
+            s = tent_blur(t.mips[m], t.mip_w[m], t.mip_h[m], u, v);
         }
         bloom = bloom + s;
     }
