@@ -14,6 +14,7 @@ OUT = os.path.join(HERE, "libsah_hip.so")
 SOURCES = ["api.cpp", "api_post.cpp", "lighting.hip", "lighting_tiled.hip", "post.hip", "lpv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
+FLAGS += os.environ.get("SAH_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DSAH_EXP_...); never set by the driver
 
 
 def needs_build():

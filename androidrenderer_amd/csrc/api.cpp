@@ -51,6 +51,13 @@ bool all_finite(const float* m, int n) {
         if (!std::isfinite(m[i])) return false;
     return true;
 }
+// |m[i]| <= 2^40 (NaN fails): with |world position| <= 2^41 (the kernel defers anything farther from the camera than 2^40) every
+// product and partial sum of an affine transform stays finite, so cascade / shadow coordinates are never NaN for shaded pixels.
+bool all_bounded(const float* m, int n) {
+    for (int i = 0; i < n; i++)
+        if (!(std::fabs(m[i]) <= 0x1p+40f)) return false;
+    return true;
+}
 
 // Decides whether the uniform blocks have the structure the fast kernel assumes (DESIGN.md "Fast path proofs").
 // Column-major m[col*4 + row].
@@ -64,6 +71,7 @@ bool detect_fast_path(const sah_lighting_desc* d, uint32_t sun_mode, uint32_t gi
         return false;
     // inverse_view: affine
     if (!(is_zero(V[3]) && is_zero(V[7]) && is_zero(V[11]) && V[15] == 1.0f)) return false;
+    if (!all_bounded(d->view->view + 12, 3)) return false;  // camera position (-view[3].xyz)
     f->p0 = P[0]; f->p12 = P[12]; f->p5 = P[5]; f->p13 = P[13];
     f->p10 = P[10]; f->p14 = P[14]; f->p11 = P[11]; f->p15 = P[15];
     if (sun_mode == SAH_SHADOW_MODE_CSM) {
@@ -71,7 +79,7 @@ bool detect_fast_path(const sah_lighting_desc* d, uint32_t sun_mode, uint32_t gi
         if (!csm.is_d16 || !csm.d16_recip_ok) return false;
         for (int c = 0; c < 4; c++) {
             const float* b = csm.biased[c];
-            if (!all_finite(b, 16)) return false;
+            if (!all_bounded(b, 16)) return false;
             if (!(is_zero(b[3]) && is_zero(b[7]) && is_zero(b[11]) && b[15] == 1.0f)) return false;
         }
     }
@@ -85,7 +93,7 @@ bool detect_fast_path(const sah_lighting_desc* d, uint32_t sun_mode, uint32_t gi
             return false;
         for (uint32_t c = 0; c < gi.lpv_num_cascades; c++) {
             const float* m = gi.lpv_cascades[c].world_to_cascade;
-            if (!all_finite(m, 16)) return false;
+            if (!all_bounded(m, 16)) return false;
             if (!(is_zero(m[1]) && is_zero(m[2]) && is_zero(m[3]) && is_zero(m[4]) && is_zero(m[6]) && is_zero(m[7]) && is_zero(m[8]) &&
                   is_zero(m[9]) && is_zero(m[11]) && m[15] == 1.0f))
                 return false;
@@ -174,6 +182,7 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->luts) (void)hipFree(ctx->luts);
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);
+    if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -430,6 +439,23 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             ctx->list_bytes = 0;
             HIP_TRY(ctx, hipMalloc((void**)&ctx->list, need));
             ctx->list_bytes = need;
+        }
+        if (gi_kind == SAH_GI_LPV) {  // gather copy of the LPV volumes, rebuilt by k_lpv_pack on every call
+            const uint64_t row = (uint64_t)(lpv.red.width + 2 * kLpvPackBorder) * kLpvPackTexel;
+            const uint64_t slice = row * (lpv.red.height + 2 * kLpvPackBorder);
+            const uint64_t total = slice * (lpv.red.depth + 2 * kLpvPackBorder) + 64;  // + slack: the last x-pair is read as 48 bytes
+            if (total >= (1ull << 32)) return fail(ctx, SAH_ERR_UNSUPPORTED, "LPV volumes too large for the packed gather copy");
+            if (ctx->lpv_packed_bytes < total) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
+                ctx->lpv_packed = nullptr;
+                ctx->lpv_packed_bytes = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->lpv_packed, total));
+                ctx->lpv_packed_bytes = total;
+            }
+            fast.lpv_packed = ctx->lpv_packed;
+            fast.pk_row_pitch = (uint32_t)row;
+            fast.pk_slice_pitch = (uint32_t)slice;
         }
         fast.sky_enabled = sky.enabled;
         fast.parity = ctx->parity;

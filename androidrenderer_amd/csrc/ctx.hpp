@@ -22,6 +22,8 @@ struct sah_ctx {
     sah::FrameState* state = nullptr;  // device
     uint32_t* list = nullptr;          // device: deferred-pixel list
     size_t list_bytes = 0;
+    uint8_t* lpv_packed = nullptr;     // device: per-frame interleaved, zero-bordered copy of the three LPV volumes (lighting.hip)
+    size_t lpv_packed_bytes = 0;
     uint32_t parity = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds (api_post.cpp)
     std::string last_error;

@@ -104,21 +104,38 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
     }
 }
 
-// ---- LPV finiteness scan (feeds the "specular quirk is inert" proof) ---------------------------------------------------
-__global__ void __launch_bounds__(256) k_lpv_scan(const VolumeArg r, const VolumeArg g, const VolumeArg b, FrameState* state, uint32_t parity) {
-    const uint32_t row = blockIdx.x;  // one block per (z, y) row of the three volumes
-    const uint32_t z = row / r.height, y = row - z * r.height;
+// ---- LPV gather copy + finiteness scan -----------------------------------------------------------------------------------
+// Once per Lighting pass (3 MiB in, 4 MiB out, L2 resident): interleaves the three RGBA16F volumes into 24-byte texels
+// {R[4], G[4], B[4]} surrounded by a two-texel border of zeros, and flags inf / NaN texels (feeds the "specular quirk is inert"
+// proof).  The fast kernel then gathers one trilinear footprint as 4 (y,z) rows x 48 contiguous bytes = 12 dwordx4 loads touching
+// 4-5 cache lines, instead of 24 dwordx2 loads over three allocations, and CLAMP_TO_BORDER needs no per-tap masking: border
+// texels are real zeros.
+__global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const VolumeArg g, const VolumeArg b, uint8_t* packed, uint32_t pk_row_pitch,
+                                                  uint32_t pk_slice_pitch, FrameState* state, uint32_t parity) {
+    const uint32_t prow = blockIdx.x;  // one block per padded (z, y) row
+    const uint32_t ph = r.height + 2 * kLpvPackBorder;
+    const uint32_t pz = prow / ph, py = prow - pz * ph;
+    const int z = (int)pz - (int)kLpvPackBorder, y = (int)py - (int)kLpvPackBorder;
+    const bool row_inside = z >= 0 && z < (int)r.depth && y >= 0 && y < (int)r.height;
     uint32_t bad = 0;
-    const VolumeArg* vols[3] = {&r, &g, &b};
+    uint8_t* dst_row = packed + (size_t)pz * pk_slice_pitch + (size_t)py * pk_row_pitch;
+    for (uint32_t px = threadIdx.x; px < r.width + 2 * kLpvPackBorder; px += 256) {
+        const int x = (int)px - (int)kLpvPackBorder;
+        uint2 t[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+        if (row_inside && x >= 0 && x < (int)r.width) {
+            t[0] = *reinterpret_cast<const uint2*>(r.ptr + (size_t)z * r.slice_pitch + (size_t)y * r.row_pitch + (size_t)x * 8);
+            t[1] = *reinterpret_cast<const uint2*>(g.ptr + (size_t)z * g.slice_pitch + (size_t)y * g.row_pitch + (size_t)x * 8);
+            t[2] = *reinterpret_cast<const uint2*>(b.ptr + (size_t)z * b.slice_pitch + (size_t)y * b.row_pitch + (size_t)x * 8);
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const uint8_t* base = vols[c]->ptr + (size_t)z * vols[c]->slice_pitch + (size_t)y * vols[c]->row_pitch;
-        for (uint32_t x = threadIdx.x; x < vols[c]->width; x += 256) {
-            const uint2 t = *reinterpret_cast<const uint2*>(base + (size_t)x * 8);
-            // fp16 exponent all ones <=> inf or NaN
-            bad |= ((t.x & 0x7c00u) == 0x7c00u) | ((t.x & 0x7c000000u) == 0x7c000000u) | ((t.y & 0x7c00u) == 0x7c00u) |
-                   ((t.y & 0x7c000000u) == 0x7c000000u);
+            for (int c = 0; c < 3; c++) {  // fp16 exponent all ones <=> inf or NaN
+                bad |= ((t[c].x & 0x7c00u) == 0x7c00u) | ((t[c].x & 0x7c000000u) == 0x7c000000u) | ((t[c].y & 0x7c00u) == 0x7c00u) |
+                       ((t[c].y & 0x7c000000u) == 0x7c000000u);
+            }
         }
+        uint2* dst = reinterpret_cast<uint2*>(dst_row + (size_t)px * kLpvPackTexel);
+        dst[0] = t[0];
+        dst[1] = t[1];
+        dst[2] = t[2];
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&state->nonfinite[parity], 1u);
 }
@@ -246,7 +263,9 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     const uint64_t groups = (uint64_t)(a.width / ppt) * rows;
     if (groups == 0) return hipSuccess;
     if (GI == SAH_GI_LPV) {
-        hipLaunchKernelGGL(k_lpv_scan, dim3(lpv.red.height * lpv.red.depth), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, f.state, f.parity);
+        const uint32_t prows = (lpv.red.height + 2 * kLpvPackBorder) * (lpv.red.depth + 2 * kLpvPackBorder);
+        hipLaunchKernelGGL(k_lpv_pack, dim3(prows), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, const_cast<uint8_t*>(f.lpv_packed), f.pk_row_pitch,
+                           f.pk_slice_pitch, f.state, f.parity);
     }
     const dim3 grid((uint32_t)((groups + 255) / 256)), block(256);
     if (ppt == 4) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4>), grid, block, 0, st, a, csm, lpv, f);

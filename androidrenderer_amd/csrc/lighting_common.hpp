@@ -302,6 +302,59 @@ SAH_DEV void lpv_fetch(const LpvArgs& L, F4 p, const Fn (&n)[4], Fn (&out)[3]) {
     out[2] = dot4(b, n);
 }
 
+// Fast-path LPV gather from the per-frame packed copy (lighting.hip: k_lpv_pack; params.hpp: FastArgs::lpv_packed) for FINITE
+// coordinates and FINITE volume contents.  The copy holds the three volumes interleaved (24-byte texels) inside a two-texel
+// border of zeros, so a trilinear footprint is 4 (y,z) rows of 48 contiguous bytes — 12 dwordx4 loads from 4 addresses — and
+// CLAMP_TO_BORDER is literal: an outside tap reads a zero texel with its true weight, exactly the sampler formula.  The base
+// index is clamped to [-2, size] per axis: both taps of an axis are then border texels whenever both true taps are outside.
+SAH_DEV void lpv_fetch_packed(const LpvArgs& L, const uint8_t* packed, uint32_t row_pitch, uint32_t slice_pitch, float u, float v, float w,
+                              const Fn (&n)[4], Fn (&out)[3]) {
+    const int W = (int)L.red.width, H = (int)L.red.height, D = (int)L.red.depth;
+    const float px = u * (float)W - 0.5f, py = v * (float)H - 0.5f, pz = w * (float)D - 0.5f;
+    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py), fz0 = __builtin_floorf(pz);
+    const float fx = px - fx0, fy = py - fy0, fz = pz - fz0;
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    const int b = (int)kLpvPackBorder;
+    const uint32_t x0 = (uint32_t)(min(max(clamp_to_int(fx0), -b), W) + b), y0 = (uint32_t)(min(max(clamp_to_int(fy0), -b), H) + b),
+                   z0 = (uint32_t)(min(max(clamp_to_int(fz0), -b), D) + b);
+#ifdef SAH_EXP_UNIFORM_GATHER  // experiment: same VALU work, every lane reads texel 0 (isolates the cost of divergent gathers)
+    const uint32_t base = (z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel) & 0u;
+#else
+    const uint32_t base = z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel;
+#endif
+    const uint32_t ro[4] = {base, base + row_pitch, base + slice_pitch, base + slice_pitch + row_pitch};  // (y0,z0) (y1,z0) (y0,z1) (y1,z1)
+    uint32_t d[4][12];  // per row: R(x0) G(x0) B(x0) R(x1) G(x1) B(x1), two dwords (four halves) each
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint4 q = *reinterpret_cast<const uint4*>(packed + ro[r] + 16u * (uint32_t)j);
+            d[r][4 * j] = q.x;
+            d[r][4 * j + 1] = q.y;
+            d[r][4 * j + 2] = q.z;
+            d[r][4 * j + 3] = q.w;
+        }
+    }
+    const float wxy[4] = {gx * gy, fx * gy, gx * fy, fx * fy};
+    float wt[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) wt[k] = wxy[k & 3] * ((k >> 2) ? fz : gz);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {  // tap order: x fastest, then y, then z
+            const int r = k >> 1, xs = k & 1;
+            const uint32_t lo = d[r][xs * 6 + c * 2], hi = d[r][xs * 6 + c * 2 + 1];
+            a[0] = fma_mix_lo(wt[k], lo, a[0]);
+            a[1] = fma_mix_hi(wt[k], lo, a[1]);
+            a[2] = fma_mix_lo(wt[k], hi, a[2]);
+            a[3] = fma_mix_hi(wt[k], hi, a[3]);
+        }
+        out[c] = dot4(a, n);
+    }
+}
+
 // Fast-path variant of lpv_fetch for FINITE coordinates and FINITE volume contents: taps outside the volume keep an
 // in-bounds (clamped) address and get a zero weight factor instead of a zero texel — fma(0, t, acc) == fma(w, 0, acc) == acc
 // for finite t, w (DESIGN.md "Fast path proofs") — so the eight loads per volume are unconditional.
@@ -324,6 +377,9 @@ SAH_DEV void lpv_fetch_fast(const LpvArgs& L, float u, float v, float w, const F
     for (int k = 0; k < 8; k++) {
         wt[k] = wxy[k & 3] * ((k >> 2) ? az1 : az0);
         off[k] = zo[k >> 2] + yo[(k >> 1) & 1] + xo[k & 1];
+#ifdef SAH_EXP_UNIFORM_GATHER  // experiment: same VALU work, every lane reads texel 0 (isolates the cost of divergent gathers)
+        off[k] = off[k] & 0u;
+#endif
     }
     const uint8_t* vols[3] = {L.red.ptr, L.green.ptr, L.blue.ptr};
     uint2 t[3][8];

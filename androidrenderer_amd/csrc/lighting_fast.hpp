@@ -41,6 +41,50 @@ template <class T> SAH_DEV V3<T> brdf_sl(const Surface<T>& s, V3<T> l, V3<T> v) 
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
 
+// fp32 brdf() of the fast path: brdf_sl<Fn> with every sqrt / divide replaced by its restricted-range twin (numerics.hpp:
+// sqrt_nr, rcp_nr, div_nr — same bits inside the domain).  `out_of_domain` is set when an operand leaves the domain for a
+// pixel whose BRDF value is used (NoL > 0); the caller then sends the pixel to the fix-up kernel.  Ranges by construction:
+// roughness is a UNORM8 value, the clamped dots are in [0,1], so only the lower bounds need a compare.
+SAH_DEV F3 brdf_fast(const Surface<Fn>& s, F3 l, F3 v, bool& out_of_domain) {
+    const Fn one = Fn(1.0f), zero = Fn(0.0f);
+    const Fn dielectric_f0 = Fn(0.04f);
+    const F3 f0 = mix(F3(dielectric_f0), s.base_color, s.metalness);
+    const F3 diffuse_color = s.base_color * (one - dielectric_f0) * (one - s.metalness);
+    const F3 vl = v + l;
+    const Fn dh = dot(vl, vl);  // <= 4 + eps
+    const F3 h = vl * Fn(rcp_nr(sqrt_nr(dh.v)));
+    Fn NoV = dot(s.normal, v) + Fn(1e-5f);
+    Fn NoL = dot(s.normal, l);
+    const Fn NoH = nclamp(dot(s.normal, h), zero, one);
+    const Fn VoH = nclamp(dot(v, h), zero, one);
+    const bool dark = NoL.v <= 0.f;
+    NoV = nabs(NoV);
+    NoL = nclamp(NoL, zero, one);
+    const Fn LoH = nclamp(dot(l, h), zero, one);
+    const F3 fd = diffuse_color * Fd_Burley(NoV, NoL, LoH, s.roughness);
+    // D_GGX
+    const Fn a = s.roughness;
+    const Fn dden = one - NoH * NoH + a * a;
+    const Fn k = Fn(div_nr(a.v, dden.v));
+    const Fn D = k * k * (one / brdf_pi<Fn>());
+    const F3 Fv = F_Schlick(VoH, f0, one);
+    // V_SmithGGXCorrelated
+    const Fn a2 = a * a;
+    const Fn argL = (-NoL * a2 + NoL) * NoL + a2, argV = (-NoV * a2 + NoV) * NoV + a2;
+    const Fn GGXL = NoV * Fn(sqrt_nr(argL.v));
+    const Fn GGXV = NoL * Fn(sqrt_nr(argV.v));
+    const Fn vden = GGXV + GGXL;
+    const Fn Vis = Fn(div_nr(0.5f, vden.v));
+    const F3 fr = (D * Vis) * Fv;
+    const F3 sum = fd + fr;
+    // lower bounds: one min3 / min per class, then one compare each.  Upper bounds hold by construction for unit N, V, L
+    // (dh <= 4, NoV <= 1.00002, a <= 1  =>  every operand above is <= 4).
+    const float lo_sqrt = __builtin_fminf(__builtin_fminf(dh.v, argL.v), argV.v);
+    const float lo_div = __builtin_fminf(dden.v, vden.v);
+    out_of_domain = !dark && !(lo_sqrt >= 0x1p-80f && lo_div >= kDivLo);
+    return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
+}
+
 struct FastPixelOut {
     uint2 lit;
     bool deferred;
@@ -65,7 +109,9 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     F3 N, ws, V;
     Fn vsz;
     if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) {
-        const Fn inv = Fn(1.0f) / nsqrt(Fn(dn));
+        // dn is a sum of squares of fp16 values: 2^-48 <= dn < 2^35 whenever it is positive and finite (checked above), so the
+        // restricted-range sqrt / reciprocal apply (numerics.hpp)
+        const Fn inv = Fn(rcp_nr(sqrt_nr(dn)));
         N = F3{Fn(si.normal[0]) * inv, Fn(si.normal[1]) * inv, Fn(si.normal[2]) * inv};
         // inverse_projection separable: vs = ((p0*X)+p12, (p5*Y)+p13, (p10*D)+p14, (p11*D)+p15)
         const Fn vw = Fn(f.p11) * Fn(D) + Fn(f.p15);
@@ -79,8 +125,9 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         ws.z = Fn(mz.x) * vx + Fn(mz.y) * vy + Fn(mz.z) * vsz + Fn(mz.w);
         const F3 d = ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])};
         const Fn d2 = dot(d, d);
-        ok = ok && finite_f(ws.x.v) && finite_f(ws.y.v) && finite_f(ws.z.v) && d2.v > 0.f && finite_f(d2.v);
-        V = d * (Fn(1.0f) / nsqrt(d2));
+        // 2^-80 <= d2 <= 2^80 implies finite ws (view_pos is finite: host check) and puts sqrt / reciprocal in their domain
+        ok = ok && d2.v >= 0x1p-80f && d2.v <= 0x1p+80f;
+        V = d * Fn(rcp_nr(sqrt_nr(d2.v)));
     }
 
     Surface<Fn> s;
@@ -104,7 +151,11 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
             const Fn cx = Fn(cs_.x) * ws.x + Fn(ct_.x);
             const Fn cy = Fn(cs_.y) * ws.y + Fn(ct_.y);
             const Fn cz = Fn(cs_.z) * ws.z + Fn(ct_.z);
-            return cx.v > 0.f && cy.v > 0.f && cz.v > 0.f && cx.v < 1.f && cy.v < 1.f && cz.v < 1.f;
+            // all(c > 0) && all(c < 1) as min3 / max3 + two compares (compares cost as much as min3: 4 cycles).  cx, cy, cz are
+            // finite for every pixel that is not deferred (finite ws, |scale|, |translate| <= 2^40: host check), so the
+            // NaN-dropping behaviour of v_min3 / v_max3 cannot matter
+            const float mn = __builtin_fminf(__builtin_fminf(cx.v, cy.v), cz.v), mxv = __builtin_fmaxf(__builtin_fmaxf(cx.v, cy.v), cz.v);
+            return mn > 0.f && mxv < 1.f;
         };
         uint32_t selected = 0;
         const bool in0 = inside(0u);
@@ -143,7 +194,10 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
 #pragma unroll
             for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
             const uint32_t cc = cascade > 3u ? 3u : cascade;  // cascade 4 means "no shadow map": keep the address legal
-            const Fn bias = Fn(0.0005f) * nsqrt(Fn(1.0f) - ndotl_sun * ndotl_sun) / ndotl_sun;
+            // 1 - ndotl^2 is 0 or >= 2^-24 (ndotl in [0,1]); 0.0005 * sqrt(.) is +0 or in [2^-24, 2^-10]; ndotl needs a lower bound
+            const Fn bias_num = Fn(0.0005f) * Fn(sqrt_nr0((Fn(1.0f) - ndotl_sun * ndotl_sun).v));
+            const Fn bias = Fn(div_nr(bias_num.v, ndotl_sun.v));
+            ok = ok && !(ndotl_sun.v > 0.f && ndotl_sun.v < kDivLo);
             // affine shadow matrix: sp.w == 1, so the perspective divide is the identity; rows come from the LDS table
             const float4 rx = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u);
             const float4 ry = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 4u);
@@ -151,7 +205,9 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
             const Fn spx = Fn(rx.x) * ws.x + Fn(rx.y) * ws.y + Fn(rx.z) * ws.z + Fn(rx.w);
             const Fn spy = Fn(ry.x) * ws.x + Fn(ry.y) * ws.y + Fn(ry.z) * ws.z + Fn(ry.w);
             const Fn spz = Fn(rz.x) * ws.x + Fn(rz.y) * ws.y + Fn(rz.z) * ws.z + Fn(rz.w);
-            const bool sp_inside = !(spx.v < 0.f || spy.v < 0.f || spz.v < 0.f || spx.v > 1.f || spy.v > 1.f || spz.v > 1.f);
+            // !(any(sp < 0) || any(sp > 1)) via min3 / max3; sp is finite for every pixel that is not deferred (see inside())
+            const float sp_mn = __builtin_fminf(__builtin_fminf(spx.v, spy.v), spz.v), sp_mx = __builtin_fmaxf(__builtin_fmaxf(spx.v, spy.v), spz.v);
+            const bool sp_inside = !(sp_mn < 0.f || sp_mx > 1.f);
             float pcf_ref = (spz - bias).v;
             pcf_ref = pcf_ref < 0.f ? 0.f : (pcf_ref > 1.f ? 1.f : pcf_ref);  // D16: D_ref clamped to [0,1]
             const VolumeArg& sm = csm.shadowmap;
@@ -163,7 +219,11 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
             const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * 2u, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * 2u;
             const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
             const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
+#ifdef SAH_EXP_UNIFORM_GATHER
+            const uint32_t pcf_off[4] = {(lo + ra + xa) & 0u, (lo + ra + xb) & 0u, (lo + rb + xa) & 0u, (lo + rb + xb) & 0u};
+#else
             const uint32_t pcf_off[4] = {lo + ra + xa, lo + ra + xb, lo + rb + xa, lo + rb + xb};
+#endif
             // PCF taps (compare LESS, then filter); the fast path is D16_UNORM only (anything else: general kernel)
             float dtap[4];
             uint16_t raw[4];
@@ -185,10 +245,14 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
             shadow = cascade > 3u ? 0.0f : shadow;
             shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
             if (__any(ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f)) {
-                const F3 b = brdf_sl(s, L, V);
-                F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
-                const bool bad = any_nan(direct);
-                direct = {bad ? Fn(0.f) : direct.x, bad ? Fn(0.f) : direct.y, bad ? Fn(0.f) : direct.z};
+                bool brdf_out_of_domain;
+                const F3 b = brdf_fast(s, L, V, brdf_out_of_domain);
+                const F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
+                // `if (any(isnan(direct))) direct = 0`: a NaN component (inf * 0 after an overflow; rare) sends the pixel to the
+                // fix-up kernel instead of paying three compare + select pairs here.  x + y + z is NaN iff a component is NaN
+                // or two are opposite infinities (then the pixel is deferred needlessly, which is harmless).
+                const float nan_probe = (direct.x + direct.y + direct.z).v;
+                ok = ok && !brdf_out_of_domain && nan_probe == nan_probe;
                 const Fn exposure = Fn(0.00031415927f);
                 sc[0] = direct.x * exposure;
                 sc[1] = direct.y * exposure;
@@ -205,7 +269,7 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     // ---------------- a3: LPV overlay ----------------
     if constexpr (GI == SAH_GI_LPV) {
         Fn indirect[3];
-        lpv_fetch_fast(lpv, lpv_u, lpv_v, lpv_w, nc, indirect);
+        lpv_fetch_packed(lpv, f.lpv_packed, f.pk_row_pitch, f.pk_slice_pitch, lpv_u, lpv_v, lpv_w, nc, indirect);
         // Fd(surface, N, N) == diffuse_color * (1/pi) exactly when N is a finite normalised vector, and the specular term
         // is (finite) * (finite * 0) == +-0 when roughness > 0 and the volumes are finite (DESIGN.md "Fast path proofs").
         const Fn dielectric_f0 = Fn(0.04f);
@@ -213,9 +277,10 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         const Fn inv_pi = (Fn(1.0f) * Fn(1.0f)) * (Fn(1.0f) / Fn(3.1415927f));
         const F3 diffuse_factor = diffuse_color * inv_pi;
         const Fn ao = Fn(p.ao);
-        F3 total = {indirect[0] * diffuse_factor.x * ao, indirect[1] * diffuse_factor.y * ao, indirect[2] * diffuse_factor.z * ao};
-        const bool bad = any_nan(total);
-        total = {bad ? Fn(0.f) : total.x, bad ? Fn(0.f) : total.y, bad ? Fn(0.f) : total.z};
+        const F3 total = {indirect[0] * diffuse_factor.x * ao, indirect[1] * diffuse_factor.y * ao, indirect[2] * diffuse_factor.z * ao};
+        // `if (any(isnan(total))) total = 0` (a NaN AO texel, inf * 0): deferred rather than selected, as for the sun term
+        const float nan_probe = (total.x + total.y + total.z).v;
+        ok = ok && nan_probe == nan_probe;
         const Fn exposure = Fn(lpv.exposure);
         lit[0] = Hn(tof(lit[0]) + (total.x * exposure).v);
         lit[1] = Hn(tof(lit[1]) + (total.y * exposure).v);

@@ -56,6 +56,57 @@ SAH_DEV Fn npow5(Fn a) {
 }
 SAH_DEV float tof(Fn a) { return a.v; }
 
+// ---- correctly rounded sqrt / reciprocal / divide for operands of KNOWN range ----------------------------------------------
+// hipcc's IEEE expansions carry range handling the fast kernel does not need once the operand range is established (by
+// construction or by a compare that sends the pixel to the fix-up kernel): sqrt = 15 instructions (denormal pre/post scaling, a
+// +-1 ulp probe with two compare/select pairs, inf/zero select), divide = 11 (two v_div_scale, v_div_fmas, v_div_fixup).  On
+// MI355X v_{mul,add,fma}_f32 issue in 2 cycles, compares / selects / v_div_* in 4, v_rcp/v_rsq/v_sqrt in 8
+// (profiles/r1_valu_issue_cost.txt), so the range handling is most of the cost (sqrt 66 -> 22 cycles, 1/x 34 -> 16, a/b 34 -> 22).
+// The sequences below are the classical Newton / Markstein refinements; `tools/microbench/exact_math_check.hip` compares
+// them with the IEEE operators for EVERY fp32 input of the stated domain (sqrt, reciprocal) and for 2^36 operand pairs
+// including all-ones / all-zeros mantissa neighbourhoods (divide).  Outside the domain the results are unspecified.
+constexpr float kNrLo = 0x1p-100f, kNrHi = 0x1p+100f;  // domain of sqrt_nr / rcp_nr (magnitudes)
+constexpr float kDivLo = 0x1p-40f, kDivHi = 0x1p+40f;  // domain of div_nr (|a|, |b|; a may also be +0)
+
+// x in [2^-100, 2^100] -> RN(sqrt(x))
+SAH_DEV float sqrt_nr(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    const float g1 = __builtin_fmaf(g, r, g), h1 = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g1, g1, x);
+    return __builtin_fmaf(d, h1, g1);
+}
+// as sqrt_nr, and +0 -> +0 (rsq(0) = +inf is clamped so that g = 0 * y stays 0)
+SAH_DEV float sqrt_nr0(float x) {
+    const float y = __builtin_fminf(__builtin_amdgcn_rsqf(x), 0x1p+100f);
+    const float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    const float g1 = __builtin_fmaf(g, r, g), h1 = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g1, g1, x);
+    return __builtin_fmaf(d, h1, g1);
+}
+// |x| in [2^-100, 2^100] -> RN(1 / x)
+SAH_DEV float rcp_nr(float x) {
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, y0, 1.0f);
+    const float y1 = __builtin_fmaf(e, y0, y0);
+    const float r = __builtin_fmaf(-x, y1, 1.0f);
+    return __builtin_fmaf(r, y1, y1);
+}
+// |a| in {+0} U [2^-40, 2^40], |b| in [2^-40, 2^40] -> RN(a / b): hipcc's own expansion minus v_div_scale / v_div_fmas scaling /
+// v_div_fixup, none of which acts on such operands
+SAH_DEV float div_nr(float a, float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    const float y1 = __builtin_fmaf(e, y0, y0);
+    const float q0 = a * y1;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y1, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y1, q1);
+}
+
 // An fp32 value is hidden from the optimiser before it is rounded to fp16.  Without this LLVM (a) narrows
 // fptrunc(fdiv(fpext, fpext)) to a half fdiv whose v_rcp_f16 expansion is not correctly rounded, and (b) fuses
 // fptrunc(fmul/fadd) into v_fma_mixlo_f16, i.e. ONE rounding of the exact result, where the contract (and the

@@ -86,7 +86,12 @@ struct FastArgs {
     uint32_t fixup_blocks;
     FrameState* state;
     uint32_t* list;  // deferred pixel indices (y * width + x), capacity width * height
+    // LPV gather copy (k_lpv_pack): texel (x,y,z) of the three volumes interleaved as 24 bytes {R[4], G[4], B[4]} (fp16) at
+    // ((z+2) * pk_slice_pitch + (y+2) * pk_row_pitch + (x+2) * 24), inside a two-texel border of zeros (= CLAMP_TO_BORDER)
+    const uint8_t* lpv_packed;
+    uint32_t pk_row_pitch, pk_slice_pitch;
 };
+constexpr uint32_t kLpvPackTexel = 24, kLpvPackBorder = 2;
 
 struct LightingArgs {
     PlaneArg color, normals, data, emission, depth, ao, shadow_mask, lit;
