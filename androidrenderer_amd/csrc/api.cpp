@@ -74,6 +74,18 @@ bool detect_fast_path(const sah_lighting_desc* d, uint32_t sun_mode, uint32_t gi
     if (!all_bounded(d->view->view + 12, 3)) return false;  // camera position (-view[3].xyz)
     f->p0 = P[0]; f->p12 = P[12]; f->p5 = P[5]; f->p13 = P[13];
     f->p10 = P[10]; f->p14 = P[14]; f->p11 = P[11]; f->p15 = P[15];
+    {
+        // Shared-reciprocal divide for vs = (X, Y, Z) / w (lighting_fast.hpp): numerators must be +0 or 2^-40 <= |n| <= 2^40.
+        // X = p0 * ndc.x + p12 with ndc.x = tx * 2 - 1 either 0 or >= 2^-24 in magnitude (tx * 2 is exact, the subtraction is exact
+        // by Sterbenz near 1 and >= 0.5 in magnitude elsewhere) and <= 2^9 when width <= 256 * render_resolution; so
+        // 2^-16 <= |p0| <= 2^30 and p12 == +0 keep X in the domain (a -0 product plus +0 is +0).  Same for Y.  Z is the constant p14
+        // when p10 == 0, which holds for every perspective projection's inverse.
+        auto in = [](float v, float lo, float hi) { return std::fabs(v) >= lo && std::fabs(v) <= hi; };
+        const float r0 = d->view->render_resolution[0], r1 = d->view->render_resolution[1];
+        f->pos_div_nr = P[10] == 0.0f && P[12] == 0.0f && !std::signbit(P[12]) && P[13] == 0.0f && !std::signbit(P[13]) &&
+                        in(P[0], 0x1p-16f, 0x1p+30f) && in(P[5], 0x1p-16f, 0x1p+30f) && in(P[14], 0x1p-40f, 0x1p+40f) && r0 > 0.f && r1 > 0.f &&
+                        (float)d->lit->width <= 256.0f * r0 && (float)d->lit->height <= 256.0f * r1;
+    }
     if (sun_mode == SAH_SHADOW_MODE_CSM) {
         if (!csm.shadowmap.ptr || (uint64_t)csm.shadowmap.slice_pitch * csm.shadowmap.depth >= (1ull << 32)) return false;
         if (!csm.is_d16 || !csm.d16_recip_ok) return false;
@@ -414,9 +426,9 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         sky.smooth_e0 = round_to_half(0.002f);
     }
 
-    // pixels per thread: 4 (16 B/lane loads) for the deferred-only variants; 2 when the LPV gather is fused in (measured on
-    // MI355X: the 4-pixel body needs 125+ VGPRs and spills)
-    int ppt = vec4ok ? (gi_kind == SAH_GI_LPV ? 2 : 4) : 1;
+    // pixels per thread: 4 (16 B/lane plane loads) whenever pitches and width allow (measured on MI355X, DESIGN.md §7: with the
+    // packed LPV gather the 4-pixel body fits 106 VGPRs without spills and beats 2 px/thread by ~4 %)
+    int ppt = vec4ok ? 4 : 1;
     if (ctx->force_ppt == 1 || ctx->force_ppt == 2 || ctx->force_ppt == 4) {
         if (ctx->force_ppt == 1 || (vec4ok && W % ctx->force_ppt == 0)) ppt = ctx->force_ppt;
     }

@@ -81,6 +81,7 @@ struct FastArgs {
     float lpv_s[4][3], lpv_t[4][3];
     float inv_ncasc;
     uint32_t ncasc_pow2;
+    uint32_t pos_div_nr;  // view-space position quotients may use the shared-reciprocal divide (lighting_fast.hpp)
     uint32_t sky_enabled;
     uint32_t parity;
     uint32_t fixup_blocks;

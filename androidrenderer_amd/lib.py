@@ -8,7 +8,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsah_hip.so")
+LIB_PATH = os.environ.get("SAH_HIP_LIBRARY") or os.path.join(_HERE, "libsah_hip.so")  # override: A/B builds of the same library
 
 
 class SahError(RuntimeError):
