@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="4k_deferred_gi", choices=sorted(WORKLOADS))
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
+    ap.add_argument("--force-gather", action="store_true", help="N=1: run the (one-rank) all-gather path anyway (rehearsal of the N>1 loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
     args = ap.parse_args()
@@ -70,9 +71,19 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_gather
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line by pointing
+        # fd 1 at stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
+    elif args.force_gather:
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29511", rank=0, world_size=1, device_id=dev)
 
     wl = WORKLOADS[args.workload]
     W, H = wl["res"]
@@ -94,18 +105,23 @@ def main():
     rows_per = -(-H // world)
     r0 = min(rank * rows_per, H)
     r1 = min(r0 + rows_per, H)
-    lit_full = torch.zeros((rows_per * world, W, 4), dtype=torch.int16, device=dev)  # equal slots for the all-gather
-    lit = lit_full[:H]
     if world > 1:
         fr.row_begin, fr.row_end = r0, r1
-    desc, keep = fr.describe(d_arr, lit)
-
     ctx = lib.Context(device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    gather = world > 1 and not args.no_gather
-    lit_bytes = lit_full.view(torch.uint8).view(-1)  # RCCL has no int16: the rows travel as bytes
+    gather = use_dist and not args.no_gather
+    # N > 1: two lit targets, so that the all-gather of frame i (RCCL's own stream) overlaps the shading of frame i + 1; a target is
+    # reused only after its gather has completed (stream-level wait).  Every gather finishes inside the timed region.
+    nbuf = 2 if (gather and not chain) else 1
     shard_bytes = rows_per * W * 8
-    my_slot = lit_bytes[rank * shard_bytes:(rank + 1) * shard_bytes]
+    bufs = []
+    for _ in range(nbuf):
+        lf = torch.zeros((rows_per * world, W, 4), dtype=torch.int16, device=dev)  # equal slots for the all-gather
+        desc_b, keep_b = fr.describe(d_arr, lf[:H])
+        lb = lf.view(torch.uint8).view(-1)  # RCCL has no int16: the rows travel as bytes
+        bufs.append({"lit": lf[:H], "desc": desc_b, "keep": keep_b, "bytes": lb, "slot": lb[rank * shard_bytes:(rank + 1) * shard_bytes]})
+    pending = [None] * nbuf
+    lit = bufs[0]["lit"]
 
     if chain:
         aa = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
@@ -127,36 +143,51 @@ def main():
         if gather:
             dist.all_gather_into_tensor(final_bytes, final_slot)
 
-    def step(e0=None, e1=None):
+    def step(i, e0=None, e1=None):
+        b = bufs[i % nbuf]
+        if pending[i % nbuf] is not None:
+            pending[i % nbuf].wait()  # the compute stream waits for the gather that last used this target
+            pending[i % nbuf] = None
         if e0 is not None:
             e0.record()
         if r1 > r0:
-            ctx.lighting(desc)
+            ctx.lighting(b["desc"])
         if e1 is not None:
             e1.record()
-        if gather:
-            dist.all_gather_into_tensor(lit_bytes, my_slot)  # in place: the input is this rank's slot of the output
+        if gather:  # in place: the input is this rank's slot of the output
+            if nbuf > 1:
+                pending[i % nbuf] = dist.all_gather_into_tensor(b["bytes"], b["slot"], async_op=True)
+            else:
+                dist.all_gather_into_tensor(b["bytes"], b["slot"])
         if chain:
             post()
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for k in range(nbuf):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev =[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(ev[i][0], ev[i][1])
+        step(i, ev[i][0], ev[i][1])
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kernel_ms_mean = sum(kernel_ms) / len(kernel_ms)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,8 +247,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        if saved_stdout is not None:
+            os.dup2(2, 1)  # teardown chatter goes to stderr as well
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
