@@ -371,6 +371,10 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         cache.probe_size[0] = gi.probe_size[0];
         cache.probe_size[1] = gi.probe_size[1];
         cache.debug_mode = gi.cache_debug_mode;
+        auto bytes = [](const sah_volume& v) { return (uint64_t)v.slice_pitch_bytes * v.depth; };
+        cache.hot_ok = bytes(gi.probe_irradiance) < (1ull << 32) && bytes(gi.probe_depth) < (1ull << 32) && bytes(gi.probe_validity) < (1ull << 32) &&
+                       gi.probe_validity.width <= 64 && gi.probe_validity.height <= 64 && gi.probe_validity.depth <= 64 &&
+                       gi.probe_size[0] >= 1 && gi.probe_size[0] <= 30 && gi.probe_size[1] >= 1 && gi.probe_size[1] <= 30;
     } else if (gi_kind == SAH_GI_RTGI) {
         const sah_gi& gi = *d->gi;
         if (!plane_ok(&gi.ray_buffer, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H) ||

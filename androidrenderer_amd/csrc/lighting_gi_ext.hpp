@@ -165,7 +165,153 @@ SAH_DEV F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_
     return irradiance * Fn(2.f) * Fn(rh(3.1415927f));  // PI = 3.1415927h (brdf.slangi wins the #ifndef race)
 }
 
-SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, Fn (&out)[4]) {
+// ---- a4, hot form ----------------------------------------------------------------------------------------------------------
+// sample_cascade() with the per-probe work reduced to what the inputs allow; every shortcut is an identity on the bits:
+//  * R11G11B10 -> fp16 is a bit shuffle (uf11 = fp16 >> 4, uf10 = fp16 >> 5: same 5-bit exponent and bias, denormals, inf, NaN),
+//    so the bilinear taps are v_fma_mix_f32 on the shuffled words instead of a branchy decode per channel;
+//  * probe texcoords lie strictly inside (0,1) (u in [1, tex_size - 1] texels), so REPEAT needs one wrap of -1 and no modulo,
+//    and u / tex_size has both operands in the restricted-range divide's domain by construction;
+//  * validity bytes go through the UNORM8 table; the octahedral direction of the shading normal is probe independent;
+//  * sqrt / reciprocal / divide use the restricted-range twins where a compare establishes the domain.  `bad` is returned
+//    set when such a compare fails: the caller then evaluates sample_cascade() for the pixel.
+SAH_DEV void probe_uv_nr(const uint32_t (&idx)[3], F2 oct, uint32_t n0, uint32_t n1, float (&uv)[2]) {
+    const uint32_t n[2] = {n0, n1};
+    const Fn o[2] = {oct.x, oct.y};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const Fn total = Fn((float)n[i]) + Fn(2.f);
+        const Fn tex_size = total * Fn(32.f);
+        Fn u = Fn((float)idx[i]) * total + total * Fn(0.5f);
+        u = u + o[i] * (Fn((float)n[i]) * Fn(0.5f));
+        uv[i] = div_nr(u.v, tex_size.v);
+    }
+}
+struct BilinearTaps {
+    uint32_t off[4];
+    float w[4];
+};
+// 2D-array bilinear set-up, REPEAT, for u, v strictly inside (0, 1): floor(p) is in [-1, size - 1]
+SAH_DEV BilinearTaps bilinear_repeat_setup_inside(const VolumeArg& v, float u, float vv, int layer) {
+    const float px = u * (float)v.width - 0.5f, py = vv * (float)v.height - 0.5f;
+    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    const float fx = px - fx0, fy = py - fy0;
+    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    x0 = x0 < 0 ? x0 + (int)v.width : x0;
+    y0 = y0 < 0 ? y0 + (int)v.height : y0;
+    const int x1 = x0 + 1 == (int)v.width ? 0 : x0 + 1, y1 = y0 + 1 == (int)v.height ? 0 : y0 + 1;
+    const uint32_t base = (uint32_t)layer * v.slice_pitch;  // atlases are < 4 GiB (host check)
+    const uint32_t r0 = base + (uint32_t)y0 * v.row_pitch, r1 = base + (uint32_t)y1 * v.row_pitch;
+    BilinearTaps t;
+    t.off[0] = r0 + (uint32_t)x0 * 4u;
+    t.off[1] = r0 + (uint32_t)x1 * 4u;
+    t.off[2] = r1 + (uint32_t)x0 * 4u;
+    t.off[3] = r1 + (uint32_t)x1 * 4u;
+    t.w[0] = wx0 * wy0;
+    t.w[1] = fx * wy0;
+    t.w[2] = wx0 * fy;
+    t.w[3] = fx * fy;
+    return t;
+}
+// octahedral_coordinates() with the reciprocal of the L1 norm from rcp_nr; `bad` when the norm is outside its domain
+SAH_DEV F2 octahedral_coordinates_nr(F3 dir, bool& bad) {
+    const Fn l1 = nabs(dir.x) + nabs(dir.y) + nabs(dir.z);
+    bad = bad || !(l1.v >= kDivLo && l1.v <= kDivHi);
+    const Fn inv = Fn(rcp_nr(l1.v));
+    F2 uv = {dir.x * inv, dir.y * inv};
+    const Fn sx = Fn(uv.x.v >= 0.f ? 1.f : -1.f), sy = Fn(uv.y.v >= 0.f ? 1.f : -1.f);
+    const F2 r = {(Fn(1.f) - nabs(uv.y)) * sx, (Fn(1.f) - nabs(uv.x)) * sy};
+    const bool fold = dir.z.v < 0.f;
+    return {fold ? r.x : uv.x, fold ? r.y : uv.y};
+}
+
+SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index, const float* lut, bool& bad) {
+    const Fn spacing = Fn(c.spacing[cascade_index]);
+    const F3 rel = location - F3{Fn(c.cascade_min[cascade_index][0]), Fn(c.cascade_min[cascade_index][1]), Fn(c.cascade_min[cascade_index][2])};
+    const F3 ps = rel / spacing;
+    const F3 min_probe = {Fn(__builtin_floorf(ps.x.v)), Fn(__builtin_floorf(ps.y.v)), Fn(__builtin_floorf(ps.z.v))};
+    const F3 alpha = {nclamp(ps.x - min_probe.x, Fn(0.f), Fn(1.f)), nclamp(ps.y - min_probe.y, Fn(0.f), Fn(1.f)),
+                      nclamp(ps.z - min_probe.z, Fn(0.f), Fn(1.f))};
+    const F2 irr_oct = octahedral_coordinates(direction);  // probe independent (IEEE form: once per pixel)
+    const bool irr_oct_ok = __builtin_fabsf(irr_oct.x.v) <= 1.0f && __builtin_fabsf(irr_oct.y.v) <= 1.0f;  // false for NaN
+    bad = bad || !irr_oct_ok;
+    F3 irradiance = F3(Fn(0.f));
+    Fn weight = Fn(0.f);
+#pragma unroll 2
+    for (uint32_t i = 0; i < 8; i++) {
+        const F3 off = {Fn((float)(i & 1u)), Fn((float)((i >> 1) & 1u)), Fn((float)((i >> 2) & 1u))};
+        const F3 probe_location = min_probe + off;
+        const F3 dir_to_probe = probe_location - ps;
+        const Fn d2 = dot(dir_to_probe, dir_to_probe);
+        const F3 pidx_f = probe_location + F3{Fn(0.f), Fn((float)cascade_index) * Fn(8.f), Fn(0.f)};
+        const uint32_t pidx[3] = {f2uint(pidx_f.x.v), f2uint(pidx_f.y.v), f2uint(pidx_f.z.v)};
+        float validity = 0.f;  // Texture2DArray<half>[uint3]: out-of-range loads return 0
+        if (pidx[0] < c.validity.width && pidx[1] < c.validity.height && pidx[2] < c.validity.depth) {
+            const uint8_t b = c.validity.ptr[pidx[2] * c.validity.slice_pitch + pidx[1] * c.validity.row_pitch + pidx[0]];
+            validity = rh(lut[256u + b]);  // lut[256 + b] == (float)b / 255.0f (api.cpp)
+        }
+        if (validity == 0.f) continue;
+        // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
+        bool pbad = !(d2.v == 0.f || (d2.v >= 0x1p-80f && d2.v <= 0x1p+80f));
+        const Fn dist = Fn(sqrt_nr0(d2.v)) * spacing;
+        const F3 tri = {nmax(Fn(0.001f), mix(Fn(1.f) - alpha.x, alpha.x, off.x)), nmax(Fn(0.001f), mix(Fn(1.f) - alpha.y, alpha.y, off.y)),
+                        nmax(Fn(0.001f), mix(Fn(1.f) - alpha.z, alpha.z, off.z))};
+        const Fn trilinear_weight = tri.x * tri.y * tri.z;
+        Fn probe_weight = Fn(1.f);
+
+        const F2 depth_oct = octahedral_coordinates_nr(-dir_to_probe, pbad);
+        float duv[2];
+        probe_uv_nr(pidx, depth_oct, 10u, 10u, duv);
+        const BilinearTaps dtaps = bilinear_repeat_setup_inside(c.depth, duv[0], duv[1], array_layer((float)pidx[2], c.depth.depth));
+        float dt0 = 0.f, dt1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t wrd = pbad ? 0u : *reinterpret_cast<const uint32_t*>(c.depth.ptr + dtaps.off[k]);  // addresses are only valid when !pbad
+            dt0 = fma_mix_lo(dtaps.w[k], wrd, dt0);
+            dt1 = fma_mix_hi(dtaps.w[k], wrd, dt1);
+        }
+        const Hn dx = Hn(dt0), dy = Hn(dt1);  // Sampler2DArray<half2>
+        const Fn variance = Fn(tof(nabs(dx * dx - dy)));
+        const Fn v = dist - Fn(tof(dx));
+        const Fn cden = variance + (v * v);
+        const bool behind = dist.v > tof(dx);
+        pbad = pbad || (behind && !((variance.v == 0.f || variance.v >= kDivLo) && variance.v <= kDivHi && cden.v >= kDivLo && cden.v <= kDivHi));
+        Fn cheb = Fn(div_nr(variance.v, cden.v));
+        cheb = nmax(cheb * cheb * cheb, Fn(0.f));
+        cheb = behind ? cheb : Fn(1.f);
+        probe_weight = probe_weight * nmax(Fn(0.05f), cheb);
+        probe_weight = nmax(Fn(0.000001f), probe_weight);
+        const Fn crush = Fn(0.2f);
+        const Fn crushed = probe_weight * ((probe_weight * probe_weight) * (Fn(1.f) / (crush * crush)));
+        probe_weight = probe_weight.v < crush.v ? crushed : probe_weight;
+        probe_weight = probe_weight * trilinear_weight;
+
+        float iuv[2];
+        probe_uv_nr(pidx, irr_oct, c.probe_size[0], c.probe_size[1], iuv);
+        const BilinearTaps itaps = bilinear_repeat_setup_inside(c.irradiance, iuv[0], iuv[1], array_layer((float)pidx[2], c.irradiance.depth));
+        float ir = 0.f, ig = 0.f, ib = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t wrd = irr_oct_ok ? *reinterpret_cast<const uint32_t*>(c.irradiance.ptr + itaps.off[k]) : 0u;
+            const uint32_t rg = ((wrd << 4) & 0x7ff0u) | ((wrd << 9) & 0x7ff00000u);  // fp16(R) | fp16(G) << 16
+            const uint32_t bb = (wrd >> 17) & 0x7fe0u;                                // fp16(B)
+            ir = fma_mix_lo(itaps.w[k], rg, ir);
+            ig = fma_mix_hi(itaps.w[k], rg, ig);
+            ib = fma_mix_lo(itaps.w[k], bb, ib);
+        }
+        const H3 pi = {Hn(ir), Hn(ig), Hn(ib)};  // Sampler2DArray<half3>
+        irradiance = irradiance + to_f(pi) * probe_weight;
+        weight = weight + probe_weight;
+        bad = bad || pbad;
+    }
+    if (weight.v == 0.f) return F3(Fn(0.f));
+    irradiance = irradiance / weight;
+    return irradiance * Fn(2.f) * Fn(rh(3.1415927f));  // PI = 3.1415927h (brdf.slangi wins the #ifndef race)
+}
+
+// `lut` != nullptr selects sample_cascade_fast(); *bad is then set when the pixel has to be re-evaluated with lut == nullptr.
+SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, Fn (&out)[4],
+                           const float* lut = nullptr, bool* bad = nullptr) {
     Surface<Hn> s;
     s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
     s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
@@ -185,7 +331,8 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x
         out[0] = out[1] = out[2] = out[3] = Fn(0.f);
         return;
     }
-    const H3 irradiance = to_h(sample_cascade(c, location, to_f(s.normal), cascade_index));
+    const H3 irradiance = to_h(lut ? sample_cascade_fast(c, location, to_f(s.normal), cascade_index, lut, *bad)
+                                   : sample_cascade(c, location, to_f(s.normal), cascade_index));
     const H3 b = Fd(s, s.normal, V) + Fr(s, s.normal, V);
     const Hn exposure = Hn::lit(0.314159f);
     H3 col = b * irradiance * exposure;

@@ -190,7 +190,9 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
             gi_lpv_frag(a, lpv, x, y, p, si, s);
             drawn = true;
         } else if constexpr (GI == SAH_GI_CACHE) {
-            gi_cache_frag(a, cache, x, y, p, si, s);
+            bool redo = false;  // hot form first; a pixel outside its preconditions (rare) is re-evaluated with the general form
+            if (cache.hot_ok) gi_cache_frag(a, cache, x, y, p, si, s, s_lut, &redo);
+            if (redo || !cache.hot_ok) gi_cache_frag(a, cache, x, y, p, si, s);
             drawn = true;
         } else if constexpr (GI == SAH_GI_RTGI) {
             gi_rtgi_frag(a, rtgi, x, y, p, si, s_lut, s);

@@ -31,6 +31,7 @@ struct CacheArgs {
     float spacing[4];
     uint32_t probe_size[2];
     uint32_t debug_mode;
+    uint32_t hot_ok;  // atlases < 4 GiB, probe grid <= 64 per axis, probe texel counts <= 30: sample_cascade_fast() applies
 };
 
 struct RtgiArgs {
