@@ -169,7 +169,24 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
             for (uint32_t j = 0; j < count; j++) {
                 const uint32_t idx = batch + (brute_force ? j : (uint32_t)s_list[j]);
                 const PointLightDev pl = lights[idx];
-                if (surface) sum = sum + point_light_contribution(s, ws, V, pl);
+                // A pixel farther than 1.001 r from the light has xr >= 1.0009, so w = clamp(1 - xr^4, 0, 1) = 0 and its term is +-0
+                // (or NaN -> 0): adding it cannot change `sum`.  Waves in which no pixel is nearer skip the light (uniform branch).
+                const float far_r = pl.radius * 1.001f, far2 = far_r * far_r;
+                const F3 lv = F3{Fn(pl.px), Fn(pl.py), Fn(pl.pz)} - ws;
+                const Fn d2 = dot(lv, lv);
+                const bool near = surface && d2.v <= far2;
+                if (!__any(near)) continue;
+                // per-light (uniform) precondition of the hot form; anything else takes the general form
+                const bool light_ok = pl.radius >= kDivLo && pl.radius <= kDivHi && __builtin_fabsf(pl.cr) < inf && __builtin_fabsf(pl.cg) < inf &&
+                                      __builtin_fabsf(pl.cb) < inf && __builtin_fabsf(pl.intensity) < inf;
+                F3 c = F3(Fn(0.f));
+                bool redo = !light_ok;
+                if (light_ok) c = point_light_contribution_fast(s, lv, d2, V, pl, redo);
+                if (__any(near && redo)) {
+                    const F3 cg = point_light_contribution(s, ws, V, pl);
+                    c = redo ? cg : c;
+                }
+                if (near) sum = sum + c;
             }
             __syncthreads();  // s_list is rewritten by the next batch
         }

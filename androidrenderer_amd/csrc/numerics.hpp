@@ -249,4 +249,49 @@ template <class T> SAH_DEV V3<T> Fr(const Surface<T>& s, V3<T> l, V3<T> v) {
     return (D * V) * Fv;
 }
 
+// fp32 brdf() = Fd() + Fr() for the hot paths: the shared sub-expressions written once, the `NoL <= 0 -> 0` early-outs as one
+// select (both halves return 0 together and 0 + 0 == +0), and every sqrt / divide replaced by its restricted-range twin
+// (sqrt_nr, rcp_nr, div_nr: same bits inside the domain).  `out_of_domain` is set when an operand leaves the domain for a pixel
+// whose BRDF value is used (NoL > 0); the caller then evaluates the general form (fix-up kernel / inline fallback).  Ranges by
+// construction for unit N, V, L: roughness is a UNORM8 value and the clamped dots are in [0,1], so only lower bounds need a compare.
+SAH_DEV F3 brdf_fast(const Surface<Fn>& s, F3 l, F3 v, bool& out_of_domain) {
+    const Fn one = Fn(1.0f), zero = Fn(0.0f);
+    const Fn dielectric_f0 = Fn(0.04f);
+    const F3 f0 = mix(F3(dielectric_f0), s.base_color, s.metalness);
+    const F3 diffuse_color = s.base_color * (one - dielectric_f0) * (one - s.metalness);
+    const F3 vl = v + l;
+    const Fn dh = dot(vl, vl);  // <= 4 + eps
+    const F3 h = vl * Fn(rcp_nr(sqrt_nr(dh.v)));
+    Fn NoV = dot(s.normal, v) + Fn(1e-5f);
+    Fn NoL = dot(s.normal, l);
+    const Fn NoH = nclamp(dot(s.normal, h), zero, one);
+    const Fn VoH = nclamp(dot(v, h), zero, one);
+    const bool dark = NoL.v <= 0.f;
+    NoV = nabs(NoV);
+    NoL = nclamp(NoL, zero, one);
+    const Fn LoH = nclamp(dot(l, h), zero, one);
+    const F3 fd = diffuse_color * Fd_Burley(NoV, NoL, LoH, s.roughness);
+    // D_GGX
+    const Fn a = s.roughness;
+    const Fn dden = one - NoH * NoH + a * a;
+    const Fn k = Fn(div_nr(a.v, dden.v));
+    const Fn D = k * k * (one / brdf_pi<Fn>());
+    const F3 Fv = F_Schlick(VoH, f0, one);
+    // V_SmithGGXCorrelated
+    const Fn a2 = a * a;
+    const Fn argL = (-NoL * a2 + NoL) * NoL + a2, argV = (-NoV * a2 + NoV) * NoV + a2;
+    const Fn GGXL = NoV * Fn(sqrt_nr(argL.v));
+    const Fn GGXV = NoL * Fn(sqrt_nr(argV.v));
+    const Fn vden = GGXV + GGXL;
+    const Fn Vis = Fn(div_nr(0.5f, vden.v));
+    const F3 fr = (D * Vis) * Fv;
+    const F3 sum = fd + fr;
+    // lower bounds: one min3 / min per class, then one compare each.  Upper bounds: dh <= 4, NoV <= 1.00002, a <= 1, so every
+    // operand above is <= 4.
+    const float lo_sqrt = __builtin_fminf(__builtin_fminf(dh.v, argL.v), argV.v);
+    const float lo_div = __builtin_fminf(dden.v, vden.v);
+    out_of_domain = !dark && !(lo_sqrt >= 0x1p-80f && lo_div >= kDivLo);
+    return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
+}
+
 }  // namespace sah
