@@ -61,7 +61,7 @@ SAH_DEV H4 load_h4(const VolumeArg& v, int x, int y, int z) {
         r.w = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.y >> 16)));
         return r;
     }
-    return {Hn(0.f), Hn(0.f), Hn(0.f), Hn(0.f)};
+    return {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
 }
 SAH_DEV void store_h4(const VolumeArg& v, int x, int y, int z, H4 c) {
     uint2 q;
@@ -75,8 +75,8 @@ struct PropArgs {
     uint32_t num_cascades;
 };
 
-__global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
-    __shared__ PropTables T;
+// tables of the 30 direction pairs, built by every block into LDS
+SAH_DEV void build_prop_tables(PropTables& T) {
     if (threadIdx.x < 24) {
         const int n = threadIdx.x >> 2, s = threadIdx.x & 3;
         const Hn small = Hn::lit(0.4472135f), big = Hn::lit(0.894427f);
@@ -90,39 +90,51 @@ __global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
         T.cur_lobe[n] = to_q(dir_to_cosine_lobe_h(c));
         T.cur_sh[n] = to_q(dir_to_sh_h(c));
     }
-    __syncthreads();
+}
+
+// one propagation step of one cell: lpv_propagate.comp.slang:76-156
+// (one colour volume per call: the three channels are independent and run as separate workgroups, blockIdx.y, which triples the
+// number of waves in flight — with one thread per cell doing all three the step was bound by its own dependency chains)
+SAH_DEV void propagate_cell(const PropTables& T, const VolumeArg& src, const VolumeArg& dst, uint32_t idx) {
     const Hn direct_sa = Hn(tof(Hn::lit(0.4006696846f)) / 3.1415927f);
     const Hn side_sa = Hn(tof(Hn::lit(0.4234413544f)) / 3.1415927f);
-
-    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= a.num_cascades * 32768u) return;
     const int cx = idx & 31, cy = (idx >> 5) & 31, cz = (idx >> 10) & 31, cascade = idx >> 15;
     const int xoff = cascade * 32;
-    H4 acc[3];
+    // All 18 neighbour texels are fetched before any arithmetic (one latency phase instead of six: with two waves per SIMD the
+    // step was latency bound).  A neighbour the shader skips (`continue`, the asymmetric [-1, 31] test) is given zero coefficients
+    // instead: max(0, dot(0, sh)) == +0 and acc + (sa * 0) * lobe == acc + (+-0) == acc for every acc this loop can hold (acc starts
+    // at +0 and +0 + -0 == +0, so it is never -0).
+    H4 coef[6];
 #pragma unroll
-    for (int c = 0; c < 3; c++) acc[c] = {Hn(0.f), Hn(0.f), Hn(0.f), Hn(0.f)};
     for (int n = 0; n < 6; n++) {
         const int nx = cx - kDir[n][0], ny = cy - kDir[n][1], nz = cz - kDir[n][2];
-        if (nx < -1 || ny < -1 || nz < -1 || nx > 31 || ny > 31 || nz > 31) continue;
-        H4 coef[3];
+        const bool skipped = nx < -1 || ny < -1 || nz < -1 || nx > 31 || ny > 31 || nz > 31;
+        coef[n] = load_h4(src, skipped ? -1 : nx + xoff, ny, nz);
+    }
+    // (Hn::lit: compile-time constants.  geo_volume_factor == 1: x * 1.0h is x for every x, the compiler folds it.)
+    const Hn zero = Hn::lit(0.f), geo_volume_factor = Hn::lit(1.f);
+    H4 acc = {zero, zero, zero, zero};
 #pragma unroll
-        for (int c = 0; c < 3; c++) coef[c] = load_h4(a.src[c], nx + xoff, ny, nz);
+    for (int n = 0; n < 6; n++) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const Hn m = nmax(Hn(0.f), dot4h(coef[c], from_q(T.eval_sh[n][s])));
-                acc[c] = acc[c] + (side_sa * m) * from_q(T.reproj_lobe[n][s]) * Hn(1.f);
-            }
+            const Hn m = nmax(zero, dot4h(coef[n], from_q(T.eval_sh[n][s])));
+            acc = acc + (side_sa * m) * from_q(T.reproj_lobe[n][s]) * geo_volume_factor;
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const Hn m = nmax(Hn(0.f), dot4h(coef[c], from_q(T.cur_sh[n])));
-            acc[c] = acc[c] + (direct_sa * m) * from_q(T.cur_lobe[n]) * Hn(1.f);
-        }
+        const Hn m = nmax(zero, dot4h(coef[n], from_q(T.cur_sh[n])));
+        acc = acc + (direct_sa * m) * from_q(T.cur_lobe[n]) * geo_volume_factor;
     }
-#pragma unroll
-    for (int c = 0; c < 3; c++) store_h4(a.dst[c], cx + xoff, cy, cz, acc[c]);
+    store_h4(dst, cx + xoff, cy, cz, acc);
+}
+
+__global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
+    __shared__ PropTables T;
+    build_prop_tables(T);
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.num_cascades * 32768u) return;
+    const uint32_t c = blockIdx.y;  // colour volume
+    propagate_cell(T, a.src[c], a.dst[c], idx);
 }
 
 struct ClearArgs {
@@ -155,7 +167,7 @@ hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], 
     PropArgs a;
     for (int i = 0; i < 3; i++) { a.src[i] = src[i]; a.dst[i] = dst[i]; }
     a.num_cascades = num_cascades;
-    hipLaunchKernelGGL(k_lpv_propagate, dim3(num_cascades * 128), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_lpv_propagate, dim3(num_cascades * 128, 3), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -141,8 +141,9 @@ template <> SAH_DEV Hn nabs<Hn>(Hn a) { return Hn::raw(__builtin_bit_cast(_Float
 // max/min with fmax/fmin NaN semantics (the non-NaN operand wins), as the oracle defines clamp().
 SAH_DEV Fn nmax(Fn a, Fn b) { return Fn(__builtin_fmaxf(a.v, b.v)); }
 SAH_DEV Fn nmin(Fn a, Fn b) { return Fn(__builtin_fminf(a.v, b.v)); }
-SAH_DEV Hn nmax(Hn a, Hn b) { return Hn(__builtin_fmaxf((float)a.v, (float)b.v)); }
-SAH_DEV Hn nmin(Hn a, Hn b) { return Hn(__builtin_fminf((float)a.v, (float)b.v)); }
+// v_max_f16 / v_min_f16: the operands are fp16 already, so this is the fp32 fmax / fmin of the (exactly) widened values
+SAH_DEV Hn nmax(Hn a, Hn b) { return Hn::raw(__builtin_fmaxf16(a.v, b.v)); }
+SAH_DEV Hn nmin(Hn a, Hn b) { return Hn::raw(__builtin_fminf16(a.v, b.v)); }
 template <class T> SAH_DEV T nclamp(T x, T lo, T hi) { return nmin(nmax(x, lo), hi); }
 SAH_DEV bool isnan_f(float x) { return x != x; }
 

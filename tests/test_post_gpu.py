@@ -90,7 +90,8 @@ def test_copy_scene(hip_ctx):
             assert (util.f16_ulp_diff(got, scene) <= 1).mean() > 0.99
 
 
-def test_lpv_propagate_and_clear(hip_ctx):
+@pytest.mark.parametrize("steps", [4, 5, 1])
+def test_lpv_propagate_and_clear(hip_ctx, steps):
     import torch
     o = util.oracle()
     vols = synth.lpv_volumes(4, seed=31)
@@ -98,7 +99,6 @@ def test_lpv_propagate_and_clear(hip_ctx):
     b_np = [np.full_like(v, 0x3C00) for v in a_np]  # garbage in B: every cell is overwritten
     a_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in a_np])
     b_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in b_np])
-    steps = 4
     assert o.orc_lpv_propagate(a_v, b_v, 4, steps) == 0
     a_t = [util.to_torch(v.view(np.uint16).copy()) for v in vols]
     b_t = [torch.full_like(t, 0x3C00) for t in a_t]

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--lights", type=int, default=256)
     ap.add_argument("--light-radius", type=float, default=4.0)
+    ap.add_argument("--only", default="", help="run only the passes whose name contains this substring")
+    ap.add_argument("--json", action="store_true", help="also print the results as one JSON object")
     args = ap.parse_args()
     import torch
 
@@ -35,7 +37,12 @@ def main():
     px = W * H
     results = {}
 
+    def wanted(name):
+        return not args.only or args.only.lower() in name.lower()
+
     def timeit(name, fn, bytes_per_call):
+        if not wanted(name):
+            return
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -52,6 +59,8 @@ def main():
 
     # ---- lighting variants ----------------------------------------------------------------------------
     def lighting_case(name, sun, gi, flavour, bpp, lights=None, flags=_abi.LIGHTING_DEFAULT_FLAGS, general=False):
+        if not wanted(name):
+            return None
         f = util.LightingFrame(W, H, seed=2, sun_mode=sun, gi=gi, flavour=flavour, shadowmap_res=4096, lights=lights, flags=flags)
         dev = f.device_arrays()
         lit = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
@@ -95,7 +104,8 @@ def main():
     bv = [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in b_t]
     timeit("lpv propagate x32", lambda: ctx.lpv_propagate(av, bv, 4, 32), 32 * 6 * 1024 * 1024)
     timeit("lpv clear", lambda: ctx.lpv_clear(av[0], av[1], av[2], bv[0], 4), 4 * 1024 * 1024)
-    print(json.dumps(results))
+    if args.json:
+        print(json.dumps(results))
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ import sys
 src, flt = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 out = "/tmp/isa_lines.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                 "-fhip-fp32-correctly-rounded-divide-sqrt", "-gline-tables-only", "-x", "hip", "-S", "--cuda-device-only", src, "-o", out],
                check=True, stderr=subprocess.DEVNULL)
 files = {}

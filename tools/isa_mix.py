@@ -7,7 +7,8 @@ import sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 out = "/tmp/isa_mix.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-x", "hip", "-S",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+                "-fhip-fp32-correctly-rounded-divide-sqrt", "-x", "hip", "-S",
                 "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
 cur, body = None, collections.defaultdict(list)
 for line in open(out):

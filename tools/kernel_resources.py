@@ -4,7 +4,8 @@ import subprocess
 import sys
 
 src = sys.argv[1]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-x", "hip", "-c", src,
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+       "-fhip-fp32-correctly-rounded-divide-sqrt", "-x", "hip", "-c", src,
        "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
 rows, cur = [], {}
