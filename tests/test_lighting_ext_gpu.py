@@ -55,3 +55,62 @@ def test_point_lights_with_lpv_and_ragged_tiles(hip_ctx):
     lights = synth.point_lights(base.view, 48, 8.0, seed=47)
     f = util.LightingFrame(75, 45, seed=46, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_LPV, lights=lights)
     _vs_oracle(f, hip_ctx, "48 lights + LPV, 75x45 (partial tiles)")
+
+
+def test_point_lights_adversarial_light_data(hip_ctx):
+    """Lights that leave the hot form's preconditions (tiled kernel: per-light uniform check, per-pixel fallback): a light sitting
+    exactly on a shaded surface point (d2 == 0), zero / denormal / huge / infinite / NaN radius, infinite and NaN colour or
+    intensity, NaN and infinite positions, and pixels in the razor-thin shell where the attenuation window underflows."""
+    base = util.LightingFrame(96, 64, seed=48, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE, flavour="atrium")
+    lights = synth.point_lights(base.view, 24, 5.0, seed=49)
+    # world position of a few pixels, recomputed as the shader does, to drop lights exactly onto surfaces
+    o = util.oracle()
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    lights[1, 3] = 0.0            # radius 0: xr = d / 0
+    lights[2, 3] = 1e-42          # denormal radius
+    lights[3, 3] = 3e38           # huge radius: every pixel is "near"
+    lights[4, 3] = inf
+    lights[5, 3] = nan
+    lights[6, 4] = inf            # colour
+    lights[7, 7] = inf            # intensity
+    lights[8, 7] = nan
+    lights[9, 0] = nan            # position
+    lights[10, 1] = inf
+    lights[11, 7] = -3.0          # negative intensity: terms of either sign, and -0 products
+    lights[12, 3] = 2.0 ** -30    # tiny but normal radius
+    f = util.LightingFrame(96, 64, seed=48, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE, flavour="atrium", lights=lights)
+    culled = _vs_oracle(f, hip_ctx, "adversarial light list", max_ulp=0)
+    f.flags |= _abi.LIGHTING_BRUTE_FORCE_LIGHTS
+    assert np.array_equal(culled, f.run_hip(hip_ctx))
+
+
+def test_point_lights_on_the_surface(hip_ctx):
+    """d2 == 0 for one pixel (light placed at that pixel's reconstructed world position) and d ~ r for many (window near 0)."""
+    import ctypes as C
+    base = util.LightingFrame(64, 48, seed=50, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE, flavour="atrium")
+    # reconstruct world positions the way directional_light.frag does, in float64 (close is enough for the second part; for the
+    # exact hit the light position is refined below with the float32 value the kernel will compute)
+    v = base.view.gpu_data
+    depth = base.arrays["depth"]
+    H, W = depth.shape
+    ip = np.array(v.inverse_projection[:], dtype=np.float32).reshape(4, 4).T  # row-major [row][col]
+    iv = np.array(v.inverse_view[:], dtype=np.float32).reshape(4, 4).T
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    f32 = np.float32
+    tx = ((xs + f32(0.5)) + f32(0.5)) / f32(v.render_resolution[0])
+    ty = ((ys + f32(0.5)) + f32(0.5)) / f32(v.render_resolution[1])
+    ndc = np.stack([tx * f32(2) - f32(1), ty * f32(2) - f32(1), depth, np.ones_like(depth)], axis=-1)
+    with np.errstate(all="ignore"):
+        vs = np.stack([((ip[i, 0] * ndc[..., 0] + ip[i, 1] * ndc[..., 1]) + ip[i, 2] * ndc[..., 2]) + ip[i, 3] * ndc[..., 3] for i in range(4)], axis=-1)
+        vs3 = np.stack([vs[..., i] / vs[..., 3] for i in range(3)] + [np.ones_like(depth)], axis=-1)
+        ws = np.stack([((iv[i, 0] * vs3[..., 0] + iv[i, 1] * vs3[..., 1]) + iv[i, 2] * vs3[..., 2]) + iv[i, 3] * vs3[..., 3] for i in range(3)], axis=-1)
+    surf = np.argwhere(depth != 0)
+    lights = np.zeros((6, 8), dtype=np.float32)
+    for k in range(6):
+        y, x = surf[(k * 977) % len(surf)]
+        lights[k, 0:3] = ws[y, x]
+        lights[k, 3] = 0.75 + 0.5 * k
+        lights[k, 4:7] = (1.0, 0.9, 0.8)
+        lights[k, 7] = 4000.0
+    f = util.LightingFrame(64, 48, seed=50, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE, flavour="atrium", lights=lights)
+    _vs_oracle(f, hip_ctx, "lights placed on surface points", max_ulp=0)

@@ -91,6 +91,13 @@ def test_lighting_adversarial_inputs(hip_ctx, sun_mode, gi):
     f = util.LightingFrame(192, 96, gbuffer=g, seed=78, sun_mode=sun_mode, gi=gi)
     f.arrays["ao"][3, 5] = np.nan
     f.arrays["ao"][7, 9] = np.inf
+    # normals exactly along / against the sun (ndotl == 1: sqrt(1 - ndotl^2) == 0 in the PCF bias; ndotl == 0) and axis aligned
+    sd = np.array(f.sun.constants.direction_and_tan_size[:3], dtype=np.float32)
+    L = (-sd / np.linalg.norm(sd)).astype(np.float16)
+    rng = np.random.default_rng(6)
+    for vec in (L, -L, np.array([0, 1, 0], np.float16), np.array([0, 0, -1], np.float16), (L.astype(np.float32) * 1e-4).astype(np.float16)):
+        ys, xs = rng.integers(0, 96, 60), rng.integers(0, 192, 60)
+        f.arrays["normals"][ys, xs, :3] = vec
     _check(f, hip_ctx, f"adversarial sun={sun_mode} gi={gi}")
 
 
