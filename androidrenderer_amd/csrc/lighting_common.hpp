@@ -249,7 +249,7 @@ SAH_DEV void sun_frag(const LightingArgs& a, const CsmArgs& csm, uint32_t x, uin
     const Fn ndotl = nclamp(dot(s.normal, L), Fn(0.f), Fn(1.f));
     Fn shadow = Fn(1.0f);
     if (ndotl.v > 0.f) shadow = sample_csm(csm, ws, vs.z, ndotl);
-    const F3 b = Fd(s, L, V) + Fr(s, L, V);
+    const F3 b = brdf_sl(s, L, V);  // == Fd(s, L, V) + Fr(s, L, V)
     F3 direct = ndotl * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * shadow;
     if (any_nan(direct)) direct = F3(Fn(0.f));
     const Fn exposure = Fn(0.00031415927f);
@@ -271,7 +271,7 @@ SAH_DEV void sun_rt(const LightingArgs& a, uint32_t x, uint32_t y, const Px& p, 
     const Hn ndotl = Hn(nclamp(dot(L, to_f(s.normal)), Fn(0.f), Fn(1.f)).v);
     const H3 V = to_h(normalize(location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
     const H3 Lh = to_h(L);
-    const H3 b = Fd(s, Lh, V) + Fr(s, Lh, V);
+    const H3 b = brdf_sl(s, Lh, V);  // == Fd(s, Lh, V) + Fr(s, Lh, V)
     const H3 nb = ndotl * b;
     F3 radiance = to_f(nb) * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])};
     if (tof(ndotl) > 0.f) radiance = radiance * Fn(p.mask);

@@ -16,31 +16,6 @@ SAH_DEV bool finite_f(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 // LDS table of the fast kernel: [0,512) format LUTs, then the per-cascade rows that are indexed per lane
 enum : uint32_t { TAB_CSM = 512, TAB_LPV = 512 + 48, TAB_VIEW = 512 + 48 + 32, TAB_SIZE = 512 + 48 + 32 + 12 };
 
-// brdf() = Fd() + Fr() (brdf.glsl:65-121 / brdf.slangi:58-114) with the shared sub-expressions written once and the
-// `NoL <= 0 -> 0` early-outs turned into one select (both halves return 0 together, and 0 + 0 == +0).
-template <class T> SAH_DEV V3<T> brdf_sl(const Surface<T>& s, V3<T> l, V3<T> v) {
-    const T one = T::lit(1.0f), zero = T::lit(0.0f);
-    const T dielectric_f0 = T::lit(0.04f);
-    const V3<T> f0 = mix(V3<T>(dielectric_f0), s.base_color, s.metalness);
-    const V3<T> diffuse_color = s.base_color * (one - dielectric_f0) * (one - s.metalness);
-    const V3<T> h = normalize(v + l);
-    T NoV = dot(s.normal, v) + T::lit(1e-5f);
-    T NoL = dot(s.normal, l);
-    const T NoH = nclamp(dot(s.normal, h), zero, one);
-    const T VoH = nclamp(dot(v, h), zero, one);
-    const bool dark = tof(NoL) <= 0.f;
-    NoV = nabs(NoV);
-    NoL = nclamp(NoL, zero, one);
-    const T LoH = nclamp(dot(l, h), zero, one);
-    const V3<T> fd = diffuse_color * Fd_Burley(NoV, NoL, LoH, s.roughness);
-    const T D = D_GGX(NoH, s.roughness);
-    const V3<T> Fv = F_Schlick(VoH, f0, one);
-    const T Vis = V_SmithGGXCorrelated(NoV, NoL, s.roughness);
-    const V3<T> fr = (D * Vis) * Fv;
-    const V3<T> sum = fd + fr;
-    return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
-}
-
 struct FastPixelOut {
     uint2 lit;
     bool deferred;

@@ -333,7 +333,7 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x
     }
     const H3 irradiance = to_h(lut ? sample_cascade_fast(c, location, to_f(s.normal), cascade_index, lut, *bad)
                                    : sample_cascade(c, location, to_f(s.normal), cascade_index));
-    const H3 b = Fd(s, s.normal, V) + Fr(s, s.normal, V);
+    const H3 b = brdf_sl(s, s.normal, V);  // == Fd(s, N, V) + Fr(s, N, V)
     const Hn exposure = Hn::lit(0.314159f);
     H3 col = b * irradiance * exposure;
     if (c.debug_mode == 1) {
@@ -349,7 +349,7 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x
 
 // ---- a5 ------------------------------------------------------------------------------------------------------------------
 SAH_DEV H3 rtgi_contribution(const Surface<Hn>& s, H3 V, H3 dir, H3 irr) {
-    const H3 b = Fd(s, dir, V) + Fr(s, dir, V);
+    const H3 b = brdf_sl(s, dir, V);  // == Fd(s, dir, V) + Fr(s, dir, V)
     const Hn ndotl = Hn(nclamp(Fn(tof(dot(dir, s.normal))), Fn(0.f), Fn(1.f)).v);
     return b * irr * ndotl;
 }
@@ -427,7 +427,7 @@ SAH_DEV F3 point_light_contribution(const Surface<Fn>& s, F3 ws, F3 V, const Poi
     const Fn x4 = x2 * x2;
     const Fn w = nclamp(Fn(1.f) - x4, Fn(0.f), Fn(1.f));
     const Fn att = (w * w) / nmax(d2, Fn(1e-4f));
-    const F3 b = Fd(s, L, V) + Fr(s, L, V);
+    const F3 b = brdf_sl(s, L, V);  // == Fd(s, L, V) + Fr(s, L, V)
     F3 c = ndotl * b * F3{Fn(pl.cr), Fn(pl.cg), Fn(pl.cb)} * (Fn(pl.intensity) * att);
     if (any_nan(c)) c = F3(Fn(0.f));
     return c;
