@@ -168,6 +168,38 @@ SAH_DEV C3 tap_lds(const char* tex, const AxisE& ax, const AxisE& ay) {
     return c;
 }
 
+// ---- a7, hot form ------------------------------------------------------------------------------------------------------------
+// The 5 boxes x 4 bilinear taps of bloom_downsample.comp:16-52 use only 6 distinct x coordinates (u -+ ix, and those -+ ix again)
+// and 6 distinct y coordinates: 12 axis set-ups per output pixel instead of 40, taps accumulated with v_fma_mix_f32 straight from
+// the packed fp16 texels.  Same taps, same order, same operators as k_bloom_downsample (kept for planes >= 2 GiB).
+__global__ void __launch_bounds__(256) k_bloom_downsample_shared(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const float ix = 1.0f / (float)sw, iy = 1.0f / (float)sh;
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    const float ox = ix * -1.0f, oy = iy * -1.0f, oz = ix * 1.0f, ow = iy * 1.0f;
+    const int pitch = (int)src.pitch;
+    auto ax_of = [&](float c) {
+        const Axis a = axis_setup(c, sw);
+        return AxisE{a.i0 * 8, a.i1 * 8, a.w0, a.w1};
+    };
+    auto ay_of = [&](float c) {
+        const Axis a = axis_setup(c, sh);
+        return AxisE{a.i0 * pitch, a.i1 * pitch, a.w0, a.w1};
+    };
+    const float ua = u + ox, ub = u + oz, vc = v + oy, vd = v + ow;  // box centres of the four corner boxes / taps of the centre box
+    const AxisE xa = ax_of(ua), xb = ax_of(ub), xaa = ax_of(ua + ox), xab = ax_of(ua + oz), xba = ax_of(ub + ox), xbb = ax_of(ub + oz);
+    const AxisE yc = ay_of(vc), yd = ay_of(vd), ycc = ay_of(vc + oy), ycd = ay_of(vc + ow), ydc = ay_of(vd + oy), ydd = ay_of(vd + ow);
+    const char* tex = reinterpret_cast<const char*>(src.ptr);
+    auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {
+        const C3 s = tap_lds(tex, xl, yt) + tap_lds(tex, xr, yt) + tap_lds(tex, xl, yb) + tap_lds(tex, xr, yb);
+        return s * 0.25f;
+    };
+    const C3 s = box(xa, xb, yc, yd) * 0.5f + box(xaa, xab, ycc, ycd) * 0.125f + box(xba, xbb, ycc, ycd) * 0.125f + box(xaa, xab, ydc, ydd) * 0.125f +
+                 box(xba, xbb, ydc, ydd) * 0.125f;
+    store_rgba16f(dst, (int)x, (int)y, s.r, s.g, s.b, 0.0f);
+}
+
 // Tonemap composite, LDS-staged.  A 256-thread workgroup produces a 32x8 output tile.  For every bloom mip the texel
 // rectangle the tile can touch (tile bounds mapped into the mip, plus the reach of the tent offsets — which are -ix, -iy
 // and +ix in x and +ix, +-iy in y because scene_upsample.frag:29-32 mixes the components of `o`) is copied into LDS once,
@@ -300,7 +332,8 @@ hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, cons
 }
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st) {
     const dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    hipLaunchKernelGGL(k_bloom_downsample, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh);
+    if ((uint64_t)src.pitch * sh < (1ull << 31)) hipLaunchKernelGGL(k_bloom_downsample_shared, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh);
+    else hipLaunchKernelGGL(k_bloom_downsample, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh);
     return hipGetLastError();
 }
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st) {
