@@ -41,6 +41,10 @@ class Volume(C.Structure):
                 ("row_pitch_bytes", C.c_uint32), ("slice_pitch_bytes", C.c_uint32), ("format", C.c_uint32)]
 
 
+class ProbeAtlases(C.Structure):  # sah_probe_atlases
+    _fields_ = [("rtgi", Volume), ("light_cache", Volume), ("depth", Volume), ("average", Volume), ("validity", Volume)]
+
+
 class GBuffer(C.Structure):
     _fields_ = [("color", Plane), ("normals", Plane), ("data", Plane), ("emission", Plane), ("depth", Plane)]
 

@@ -14,6 +14,8 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
+hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, hipStream_t st);
 }  // namespace sah
 
 namespace {
@@ -156,6 +158,63 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, ctx->stream));
         else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, ctx->stream));
     }
+    return SAH_OK;
+}
+
+// ---- irradiance-cache probe maintenance (a11) ---------------------------------------------------------------------------
+static bool probe_vol_ok(const sah_volume& v, uint32_t format, uint32_t bpp, uint32_t w, uint32_t h) {
+    return v.ptr && v.format == format && v.width == w && v.height == h && v.depth == 32 && (uint64_t)v.row_pitch_bytes >= (uint64_t)w * bpp &&
+           (uint64_t)v.slice_pitch_bytes >= (uint64_t)v.row_pitch_bytes * h && ((uintptr_t)v.ptr % 4) == 0 && (bpp == 1 || (v.row_pitch_bytes % 4) == 0) &&
+           (bpp == 1 || (v.slice_pitch_bytes % 4) == 0);
+}
+static int probe_atlases_args(sah_ctx* ctx, const sah_probe_atlases* a, sah::ProbeAtlasArgs* out) {
+    if (!a) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "null probe atlases");
+    // extents of irradiance_cache.cpp:94-183: probe grid 32 x (8 * 4) x 32, blocks 7x8 / 13x13 / 12x12 / 1x1
+    if (!probe_vol_ok(a->rtgi, SAH_FORMAT_B10G11R11_UFLOAT_PACK32, 4, 32 * 7, 32 * 8) ||
+        !probe_vol_ok(a->light_cache, SAH_FORMAT_B10G11R11_UFLOAT_PACK32, 4, 32 * 13, 32 * 13) ||
+        !probe_vol_ok(a->depth, SAH_FORMAT_R16G16_SFLOAT, 4, 32 * 12, 32 * 12) || !probe_vol_ok(a->average, SAH_FORMAT_B10G11R11_UFLOAT_PACK32, 4, 32, 32) ||
+        !probe_vol_ok(a->validity, SAH_FORMAT_R8_UNORM, 1, 32, 32))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT,
+                    "probe atlases must be rtgi 224x256x32 B10G11R11, light cache 416x416x32 B10G11R11, depth 384x384x32 R16G16F, "
+                    "average 32x32x32 B10G11R11, validity 32x32x32 R8_UNORM");
+    out->rtgi = varg(a->rtgi);
+    out->light_cache = varg(a->light_cache);
+    out->depth = varg(a->depth);
+    out->average = varg(a->average);
+    out->validity = varg(a->validity);
+    return SAH_OK;
+}
+
+int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_atlases* dst, const float cascade_movement[4][3]) {
+    if (!ctx || !cascade_movement) return SAH_ERR_INVALID_ARGUMENT;
+    sah::ProbeAtlasArgs s, d;
+    int rc = probe_atlases_args(ctx, src, &s);
+    if (rc != SAH_OK) return rc;
+    rc = probe_atlases_args(ctx, dst, &d);
+    if (rc != SAH_OK) return rc;
+    if (s.rtgi.ptr == d.rtgi.ptr || s.light_cache.ptr == d.light_cache.ptr || s.depth.ptr == d.depth.ptr || s.average.ptr == d.average.ptr ||
+        s.validity.ptr == d.validity.ptr)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "probe copy: source and destination atlases must not alias");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_probe_copy(s, d, cascade_movement, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_volume* trace_results, const uint32_t* probes_to_update,
+                     uint32_t num_probes) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    sah::ProbeAtlasArgs a;
+    const int rc = probe_atlases_args(ctx, atlases, &a);
+    if (rc != SAH_OK) return rc;
+    if (num_probes == 0) return SAH_OK;
+    if (!probes_to_update) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "probes_to_update is null");
+    if (!trace_results || !trace_results->ptr || trace_results->format != SAH_FORMAT_R16G16B16A16_SFLOAT || trace_results->width != 20 ||
+        trace_results->height != 20 || trace_results->depth < num_probes || trace_results->row_pitch_bytes < 20 * 8 ||
+        (uint64_t)trace_results->slice_pitch_bytes < (uint64_t)trace_results->row_pitch_bytes * 20 || ((uintptr_t)trace_results->ptr % 8) ||
+        (trace_results->row_pitch_bytes % 8) || (trace_results->slice_pitch_bytes % 8))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "trace_results must be R16G16B16A16_SFLOAT 20 x 20 x >= num_probes, 8-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_probe_update(a, varg(*trace_results), probes_to_update, num_probes, ctx->stream));
     return SAH_OK;
 }
 

@@ -24,6 +24,10 @@ struct LpvArgs {
     float exposure;
 };
 
+struct ProbeAtlasArgs {  // sah_probe_atlases (probes.hip)
+    VolumeArg rtgi, light_cache, depth, average, validity;
+};
+
 struct CacheArgs {
     VolumeArg irradiance, depth, validity;
     float cascade_min[4][3];

@@ -22,7 +22,7 @@ _lib = None
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
-           "sah_allgather_rows"]
+           "sah_probe_copy", "sah_probe_update", "sah_allgather_rows"]
 
 
 def load():
@@ -52,6 +52,8 @@ def load():
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
     lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32]
+    lib.sah_probe_copy.argtypes = [C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
+    lib.sah_probe_update.argtypes = [C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
@@ -109,6 +111,15 @@ class Context:
         a = (_abi.Volume * 3)(*a_rgb)
         b = (_abi.Volume * 3)(*b_rgb)
         self._check(self.lib.sah_lpv_propagate(self.handle, a, b, num_cascades, steps))
+
+    def probe_copy(self, src, dst, cascade_movement):
+        """src, dst: _abi.ProbeAtlases; cascade_movement: 4 x 3 floats (probe cells per cascade)."""
+        mv = ((C.c_float * 3) * 4)(*[(C.c_float * 3)(*[float(v) for v in row]) for row in cascade_movement])
+        self._check(self.lib.sah_probe_copy(self.handle, C.byref(src), C.byref(dst), mv))
+
+    def probe_update(self, atlases, trace_results, probes_to_update_ptr, num_probes):
+        """probes_to_update_ptr: device address of num_probes packed uint32 triples."""
+        self._check(self.lib.sah_probe_update(self.handle, C.byref(atlases), C.byref(trace_results), C.c_void_p(probes_to_update_ptr), num_probes))
 
     def allgather_rows(self, image, rows_per_rank):
         self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank))

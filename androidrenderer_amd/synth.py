@@ -254,3 +254,38 @@ def hdr_scene(width, height, seed=11):
     out[..., :3] = np.minimum(c, 60000.0).astype(np.float16)
     out[..., 3] = 1.0
     return out
+
+
+def probe_maintenance_inputs(seed=12, num_probes=48):
+    """Inputs of the irradiance-cache maintenance passes (a11; RenderCore/render/gi/irradiance_cache.cpp:94-183, 585-724): the five
+    probe atlases (random finite R11G11B10 / RG16F / R8 contents), trace results 20 x 20 x P RGBA16F (a = hit distance, ~25 % misses
+    with a <= 0) and P distinct probe ids that include the grid corners."""
+    g = rng(seed)
+
+    def r11(shape):
+        return pack_r11g11b10(g.uniform(0.0, 8.0, shape + (3,)).astype(np.float32))
+
+    atl = {
+        "rtgi": r11((32, 256, 224)),
+        "light_cache": r11((32, 416, 416)),
+        "depth": g.uniform(0.0, 6.0, (32, 384, 384, 2)).astype(np.float16),
+        "average": r11((32, 32, 32)),
+        "validity": g.integers(0, 256, (32, 32, 32), dtype=np.uint8),
+    }
+    trace = np.zeros((num_probes, 20, 20, 4), dtype=np.float16)
+    trace[..., :3] = g.uniform(0.0, 5.0, (num_probes, 20, 20, 3)).astype(np.float16)
+    dist = g.uniform(0.05, 30.0, (num_probes, 20, 20)).astype(np.float16)
+    miss = g.random((num_probes, 20, 20)) < 0.25
+    dist[miss] = np.where(g.random(int(miss.sum())) < 0.5, np.float16(-1.0), np.float16(0.0))
+    trace[..., 3] = dist
+    if num_probes > 2:
+        trace[1, ..., 3] = np.float16(-1.0)  # a probe whose rays all miss
+        trace[2, ..., 3] = np.float16(2.5)   # a probe whose rays all hit
+    cells = g.permutation(32 * 32 * 32)[:num_probes]
+    ids = np.stack([cells % 32, (cells // 32) % 32, cells // 1024], axis=-1).astype(np.uint32)
+    corners = np.array([[0, 0, 0], [31, 31, 31], [31, 0, 31], [0, 31, 0]], dtype=np.uint32)
+    k = min(len(corners), num_probes)
+    # keep ids distinct: drop any random id that equals a corner, then prepend the corners
+    keep = [tuple(i) for i in ids if tuple(i) not in {tuple(c) for c in corners[:k]}]
+    ids = np.array([tuple(c) for c in corners[:k]] + keep, dtype=np.uint32)[:num_probes]
+    return atl, trace, np.ascontiguousarray(ids)

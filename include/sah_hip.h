@@ -248,6 +248,35 @@ int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, 
 int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades,
                       uint32_t steps);
 
+/* Irradiance-cache probe maintenance (a11) — RenderCore/render/gi/irradiance_cache.cpp:455-486 (copy_probes_to_new_texture)
+ * and :585-724 (dispatch_probe_updates, minus the ray-tracing pass whose output `trace_results` is an input here).
+ * Atlases are 2D arrays of 32 layers with one block per probe (irradiance_cache.cpp:94-183); probe grid 32 x (8 * 4 cascades) x 32;
+ * block sizes are fixed by the shaders: rtgi 7x8, light cache 13x13, depth 12x12 texels (interior 5x6, 11x11, 10x10).
+ *
+ * The reference shaders race in two places (several invocations of one dispatch store different values to the same texel:
+ * write_probe_texel_with_border for odd probe widths, gi/cache/probe_update.slangi:4-37, and init_new_probe's depth clear at
+ * light-cache offsets, gi/cache/copy_cascades.comp.slang:39-45) and use WaveActiveSum on half3 (probe_finalize.comp.slang:66),
+ * whose summation order the API leaves open.  This ABI fixes an order: stores of one dispatch take effect in
+ * ascending linear invocation index (program order inside an invocation), the wave sum adds in lane order in fp16; out-of-range
+ * image stores are dropped, out-of-range loads return 0. */
+typedef struct sah_probe_atlases {
+    sah_volume rtgi;        /* B10G11R11_UFLOAT_PACK32, (32*7)  x (32*8)  x 32 */
+    sah_volume light_cache; /* B10G11R11_UFLOAT_PACK32, (32*13) x (32*13) x 32 */
+    sah_volume depth;       /* R16G16_SFLOAT,           (32*12) x (32*12) x 32 */
+    sah_volume average;     /* B10G11R11_UFLOAT_PACK32, 32 x 32 x 32 */
+    sah_volume validity;    /* R8_UNORM,                32 x 32 x 32 */
+} sah_probe_atlases;
+
+/* copy_cascades.comp.slang:86-99: scroll every cascade by cascade_movement[c] (probe cells, truncated toward zero), copying probe
+ * blocks src -> dst and initialising the probes that scroll in (validity 1.0 marks them new).  src and dst must not alias. */
+int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_atlases* dst, const float cascade_movement[4][3]);
+
+/* probe_depth_update, probe_light_cache_update, probe_rtgi_update, probe_finalize, in that order, for `num_probes` probes.
+ * trace_results: R16G16B16A16_SFLOAT 20 x 20 x num_probes (rgb = radiance, a = hit distance, <= 0: miss);
+ * probes_to_update: DEVICE pointer to num_probes tightly packed uint32 triples (probe x, y, layer), all distinct. */
+int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_volume* trace_results, const uint32_t* probes_to_update,
+                     uint32_t num_probes);
+
 /* Multi-GPU: in-place all-gather of row blocks of `image` (rank r owns rows
  * [rows_per_rank*r, rows_per_rank*(r+1))) over RCCL. */
 int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank);

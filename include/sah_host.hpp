@@ -317,6 +317,79 @@ private:
     std::array<sah_lpv_cascade_matrices, 4> cascades{};
 };
 
+// RenderCore/render/gi/irradiance_cache.{hpp,cpp}: atlases :94-183, cascade placement :298-372, copy_probes_to_new_texture
+// :455-486, dispatch_probe_updates :585-724, overlay :203-245.  Probe ray tracing (probe_tracing.rt.slang) is outside the hot
+// path: set_trace_results() is the seam that hands its output (20 x 20 rays per probe) and the probe list to the update passes.
+class IrradianceCache : public IGlobalIlluminator {
+public:
+    explicit IrradianceCache(RenderBackend& backend) {
+        auto& alloc = backend.get_global_allocator();
+        const uint32_t r11 = SAH_FORMAT_B10G11R11_UFLOAT_PACK32;
+        for (int s = 0; s < 2; s++) {  // a / b sets, swapped by copy_probes_to_new_texture
+            const std::string tag = s ? "_b" : "_a";
+            set[s].rtgi = alloc.create_texture("probe_rtgi" + tag, r11, 32 * 7, 32 * 8, 32);
+            set[s].light_cache = alloc.create_texture("probe_light_cache" + tag, r11, 32 * 13, 32 * 13, 32);
+            set[s].depth = alloc.create_texture("probe_depth" + tag, SAH_FORMAT_R16G16_SFLOAT, 32 * 12, 32 * 12, 32);
+            set[s].average = alloc.create_texture("probe_average" + tag, r11, 32, 32, 32);
+            set[s].validity = alloc.create_texture("probe_validity" + tag, SAH_FORMAT_R8_UNORM, 32, 32, 32);
+        }
+        for (int c = 0; c < 4; c++) cascades[c].probe_spacing = 0.5f * std::pow(2.f, (float)c);
+    }
+    // irradiance_cache.cpp:298-372 places the cascades around the camera on a probe_spacing grid and records how many cells each
+    // one moved; here the caller provides both (placement is scene logic, outside the hot path)
+    void set_cascade(uint32_t c, const Vec3& min, float spacing, const Vec3& movement_cells) {
+        for (int i = 0; i < 3; i++) { cascades[c].min[i] = min[i]; movement[c][i] = movement_cells[i]; }
+        cascades[c].probe_spacing = spacing;
+    }
+    void set_trace_results(TextureHandle trace_results_in, const uint32_t* probes_to_update_device, uint32_t num_probes_in) {
+        trace_results = trace_results_in;
+        probes_to_update = probes_to_update_device;
+        num_probes = num_probes_in;
+    }
+    void pre_render(RenderGraph& graph, const SceneView&, const RenderScene&, TextureHandle) override {
+        copy_probes_to_new_texture(graph);
+        dispatch_probe_updates(graph);
+    }
+    void post_render(RenderGraph&, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {}
+    void copy_probes_to_new_texture(RenderGraph& graph) {
+        graph.add_pass({"cascade_copy", [this](sah_ctx* ctx) {
+                            const sah_probe_atlases a = atlases(0), b = atlases(1);
+                            return sah_probe_copy(ctx, &a, &b, movement);
+                        }});
+        std::swap(set[0], set[1]);  // swap_probe_textures(): "a" is the current set again
+    }
+    void dispatch_probe_updates(RenderGraph& graph) {
+        if (num_probes == 0 || trace_results == nullptr) return;  // irradiance_cache.cpp:590-592
+        graph.add_pass({"probe updates", [this](sah_ctx* ctx) {
+                            const sah_probe_atlases a = atlases(0);
+                            return sah_probe_update(ctx, &a, &trace_results->desc, probes_to_update, num_probes);
+                        }});
+    }
+    void render_to_lit_scene(sah_gi& gi, TextureHandle, TextureHandle) const override {
+        gi.kind = SAH_GI_CACHE;
+        gi.probe_irradiance = set[0].rtgi->desc;
+        gi.probe_depth = set[0].depth->desc;
+        gi.probe_validity = set[0].validity->desc;
+        for (int c = 0; c < 4; c++) gi.probe_cascades[c] = cascades[c];
+        gi.probe_size[0] = 5;
+        gi.probe_size[1] = 6;
+        gi.cache_debug_mode = 0;
+    }
+    sah_probe_atlases atlases(int s) const {
+        return sah_probe_atlases{set[s].rtgi->desc, set[s].light_cache->desc, set[s].depth->desc, set[s].average->desc, set[s].validity->desc};
+    }
+
+private:
+    struct Set {
+        TextureHandle rtgi{}, light_cache{}, depth{}, average{}, validity{};
+    } set[2];
+    std::array<sah_probe_cascade, 4> cascades{};
+    float movement[4][3] = {};
+    TextureHandle trace_results{};
+    const uint32_t* probes_to_update = nullptr;
+    uint32_t num_probes = 0;
+};
+
 // ---- LightingPhase (RenderCore/render/phase/lighting_phase.hpp:17-57, .cpp:34-134) -------------------------------------
 class LightingPhase {
 public:

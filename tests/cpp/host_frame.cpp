@@ -72,6 +72,18 @@ int main(int argc, char** argv) {
     ui.set_resources(antialiased, swapchain);
 
     RenderGraph graph{backend};
+    // the irradiance cache's maintenance passes through the same graph (a11): scroll cascade 0 by one cell, update three probes from
+    // an all-miss trace; checked here only for "runs without error" — tests/test_probes.py holds the parity checks
+    IrradianceCache cache(backend);
+    cache.set_cascade(0, {-8.f, -2.f, -8.f}, 0.5f, {1.f, 0.f, 0.f});
+    TextureHandle trace = alloc.create_texture("probe_trace_results", SAH_FORMAT_R16G16B16A16_SFLOAT, 20, 20, 3);
+    const uint32_t probe_ids[9] = {0, 0, 0, 5, 9, 7, 31, 31, 31};
+    uint32_t* probe_ids_dev = nullptr;
+    if (hipMalloc(&probe_ids_dev, sizeof(probe_ids)) != hipSuccess || hipMemcpy(probe_ids_dev, probe_ids, sizeof(probe_ids), hipMemcpyHostToDevice) != hipSuccess)
+        return 3;
+    cache.set_trace_results(trace, probe_ids_dev, 3);
+    cache.pre_render(graph, view, scene, nullptr);
+
     const IGlobalIlluminator* gi = &lpv;
     lpv.post_render(graph, view, scene, gbuffer, nullptr);
     lighting.render(graph, view, gbuffer, lit_scene, ao, gi);

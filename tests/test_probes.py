@@ -1,0 +1,150 @@
+"""Irradiance-cache probe maintenance (a11): sah_probe_copy / sah_probe_update.
+CPU: known-answer tests of the oracle (identity scroll, new-probe initialisation incl. the misplaced depth clear, the border
+writer's geometry, mean-of-hits depth).  GPU: HIP == oracle bit for bit, including the store-order cases the ABI defines."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, synth
+from tests import util
+
+
+def _copy_arrays(a):
+    return {k: v.copy() for k, v in a.items()}
+
+
+def _oracle_copy(src, dst, movement):
+    o = util.oracle()
+    mv = ((C.c_float * 3) * 4)(*[(C.c_float * 3)(*row) for row in movement])
+    s, d = util.probe_atlases_desc(src), util.probe_atlases_desc(dst)
+    assert o.orc_probe_copy(C.byref(s), C.byref(d), mv) == 0
+
+
+def _oracle_update(atl, trace, ids):
+    o = util.oracle()
+    a = util.probe_atlases_desc(atl)
+    tv = images.volume(trace.view(np.uint16), _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_probe_update(C.byref(a), C.byref(tv), ids.ctypes.data, len(ids)) == 0
+
+
+def _f16(bits):
+    return np.asarray(bits, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+def test_copy_zero_movement_is_identity():
+    src, _, _ = synth.probe_maintenance_inputs(seed=21, num_probes=4)
+    dst = {k: np.full_like(v, 0x55 if v.dtype == np.uint8 else 0) for k, v in src.items()}
+    dst["depth"] = np.full_like(src["depth"], 7.0)
+    _oracle_copy(src, dst, [[0, 0, 0]] * 4)
+    for k in ("rtgi", "light_cache", "average", "validity"):
+        assert np.array_equal(dst[k], src[k]), k
+    assert np.array_equal(dst["depth"].view(np.uint16), src["depth"].view(np.uint16))
+
+
+def test_copy_scroll_initialises_new_probes_and_misplaces_the_depth_clear():
+    src, _, _ = synth.probe_maintenance_inputs(seed=22, num_probes=4)
+    dst = _copy_arrays(src)
+    dst["depth"][...] = 9.0
+    # cascade 0 scrolls by +1 in x (probes x = 0 are new), fractional movement truncates toward zero, cascade 3 scrolls out entirely
+    mv = [[1.7, 0, 0], [-0.9, 0.9, 0], [0, 0, 0], [0, 9, 0]]
+    _oracle_copy(src, dst, mv)
+    # cascade 0, probe (x=5, y=3, z=7) copies from (4, 3, 7)
+    assert np.array_equal(dst["rtgi"][7, 3 * 8:3 * 8 + 8, 5 * 7:5 * 7 + 7], src["rtgi"][7, 3 * 8:3 * 8 + 8, 4 * 7:4 * 7 + 7])
+    assert dst["validity"][7, 3, 5] == src["validity"][7, 3, 4]
+    # new probes: x = 0 of cascade 0 -> validity 1.0, zeros
+    assert (dst["validity"][:, 0:8, 0] == 255).all() and (dst["average"][:, 0:8, 0] == 0).all()
+    assert (dst["rtgi"][:, 0:64, 0:7] == 0).all() and (dst["light_cache"][:, 0:8 * 13, 0:13] == 0).all()
+    # cascade 1 moved by (int)(-0.9, 0.9) = (0, 0): identity
+    assert np.array_equal(dst["average"][:, 8:16, :], src["average"][:, 8:16, :])
+    # cascade 3 scrolled out: every probe is new
+    assert (dst["validity"][:, 24:32, :] == 255).all()
+    # the depth clear of a new probe lands at light-cache offsets: probe (0, 2, z) zeroes depth[z, 26:38, 0:12] — but texels that a
+    # LATER probe's copy also writes keep the copied value (cell (0..0, y=2..3) with x = 0 are themselves new, so nobody copies here)
+    d = dst["depth"].astype(np.float32)
+    assert (d[5, 26:38, 0:12] == 0).all()
+    # the properly placed depth block of a new probe is NOT cleared by anyone unless a misplaced clear covers it: probe (0,7,z) of
+    # cascade 0 owns depth rows 84..95, cols 0..11; the misplaced clears of probes (0,6) [rows 78..89] and (0,7) [rows 91..102] cover
+    # rows 84..89 and 91..95, row 90 survives with the old contents
+    assert (d[5, 90, 0:12] == 9.0).all() and (d[5, 84:90, 0:12] == 0).all() and (d[5, 91:96, 0:12] == 0).all()
+
+
+def test_update_depth_is_mean_of_hits_and_border_geometry():
+    atl, trace, ids = synth.probe_maintenance_inputs(seed=23, num_probes=6)
+    before = _copy_arrays(atl)
+    _oracle_update(atl, trace, ids)
+    d = atl["depth"].view(np.uint16)
+    for p in (2, 4):  # probe 2: every ray hits at 2.5
+        x, y, z = (int(v) for v in ids[p])
+        bx, by = x * 12, y * 12
+        hit = trace[p, ..., 3].astype(np.float32)
+        for ty in range(10):
+            for tx in range(10):
+                h = hit[2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2].reshape(-1)
+                acc, n = np.float16(0), np.float16(0)
+                for v in h:  # order i = 0..3: (0,0), (1,0), (0,1), (1,1)
+                    if v > 0:
+                        acc = np.float16(acc + np.float16(v))
+                        n = np.float16(n + np.float16(1))
+                mean = np.float16(np.float32(acc) / np.float32(n)) if n > 0 else np.float16(0)
+                # interior texel (tx, ty) sits at block offset (tx, ty), not (tx + 1, ty + 1)
+                assert d[z, by + ty, bx + tx, 0] == mean.view(np.uint16), (p, tx, ty)
+                assert d[z, by + ty, bx + tx, 1] == np.float16(mean * mean).view(np.uint16)
+    # probe 1: all rays miss -> depth 0, validity 0
+    x, y, z = (int(v) for v in ids[1])
+    assert (d[z, y * 12:y * 12 + 10, x * 12:x * 12 + 10] == 0).all()
+    # border cell 10 of the block mirrors interior texels: column 10 holds texel (9, 9 - j) for row j (probe_update.slangi:22-28)
+    x, y, z = (int(v) for v in ids[2])
+    assert (d[z, y * 12:y * 12 + 10, x * 12 + 10] == d[z, y * 12:y * 12 + 10, x * 12 + 9][::-1]).all()
+    # untouched texels keep their contents (cell 11 of the block belongs to nobody)
+    assert np.array_equal(d[z, y * 12:y * 12 + 10, x * 12 + 11], before["depth"].view(np.uint16)[z, y * 12:y * 12 + 10, x * 12 + 11])
+
+
+def test_update_finalize_validity_counts_two_texels_times_64():
+    atl, trace, ids = synth.probe_maintenance_inputs(seed=24, num_probes=5)
+    _oracle_update(atl, trace, ids)
+    x, y, z = (int(v) for v in ids[2])  # all rays hit: both tested texels valid -> 128 / 100 saturates
+    assert atl["validity"][z, y, x] == 255
+    x, y, z = (int(v) for v in ids[1])  # all rays miss; the tested texels are block cells (1,1) and (5,7) = interior (1,1), (5,7): 0
+    assert atl["validity"][z, y, x] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("movement", [[[0, 0, 0]] * 4, [[1.7, 0, 0], [-0.9, 0.9, 0], [0, 0, 0], [0, 9, 0]],
+                                      [[-3, 2, 5], [31, 0, -31], [0, -7.5, 0], [np.nan, 0, 1e30]]])
+def test_hip_probe_copy_matches_oracle(hip_ctx, movement):
+    import torch
+    src, _, _ = synth.probe_maintenance_inputs(seed=25, num_probes=4)
+    src["rtgi"][3, 10, 20] = 0x7c1 | (0x7e3 << 11) | (0x3ff << 22)  # NaN patterns: canonicalised by the half3 round trip
+    src["rtgi"][3, 10, 21] = 0x7c0 | (0x7c0 << 11) | (0x3e0 << 22)  # infinities survive
+    dst0 = synth.probe_maintenance_inputs(seed=26, num_probes=4)[0]  # previous contents of the destination
+    want = _copy_arrays(dst0)
+    _oracle_copy(src, want, movement)
+    s_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in src.items()}
+    d_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in dst0.items()}
+    hip_ctx.probe_copy(util.probe_atlases_desc(s_t), util.probe_atlases_desc(d_t), movement)
+    torch.cuda.synchronize()
+    for k in want:
+        got = d_t[k].cpu().numpy()
+        ref = want[k].view(np.uint16) if want[k].dtype == np.float16 else want[k]
+        assert np.array_equal(got.view(ref.dtype).reshape(ref.shape), ref), f"atlas {k} differs"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_probes", [1, 48, 300])
+def test_hip_probe_update_matches_oracle(hip_ctx, num_probes):
+    import torch
+    atl, trace, ids = synth.probe_maintenance_inputs(seed=27, num_probes=num_probes)
+    want = _copy_arrays(atl)
+    _oracle_update(want, trace, ids)
+    a_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in atl.items()}
+    tr_t = util.to_torch(trace.view(np.uint16))
+    ids_t = torch.from_numpy(ids.view(np.int32)).cuda()
+    hip_ctx.probe_update(util.probe_atlases_desc(a_t), images.volume(tr_t, _abi.FORMAT_R16G16B16A16_SFLOAT), ids_t.data_ptr(), num_probes)
+    torch.cuda.synchronize()
+    for k in want:
+        got = a_t[k].cpu().numpy()
+        ref = want[k].view(np.uint16) if want[k].dtype == np.float16 else want[k]
+        assert np.array_equal(got.view(ref.dtype).reshape(ref.shape), ref), f"atlas {k} differs"
+    # something was written
+    assert not np.array_equal(want["depth"].view(np.uint16), atl["depth"].view(np.uint16))

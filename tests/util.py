@@ -54,8 +54,20 @@ def oracle():
     o.orc_sample_trilinear.argtypes = [C.POINTER(_abi.Volume), C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]
     o.orc_sample_shadow.argtypes = [C.POINTER(_abi.Volume), C.c_float, C.c_float, C.c_int, C.c_float]
     o.orc_sample_shadow.restype = C.c_float
+    o.orc_probe_copy.argtypes = [C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
+    o.orc_probe_update.argtypes = [C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
     _oracle = o
     return o
+
+
+def probe_atlases_desc(arrays):
+    """dict of numpy / torch atlases (synth.probe_maintenance_inputs) -> _abi.ProbeAtlases"""
+    from androidrenderer_amd import images
+    return _abi.ProbeAtlases(images.volume(arrays["rtgi"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32),
+                             images.volume(arrays["light_cache"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32),
+                             images.volume(arrays["depth"], _abi.FORMAT_R16G16_SFLOAT),
+                             images.volume(arrays["average"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32),
+                             images.volume(arrays["validity"], _abi.FORMAT_R8_UNORM))
 
 
 # ---- ULP metrics -----------------------------------------------------------------------------------
