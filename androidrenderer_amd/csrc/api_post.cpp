@@ -14,6 +14,7 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st);
 hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
 hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, hipStream_t st);
 }  // namespace sah
@@ -158,6 +159,16 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, ctx->stream));
         else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, ctx->stream));
     }
+    return SAH_OK;
+}
+
+int sah_ao_clear(sah_ctx* ctx, const sah_plane* ao) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!ao || !ao->ptr || ao->format != SAH_FORMAT_R32_SFLOAT || !ao->width || !ao->height || (uint64_t)ao->row_pitch_bytes < (uint64_t)ao->width * 4 ||
+        ((uintptr_t)ao->ptr % 4) || (ao->row_pitch_bytes % 4))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "the AO target must be an R32_SFLOAT plane");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_fill_r32f(parg(ao), ao->width, ao->height, 1.0f, ctx->stream));
     return SAH_OK;
 }
 

@@ -324,6 +324,17 @@ __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
     *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(t.out.ptr) + (size_t)y * t.out.pitch + (size_t)x * 4) = px;
 }
 
+// ---- a12 (AO mode Off): clear the R32F target to 1.0 — ambient_occlusion_phase.cpp:167-179 ------------------------------
+__global__ void __launch_bounds__(256) k_fill_r32f(PlaneArg dst, uint32_t w, uint32_t h, float value) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    *reinterpret_cast<float*>(const_cast<uint8_t*>(dst.ptr) + (size_t)y * dst.pitch + (size_t)x * 4) = value;
+}
+hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_r32f, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, st, dst, w, h, value);
+    return hipGetLastError();
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st) {
     const dim3 grid((dw + 63) / 64, (dh + 3) / 4);

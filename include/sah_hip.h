@@ -248,6 +248,11 @@ int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, 
 int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades,
                       uint32_t steps);
 
+/* AmbientOcclusionPhase::generate_ao with r.AO.Mode = Off — RenderCore/render/phase/ambient_occlusion_phase.cpp:167-179: the AO
+ * target (R32_SFLOAT) is cleared to 1.0.  RTAO / CACAO need the scene BVH and stay in the renderer; their output is the `ao` input
+ * plane of sah_lighting. */
+int sah_ao_clear(sah_ctx* ctx, const sah_plane* ao);
+
 /* Irradiance-cache probe maintenance (a11) — RenderCore/render/gi/irradiance_cache.cpp:455-486 (copy_probes_to_new_texture)
  * and :585-724 (dispatch_probe_updates, minus the ray-tracing pass whose output `trace_results` is an input here).
  * Atlases are 2D arrays of 32 layers with one block per probe (irradiance_cache.cpp:94-183); probe grid 32 x (8 * 4 cascades) x 32;

@@ -390,6 +390,18 @@ private:
     uint32_t num_probes = 0;
 };
 
+// RenderCore/render/phase/ambient_occlusion_phase.cpp:157-189.  Only r.AO.Mode = Off is on this side of the boundary (the target
+// is cleared to 1.0, :167-179); RTAO and CACAO need the BVH / the Vulkan SDK and hand their result over as the AO plane.
+class AmbientOcclusionPhase {
+public:
+    void generate_ao(RenderGraph& graph, TextureHandle ao_out) {
+        graph.add_pass({"Clear AO", [ao_out](sah_ctx* ctx) {
+                            const sah_plane p = ao_out->plane();
+                            return sah_ao_clear(ctx, &p);
+                        }});
+    }
+};
+
 // ---- LightingPhase (RenderCore/render/phase/lighting_phase.hpp:17-57, .cpp:34-134) -------------------------------------
 class LightingPhase {
 public:

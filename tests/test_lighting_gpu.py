@@ -120,3 +120,22 @@ def test_lighting_no_quirk_flag(hip_ctx):
 def test_lighting_no_sky(hip_ctx):
     f = util.LightingFrame(128, 72, seed=14, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_NONE, sky=False)
     _check(f, hip_ctx, "no sky")
+
+
+def test_ao_off_mode_clear_equals_no_ao_plane(hip_ctx):
+    """a12: AO mode Off clears the AO target to 1.0 (ambient_occlusion_phase.cpp:167-179); the LPV overlay must then give exactly
+    what it gives with a constant-one AO plane, on a pitched plane whose padding stays untouched."""
+    import torch
+    from androidrenderer_amd import images
+    f = util.LightingFrame(160, 90, seed=91, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    f.arrays["ao"] = np.ones((90, 160), dtype=np.float32)
+    want = f.run_oracle()
+    dev = f.device_arrays()
+    padded = torch.full((90, 192), 7.0, dtype=torch.float32, device="cuda")  # row pitch 768 bytes, 160 texels used
+    ao_view = padded[:, :160]
+    hip_ctx.ao_clear(_abi.Plane(padded.data_ptr(), 160, 90, 192 * 4, _abi.FORMAT_R32_SFLOAT))
+    torch.cuda.synchronize()
+    assert bool((ao_view == 1.0).all()) and bool((padded[:, 160:] == 7.0).all())
+    dev["ao"] = ao_view.contiguous()
+    got = f.run_hip(hip_ctx, dev)
+    assert np.array_equal(got, want)
