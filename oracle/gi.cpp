@@ -355,3 +355,22 @@ bool gi_rtgi_frag(const sah_lighting_desc& d, int x, int y, float depth, const T
 }
 
 }  // namespace orc
+
+// exports for the known-answer tests (SURVEY.md §8-c fixture i)
+extern "C" void orc_dir_to_sh(const float* d3, float* out4) {
+    orc::F o[4];
+    orc::dir_to_sh(orc::F3{orc::F(d3[0]), orc::F(d3[1]), orc::F(d3[2])}, o);
+    for (int i = 0; i < 4; i++) out4[i] = o[i].v;
+}
+extern "C" void orc_octahedral_coordinates(const float* d3, float* out2) {
+    const orc::F2 uv = orc::octahedral_coordinates(orc::F3{orc::F(d3[0]), orc::F(d3[1]), orc::F(d3[2])});
+    out2[0] = uv.x.v;
+    out2[1] = uv.y.v;
+}
+extern "C" void orc_probe_uv(const uint32_t* idx3, const float* oct2, uint32_t n0, uint32_t n1, float* out2) {
+    const uint32_t n[2] = {n0, n1};
+    orc::F uv[2];
+    orc::probe_uv(idx3, orc::F2{orc::F(oct2[0]), orc::F(oct2[1])}, n, uv);
+    out2[0] = uv[0].v;
+    out2[1] = uv[1].v;
+}

@@ -243,3 +243,13 @@ extern "C" int orc_lighting(const sah_lighting_desc* d) {
     }
     return SAH_OK;
 }
+
+// exports for the known-answer tests (SURVEY.md §8-c fixture iii: the half-pixel offset quirk)
+extern "C" void orc_viewspace_position_glsl(const sah_view_data* view, int x, int y, float depth, float* out3) {
+    const orc::F3 p = orc::viewspace_position_glsl(*view, x, y, depth);
+    out3[0] = p.x.v; out3[1] = p.y.v; out3[2] = p.z.v;
+}
+extern "C" void orc_worldspace_location_slang(const sah_view_data* view, int x, int y, float depth, float* out3) {
+    const orc::F3 p = orc::worldspace_location_slang(*view, x, y, depth);
+    out3[0] = p.x.v; out3[1] = p.y.v; out3[2] = p.z.v;
+}

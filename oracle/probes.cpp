@@ -283,3 +283,14 @@ extern "C" int orc_probe_update(const sah_probe_atlases* atl, const sah_volume* 
     }
     return SAH_OK;
 }
+
+// exports for the known-answer tests (SURVEY.md §8-c fixture i): texel -> octahedral coordinates -> direction
+extern "C" void orc_octahedral_direction_of_texel(uint32_t tx, uint32_t ty, uint32_t nx, uint32_t ny, float* coords2, float* dir3) {
+    const F2 c = normalized_octahedral_coordinates(tx, ty, nx, ny);
+    const F3 d = octahedral_direction(c);
+    coords2[0] = c.x.v;
+    coords2[1] = c.y.v;
+    dir3[0] = d.x.v;
+    dir3[1] = d.y.v;
+    dir3[2] = d.z.v;
+}

@@ -190,3 +190,77 @@ def test_quirk_tonemap_vflip_and_double_gamma(oracle):
     c = 0.5 ** (1 / 2.2)
     expect = round((1.055 * c ** (1 / 2.4) - 0.055) * 255.0)
     assert out[h - 1, 2, 0] == expect and out[h - 1, 2, 3] == 255
+
+
+# ---- SH / octahedral / probe addressing (fixture i) ----------------------------------------------------------------
+def _f3(*v):
+    return (C.c_float * 3)(*v)
+
+
+def test_dir_to_sh_of_plus_z(oracle):
+    out = (C.c_float * 4)()
+    oracle.orc_dir_to_sh(_f3(0.0, 0.0, 1.0), out)
+    # spherical_harmonics.glsl:32-34: (c0, -c1*y, c1*z, -c1*x) with c0 = 0.282094792, c1 = 0.488602512
+    assert out[0] == np.float32(0.282094792) and out[2] == np.float32(0.488602512)
+    assert out[1] == 0.0 and math.copysign(1.0, out[1]) == -1.0 and out[3] == 0.0 and math.copysign(1.0, out[3]) == -1.0  # -c1 * 0 == -0
+
+
+def test_octahedral_round_trip_on_texel_centres(oracle):
+    coords, d, uv = (C.c_float * 2)(), (C.c_float * 3)(), (C.c_float * 2)()
+    for n in (5, 6, 10, 11, 20):
+        for ty in range(n):
+            for tx in range(n):
+                oracle.orc_octahedral_direction_of_texel(tx, ty, n, n, coords, d)
+                assert abs(coords[0] - ((tx + 0.5) / n * 2 - 1)) < 1e-6 and abs(coords[1] - ((ty + 0.5) / n * 2 - 1)) < 1e-6
+                assert abs(d[0] ** 2 + d[1] ** 2 + d[2] ** 2 - 1.0) < 1e-6
+                oracle.orc_octahedral_coordinates(d, uv)  # direction -> coordinates (octahedral.slangi:56-63) inverts the mapping
+                assert abs(uv[0] - coords[0]) < 2e-6 and abs(uv[1] - coords[1]) < 2e-6, (n, tx, ty)
+    oracle.orc_octahedral_direction_of_texel(7, 3, 5, 6, coords, d)  # texel indices wrap: 7 % 5 = 2, 3 % 6 = 3
+    assert abs(coords[0] - 0.0) < 1e-7 and abs(coords[1] - (3.5 / 6 * 2 - 1)) < 1e-6
+
+
+def test_probe_uv_of_corner_probes(oracle):
+    uv = (C.c_float * 2)()
+    zero2 = (C.c_float * 2)(0.0, 0.0)
+    # octahedral.slangi:65-74 with 10 x 10 depth probes (12-texel blocks, 384-texel atlas): block centre of probe i is (12 i + 6) / 384
+    oracle.orc_probe_uv((C.c_uint32 * 3)(0, 0, 0), zero2, 10, 10, uv)
+    assert uv[0] == np.float32(6.0 / 384.0) and uv[1] == np.float32(6.0 / 384.0)
+    oracle.orc_probe_uv((C.c_uint32 * 3)(31, 31, 5), zero2, 10, 10, uv)
+    assert uv[0] == np.float32(378.0 / 384.0) and uv[1] == np.float32(378.0 / 384.0)
+    # 5 x 6 irradiance probes: octant coordinate +1 moves half an interior width from the centre
+    oracle.orc_probe_uv((C.c_uint32 * 3)(3, 9, 0), (C.c_float * 2)(1.0, -1.0), 5, 6, uv)
+    assert uv[0] == np.float32((3 * 7 + 3.5 + 2.5) / 224.0) and uv[1] == np.float32((9 * 8 + 4.0 - 3.0) / 256.0)
+
+
+# ---- more quirks (fixture iii) ---------------------------------------------------------------------------------------
+def test_quirk_glsl_passes_use_x_plus_one_over_width(oracle):
+    from androidrenderer_amd import scene
+    view = scene.SceneView.default(64, 36)
+    g, s = (C.c_float * 3)(), (C.c_float * 3)()
+    ip = np.array(view.gpu_data.inverse_projection[:], dtype=np.float64).reshape(4, 4).T
+
+    def viewspace(tx, ty, depth):
+        v = ip @ np.array([tx * 2 - 1, ty * 2 - 1, depth, 1.0])
+        return v[:3] / v[3]
+
+    oracle.orc_viewspace_position_glsl(C.byref(view.gpu_data), 10, 7, C.c_float(0.25), g)
+    want = viewspace((10 + 1.0) / 64.0, (7 + 1.0) / 36.0, 0.25)  # gl_FragCoord already holds the +0.5; the shader adds it again
+    assert np.allclose([g[0], g[1], g[2]], want, rtol=1e-5)
+    centre = viewspace((10 + 0.5) / 64.0, (7 + 0.5) / 36.0, 0.25)
+    assert not np.allclose([g[0], g[1]], centre[:2], rtol=1e-3)
+    # the Slang passes use the true pixel centre (directional_light.rt.slang:39-48); compare in world space through inverse_view
+    oracle.orc_worldspace_location_slang(C.byref(view.gpu_data), 10, 7, C.c_float(0.25), s)
+    iv = np.array(view.gpu_data.inverse_view[:], dtype=np.float64).reshape(4, 4).T
+    assert np.allclose([s[0], s[1], s[2]], (iv @ np.append(centre, 1.0))[:3], rtol=1e-4, atol=1e-5)
+
+
+def test_quirk_nan_lighting_terms_are_zeroed_not_propagated():
+    """`if (any(isnan(total_lighting))) total_lighting = vec3(0)` (gi/lpv/overlay.frag:156-158): a NaN AO texel makes the GI term of
+    that pixel exactly what a zero AO texel makes it."""
+    f = util.LightingFrame(32, 18, seed=3, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    f.arrays["ao"][5, 9] = np.nan
+    with_nan = f.run_oracle()
+    f.arrays["ao"][5, 9] = 0.0
+    with_zero = f.run_oracle()
+    assert np.array_equal(with_nan, with_zero)
+    assert (with_nan[5, 9].view(np.float16)[:3] == with_nan[5, 9].view(np.float16)[:3]).all()  # no NaN in the output
