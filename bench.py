@@ -35,13 +35,46 @@ WORKLOADS = {
     "4k_deferred_only": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none"),
     "1080p_deferred_gi": dict(res=(1920, 1080), gbuffer="atrium", sun="csm", gi="lpv"),
     "8k_deferred_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv"),
-    "1080p_64_lights": dict(res=(1920, 1080), gbuffer="random", sun="csm", gi="none", lights=64),            # configs[1]
-    "4k_256_lights": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none", lights=256),             # configs[2]
-    "4k_probe_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True),         # configs[3]
+    # light radii per SURVEY.md §8-d: 64 lights r = 6 m, 256 lights r = 4 m, 1024 lights r = 3 m
+    "1080p_64_lights": dict(res=(1920, 1080), gbuffer="random", sun="csm", gi="none", lights=64, radius=6.0),            # configs[1]
+    "4k_256_lights": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none", lights=256, radius=4.0),             # configs[2]
+    "4k_probe_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True),                     # configs[3]
     "4k_lpv_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", chain=True),
-    "8k_1024_lights_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv", lights=1024),         # configs[4]
+    "8k_1024_lights_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv", lights=1024, radius=3.0),         # configs[4]
 }
-LIGHT_RADIUS = 4.0
+
+
+def light_stats(torch, fr, d_arr, lights_np, dev):
+    """Mean lights per 16x16 tile after culling and mean lights shaded per surface pixel (SURVEY.md §8-d asks for both with every
+    number).  Statistics only: positions are recomputed here in plain fp32 torch, not with the kernel's exact operator order."""
+    v = fr.view.gpu_data
+    W, H = fr.width, fr.height
+    ip = torch.tensor(v.inverse_projection[:], dtype=torch.float32, device=dev).reshape(4, 4).T
+    iv = torch.tensor(v.inverse_view[:], dtype=torch.float32, device=dev).reshape(4, 4).T
+    depth = d_arr["depth"].view(torch.float32)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+    ndc = torch.stack([(xs + 1.0) / v.render_resolution[0] * 2 - 1, (ys + 1.0) / v.render_resolution[1] * 2 - 1, depth, torch.ones_like(depth)], dim=-1)
+    vs = ndc @ ip.T
+    vs = torch.cat([vs[..., :3] / vs[..., 3:4], torch.ones_like(depth)[..., None]], dim=-1)
+    ws = (vs @ iv.T)[..., :3]
+    surf = (depth != 0) & torch.isfinite(ws).all(dim=-1)
+    th, tw = (H + 15) // 16, (W + 15) // 16
+    big = torch.full((th * 16, tw * 16, 3), float("inf"), device=dev)
+    lo_src, hi_src = big.clone(), -big
+    lo_src[:H, :W][surf] = ws[surf]
+    hi_src[:H, :W][surf] = ws[surf]
+    lo = lo_src.reshape(th, 16, tw, 16, 3).amin(dim=(1, 3))
+    hi = hi_src.reshape(th, 16, tw, 16, 3).amax(dim=(1, 3))
+    L = torch.from_numpy(lights_np).to(dev)
+    per_tile = torch.zeros((th, tw), device=dev)
+    per_px = torch.zeros((H, W), device=dev)
+    for i in range(L.shape[0]):
+        c, r = L[i, :3], L[i, 3]
+        d = torch.clamp(torch.maximum(lo - c, c - hi), min=0.0)
+        per_tile += ((d * d).sum(-1) <= (r * 1.0001 + 1e-6) ** 2).float()
+        per_px += (((ws - c) ** 2).sum(-1) <= (r * 1.001) ** 2).float()
+    return {"lights_per_tile_mean": round(float(per_tile.mean()), 2), "lights_per_tile_max": int(per_tile.max()),
+            "lights_shaded_per_pixel_mean": round(float(per_px[surf].mean()) if bool(surf.any()) else 0.0, 3)}
 
 
 def main():
@@ -95,7 +128,7 @@ def main():
     # ---- inputs (identical on every rank: generated from fixed seeds) ----------------------------------------------
     lights = None
     if n_lights:
-        lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, LIGHT_RADIUS, seed=8)
+        lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, wl["radius"], seed=8)
     fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
                               synth_device=str(dev))
     d_arr = fr.device_arrays(dev)
@@ -208,7 +241,7 @@ def main():
         gi_txt = {"none": "no GI", "lpv": "LPV GI gather + AO", "cache": "irradiance-cache probe gather", "rtgi": "RTGI reconstruction"}[wl["gi"]]
         parts = [sun_txt, gi_txt, "emissive", "sky"]
         if n_lights:
-            parts.insert(1, f"{n_lights} point lights (r={LIGHT_RADIUS} m) with LDS tile culling")
+            parts.insert(1, f"{n_lights} point lights (r={wl['radius']} m) with LDS tile culling")
         what = "fused deferred lighting (" + " + ".join(parts) + ")"
         if chain:
             what += " + copy scene + bloom pyramid + tonemap composite"
@@ -245,6 +278,16 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_pixel * my_px,
             },
         }
+        if n_lights:
+            out["config"].update(light_stats(torch, fr, d_arr, lights, dev))
+        vpath = os.path.join(ROOT, "profiles", "valu.json")  # second roofline: VALU instruction stream of the dominant kernel
+        if os.path.exists(vpath):
+            try:
+                vinfo = json.load(open(vpath)).get(args.workload)
+                if vinfo:
+                    out["roofline"]["valu"] = vinfo
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)
         if saved_stdout is not None:
