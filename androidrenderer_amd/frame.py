@@ -24,7 +24,8 @@ def from_torch(t, dtype):
 
 class LightingInputs:
     def __init__(self, width, height, gbuffer=None, seed=1, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_NONE, sky=True, flavour="random",
-                 flags=_abi.LIGHTING_DEFAULT_FLAGS, shadowmap_res=256, lights=None, cache_debug_mode=0, num_extra_rays=0, synth_device="cpu"):
+                 flags=_abi.LIGHTING_DEFAULT_FLAGS, shadowmap_res=256, lights=None, cache_debug_mode=0, num_extra_rays=0, synth_device="cpu",
+                 shadow="noise"):
         self.width, self.height = width, height
         self.view = scene.SceneView.default(width, height)
         self.sun = scene.DirectionalLight(shadow_mode=sun_mode)
@@ -43,7 +44,10 @@ class LightingInputs:
             self.arrays["sky_v"] = luts["sky_view"]
         if sun_mode == _abi.SHADOW_MODE_CSM:
             self.sun.update_shadow_cascades(self.view, resolution=shadowmap_res)
-            self.arrays["shadowmap"] = synth.shadowmap(shadowmap_res, 4, seed + 300)
+            if shadow == "scene" and flavour == "atrium":  # depth of the atrium's own boxes as seen from the sun
+                self.arrays["shadowmap"] = synth.atrium_shadowmap(self.sun.constants, shadowmap_res, 4, device=synth_device)
+            else:  # D16 noise in [0.3, 0.7]
+                self.arrays["shadowmap"] = synth.shadowmap(shadowmap_res, 4, seed + 300)
         if sun_mode == _abi.SHADOW_MODE_RT:
             self.arrays["shadow_mask"] = synth.shadow_mask(width, height, seed + 400)
         self.lpv = None

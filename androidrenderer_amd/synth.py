@@ -174,6 +174,44 @@ def shadowmap(resolution=1024, cascades=4, seed=6):
     return g.integers(int(0.3 * 65535), int(0.7 * 65535), (cascades, resolution, resolution), dtype=np.uint16)
 
 
+def atrium_shadowmap(sun_constants, resolution=4096, cascades=4, device="cpu"):
+    """Cascaded shadow map of the procedural atrium (SURVEY §8-f2 stand-in for the CSM depth pass, directional_light.cpp:286-327):
+    every D16 texel holds the shadow-space depth of the nearest atrium box along the sun direction, found by intersecting the
+    texel's ray — the segment between the cascade's z = 0 and z = 1 planes through cascade_inverse_matrices — with the boxes
+    (torch on `device`).  No occluder: 1.0.  The same boxes produce the G-buffer (atrium_gbuffer), so lit / shadowed regions are
+    coherent with the geometry, which random depth noise (shadowmap()) is not."""
+    import torch
+    dev = torch.device(device)
+    f32 = torch.float32
+    out = np.zeros((cascades, resolution, resolution), dtype=np.uint16)
+    c = (torch.arange(resolution, dtype=f32, device=dev) + 0.5) / resolution * 2.0 - 1.0
+    boxes = _atrium_boxes()
+    rows = max(1, min(resolution, (1 << 22) // resolution))  # ~4M rays per chunk
+    for ci in range(cascades):
+        inv = torch.tensor(np.array(sun_constants.cascade_inverse_matrices[ci][:], dtype=np.float32).reshape(4, 4), device=dev)  # [col][row]
+
+        def unproject(x, y, z):
+            p = x.unsqueeze(-1) * inv[0] + y.unsqueeze(-1) * inv[1] + z * inv[2] + inv[3]
+            return p[..., :3] / p[..., 3:4]
+
+        for r0 in range(0, resolution, rows):
+            yy, xx = torch.meshgrid(c[r0:r0 + rows], c, indexing="ij")
+            p0, p1 = unproject(xx, yy, 0.0), unproject(xx, yy, 1.0)
+            d = p1 - p0
+            d = torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+            inv_d = 1.0 / d
+            t_best = torch.ones(xx.shape, dtype=f32, device=dev)
+            for bmin, bmax, _ in boxes:
+                t0 = (torch.tensor(bmin, device=dev) - p0) * inv_d
+                t1 = (torch.tensor(bmax, device=dev) - p0) * inv_d
+                tnear = torch.minimum(t0, t1).max(dim=-1).values
+                tfar = torch.maximum(t0, t1).min(dim=-1).values
+                hit = (tnear <= tfar) & (tfar > 0.0)
+                t_best = torch.where(hit, torch.minimum(t_best, tnear.clamp_min(0.0)), t_best)
+            out[ci, r0:r0 + rows] = torch.round(t_best.clamp(0.0, 1.0) * 65535.0).to(torch.int32).cpu().numpy().astype(np.uint16)
+    return out
+
+
 def sky_luts(seed=7):
     """Stand-in LUT contents (the LUT generators are a 'next' row): smooth positive RGBA16F fields."""
     g = rng(seed)

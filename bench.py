@@ -31,6 +31,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # BASELINE.json configs[1..4] plus diagnostics.  The headline (`metric`) is 4k_deferred_gi.
 WORKLOADS = {
     "4k_deferred_gi": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv"),
+    "4k_deferred_gi_scene_shadow": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", shadow="scene"),  # CSM ray-cast from the atrium
     "4k_deferred_gi_random": dict(res=(3840, 2160), gbuffer="random", sun="csm", gi="lpv"),
     "4k_deferred_only": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none"),
     "1080p_deferred_gi": dict(res=(1920, 1080), gbuffer="atrium", sun="csm", gi="lpv"),
@@ -84,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="4k_deferred_gi", choices=sorted(WORKLOADS))
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the (one-rank) all-gather path anyway (rehearsal of the N>1 loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
@@ -130,7 +132,7 @@ def main():
     if n_lights:
         lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, wl["radius"], seed=8)
     fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
-                              synth_device=str(dev))
+                              synth_device=str(dev), shadow=wl.get("shadow", "noise"))
     d_arr = fr.device_arrays(dev)
     bytes_per_pixel = fr.bytes_per_pixel()
 
@@ -145,7 +147,7 @@ def main():
     gather = use_dist and not args.no_gather
     # N > 1: two lit targets, so that the all-gather of frame i (RCCL's own stream) overlaps the shading of frame i + 1; a target is
     # reused only after its gather has completed (stream-level wait).  Every gather finishes inside the timed region.
-    nbuf = 2 if (gather and not chain) else 1
+    nbuf = 2 if (gather and not chain and not args.no_overlap) else 1
     shard_bytes = rows_per * W * 8
     bufs = []
     for _ in range(nbuf):
@@ -264,6 +266,7 @@ def main():
                 "gbuffer": wl["gbuffer"],
                 "parallelism": "row-shard x%d + RCCL all-gather of lit rows" % world if world > 1 else "single GPU",
                 "gather": bool(gather),
+                "gather_overlapped_with_next_frame": bool(gather and nbuf > 1),
             },
             "roofline": {
                 "bound": "hbm",

@@ -40,6 +40,19 @@ def test_lighting_atrium_lpv(hip_ctx, sun_mode):
     _check(f, hip_ctx, f"atrium sun={sun_mode} lpv")
 
 
+@pytest.mark.parametrize("gi", [_abi.GI_NONE, _abi.GI_LPV])
+def test_lighting_atrium_with_its_own_shadow_map(hip_ctx, gi):
+    """Shadow map ray-cast from the atrium's boxes (synth.atrium_shadowmap): large coherent lit / shadowed regions, so whole
+    waves take the 'no lane is lit and unshadowed' exit that random depth noise never triggers."""
+    f = util.LightingFrame(320, 180, seed=6, sun_mode=_abi.SHADOW_MODE_CSM, gi=gi, flavour="atrium", shadowmap_res=512, shadow="scene")
+    _check(f, hip_ctx, f"atrium + scene shadow map gi={gi}")
+    lit = f.run_oracle().view(np.float16).astype(np.float32)[..., :3].sum(-1)
+    surf = (f.arrays["depth"] != 0) & (f.arrays["emission"][..., :3].sum(-1) == 0)
+    if gi == _abi.GI_NONE:
+        frac = float((lit[surf] > 0).mean())
+        assert 0.05 < frac < 0.6, frac  # some of the atrium is in the sun, most of it is not
+
+
 def test_lighting_ragged_width(hip_ctx):
     # width not a multiple of 4: scalar path
     f = util.LightingFrame(131, 37, seed=3, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV)
