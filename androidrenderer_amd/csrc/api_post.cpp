@@ -14,6 +14,7 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+hipError_t launch_sky_luts(const PlaneArg& transmittance, const PlaneArg& multiscattering, const PlaneArg& sky_view, const float light_vector[3], hipStream_t st);
 hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st);
 hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
 hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, hipStream_t st);
@@ -159,6 +160,17 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, ctx->stream));
         else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, ctx->stream));
     }
+    return SAH_OK;
+}
+
+int sah_sky_update_luts(sah_ctx* ctx, const sah_plane* transmittance, const sah_plane* multiscattering, const sah_plane* sky_view,
+                        const float light_vector[3]) {
+    if (!ctx || !light_vector) return SAH_ERR_INVALID_ARGUMENT;
+    auto ok = [](const sah_plane* p, uint32_t w, uint32_t h) { return rgba16f_ok(p) && p->width == w && p->height == h; };
+    if (!ok(transmittance, 256, 64) || !ok(multiscattering, 32, 32) || !ok(sky_view, 200, 200))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "sky LUTs must be RGBA16F 256x64 (transmittance), 32x32 (multiple scattering), 200x200 (sky view)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_sky_luts(parg(transmittance), parg(multiscattering), parg(sky_view), light_vector, ctx->stream));
     return SAH_OK;
 }
 

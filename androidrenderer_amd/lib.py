@@ -22,7 +22,7 @@ _lib = None
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
-           "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_allgather_rows"]
+           "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_allgather_rows"]
 
 
 def load():
@@ -53,6 +53,7 @@ def load():
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
     lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32]
     lib.sah_ao_clear.argtypes = [C.c_void_p, C.POINTER(_abi.Plane)]
+    lib.sah_sky_update_luts.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(C.c_float)]
     lib.sah_probe_copy.argtypes =[C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
     lib.sah_probe_update.argtypes = [C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -112,6 +113,10 @@ class Context:
         a = (_abi.Volume * 3)(*a_rgb)
         b = (_abi.Volume * 3)(*b_rgb)
         self._check(self.lib.sah_lpv_propagate(self.handle, a, b, num_cascades, steps))
+
+    def sky_update_luts(self, transmittance, multiscattering, sky_view, light_vector):
+        lv = (C.c_float * 3)(*[float(v) for v in light_vector])
+        self._check(self.lib.sah_sky_update_luts(self.handle, C.byref(transmittance), C.byref(multiscattering), C.byref(sky_view), lv))
 
     def ao_clear(self, ao):
         self._check(self.lib.sah_ao_clear(self.handle, C.byref(ao)))

@@ -248,6 +248,13 @@ int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, 
 int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades,
                       uint32_t steps);
 
+/* ProceduralSky::update_sky_luts — RenderCore/render/procedural_sky.cpp:75-149: transmittance (256x64), multiple-scattering (32x32)
+ * and sky-view (200x200) LUTs, all R16G16B16A16_SFLOAT, generated in that order (shaders/sky/{transmittance,multiscattering,
+ * sky_view}_lut.comp); light_vector is the sky-view push constant (the direction the sun light travels).  The transmittance and
+ * sky-view LUTs are the `sky` inputs of sah_lighting. */
+int sah_sky_update_luts(sah_ctx* ctx, const sah_plane* transmittance, const sah_plane* multiscattering, const sah_plane* sky_view,
+                        const float light_vector[3]);
+
 /* AmbientOcclusionPhase::generate_ao with r.AO.Mode = Off — RenderCore/render/phase/ambient_occlusion_phase.cpp:167-179: the AO
  * target (R32_SFLOAT) is cleared to 1.0.  RTAO / CACAO need the scene BVH and stay in the renderer; their output is the `ao` input
  * plane of sah_lighting. */

@@ -246,8 +246,20 @@ private:
     sah_sun_light_constants constants{};
 };
 
-struct ProceduralSky {  // RenderCore/render/procedural_sky.hpp — only what the sky fill reads
-    TextureHandle transmittance_lut = nullptr, sky_view_lut = nullptr;
+// RenderCore/render/procedural_sky.{hpp,cpp}: LUT allocation :31-60, update_sky_luts :75-149; the sky fill reads two of the LUTs
+struct ProceduralSky {
+    TextureHandle transmittance_lut = nullptr, multiscattering_lut = nullptr, sky_view_lut = nullptr;
+    void create_luts(ResourceAllocator& alloc) {
+        transmittance_lut = alloc.create_texture("Transmittance LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 256, 64);
+        multiscattering_lut = alloc.create_texture("Multiscattering LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 32, 32);
+        sky_view_lut = alloc.create_texture("Sky view LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 200, 200);
+    }
+    void update_sky_luts(RenderGraph& graph, const Vec3& light_vector) const {
+        graph.add_pass({"Update sky LUTs", [this, light_vector](sah_ctx* ctx) {
+                            const sah_plane t = transmittance_lut->plane(), m = multiscattering_lut->plane(), s = sky_view_lut->plane();
+                            return sah_sky_update_luts(ctx, &t, &m, &s, light_vector.data());
+                        }});
+    }
 };
 
 struct RenderScene {  // the slice of RenderCore/render/render_scene.hpp the hot path touches

@@ -54,7 +54,8 @@ def oracle():
     o.orc_sample_trilinear.argtypes = [C.POINTER(_abi.Volume), C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]
     o.orc_sample_shadow.argtypes = [C.POINTER(_abi.Volume), C.c_float, C.c_float, C.c_int, C.c_float]
     o.orc_sample_shadow.restype = C.c_float
-    o.orc_dir_to_sh.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    o.orc_sky_update_luts.argtypes = [C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(C.c_float)]
+    o.orc_dir_to_sh.argtypes =[C.POINTER(C.c_float), C.POINTER(C.c_float)]
     o.orc_octahedral_coordinates.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
     o.orc_probe_uv.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
     o.orc_octahedral_direction_of_texel.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]

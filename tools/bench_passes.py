@@ -104,6 +104,23 @@ def main():
     bv = [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in b_t]
     timeit("lpv propagate x32", lambda: ctx.lpv_propagate(av, bv, 4, 32), 32 * 6 * 1024 * 1024)
     timeit("lpv clear", lambda: ctx.lpv_clear(av[0], av[1], av[2], bv[0], 4), 4 * 1024 * 1024)
+
+    # ---- probe maintenance (a11) and sky LUTs (f3): tiny, launch bound -------------------------------------------------------
+    if wanted("probe copy") or wanted("probe update x256"):
+        atl, trace, ids = synth.probe_maintenance_inputs(seed=12, num_probes=256)
+        a_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in atl.items()}
+        b_t = {k: torch.zeros_like(v) for k, v in a_t.items()}
+        a_d, b_d = util.probe_atlases_desc(a_t), util.probe_atlases_desc(b_t)
+        tr_t = util.to_torch(trace.view(np.uint16))
+        ids_t = torch.from_numpy(ids.view(np.int32)).cuda()
+        tv = images.volume(tr_t, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        atlas_bytes = sum(int(v.numel() * v.element_size()) for v in a_t.values())
+        timeit("probe copy (5 atlases)", lambda: ctx.probe_copy(a_d, b_d, [[1, 0, 0], [0, 1, 0], [0, 0, -1], [0, 0, 0]]), 2 * atlas_bytes)
+        timeit("probe update x256", lambda: ctx.probe_update(a_d, tv, ids_t.data_ptr(), 256), 256 * 20 * 20 * 8)
+    if wanted("sky LUT update"):
+        luts = [torch.zeros(shape, dtype=torch.int16, device="cuda") for shape in ((64, 256, 4), (32, 32, 4), (200, 200, 4))]
+        lp = [images.plane(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in luts]
+        timeit("sky LUT update (3 LUTs)", lambda: ctx.sky_update_luts(lp[0], lp[1], lp[2], (0.3, -0.8, 0.52)), (256 * 64 + 32 * 32 + 200 * 200) * 8)
     if args.json:
         print(json.dumps(results))
 
