@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
 
 // ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
 template <int SUN, int GI, int PPT>
+// (106 VGPRs at 4 px/thread = 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 36-44 bytes per lane and is 12-20 %
+// slower, measured.)
 __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const FastArgs f) {
     __shared__ __attribute__((aligned(16))) float s_lut[TAB_SIZE];
     s_lut[threadIdx.x] = a.luts[threadIdx.x];

@@ -4,7 +4,5 @@
 ARGS=$1; shift
 for n in "$@"; do
   if [ "$n" = base ]; then unset SAH_HIP_LIBRARY; else export SAH_HIP_LIBRARY=$PWD/build_ab/$n.so; fi
-  for p in 2 4; do
-    SAH_FORCE_PPT=$p python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline $ARGS | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n ppt $p', d['ms_per_step'], d['roofline']['kernel_ms_mean'])"
-  done
+  python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline $ARGS | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n', d['ms_per_step'], d['roofline']['kernel_ms_mean'], d['roofline']['kernel_ms_min'])"
 done
