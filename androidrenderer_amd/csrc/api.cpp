@@ -374,7 +374,10 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         auto bytes = [](const sah_volume& v) { return (uint64_t)v.slice_pitch_bytes * v.depth; };
         cache.hot_ok = bytes(gi.probe_irradiance) < (1ull << 32) && bytes(gi.probe_depth) < (1ull << 32) && bytes(gi.probe_validity) < (1ull << 32) &&
                        gi.probe_validity.width <= 64 && gi.probe_validity.height <= 64 && gi.probe_validity.depth <= 64 &&
-                       gi.probe_size[0] >= 1 && gi.probe_size[0] <= 30 && gi.probe_size[1] >= 1 && gi.probe_size[1] <= 30;
+                       gi.probe_size[0] >= 1 && gi.probe_size[0] <= 30 && gi.probe_size[1] >= 1 && gi.probe_size[1] <= 30 &&
+                       // atlases exactly 32 blocks wide, as get_probe_uv assumes: texcoords then never reach the REPEAT seam
+                       gi.probe_irradiance.width == 32u * (gi.probe_size[0] + 2u) && gi.probe_irradiance.height == 32u * (gi.probe_size[1] + 2u) &&
+                       gi.probe_depth.width == 32u * 12u && gi.probe_depth.height == 32u * 12u;
     } else if (gi_kind == SAH_GI_RTGI) {
         const sah_gi& gi = *d->gi;
         if (!plane_ok(&gi.ray_buffer, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H) ||

@@ -97,10 +97,6 @@ SAH_DEV void tri_accumulate(const VolumeArg& v, const TriSetup& s, float (&out)[
         for (int c = 0; c < 4; c++) out[c] = __builtin_fmaf(s.w[k], (float)t[k][c], out[c]);
     }
 }
-SAH_DEV void sample_trilinear_border(const VolumeArg& v, float u, float vv, float w, float (&out)[4]) {
-    const TriSetup s = tri_setup(v.width, v.height, v.depth, u, vv, w);
-    tri_accumulate(v, s, out);
-}
 
 // 2D RGBA16F, linear, REPEAT (sky LUTs: RenderCore/render/procedural_sky.cpp:62-68)
 SAH_DEV void sample_bilinear_repeat_rgba16f(const PlaneArg& p, uint32_t W, uint32_t H, float u, float v, float (&out)[4]) {
@@ -350,53 +346,6 @@ SAH_DEV void lpv_fetch_packed(const LpvArgs& L, const uint8_t* packed, uint32_t 
             a[1] = fma_mix_hi(wt[k], lo, a[1]);
             a[2] = fma_mix_lo(wt[k], hi, a[2]);
             a[3] = fma_mix_hi(wt[k], hi, a[3]);
-        }
-        out[c] = dot4(a, n);
-    }
-}
-
-// Fast-path variant of lpv_fetch for FINITE coordinates and FINITE volume contents: taps outside the volume keep an
-// in-bounds (clamped) address and get a zero weight factor instead of a zero texel — fma(0, t, acc) == fma(w, 0, acc) == acc
-// for finite t, w (DESIGN.md "Fast path proofs") — so the eight loads per volume are unconditional.
-SAH_DEV void lpv_fetch_fast(const LpvArgs& L, float u, float v, float w, const Fn (&n)[4], Fn (&out)[3]) {
-    const int W = (int)L.red.width, H = (int)L.red.height, D = (int)L.red.depth;
-    const float px = u * (float)W - 0.5f, py = v * (float)H - 0.5f, pz = w * (float)D - 0.5f;
-    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py), fz0 = __builtin_floorf(pz);
-    const float fx = px - fx0, fy = py - fy0, fz = pz - fz0;
-    const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0), z0 = clamp_to_int(fz0);
-    const float ax0 = ((unsigned)x0 < (unsigned)W) ? 1.0f - fx : 0.f, ax1 = ((unsigned)(x0 + 1) < (unsigned)W) ? fx : 0.f;
-    const float ay0 = ((unsigned)y0 < (unsigned)H) ? 1.0f - fy : 0.f, ay1 = ((unsigned)(y0 + 1) < (unsigned)H) ? fy : 0.f;
-    const float az0 = ((unsigned)z0 < (unsigned)D) ? 1.0f - fz : 0.f, az1 = ((unsigned)(z0 + 1) < (unsigned)D) ? fz : 0.f;
-    const uint32_t xo[2] = {(uint32_t)min(max(x0, 0), W - 1) * 8u, (uint32_t)min(max(x0 + 1, 0), W - 1) * 8u};
-    const uint32_t yo[2] = {(uint32_t)min(max(y0, 0), H - 1) * L.red.row_pitch, (uint32_t)min(max(y0 + 1, 0), H - 1) * L.red.row_pitch};
-    const uint32_t zo[2] = {(uint32_t)min(max(z0, 0), D - 1) * L.red.slice_pitch, (uint32_t)min(max(z0 + 1, 0), D - 1) * L.red.slice_pitch};
-    const float wxy[4] = {ax0 * ay0, ax1 * ay0, ax0 * ay1, ax1 * ay1};
-    float wt[8];
-    uint32_t off[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        wt[k] = wxy[k & 3] * ((k >> 2) ? az1 : az0);
-        off[k] = zo[k >> 2] + yo[(k >> 1) & 1] + xo[k & 1];
-#ifdef SAH_EXP_UNIFORM_GATHER  // experiment: same VALU work, every lane reads texel 0 (isolates the cost of divergent gathers)
-        off[k] = off[k] & 0u;
-#endif
-    }
-    const uint8_t* vols[3] = {L.red.ptr, L.green.ptr, L.blue.ptr};
-    uint2 t[3][8];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) t[c][k] = *reinterpret_cast<const uint2*>(vols[c] + off[k]);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            a[0] = fma_mix_lo(wt[k], t[c][k].x, a[0]);
-            a[1] = fma_mix_hi(wt[k], t[c][k].x, a[1]);
-            a[2] = fma_mix_lo(wt[k], t[c][k].y, a[2]);
-            a[3] = fma_mix_hi(wt[k], t[c][k].y, a[3]);
         }
         out[c] = dot4(a, n);
     }

@@ -187,31 +187,32 @@ SAH_DEV void probe_uv_nr(const uint32_t (&idx)[3], F2 oct, uint32_t n0, uint32_t
     }
 }
 struct BilinearTaps {
-    uint32_t off[4];
+    uint32_t row0, row1;  // byte offsets of texel (x0, y0) and (x0, y0 + 1); texel (x0 + 1, .) follows at +4
     float w[4];
 };
-// 2D-array bilinear set-up, REPEAT, for u, v strictly inside (0, 1): floor(p) is in [-1, size - 1]
-SAH_DEV BilinearTaps bilinear_repeat_setup_inside(const VolumeArg& v, float u, float vv, int layer) {
+// 2D-array bilinear set-up for probe texcoords: u * width lies in [1, width - 1] (probe_uv_nr on an atlas that is exactly
+// 32 blocks wide: CacheArgs::hot_ok), so floor(u * width - 0.5) is in [0, width - 2] and REPEAT never wraps: the two taps of a row
+// are adjacent in memory and are fetched as one 8-byte load.  The clamp only matters for garbage coordinates of a pixel that is
+// being re-evaluated anyway (`bad`): it keeps every address inside the atlas, so the loads need no predicate.
+SAH_DEV BilinearTaps bilinear_setup_probe(const VolumeArg& v, float u, float vv, int layer) {
     const float px = u * (float)v.width - 0.5f, py = vv * (float)v.height - 0.5f;
     const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
     const float fx = px - fx0, fy = py - fy0;
     const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    int x0 = (int)fx0, y0 = (int)fy0;
-    x0 = x0 < 0 ? x0 + (int)v.width : x0;
-    y0 = y0 < 0 ? y0 + (int)v.height : y0;
-    const int x1 = x0 + 1 == (int)v.width ? 0 : x0 + 1, y1 = y0 + 1 == (int)v.height ? 0 : y0 + 1;
-    const uint32_t base = (uint32_t)layer * v.slice_pitch;  // atlases are < 4 GiB (host check)
-    const uint32_t r0 = base + (uint32_t)y0 * v.row_pitch, r1 = base + (uint32_t)y1 * v.row_pitch;
+    const int x0 = min(max(clamp_to_int(fx0), 0), (int)v.width - 2), y0 = min(max(clamp_to_int(fy0), 0), (int)v.height - 2);
     BilinearTaps t;
-    t.off[0] = r0 + (uint32_t)x0 * 4u;
-    t.off[1] = r0 + (uint32_t)x1 * 4u;
-    t.off[2] = r1 + (uint32_t)x0 * 4u;
-    t.off[3] = r1 + (uint32_t)x1 * 4u;
+    t.row0 = (uint32_t)layer * v.slice_pitch + (uint32_t)y0 * v.row_pitch + (uint32_t)x0 * 4u;  // atlases are < 4 GiB (host check)
+    t.row1 = t.row0 + v.row_pitch;
     t.w[0] = wx0 * wy0;
     t.w[1] = fx * wy0;
     t.w[2] = wx0 * fy;
     t.w[3] = fx * fy;
     return t;
+}
+SAH_DEV uint2 load_pair(const uint8_t* base, uint32_t off) {  // 4-byte aligned, 8 bytes
+    uint2 q;
+    __builtin_memcpy(&q, base + off, 8);
+    return q;
 }
 // octahedral_coordinates() with the reciprocal of the L1 norm from rcp_nr; `bad` when the norm is outside its domain
 SAH_DEV F2 octahedral_coordinates_nr(F3 dir, bool& bad) {
@@ -262,13 +263,14 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const F2 depth_oct = octahedral_coordinates_nr(-dir_to_probe, pbad);
         float duv[2];
         probe_uv_nr(pidx, depth_oct, 10u, 10u, duv);
-        const BilinearTaps dtaps = bilinear_repeat_setup_inside(c.depth, duv[0], duv[1], array_layer((float)pidx[2], c.depth.depth));
+        const BilinearTaps dtaps = bilinear_setup_probe(c.depth, duv[0], duv[1], array_layer((float)pidx[2], c.depth.depth));
+        const uint2 d0 = load_pair(c.depth.ptr, dtaps.row0), d1 = load_pair(c.depth.ptr, dtaps.row1);
+        const uint32_t dw[4] = {d0.x, d0.y, d1.x, d1.y};  // tap order (x0,y0) (x1,y0) (x0,y1) (x1,y1)
         float dt0 = 0.f, dt1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t wrd = pbad ? 0u : *reinterpret_cast<const uint32_t*>(c.depth.ptr + dtaps.off[k]);  // addresses are only valid when !pbad
-            dt0 = fma_mix_lo(dtaps.w[k], wrd, dt0);
-            dt1 = fma_mix_hi(dtaps.w[k], wrd, dt1);
+            dt0 = fma_mix_lo(dtaps.w[k], dw[k], dt0);
+            dt1 = fma_mix_hi(dtaps.w[k], dw[k], dt1);
         }
         const Hn dx = Hn(dt0), dy = Hn(dt1);  // Sampler2DArray<half2>
         const Fn variance = Fn(tof(nabs(dx * dx - dy)));
@@ -288,11 +290,13 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
 
         float iuv[2];
         probe_uv_nr(pidx, irr_oct, c.probe_size[0], c.probe_size[1], iuv);
-        const BilinearTaps itaps = bilinear_repeat_setup_inside(c.irradiance, iuv[0], iuv[1], array_layer((float)pidx[2], c.irradiance.depth));
+        const BilinearTaps itaps = bilinear_setup_probe(c.irradiance, iuv[0], iuv[1], array_layer((float)pidx[2], c.irradiance.depth));
+        const uint2 i0 = load_pair(c.irradiance.ptr, itaps.row0), i1 = load_pair(c.irradiance.ptr, itaps.row1);
+        const uint32_t iw[4] = {i0.x, i0.y, i1.x, i1.y};
         float ir = 0.f, ig = 0.f, ib = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t wrd = irr_oct_ok ? *reinterpret_cast<const uint32_t*>(c.irradiance.ptr + itaps.off[k]) : 0u;
+            const uint32_t wrd = iw[k];
             const uint32_t rg = ((wrd << 4) & 0x7ff0u) | ((wrd << 9) & 0x7ff00000u);  // fp16(R) | fp16(G) << 16
             const uint32_t bb = (wrd >> 17) & 0x7fe0u;                                // fp16(B)
             ir = fma_mix_lo(itaps.w[k], rg, ir);
