@@ -402,6 +402,41 @@ private:
     uint32_t num_probes = 0;
 };
 
+// RenderCore/render/gi/rtgi.{hpp,cpp}: the ray-traced passes (ray generation, hit shading) stay in the renderer; their two
+// per-pixel outputs — ray direction + distance, ray irradiance — are what the reconstruction overlay (rtgi.cpp:160-188,
+// gi/rtgi/overlay.frag.slang:68-117) binds.  It owns an IrradianceCache, as the reference does (rtgi.hpp: irradiance_cache).
+class RayTracedGlobalIllumination : public IGlobalIlluminator {
+public:
+    explicit RayTracedGlobalIllumination(RenderBackend& backend) : cache(backend) {}
+    void set_ray_textures(TextureHandle ray_texture_in, TextureHandle ray_irradiance_in) {
+        ray_texture = ray_texture_in;
+        ray_irradiance = ray_irradiance_in;
+    }
+    void set_reconstruction(uint32_t num_samples, float size) {  // r.GI.Reconstruction.NumSamples / .Size
+        num_extra_rays = num_samples;
+        extra_ray_radius = size;
+    }
+    IrradianceCache& get_irradiance_cache() { return cache; }
+    void pre_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, TextureHandle noise_tex) override {
+        cache.pre_render(graph, view, scene, noise_tex);  // rtgi.cpp:60-75: the cache updates first
+    }
+    void post_render(RenderGraph&, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {}
+    void render_to_lit_scene(sah_gi& gi, TextureHandle, TextureHandle noise_tex) const override {
+        gi.kind = SAH_GI_RTGI;
+        gi.ray_buffer = ray_texture->plane();
+        gi.ray_irradiance = ray_irradiance->plane();
+        if (noise_tex) gi.noise = noise_tex->plane();
+        gi.num_extra_rays = noise_tex ? num_extra_rays : 0;
+        gi.extra_ray_radius = extra_ray_radius;
+    }
+
+private:
+    IrradianceCache cache;
+    TextureHandle ray_texture{}, ray_irradiance{};
+    uint32_t num_extra_rays = 0;
+    float extra_ray_radius = 16.f;
+};
+
 // RenderCore/render/phase/ambient_occlusion_phase.cpp:157-189.  Only r.AO.Mode = Off is on this side of the boundary (the target
 // is cleared to 1.0, :167-179); RTAO and CACAO need the BVH / the Vulkan SDK and hand their result over as the AO plane.
 class AmbientOcclusionPhase {
