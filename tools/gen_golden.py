@@ -279,6 +279,55 @@ class Frame:
     def emissive(self):
         return [F(e * f32(3.1415927)) for e in self.emis]
 
+    def rtgi_overlay(self):
+        """gi/rtgi/overlay.frag.slang:61-117 with num_extra_rays == 0: brdf(surface, ray dir, V) * ray irradiance * clamp(dir . N),
+        all in half precision; NaN -> 0; returns rgb (alpha of the fragment is 1)."""
+        _, ws = self.position(False)
+        view = np.array(self.view.view[:], dtype=f32)
+        cam = [F(-view[12 + i]) for i in range(3)]
+        Nh = normalize3([h(n) for n in self.nrm], h)
+        with np.errstate(invalid="ignore"):
+            V = [h(x) for x in normalize3([F(ws[i] - cam[i]) for i in range(3)])]
+        rb = self.f.arrays["ray_buffer"].astype(f32)
+        ri = self.f.arrays["ray_irr"].astype(f32)
+        d = [rb[..., i] for i in range(3)]
+        irr = [ri[..., i] for i in range(3)]
+        b = brdf([h(c) for c in self.base], Nh, h(self.rough), h(self.metal), d, V, h)
+        dn = h(h(h(d[0] * Nh[0]) + h(d[1] * Nh[1])) + h(d[2] * Nh[2]))
+        ndotl = h(clamp01(dn))
+        rad = [h(h(b[i] * irr[i]) * ndotl) for i in range(3)]
+        bad = np.isnan(rad[0]) | np.isnan(rad[1]) | np.isnan(rad[2])
+        return [np.where(bad, f32(0), h(r / f32(1))) for r in rad]
+
+    def point_lights(self, lights):
+        """Extension a9: fp32, lights in index order, NaN terms dropped, sum * 0.00031415927."""
+        _, ws = self.position(True)
+        view = np.array(self.view.view[:], dtype=f32)
+        cam = [F(-view[12 + i]) for i in range(3)]
+        N = normalize3(self.nrm)
+        with np.errstate(invalid="ignore"):
+            V = normalize3([F(ws[i] - cam[i]) for i in range(3)])
+        total = [np.zeros(self.depth.shape, dtype=f32) for _ in range(3)]
+        for pl in np.asarray(lights, dtype=f32):
+            with np.errstate(all="ignore"):
+                lv = [F(pl[i] - ws[i]) for i in range(3)]
+                d2 = dot3_r(lv, lv)
+                inv = F(f32(1) / F(np.sqrt(d2)))
+                L = [F(lv[i] * inv) for i in range(3)]
+                dist = F(np.sqrt(d2))
+                ndotl = clamp01(dot3_r(N, L))
+                xr = F(dist / pl[3])
+                x2 = F(xr * xr)
+                x4 = F(x2 * x2)
+                w = clamp01(F(f32(1) - x4))
+                att = F(F(w * w) / np.maximum(d2, f32(1e-4)))
+                b = brdf(self.base, N, self.rough, self.metal, L, V)
+                k = F(pl[7] * att)
+                c = [F(F(F(ndotl * b[i]) * pl[4 + i]) * k) for i in range(3)]
+            bad = np.isnan(c[0]) | np.isnan(c[1]) | np.isnan(c[2])
+            total = [F(total[i] + np.where(bad, f32(0), c[i])) for i in range(3)]
+        return [F(t * f32(0.00031415927)) for t in total]
+
 
 def dot3_r(a, b):
     return F(F(F(a[0] * b[0]) + F(a[1] * b[1])) + F(a[2] * b[2]))
@@ -298,7 +347,7 @@ def brdf_fd_nn(base, n, rough, metal):
     return [F(d * fdv) for d in diff]
 
 
-def compose(fr, sun_mode, gi):
+def compose(fr, sun_mode, gi, lights=None):
     """lighting_phase.cpp:99-134 with the RGBA16F blend roundings."""
     surf = fr.depth != 0
     lit = [np.zeros(fr.depth.shape, dtype=f32) for _ in range(4)]
@@ -307,8 +356,13 @@ def compose(fr, sun_mode, gi):
         for i in range(3):
             lit[i] = np.where(surf, h(F(F(s[i] * s[i]) + F(lit[i] * lit[i]))), lit[i])  # SRC_COLOR / DST_COLOR blend
         # alpha factors ZERO/ZERO: stays 0
-    if gi == _abi.GI_LPV:
-        g = fr.lpv_overlay()
+    if lights is not None:  # extension a9: additive, after the CSM sun, before the GI overlay
+        pl = fr.point_lights(lights)
+        for i in range(3):
+            lit[i] = np.where(surf, h(F(lit[i] + pl[i])), lit[i])
+        lit[3] = np.where(surf, h(F(lit[3] + f32(1))), lit[3])
+    if gi in (_abi.GI_LPV, _abi.GI_RTGI):
+        g = fr.lpv_overlay() if gi == _abi.GI_LPV else fr.rtgi_overlay()
         for i in range(3):
             lit[i] = np.where(surf, h(F(lit[i] + g[i])), lit[i])
         lit[3] = np.where(surf, h(F(lit[3] + f32(1))), lit[3])
@@ -388,6 +442,87 @@ def tonemap(scene_bits, mips_bits, ow, oh):
     return out
 
 
+def copy_scene(lit_bits):
+    """util/copy_with_sampler.frag.slang:9-12 as drawn by scene_renderer.cpp:502-527: antialiased = bilinear (REPEAT) sample of
+    lit_scene at SV_Position.xy * (1/W, 1/H); all four channels."""
+    img = lit_bits.view(np.float16).astype(f32)
+    Hh, W = img.shape[:2]
+    ys, xs = np.meshgrid(np.arange(Hh, dtype=f32), np.arange(W, dtype=f32), indexing="ij")
+    u, v = F(F(xs + f32(0.5)) * F(f32(1) / f32(W))), F(F(ys + f32(0.5)) * F(f32(1) / f32(Hh)))
+    x0, wx0, fx = axis(u, W)
+    y0, wy0, fy = axis(v, Hh)
+    acc = np.zeros(img.shape, dtype=f32)
+    for (dy, dx, w) in ((0, 0, F(wx0 * wy0)), (0, 1, F(fx * wy0)), (1, 0, F(wx0 * fy)), (1, 1, F(fx * fy))):
+        acc = fma(w[..., None], img[(y0 + dy) % Hh, (x0 + dx) % W], acc)
+    with np.errstate(over="ignore"):
+        return acc.astype(np.float16).view(np.uint16)
+
+
+def lpv_propagate(vols, steps, num_cascades=1):
+    """gi/lpv/lpv_propagate.comp.slang:76-156 in half precision (numpy float16 arithmetic rounds after every operator), use_gv = false.
+    vols: three (32, 32, 32 * num_cascades, 4) float16 arrays [z][y][x][c]; returns the three arrays after `steps` ping-pong steps."""
+    hf = np.float16
+    orient = np.array([[1, 0, 0, 0, 1, 0, 0, 0, 1], [-1, 0, 0, 0, 1, 0, 0, 0, -1], [0, 0, 1, 0, 1, 0, -1, 0, 0], [0, 0, -1, 0, 1, 0, 1, 0, 0],
+                       [1, 0, 0, 0, 0, 1, 0, -1, 0], [1, 0, 0, 0, 0, -1, 0, 1, 0]], dtype=np.float32).reshape(6, 3, 3)
+    dirs = np.array([[0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0]], dtype=np.int64)
+    sides = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]], dtype=np.float32)
+
+    def hmul33(M, v):  # half3 = mul(half3x3, half3): products and sums in half, left to right
+        M = M.astype(hf)
+        return [hf(hf(hf(M[r, 0] * v[0]) + hf(M[r, 1] * v[1])) + hf(M[r, 2] * v[2])) for r in range(3)]
+
+    def sh(d):  # float literal * half -> float, rounded by the half4 constructor
+        return [hf(0.282094792), hf(f32(-0.488602512) * f32(d[1])), hf(f32(0.488602512) * f32(d[2])), hf(f32(-0.488602512) * f32(d[0]))]
+
+    def lobe(d):
+        return [hf(0.886226925), hf(f32(-1.02332671) * f32(d[1])), hf(f32(1.02332671) * f32(d[2])), hf(f32(-1.02332671) * f32(d[0]))]
+
+    small, big = hf(0.4472135), hf(0.894427)
+    direct_sa = hf(f32(hf(0.4006696846)) / f32(3.1415927))
+    side_sa = hf(f32(hf(0.4234413544)) / f32(3.1415927))
+    W = 32 * num_cascades
+    cur = [v.copy() for v in vols]
+    for _ in range(steps):
+        nxt = []
+        for vol in cur:
+            acc = np.zeros((32, 32, W, 4), dtype=hf)
+            for n in range(6):
+                dx, dy, dz = (int(t) for t in dirs[n])
+                # neighbour cell = cell - dir; cells whose neighbour index leaves [-1, 31] (per cascade, asymmetric) are skipped;
+                # index -1 in x reads the previous cascade's last column (or zero at the volume edge), other out-of-range reads are zero
+                coef = np.zeros((32, 32, W, 4), dtype=hf)
+                skip = np.zeros((32, 32, W), dtype=bool)
+                zs, ys, xs = np.meshgrid(np.arange(32), np.arange(32), np.arange(W), indexing="ij")
+                cx = xs % 32
+                nx, ny, nz = cx - dx, ys - dy, zs - dz
+                skip = (nx < -1) | (ny < -1) | (nz < -1) | (nx > 31) | (ny > 31) | (nz > 31)
+                gx = nx + (xs - cx)
+                ok = (~skip) & (gx >= 0) & (gx < W) & (ny >= 0) & (ny < 32) & (nz >= 0) & (nz < 32)
+                coef[ok] = vol[nz[ok], ny[ok], gx[ok]]
+                with np.errstate(all="ignore"):
+                    for s in range(4):
+                        e = hmul33(orient[n], [hf(hf(sides[s, 0]) * small), hf(hf(sides[s, 1]) * small), big])
+                        r = hmul33(orient[n], [hf(sides[s, 0]), hf(sides[s, 1]), hf(0)])
+                        es, rl = sh(e), lobe(r)
+                        dot = hf(hf(hf(coef[..., 0] * es[0]) + hf(coef[..., 1] * es[1])) + hf(coef[..., 2] * es[2]))
+                        dot = hf(dot + hf(coef[..., 3] * es[3]))
+                        m = np.maximum(hf(0), dot)
+                        k = hf(side_sa * m)
+                        add = np.stack([hf(hf(k * rl[c]) * hf(1)) for c in range(4)], axis=-1)
+                        acc = np.where(skip[..., None], acc, hf(acc + add))
+                    c = [hf(t) for t in dirs[n]]
+                    cs, cl = sh(c), lobe(c)
+                    dot = hf(hf(hf(coef[..., 0] * cs[0]) + hf(coef[..., 1] * cs[1])) + hf(coef[..., 2] * cs[2]))
+                    dot = hf(dot + hf(coef[..., 3] * cs[3]))
+                    m = np.maximum(hf(0), dot)
+                    k = hf(direct_sa * m)
+                    add = np.stack([hf(hf(k * cl[ch]) * hf(1)) for ch in range(4)], axis=-1)
+                    acc = np.where(skip[..., None], acc, hf(acc + add))
+            nxt.append(acc)
+        cur = nxt
+    return cur
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -406,6 +541,34 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, f"{name}_{W}x{Hh}.npz"), lit=lit, seed=seed, sun_mode=sun_mode, gi=gi,
                             inputs_sha256=inputs_digest(fr.f.arrays))
         print(name, "ok", lit.shape)
+    # RT sun + RTGI reconstruction (a1b + a5), CSM sun + 12 point lights (a1 + a9)
+    fr = Frame(W, Hh, 105, _abi.SHADOW_MODE_RT, _abi.GI_RTGI)
+    lit = compose(fr, _abi.SHADOW_MODE_RT, _abi.GI_RTGI)
+    np.savez_compressed(os.path.join(GOLDEN, f"lighting_rt_rtgi_{W}x{Hh}.npz"), lit=lit, seed=105, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_RTGI,
+                        inputs_sha256=inputs_digest(fr.f.arrays))
+    print("lighting_rt_rtgi ok")
+    fr = Frame(W, Hh, 106, _abi.SHADOW_MODE_CSM, _abi.GI_NONE)
+    lights = synth.point_lights(fr.f.view, 12, 6.0, seed=107)
+    lit = compose(fr, _abi.SHADOW_MODE_CSM, _abi.GI_NONE, lights=lights)
+    np.savez_compressed(os.path.join(GOLDEN, f"lighting_csm_lights_{W}x{Hh}.npz"), lit=lit, seed=106, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE,
+                        lights=lights, inputs_sha256=inputs_digest(fr.f.arrays))
+    print("lighting_csm_lights ok")
+    # copy scene (a13) of the CSM + LPV image
+    src = np.load(os.path.join(GOLDEN, f"lighting_csm_lpv_{W}x{Hh}.npz"))["lit"]
+    np.savez_compressed(os.path.join(GOLDEN, f"copy_scene_{W}x{Hh}.npz"), out=copy_scene(src))
+    print("copy_scene ok")
+    # LPV propagate (a10): two cascades, sparse injected light incl. cells on the cascade seam and the volume border, 3 steps
+    g = synth.rng(108)
+    vols = [np.zeros((32, 32, 64, 4), dtype=np.float16) for _ in range(3)]
+    cells = [(0, 0, 0), (31, 31, 63), (5, 7, 31), (5, 7, 32), (16, 0, 40), (0, 16, 33)] + [tuple(int(t) for t in g.integers(0, (32, 32, 64))) for _ in range(40)]
+    for v in vols:
+        for (z, y, x) in cells:
+            v[z, y, x] = g.uniform(-1.0, 2.0, 4).astype(np.float16)
+    out = lpv_propagate(vols, steps=3, num_cascades=2)
+    np.savez_compressed(os.path.join(GOLDEN, "lpv_propagate_2c_3steps.npz"), **{f"in{i}": vols[i].view(np.uint16) for i in range(3)},
+                        **{f"out{i}": out[i].view(np.uint16) for i in range(3)})
+    print("lpv_propagate ok")
+
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
     for (mw, mh) in images.bloom_mip_sizes(W, Hh, 6):
