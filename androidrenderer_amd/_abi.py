@@ -45,6 +45,32 @@ class ProbeAtlases(C.Structure):  # sah_probe_atlases
     _fields_ = [("rtgi", Volume), ("light_cache", Volume), ("depth", Volume), ("average", Volume), ("validity", Volume)]
 
 
+PRIMITIVE_TYPE_SOLID, PRIMITIVE_TYPE_CUTOUT = 0, 1
+RASTER_STATS_WORDS = 8
+
+
+class VertexData(C.Structure):  # sah_vertex_data, 40 bytes
+    _fields_ = [("normal", C.c_float * 3), ("tangent", C.c_float * 4), ("texcoord", C.c_float * 2), ("color", C.c_uint32)]
+
+
+class Material(C.Structure):  # sah_material, 112 bytes
+    _fields_ = [("base_color_tint", C.c_float * 4), ("emission_factor", C.c_float * 4), ("metalness_factor", C.c_float),
+                ("roughness_factor", C.c_float), ("opacity_threshold", C.c_float), ("padding1", C.c_float),
+                ("base_color_texel", C.c_float * 4), ("normal_texel", C.c_float * 4), ("data_texel", C.c_float * 4),
+                ("emission_texel", C.c_float * 4)]
+
+
+class Primitive(C.Structure):  # sah_primitive, 96 bytes
+    _fields_ = [("model", C.c_float * 16), ("first_index", C.c_uint32), ("index_count", C.c_uint32), ("vertex_offset", C.c_int32),
+                ("type", C.c_uint32), ("material", C.c_uint32), ("padding", C.c_uint32 * 3)]
+
+
+class SceneGeometry(C.Structure):  # sah_scene_geometry
+    _fields_ = [("vertex_positions", C.c_void_p), ("vertex_data", C.c_void_p), ("indices", C.c_void_p), ("primitives", C.c_void_p),
+                ("materials", C.c_void_p), ("num_vertices", C.c_uint32), ("num_indices", C.c_uint32), ("num_primitives", C.c_uint32),
+                ("num_materials", C.c_uint32)]
+
+
 class GBuffer(C.Structure):
     _fields_ = [("color", Plane), ("normals", Plane), ("data", Plane), ("emission", Plane), ("depth", Plane)]
 

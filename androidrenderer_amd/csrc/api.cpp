@@ -196,6 +196,10 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->list) (void)hipFree(ctx->list);
     if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
+    for (void* p : ctx->raster.ptr)
+        if (p) (void)hipFree(p);
+    if (ctx->raster.half_to_srgb8) (void)hipFree(ctx->raster.half_to_srgb8);
+    if (ctx->raster.host_counters) (void)hipHostFree(ctx->raster.host_counters);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

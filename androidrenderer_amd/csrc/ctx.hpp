@@ -26,6 +26,12 @@ struct sah_ctx {
     size_t lpv_packed_bytes = 0;
     uint32_t parity = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds (api_post.cpp)
+    struct RasterScratch {             // device buffers of the scene rasteriser, grown on demand (api_raster.cpp)
+        void* ptr[8] = {};
+        size_t bytes[8] = {};
+        uint8_t* half_to_srgb8 = nullptr;
+        uint32_t* host_counters = nullptr;  // pinned, 16 words
+    } raster;
     std::string last_error;
 };
 

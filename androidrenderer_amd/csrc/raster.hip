@@ -1,0 +1,518 @@
+// Scene rasterisation as compute: the sun shadow cascades and the depth + G-buffer pass.
+//   reference: RenderCore/render/directional_light.cpp:286-327, RenderCore/render/phase/gbuffer_phase.cpp:27-97,
+//              RenderCore/render/material_pipelines.cpp:13-62,104-140, RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253,
+//              RenderCore/render/render_scene.cpp:196-222 (cull mode / front face)
+// The reference uses the fixed-function rasteriser.  Here: a set-up kernel turns every (view, triangle) into window-space records
+// (vertex stage, Sutherland-Hodgman against the depth planes and a guard band, fan, 24.8 snapping, culling), the records are binned
+// to 64x64-pixel tiles (count, scan, fill), and one workgroup per tile resolves visibility in LDS with ds_min_u32 (D16 shadow maps)
+// or ds_max_u64 on (depth, ~draw order) keys (G-buffer), then shades and writes its tile once, coalesced.  Depth tests are
+// order-independent by construction, so the images do not depend on the (nondeterministic) order of the bin lists.  The
+// rasterisation rules — the part the API leaves to the implementation — are DESIGN.md §5d; arithmetic follows §3 (every fp32
+// operator individually rounded; half expressions rounded after every operator).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "numerics.hpp"
+#include "raster_args.hpp"
+
+namespace sah {
+namespace {
+
+constexpr int kTile = 64;               // pixels per tile edge
+constexpr float kGuardBand = 256.0f;    // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
+constexpr float kCoordLimit = 0x1p29f;  // snapped coordinates beyond this drop the triangle
+constexpr uint32_t kSmallArea = 16;     // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone
+
+enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_STATS = 4 };  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
+
+struct ClipVertex {
+    float c[4];
+    float bary[3];
+};
+
+SAH_DEV float mat_row(const float* m, int r, float x, float y, float z, float w) { return ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w; }
+SAH_DEV void mat_vec(const float* m, const float v[4], float out[4]) {
+    for (int r = 0; r < 4; r++) out[r] = mat_row(m, r, v[0], v[1], v[2], v[3]);
+}
+
+SAH_DEV float plane_distance(const ClipVertex& v, int plane) {
+    switch (plane) {
+        case 0: return v.c[2];
+        case 1: return v.c[3] - v.c[2];
+        case 2: return kGuardBand * v.c[3] - v.c[0];
+        case 3: return kGuardBand * v.c[3] + v.c[0];
+        case 4: return kGuardBand * v.c[3] - v.c[1];
+        default: return kGuardBand * v.c[3] + v.c[1];
+    }
+}
+SAH_DEV ClipVertex lerp_vertex(const ClipVertex& in, const ClipVertex& out, float d_in, float d_out) {
+    const float t = d_in / (d_in - d_out);
+    ClipVertex r;
+    for (int k = 0; k < 4; k++) r.c[k] = in.c[k] + (out.c[k] - in.c[k]) * t;
+    for (int k = 0; k < 3; k++) r.bary[k] = in.bary[k] + (out.bary[k] - in.bary[k]) * t;
+    return r;
+}
+// Sutherland-Hodgman in place (rare path: most triangles are inside every plane and skip it)
+__device__ __noinline__ int clip_polygon(ClipVertex* poly, int n, int first_plane) {
+    ClipVertex tmp[12];
+    for (int plane = first_plane; plane < 6 && n >= 3; plane++) {
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipVertex a = poly[i];
+            const ClipVertex b = poly[i + 1 == n ? 0 : i + 1];
+            const float da = plane_distance(a, plane), db = plane_distance(b, plane);
+            const bool ia = da >= 0.0f, ib = db >= 0.0f;
+            if (ia) tmp[m++] = a;
+            if (ia != ib) tmp[m++] = ia ? lerp_vertex(a, b, da, db) : lerp_vertex(b, a, db, da);
+        }
+        n = m;
+        for (int i = 0; i < n; i++) poly[i] = tmp[i];
+    }
+    return n < 3 ? 0 : n;
+}
+
+struct WindowVertex {
+    int32_t X, Y;
+    float z, inv_w;
+    float bary[3];
+    bool finite;
+};
+SAH_DEV bool is_finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
+SAH_DEV WindowVertex to_window(const ClipVertex& v, float half_w, float half_h) {
+    WindowVertex r;
+    const float xd = v.c[0] / v.c[3], yd = v.c[1] / v.c[3];
+    r.z = v.c[2] / v.c[3];
+    r.inv_w = 1.0f / v.c[3];
+    const float xf = xd * half_w + half_w, yf = yd * half_h + half_h;
+    const float sx = xf * 256.0f, sy = yf * 256.0f;
+    r.finite = is_finite(sx) && is_finite(sy) && is_finite(r.z) && is_finite(r.inv_w) && __builtin_fabsf(sx) <= kCoordLimit && __builtin_fabsf(sy) <= kCoordLimit;
+    r.X = r.finite ? (int32_t)__builtin_rintf(sx) : 0;
+    r.Y = r.finite ? (int32_t)__builtin_rintf(sy) : 0;
+    for (int k = 0; k < 3; k++) r.bary[k] = v.bary[k];
+    return r;
+}
+
+SAH_DEV int32_t first_px(int32_t lo) { const int32_t a = lo - 128; return a <= 0 ? 0 : (a + 255) >> 8; }
+SAH_DEV int32_t last_px(int32_t hi, uint32_t size) {
+    const int32_t a = hi - 128;
+    if (a < 0) return -1;
+    const int32_t p = a >> 8;
+    return p < (int32_t)size - 1 ? p : (int32_t)size - 1;
+}
+
+// ---- K0: exclusive scan (single workgroup, chunked) ------------------------------------------------------------------------------
+// mode 0: in[i] = primitives[i].index_count / 3; mode 1: in[i] = values[i]
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const sah_primitive* prims, const uint32_t* values, uint32_t n, uint32_t* out, uint32_t* total) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? (prims ? prims[i].index_count / 3u : values[i]) : 0u;
+        uint32_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0;
+        for (uint32_t w = 0; w < wave; w++) wave_base += s_wave[w];
+        const uint32_t carry = s_carry;
+        if (i < n) out[i] = carry + wave_base + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wave_base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+
+// ---- K1: vertex stage, clipping, fan, snapping, culling -> records ----------------------------------------------------------------
+SAH_DEV uint32_t find_primitive(const uint32_t* tri_base, uint32_t n, uint32_t t) {  // last p with tri_base[p] <= t
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tri_base[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool GBUFFER>
+__global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
+    const uint32_t total = a.counters[C_TRIS];
+    const uint64_t work = (uint64_t)total * a.num_views;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < work; w += (uint64_t)gridDim.x * 256) {
+        const uint32_t view = (uint32_t)(w / total), t = (uint32_t)(w % total);
+        const uint32_t p = find_primitive(a.tri_base, a.num_primitives, t);
+        const sah_primitive& prim = a.primitives[p];
+        const uint32_t tri = t - a.tri_base[p];
+        atomicAdd(&a.counters[C_STATS + 0], 1u);
+        ClipVertex poly[12];
+        bool finite = true, inside = true;
+        // a draw that points outside the index / vertex / material arrays is dropped, never dereferenced
+        bool in_range = (uint64_t)prim.first_index + 3ull * tri + 3ull <= a.num_indices && (!GBUFFER || prim.material < a.num_materials);
+        for (int k = 0; k < 3 && in_range; k++) {
+            const int64_t v = (int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k];
+            in_range = v >= 0 && v < (int64_t)a.num_vertices;
+        }
+        if (!in_range) { atomicAdd(&a.counters[C_STATS + 2], 1u); continue; }
+        for (int k = 0; k < 3; k++) {
+            const uint32_t idx = a.indices[prim.first_index + 3 * tri + k];
+            const float* pos = a.positions + 3 * ((int64_t)prim.vertex_offset + idx);
+            const float local[4] = {pos[0], pos[1], pos[2], 1.0f};
+            float world[4], clip[4];
+            mat_vec(prim.model, local, world);
+            if (GBUFFER) {
+                float vs[4];
+                mat_vec(a.view_matrix, world, vs);
+                mat_vec(a.clip_matrix[0], vs, clip);
+            } else {
+                mat_vec(a.clip_matrix[view], world, clip);
+            }
+            for (int j = 0; j < 4; j++) { poly[k].c[j] = clip[j]; finite = finite && is_finite(clip[j]); }
+            for (int j = 0; j < 3; j++) poly[k].bary[j] = j == k ? 1.0f : 0.0f;
+            for (int plane = GBUFFER ? 0 : 2; plane < 6; plane++) inside = inside && plane_distance(poly[k], plane) >= 0.0f;
+        }
+        if (!finite) { atomicAdd(&a.counters[C_STATS + 2], 1u); continue; }
+        int n = 3;
+        if (!inside) n = clip_polygon(poly, 3, GBUFFER ? 0 : 2);
+        if (n == 0) { atomicAdd(&a.counters[C_STATS + 1], 1u); continue; }
+        const bool cull_back = prim.type == SAH_PRIMITIVE_TYPE_SOLID;
+        const WindowVertex v0 = to_window(poly[0], a.half_w, a.half_h);
+        WindowVertex prev = to_window(poly[1], a.half_w, a.half_h);
+        for (int i = 1; i + 1 < n; i++) {
+            WindowVertex v1 = prev, v2 = to_window(poly[i + 1], a.half_w, a.half_h);
+            prev = v2;
+            if (!v0.finite || !v1.finite || !v2.finite) { atomicAdd(&a.counters[C_STATS + 2], 1u); continue; }
+            int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
+            if (area == 0 || (area < 0 && cull_back)) { atomicAdd(&a.counters[C_STATS + 1], 1u); continue; }
+            if (area < 0) { const WindowVertex s = v1; v1 = v2; v2 = s; }
+            const int32_t minx = min(v0.X, min(v1.X, v2.X)), maxx = max(v0.X, max(v1.X, v2.X));
+            const int32_t miny = min(v0.Y, min(v1.Y, v2.Y)), maxy = max(v0.Y, max(v1.Y, v2.Y));
+            const int32_t x0 = first_px(minx), x1 = last_px(maxx, a.width), y0 = first_px(miny), y1 = last_px(maxy, a.height);
+            if (x0 > x1 || y0 > y1) { atomicAdd(&a.counters[C_STATS + 1], 1u); continue; }
+            atomicAdd(&a.counters[C_STATS + 3], 1u);
+            const uint32_t r = atomicAdd(&a.counters[C_RECORDS], 1u);
+            if (r >= a.record_capacity) continue;  // the host sees the count, grows the buffer and runs the pass again
+            RasterRecord rec;
+            rec.X[0] = v0.X; rec.X[1] = v1.X; rec.X[2] = v2.X;
+            rec.Y[0] = v0.Y; rec.Y[1] = v1.Y; rec.Y[2] = v2.Y;
+            rec.z[0] = v0.z; rec.z[1] = v1.z; rec.z[2] = v2.z;
+            rec.view = view;
+            rec.x0 = (uint16_t)x0; rec.x1 = (uint16_t)x1; rec.y0 = (uint16_t)y0; rec.y1 = (uint16_t)y1;
+            a.records[r] = rec;
+            if (GBUFFER) {
+                RasterAttr at;
+                at.inv_w[0] = v0.inv_w; at.inv_w[1] = v1.inv_w; at.inv_w[2] = v2.inv_w;
+                for (int k = 0; k < 3; k++) { at.bary[0][k] = v0.bary[k]; at.bary[1][k] = v1.bary[k]; at.bary[2][k] = v2.bary[k]; }
+                at.primitive = p;
+                at.first_index = prim.first_index + 3 * tri;
+                at.seq = t * 8u + (uint32_t)(i - 1);
+                at.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
+                a.attrs[r] = at;
+            }
+        }
+    }
+}
+
+// ---- K2 / K4: binning -------------------------------------------------------------------------------------------------------------
+// One wave per 64 records.  A record that touches up to 4 tiles is binned by its own lane; wider ones are taken one at a time by the
+// whole wave (ballot + readlane), lanes striding over the tiles of the bounding box.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
+    const uint32_t nrec = min(a.counters[C_RECORDS], a.record_capacity);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * 4u;
+    for (uint32_t base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < nrec; base += waves * 64u) {
+        const uint32_t r = base + lane;
+        uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, view = 0;
+        if (r < nrec) {
+            const RasterRecord& rec = a.records[r];
+            tx0 = rec.x0 / kTile; tx1 = rec.x1 / kTile; ty0 = rec.y0 / kTile; ty1 = rec.y1 / kTile; view = rec.view;
+        }
+        const uint32_t ntiles = r < nrec ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
+        auto visit = [&](uint32_t tile, uint32_t rec_index) {
+            if (FILL) {
+                const uint32_t pos = atomicAdd(&a.tile_cursor[tile], 1u);
+                a.pairs[a.tile_offset[tile] + pos] = rec_index;
+            } else {
+                atomicAdd(&a.tile_count[tile], 1u);
+                atomicAdd(&a.counters[C_STATS + 4], 1u);
+            }
+        };
+        if (ntiles && ntiles <= 4)
+            for (uint32_t ty = ty0; ty <= ty1; ty++)
+                for (uint32_t tx = tx0; tx <= tx1; tx++) visit((view * a.tiles_y + ty) * a.tiles_x + tx, r);
+        uint64_t wide = __ballot(ntiles > 4);
+        while (wide) {
+            const int src = __builtin_ctzll(wide);
+            wide &= wide - 1;
+            const uint32_t bx0 = __shfl(tx0, src, 64), bx1 = __shfl(tx1, src, 64), by0 = __shfl(ty0, src, 64), by1 = __shfl(ty1, src, 64);
+            const uint32_t bview = __shfl(view, src, 64), bw = bx1 - bx0 + 1, count = bw * (by1 - by0 + 1);
+            for (uint32_t i = lane; i < count; i += 64) visit((bview * a.tiles_y + by0 + i / bw) * a.tiles_x + bx0 + i % bw, base + (uint32_t)src);
+        }
+    }
+}
+
+// ---- K5: one workgroup per tile -----------------------------------------------------------------------------------------------------
+struct EdgeSetup {
+    int32_t X[3], Y[3];
+    int32_t dx[3], dy[3];  // edge i runs from vertex i+1 to vertex i+2
+    bool tl[3];
+    float z[3];
+    float area;
+};
+SAH_DEV EdgeSetup edge_setup(const RasterRecord& rec) {
+    EdgeSetup e;
+    for (int i = 0; i < 3; i++) { e.X[i] = rec.X[i]; e.Y[i] = rec.Y[i]; e.z[i] = rec.z[i]; }
+    for (int i = 0; i < 3; i++) {
+        const int a = (i + 1) % 3, b = (i + 2) % 3;
+        e.dx[i] = e.X[b] - e.X[a];
+        e.dy[i] = e.Y[b] - e.Y[a];
+        e.tl[i] = e.dy[i] < 0 || (e.dy[i] == 0 && e.dx[i] > 0);
+    }
+    const int64_t area = (int64_t)(e.X[1] - e.X[0]) * (e.Y[2] - e.Y[0]) - (int64_t)(e.X[2] - e.X[0]) * (e.Y[1] - e.Y[0]);
+    e.area = (float)area;
+    return e;
+}
+// coverage of pixel (px, py) and its screen-space barycentrics
+SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, float b[3]) {
+    const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+    bool inside = true;
+    for (int i = 0; i < 3; i++) {
+        const int a = (i + 1) % 3;
+        const int64_t v = (int64_t)e.dx[i] * (cy - e.Y[a]) - (int64_t)e.dy[i] * (cx - e.X[a]);
+        inside = inside && (v > 0 || (v == 0 && e.tl[i]));
+        b[i] = (float)v / e.area;
+    }
+    return inside;
+}
+SAH_DEV float fragment_depth(const EdgeSetup& e, const float b[3]) {
+    const float z = (b[0] * e.z[0] + b[1] * e.z[1]) + b[2] * e.z[2];
+    return __builtin_fminf(__builtin_fmaxf(z, 0.0f), 1.0f);  // depth clamp (shadow PSO) / [0,1] viewport range; NaN -> 0
+}
+
+// perspective-correct barycentrics in the INPUT triangle
+SAH_DEV void input_barycentrics(const RasterAttr& at, const float b[3], float lambda[3]) {
+    const float q0 = b[0] * at.inv_w[0], q1 = b[1] * at.inv_w[1], q2 = b[2] * at.inv_w[2];
+    const float s = (q0 + q1) + q2;
+    const float l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
+    for (int k = 0; k < 3; k++) lambda[k] = (l0 * at.bary[0][k] + l1 * at.bary[1][k]) + l2 * at.bary[2][k];
+}
+SAH_DEV float interp_h(const float lambda[3], float a, float b, float c) { return rh((lambda[0] * a + lambda[1] * b) + lambda[2] * c); }
+SAH_DEV float unorm8_channel(uint32_t packed, int k) { return (float)((packed >> (8 * k)) & 0xffu) / 255.0f; }
+SAH_DEV Hn hmul(Hn a, Hn b) { return a * b; }
+
+// alpha of tinted_base_color (gltf_basic_pbr.slang:181-189)
+SAH_DEV float tinted_alpha(const RasterArgs& a, const RasterAttr& at, const float lambda[3]) {
+    const sah_primitive& prim = a.primitives[at.primitive];
+    float ca[3];
+    for (int k = 0; k < 3; k++) ca[k] = rh(unorm8_channel(a.vertex_data[(int64_t)prim.vertex_offset + a.indices[at.first_index + k]].color, 3));
+    const sah_material& m = a.materials[prim.material];
+    const Hn alpha = Hn(m.base_color_texel[3]) * Hn(interp_h(lambda, ca[0], ca[1], ca[2])) * Hn(m.base_color_tint[3]);
+    return tof(alpha);
+}
+
+SAH_DEV uint32_t unorm8_of(float c) {  // floor(c * 255 + 0.5) in fp32, clamped, NaN -> 0
+    if (!(c > 0.0f)) return 0u;
+    if (c >= 1.0f) return 255u;
+    return (uint32_t)(c * 255.0f + 0.5f);
+}
+
+template <bool GBUFFER>
+SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t px, int32_t py, int32_t tile_x, int32_t tile_y, uint32_t* s_depth,
+                        unsigned long long* s_key) {
+    float b[3];
+    if (!cover(e, px, py, b)) return;
+    const float z = fragment_depth(e, b);
+    const uint32_t slot = (uint32_t)(py - tile_y) * kTile + (uint32_t)(px - tile_x);
+    if (!GBUFFER) {
+        atomicMin(&s_depth[slot], (uint32_t)__builtin_rintf(z * 65535.0f));
+    } else {
+        if (!(z > 0.0f)) return;  // cannot pass GREATER against the cleared 0
+        const RasterAttr& at = a.attrs[rec_index];
+        if (at.cutout) {
+            float lambda[3];
+            input_barycentrics(at, b, lambda);
+            if (tinted_alpha(a, at, lambda) <= a.materials[a.primitives[at.primitive].material].opacity_threshold) return;
+        }
+        atomicMax(&s_key[slot], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xffffffffu - at.seq));
+    }
+}
+
+SAH_DEV void rotate_normalize(const float* m, const float v[3], float out[3]) {
+    float r[3];
+    for (int i = 0; i < 3; i++) r[i] = (m[i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2];
+    const float inv = 1.0f / __builtin_sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    for (int i = 0; i < 3; i++) out[i] = rh(r[i] * inv);
+}
+
+// fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_MAIN_VIEW, constant textures)
+SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px, int32_t py, float z) {
+    const RasterRecord& rec = a.records[rec_index];
+    const RasterAttr& at = a.attrs[rec_index];
+    const EdgeSetup e = edge_setup(rec);
+    float b[3], lambda[3];
+    cover(e, px, py, b);
+    input_barycentrics(at, b, lambda);
+    const sah_primitive& prim = a.primitives[at.primitive];
+    const sah_material& m = a.materials[prim.material];
+    float color[3][4], normal[3][3], tangent[3][4];
+    for (int k = 0; k < 3; k++) {
+        const sah_vertex_data& vd = a.vertex_data[(int64_t)prim.vertex_offset + a.indices[at.first_index + k]];
+        for (int c = 0; c < 4; c++) color[k][c] = rh(unorm8_channel(vd.color, c));
+        rotate_normalize(prim.model, vd.normal, normal[k]);
+        rotate_normalize(prim.model, vd.tangent, tangent[k]);
+        tangent[k][3] = rh(vd.tangent[3]);
+    }
+    Hn col[4], N[3], T[4];
+    for (int c = 0; c < 4; c++) col[c] = Hn(interp_h(lambda, color[0][c], color[1][c], color[2][c]));
+    for (int c = 0; c < 3; c++) N[c] = Hn(interp_h(lambda, normal[0][c], normal[1][c], normal[2][c]));
+    for (int c = 0; c < 4; c++) T[c] = Hn(interp_h(lambda, tangent[0][c], tangent[1][c], tangent[2][c]));
+    Hn tinted[4];
+    for (int c = 0; c < 4; c++) tinted[c] = Hn(m.base_color_texel[c]) * col[c] * Hn(m.base_color_tint[c]);
+    // bitangent = cross(normal, tangent.xyz) * tangent.w; normal = normal_sample * TBN (:197-207)
+    const Hn B[3] = {(N[1] * T[2] - N[2] * T[1]) * T[3], (N[2] * T[0] - N[0] * T[2]) * T[3], (N[0] * T[1] - N[1] * T[0]) * T[3]};
+    Hn ns[3], n_out[3];
+    for (int c = 0; c < 3; c++) ns[c] = Hn(m.normal_texel[c]) * Hn::lit(2.0f) - Hn::lit(1.0f);
+    for (int c = 0; c < 3; c++) n_out[c] = ns[0] * T[c] + ns[1] * B[c] + ns[2] * N[c];
+    const float factor[4] = {0.0f, m.roughness_factor, m.metalness_factor, 0.0f};
+    uint32_t color_bits = 0, data_bits = 0, emission_bits = 0;
+    for (int c = 0; c < 4; c++) {
+        const Hn d = Hn(m.data_texel[c]) * Hn(factor[c]);
+        const Hn em = Hn(m.emission_texel[c]) * Hn(m.emission_factor[c]);
+        data_bits |= unorm8_of(tof(d)) << (8 * c);
+        emission_bits |= (c < 3 ? (uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, em.v)] : unorm8_of(tof(em))) << (8 * c);
+        color_bits |= (c < 3 ? (uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, tinted[c].v)] : unorm8_of(tof(tinted[c]))) << (8 * c);
+    }
+    uint2 nbits;
+    nbits.x = (uint32_t)__builtin_bit_cast(uint16_t, n_out[0].v) | ((uint32_t)__builtin_bit_cast(uint16_t, n_out[1].v) << 16);
+    nbits.y = (uint32_t)__builtin_bit_cast(uint16_t, n_out[2].v);
+    *(uint32_t*)(a.out_color.ptr + (size_t)py * a.out_color.pitch + (size_t)px * 4) = color_bits;
+    *(uint2*)(a.out_normals.ptr + (size_t)py * a.out_normals.pitch + (size_t)px * 8) = nbits;
+    *(uint32_t*)(a.out_data.ptr + (size_t)py * a.out_data.pitch + (size_t)px * 4) = data_bits;
+    *(uint32_t*)(a.out_emission.ptr + (size_t)py * a.out_emission.pitch + (size_t)px * 4) = emission_bits;
+    *(float*)(a.out_depth.ptr + (size_t)py * a.out_depth.pitch + (size_t)px * 4) = z;
+}
+
+template <bool GBUFFER>
+__global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
+    __shared__ uint32_t s_depth[GBUFFER ? 1 : kTile * kTile];
+    __shared__ unsigned long long s_key[GBUFFER ? kTile * kTile : 1];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, view = tile / (a.tiles_x * a.tiles_y);
+    const int32_t tile_x = (int32_t)tx * kTile, tile_y = (int32_t)ty * kTile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < kTile * kTile; i += 256) {
+        if (GBUFFER) s_key[i] = 0ull; else s_depth[i] = 0xffffu;
+    }
+    __syncthreads();
+    const uint32_t begin = a.tile_offset[tile], count = a.tile_count[tile];
+    for (uint32_t base = wave * 64u; base < count; base += 256u) {
+        const uint32_t li = base + lane;
+        uint32_t rec_index = 0;
+        int32_t x0 = 1, x1 = 0, y0 = 1, y1 = 0;
+        if (li < count) {
+            rec_index = a.pairs[begin + li];
+            const RasterRecord& rec = a.records[rec_index];
+            x0 = max((int32_t)rec.x0, tile_x); x1 = min((int32_t)rec.x1, tile_x + kTile - 1);
+            y0 = max((int32_t)rec.y0, tile_y); y1 = min((int32_t)rec.y1, tile_y + kTile - 1);
+        }
+        const uint32_t area = li < count ? (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)) : 0u;
+        if (area && area <= kSmallArea) {
+            const EdgeSetup e = edge_setup(a.records[rec_index]);
+            for (int32_t py = y0; py <= y1; py++)
+                for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER>(a, e, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
+        }
+        uint64_t big = __ballot(area > kSmallArea);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t ri = __shfl(rec_index, src, 64);
+            const int32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64), by0 = __shfl(y0, src, 64), by1 = __shfl(y1, src, 64);
+            const EdgeSetup e = edge_setup(a.records[ri]);
+            // lanes form an 8x8 block that sweeps the clipped bounding box
+            const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+            for (int32_t oy = by0; oy <= by1; oy += 8)
+                for (int32_t ox = bx0; ox <= bx1; ox += 8) {
+                    const int32_t px = ox + lx, py = oy + ly;
+                    if (px <= bx1 && py <= by1) test_pixel<GBUFFER>(a, e, ri, px, py, tile_x, tile_y, s_depth, s_key);
+                }
+        }
+    }
+    __syncthreads();
+    if (!GBUFFER) {
+        // 64 texels of D16 per row = 32 dwords; 256 threads write 8 rows per step
+        uint8_t* base = (uint8_t*)a.shadowmap.ptr + (size_t)view * a.shadowmap.slice_pitch;
+        const bool pair_ok = (a.shadowmap.row_pitch % 4u) == 0 && ((uintptr_t)a.shadowmap.ptr % 4u) == 0 && (a.shadowmap.slice_pitch % 4u) == 0;
+        for (uint32_t i = tid; i < kTile * kTile / 2; i += 256) {
+            const uint32_t row = i / (kTile / 2), col = (i % (kTile / 2)) * 2;
+            const uint32_t px = (uint32_t)tile_x + col, py = (uint32_t)tile_y + row;
+            if (py >= a.height || px >= a.width) continue;
+            const uint32_t d0 = s_depth[row * kTile + col], d1 = s_depth[row * kTile + col + 1];
+            uint8_t* dst = base + (size_t)py * a.shadowmap.row_pitch + (size_t)px * 2;
+            if (pair_ok && px + 1 < a.width) {
+                *(uint32_t*)dst = d0 | (d1 << 16);
+            } else {
+                *(uint16_t*)dst = (uint16_t)d0;
+                if (px + 1 < a.width) *(uint16_t*)(dst + 2) = (uint16_t)d1;
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < kTile * kTile; i += 256) {
+            const int32_t px = tile_x + (int32_t)(i % kTile), py = tile_y + (int32_t)(i / kTile);
+            if ((uint32_t)px >= a.width || (uint32_t)py >= a.height) continue;
+            const unsigned long long key = s_key[i];
+            if (key == 0ull) {  // clear values, gbuffer_phase.cpp:66-87
+                *(uint32_t*)(a.out_color.ptr + (size_t)py * a.out_color.pitch + (size_t)px * 4) = 0u;
+                *(uint2*)(a.out_normals.ptr + (size_t)py * a.out_normals.pitch + (size_t)px * 8) = make_uint2(0x38003800u, 0x00003c00u);
+                *(uint32_t*)(a.out_data.ptr + (size_t)py * a.out_data.pitch + (size_t)px * 4) = 0u;
+                *(uint32_t*)(a.out_emission.ptr + (size_t)py * a.out_emission.pitch + (size_t)px * 4) = 0u;
+                *(float*)(a.out_depth.ptr + (size_t)py * a.out_depth.pitch + (size_t)px * 4) = 0.0f;
+            } else {
+                const uint32_t seq = 0xffffffffu - (uint32_t)key;
+                shade_and_store(a, a.seq_to_record[seq], px, py, __uint_as_float((uint32_t)(key >> 32)));
+            }
+        }
+    }
+}
+
+// seq -> record index (G-buffer resolve)
+__global__ __launch_bounds__(256) void k_seq_table(const RasterArgs a) {
+    const uint32_t nrec = min(a.counters[C_RECORDS], a.record_capacity);
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256) a.seq_to_record[a.attrs[r].seq] = r;
+}
+
+}  // namespace
+
+// Stage 1: scan the draws, set up the records, count the bins, scan the bins.  The caller then reads `counters` back.
+hipError_t launch_raster_setup(const RasterArgs& a, bool gbuffer, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(a.counters, 0, 16 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    const uint32_t ntiles = a.tiles_x * a.tiles_y * a.num_views;
+    e = hipMemsetAsync(a.tile_count, 0, (size_t)ntiles * 2 * sizeof(uint32_t), st);  // tile_count and tile_cursor are adjacent
+    if (e != hipSuccess) return e;
+    if (a.num_primitives == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, a.primitives, (const uint32_t*)nullptr, a.num_primitives, a.tri_base, &a.counters[C_TRIS]);
+    if (gbuffer) hipLaunchKernelGGL(k_setup<true>, dim3(2048), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_setup<false>, dim3(2048), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_bin<false>, dim3(1024), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const sah_primitive*)nullptr, (const uint32_t*)a.tile_count, ntiles, a.tile_offset, &a.counters[C_PAIRS]);
+    return hipGetLastError();
+}
+
+// Stage 2: fill the bins, rasterise and write the images.
+hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st) {
+    const uint32_t ntiles = a.tiles_x * a.tiles_y * a.num_views;
+    if (a.num_primitives) {
+        hipLaunchKernelGGL(k_bin<true>, dim3(1024), dim3(256), 0, st, a);
+        if (gbuffer) hipLaunchKernelGGL(k_seq_table, dim3(1024), dim3(256), 0, st, a);
+    }
+    if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace sah

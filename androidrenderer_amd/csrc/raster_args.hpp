@@ -1,0 +1,62 @@
+// Kernel-argument block and scratch records of the scene rasteriser (raster.hip, api_raster.cpp).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/sah_hip.h"
+#include "params.hpp"
+
+namespace sah {
+
+// One window-space triangle of one view: clipped, fanned, snapped to 1/256 pixel, oriented so that its area is positive.
+struct RasterRecord {
+    int32_t X[3], Y[3];
+    float z[3];
+    uint32_t view;
+    uint16_t x0, x1, y0, y1;  // candidate pixels (centres inside the bounding box), clipped to the viewport
+};
+static_assert(sizeof(RasterRecord) == 48, "RasterRecord layout");
+
+// G-buffer pass only: what the fragment stage needs to interpolate the INPUT triangle's varyings.
+struct RasterAttr {
+    float inv_w[3];
+    float bary[3][3];      // barycentric coordinates of the record's vertices in the input triangle (identity unless clipped)
+    uint32_t primitive;
+    uint32_t first_index;  // of the input triangle, in the index stream
+    uint32_t seq;          // draw order: (running triangle number) * 8 + fan index
+    uint32_t cutout;
+};
+static_assert(sizeof(RasterAttr) == 64, "RasterAttr layout");
+
+struct RasterArgs {
+    // scene
+    const float* positions;
+    const sah_vertex_data* vertex_data;
+    const uint32_t* indices;
+    const sah_primitive* primitives;
+    const sah_material* materials;
+    uint32_t num_primitives, num_indices, num_vertices, num_materials;
+    // views
+    uint32_t num_views;
+    float view_matrix[16];     // G-buffer: world -> view
+    float clip_matrix[4][16];  // shadow: world -> clip per cascade; G-buffer: [0] = projection
+    uint32_t width, height;
+    float half_w, half_h;
+    uint32_t tiles_x, tiles_y;
+    // scratch (device)
+    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [4..11] stats
+    uint32_t* tri_base;  // num_primitives
+    RasterRecord* records;
+    RasterAttr* attrs;
+    uint32_t record_capacity;
+    uint32_t* tile_count;   // num_views * tiles_y * tiles_x, followed by tile_cursor
+    uint32_t* tile_cursor;
+    uint32_t* tile_offset;
+    uint32_t* pairs;
+    uint32_t* seq_to_record;
+    const uint8_t* half_to_srgb8;  // 65536 entries: fp16 bit pattern -> sRGB8 code
+    // outputs
+    VolumeArg shadowmap;
+    PlaneArg out_color, out_normals, out_data, out_emission, out_depth;
+};
+
+}  // namespace sah

@@ -22,7 +22,7 @@ _lib = None
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
-           "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_allgather_rows"]
+           "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_allgather_rows"]
 
 
 def load():
@@ -56,6 +56,9 @@ def load():
     lib.sah_sky_update_luts.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(C.c_float)]
     lib.sah_probe_copy.argtypes =[C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
     lib.sah_probe_update.argtypes = [C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
+    lib.sah_shadow_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.c_uint32,
+                                      C.POINTER(_abi.Volume), C.c_void_p]
+    lib.sah_gbuffer_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.GBuffer), C.c_void_p]
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
@@ -129,6 +132,13 @@ class Context:
     def probe_update(self, atlases, trace_results, probes_to_update_ptr, num_probes):
         """probes_to_update_ptr: device address of num_probes packed uint32 triples."""
         self._check(self.lib.sah_probe_update(self.handle, C.byref(atlases), C.byref(trace_results), C.c_void_p(probes_to_update_ptr), num_probes))
+
+    def shadow_render(self, scene, sun, num_cascades, shadowmap, stats_ptr=None):
+        """scene: _abi.SceneGeometry of device addresses; stats_ptr: device address of 8 uint32 or None."""
+        self._check(self.lib.sah_shadow_render(self.handle, C.byref(scene), C.byref(sun), num_cascades, C.byref(shadowmap), C.c_void_p(stats_ptr)))
+
+    def gbuffer_render(self, scene, view, gbuffer, stats_ptr=None):
+        self._check(self.lib.sah_gbuffer_render(self.handle, C.byref(scene), C.byref(view), C.byref(gbuffer), C.c_void_p(stats_ptr)))
 
     def allgather_rows(self, image, rows_per_rank):
         self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank))

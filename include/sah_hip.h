@@ -289,6 +289,70 @@ int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_a
 int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_volume* trace_results, const uint32_t* probes_to_update,
                      uint32_t num_probes);
 
+/* ---- producers either side of the lighting pass ----------------------------------------------------------
+ * The two rasterisation passes whose outputs a1 gathers from: the sun shadow cascades (depth only, multiview) and the G-buffer.
+ * The reference draws them with the hardware rasteriser; here they are compute passes (bin to 64x64 tiles, depth test in LDS)
+ * that follow the Vulkan rasterisation rules as DESIGN.md §5d pins them down: fixed-point window coordinates with 8 sub-pixel
+ * bits, pixel-centre sampling, top-left rule, clockwise front faces, screen-linear depth, perspective-correct attributes.
+ * Everything below is a DEVICE pointer unless noted. */
+
+/* StandardVertexData — RenderCore/shared/vertex_data.hpp:22-27 (40 bytes; positions live in their own float3 stream). */
+typedef struct sah_vertex_data {
+    float normal[3];
+    float tangent[4];
+    float texcoord[2];
+    uint32_t color; /* unorm4, r in the low byte */
+} sah_vertex_data;
+
+/* BasicPbrMaterialGpu — RenderCore/shared/basic_pbr_material.hpp:6-19, with each bindless texture index replaced by the
+ * texel a 1x1 texture of that slot would return (the glTF assets are not part of the tree; mip-biased sampling of real textures is
+ * the renderer's side of the seam). */
+typedef struct sah_material {
+    float base_color_tint[4];
+    float emission_factor[4];
+    float metalness_factor, roughness_factor, opacity_threshold, padding1;
+    float base_color_texel[4], normal_texel[4], data_texel[4], emission_texel[4];
+} sah_material;
+
+#define SAH_PRIMITIVE_TYPE_SOLID 0  /* back faces culled (render_scene.cpp:196-197) */
+#define SAH_PRIMITIVE_TYPE_CUTOUT 1 /* no culling, alpha test against opacity_threshold (render_scene.cpp:221-222) */
+
+/* One draw: PrimitiveDataGPU::model (RenderCore/shared/primitive_data.hpp:33-50) plus the VkDrawIndexedIndirectCommand range. */
+typedef struct sah_primitive {
+    float model[16];
+    uint32_t first_index, index_count;
+    int32_t vertex_offset;
+    uint32_t type;
+    uint32_t material;
+    uint32_t padding[3];
+} sah_primitive;
+
+typedef struct sah_scene_geometry {
+    const float* vertex_positions;      /* 3 floats per vertex, tightly packed */
+    const sah_vertex_data* vertex_data; /* may be NULL for sah_shadow_render */
+    const uint32_t* indices;
+    const sah_primitive* primitives;    /* draw order: lower index wins a depth tie */
+    const sah_material* materials;      /* may be NULL for sah_shadow_render */
+    uint32_t num_vertices, num_indices, num_primitives, num_materials;
+} sah_scene_geometry;
+
+/* Written by both passes when `stats` is not NULL (device memory, 8 x uint32): [0] (view, triangle) pairs processed, [1] culled,
+ * degenerate, clipped away or covering no pixel centre, [2] dropped (non-finite or out-of-range coordinates, indices outside the
+ * arrays), [3] window-space triangles rasterised (after clipping and fanning), [4] (tile, triangle) bin entries, [5..7] reserved. */
+#define SAH_RASTER_STATS_WORDS 8
+
+/* DirectionalLight::render_shadows — RenderCore/render/directional_light.cpp:286-327 with the `_shadow` pipelines of
+ * RenderCore/render/material_pipelines.cpp:31-62 (compare LESS, depth clamp) and the SAH_MULTIVIEW vertex stage of
+ * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-146.  Clears every layer of `shadowmap` (D16_UNORM 2D array) to 1.0 and
+ * rasterises every primitive into each of the `num_cascades` layers with sun->cascade_matrices[layer]. */
+int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_light_constants* sun, uint32_t num_cascades,
+                      const sah_volume* shadowmap, uint32_t* stats);
+
+/* Depth pre-pass + G-buffer pass — RenderCore/render/phase/gbuffer_phase.cpp:27-97 (clear values :66-87), pipelines
+ * RenderCore/render/material_pipelines.cpp:13-29,104-140 (reverse-Z GREATER, then EQUAL), shaders
+ * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253 (SAH_MAIN_VIEW).  Writes all five planes of `out`. */
+int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_view_data* view, const sah_gbuffer* out, uint32_t* stats);
+
 /* Multi-GPU: in-place all-gather of row blocks of `image` (rank r owns rows
  * [rows_per_rank*r, rows_per_rank*(r+1))) over RCCL. */
 int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank);

@@ -1,0 +1,354 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// CPU restatement of the two rasterisation passes either side of the lighting pass:
+//   sun shadow cascades   RenderCore/render/directional_light.cpp:286-327, pipelines RenderCore/render/material_pipelines.cpp:31-62,
+//                         vertex stage RenderCore/shaders/materials/gltf_basic_pbr.slang:110-146 (SAH_MULTIVIEW)
+//   depth + G-buffer      RenderCore/render/phase/gbuffer_phase.cpp:27-97, pipelines material_pipelines.cpp:13-29,104-140,
+//                         shaders gltf_basic_pbr.slang:110-253 (SAH_MAIN_VIEW); cull / front face RenderCore/render/render_scene.cpp:196-222
+// The reference hands these to the hardware rasteriser.  What is restated is the Vulkan 1.4 rasterisation contract with the
+// implementation-defined parts fixed as DESIGN.md §5d lists them: immediate mode, one triangle after the other in draw order.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/sah_hip.h"
+#include "codec.hpp"
+#include "math.hpp"
+
+namespace orc {
+namespace {
+
+constexpr int kSubPixel = 256;             // 8 sub-pixel bits
+constexpr float kGuardBand = 256.0f;       // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
+constexpr int64_t kCoordLimit = 1ll << 29; // snapped coordinates beyond this drop the triangle
+
+struct ClipVertex {
+    F c[4];     // clip-space x y z w
+    F bary[3];  // barycentric coordinates in the input triangle
+};
+struct RasterVertex {
+    int64_t X, Y;
+    F z, inv_w;
+    F bary[3];
+    bool finite;
+};
+
+ClipVertex lerp_vertex(const ClipVertex& in, const ClipVertex& out, F d_in, F d_out) {
+    const F t = d_in / (d_in - d_out);
+    ClipVertex r;
+    for (int k = 0; k < 4; k++) r.c[k] = in.c[k] + (out.c[k] - in.c[k]) * t;
+    for (int k = 0; k < 3; k++) r.bary[k] = in.bary[k] + (out.bary[k] - in.bary[k]) * t;
+    return r;
+}
+
+// plane distances, in clipping order; a vertex is kept when d >= 0
+F plane_distance(const ClipVertex& v, int plane) {
+    switch (plane) {
+        case 0: return v.c[2];                              // z >= 0
+        case 1: return v.c[3] - v.c[2];                     // z <= w
+        case 2: return F(kGuardBand) * v.c[3] - v.c[0];
+        case 3: return F(kGuardBand) * v.c[3] + v.c[0];
+        case 4: return F(kGuardBand) * v.c[3] - v.c[1];
+        default: return F(kGuardBand) * v.c[3] + v.c[1];
+    }
+}
+
+// Sutherland-Hodgman; the new vertex of a crossing edge is always computed from the inside vertex towards the outside one
+int clip_polygon(ClipVertex* poly, int n, int first_plane) {
+    ClipVertex tmp[12];
+    for (int plane = first_plane; plane < 6 && n >= 3; plane++) {
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipVertex& a = poly[i];
+            const ClipVertex& b = poly[(i + 1) % n];
+            const F da = plane_distance(a, plane), db = plane_distance(b, plane);
+            const bool ia = da.v >= 0.0f, ib = db.v >= 0.0f;
+            if (ia) tmp[m++] = a;
+            if (ia != ib) tmp[m++] = ia ? lerp_vertex(a, b, da, db) : lerp_vertex(b, a, db, da);
+        }
+        n = m;
+        for (int i = 0; i < n; i++) poly[i] = tmp[i];
+    }
+    return n < 3 ? 0 : n;
+}
+
+RasterVertex to_window(const ClipVertex& v, uint32_t W, uint32_t H) {
+    RasterVertex r;
+    const F xd = v.c[0] / v.c[3], yd = v.c[1] / v.c[3];
+    r.z = v.c[2] / v.c[3];
+    r.inv_w = F(1.0f) / v.c[3];
+    const F hw = F((float)W * 0.5f), hh = F((float)H * 0.5f);
+    const F xf = xd * hw + hw, yf = yd * hh + hh;
+    const float sx = xf.v * (float)kSubPixel, sy = yf.v * (float)kSubPixel;
+    r.finite = std::isfinite(sx) && std::isfinite(sy) && std::isfinite(r.z.v) && std::isfinite(r.inv_w.v) &&
+               std::fabs(sx) <= (float)kCoordLimit && std::fabs(sy) <= (float)kCoordLimit;
+    r.X = r.finite ? (int64_t)std::nearbyint(sx) : 0;
+    r.Y = r.finite ? (int64_t)std::nearbyint(sy) : 0;
+    for (int k = 0; k < 3; k++) r.bary[k] = v.bary[k];
+    return r;
+}
+
+struct Fragment {
+    int x, y;
+    F z;
+    F lambda[3];  // perspective-correct barycentrics in the input triangle
+};
+
+struct Stats {
+    uint32_t w[SAH_RASTER_STATS_WORDS] = {};
+};
+
+inline bool top_left(int64_t dx, int64_t dy) { return dy < 0 || (dy == 0 && dx > 0); }
+
+// Rasterises one window-space triangle; `emit` is called for every covered pixel centre.
+template <class Emit>
+void raster_triangle(RasterVertex v0, RasterVertex v1, RasterVertex v2, bool cull_back, uint32_t W, uint32_t H, Stats& st, Emit&& emit) {
+    if (!v0.finite || !v1.finite || !v2.finite) { st.w[2]++; return; }
+    int64_t area = (v1.X - v0.X) * (v2.Y - v0.Y) - (v2.X - v0.X) * (v1.Y - v0.Y);
+    if (area == 0 || (area < 0 && cull_back)) { st.w[1]++; return; }
+    if (area < 0) { std::swap(v1, v2); area = -area; }
+    const int64_t minx = std::min(v0.X, std::min(v1.X, v2.X)), maxx = std::max(v0.X, std::max(v1.X, v2.X));
+    const int64_t miny = std::min(v0.Y, std::min(v1.Y, v2.Y)), maxy = std::max(v0.Y, std::max(v1.Y, v2.Y));
+    // pixel p is a candidate when its centre 256 p + 128 lies in [min, max]
+    auto first_px = [](int64_t lo) { const int64_t a = lo - 128; return a <= 0 ? (int64_t)0 : (a + 255) / 256; };
+    auto last_px = [](int64_t hi, uint32_t size) {
+        const int64_t a = hi - 128;
+        if (a < 0) return (int64_t)-1;
+        return std::min<int64_t>(a / 256, (int64_t)size - 1);
+    };
+    const int64_t x0 = first_px(minx), x1 = last_px(maxx, W), y0 = first_px(miny), y1 = last_px(maxy, H);
+    if (x0 > x1 || y0 > y1) { st.w[1]++; return; }
+    st.w[3]++;
+    const RasterVertex* v[3] = {&v0, &v1, &v2};
+    const F farea = F((float)area);
+    for (int64_t py = y0; py <= y1; py++)
+        for (int64_t px = x0; px <= x1; px++) {
+            const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+            int64_t e[3];
+            bool inside = true;
+            for (int i = 0; i < 3; i++) {
+                const RasterVertex &a = *v[(i + 1) % 3], &b = *v[(i + 2) % 3];
+                const int64_t dx = b.X - a.X, dy = b.Y - a.Y;
+                e[i] = dx * (cy - a.Y) - dy * (cx - a.X);
+                inside = inside && (e[i] > 0 || (e[i] == 0 && top_left(dx, dy)));
+            }
+            if (!inside) continue;
+            Fragment f;
+            f.x = (int)px;
+            f.y = (int)py;
+            const F b0 = F((float)e[0]) / farea, b1 = F((float)e[1]) / farea, b2 = F((float)e[2]) / farea;
+            f.z = b0 * v0.z + b1 * v1.z + b2 * v2.z;
+            const F q0 = b0 * v0.inv_w, q1 = b1 * v1.inv_w, q2 = b2 * v2.inv_w;
+            const F s = q0 + q1 + q2;
+            const F l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
+            for (int k = 0; k < 3; k++) f.lambda[k] = l0 * v0.bary[k] + l1 * v1.bary[k] + l2 * v2.bary[k];
+            emit(f);
+        }
+}
+
+M4 load_m4(const float* p) {
+    M4 m;
+    std::memcpy(m.m, p, 64);
+    return m;
+}
+
+// Vertex fetch + clip + fan for input triangle `tri` of primitive `prim`; `to_clip` maps the world-space position to clip space.
+template <class ToClip, class Emit>
+void process_triangle(const sah_scene_geometry& g, const sah_primitive& prim, uint32_t tri, bool clip_depth, uint32_t W, uint32_t H, Stats& st,
+                      ToClip&& to_clip, Emit&& emit) {
+    st.w[0]++;
+    ClipVertex poly[12];
+    const M4 model = load_m4(prim.model);
+    for (int k = 0; k < 3; k++) {
+        const uint32_t idx = g.indices[prim.first_index + 3 * tri + k];
+        const float* p = g.vertex_positions + 3 * ((int64_t)prim.vertex_offset + idx);
+        const F4 world = mul(model, F4{F(p[0]), F(p[1]), F(p[2]), F(1.0f)});
+        const F4 c = to_clip(world);
+        poly[k].c[0] = c.x; poly[k].c[1] = c.y; poly[k].c[2] = c.z; poly[k].c[3] = c.w;
+        for (int j = 0; j < 3; j++) poly[k].bary[j] = F(j == k ? 1.0f : 0.0f);
+        for (int j = 0; j < 4; j++)
+            if (!std::isfinite(poly[k].c[j].v)) { st.w[2]++; return; }
+    }
+    const int n = clip_polygon(poly, 3, clip_depth ? 0 : 2);
+    if (n == 0) { st.w[1]++; return; }
+    RasterVertex rv[12];
+    for (int i = 0; i < n; i++) rv[i] = to_window(poly[i], W, H);
+    const bool cull_back = prim.type == SAH_PRIMITIVE_TYPE_SOLID;
+    for (int i = 1; i + 1 < n; i++) raster_triangle(rv[0], rv[i], rv[i + 1], cull_back, W, H, st, [&](const Fragment& f) { emit(f, (uint32_t)(i - 1)); });
+}
+
+void write_stats(uint32_t* out, const Stats& st) {
+    if (out) std::memcpy(out, st.w, sizeof(st.w));
+}
+
+bool geometry_ok(const sah_scene_geometry* g, bool need_attributes) {
+    if (!g || (g->num_primitives && !g->primitives)) return false;
+    if (need_attributes && g->num_primitives && (!g->vertex_data || !g->materials)) return false;
+    for (uint32_t p = 0; p < g->num_primitives; p++) {
+        const sah_primitive& pr = g->primitives[p];
+        if (pr.index_count % 3 || (uint64_t)pr.first_index + pr.index_count > g->num_indices) return false;
+        if (pr.type > SAH_PRIMITIVE_TYPE_CUTOUT) return false;
+        if (need_attributes && pr.material >= g->num_materials) return false;
+        for (uint32_t i = 0; i < pr.index_count; i++) {
+            const int64_t v = (int64_t)pr.vertex_offset + g->indices[pr.first_index + i];
+            if (v < 0 || v >= (int64_t)g->num_vertices) return false;
+        }
+    }
+    return true;
+}
+
+// ---- G-buffer fragment stage (gltf_basic_pbr.slang:169-253, SAH_MAIN_VIEW) -----------------------------------------------------
+struct VertexOut {  // the half-precision varyings of VertexOutput (:83-96), held as fp16-representable fp32
+    H color[4];
+    H normal[3];
+    H tangent[4];
+};
+
+VertexOut vertex_outputs(const sah_scene_geometry& g, const sah_primitive& prim, uint32_t index) {
+    const sah_vertex_data& vd = g.vertex_data[(int64_t)prim.vertex_offset + index];
+    const M4 model = load_m4(prim.model);
+    VertexOut o;
+    for (int k = 0; k < 4; k++) o.color[k] = H(unorm8_to_float((uint8_t)(vd.color >> (8 * k))));
+    // (float3x3)model * v, then normalize in fp32, then the (half3) conversion (:139-141)
+    auto rotate = [&](const float* v) {
+        F3 r;
+        F* out[3] = {&r.x, &r.y, &r.z};
+        for (int i = 0; i < 3; i++) *out[i] = F(model.m[0 + i]) * F(v[0]) + F(model.m[4 + i]) * F(v[1]) + F(model.m[8 + i]) * F(v[2]);
+        return normalize(r);
+    };
+    const F3 n = rotate(vd.normal), t = rotate(vd.tangent);
+    o.normal[0] = H(n.x.v); o.normal[1] = H(n.y.v); o.normal[2] = H(n.z.v);
+    o.tangent[0] = H(t.x.v); o.tangent[1] = H(t.y.v); o.tangent[2] = H(t.z.v);
+    o.tangent[3] = H(vd.tangent[3]);
+    return o;
+}
+
+H interpolate(const F lambda[3], H a, H b, H c) { return H((lambda[0] * F(a.v) + lambda[1] * F(b.v) + lambda[2] * F(c.v)).v); }
+
+struct GbufferTexel {
+    uint8_t color[4];
+    uint16_t normal[4];
+    uint8_t data[4];
+    uint8_t emission[4];
+    bool discarded;
+};
+
+uint8_t srgb8(H v) { return float_to_unorm8(linear_to_srgb_f(v.v)); }
+
+GbufferTexel shade_fragment(const sah_material& m, const VertexOut vo[3], const F lambda[3]) {
+    GbufferTexel out{};
+    H color[4], normal[3], tangent[4];
+    for (int k = 0; k < 4; k++) color[k] = interpolate(lambda, vo[0].color[k], vo[1].color[k], vo[2].color[k]);
+    for (int k = 0; k < 3; k++) normal[k] = interpolate(lambda, vo[0].normal[k], vo[1].normal[k], vo[2].normal[k]);
+    for (int k = 0; k < 4; k++) tangent[k] = interpolate(lambda, vo[0].tangent[k], vo[1].tangent[k], vo[2].tangent[k]);
+    // base colour (:181-189)
+    H tinted[4];
+    for (int k = 0; k < 4; k++) tinted[k] = H(m.base_color_texel[k]) * color[k] * H(m.base_color_tint[k]);
+    out.discarded = tinted[3].v <= m.opacity_threshold;
+    // normals (:197-207)
+    const H3 N{normal[0], normal[1], normal[2]}, T{tangent[0], tangent[1], tangent[2]};
+    const H3 B = cross(N, T) * tangent[3];
+    H ns[3];
+    for (int k = 0; k < 3; k++) ns[k] = H(m.normal_texel[k]) * H(2.0f) - H(1.0f);
+    const H nx = ns[0] * T.x + ns[1] * B.x + ns[2] * N.x;
+    const H ny = ns[0] * T.y + ns[1] * B.y + ns[2] * N.y;
+    const H nz = ns[0] * T.z + ns[1] * B.z + ns[2] * N.z;
+    // data (:213-218) and emission (:221-226)
+    const H factor[4] = {H(0.0f), H(m.roughness_factor), H(m.metalness_factor), H(0.0f)};
+    for (int k = 0; k < 4; k++) {
+        const H d = H(m.data_texel[k]) * factor[k];
+        const H e = H(m.emission_texel[k]) * H(m.emission_factor[k]);
+        out.data[k] = float_to_unorm8(d.v);
+        out.emission[k] = k < 3 ? srgb8(e) : float_to_unorm8(e.v);
+        out.color[k] = k < 3 ? srgb8(tinted[k]) : float_to_unorm8(tinted[k].v);
+    }
+    out.normal[0] = f32_to_f16(nx.v); out.normal[1] = f32_to_f16(ny.v); out.normal[2] = f32_to_f16(nz.v); out.normal[3] = 0;
+    return out;
+}
+
+bool plane_is(const sah_plane& p, uint32_t fmt, uint32_t w, uint32_t h) { return p.ptr && p.format == fmt && p.width == w && p.height == h; }
+
+}  // namespace
+}  // namespace orc
+
+extern "C" {
+
+int orc_shadow_render(const sah_scene_geometry* scene, const sah_sun_light_constants* sun, uint32_t num_cascades, const sah_volume* shadowmap,
+                      uint32_t* stats) {
+    using namespace orc;
+    if (!geometry_ok(scene, false) || !sun || !shadowmap || !shadowmap->ptr || shadowmap->format != SAH_FORMAT_D16_UNORM || num_cascades == 0 ||
+        num_cascades > 4 || shadowmap->depth < num_cascades || shadowmap->width > 8192 || shadowmap->height > 8192)
+        return SAH_ERR_INVALID_ARGUMENT;
+    const uint32_t W = shadowmap->width, H = shadowmap->height;
+    Stats st;
+    for (uint32_t layer = 0; layer < num_cascades; layer++) {
+        uint8_t* base = (uint8_t*)shadowmap->ptr + (size_t)layer * shadowmap->slice_pitch_bytes;
+        for (uint32_t y = 0; y < H; y++) {
+            uint16_t* row = (uint16_t*)(base + (size_t)y * shadowmap->row_pitch_bytes);
+            for (uint32_t x = 0; x < W; x++) row[x] = 0xffffu;  // clear value 1.0 (directional_light.cpp:311)
+        }
+        const M4 world_to_ndc = load_m4(sun->cascade_matrices[layer]);
+        for (uint32_t p = 0; p < scene->num_primitives; p++) {
+            const sah_primitive& prim = scene->primitives[p];
+            for (uint32_t tri = 0; tri < prim.index_count / 3; tri++)
+                process_triangle(*scene, prim, tri, /*clip_depth=*/false, W, H, st, [&](F4 world) { return mul(world_to_ndc, world); },
+                                 [&](const Fragment& f, uint32_t) {
+                                     const F z = nclamp(f.z, F(0.0f), F(1.0f));  // depth clamp; NaN -> 0
+                                     const uint32_t code = (uint32_t)std::nearbyint(z.v * 65535.0f);
+                                     uint16_t* texel = (uint16_t*)(base + (size_t)f.y * shadowmap->row_pitch_bytes) + f.x;
+                                     if (code < *texel) *texel = (uint16_t)code;  // VK_COMPARE_OP_LESS
+                                 });
+        }
+    }
+    write_stats(stats, st);
+    return SAH_OK;
+}
+
+int orc_gbuffer_render(const sah_scene_geometry* scene, const sah_view_data* view, const sah_gbuffer* out, uint32_t* stats) {
+    using namespace orc;
+    if (!geometry_ok(scene, true) || !view || !out) return SAH_ERR_INVALID_ARGUMENT;
+    const uint32_t W = out->depth.width, H = out->depth.height;
+    if (W == 0 || H == 0 || W > 8192 || H > 8192 || !plane_is(out->depth, SAH_FORMAT_D32_SFLOAT, W, H) || !plane_is(out->color, SAH_FORMAT_R8G8B8A8_SRGB, W, H) ||
+        !plane_is(out->normals, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H) || !plane_is(out->data, SAH_FORMAT_R8G8B8A8_UNORM, W, H) ||
+        !plane_is(out->emission, SAH_FORMAT_R8G8B8A8_SRGB, W, H))
+        return SAH_ERR_INVALID_ARGUMENT;
+    auto at = [&](const sah_plane& p, int x, int y, int bpp) { return (uint8_t*)p.ptr + (size_t)y * p.row_pitch_bytes + (size_t)x * bpp; };
+    // clear values: gbuffer_phase.cpp:66-87; depth 0 = far plane of the reversed-Z projection
+    const uint16_t clear_normal[4] = {f32_to_f16(0.5f), f32_to_f16(0.5f), f32_to_f16(1.0f), 0};
+    for (uint32_t y = 0; y < H; y++)
+        for (uint32_t x = 0; x < W; x++) {
+            std::memset(at(out->color, x, y, 4), 0, 4);
+            std::memcpy(at(out->normals, x, y, 8), clear_normal, 8);
+            std::memset(at(out->data, x, y, 4), 0, 4);
+            std::memset(at(out->emission, x, y, 4), 0, 4);
+            std::memset(at(out->depth, x, y, 4), 0, 4);
+        }
+    const M4 V = load_m4(view->view), P = load_m4(view->projection);
+    Stats st;
+    for (uint32_t p = 0; p < scene->num_primitives; p++) {
+        const sah_primitive& prim = scene->primitives[p];
+        const sah_material& mat = scene->materials[prim.material];
+        for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {
+            VertexOut vo[3];
+            for (int k = 0; k < 3; k++) vo[k] = vertex_outputs(*scene, prim, scene->indices[prim.first_index + 3 * tri + k]);
+            process_triangle(*scene, prim, tri, /*clip_depth=*/true, W, H, st, [&](F4 world) { return mul(P, mul(V, world)); },
+                             [&](const Fragment& f, uint32_t) {
+                                 const F z = nclamp(f.z, F(0.0f), F(1.0f));
+                                 float stored;
+                                 std::memcpy(&stored, at(out->depth, f.x, f.y, 4), 4);
+                                 if (!(z.v > stored)) return;  // VK_COMPARE_OP_GREATER: the first of equal depths stays
+                                 const GbufferTexel t = shade_fragment(mat, vo, f.lambda);
+                                 if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && t.discarded) return;
+                                 std::memcpy(at(out->depth, f.x, f.y, 4), &z.v, 4);
+                                 std::memcpy(at(out->color, f.x, f.y, 4), t.color, 4);
+                                 std::memcpy(at(out->normals, f.x, f.y, 8), t.normal, 8);
+                                 std::memcpy(at(out->data, f.x, f.y, 4), t.data, 4);
+                                 std::memcpy(at(out->emission, f.x, f.y, 4), t.emission, 4);
+                             });
+        }
+    }
+    write_stats(stats, st);
+    return SAH_OK;
+}
+
+}  // extern "C"

