@@ -79,29 +79,33 @@ class Mesh:
             p["material"] = material_index
         self.primitives.append(p)
 
-    def add_box(self, bmin, bmax, material_index, **kw):
-        """Axis-aligned box, outward normals, clockwise front faces as seen from outside (render_scene.cpp:196-197)."""
+    def add_box(self, bmin, bmax, material_index, subdiv=1, **kw):
+        """Axis-aligned box, outward normals, every face a grid of subdiv x subdiv quads."""
         bmin, bmax = np.asarray(bmin, np.float32), np.asarray(bmax, np.float32)
         pos, nrm, idx = [], [], []
+        n1 = subdiv + 1
         for axis in range(3):
             for sign in (-1.0, 1.0):
                 u, v = (axis + 1) % 3, (axis + 2) % 3
                 n = np.zeros(3, np.float32)
                 n[axis] = sign
-                corners = []
-                for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):
-                    c = np.zeros(3, np.float32)
-                    c[axis] = bmax[axis] if sign > 0 else bmin[axis]
-                    c[u] = bmax[u] if du else bmin[u]
-                    c[v] = bmax[v] if dv else bmin[v]
-                    corners.append(c)
                 base = len(pos)
-                pos += corners
-                nrm += [n] * 4
+                tu = np.linspace(bmin[u], bmax[u], n1, dtype=np.float32)
+                tv = np.linspace(bmin[v], bmax[v], n1, dtype=np.float32)
+                for j in range(n1):
+                    for i in range(n1):
+                        c = np.zeros(3, np.float32)
+                        c[axis] = bmax[axis] if sign > 0 else bmin[axis]
+                        c[u], c[v] = tu[i], tv[j]
+                        pos.append(c)
+                        nrm.append(n)
                 # counter-clockwise seen from outside in the right-handed y-up world (glTF); the projection has no y flip, so these
-                # arrive clockwise in window coordinates
+                # arrive clockwise in window coordinates (front faces, render_scene.cpp:196-197)
                 quad = (0, 1, 2, 0, 2, 3) if sign > 0 else (0, 2, 1, 0, 3, 2)
-                idx += [base + q for q in quad]
+                for j in range(subdiv):
+                    for i in range(subdiv):
+                        corners = (base + j * n1 + i, base + j * n1 + i + 1, base + (j + 1) * n1 + i + 1, base + (j + 1) * n1 + i)
+                        idx += [corners[q] for q in quad]
         return self.add_primitive(pos, nrm, idx, material_index, **kw)
 
     def arrays(self):
@@ -155,14 +159,14 @@ _ATRIUM_ROUGH = [0.65, 0.8, 0.7, 0.5, 0.4, 0.3]
 _ATRIUM_METAL = [0.0, 0.0, 0.0, 0.1, 0.0, 0.9]
 
 
-def atrium():
-    """The procedural atrium as a mesh: one primitive per box (12 triangles each), six materials, emissive lamps."""
+def atrium(subdiv=1):
+    """The procedural atrium as a mesh: one primitive per box (12 * subdiv^2 triangles each), six materials, emissive lamps."""
     m = Mesh()
     for i in range(6):
         emission = (1.0, 0.67, 0.4, 0.0) if i == 5 else (0, 0, 0, 0)
         m.add_material(material(base=_ATRIUM_BASE[i] + (1.0,), rough=_ATRIUM_ROUGH[i], metal=_ATRIUM_METAL[i], emission=emission))
     for bmin, bmax, mat in synth._atrium_boxes():
-        m.add_box(bmin, bmax, mat)
+        m.add_box(bmin, bmax, mat, subdiv=subdiv)
     return m
 
 

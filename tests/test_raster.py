@@ -253,7 +253,6 @@ def test_hip_gbuffer_matches_oracle_on_triangle_soup(hip_ctx, seed, res):
     got, got_stats = _hip_gbuffer(hip_ctx, arrays, view, *res)
     _assert_gbuffers_equal(got, want)
     assert list(got_stats[:4]) == list(want_stats[:4])
-    assert want_stats[3] > want_stats[0] - want_stats[1] - 50 or True
     if res[0] > 8:
         assert (want["depth"] > 0).mean() > 0.2
 

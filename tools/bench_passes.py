@@ -121,6 +121,25 @@ def main():
         luts = [torch.zeros(shape, dtype=torch.int16, device="cuda") for shape in ((64, 256, 4), (32, 32, 4), (200, 200, 4))]
         lp = [images.plane(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in luts]
         timeit("sky LUT update (3 LUTs)", lambda: ctx.sky_update_luts(lp[0], lp[1], lp[2], (0.3, -0.8, 0.52)), (256 * 64 + 32 * 32 + 200 * 200) * 8)
+    # ---- scene rasteriser (f1, f2): the atrium at two tessellations --------------------------------------------------------------
+    if wanted("raster"):
+        from androidrenderer_amd import mesh, scene
+        view = scene.SceneView.default(W, H)
+        sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+        constants = sun.update_shadow_cascades(view, resolution=4096)
+        gb = {"color": torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"), "normals": torch.zeros((H, W, 4), dtype=torch.int16, device="cuda"),
+              "data": torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"), "emission": torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"),
+              "depth": torch.zeros((H, W), dtype=torch.float32, device="cuda")}
+        gbd = images.gbuffer(gb)
+        sm = torch.zeros((4, 4096, 4096), dtype=torch.int16, device="cuda")
+        smv = images.volume(sm, _abi.FORMAT_D16_UNORM)
+        for subdiv in (1, 24):
+            arrays = mesh.atrium(subdiv).arrays()
+            dev = mesh.to_device(arrays)
+            geo = mesh.geometry(dev, [])
+            tris = int(arrays["indices"].shape[0] // 3)
+            timeit(f"raster gbuffer {tris} tris", lambda: ctx.gbuffer_render(geo, view.gpu_data, gbd), 24 * px)
+            timeit(f"raster shadow 4x4096^2 {tris} tris", lambda: ctx.shadow_render(geo, constants, 4, smv), 4 * 4096 * 4096 * 2)
     if args.json:
         print(json.dumps(results))
 
