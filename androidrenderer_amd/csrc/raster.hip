@@ -139,16 +139,56 @@ SAH_DEV uint32_t find_primitive(const uint32_t* tri_base, uint32_t n, uint32_t t
     return lo;
 }
 
+// One atomic per wave instead of one per lane (the counters are single addresses: per-lane atomics serialise in L2).
+SAH_DEV uint32_t wave_sum(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+SAH_DEV void flush_stat(uint32_t* counter, uint32_t local) {  // every lane of the wave must call this
+    const uint32_t total = wave_sum(local);
+    if ((threadIdx.x & 63u) == 0 && total) atomicAdd(counter, total);
+}
+// slot for the lanes that `want` one: the first of them adds the count, the rest take consecutive slots
+SAH_DEV uint32_t wave_alloc(uint32_t* counter, bool want) {
+    const uint64_t mask = __ballot(want);
+    uint32_t slot = 0;
+    if (want) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __builtin_ctzll(mask);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
+        base = __shfl(base, leader, 64);
+        slot = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    }
+    return slot;
+}
+
+// the half-precision varyings of one vertex (gltf_basic_pbr.slang:134-143): colour, normalize(model3x3 * normal), tangent
+SAH_DEV void rotate_normalize(const float* m, const float v[3], uint16_t out[3]) {
+    float r[3];
+    for (int i = 0; i < 3; i++) r[i] = (m[i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2];
+    const float inv = 1.0f / __builtin_sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    for (int i = 0; i < 3; i++) out[i] = f2h(r[i] * inv);
+}
+SAH_DEV void vertex_outputs(const sah_primitive& prim, const sah_vertex_data& vd, uint16_t out[12]) {
+    for (int c = 0; c < 4; c++) out[c] = f2h((float)((vd.color >> (8 * c)) & 0xffu) / 255.0f);
+    rotate_normalize(prim.model, vd.normal, out + 4);
+    rotate_normalize(prim.model, vd.tangent, out + 7);
+    out[10] = f2h(vd.tangent[3]);
+    out[11] = 0;
+}
+
 template <bool GBUFFER>
 __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
     const uint32_t total = a.counters[C_TRIS];
     const uint64_t work = (uint64_t)total * a.num_views;
+    uint32_t st_in = 0, st_culled = 0, st_dropped = 0, st_raster = 0;
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < work; w += (uint64_t)gridDim.x * 256) {
         const uint32_t view = (uint32_t)(w / total), t = (uint32_t)(w % total);
         const uint32_t p = find_primitive(a.tri_base, a.num_primitives, t);
         const sah_primitive& prim = a.primitives[p];
         const uint32_t tri = t - a.tri_base[p];
-        atomicAdd(&a.counters[C_STATS + 0], 1u);
+        st_in++;
         ClipVertex poly[12];
         bool finite = true, inside = true;
         // a draw that points outside the index / vertex / material arrays is dropped, never dereferenced
@@ -157,7 +197,7 @@ __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
             const int64_t v = (int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k];
             in_range = v >= 0 && v < (int64_t)a.num_vertices;
         }
-        if (!in_range) { atomicAdd(&a.counters[C_STATS + 2], 1u); continue; }
+        if (!in_range) { st_dropped++; continue; }
         for (int k = 0; k < 3; k++) {
             const uint32_t idx = a.indices[prim.first_index + 3 * tri + k];
             const float* pos = a.positions + 3 * ((int64_t)prim.vertex_offset + idx);
@@ -175,26 +215,26 @@ __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
             for (int j = 0; j < 3; j++) poly[k].bary[j] = j == k ? 1.0f : 0.0f;
             for (int plane = GBUFFER ? 0 : 2; plane < 6; plane++) inside = inside && plane_distance(poly[k], plane) >= 0.0f;
         }
-        if (!finite) { atomicAdd(&a.counters[C_STATS + 2], 1u); continue; }
+        if (!finite) { st_dropped++; continue; }
         int n = 3;
         if (!inside) n = clip_polygon(poly, 3, GBUFFER ? 0 : 2);
-        if (n == 0) { atomicAdd(&a.counters[C_STATS + 1], 1u); continue; }
+        if (n == 0) { st_culled++; continue; }
         const bool cull_back = prim.type == SAH_PRIMITIVE_TYPE_SOLID;
         const WindowVertex v0 = to_window(poly[0], a.half_w, a.half_h);
         WindowVertex prev = to_window(poly[1], a.half_w, a.half_h);
         for (int i = 1; i + 1 < n; i++) {
             WindowVertex v1 = prev, v2 = to_window(poly[i + 1], a.half_w, a.half_h);
             prev = v2;
-            if (!v0.finite || !v1.finite || !v2.finite) { atomicAdd(&a.counters[C_STATS + 2], 1u); continue; }
+            if (!v0.finite || !v1.finite || !v2.finite) { st_dropped++; continue; }
             int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
-            if (area == 0 || (area < 0 && cull_back)) { atomicAdd(&a.counters[C_STATS + 1], 1u); continue; }
+            if (area == 0 || (area < 0 && cull_back)) { st_culled++; continue; }
             if (area < 0) { const WindowVertex s = v1; v1 = v2; v2 = s; }
             const int32_t minx = min(v0.X, min(v1.X, v2.X)), maxx = max(v0.X, max(v1.X, v2.X));
             const int32_t miny = min(v0.Y, min(v1.Y, v2.Y)), maxy = max(v0.Y, max(v1.Y, v2.Y));
             const int32_t x0 = first_px(minx), x1 = last_px(maxx, a.width), y0 = first_px(miny), y1 = last_px(maxy, a.height);
-            if (x0 > x1 || y0 > y1) { atomicAdd(&a.counters[C_STATS + 1], 1u); continue; }
-            atomicAdd(&a.counters[C_STATS + 3], 1u);
-            const uint32_t r = atomicAdd(&a.counters[C_RECORDS], 1u);
+            if (x0 > x1 || y0 > y1) { st_culled++; continue; }
+            st_raster++;
+            const uint32_t r = wave_alloc(&a.counters[C_RECORDS], true);
             if (r >= a.record_capacity) continue;  // the host sees the count, grows the buffer and runs the pass again
             RasterRecord rec;
             rec.X[0] = v0.X; rec.X[1] = v1.X; rec.X[2] = v2.X;
@@ -208,13 +248,19 @@ __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
                 at.inv_w[0] = v0.inv_w; at.inv_w[1] = v1.inv_w; at.inv_w[2] = v2.inv_w;
                 for (int k = 0; k < 3; k++) { at.bary[0][k] = v0.bary[k]; at.bary[1][k] = v1.bary[k]; at.bary[2][k] = v2.bary[k]; }
                 at.primitive = p;
-                at.first_index = prim.first_index + 3 * tri;
+                at.material = prim.material;
                 at.seq = t * 8u + (uint32_t)(i - 1);
                 at.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
+                for (int k = 0; k < 3; k++)
+                    vertex_outputs(prim, a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]], at.vout[k]);
                 a.attrs[r] = at;
             }
         }
     }
+    flush_stat(&a.counters[C_STATS + 0], st_in);
+    flush_stat(&a.counters[C_STATS + 1], st_culled);
+    flush_stat(&a.counters[C_STATS + 2], st_dropped);
+    flush_stat(&a.counters[C_STATS + 3], st_raster);
 }
 
 // ---- K2 / K4: binning -------------------------------------------------------------------------------------------------------------
@@ -225,6 +271,7 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
     const uint32_t nrec = min(a.counters[C_RECORDS], a.record_capacity);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves = gridDim.x * 4u;
+    uint32_t st_pairs = 0;
     for (uint32_t base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < nrec; base += waves * 64u) {
         const uint32_t r = base + lane;
         uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, view = 0;
@@ -239,7 +286,7 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
                 a.pairs[a.tile_offset[tile] + pos] = rec_index;
             } else {
                 atomicAdd(&a.tile_count[tile], 1u);
-                atomicAdd(&a.counters[C_STATS + 4], 1u);
+                st_pairs++;
             }
         };
         if (ntiles && ntiles <= 4)
@@ -254,6 +301,7 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
             for (uint32_t i = lane; i < count; i += 64) visit((bview * a.tiles_y + by0 + i / bw) * a.tiles_x + bx0 + i % bw, base + (uint32_t)src);
         }
     }
+    if (!FILL) flush_stat(&a.counters[C_STATS + 4], st_pairs);
 }
 
 // ---- K5: one workgroup per tile -----------------------------------------------------------------------------------------------------
@@ -277,17 +325,29 @@ SAH_DEV EdgeSetup edge_setup(const RasterRecord& rec) {
     e.area = (float)area;
     return e;
 }
-// coverage of pixel (px, py) and its screen-space barycentrics
+// coverage of pixel (px, py); on a hit, its screen-space barycentrics
 SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, float b[3]) {
     const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+    int64_t v[3];
     bool inside = true;
     for (int i = 0; i < 3; i++) {
         const int a = (i + 1) % 3;
-        const int64_t v = (int64_t)e.dx[i] * (cy - e.Y[a]) - (int64_t)e.dy[i] * (cx - e.X[a]);
-        inside = inside && (v > 0 || (v == 0 && e.tl[i]));
-        b[i] = (float)v / e.area;
+        v[i] = (int64_t)e.dx[i] * (cy - e.Y[a]) - (int64_t)e.dy[i] * (cx - e.X[a]);
+        inside = inside && (v[i] > 0 || (v[i] == 0 && e.tl[i]));
     }
+    if (inside)
+        for (int i = 0; i < 3; i++) b[i] = (float)v[i] / e.area;
     return inside;
+}
+// no pixel centre of the 8x8 block at (ox, oy) can be inside: some edge function is negative at its most favourable corner
+SAH_DEV bool block_outside(const EdgeSetup& e, int32_t ox, int32_t oy) {
+    const int32_t cx0 = ox * 256 + 128, cy0 = oy * 256 + 128, span = 7 * 256;
+    for (int i = 0; i < 3; i++) {
+        const int a = (i + 1) % 3;
+        const int32_t cy = e.dx[i] > 0 ? cy0 + span : cy0, cx = e.dy[i] < 0 ? cx0 + span : cx0;
+        if ((int64_t)e.dx[i] * (cy - e.Y[a]) - (int64_t)e.dy[i] * (cx - e.X[a]) < 0) return true;
+    }
+    return false;
 }
 SAH_DEV float fragment_depth(const EdgeSetup& e, const float b[3]) {
     const float z = (b[0] * e.z[0] + b[1] * e.z[1]) + b[2] * e.z[2];
@@ -301,18 +361,9 @@ SAH_DEV void input_barycentrics(const RasterAttr& at, const float b[3], float la
     const float l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
     for (int k = 0; k < 3; k++) lambda[k] = (l0 * at.bary[0][k] + l1 * at.bary[1][k]) + l2 * at.bary[2][k];
 }
-SAH_DEV float interp_h(const float lambda[3], float a, float b, float c) { return rh((lambda[0] * a + lambda[1] * b) + lambda[2] * c); }
-SAH_DEV float unorm8_channel(uint32_t packed, int k) { return (float)((packed >> (8 * k)) & 0xffu) / 255.0f; }
-SAH_DEV Hn hmul(Hn a, Hn b) { return a * b; }
-
-// alpha of tinted_base_color (gltf_basic_pbr.slang:181-189)
-SAH_DEV float tinted_alpha(const RasterArgs& a, const RasterAttr& at, const float lambda[3]) {
-    const sah_primitive& prim = a.primitives[at.primitive];
-    float ca[3];
-    for (int k = 0; k < 3; k++) ca[k] = rh(unorm8_channel(a.vertex_data[(int64_t)prim.vertex_offset + a.indices[at.first_index + k]].color, 3));
-    const sah_material& m = a.materials[prim.material];
-    const Hn alpha = Hn(m.base_color_texel[3]) * Hn(interp_h(lambda, ca[0], ca[1], ca[2])) * Hn(m.base_color_tint[3]);
-    return tof(alpha);
+// varying `c` of the three vertices, interpolated in fp32 and rounded to half
+SAH_DEV Hn interp_h(const RasterAttr& at, const float lambda[3], int c) {
+    return Hn((lambda[0] * h2f(at.vout[0][c]) + lambda[1] * h2f(at.vout[1][c])) + lambda[2] * h2f(at.vout[2][c]));
 }
 
 SAH_DEV uint32_t unorm8_of(float c) {  // floor(c * 255 + 0.5) in fp32, clamped, NaN -> 0
@@ -333,44 +384,29 @@ SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_in
     } else {
         if (!(z > 0.0f)) return;  // cannot pass GREATER against the cleared 0
         const RasterAttr& at = a.attrs[rec_index];
-        if (at.cutout) {
+        if (at.cutout) {  // alpha of tinted_base_color against the threshold (gltf_basic_pbr.slang:181-189)
             float lambda[3];
             input_barycentrics(at, b, lambda);
-            if (tinted_alpha(a, at, lambda) <= a.materials[a.primitives[at.primitive].material].opacity_threshold) return;
+            const sah_material& m = a.materials[at.material];
+            const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
+            if (tof(alpha) <= m.opacity_threshold) return;
         }
         atomicMax(&s_key[slot], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xffffffffu - at.seq));
     }
 }
 
-SAH_DEV void rotate_normalize(const float* m, const float v[3], float out[3]) {
-    float r[3];
-    for (int i = 0; i < 3; i++) r[i] = (m[i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2];
-    const float inv = 1.0f / __builtin_sqrtf((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
-    for (int i = 0; i < 3; i++) out[i] = rh(r[i] * inv);
-}
-
 // fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_MAIN_VIEW, constant textures)
 SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px, int32_t py, float z) {
-    const RasterRecord& rec = a.records[rec_index];
     const RasterAttr& at = a.attrs[rec_index];
-    const EdgeSetup e = edge_setup(rec);
-    float b[3], lambda[3];
+    const EdgeSetup e = edge_setup(a.records[rec_index]);
+    float b[3] = {0.f, 0.f, 0.f}, lambda[3];
     cover(e, px, py, b);
     input_barycentrics(at, b, lambda);
-    const sah_primitive& prim = a.primitives[at.primitive];
-    const sah_material& m = a.materials[prim.material];
-    float color[3][4], normal[3][3], tangent[3][4];
-    for (int k = 0; k < 3; k++) {
-        const sah_vertex_data& vd = a.vertex_data[(int64_t)prim.vertex_offset + a.indices[at.first_index + k]];
-        for (int c = 0; c < 4; c++) color[k][c] = rh(unorm8_channel(vd.color, c));
-        rotate_normalize(prim.model, vd.normal, normal[k]);
-        rotate_normalize(prim.model, vd.tangent, tangent[k]);
-        tangent[k][3] = rh(vd.tangent[3]);
-    }
+    const sah_material& m = a.materials[at.material];
     Hn col[4], N[3], T[4];
-    for (int c = 0; c < 4; c++) col[c] = Hn(interp_h(lambda, color[0][c], color[1][c], color[2][c]));
-    for (int c = 0; c < 3; c++) N[c] = Hn(interp_h(lambda, normal[0][c], normal[1][c], normal[2][c]));
-    for (int c = 0; c < 4; c++) T[c] = Hn(interp_h(lambda, tangent[0][c], tangent[1][c], tangent[2][c]));
+    for (int c = 0; c < 4; c++) col[c] = interp_h(at, lambda, c);
+    for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
+    for (int c = 0; c < 4; c++) T[c] = interp_h(at, lambda, 7 + c);
     Hn tinted[4];
     for (int c = 0; c < 4; c++) tinted[c] = Hn(m.base_color_texel[c]) * col[c] * Hn(m.base_color_tint[c]);
     // bitangent = cross(normal, tangent.xyz) * tangent.w; normal = normal_sample * TBN (:197-207)
@@ -430,13 +466,16 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
         while (big) {
             const int src = __builtin_ctzll(big);
             big &= big - 1;
-            const uint32_t ri = __shfl(rec_index, src, 64);
-            const int32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64), by0 = __shfl(y0, src, 64), by1 = __shfl(y1, src, 64);
+            // readfirstlane: the record and everything derived from it is wave-uniform (scalar loads, scalar edge set-up)
+            const uint32_t ri = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(rec_index, src, 64));
+            const int32_t bx0 = __builtin_amdgcn_readfirstlane(__shfl(x0, src, 64)), bx1 = __builtin_amdgcn_readfirstlane(__shfl(x1, src, 64));
+            const int32_t by0 = __builtin_amdgcn_readfirstlane(__shfl(y0, src, 64)), by1 = __builtin_amdgcn_readfirstlane(__shfl(y1, src, 64));
             const EdgeSetup e = edge_setup(a.records[ri]);
             // lanes form an 8x8 block that sweeps the clipped bounding box
             const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
             for (int32_t oy = by0; oy <= by1; oy += 8)
                 for (int32_t ox = bx0; ox <= bx1; ox += 8) {
+                    if (block_outside(e, ox, oy)) continue;
                     const int32_t px = ox + lx, py = oy + ly;
                     if (px <= bx1 && py <= by1) test_pixel<GBUFFER>(a, e, ri, px, py, tile_x, tile_y, s_depth, s_key);
                 }

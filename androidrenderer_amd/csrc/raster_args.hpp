@@ -21,11 +21,12 @@ struct RasterAttr {
     float inv_w[3];
     float bary[3][3];      // barycentric coordinates of the record's vertices in the input triangle (identity unless clipped)
     uint32_t primitive;
-    uint32_t first_index;  // of the input triangle, in the index stream
+    uint32_t material;
     uint32_t seq;          // draw order: (running triangle number) * 8 + fan index
     uint32_t cutout;
+    uint16_t vout[3][12];  // fp16 varyings of the input triangle's vertices: colour rgba, normal xyz, tangent xyzw, pad
 };
-static_assert(sizeof(RasterAttr) == 64, "RasterAttr layout");
+static_assert(sizeof(RasterAttr) == 136, "RasterAttr layout");
 
 struct RasterArgs {
     // scene
