@@ -16,7 +16,7 @@ hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st
 
 namespace {
 constexpr uint32_t kTile = 64;
-constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^29
+constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^24.1
 enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ };
 
 int ensure(sah_ctx* ctx, int slot, size_t bytes) {

@@ -19,8 +19,8 @@ namespace sah {
 namespace {
 
 constexpr int kTile = 64;               // pixels per tile edge
-constexpr float kGuardBand = 256.0f;    // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
-constexpr float kCoordLimit = 0x1p29f;  // snapped coordinates beyond this drop the triangle
+constexpr float kGuardBand = 16.0f;     // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
+constexpr float kCoordLimit = 0x1p24f + 4096.0f;  // snapped coordinates beyond this drop the triangle: edge functions stay below 2^52
 constexpr uint32_t kSmallArea = 16;     // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone
 
 enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_STATS = 4 };  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
@@ -305,47 +305,48 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
 }
 
 // ---- K5: one workgroup per tile -----------------------------------------------------------------------------------------------------
+// Edge functions in fp64.  Window coordinates are integers below 2^24.1 (guard band 16 half-viewports of at most 8192 pixels, 8
+// sub-pixel bits), so every product and sum below is an integer of magnitude < 2^52: fp64 evaluates it EXACTLY, and (float)E is the
+// single correctly rounded conversion of the integer the specification talks about.  E_i(px, py) = c_i + px a_i + py b_i.
 struct EdgeSetup {
-    int32_t X[3], Y[3];
-    int32_t dx[3], dy[3];  // edge i runs from vertex i+1 to vertex i+2
+    double a[3], b[3], c[3];
     bool tl[3];
     float z[3];
-    float area;
+    float inv_area;
 };
 SAH_DEV EdgeSetup edge_setup(const RasterRecord& rec) {
     EdgeSetup e;
-    for (int i = 0; i < 3; i++) { e.X[i] = rec.X[i]; e.Y[i] = rec.Y[i]; e.z[i] = rec.z[i]; }
     for (int i = 0; i < 3; i++) {
-        const int a = (i + 1) % 3, b = (i + 2) % 3;
-        e.dx[i] = e.X[b] - e.X[a];
-        e.dy[i] = e.Y[b] - e.Y[a];
-        e.tl[i] = e.dy[i] < 0 || (e.dy[i] == 0 && e.dx[i] > 0);
+        const int va = (i + 1) % 3, vb = (i + 2) % 3;  // edge i runs from vertex i+1 to vertex i+2
+        const int32_t dx = rec.X[vb] - rec.X[va], dy = rec.Y[vb] - rec.Y[va];
+        e.tl[i] = dy < 0 || (dy == 0 && dx > 0);
+        e.a[i] = -256.0 * (double)dy;
+        e.b[i] = 256.0 * (double)dx;
+        e.c[i] = (double)dx * (double)(128 - rec.Y[va]) - (double)dy * (double)(128 - rec.X[va]);
+        e.z[i] = rec.z[i];
     }
-    const int64_t area = (int64_t)(e.X[1] - e.X[0]) * (e.Y[2] - e.Y[0]) - (int64_t)(e.X[2] - e.X[0]) * (e.Y[1] - e.Y[0]);
-    e.area = (float)area;
+    const double area = (double)(rec.X[1] - rec.X[0]) * (double)(rec.Y[2] - rec.Y[0]) - (double)(rec.X[2] - rec.X[0]) * (double)(rec.Y[1] - rec.Y[0]);
+    e.inv_area = 1.0f / (float)area;
     return e;
 }
 // coverage of pixel (px, py); on a hit, its screen-space barycentrics
 SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, float b[3]) {
-    const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
-    int64_t v[3];
+    const double x = (double)px, y = (double)py;
+    double v[3];
     bool inside = true;
     for (int i = 0; i < 3; i++) {
-        const int a = (i + 1) % 3;
-        v[i] = (int64_t)e.dx[i] * (cy - e.Y[a]) - (int64_t)e.dy[i] * (cx - e.X[a]);
-        inside = inside && (v[i] > 0 || (v[i] == 0 && e.tl[i]));
+        v[i] = __builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i]));
+        inside = inside && (v[i] > 0.0 || (v[i] == 0.0 && e.tl[i]));
     }
     if (inside)
-        for (int i = 0; i < 3; i++) b[i] = (float)v[i] / e.area;
+        for (int i = 0; i < 3; i++) b[i] = (float)v[i] * e.inv_area;
     return inside;
 }
 // no pixel centre of the 8x8 block at (ox, oy) can be inside: some edge function is negative at its most favourable corner
 SAH_DEV bool block_outside(const EdgeSetup& e, int32_t ox, int32_t oy) {
-    const int32_t cx0 = ox * 256 + 128, cy0 = oy * 256 + 128, span = 7 * 256;
     for (int i = 0; i < 3; i++) {
-        const int a = (i + 1) % 3;
-        const int32_t cy = e.dx[i] > 0 ? cy0 + span : cy0, cx = e.dy[i] < 0 ? cx0 + span : cx0;
-        if ((int64_t)e.dx[i] * (cy - e.Y[a]) - (int64_t)e.dy[i] * (cx - e.X[a]) < 0) return true;
+        const double x = (double)(e.a[i] > 0.0 ? ox + 7 : ox), y = (double)(e.b[i] > 0.0 ? oy + 7 : oy);
+        if (__builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i])) < 0.0) return true;
     }
     return false;
 }

@@ -19,8 +19,8 @@ namespace orc {
 namespace {
 
 constexpr int kSubPixel = 256;             // 8 sub-pixel bits
-constexpr float kGuardBand = 256.0f;       // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
-constexpr int64_t kCoordLimit = 1ll << 29; // snapped coordinates beyond this drop the triangle
+constexpr float kGuardBand = 16.0f;        // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
+constexpr int64_t kCoordLimit = (1ll << 24) + 4096;  // snapped coordinates beyond this drop the triangle (edge functions stay below 2^52)
 
 struct ClipVertex {
     F c[4];     // clip-space x y z w
@@ -120,7 +120,7 @@ void raster_triangle(RasterVertex v0, RasterVertex v1, RasterVertex v2, bool cul
     if (x0 > x1 || y0 > y1) { st.w[1]++; return; }
     st.w[3]++;
     const RasterVertex* v[3] = {&v0, &v1, &v2};
-    const F farea = F((float)area);
+    const F inv_area = F(1.0f) / F((float)area);
     for (int64_t py = y0; py <= y1; py++)
         for (int64_t px = x0; px <= x1; px++) {
             const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
@@ -136,7 +136,7 @@ void raster_triangle(RasterVertex v0, RasterVertex v1, RasterVertex v2, bool cul
             Fragment f;
             f.x = (int)px;
             f.y = (int)py;
-            const F b0 = F((float)e[0]) / farea, b1 = F((float)e[1]) / farea, b2 = F((float)e[2]) / farea;
+            const F b0 = F((float)e[0]) * inv_area, b1 = F((float)e[1]) * inv_area, b2 = F((float)e[2]) * inv_area;
             f.z = b0 * v0.z + b1 * v1.z + b2 * v2.z;
             const F q0 = b0 * v0.inv_w, q1 = b1 * v1.inv_w, q2 = b2 * v2.inv_w;
             const F s = q0 + q1 + q2;
