@@ -17,7 +17,7 @@ hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st
 namespace {
 constexpr uint32_t kTile = 64;
 constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^24.1
-enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ };
+enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ };
 
 int ensure(sah_ctx* ctx, int slot, size_t bytes) {
     auto& r = ctx->raster;
@@ -75,8 +75,11 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
     if (int rc = ensure(ctx, S_TRI_BASE, (size_t)(scene->num_primitives + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
     if (int rc = ensure(ctx, S_TILES, (size_t)ntiles * 3 * sizeof(uint32_t)); rc != SAH_OK) return rc;
     // first guess: every index triple is drawn once per view and survives; instanced index ranges or clipping can exceed it
-    size_t want_records = (size_t)(scene->num_indices / 3) * a.num_views + 1024;
+    size_t want_records = (size_t)(scene->num_indices / 3) * a.num_views + 1024, want_clipped = want_records / 8 + 1024;
     for (int attempt = 0; attempt < 3; attempt++) {
+        if (int rc = ensure(ctx, S_CLIPQ, want_clipped * sizeof(uint2)); rc != SAH_OK) return rc;
+        a.clip_queue = (uint2*)r.ptr[S_CLIPQ];
+        a.clip_capacity = (uint32_t)std::min<size_t>(r.bytes[S_CLIPQ] / sizeof(uint2), 0xffffffffu);
         if (int rc = ensure(ctx, S_RECORDS, want_records * sizeof(sah::RasterRecord)); rc != SAH_OK) return rc;
         if (gbuffer)
             if (int rc = ensure(ctx, S_ATTRS, want_records * sizeof(sah::RasterAttr)); rc != SAH_OK) return rc;
@@ -92,9 +95,13 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         HIP_TRY(ctx, sah::launch_raster_setup(a, gbuffer, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(r.host_counters, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (r.host_counters[1] <= a.record_capacity) break;
-        if (attempt == 2) return fail(ctx, SAH_ERR_HIP, "rasteriser: record buffer still too small after regrowing");
-        want_records = r.host_counters[1];
+        // records: one slot per (view, triangle) plus the appended fans of the clipped ones
+        const size_t need_records = (size_t)r.host_counters[0] * a.num_views + r.host_counters[1];
+        if (need_records <= a.record_capacity && r.host_counters[3] <= a.clip_capacity) break;
+        if (attempt == 2) return fail(ctx, SAH_ERR_HIP, "rasteriser: scratch buffers still too small after regrowing");
+        // a short clip queue also hides records: size both for the worst case of what was seen
+        want_clipped = std::max<size_t>(want_clipped, r.host_counters[3]);
+        want_records = std::max<size_t>(want_records, need_records + 7 * (size_t)r.host_counters[3]);
     }
     const uint32_t total_tris = r.host_counters[0], pairs = r.host_counters[2];
     if (total_tris >= (1u << 28)) return fail(ctx, SAH_ERR_UNSUPPORTED, "rasteriser: more than 2^28 triangles in one pass");

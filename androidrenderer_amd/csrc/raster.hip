@@ -22,8 +22,9 @@ constexpr int kTile = 64;               // pixels per tile edge
 constexpr float kGuardBand = 16.0f;     // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
 constexpr float kCoordLimit = 0x1p24f + 4096.0f;  // snapped coordinates beyond this drop the triangle: edge functions stay below 2^52
 constexpr uint32_t kSmallArea = 16;     // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone
+constexpr uint32_t kMediumArea = 1024;  // ... up to which one wave does; above, the whole workgroup
 
-enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_STATS = 4 };  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
+enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4 };  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
 
 struct ClipVertex {
     float c[4];
@@ -144,9 +145,19 @@ SAH_DEV uint32_t wave_sum(uint32_t v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
-SAH_DEV void flush_stat(uint32_t* counter, uint32_t local) {  // every lane of the wave must call this
-    const uint32_t total = wave_sum(local);
-    if ((threadIdx.x & 63u) == 0 && total) atomicAdd(counter, total);
+// Adds the workgroup's sum of `local[i]` to counter[i], one global atomic per counter and workgroup (every thread must call this;
+// `s_acc` is N words of LDS).  The counters are single addresses and such atomics complete at a few tens of nanoseconds each, device
+// wide: per-wave flushes of four counters cost more than the set-up work itself.
+template <int N>
+SAH_DEV void block_flush(uint32_t* counter, const uint32_t (&local)[N], uint32_t* s_acc) {
+    if (threadIdx.x < N) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = 0; i < N; i++) {
+        const uint32_t total = wave_sum(local[i]);
+        if ((threadIdx.x & 63u) == 0 && total) atomicAdd(&s_acc[i], total);
+    }
+    __syncthreads();
+    if (threadIdx.x < N && s_acc[threadIdx.x]) atomicAdd(&counter[threadIdx.x], s_acc[threadIdx.x]);
 }
 // slot for the lanes that `want` one: the first of them adds the count, the rest take consecutive slots
 SAH_DEV uint32_t wave_alloc(uint32_t* counter, bool want) {
@@ -178,89 +189,144 @@ SAH_DEV void vertex_outputs(const sah_primitive& prim, const sah_vertex_data& vd
     out[11] = 0;
 }
 
+constexpr uint32_t kAppend = 0xffffffffu;
+SAH_DEV void mark_empty(RasterRecord& r) { r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0; }
+SAH_DEV bool is_empty(const RasterRecord& r) { return r.x0 > r.x1; }
+SAH_DEV uint32_t record_count(const RasterArgs& a) {  // direct slots + appended fans, clamped to the buffer
+    const uint64_t n = (uint64_t)a.counters[C_TRIS] * a.num_views + a.counters[C_RECORDS];
+    return n < a.record_capacity ? (uint32_t)n : a.record_capacity;
+}
+
+struct SetupStats {
+    uint32_t in = 0, culled = 0, dropped = 0, raster = 0;
+};
+
+// One window-space triangle of the fan: facing, bounding box, record.
+template <bool GBUFFER>
+SAH_DEV void emit_triangle(const RasterArgs& a, SetupStats& st, uint32_t view, uint32_t p, const sah_primitive& prim, uint32_t tri, uint32_t seq,
+                           const WindowVertex& v0, WindowVertex v1, WindowVertex v2, uint32_t slot) {
+    if (!v0.finite || !v1.finite || !v2.finite) { st.dropped++; return; }
+    const int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
+    if (area == 0 || (area < 0 && prim.type == SAH_PRIMITIVE_TYPE_SOLID)) { st.culled++; return; }
+    if (area < 0) { const WindowVertex s = v1; v1 = v2; v2 = s; }
+    const int32_t minx = min(v0.X, min(v1.X, v2.X)), maxx = max(v0.X, max(v1.X, v2.X));
+    const int32_t miny = min(v0.Y, min(v1.Y, v2.Y)), maxy = max(v0.Y, max(v1.Y, v2.Y));
+    const int32_t x0 = first_px(minx), x1 = last_px(maxx, a.width), y0 = first_px(miny), y1 = last_px(maxy, a.height);
+    if (x0 > x1 || y0 > y1) { st.culled++; return; }
+    st.raster++;
+    // Unclipped triangles own the slot of their work item (no allocation: a single-address atomic per wave was the bottleneck of this
+    // kernel); the fans of clipped ones are appended behind those.
+    const uint32_t r = slot != kAppend ? slot : a.counters[C_TRIS] * a.num_views + wave_alloc(&a.counters[C_RECORDS], true);
+    if (r >= a.record_capacity) return;  // the host sees the counts, grows the buffer and runs the pass again
+    RasterRecord rec;
+    rec.X[0] = v0.X; rec.X[1] = v1.X; rec.X[2] = v2.X;
+    rec.Y[0] = v0.Y; rec.Y[1] = v1.Y; rec.Y[2] = v2.Y;
+    rec.z[0] = v0.z; rec.z[1] = v1.z; rec.z[2] = v2.z;
+    rec.view = view;
+    rec.x0 = (uint16_t)x0; rec.x1 = (uint16_t)x1; rec.y0 = (uint16_t)y0; rec.y1 = (uint16_t)y1;
+    rec.seq = seq;
+    rec.cutout = GBUFFER && prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
+    a.records[r] = rec;
+    if (GBUFFER) {
+        RasterAttr at;
+        at.inv_w[0] = v0.inv_w; at.inv_w[1] = v1.inv_w; at.inv_w[2] = v2.inv_w;
+        for (int k = 0; k < 3; k++) { at.bary[0][k] = v0.bary[k]; at.bary[1][k] = v1.bary[k]; at.bary[2][k] = v2.bary[k]; }
+        at.primitive = p;
+        at.material = prim.material;
+        at.seq = seq;
+        at.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
+        for (int k = 0; k < 3; k++)
+            vertex_outputs(prim, a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]], at.vout[k]);
+        a.attrs[r] = at;
+    }
+}
+
+// vertex stage of corner k of input triangle `tri` (gltf_basic_pbr.slang:126-133)
+template <bool GBUFFER>
+SAH_DEV ClipVertex clip_vertex(const RasterArgs& a, const sah_primitive& prim, uint32_t view, uint32_t tri, int k) {
+    const uint32_t idx = a.indices[prim.first_index + 3 * tri + k];
+    const float* pos = a.positions + 3 * ((int64_t)prim.vertex_offset + idx);
+    const float local[4] = {pos[0], pos[1], pos[2], 1.0f};
+    float world[4], clip[4];
+    mat_vec(prim.model, local, world);
+    if (GBUFFER) {
+        float vs[4];
+        mat_vec(a.view_matrix, world, vs);
+        mat_vec(a.clip_matrix[0], vs, clip);
+    } else {
+        mat_vec(a.clip_matrix[view], world, clip);
+    }
+    ClipVertex c;
+    for (int j = 0; j < 4; j++) c.c[j] = clip[j];
+    for (int j = 0; j < 3; j++) c.bary[j] = j == k ? 1.0f : 0.0f;
+    return c;
+}
+
+// Rare path: the triangle crosses a clipping plane.  k_setup queues it and this kernel, launched right after, clips and fans it, so
+// that the polygon arrays (scratch memory) and their registers burden only the triangles that need them.
+template <bool GBUFFER>
+__global__ __launch_bounds__(256) void k_setup_clipped(const RasterArgs a) {
+    const uint32_t queued = min(a.counters[C_CLIPPED], a.clip_capacity);
+    SetupStats st;
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < queued; q += gridDim.x * 256) {
+        const uint32_t view = a.clip_queue[q].x, t = a.clip_queue[q].y;
+        const uint32_t p = find_primitive(a.tri_base, a.num_primitives, t);
+        const sah_primitive& prim = a.primitives[p];
+        const uint32_t tri = t - a.tri_base[p];
+        ClipVertex poly[12];
+        for (int k = 0; k < 3; k++) poly[k] = clip_vertex<GBUFFER>(a, prim, view, tri, k);
+        const int n = clip_polygon(poly, 3, GBUFFER ? 0 : 2);
+        if (n == 0) { st.culled++; continue; }
+        const WindowVertex v0 = to_window(poly[0], a.half_w, a.half_h);
+        WindowVertex prev = to_window(poly[1], a.half_w, a.half_h);
+        for (int i = 1; i + 1 < n; i++) {
+            const WindowVertex next = to_window(poly[i + 1], a.half_w, a.half_h);
+            emit_triangle<GBUFFER>(a, st, view, p, prim, tri, t * 8u + (uint32_t)(i - 1), v0, prev, next, kAppend);
+            prev = next;
+        }
+    }
+    __shared__ uint32_t s_acc[4];
+    const uint32_t local[4] = {0u, st.culled, st.dropped, st.raster};
+    block_flush<4>(&a.counters[C_STATS], local, s_acc);
+}
+
 template <bool GBUFFER>
 __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
     const uint32_t total = a.counters[C_TRIS];
     const uint64_t work = (uint64_t)total * a.num_views;
-    uint32_t st_in = 0, st_culled = 0, st_dropped = 0, st_raster = 0;
+    SetupStats st;
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < work; w += (uint64_t)gridDim.x * 256) {
         const uint32_t view = (uint32_t)(w / total), t = (uint32_t)(w % total);
         const uint32_t p = find_primitive(a.tri_base, a.num_primitives, t);
         const sah_primitive& prim = a.primitives[p];
         const uint32_t tri = t - a.tri_base[p];
-        st_in++;
-        ClipVertex poly[12];
-        bool finite = true, inside = true;
+        st.in++;
+        if (w < a.record_capacity) mark_empty(a.records[w]);  // overwritten below if the triangle survives unclipped
         // a draw that points outside the index / vertex / material arrays is dropped, never dereferenced
         bool in_range = (uint64_t)prim.first_index + 3ull * tri + 3ull <= a.num_indices && (!GBUFFER || prim.material < a.num_materials);
         for (int k = 0; k < 3 && in_range; k++) {
             const int64_t v = (int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k];
             in_range = v >= 0 && v < (int64_t)a.num_vertices;
         }
-        if (!in_range) { st_dropped++; continue; }
-        for (int k = 0; k < 3; k++) {
-            const uint32_t idx = a.indices[prim.first_index + 3 * tri + k];
-            const float* pos = a.positions + 3 * ((int64_t)prim.vertex_offset + idx);
-            const float local[4] = {pos[0], pos[1], pos[2], 1.0f};
-            float world[4], clip[4];
-            mat_vec(prim.model, local, world);
-            if (GBUFFER) {
-                float vs[4];
-                mat_vec(a.view_matrix, world, vs);
-                mat_vec(a.clip_matrix[0], vs, clip);
-            } else {
-                mat_vec(a.clip_matrix[view], world, clip);
-            }
-            for (int j = 0; j < 4; j++) { poly[k].c[j] = clip[j]; finite = finite && is_finite(clip[j]); }
-            for (int j = 0; j < 3; j++) poly[k].bary[j] = j == k ? 1.0f : 0.0f;
-            for (int plane = GBUFFER ? 0 : 2; plane < 6; plane++) inside = inside && plane_distance(poly[k], plane) >= 0.0f;
-        }
-        if (!finite) { st_dropped++; continue; }
-        int n = 3;
-        if (!inside) n = clip_polygon(poly, 3, GBUFFER ? 0 : 2);
-        if (n == 0) { st_culled++; continue; }
-        const bool cull_back = prim.type == SAH_PRIMITIVE_TYPE_SOLID;
-        const WindowVertex v0 = to_window(poly[0], a.half_w, a.half_h);
-        WindowVertex prev = to_window(poly[1], a.half_w, a.half_h);
-        for (int i = 1; i + 1 < n; i++) {
-            WindowVertex v1 = prev, v2 = to_window(poly[i + 1], a.half_w, a.half_h);
-            prev = v2;
-            if (!v0.finite || !v1.finite || !v2.finite) { st_dropped++; continue; }
-            int64_t area = (int64_t)(v1.X - v0.X) * (v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (v1.Y - v0.Y);
-            if (area == 0 || (area < 0 && cull_back)) { st_culled++; continue; }
-            if (area < 0) { const WindowVertex s = v1; v1 = v2; v2 = s; }
-            const int32_t minx = min(v0.X, min(v1.X, v2.X)), maxx = max(v0.X, max(v1.X, v2.X));
-            const int32_t miny = min(v0.Y, min(v1.Y, v2.Y)), maxy = max(v0.Y, max(v1.Y, v2.Y));
-            const int32_t x0 = first_px(minx), x1 = last_px(maxx, a.width), y0 = first_px(miny), y1 = last_px(maxy, a.height);
-            if (x0 > x1 || y0 > y1) { st_culled++; continue; }
-            st_raster++;
-            const uint32_t r = wave_alloc(&a.counters[C_RECORDS], true);
-            if (r >= a.record_capacity) continue;  // the host sees the count, grows the buffer and runs the pass again
-            RasterRecord rec;
-            rec.X[0] = v0.X; rec.X[1] = v1.X; rec.X[2] = v2.X;
-            rec.Y[0] = v0.Y; rec.Y[1] = v1.Y; rec.Y[2] = v2.Y;
-            rec.z[0] = v0.z; rec.z[1] = v1.z; rec.z[2] = v2.z;
-            rec.view = view;
-            rec.x0 = (uint16_t)x0; rec.x1 = (uint16_t)x1; rec.y0 = (uint16_t)y0; rec.y1 = (uint16_t)y1;
-            a.records[r] = rec;
-            if (GBUFFER) {
-                RasterAttr at;
-                at.inv_w[0] = v0.inv_w; at.inv_w[1] = v1.inv_w; at.inv_w[2] = v2.inv_w;
-                for (int k = 0; k < 3; k++) { at.bary[0][k] = v0.bary[k]; at.bary[1][k] = v1.bary[k]; at.bary[2][k] = v2.bary[k]; }
-                at.primitive = p;
-                at.material = prim.material;
-                at.seq = t * 8u + (uint32_t)(i - 1);
-                at.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
-                for (int k = 0; k < 3; k++)
-                    vertex_outputs(prim, a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]], at.vout[k]);
-                a.attrs[r] = at;
-            }
+        if (!in_range) { st.dropped++; continue; }
+        const ClipVertex c0 = clip_vertex<GBUFFER>(a, prim, view, tri, 0), c1 = clip_vertex<GBUFFER>(a, prim, view, tri, 1),
+                         c2 = clip_vertex<GBUFFER>(a, prim, view, tri, 2);
+        bool finite = true, inside = true;
+        for (int j = 0; j < 4; j++) finite = finite && is_finite(c0.c[j]) && is_finite(c1.c[j]) && is_finite(c2.c[j]);
+        for (int plane = GBUFFER ? 0 : 2; plane < 6; plane++)
+            inside = inside && plane_distance(c0, plane) >= 0.0f && plane_distance(c1, plane) >= 0.0f && plane_distance(c2, plane) >= 0.0f;
+        if (!finite) { st.dropped++; continue; }
+        if (inside) {
+            emit_triangle<GBUFFER>(a, st, view, p, prim, tri, t * 8u, to_window(c0, a.half_w, a.half_h), to_window(c1, a.half_w, a.half_h),
+                                   to_window(c2, a.half_w, a.half_h), w < a.record_capacity ? (uint32_t)w : a.record_capacity);
+        } else {
+            const uint32_t q = wave_alloc(&a.counters[C_CLIPPED], true);
+            if (q < a.clip_capacity) a.clip_queue[q] = make_uint2(view, t);  // overflow: the host sees the count and runs the pass again
         }
     }
-    flush_stat(&a.counters[C_STATS + 0], st_in);
-    flush_stat(&a.counters[C_STATS + 1], st_culled);
-    flush_stat(&a.counters[C_STATS + 2], st_dropped);
-    flush_stat(&a.counters[C_STATS + 3], st_raster);
+    __shared__ uint32_t s_acc[4];
+    const uint32_t local[4] = {st.in, st.culled, st.dropped, st.raster};
+    block_flush<4>(&a.counters[C_STATS], local, s_acc);
 }
 
 // ---- K2 / K4: binning -------------------------------------------------------------------------------------------------------------
@@ -268,18 +334,20 @@ __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
 // whole wave (ballot + readlane), lanes striding over the tiles of the bounding box.
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
-    const uint32_t nrec = min(a.counters[C_RECORDS], a.record_capacity);
+    const uint32_t nrec = record_count(a);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves = gridDim.x * 4u;
     uint32_t st_pairs = 0;
     for (uint32_t base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < nrec; base += waves * 64u) {
         const uint32_t r = base + lane;
         uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, view = 0;
+        bool live = false;
         if (r < nrec) {
             const RasterRecord& rec = a.records[r];
-            tx0 = rec.x0 / kTile; tx1 = rec.x1 / kTile; ty0 = rec.y0 / kTile; ty1 = rec.y1 / kTile; view = rec.view;
+            live = !is_empty(rec);
+            if (live) { tx0 = rec.x0 / kTile; tx1 = rec.x1 / kTile; ty0 = rec.y0 / kTile; ty1 = rec.y1 / kTile; view = rec.view; }
         }
-        const uint32_t ntiles = r < nrec ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
+        const uint32_t ntiles = live ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
         auto visit = [&](uint32_t tile, uint32_t rec_index) {
             if (FILL) {
                 const uint32_t pos = atomicAdd(&a.tile_cursor[tile], 1u);
@@ -289,7 +357,28 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
                 st_pairs++;
             }
         };
-        if (ntiles && ntiles <= 4)
+        // single-tile records (most of a dense mesh): neighbouring triangles land in the same few tiles, so the lanes that share a tile
+        // share one atomic — per-address atomic throughput is what bounds this kernel
+        uint64_t single = __ballot(ntiles == 1);
+        const uint32_t my_tile = (view * a.tiles_y + ty0) * a.tiles_x + tx0;
+        while (single) {
+            const int leader = __builtin_ctzll(single);
+            const uint32_t tile = __shfl(my_tile, leader, 64);
+            const uint64_t same = __ballot(ntiles == 1 && my_tile == tile) & single;
+            single &= ~same;
+            const uint32_t n = (uint32_t)__builtin_popcountll(same);
+            const bool mine = (same >> lane) & 1ull;
+            if (FILL) {
+                uint32_t first = 0;
+                if ((int)lane == leader) first = atomicAdd(&a.tile_cursor[tile], n);
+                first = __shfl(first, leader, 64);
+                if (mine) a.pairs[a.tile_offset[tile] + first + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull))] = r;
+            } else {
+                if ((int)lane == leader) atomicAdd(&a.tile_count[tile], n);
+                st_pairs += mine ? 1u : 0u;
+            }
+        }
+        if (ntiles > 1 && ntiles <= 4)
             for (uint32_t ty = ty0; ty <= ty1; ty++)
                 for (uint32_t tx = tx0; tx <= tx1; tx++) visit((view * a.tiles_y + ty) * a.tiles_x + tx, r);
         uint64_t wide = __ballot(ntiles > 4);
@@ -301,7 +390,9 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
             for (uint32_t i = lane; i < count; i += 64) visit((bview * a.tiles_y + by0 + i / bw) * a.tiles_x + bx0 + i % bw, base + (uint32_t)src);
         }
     }
-    if (!FILL) flush_stat(&a.counters[C_STATS + 4], st_pairs);
+    __shared__ uint32_t s_acc[1];
+    const uint32_t local[1] = {FILL ? 0u : st_pairs};
+    block_flush<1>(&a.counters[C_STATS + 4], local, s_acc);
 }
 
 // ---- K5: one workgroup per tile -----------------------------------------------------------------------------------------------------
@@ -310,16 +401,36 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
 // single correctly rounded conversion of the integer the specification talks about.  E_i(px, py) = c_i + px a_i + py b_i.
 struct EdgeSetup {
     double a[3], b[3], c[3];
-    bool tl[3];
+    uint32_t tl;  // bit i: edge i is a top or left edge
     float z[3];
     float inv_area;
+    uint32_t seq, cutout;
 };
+SAH_DEV uint32_t readlane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+SAH_DEV float readlane(float v, int src) { return __uint_as_float(readlane(__float_as_uint(v), src)); }
+SAH_DEV double readlane(double v, int src) {
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+    return __builtin_bit_cast(double, (uint64_t)readlane((uint32_t)bits, src) | ((uint64_t)readlane((uint32_t)(bits >> 32), src) << 32));
+}
+// lane `src`'s set-up, in scalar registers of every lane of the wave
+SAH_DEV EdgeSetup broadcast(const EdgeSetup& e, int src) {
+    EdgeSetup r;
+    for (int i = 0; i < 3; i++) { r.a[i] = readlane(e.a[i], src); r.b[i] = readlane(e.b[i], src); r.c[i] = readlane(e.c[i], src); r.z[i] = readlane(e.z[i], src); }
+    r.tl = readlane(e.tl, src);
+    r.inv_area = readlane(e.inv_area, src);
+    r.seq = readlane(e.seq, src);
+    r.cutout = readlane(e.cutout, src);
+    return r;
+}
 SAH_DEV EdgeSetup edge_setup(const RasterRecord& rec) {
     EdgeSetup e;
+    e.tl = 0;
+    e.seq = rec.seq;
+    e.cutout = rec.cutout;
     for (int i = 0; i < 3; i++) {
         const int va = (i + 1) % 3, vb = (i + 2) % 3;  // edge i runs from vertex i+1 to vertex i+2
         const int32_t dx = rec.X[vb] - rec.X[va], dy = rec.Y[vb] - rec.Y[va];
-        e.tl[i] = dy < 0 || (dy == 0 && dx > 0);
+        e.tl |= (dy < 0 || (dy == 0 && dx > 0)) ? 1u << i : 0u;
         e.a[i] = -256.0 * (double)dy;
         e.b[i] = 256.0 * (double)dx;
         e.c[i] = (double)dx * (double)(128 - rec.Y[va]) - (double)dy * (double)(128 - rec.X[va]);
@@ -336,7 +447,7 @@ SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, float b[3]) {
     bool inside = true;
     for (int i = 0; i < 3; i++) {
         v[i] = __builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i]));
-        inside = inside && (v[i] > 0.0 || (v[i] == 0.0 && e.tl[i]));
+        inside = inside && (v[i] > 0.0 || (v[i] == 0.0 && ((e.tl >> i) & 1u)));
     }
     if (inside)
         for (int i = 0; i < 3; i++) b[i] = (float)v[i] * e.inv_area;
@@ -384,15 +495,15 @@ SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_in
         atomicMin(&s_depth[slot], (uint32_t)__builtin_rintf(z * 65535.0f));
     } else {
         if (!(z > 0.0f)) return;  // cannot pass GREATER against the cleared 0
-        const RasterAttr& at = a.attrs[rec_index];
-        if (at.cutout) {  // alpha of tinted_base_color against the threshold (gltf_basic_pbr.slang:181-189)
+        if (e.cutout) {  // alpha of tinted_base_color against the threshold (gltf_basic_pbr.slang:181-189)
+            const RasterAttr& at = a.attrs[rec_index];
             float lambda[3];
             input_barycentrics(at, b, lambda);
             const sah_material& m = a.materials[at.material];
             const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
             if (tof(alpha) <= m.opacity_threshold) return;
         }
-        atomicMax(&s_key[slot], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xffffffffu - at.seq));
+        atomicMax(&s_key[slot], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xffffffffu - e.seq));
     }
 }
 
@@ -434,6 +545,13 @@ SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px
     *(float*)(a.out_depth.ptr + (size_t)py * a.out_depth.pitch + (size_t)px * 4) = z;
 }
 
+constexpr uint32_t kBigSlots = 64;  // workgroup-cooperative records per round of 256 list entries; the rest fall back to their wave
+struct BigRecord {
+    EdgeSetup e;
+    uint32_t rec_index;
+    int32_t x0, x1, y0, y1;
+};
+
 template <bool GBUFFER>
 __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
     __shared__ uint32_t s_depth[GBUFFER ? 1 : kTile * kTile];
@@ -446,35 +564,75 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
         if (GBUFFER) s_key[i] = 0ull; else s_depth[i] = 0xffffu;
     }
     __syncthreads();
+    // The tile's list in rounds of 256 entries, one per thread.  A record whose bounding box covers at most kSmallArea pixels of the
+    // tile is walked by its own lane, up to kMediumArea by its wave; the others go to an LDS list and are rasterised by the whole
+    // workgroup, one after the other: lanes form an 8x8 pixel block, the four waves take alternate block rows of the bounding box.
+    __shared__ BigRecord s_big[kBigSlots];
+    __shared__ uint32_t s_nbig;
+#ifdef SAH_EXP_RASTER_SKIP_LIST  // timing experiment: tile init + write-out only
+    const uint32_t begin = 0, count = 0;
+#else
     const uint32_t begin = a.tile_offset[tile], count = a.tile_count[tile];
-    for (uint32_t base = wave * 64u; base < count; base += 256u) {
-        const uint32_t li = base + lane;
-        uint32_t rec_index = 0;
+#endif
+    for (uint32_t base = 0; base < count; base += 256u) {
+        if (tid == 0) s_nbig = 0;
+        __syncthreads();
+        const uint32_t li = base + tid;
+        uint32_t rec_index = 0, area = 0;
         int32_t x0 = 1, x1 = 0, y0 = 1, y1 = 0;
+        EdgeSetup mine{};
+        bool medium_rec = false;
         if (li < count) {
             rec_index = a.pairs[begin + li];
-            const RasterRecord& rec = a.records[rec_index];
+            const RasterRecord rec = a.records[rec_index];
             x0 = max((int32_t)rec.x0, tile_x); x1 = min((int32_t)rec.x1, tile_x + kTile - 1);
             y0 = max((int32_t)rec.y0, tile_y); y1 = min((int32_t)rec.y1, tile_y + kTile - 1);
+            area = (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1));
+            mine = edge_setup(rec);  // every lane sets up its own record: 64 set-ups for the price of one
+            medium_rec = area > kSmallArea && area <= kMediumArea;
+            if (area <= kSmallArea) {
+                for (int32_t py = y0; py <= y1; py++)
+                    for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER>(a, mine, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
+            } else if (area > kMediumArea) {
+                const uint32_t slot = atomicAdd(&s_nbig, 1u);
+                if (slot < kBigSlots) {
+                    s_big[slot].e = mine;
+                    s_big[slot].rec_index = rec_index;
+                    s_big[slot].x0 = x0; s_big[slot].x1 = x1; s_big[slot].y0 = y0; s_big[slot].y1 = y1;
+                } else {
+                    medium_rec = true;  // list full: the wave does it
+                }
+            }
         }
-        const uint32_t area = li < count ? (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1)) : 0u;
-        if (area && area <= kSmallArea) {
-            const EdgeSetup e = edge_setup(a.records[rec_index]);
-            for (int32_t py = y0; py <= y1; py++)
-                for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER>(a, e, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
-        }
-        uint64_t big = __ballot(area > kSmallArea);
-        while (big) {
-            const int src = __builtin_ctzll(big);
-            big &= big - 1;
-            // readfirstlane: the record and everything derived from it is wave-uniform (scalar loads, scalar edge set-up)
-            const uint32_t ri = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(rec_index, src, 64));
-            const int32_t bx0 = __builtin_amdgcn_readfirstlane(__shfl(x0, src, 64)), bx1 = __builtin_amdgcn_readfirstlane(__shfl(x1, src, 64));
-            const int32_t by0 = __builtin_amdgcn_readfirstlane(__shfl(y0, src, 64)), by1 = __builtin_amdgcn_readfirstlane(__shfl(y1, src, 64));
-            const EdgeSetup e = edge_setup(a.records[ri]);
-            // lanes form an 8x8 block that sweeps the clipped bounding box
-            const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+        // medium records: one at a time by the wave that read them, lanes as an 8x8 block sweeping the clipped bounding box; the
+        // owner lane's set-up moves to scalar registers with v_readlane (no memory round trip per record)
+        uint64_t medium = __ballot(medium_rec);
+        while (medium) {
+            const int src = __builtin_ctzll(medium);
+            medium &= medium - 1;
+            const uint32_t ri = readlane(rec_index, src);
+            const int32_t bx0 = (int32_t)readlane((uint32_t)x0, src), bx1 = (int32_t)readlane((uint32_t)x1, src);
+            const int32_t by0 = (int32_t)readlane((uint32_t)y0, src), by1 = (int32_t)readlane((uint32_t)y1, src);
+            const EdgeSetup e = broadcast(mine, src);
             for (int32_t oy = by0; oy <= by1; oy += 8)
+                for (int32_t ox = bx0; ox <= bx1; ox += 8) {
+                    if (block_outside(e, ox, oy)) continue;
+                    const int32_t px = ox + (int32_t)(lane & 7u), py = oy + (int32_t)(lane >> 3);
+                    if (px <= bx1 && py <= by1) test_pixel<GBUFFER>(a, e, ri, px, py, tile_x, tile_y, s_depth, s_key);
+                }
+        }
+        __syncthreads();
+#ifdef SAH_EXP_RASTER_SKIP_BIG  // timing experiment: no workgroup-cooperative records
+        const uint32_t nbig = 0;
+#else
+        const uint32_t nbig = min(s_nbig, kBigSlots);
+#endif
+        const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+        for (uint32_t k = 0; k < nbig; k++) {
+            const EdgeSetup e = s_big[k].e;  // same address in every lane: an LDS broadcast
+            const uint32_t ri = s_big[k].rec_index;
+            const int32_t bx0 = s_big[k].x0, bx1 = s_big[k].x1, by0 = s_big[k].y0, by1 = s_big[k].y1;
+            for (int32_t oy = by0 + 8 * (int32_t)wave; oy <= by1; oy += 32)
                 for (int32_t ox = bx0; ox <= bx1; ox += 8) {
                     if (block_outside(e, ox, oy)) continue;
                     const int32_t px = ox + lx, py = oy + ly;
@@ -505,7 +663,11 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
             const int32_t px = tile_x + (int32_t)(i % kTile), py = tile_y + (int32_t)(i / kTile);
             if ((uint32_t)px >= a.width || (uint32_t)py >= a.height) continue;
             const unsigned long long key = s_key[i];
+#ifdef SAH_EXP_RASTER_SKIP_RESOLVE  // timing experiment: no fragment stage
+            if (true) {
+#else
             if (key == 0ull) {  // clear values, gbuffer_phase.cpp:66-87
+#endif
                 *(uint32_t*)(a.out_color.ptr + (size_t)py * a.out_color.pitch + (size_t)px * 4) = 0u;
                 *(uint2*)(a.out_normals.ptr + (size_t)py * a.out_normals.pitch + (size_t)px * 8) = make_uint2(0x38003800u, 0x00003c00u);
                 *(uint32_t*)(a.out_data.ptr + (size_t)py * a.out_data.pitch + (size_t)px * 4) = 0u;
@@ -521,8 +683,9 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
 
 // seq -> record index (G-buffer resolve)
 __global__ __launch_bounds__(256) void k_seq_table(const RasterArgs a) {
-    const uint32_t nrec = min(a.counters[C_RECORDS], a.record_capacity);
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256) a.seq_to_record[a.attrs[r].seq] = r;
+    const uint32_t nrec = record_count(a);
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256)
+        if (!is_empty(a.records[r])) a.seq_to_record[a.attrs[r].seq] = r;
 }
 
 }  // namespace
@@ -536,8 +699,13 @@ hipError_t launch_raster_setup(const RasterArgs& a, bool gbuffer, hipStream_t st
     if (e != hipSuccess) return e;
     if (a.num_primitives == 0) return hipSuccess;
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, a.primitives, (const uint32_t*)nullptr, a.num_primitives, a.tri_base, &a.counters[C_TRIS]);
-    if (gbuffer) hipLaunchKernelGGL(k_setup<true>, dim3(2048), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_setup<false>, dim3(2048), dim3(256), 0, st, a);
+    if (gbuffer) {
+        hipLaunchKernelGGL(k_setup<true>, dim3(1024), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_setup_clipped<true>, dim3(64), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_setup<false>, dim3(1024), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_setup_clipped<false>, dim3(64), dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(k_bin<false>, dim3(1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const sah_primitive*)nullptr, (const uint32_t*)a.tile_count, ntiles, a.tile_offset, &a.counters[C_PAIRS]);
     return hipGetLastError();

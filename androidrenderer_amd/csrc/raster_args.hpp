@@ -1,5 +1,6 @@
 // Kernel-argument block and scratch records of the scene rasteriser (raster.hip, api_raster.cpp).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/sah_hip.h"
@@ -12,9 +13,11 @@ struct RasterRecord {
     int32_t X[3], Y[3];
     float z[3];
     uint32_t view;
-    uint16_t x0, x1, y0, y1;  // candidate pixels (centres inside the bounding box), clipped to the viewport
+    uint16_t x0, x1, y0, y1;  // candidate pixels (centres inside the bounding box), clipped to the viewport; x0 > x1: empty slot
+    uint32_t seq;             // G-buffer: draw order, (running triangle number) * 8 + fan index
+    uint32_t cutout;          // G-buffer: alpha-tested primitive
 };
-static_assert(sizeof(RasterRecord) == 48, "RasterRecord layout");
+static_assert(sizeof(RasterRecord) == 56, "RasterRecord layout");
 
 // G-buffer pass only: what the fragment stage needs to interpolate the INPUT triangle's varyings.
 struct RasterAttr {
@@ -44,11 +47,13 @@ struct RasterArgs {
     float half_w, half_h;
     uint32_t tiles_x, tiles_y;
     // scratch (device)
-    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [4..11] stats
+    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats
     uint32_t* tri_base;  // num_primitives
     RasterRecord* records;
     RasterAttr* attrs;
     uint32_t record_capacity;
+    uint2* clip_queue;  // (view, running triangle number) of the triangles that cross a clipping plane
+    uint32_t clip_capacity;
     uint32_t* tile_count;   // num_views * tiles_y * tiles_x, followed by tile_cursor
     uint32_t* tile_cursor;
     uint32_t* tile_offset;
