@@ -54,8 +54,7 @@ SAH_DEV ClipVertex lerp_vertex(const ClipVertex& in, const ClipVertex& out, floa
     return r;
 }
 // Sutherland-Hodgman in place (rare path: most triangles are inside every plane and skip it)
-__device__ __noinline__ int clip_polygon(ClipVertex* poly, int n, int first_plane) {
-    ClipVertex tmp[12];
+SAH_DEV int clip_polygon(ClipVertex* poly, ClipVertex* tmp, int n, int first_plane) {
     for (int plane = first_plane; plane < 6 && n >= 3; plane++) {
         int m = 0;
         for (int i = 0; i < n; i++) {
@@ -265,17 +264,20 @@ SAH_DEV ClipVertex clip_vertex(const RasterArgs& a, const sah_primitive& prim, u
 // Rare path: the triangle crosses a clipping plane.  k_setup queues it and this kernel, launched right after, clips and fans it, so
 // that the polygon arrays (scratch memory) and their registers burden only the triangles that need them.
 template <bool GBUFFER>
-__global__ __launch_bounds__(256) void k_setup_clipped(const RasterArgs a) {
+__global__ __launch_bounds__(64) void k_setup_clipped(const RasterArgs a) {
+    // the polygons live in LDS, 12 vertices per lane and buffer: dynamically indexed private arrays would sit in scratch memory,
+    // and the clipping loop is one long chain of dependent accesses to them
+    __shared__ ClipVertex s_poly[64 * 12], s_tmp[64 * 12];
     const uint32_t queued = min(a.counters[C_CLIPPED], a.clip_capacity);
     SetupStats st;
-    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < queued; q += gridDim.x * 256) {
+    ClipVertex* poly = s_poly + threadIdx.x * 12;
+    for (uint32_t q = blockIdx.x * 64 + threadIdx.x; q < queued; q += gridDim.x * 64) {
         const uint32_t view = a.clip_queue[q].x, t = a.clip_queue[q].y;
         const uint32_t p = find_primitive(a.tri_base, a.num_primitives, t);
         const sah_primitive& prim = a.primitives[p];
         const uint32_t tri = t - a.tri_base[p];
-        ClipVertex poly[12];
         for (int k = 0; k < 3; k++) poly[k] = clip_vertex<GBUFFER>(a, prim, view, tri, k);
-        const int n = clip_polygon(poly, 3, GBUFFER ? 0 : 2);
+        const int n = clip_polygon(poly, s_tmp + threadIdx.x * 12, 3, GBUFFER ? 0 : 2);
         if (n == 0) { st.culled++; continue; }
         const WindowVertex v0 = to_window(poly[0], a.half_w, a.half_h);
         WindowVertex prev = to_window(poly[1], a.half_w, a.half_h);
@@ -701,10 +703,10 @@ hipError_t launch_raster_setup(const RasterArgs& a, bool gbuffer, hipStream_t st
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, a.primitives, (const uint32_t*)nullptr, a.num_primitives, a.tri_base, &a.counters[C_TRIS]);
     if (gbuffer) {
         hipLaunchKernelGGL(k_setup<true>, dim3(1024), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_setup_clipped<true>, dim3(64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_setup_clipped<true>, dim3(256), dim3(64), 0, st, a);
     } else {
         hipLaunchKernelGGL(k_setup<false>, dim3(1024), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_setup_clipped<false>, dim3(64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_setup_clipped<false>, dim3(256), dim3(64), 0, st, a);
     }
     hipLaunchKernelGGL(k_bin<false>, dim3(1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const sah_primitive*)nullptr, (const uint32_t*)a.tile_count, ntiles, a.tile_offset, &a.counters[C_PAIRS]);
