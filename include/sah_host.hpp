@@ -174,6 +174,18 @@ inline Vec3 v_normalize(Vec3 a) {
     const float inv = 1.0f / std::sqrt(v_dot(a, a));
     return {a[0] * inv, a[1] * inv, a[2] * inv};
 }
+inline Mat4 ortho(float left, float right, float bottom, float top, float z_near, float z_far) {  // glm::ortho, RH, depth 0..1
+    Mat4 m{};
+    m[0] = 2.f / (right - left); m[5] = 2.f / (top - bottom); m[10] = -1.f / (z_far - z_near);
+    m[12] = -(right + left) / (right - left); m[13] = -(top + bottom) / (top - bottom); m[14] = -z_near / (z_far - z_near); m[15] = 1.f;
+    return m;
+}
+inline Mat4 perspective_fov(float fov, float width, float height, float z_near, float z_far) {  // glm::perspectiveFov, RH, depth 0..1
+    const float h = std::cos(0.5f * fov) / std::sin(0.5f * fov), w = h * height / width;
+    Mat4 m{};
+    m[0] = w; m[5] = h; m[10] = z_far / (z_near - z_far); m[11] = -1.f; m[14] = -(z_far * z_near) / (z_far - z_near);
+    return m;
+}
 inline Mat4 look_at(Vec3 eye, Vec3 center, Vec3 up) {  // glm::lookAt, right-handed
     const Vec3 f = v_normalize(v_sub(center, eye)), s = v_normalize(v_cross(f, up)), u = v_cross(s, f);
     Mat4 m = mat_identity();
@@ -193,6 +205,8 @@ public:
     void set_perspective_projection(float fov_in, float aspect_in, float near_in) { fov = fov_in; aspect = aspect_in; near_value = near_in; }
     Vec3 get_position() const { return position; }
     Vec3 get_forward() const { return forward; }
+    float get_fov() const { return fov; }  // degrees (scene_view.cpp:95-97)
+    float get_aspect_ratio() const { return aspect; }
     float get_near() const { return near_value; }
     const sah_view_data& get_gpu_data() const { return gpu_data; }
     void update_transforms() {
@@ -235,6 +249,57 @@ public:
         for (int i = 0; i < 3; i++) constants.direction_and_tan_size[i] = n[i];
         constants.direction_and_tan_size[3] = std::tan(0.545f * 3.14159265358979f / 180.0f);
     }
+    // directional_light.cpp:84-230: practical split scheme (lambda blend of logarithmic and uniform splits), a bounding sphere per
+    // slice of the camera frustum, radius doubled and snapped to 1/16, an orthographic light frustum looking at the sphere centre.
+    // glm::perspectiveFov receives get_fov() — degrees — where it expects radians, as in the reference (:164-170).
+    void update_shadow_cascades(const SceneView& view, uint32_t num_cascades = 4, float max_shadow_distance = 128.f, float cascade_split_lambda = 0.95f,
+                                uint32_t csm_resolution = 4096) {
+        if (get_shadow_mode() != SunShadowMode::CascadedShadowMaps) return;
+        const float z_near = view.get_near(), clip_range = z_near + max_shadow_distance, ratio = clip_range / z_near;
+        float splits[4] = {};
+        for (uint32_t i = 0; i < num_cascades && i < 4; i++) {
+            const float p = (float)((int32_t)i + 1) / (float)num_cascades;
+            const float log = z_near * std::pow(ratio, p), uniform = z_near + max_shadow_distance * p;
+            splits[i] = (cascade_split_lambda * (log - uniform) + uniform - z_near) / clip_range;
+        }
+        const Vec3 light_dir = v_normalize({constants.direction_and_tan_size[0], constants.direction_and_tan_size[1], constants.direction_and_tan_size[2]});
+        float last_split = z_near;
+        for (uint32_t i = 0; i < num_cascades && i < 4; i++) {
+            const Mat4 projection = perspective_fov(view.get_fov(), view.get_aspect_ratio(), 1.f, last_split * max_shadow_distance, splits[i] * max_shadow_distance);
+            Mat4 view_matrix;
+            std::memcpy(view_matrix.data(), view.get_gpu_data().view, 64);
+            const Mat4 inverse_camera = mat_inverse(mat_mul(projection, view_matrix));
+            Vec3 corners[8];
+            Vec3 center{};
+            for (int c = 0; c < 8; c++) {
+                const float ndc[4] = {(c & 1) ^ ((c >> 1) & 1) ? 1.f : -1.f, (c & 2) ? -1.f : 1.f, (c & 4) ? 1.f : -1.f, 1.f};
+                float w[4] = {};
+                for (int r = 0; r < 4; r++)
+                    for (int k = 0; k < 4; k++) w[r] += inverse_camera[k * 4 + r] * ndc[k];
+                corners[c] = {w[0] / w[3], w[1] / w[3], w[2] / w[3]};
+                for (int k = 0; k < 3; k++) center[k] += corners[c][k];
+            }
+            for (int k = 0; k < 3; k++) center[k] /= 8.f;
+            float radius = 0.f;
+            for (const Vec3& c : corners) radius = std::max(radius, std::sqrt(v_dot(v_sub(c, center), v_sub(c, center))));
+            radius = std::ceil(radius * 2.f * 16.f) / 16.f;
+            const Mat4 light_view = look_at({center[0] - light_dir[0] * radius, center[1] - light_dir[1] * radius, center[2] - light_dir[2] * radius}, center, {0.f, 1.f, 0.f});
+            const Mat4 m = mat_mul(ortho(-radius, radius, -radius, radius, 0.f, radius + radius), light_view);
+            for (int k = 0; k < 4; k++) constants.data[i][k] = 0.f;
+            constants.data[i][0] = splits[i] * clip_range * -1.f;
+            std::memcpy(constants.cascade_matrices[i], m.data(), 64);
+            std::memcpy(constants.cascade_inverse_matrices[i], mat_inverse(m).data(), 64);
+            last_split = splits[i];
+        }
+        constants.csm_resolution[0] = constants.csm_resolution[1] = csm_resolution;
+    }
+    // directional_light.cpp:286-327: the "Sun shadow" pass — every primitive into every cascade layer, depth only
+    void render_shadows(RenderGraph& graph, const sah_scene_geometry& geometry, uint32_t num_cascades = 4) const {
+        if (get_shadow_mode() != SunShadowMode::CascadedShadowMaps || !shadowmap_handle) return;
+        graph.add_pass({"Sun shadow", [this, &geometry, num_cascades](sah_ctx* ctx) {
+                            return sah_shadow_render(ctx, &geometry, &constants, num_cascades, &shadowmap_handle->desc, nullptr);
+                        }});
+    }
     void set_shadow_mode(SunShadowMode m) { constants.shadow_mode = (uint32_t)m; }
     SunShadowMode get_shadow_mode() const { return (SunShadowMode)constants.shadow_mode; }
     sah_sun_light_constants& get_constants() { return constants; }
@@ -265,6 +330,7 @@ struct ProceduralSky {
 struct RenderScene {  // the slice of RenderCore/render/render_scene.hpp the hot path touches
     DirectionalLight sun;
     ProceduralSky sky;
+    sah_scene_geometry geometry{};  // device-side mesh pool + primitive buffer (render_scene.hpp: get_meshes(), get_primitive_buffer())
     DirectionalLight& get_sun_light() { return sun; }
     ProceduralSky& get_sky() { return sky; }
 };
@@ -450,6 +516,20 @@ public:
 };
 
 // ---- LightingPhase (RenderCore/render/phase/lighting_phase.hpp:17-57, .cpp:34-134) -------------------------------------
+// RenderCore/render/phase/gbuffer_phase.cpp:17-97 (and the depth pre-pass it relies on, phase/depth_culling_phase.cpp): visibility and
+// the four G-buffer targets in one compute pass.  The indirect draw buffers of the reference (GPU culling results) have no
+// counterpart: every primitive of the scene is submitted.
+class GbufferPhase {
+public:
+    void render(RenderGraph& graph, const RenderScene& scene, const GBuffer& gbuffer, const SceneView& player_view) {
+        graph.add_pass({"gbuffer", [&scene, &gbuffer, &player_view](sah_ctx* ctx) {
+                            const sah_gbuffer g = {gbuffer.color->plane(), gbuffer.normals->plane(), gbuffer.data->plane(), gbuffer.emission->plane(),
+                                                   gbuffer.depth->plane()};
+                            return sah_gbuffer_render(ctx, &scene.geometry, &player_view.get_gpu_data(), &g, nullptr);
+                        }});
+    }
+};
+
 class LightingPhase {
 public:
     void set_scene(RenderScene& scene_in) { scene = &scene_in; }

@@ -1,0 +1,90 @@
+// The two producer passes through the C++ host façade (include/sah_host.hpp): DirectionalLight::update_shadow_cascades +
+// render_shadows (RenderCore/render/directional_light.cpp:84-230,286-327) and GbufferPhase::render
+// (RenderCore/render/phase/gbuffer_phase.cpp:17-97).  The mesh comes from a file written by tests/test_host_facade_gpu.py; the
+// uniform blocks built here go back with the images so that the test can hand the very same blocks to the oracle.
+//
+//   host_raster <in.bin> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "sah_host.hpp"
+
+static std::vector<unsigned char> read_blob(FILE* f, size_t n) {
+    std::vector<unsigned char> v(n);
+    if (n && fread(v.data(), 1, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+    return v;
+}
+static void* to_device(const std::vector<unsigned char>& v) {
+    void* p = nullptr;
+    if (v.empty()) return nullptr;
+    if (hipMalloc(&p, v.size()) != hipSuccess || hipMemcpy(p, v.data(), v.size(), hipMemcpyHostToDevice) != hipSuccess) exit(3);
+    return p;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) { fprintf(stderr, "usage: host_raster in.bin out.bin\n"); return 2; }
+    FILE* in = fopen(argv[1], "rb");
+    if (!in) { perror("open input"); return 2; }
+    uint32_t hdr[7];  // W, H, shadow resolution, vertices, indices, primitives, materials
+    if (fread(hdr, 4, 7, in) != 7) return 2;
+    const uint32_t W = hdr[0], H = hdr[1], R = hdr[2];
+
+    using namespace sah;
+    RenderBackend backend(0);
+    auto& alloc = backend.get_global_allocator();
+
+    RenderScene scene;
+    scene.geometry.num_vertices = hdr[3];
+    scene.geometry.num_indices = hdr[4];
+    scene.geometry.num_primitives = hdr[5];
+    scene.geometry.num_materials = hdr[6];
+    scene.geometry.vertex_positions = (const float*)to_device(read_blob(in, (size_t)hdr[3] * 12));
+    scene.geometry.vertex_data = (const sah_vertex_data*)to_device(read_blob(in, (size_t)hdr[3] * sizeof(sah_vertex_data)));
+    scene.geometry.indices = (const uint32_t*)to_device(read_blob(in, (size_t)hdr[4] * 4));
+    scene.geometry.primitives = (const sah_primitive*)to_device(read_blob(in, (size_t)hdr[5] * sizeof(sah_primitive)));
+    scene.geometry.materials = (const sah_material*)to_device(read_blob(in, (size_t)hdr[6] * sizeof(sah_material)));
+    fclose(in);
+
+    SceneView view;  // start-up camera of the reference: scene_renderer.cpp:53-54,105-116
+    view.rotate(0.f, 90.f * 3.14159265358979f / 180.f);
+    view.set_position({-7.f, 1.f, 0.f});
+    view.set_render_resolution(W, H);
+    view.set_perspective_projection(75.f, (float)W / (float)H, 0.05f);
+    view.update_transforms();
+
+    scene.sun.set_shadow_mode(SunShadowMode::CascadedShadowMaps);
+    scene.sun.shadowmap_handle = alloc.create_texture("Sun shadowmap", SAH_FORMAT_D16_UNORM, R, R, 4);
+    scene.sun.update_shadow_cascades(view, 4, 128.f, 0.95f, R);
+
+    GBuffer gbuffer;
+    gbuffer.color = alloc.create_texture("gbuffer_color", SAH_FORMAT_R8G8B8A8_SRGB, W, H);
+    gbuffer.normals = alloc.create_texture("gbuffer_normals", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    gbuffer.data = alloc.create_texture("gbuffer_data", SAH_FORMAT_R8G8B8A8_UNORM, W, H);
+    gbuffer.emission = alloc.create_texture("gbuffer_emission", SAH_FORMAT_R8G8B8A8_SRGB, W, H);
+    gbuffer.depth = alloc.create_texture("gbuffer_depth", SAH_FORMAT_D32_SFLOAT, W, H);
+
+    RenderGraph graph{backend};
+    scene.sun.render_shadows(graph, scene.geometry);
+    GbufferPhase gbuffer_phase;
+    gbuffer_phase.render(graph, scene, gbuffer, view);
+    graph.finish();
+    for (const auto& e : graph.get_errors()) fprintf(stderr, "pass failed: %s\n", e.c_str());
+    if (!graph.get_errors().empty()) return 1;
+
+    FILE* out = fopen(argv[2], "wb");
+    if (!out) { perror("open output"); return 2; }
+    fwrite(&view.get_gpu_data(), sizeof(sah_view_data), 1, out);
+    fwrite(&scene.sun.get_constants(), sizeof(sah_sun_light_constants), 1, out);
+    std::vector<unsigned char> buf((size_t)R * R * 4 * 2);
+    alloc.download(scene.sun.shadowmap_handle, buf.data(), R * 2);
+    fwrite(buf.data(), 1, buf.size(), out);
+    const struct { TextureHandle t; uint32_t bpp; } planes[5] = {{gbuffer.color, 4}, {gbuffer.normals, 8}, {gbuffer.data, 4}, {gbuffer.emission, 4}, {gbuffer.depth, 4}};
+    for (const auto& p : planes) {
+        buf.resize((size_t)W * H * p.bpp);
+        alloc.download(p.t, buf.data(), W * p.bpp);
+        fwrite(buf.data(), 1, buf.size(), out);
+    }
+    fclose(out);
+    return 0;
+}

@@ -96,3 +96,71 @@ def test_frame_through_cpp_facade(tmp_path, sun_mode):
     # the camera the C++ SceneView builds is the reference's start-up camera, like scene.py's
     assert np.allclose(np.array(view_c.view[:]), np.array(view.gpu_data.view[:]), atol=1e-5)
     assert math.isclose(view_c.inverse_projection[0], view.gpu_data.inverse_projection[0], rel_tol=1e-5)
+
+
+RASTER_EXE = os.path.join(ROOT, "tests", "cpp", "host_raster")
+
+
+def _build_raster():
+    src = os.path.join(ROOT, "tests", "cpp", "host_raster.cpp")
+    if os.path.exists(RASTER_EXE) and os.path.getmtime(RASTER_EXE) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "sah_host.hpp"))):
+        return
+    libdir = os.path.join(ROOT, "androidrenderer_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", RASTER_EXE, "-L", libdir,
+                           "-lsah_hip", f"-Wl,-rpath,{libdir}"])
+
+
+def test_producer_passes_through_cpp_facade(tmp_path):
+    """update_shadow_cascades + render_shadows + GbufferPhase::render in C++ against the oracle fed with the blocks C++ built, and
+    the C++ cascade fitting against scene.py's."""
+    from androidrenderer_amd import mesh
+    _build_raster()
+    W, H, R = 160, 90, 256
+    arrays = mesh.atrium(2).arrays()
+    counts = mesh.with_counts(arrays)["counts"]
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(np.array([W, H, R, counts["vertices"], counts["indices"], counts["primitives"], counts["materials"]], dtype=np.uint32).tobytes())
+        for k in ("positions", "vertex_data", "indices", "primitives", "materials"):
+            f.write(np.ascontiguousarray(arrays[k]).tobytes())
+    subprocess.check_call([RASTER_EXE, str(inp), str(outp)])
+    blob = open(outp, "rb").read()
+    off = 0
+
+    def take(n):
+        nonlocal off
+        b = blob[off:off + n]
+        off += n
+        return b
+
+    view_c = _abi.ViewData.from_buffer_copy(take(432))
+    sun_c = _abi.SunLightConstants.from_buffer_copy(take(640))
+    sm = np.frombuffer(take(4 * R * R * 2), dtype=np.uint16).reshape(4, R, R)
+    got = {"color": np.frombuffer(take(W * H * 4), np.uint8).reshape(H, W, 4), "normals": np.frombuffer(take(W * H * 8), np.uint16).reshape(H, W, 4),
+           "data": np.frombuffer(take(W * H * 4), np.uint8).reshape(H, W, 4), "emission": np.frombuffer(take(W * H * 4), np.uint8).reshape(H, W, 4),
+           "depth": np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)}
+    assert off == len(blob)
+    o = util.oracle()
+    keep = []
+    g = mesh.geometry(mesh.with_counts(arrays), keep)
+    want_sm = np.zeros_like(sm)
+    vol = images.volume(want_sm, _abi.FORMAT_D16_UNORM)
+    assert o.orc_shadow_render(C.byref(g), C.byref(sun_c), 4, C.byref(vol), None) == 0
+    assert np.array_equal(sm, want_sm)
+    assert (sm != 0xffff).mean() > 0.2
+    want = {"color": np.zeros((H, W, 4), np.uint8), "normals": np.zeros((H, W, 4), np.uint16), "data": np.zeros((H, W, 4), np.uint8),
+            "emission": np.zeros((H, W, 4), np.uint8), "depth": np.zeros((H, W), np.float32)}
+    gb = images.gbuffer(want)
+    assert o.orc_gbuffer_render(C.byref(g), C.byref(view_c), C.byref(gb), None) == 0
+    for k in want:
+        assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), k
+    assert (want["depth"] > 0).mean() > 0.9
+    # cascade fitting: same algorithm as scene.py (glm restated twice); the inverses differ in rounding, so compare loosely
+    view = scene.SceneView.default(W, H)
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+    py = sun.update_shadow_cascades(view, resolution=R)
+    for c in range(4):
+        a, b = np.array(sun_c.cascade_matrices[c][:]), np.array(py.cascade_matrices[c][:])
+        assert np.allclose(a, b, rtol=2e-3, atol=2e-3), (c, a, b)
+        assert math.isclose(sun_c.data[c][0], py.data[c][0], rel_tol=1e-5)
+    assert sun_c.csm_resolution[0] == R
