@@ -321,3 +321,29 @@ def test_hip_raster_rejects_bad_arguments(hip_ctx):
     vol.format = _abi.FORMAT_R16_SFLOAT
     with pytest.raises(RuntimeError):
         hip_ctx.shadow_render(g, _ortho_sun(), 1, vol)
+
+
+@pytest.mark.gpu
+def test_rasterised_atrium_through_the_lighting_pass(hip_ctx):
+    """producers -> consumer on the GPU: sah_gbuffer_render + sah_shadow_render feed sah_lighting (sun CSM + LPV), against the oracle
+    running the same chain on the CPU"""
+    w, h, res = 256, 144, 512
+    arrays = mesh.atrium(3).arrays()
+    fr = util.LightingFrame(w, h, gbuffer=_new_gbuffer(w, h), seed=21, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, shadowmap_res=res)
+    got_gb, _ = _hip_gbuffer(hip_ctx, arrays, fr.view, w, h)
+    got_sm, _ = _hip_shadow(hip_ctx, arrays, fr.sun.constants, 4, (res, res))
+    want_gb, _ = _oracle_gbuffer(arrays, fr.view, w, h)
+    want_sm, _ = _oracle_shadow(arrays, fr.sun.constants, 4, (res, res))
+    _assert_gbuffers_equal(got_gb, want_gb)
+    assert np.array_equal(got_sm, want_sm)
+    for k in ("color", "normals", "data", "emission", "depth"):
+        fr.arrays[k] = np.ascontiguousarray(got_gb[k])
+    fr.arrays["shadowmap"] = np.ascontiguousarray(got_sm)
+    lit_hip = fr.run_hip(hip_ctx)
+    lit_oracle = fr.run_oracle()
+    d = util.f16_ulp_diff(lit_hip, lit_oracle)
+    assert d.max() == 0, util.report_ulp("lit", d)
+    rgb = lit_oracle[..., :3].view(np.float16).astype(np.float32)
+    lum = rgb.sum(axis=-1)
+    assert np.isfinite(lum).all() and (lum > 0).mean() > 0.9
+    assert lum.max() > 20 * np.median(lum[lum > 0])  # sunlit floor next to shadowed walls: the shadow map is doing something
