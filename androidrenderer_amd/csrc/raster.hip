@@ -340,11 +340,14 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves = gridDim.x * 4u;
     uint32_t st_pairs = 0;
-    for (uint32_t base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < nrec; base += waves * 64u) {
+    // records per wave: 64 when there are plenty, fewer when the scene is a handful of screen-filling triangles (each of which is
+    // a long loop over tiles that should not queue up behind 63 others in one wave)
+    const uint32_t per_wave = min(64u, max(1u, (nrec + waves - 1) / waves));
+    for (uint32_t base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * per_wave; base < nrec; base += waves * per_wave) {
         const uint32_t r = base + lane;
         uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, view = 0;
         bool live = false;
-        if (r < nrec) {
+        if (lane < per_wave && r < nrec) {
             const RasterRecord& rec = a.records[r];
             live = !is_empty(rec);
             if (live) { tx0 = rec.x0 / kTile; tx1 = rec.x1 / kTile; ty0 = rec.y0 / kTile; ty1 = rec.y1 / kTile; view = rec.view; }
@@ -403,8 +406,8 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
 // single correctly rounded conversion of the integer the specification talks about.  E_i(px, py) = c_i + px a_i + py b_i.
 struct EdgeSetup {
     double a[3], b[3], c[3];
-    uint32_t tl;  // bit i: edge i is a top or left edge
-    float z[3];
+    uint32_t tl;        // bit i: edge i is a top or left edge
+    double zc, zx, zy;  // depth plane z(px, py) = zc + px zx + py zy
     float inv_area;
     uint32_t seq, cutout;
 };
@@ -417,7 +420,8 @@ SAH_DEV double readlane(double v, int src) {
 // lane `src`'s set-up, in scalar registers of every lane of the wave
 SAH_DEV EdgeSetup broadcast(const EdgeSetup& e, int src) {
     EdgeSetup r;
-    for (int i = 0; i < 3; i++) { r.a[i] = readlane(e.a[i], src); r.b[i] = readlane(e.b[i], src); r.c[i] = readlane(e.c[i], src); r.z[i] = readlane(e.z[i], src); }
+    for (int i = 0; i < 3; i++) { r.a[i] = readlane(e.a[i], src); r.b[i] = readlane(e.b[i], src); r.c[i] = readlane(e.c[i], src); }
+    r.zc = readlane(e.zc, src); r.zx = readlane(e.zx, src); r.zy = readlane(e.zy, src);
     r.tl = readlane(e.tl, src);
     r.inv_area = readlane(e.inv_area, src);
     r.seq = readlane(e.seq, src);
@@ -436,24 +440,37 @@ SAH_DEV EdgeSetup edge_setup(const RasterRecord& rec) {
         e.a[i] = -256.0 * (double)dy;
         e.b[i] = 256.0 * (double)dx;
         e.c[i] = (double)dx * (double)(128 - rec.Y[va]) - (double)dy * (double)(128 - rec.X[va]);
-        e.z[i] = rec.z[i];
     }
     const double area = (double)(rec.X[1] - rec.X[0]) * (double)(rec.Y[2] - rec.Y[0]) - (double)(rec.X[2] - rec.X[0]) * (double)(rec.Y[1] - rec.Y[0]);
     e.inv_area = 1.0f / (float)area;
+    // depth plane: sum_i E_i(px, py) z_i / area, coefficient by coefficient in fp64 (every operator rounded)
+    const double inv = 1.0 / area, z0 = (double)rec.z[0], z1 = (double)rec.z[1], z2 = (double)rec.z[2];
+    e.zc = ((e.c[0] * z0 + e.c[1] * z1) + e.c[2] * z2) * inv;
+    e.zx = ((e.a[0] * z0 + e.a[1] * z1) + e.a[2] * z2) * inv;
+    e.zy = ((e.b[0] * z0 + e.b[1] * z1) + e.b[2] * z2) * inv;
     return e;
 }
-// coverage of pixel (px, py); on a hit, its screen-space barycentrics
-SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, float b[3]) {
+// coverage of pixel (px, py); v = the three edge functions
+SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, double v[3]) {
     const double x = (double)px, y = (double)py;
-    double v[3];
     bool inside = true;
     for (int i = 0; i < 3; i++) {
         v[i] = __builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i]));
         inside = inside && (v[i] > 0.0 || (v[i] == 0.0 && ((e.tl >> i) & 1u)));
     }
-    if (inside)
-        for (int i = 0; i < 3; i++) b[i] = (float)v[i] * e.inv_area;
     return inside;
+}
+// screen-space barycentrics from the edge functions
+SAH_DEV void barycentrics(const EdgeSetup& e, const double v[3], float b[3]) {
+    for (int i = 0; i < 3; i++) b[i] = (float)v[i] * e.inv_area;
+}
+// every pixel centre of the 8x8 block at (ox, oy) is strictly inside: all edge functions positive at their least favourable corner
+SAH_DEV bool block_inside(const EdgeSetup& e, int32_t ox, int32_t oy) {
+    for (int i = 0; i < 3; i++) {
+        const double x = (double)(e.a[i] > 0.0 ? ox : ox + 7), y = (double)(e.b[i] > 0.0 ? oy : oy + 7);
+        if (!(__builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i])) > 0.0)) return false;
+    }
+    return true;
 }
 // no pixel centre of the 8x8 block at (ox, oy) can be inside: some edge function is negative at its most favourable corner
 SAH_DEV bool block_outside(const EdgeSetup& e, int32_t ox, int32_t oy) {
@@ -463,8 +480,8 @@ SAH_DEV bool block_outside(const EdgeSetup& e, int32_t ox, int32_t oy) {
     }
     return false;
 }
-SAH_DEV float fragment_depth(const EdgeSetup& e, const float b[3]) {
-    const float z = (b[0] * e.z[0] + b[1] * e.z[1]) + b[2] * e.z[2];
+SAH_DEV float fragment_depth(const EdgeSetup& e, int32_t px, int32_t py) {
+    const float z = (float)__builtin_fma((double)py, e.zy, __builtin_fma((double)px, e.zx, e.zc));
     return __builtin_fminf(__builtin_fmaxf(z, 0.0f), 1.0f);  // depth clamp (shadow PSO) / [0,1] viewport range; NaN -> 0
 }
 
@@ -486,12 +503,11 @@ SAH_DEV uint32_t unorm8_of(float c) {  // floor(c * 255 + 0.5) in fp32, clamped,
     return (uint32_t)(c * 255.0f + 0.5f);
 }
 
+// depth test of a covered pixel; v = its edge functions (read by cutout fragments only)
 template <bool GBUFFER>
-SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t px, int32_t py, int32_t tile_x, int32_t tile_y, uint32_t* s_depth,
-                        unsigned long long* s_key) {
-    float b[3];
-    if (!cover(e, px, py, b)) return;
-    const float z = fragment_depth(e, b);
+SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t px, int32_t py, const double v[3], int32_t tile_x, int32_t tile_y,
+                           uint32_t* s_depth, unsigned long long* s_key) {
+    const float z = fragment_depth(e, px, py);
     const uint32_t slot = (uint32_t)(py - tile_y) * kTile + (uint32_t)(px - tile_x);
     if (!GBUFFER) {
         atomicMin(&s_depth[slot], (uint32_t)__builtin_rintf(z * 65535.0f));
@@ -499,7 +515,8 @@ SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_in
         if (!(z > 0.0f)) return;  // cannot pass GREATER against the cleared 0
         if (e.cutout) {  // alpha of tinted_base_color against the threshold (gltf_basic_pbr.slang:181-189)
             const RasterAttr& at = a.attrs[rec_index];
-            float lambda[3];
+            float b[3], lambda[3];
+            barycentrics(e, v, b);
             input_barycentrics(at, b, lambda);
             const sah_material& m = a.materials[at.material];
             const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
@@ -508,13 +525,62 @@ SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_in
         atomicMax(&s_key[slot], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xffffffffu - e.seq));
     }
 }
+template <bool GBUFFER>
+SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t px, int32_t py, int32_t tile_x, int32_t tile_y, uint32_t* s_depth,
+                        unsigned long long* s_key) {
+    double v[3];
+    if (cover(e, px, py, v)) emit_fragment<GBUFFER>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
+}
+
+// One wave sweeps rows first_row, first_row + row_step, ... of 8x8 pixel blocks over the clipped bounding box, lanes as the pixels of
+// a block.  Per block the edge functions advance by one fp64 add each (exact: integers below 2^52); a block whose most favourable
+// corner is outside an edge is skipped, one whose least favourable corner is inside all three needs no per-pixel coverage test.
+template <bool GBUFFER>
+SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1, int32_t first_row,
+                   int32_t row_step, uint32_t lane, int32_t tile_x, int32_t tile_y, uint32_t* s_depth, unsigned long long* s_key) {
+    const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+    double kmax[3], kmin[3], lane_off[3], step_x[3];
+    for (int i = 0; i < 3; i++) {
+        kmax[i] = 7.0 * (__builtin_fmax(e.a[i], 0.0) + __builtin_fmax(e.b[i], 0.0));
+        kmin[i] = 7.0 * (__builtin_fmin(e.a[i], 0.0) + __builtin_fmin(e.b[i], 0.0));
+        lane_off[i] = __builtin_fma((double)lx, e.a[i], (double)ly * e.b[i]);
+        step_x[i] = 8.0 * e.a[i];
+    }
+    for (int32_t oy = first_row; oy <= by1; oy += row_step) {
+        double base[3];
+        for (int i = 0; i < 3; i++) base[i] = __builtin_fma((double)oy, e.b[i], __builtin_fma((double)bx0, e.a[i], e.c[i]));
+        for (int32_t ox = bx0; ox <= bx1; ox += 8) {
+            bool outside = false, all_in = true;
+            for (int i = 0; i < 3; i++) {
+                outside = outside || base[i] + kmax[i] < 0.0;
+                all_in = all_in && base[i] + kmin[i] > 0.0;
+            }
+            const int32_t px = ox + lx, py = oy + ly;
+            if (!outside && px <= bx1 && py <= by1) {
+                double v[3] = {0.0, 0.0, 0.0};
+                bool covered = all_in;
+                if (!all_in || (GBUFFER && e.cutout)) {
+                    covered = true;
+                    for (int i = 0; i < 3; i++) {
+                        v[i] = base[i] + lane_off[i];
+                        covered = covered && (v[i] > 0.0 || (v[i] == 0.0 && ((e.tl >> i) & 1u)));
+                    }
+                }
+                if (covered) emit_fragment<GBUFFER>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
+            }
+            for (int i = 0; i < 3; i++) base[i] += step_x[i];
+        }
+    }
+}
 
 // fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_MAIN_VIEW, constant textures)
 SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px, int32_t py, float z) {
     const RasterAttr& at = a.attrs[rec_index];
     const EdgeSetup e = edge_setup(a.records[rec_index]);
-    float b[3] = {0.f, 0.f, 0.f}, lambda[3];
-    cover(e, px, py, b);
+    double v[3];
+    float b[3], lambda[3];
+    cover(e, px, py, v);
+    barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
     const sah_material& m = a.materials[at.material];
     Hn col[4], N[3], T[4];
@@ -616,12 +682,7 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
             const int32_t bx0 = (int32_t)readlane((uint32_t)x0, src), bx1 = (int32_t)readlane((uint32_t)x1, src);
             const int32_t by0 = (int32_t)readlane((uint32_t)y0, src), by1 = (int32_t)readlane((uint32_t)y1, src);
             const EdgeSetup e = broadcast(mine, src);
-            for (int32_t oy = by0; oy <= by1; oy += 8)
-                for (int32_t ox = bx0; ox <= bx1; ox += 8) {
-                    if (block_outside(e, ox, oy)) continue;
-                    const int32_t px = ox + (int32_t)(lane & 7u), py = oy + (int32_t)(lane >> 3);
-                    if (px <= bx1 && py <= by1) test_pixel<GBUFFER>(a, e, ri, px, py, tile_x, tile_y, s_depth, s_key);
-                }
+            sweep<GBUFFER>(a, e, ri, bx0, bx1, by0, by1, by0, 8, lane, tile_x, tile_y, s_depth, s_key);
         }
         __syncthreads();
 #ifdef SAH_EXP_RASTER_SKIP_BIG  // timing experiment: no workgroup-cooperative records
@@ -629,17 +690,11 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
 #else
         const uint32_t nbig = min(s_nbig, kBigSlots);
 #endif
-        const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
         for (uint32_t k = 0; k < nbig; k++) {
             const EdgeSetup e = s_big[k].e;  // same address in every lane: an LDS broadcast
             const uint32_t ri = s_big[k].rec_index;
             const int32_t bx0 = s_big[k].x0, bx1 = s_big[k].x1, by0 = s_big[k].y0, by1 = s_big[k].y1;
-            for (int32_t oy = by0 + 8 * (int32_t)wave; oy <= by1; oy += 32)
-                for (int32_t ox = bx0; ox <= bx1; ox += 8) {
-                    if (block_outside(e, ox, oy)) continue;
-                    const int32_t px = ox + lx, py = oy + ly;
-                    if (px <= bx1 && py <= by1) test_pixel<GBUFFER>(a, e, ri, px, py, tile_x, tile_y, s_depth, s_key);
-                }
+            sweep<GBUFFER>(a, e, ri, bx0, bx1, by0, by1, by0 + 8 * (int32_t)wave, 32, lane, tile_x, tile_y, s_depth, s_key);
         }
     }
     __syncthreads();
@@ -676,18 +731,21 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
                 *(uint32_t*)(a.out_emission.ptr + (size_t)py * a.out_emission.pitch + (size_t)px * 4) = 0u;
                 *(float*)(a.out_depth.ptr + (size_t)py * a.out_depth.pitch + (size_t)px * 4) = 0.0f;
             } else {
+                // an unclipped triangle sits in the slot of its work item (one view: slot = running triangle number = seq / 8);
+                // the fans of clipped ones were appended and are found through the table
                 const uint32_t seq = 0xffffffffu - (uint32_t)key;
-                shade_and_store(a, a.seq_to_record[seq], px, py, __uint_as_float((uint32_t)(key >> 32)));
+                uint32_t r = seq >> 3;
+                if ((seq & 7u) != 0u || r >= a.record_capacity || is_empty(a.records[r])) r = a.seq_to_record[seq];
+                shade_and_store(a, r, px, py, __uint_as_float((uint32_t)(key >> 32)));
             }
         }
     }
 }
 
-// seq -> record index (G-buffer resolve)
+// seq -> record index for the appended records (fans of clipped triangles; G-buffer resolve)
 __global__ __launch_bounds__(256) void k_seq_table(const RasterArgs a) {
-    const uint32_t nrec = record_count(a);
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256)
-        if (!is_empty(a.records[r])) a.seq_to_record[a.attrs[r].seq] = r;
+    const uint32_t nrec = record_count(a), first = a.counters[C_TRIS] * a.num_views;
+    for (uint32_t r = first + blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256) a.seq_to_record[a.records[r].seq] = r;
 }
 
 }  // namespace
@@ -718,7 +776,7 @@ hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st
     const uint32_t ntiles = a.tiles_x * a.tiles_y * a.num_views;
     if (a.num_primitives) {
         hipLaunchKernelGGL(k_bin<true>, dim3(1024), dim3(256), 0, st, a);
-        if (gbuffer) hipLaunchKernelGGL(k_seq_table, dim3(1024), dim3(256), 0, st, a);
+        if (gbuffer) hipLaunchKernelGGL(k_seq_table, dim3(64), dim3(256), 0, st, a);
     }
     if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles), dim3(256), 0, st, a);

@@ -121,6 +121,23 @@ void raster_triangle(RasterVertex v0, RasterVertex v1, RasterVertex v2, bool cul
     st.w[3]++;
     const RasterVertex* v[3] = {&v0, &v1, &v2};
     const F inv_area = F(1.0f) / F((float)area);
+    // Depth is linear in window space: z(px, py) = zc + px zx + py zy, the three coefficients formed once per triangle in fp64
+    // from the edge functions E_i(px, py) = c_i + a_i px + b_i py (exact integers) and the vertex depths, every operator rounded.
+    double zc, zx, zy;
+    {
+        double ea[3], eb[3], ec[3];
+        for (int i = 0; i < 3; i++) {
+            const RasterVertex &a = *v[(i + 1) % 3], &b = *v[(i + 2) % 3];
+            const double dx = (double)(b.X - a.X), dy = (double)(b.Y - a.Y);
+            ea[i] = -256.0 * dy;
+            eb[i] = 256.0 * dx;
+            ec[i] = dx * (double)(128 - a.Y) - dy * (double)(128 - a.X);
+        }
+        const double inv = 1.0 / (double)area, z0 = (double)v0.z.v, z1 = (double)v1.z.v, z2 = (double)v2.z.v;
+        zc = ((ec[0] * z0 + ec[1] * z1) + ec[2] * z2) * inv;
+        zx = ((ea[0] * z0 + ea[1] * z1) + ea[2] * z2) * inv;
+        zy = ((eb[0] * z0 + eb[1] * z1) + eb[2] * z2) * inv;
+    }
     for (int64_t py = y0; py <= y1; py++)
         for (int64_t px = x0; px <= x1; px++) {
             const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
@@ -137,7 +154,7 @@ void raster_triangle(RasterVertex v0, RasterVertex v1, RasterVertex v2, bool cul
             f.x = (int)px;
             f.y = (int)py;
             const F b0 = F((float)e[0]) * inv_area, b1 = F((float)e[1]) * inv_area, b2 = F((float)e[2]) * inv_area;
-            f.z = b0 * v0.z + b1 * v1.z + b2 * v2.z;
+            f.z = F((float)std::fma((double)py, zy, std::fma((double)px, zx, zc)));
             const F q0 = b0 * v0.inv_w, q1 = b1 * v1.inv_w, q2 = b2 * v2.inv_w;
             const F s = q0 + q1 + q2;
             const F l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
