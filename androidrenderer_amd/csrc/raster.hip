@@ -536,8 +536,10 @@ SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_in
 // a block.  Per block the edge functions advance by one fp64 add each (exact: integers below 2^52); a block whose most favourable
 // corner is outside an edge is skipped, one whose least favourable corner is inside all three needs no per-pixel coverage test.
 template <bool GBUFFER>
-SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1, int32_t first_row,
+SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t sx0, int32_t sx1, int32_t bx1, int32_t by1, int32_t first_row,
                    int32_t row_step, uint32_t lane, int32_t tile_x, int32_t tile_y, uint32_t* s_depth, unsigned long long* s_key) {
+    // blocks start at x = sx0, sx0 + 8, ... <= sx1; pixels beyond (bx1, by1) are outside the record's clipped bounding box
+    const int32_t bx0 = sx0;
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     double kmax[3], kmin[3], lane_off[3], step_x[3];
     for (int i = 0; i < 3; i++) {
@@ -549,7 +551,7 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
     for (int32_t oy = first_row; oy <= by1; oy += row_step) {
         double base[3];
         for (int i = 0; i < 3; i++) base[i] = __builtin_fma((double)oy, e.b[i], __builtin_fma((double)bx0, e.a[i], e.c[i]));
-        for (int32_t ox = bx0; ox <= bx1; ox += 8) {
+        for (int32_t ox = bx0; ox <= sx1; ox += 8) {
             bool outside = false, all_in = true;
             for (int i = 0; i < 3; i++) {
                 outside = outside || base[i] + kmax[i] < 0.0;
@@ -613,7 +615,8 @@ SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px
     *(float*)(a.out_depth.ptr + (size_t)py * a.out_depth.pitch + (size_t)px * 4) = z;
 }
 
-constexpr uint32_t kBigSlots = 64;  // workgroup-cooperative records per round of 256 list entries; the rest fall back to their wave
+constexpr uint32_t kTileThreads = 256;   // 1024 (16 waves per tile, to shorten the densest tiles) measured 1.1x - 2.5x slower
+constexpr uint32_t kBigSlots = 64;       // workgroup-cooperative records per round of list entries; the rest fall back to their wave
 struct BigRecord {
     EdgeSetup e;
     uint32_t rec_index;
@@ -621,14 +624,14 @@ struct BigRecord {
 };
 
 template <bool GBUFFER>
-__global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
+__global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs a) {
     __shared__ uint32_t s_depth[GBUFFER ? 1 : kTile * kTile];
     __shared__ unsigned long long s_key[GBUFFER ? kTile * kTile : 1];
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, view = tile / (a.tiles_x * a.tiles_y);
     const int32_t tile_x = (int32_t)tx * kTile, tile_y = (int32_t)ty * kTile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < kTile * kTile; i += 256) {
+    for (uint32_t i = tid; i < kTile * kTile; i += kTileThreads) {
         if (GBUFFER) s_key[i] = 0ull; else s_depth[i] = 0xffffu;
     }
     __syncthreads();
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
 #else
     const uint32_t begin = a.tile_offset[tile], count = a.tile_count[tile];
 #endif
-    for (uint32_t base = 0; base < count; base += 256u) {
+    for (uint32_t base = 0; base < count; base += kTileThreads) {
         if (tid == 0) s_nbig = 0;
         __syncthreads();
         const uint32_t li = base + tid;
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
             const int32_t bx0 = (int32_t)readlane((uint32_t)x0, src), bx1 = (int32_t)readlane((uint32_t)x1, src);
             const int32_t by0 = (int32_t)readlane((uint32_t)y0, src), by1 = (int32_t)readlane((uint32_t)y1, src);
             const EdgeSetup e = broadcast(mine, src);
-            sweep<GBUFFER>(a, e, ri, bx0, bx1, by0, by1, by0, 8, lane, tile_x, tile_y, s_depth, s_key);
+            sweep<GBUFFER>(a, e, ri, bx0, bx1, bx1, by1, by0, 8, lane, tile_x, tile_y, s_depth, s_key);
         }
         __syncthreads();
 #ifdef SAH_EXP_RASTER_SKIP_BIG  // timing experiment: no workgroup-cooperative records
@@ -694,7 +697,13 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
             const EdgeSetup e = s_big[k].e;  // same address in every lane: an LDS broadcast
             const uint32_t ri = s_big[k].rec_index;
             const int32_t bx0 = s_big[k].x0, bx1 = s_big[k].x1, by0 = s_big[k].y0, by1 = s_big[k].y1;
-            sweep<GBUFFER>(a, e, ri, bx0, bx1, by0, by1, by0 + 8 * (int32_t)wave, 32, lane, tile_x, tile_y, s_depth, s_key);
+            if constexpr (kTileThreads == 256) {  // 4 waves: alternate block rows
+                sweep<GBUFFER>(a, e, ri, bx0, bx1, bx1, by1, by0 + 8 * (int32_t)wave, 32, lane, tile_x, tile_y, s_depth, s_key);
+            } else {  // 16 waves: block row (wave % 8) of the at most 8, left or right half of the block columns (wave / 8)
+                const int32_t half = (((bx1 - bx0) >> 3) + 2) >> 1;
+                const int32_t sx0 = bx0 + 8 * half * (int32_t)(wave >> 3), sx1 = min(bx1, sx0 + 8 * half - 1);
+                if (sx0 <= bx1) sweep<GBUFFER>(a, e, ri, sx0, sx1, bx1, by1, by0 + 8 * (int32_t)(wave & 7u), 64, lane, tile_x, tile_y, s_depth, s_key);
+            }
         }
     }
     __syncthreads();
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
         // 64 texels of D16 per row = 32 dwords; 256 threads write 8 rows per step
         uint8_t* base = (uint8_t*)a.shadowmap.ptr + (size_t)view * a.shadowmap.slice_pitch;
         const bool pair_ok = (a.shadowmap.row_pitch % 4u) == 0 && ((uintptr_t)a.shadowmap.ptr % 4u) == 0 && (a.shadowmap.slice_pitch % 4u) == 0;
-        for (uint32_t i = tid; i < kTile * kTile / 2; i += 256) {
+        for (uint32_t i = tid; i < kTile * kTile / 2; i += kTileThreads) {
             const uint32_t row = i / (kTile / 2), col = (i % (kTile / 2)) * 2;
             const uint32_t px = (uint32_t)tile_x + col, py = (uint32_t)tile_y + row;
             if (py >= a.height || px >= a.width) continue;
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(256) void k_raster_tiles(const RasterArgs a) {
             }
         }
     } else {
-        for (uint32_t i = tid; i < kTile * kTile; i += 256) {
+        for (uint32_t i = tid; i < kTile * kTile; i += kTileThreads) {
             const int32_t px = tile_x + (int32_t)(i % kTile), py = tile_y + (int32_t)(i / kTile);
             if ((uint32_t)px >= a.width || (uint32_t)py >= a.height) continue;
             const unsigned long long key = s_key[i];
@@ -778,8 +787,8 @@ hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st
         hipLaunchKernelGGL(k_bin<true>, dim3(1024), dim3(256), 0, st, a);
         if (gbuffer) hipLaunchKernelGGL(k_seq_table, dim3(64), dim3(256), 0, st, a);
     }
-    if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles), dim3(256), 0, st, a);
+    if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, st, a);
+    else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles), dim3(kTileThreads), 0, st, a);
     return hipGetLastError();
 }
 
