@@ -464,22 +464,6 @@ SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, double v[3]) {
 SAH_DEV void barycentrics(const EdgeSetup& e, const double v[3], float b[3]) {
     for (int i = 0; i < 3; i++) b[i] = (float)v[i] * e.inv_area;
 }
-// every pixel centre of the 8x8 block at (ox, oy) is strictly inside: all edge functions positive at their least favourable corner
-SAH_DEV bool block_inside(const EdgeSetup& e, int32_t ox, int32_t oy) {
-    for (int i = 0; i < 3; i++) {
-        const double x = (double)(e.a[i] > 0.0 ? ox : ox + 7), y = (double)(e.b[i] > 0.0 ? oy : oy + 7);
-        if (!(__builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i])) > 0.0)) return false;
-    }
-    return true;
-}
-// no pixel centre of the 8x8 block at (ox, oy) can be inside: some edge function is negative at its most favourable corner
-SAH_DEV bool block_outside(const EdgeSetup& e, int32_t ox, int32_t oy) {
-    for (int i = 0; i < 3; i++) {
-        const double x = (double)(e.a[i] > 0.0 ? ox + 7 : ox), y = (double)(e.b[i] > 0.0 ? oy + 7 : oy);
-        if (__builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i])) < 0.0) return true;
-    }
-    return false;
-}
 SAH_DEV float fragment_depth(const EdgeSetup& e, int32_t px, int32_t py) {
     const float z = (float)__builtin_fma((double)py, e.zy, __builtin_fma((double)px, e.zx, e.zc));
     return __builtin_fminf(__builtin_fmaxf(z, 0.0f), 1.0f);  // depth clamp (shadow PSO) / [0,1] viewport range; NaN -> 0
