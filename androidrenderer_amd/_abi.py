@@ -71,6 +71,10 @@ class SceneGeometry(C.Structure):  # sah_scene_geometry
                 ("num_materials", C.c_uint32)]
 
 
+class RsmTargets(C.Structure):  # sah_rsm_targets
+    _fields_ = [("flux", Volume), ("normals", Volume), ("depth", Volume)]
+
+
 class GBuffer(C.Structure):
     _fields_ = [("color", Plane), ("normals", Plane), ("data", Plane), ("emission", Plane), ("depth", Plane)]
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("SAH_HIP_LIBRARY") or os.path.join(HERE, "libsah_hip.so")
 SOURCES = ["api.cpp", "api_post.cpp", "api_raster.cpp", "lighting.hip", "lighting_tiled.hip", "post.hip", "lpv.hip", "probes.hip", "sky_luts.hip",
-           "raster.hip"]
+           "raster.hip", "vpl.hip"]
 # -fno-slp-vectorize: on MI355X v_pk_{mul,add,fma}_f32 issue in 4 cycles against 2 for the scalar forms (profiles/r1_valu_issue_cost.txt),
 # so the SLP vectoriser's packed pairs gain nothing and cost the register shuffles that feed them.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",

@@ -12,12 +12,16 @@
 namespace sah {
 hipError_t launch_raster_setup(const RasterArgs& a, bool gbuffer, hipStream_t st);
 hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st);
+hipError_t launch_extract_vpls(const VolumeArg& flux, const VolumeArg& normals, const VolumeArg& depth, const sah_lpv_cascade_matrices& c, uint32_t cascade,
+                               float grid_cell_size, const float* luts, sah_packed_vpl* list, uint32_t* count, hipStream_t st);
+hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count, uint32_t capacity, const sah_lpv_cascade_matrices& c, uint32_t cascade,
+                              uint32_t num_cascades, const VolumeArg rgb[3], uint32_t* cells_scratch, hipStream_t st);
 }  // namespace sah
 
 namespace {
 constexpr uint32_t kTile = 64;
 constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^24.1
-enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ };
+enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ, S_VPL_CELLS };
 
 int ensure(sah_ctx* ctx, int slot, size_t bytes) {
     auto& r = ctx->raster;
@@ -108,7 +112,7 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
     if (int rc = ensure(ctx, S_PAIRS, (size_t)(pairs + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
     a.pairs = (uint32_t*)r.ptr[S_PAIRS];
     if (gbuffer) {
-        if (int rc = ensure(ctx, S_SEQ, ((size_t)total_tris * 8 + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
+        if (int rc = ensure(ctx, S_SEQ, ((size_t)total_tris * 8 * a.num_views + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
         a.seq_to_record = (uint32_t*)r.ptr[S_SEQ];
     }
     HIP_TRY(ctx, sah::launch_raster_tiles(a, gbuffer, ctx->stream));
@@ -187,6 +191,79 @@ int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_
     a.out_emission = parg(&out->emission);
     a.out_depth = parg(&out->depth);
     return run(ctx, a, scene, true, stats);
+}
+
+int sah_rsm_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_light_constants* sun, const sah_lpv_cascade_matrices* cascades,
+                   uint32_t num_cascades, const sah_rsm_targets* rsm, uint32_t* stats) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!geometry_ok(scene, true) || !sun || !cascades || !rsm || num_cascades == 0 || num_cascades > 4)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rsm_render: bad scene, sun, cascades or targets");
+    const uint32_t W = rsm->depth.width, H = rsm->depth.height;
+    if (W == 0 || H == 0 || W > kMaxExtent || H > kMaxExtent) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rsm_render: extent must be 1..%u", kMaxExtent);
+    const struct { const sah_volume* v; uint32_t fmt; uint32_t bpp; const char* name; } targets[3] = {
+        {&rsm->flux, SAH_FORMAT_R8G8B8A8_SRGB, 4, "flux"}, {&rsm->normals, SAH_FORMAT_R8G8B8A8_UNORM, 4, "normals"}, {&rsm->depth, SAH_FORMAT_D16_UNORM, 2, "depth"}};
+    for (const auto& t : targets)
+        if (!t.v->ptr || t.v->format != t.fmt || t.v->width != W || t.v->height != H || t.v->depth < num_cascades ||
+            (uint64_t)t.v->row_pitch_bytes < (uint64_t)W * t.bpp || (uint64_t)t.v->slice_pitch_bytes < (uint64_t)t.v->row_pitch_bytes * H ||
+            ((uintptr_t)t.v->ptr % t.bpp) || (t.v->row_pitch_bytes % t.bpp) || (t.v->slice_pitch_bytes % t.bpp))
+            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "rsm_render: target '%s' has the wrong format, extent, layers or alignment", t.name);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure_srgb_table(ctx); rc != SAH_OK) return rc;
+    sah::RasterArgs a{};
+    fill_scene(a, scene);
+    a.num_views = num_cascades;
+    for (uint32_t c = 0; c < num_cascades; c++) std::memcpy(a.clip_matrix[c], cascades[c].rsm_vp, 64);
+    a.width = W;
+    a.height = H;
+    a.half_w = (float)W * 0.5f;
+    a.half_h = (float)H * 0.5f;
+    a.tiles_x = (W + kTile - 1) / kTile;
+    a.tiles_y = (H + kTile - 1) / kTile;
+    a.half_to_srgb8 = ctx->raster.half_to_srgb8;
+    a.rsm = 1;
+    for (int k = 0; k < 3; k++) a.sun_direction[k] = sun->direction_and_tan_size[k];
+    a.rsm_flux = varg(rsm->flux);
+    a.rsm_normals = varg(rsm->normals);
+    a.rsm_depth = varg(rsm->depth);
+    return run(ctx, a, scene, true, stats);
+}
+
+int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv_cascade_matrices* cascades, uint32_t cascade_index,
+                         float grid_cell_size, sah_packed_vpl* vpl_list, uint32_t* vpl_count) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!rsm || !cascades || !vpl_list || !vpl_count || cascade_index >= 4) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "lpv_extract_vpls: null argument or cascade index");
+    const uint32_t res = rsm->depth.width;
+    if (res == 0 || (res % 2) || rsm->depth.height != res || rsm->flux.width != res || rsm->flux.height != res || rsm->normals.width != res ||
+        rsm->normals.height != res || cascade_index >= rsm->depth.depth || cascade_index >= rsm->flux.depth || cascade_index >= rsm->normals.depth)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "lpv_extract_vpls: the RSM layers must be square, of even size and cover the cascade");
+    if (!rsm->flux.ptr || !rsm->normals.ptr || !rsm->depth.ptr || rsm->flux.format != SAH_FORMAT_R8G8B8A8_SRGB || rsm->normals.format != SAH_FORMAT_R8G8B8A8_UNORM ||
+        rsm->depth.format != SAH_FORMAT_D16_UNORM)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "lpv_extract_vpls: RSM formats are RGBA8_SRGB / RGBA8_UNORM / D16_UNORM");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah::launch_extract_vpls(varg(rsm->flux), varg(rsm->normals), varg(rsm->depth), cascades[cascade_index], cascade_index, grid_cell_size, ctx->luts,
+                                          vpl_list, vpl_count, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint32_t* vpl_count, uint32_t capacity, const sah_lpv_cascade_matrices* cascades,
+                        uint32_t cascade_index, uint32_t num_cascades, const sah_volume rgb[3]) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!vpl_list || !vpl_count || !cascades || !rgb || num_cascades == 0 || num_cascades > 4 || cascade_index >= num_cascades)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "lpv_inject_vpls: null argument or cascade index");
+    sah::VolumeArg v[3];
+    for (int c = 0; c < 3; c++) {
+        if (!rgb[c].ptr || rgb[c].format != SAH_FORMAT_R16G16B16A16_SFLOAT || rgb[c].width != rgb[0].width || rgb[c].height != rgb[0].height ||
+            rgb[c].depth != rgb[0].depth || rgb[c].width == 0 || (uint64_t)rgb[c].row_pitch_bytes < (uint64_t)rgb[c].width * 8 ||
+            (uint64_t)rgb[c].slice_pitch_bytes < (uint64_t)rgb[c].row_pitch_bytes * rgb[c].height || ((uintptr_t)rgb[c].ptr % 8) || (rgb[c].row_pitch_bytes % 8) ||
+            (rgb[c].slice_pitch_bytes % 8) || (uint64_t)rgb[c].width * rgb[c].height * rgb[c].depth >= 0xffffffffull)
+            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "lpv_inject_vpls: the three volumes must be RGBA16F of one extent, 8-byte aligned");
+        v[c] = varg(rgb[c]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure(ctx, S_VPL_CELLS, ((size_t)capacity + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
+    HIP_TRY(ctx, sah::launch_inject_vpls(vpl_list, vpl_count, capacity, cascades[cascade_index], cascade_index, num_cascades, v,
+                                         (uint32_t*)ctx->raster.ptr[S_VPL_CELLS], ctx->stream));
+    return SAH_OK;
 }
 
 }  // extern "C"

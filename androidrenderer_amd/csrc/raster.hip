@@ -248,11 +248,11 @@ SAH_DEV ClipVertex clip_vertex(const RasterArgs& a, const sah_primitive& prim, u
     const float local[4] = {pos[0], pos[1], pos[2], 1.0f};
     float world[4], clip[4];
     mat_vec(prim.model, local, world);
-    if (GBUFFER) {
+    if (GBUFFER && !a.rsm) {
         float vs[4];
         mat_vec(a.view_matrix, world, vs);
         mat_vec(a.clip_matrix[0], vs, clip);
-    } else {
+    } else {  // shadow cascades and RSM layers: one world -> clip matrix per view
         mat_vec(a.clip_matrix[view], world, clip);
     }
     ClipVertex c;
@@ -496,7 +496,10 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
     if (!GBUFFER) {
         atomicMin(&s_depth[slot], (uint32_t)__builtin_rintf(z * 65535.0f));
     } else {
-        if (!(z > 0.0f)) return;  // cannot pass GREATER against the cleared 0
+        // key: the larger wins.  G-buffer: reverse-Z depth bits (GREATER against the cleared 0).  RSM: D16 compare LESS against the
+        // cleared 1.0, so the key holds 0xffff - code and a fragment at code 0xffff cannot pass.
+        const uint32_t depth_key = a.rsm ? 0xffffu - (uint32_t)__builtin_rintf(z * 65535.0f) : __float_as_uint(z);
+        if (a.rsm ? depth_key == 0u : !(z > 0.0f)) return;
         if (e.cutout) {  // alpha of tinted_base_color against the threshold (gltf_basic_pbr.slang:181-189)
             const RasterAttr& at = a.attrs[rec_index];
             float b[3], lambda[3];
@@ -506,7 +509,7 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
             const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
             if (tof(alpha) <= m.opacity_threshold) return;
         }
-        atomicMax(&s_key[slot], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(0xffffffffu - e.seq));
+        atomicMax(&s_key[slot], ((unsigned long long)depth_key << 32) | (unsigned long long)(0xffffffffu - e.seq));
     }
 }
 template <bool GBUFFER>
@@ -597,6 +600,36 @@ SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px
     *(uint32_t*)(a.out_data.ptr + (size_t)py * a.out_data.pitch + (size_t)px * 4) = data_bits;
     *(uint32_t*)(a.out_emission.ptr + (size_t)py * a.out_emission.pitch + (size_t)px * 4) = emission_bits;
     *(float*)(a.out_depth.ptr + (size_t)py * a.out_depth.pitch + (size_t)px * 4) = z;
+}
+
+// RSM fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_RSM): flux = Fd(surface, -sun direction, normal) with
+// the metalness / roughness this variant leaves at 0, normal * 0.5 + 0.5; the D16 code goes to the depth layer
+SAH_DEV void shade_rsm_and_store(const RasterArgs& a, uint32_t rec_index, uint32_t layer, int32_t px, int32_t py, uint32_t depth_code) {
+    const RasterAttr& at = a.attrs[rec_index];
+    const EdgeSetup e = edge_setup(a.records[rec_index]);
+    double v[3];
+    float b[3], lambda[3];
+    cover(e, px, py, v);
+    barycentrics(e, v, b);
+    input_barycentrics(at, b, lambda);
+    const sah_material& m = a.materials[at.material];
+    Hn tinted[3], N[3];
+    for (int c = 0; c < 3; c++) tinted[c] = Hn(m.base_color_texel[c]) * interp_h(at, lambda, c) * Hn(m.base_color_tint[c]);
+    for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
+    Surface<Hn> s;
+    s.base_color = {tinted[0], tinted[1], tinted[2]};
+    s.normal = {N[0], N[1], N[2]};
+    s.metalness = Hn::lit(0.0f);
+    s.roughness = Hn::lit(0.0f);
+    const V3<Hn> l = {-Hn(a.sun_direction[0]), -Hn(a.sun_direction[1]), -Hn(a.sun_direction[2])};
+    const V3<Hn> flux = Fd(s, l, s.normal);
+    const uint32_t flux_bits = (uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, flux.x.v)] | ((uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, flux.y.v)] << 8) |
+                               ((uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, flux.z.v)] << 16) | 0xff000000u;
+    uint32_t normal_bits = 0xff000000u;
+    for (int c = 0; c < 3; c++) normal_bits |= unorm8_of(tof(N[c] * Hn::lit(0.5f) + Hn::lit(0.5f))) << (8 * c);
+    *(uint32_t*)(a.rsm_flux.ptr + (size_t)layer * a.rsm_flux.slice_pitch + (size_t)py * a.rsm_flux.row_pitch + (size_t)px * 4) = flux_bits;
+    *(uint32_t*)(a.rsm_normals.ptr + (size_t)layer * a.rsm_normals.slice_pitch + (size_t)py * a.rsm_normals.row_pitch + (size_t)px * 4) = normal_bits;
+    *(uint16_t*)(a.rsm_depth.ptr + (size_t)layer * a.rsm_depth.slice_pitch + (size_t)py * a.rsm_depth.row_pitch + (size_t)px * 2) = (uint16_t)depth_code;
 }
 
 constexpr uint32_t kTileThreads = 256;   // 1024 (16 waves per tile, to shorten the densest tiles) measured 1.1x - 2.5x slower
@@ -716,7 +749,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
 #ifdef SAH_EXP_RASTER_SKIP_RESOLVE  // timing experiment: no fragment stage
             if (true) {
 #else
-            if (key == 0ull) {  // clear values, gbuffer_phase.cpp:66-87
+            if (key == 0ull && a.rsm) {  // clear values, light_propagation_volume.cpp:586-606
+                *(uint32_t*)(a.rsm_flux.ptr + (size_t)view * a.rsm_flux.slice_pitch + (size_t)py * a.rsm_flux.row_pitch + (size_t)px * 4) = 0u;
+                *(uint32_t*)(a.rsm_normals.ptr + (size_t)view * a.rsm_normals.slice_pitch + (size_t)py * a.rsm_normals.row_pitch + (size_t)px * 4) = 0x00ff8080u;
+                *(uint16_t*)(a.rsm_depth.ptr + (size_t)view * a.rsm_depth.slice_pitch + (size_t)py * a.rsm_depth.row_pitch + (size_t)px * 2) = 0xffffu;
+            } else if (key == 0ull) {  // clear values, gbuffer_phase.cpp:66-87
 #endif
                 *(uint32_t*)(a.out_color.ptr + (size_t)py * a.out_color.pitch + (size_t)px * 4) = 0u;
                 *(uint2*)(a.out_normals.ptr + (size_t)py * a.out_normals.pitch + (size_t)px * 8) = make_uint2(0x38003800u, 0x00003c00u);
@@ -726,10 +763,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
             } else {
                 // an unclipped triangle sits in the slot of its work item (one view: slot = running triangle number = seq / 8);
                 // the fans of clipped ones were appended and are found through the table
-                const uint32_t seq = 0xffffffffu - (uint32_t)key;
-                uint32_t r = seq >> 3;
-                if ((seq & 7u) != 0u || r >= a.record_capacity || is_empty(a.records[r])) r = a.seq_to_record[seq];
-                shade_and_store(a, r, px, py, __uint_as_float((uint32_t)(key >> 32)));
+                const uint32_t seq = 0xffffffffu - (uint32_t)key, total = a.counters[C_TRIS];
+                uint64_t r = (uint64_t)view * total + (seq >> 3);
+                if ((seq & 7u) != 0u || r >= a.record_capacity || is_empty(a.records[r])) r = a.seq_to_record[(uint64_t)view * total * 8u + seq];
+                if (a.rsm) shade_rsm_and_store(a, (uint32_t)r, view, px, py, 0xffffu - (uint32_t)(key >> 32));
+                else shade_and_store(a, (uint32_t)r, px, py, __uint_as_float((uint32_t)(key >> 32)));
             }
         }
     }
@@ -738,7 +776,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
 // seq -> record index for the appended records (fans of clipped triangles; G-buffer resolve)
 __global__ __launch_bounds__(256) void k_seq_table(const RasterArgs a) {
     const uint32_t nrec = record_count(a), first = a.counters[C_TRIS] * a.num_views;
-    for (uint32_t r = first + blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256) a.seq_to_record[a.records[r].seq] = r;
+    for (uint32_t r = first + blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256)
+        a.seq_to_record[(uint64_t)a.records[r].view * a.counters[C_TRIS] * 8u + a.records[r].seq] = r;
 }
 
 }  // namespace

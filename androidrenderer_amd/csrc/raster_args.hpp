@@ -60,6 +60,10 @@ struct RasterArgs {
     uint32_t* pairs;
     uint32_t* seq_to_record;
     const uint8_t* half_to_srgb8;  // 65536 entries: fp16 bit pattern -> sRGB8 code
+    // RSM variant of the G-buffer path (sah_rsm_render): per-view clip matrices, D16 LESS, flux / normal targets
+    uint32_t rsm;
+    float sun_direction[3];
+    VolumeArg rsm_flux, rsm_normals, rsm_depth;
     // outputs
     VolumeArg shadowmap;
     PlaneArg out_color, out_normals, out_data, out_emission, out_depth;

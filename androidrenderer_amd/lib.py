@@ -22,7 +22,8 @@ _lib = None
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
-           "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_allgather_rows"]
+           "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
+           "sah_lpv_inject_vpls", "sah_allgather_rows"]
 
 
 def load():
@@ -59,6 +60,12 @@ def load():
     lib.sah_shadow_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.c_uint32,
                                       C.POINTER(_abi.Volume), C.c_void_p]
     lib.sah_gbuffer_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.GBuffer), C.c_void_p]
+    lib.sah_rsm_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.LpvCascadeMatrices),
+                                   C.c_uint32, C.POINTER(_abi.RsmTargets), C.c_void_p]
+    lib.sah_lpv_extract_vpls.argtypes = [C.c_void_p, C.POINTER(_abi.RsmTargets), C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_float, C.c_void_p,
+                                         C.c_void_p]
+    lib.sah_lpv_inject_vpls.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_uint32,
+                                        C.POINTER(_abi.Volume)]
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
@@ -139,6 +146,19 @@ class Context:
 
     def gbuffer_render(self, scene, view, gbuffer, stats_ptr=None):
         self._check(self.lib.sah_gbuffer_render(self.handle, C.byref(scene), C.byref(view), C.byref(gbuffer), C.c_void_p(stats_ptr)))
+
+    def rsm_render(self, scene, sun, cascades, num_cascades, rsm, stats_ptr=None):
+        """cascades: (LpvCascadeMatrices * n) host array; rsm: _abi.RsmTargets of device volumes."""
+        self._check(self.lib.sah_rsm_render(self.handle, C.byref(scene), C.byref(sun), cascades, num_cascades, C.byref(rsm), C.c_void_p(stats_ptr)))
+
+    def lpv_extract_vpls(self, rsm, cascades, cascade_index, grid_cell_size, vpl_list_ptr, vpl_count_ptr):
+        self._check(self.lib.sah_lpv_extract_vpls(self.handle, C.byref(rsm), cascades, cascade_index, grid_cell_size, C.c_void_p(vpl_list_ptr),
+                                                  C.c_void_p(vpl_count_ptr)))
+
+    def lpv_inject_vpls(self, vpl_list_ptr, vpl_count_ptr, capacity, cascades, cascade_index, num_cascades, rgb):
+        vols = (_abi.Volume * 3)(*rgb)
+        self._check(self.lib.sah_lpv_inject_vpls(self.handle, C.c_void_p(vpl_list_ptr), C.c_void_p(vpl_count_ptr), capacity, cascades, cascade_index,
+                                                 num_cascades, vols))
 
     def allgather_rows(self, image, rows_per_rank):
         self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank))

@@ -353,6 +353,43 @@ int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_s
  * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253 (SAH_MAIN_VIEW).  Writes all five planes of `out`. */
 int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_view_data* view, const sah_gbuffer* out, uint32_t* stats);
 
+/* ---- LPV injection chain: RSM -> VPL list -> LPV (SURVEY.md §8-f4 and the producers of a3's volumes) -------------------------
+ * LightPropagationVolume::inject_indirect_sun_light — RenderCore/render/gi/light_propagation_volume.cpp:548-697. */
+
+/* RSM targets, 2D arrays with one layer per LPV cascade (light_propagation_volume.cpp:422-452). */
+typedef struct sah_rsm_targets {
+    sah_volume flux;    /* R8G8B8A8_SRGB  */
+    sah_volume normals; /* R8G8B8A8_UNORM */
+    sah_volume depth;   /* D16_UNORM      */
+} sah_rsm_targets;
+
+/* "Render RSM" (light_propagation_volume.cpp:566-615): every primitive into every cascade layer through cascades[i].rsm_vp with the
+ * `_rsm` pipelines (material_pipelines.cpp:69-102: compare LESS, no depth clamp) and the SAH_RSM stages of
+ * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253 — flux = Fd(surface, -sun direction, normal) with the metalness and
+ * roughness the shader leaves at 0 in this variant, normal * 0.5 + 0.5.  Same rasteriser and rules as sah_shadow_render. */
+int sah_rsm_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_light_constants* sun, const sah_lpv_cascade_matrices* cascades,
+                   uint32_t num_cascades, const sah_rsm_targets* rsm, uint32_t* stats);
+
+/* PackedVPL — RenderCore/shared/vpl.hpp:21-23: position.xy | position.z, color.r | color.gb as halfs, normal as snorm4x8. */
+typedef struct sah_packed_vpl {
+    uint32_t data[4];
+} sah_packed_vpl;
+
+/* "Extract VPLs" — RenderCore/shaders/gi/lpv/rsm_generate_vpls.comp:86-139, one invocation per 2x2 RSM texels of layer
+ * `cascade_index`.  The shader appends with atomicAdd, so the order of its list is not a function of the input; this ABI stores the
+ * lights in ascending invocation index (row-major over the (res/2)^2 invocations), which also fixes the order in which
+ * sah_lpv_inject_vpls adds them.  round() and packSnorm4x8 round half to even.  vpl_list: room for (res/2)^2 entries; vpl_count:
+ * one uint32; both DEVICE pointers. */
+int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv_cascade_matrices* cascades, uint32_t cascade_index,
+                         float grid_cell_size, sah_packed_vpl* vpl_list, uint32_t* vpl_count);
+
+/* "VPL Injection" — the point-list render pass of light_propagation_volume.cpp:699-760 with
+ * RenderCore/shaders/gi/lpv/vpl_injection.{vert,frag} and additive blending into the three RGBA16F volumes: VPL i lands in the cell
+ * (floor(x_f), floor(y_f), int(z * 32)) of its cascade, lights that fall outside the volume are dropped, and lights of one cell are
+ * added in list order, each sum rounded to half (what the blend unit does in primitive order). */
+int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint32_t* vpl_count, uint32_t capacity,
+                        const sah_lpv_cascade_matrices* cascades, uint32_t cascade_index, uint32_t num_cascades, const sah_volume rgb[3]);
+
 /* Multi-GPU: in-place all-gather of row blocks of `image` (rank r owns rows
  * [rows_per_rank*r, rows_per_rank*(r+1))) over RCCL. */
 int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank);

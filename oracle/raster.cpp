@@ -13,6 +13,7 @@
 
 #include "../include/sah_hip.h"
 #include "codec.hpp"
+#include "brdf.hpp"
 #include "math.hpp"
 
 namespace orc {
@@ -285,6 +286,34 @@ GbufferTexel shade_fragment(const sah_material& m, const VertexOut vo[3], const 
 
 bool plane_is(const sah_plane& p, uint32_t fmt, uint32_t w, uint32_t h) { return p.ptr && p.format == fmt && p.width == w && p.height == h; }
 
+// ---- RSM fragment stage (gltf_basic_pbr.slang:169-253, SAH_RSM) -------------------------------------------------------------------
+// gbuffer.normal = vertex.normal (no normal map outside SAH_MAIN_VIEW); gbuffer.data stays 0 in this variant (its block is compiled
+// out, :210-227), so the surface has metalness 0 and roughness 0; flux = Fd(surface, -sun direction, surface.normal).
+struct RsmTexel {
+    uint8_t flux[4], normal[4];
+    bool discarded;
+};
+RsmTexel shade_rsm_fragment(const sah_material& m, const VertexOut vo[3], const F lambda[3], const float sun_direction[3]) {
+    RsmTexel out{};
+    H color[4], normal[3];
+    for (int k = 0; k < 4; k++) color[k] = interpolate(lambda, vo[0].color[k], vo[1].color[k], vo[2].color[k]);
+    for (int k = 0; k < 3; k++) normal[k] = interpolate(lambda, vo[0].normal[k], vo[1].normal[k], vo[2].normal[k]);
+    H tinted[4];
+    for (int k = 0; k < 4; k++) tinted[k] = H(m.base_color_texel[k]) * color[k] * H(m.base_color_tint[k]);
+    out.discarded = tinted[3].v <= m.opacity_threshold;
+    Surface<H> s;
+    s.base_color = {tinted[0], tinted[1], tinted[2]};
+    s.normal = {normal[0], normal[1], normal[2]};
+    s.metalness = H(0.0f);
+    s.roughness = H(0.0f);
+    const H3 l{-H(sun_direction[0]), -H(sun_direction[1]), -H(sun_direction[2])};
+    const H3 flux = Fd(s, l, s.normal);
+    out.flux[0] = srgb8(flux.x); out.flux[1] = srgb8(flux.y); out.flux[2] = srgb8(flux.z); out.flux[3] = 255;
+    for (int k = 0; k < 3; k++) out.normal[k] = float_to_unorm8((normal[k] * H(0.5f) + H(0.5f)).v);
+    out.normal[3] = 255;
+    return out;
+}
+
 }  // namespace
 }  // namespace orc
 
@@ -362,6 +391,56 @@ int orc_gbuffer_render(const sah_scene_geometry* scene, const sah_view_data* vie
                                  std::memcpy(at(out->data, f.x, f.y, 4), t.data, 4);
                                  std::memcpy(at(out->emission, f.x, f.y, 4), t.emission, 4);
                              });
+        }
+    }
+    write_stats(stats, st);
+    return SAH_OK;
+}
+
+int orc_rsm_render(const sah_scene_geometry* scene, const sah_sun_light_constants* sun, const sah_lpv_cascade_matrices* cascades, uint32_t num_cascades,
+                   const sah_rsm_targets* rsm, uint32_t* stats) {
+    using namespace orc;
+    if (!geometry_ok(scene, true) || !sun || !cascades || !rsm || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
+    const uint32_t W = rsm->depth.width, H = rsm->depth.height;
+    if (W == 0 || H == 0 || W > 8192 || H > 8192 || rsm->depth.format != SAH_FORMAT_D16_UNORM || rsm->flux.format != SAH_FORMAT_R8G8B8A8_SRGB ||
+        rsm->normals.format != SAH_FORMAT_R8G8B8A8_UNORM || rsm->flux.width != W || rsm->flux.height != H || rsm->normals.width != W ||
+        rsm->normals.height != H || rsm->depth.depth < num_cascades || rsm->flux.depth < num_cascades || rsm->normals.depth < num_cascades)
+        return SAH_ERR_INVALID_ARGUMENT;
+    auto at = [&](const sah_volume& v, uint32_t layer, int x, int y, int bpp) {
+        return (uint8_t*)v.ptr + (size_t)layer * v.slice_pitch_bytes + (size_t)y * v.row_pitch_bytes + (size_t)x * bpp;
+    };
+    Stats st;
+    for (uint32_t layer = 0; layer < num_cascades; layer++) {
+        const uint8_t clear_normal[4] = {128, 128, 255, 0};  // (0.5, 0.5, 1, 0), light_propagation_volume.cpp:596-600
+        for (uint32_t y = 0; y < H; y++)
+            for (uint32_t x = 0; x < W; x++) {
+                std::memset(at(rsm->flux, layer, x, y, 4), 0, 4);
+                std::memcpy(at(rsm->normals, layer, x, y, 4), clear_normal, 4);
+                const uint16_t one = 0xffffu;
+                std::memcpy(at(rsm->depth, layer, x, y, 2), &one, 2);
+            }
+        const M4 rsm_vp = load_m4(cascades[layer].rsm_vp);
+        for (uint32_t p = 0; p < scene->num_primitives; p++) {
+            const sah_primitive& prim = scene->primitives[p];
+            const sah_material& mat = scene->materials[prim.material];
+            for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {
+                VertexOut vo[3];
+                for (int k = 0; k < 3; k++) vo[k] = vertex_outputs(*scene, prim, scene->indices[prim.first_index + 3 * tri + k]);
+                process_triangle(*scene, prim, tri, /*clip_depth=*/true, W, H, st, [&](F4 world) { return mul(rsm_vp, world); },
+                                 [&](const Fragment& f, uint32_t) {
+                                     const F z = nclamp(f.z, F(0.0f), F(1.0f));
+                                     const uint32_t code = (uint32_t)std::nearbyint(z.v * 65535.0f);
+                                     uint16_t stored;
+                                     std::memcpy(&stored, at(rsm->depth, layer, f.x, f.y, 2), 2);
+                                     if (!(code < stored)) return;  // VK_COMPARE_OP_LESS on the D16 code: the first of equal codes stays
+                                     const RsmTexel t = shade_rsm_fragment(mat, vo, f.lambda, sun->direction_and_tan_size);
+                                     if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && t.discarded) return;
+                                     const uint16_t c16 = (uint16_t)code;
+                                     std::memcpy(at(rsm->depth, layer, f.x, f.y, 2), &c16, 2);
+                                     std::memcpy(at(rsm->flux, layer, f.x, f.y, 4), t.flux, 4);
+                                     std::memcpy(at(rsm->normals, layer, f.x, f.y, 4), t.normal, 4);
+                                 });
+            }
         }
     }
     write_stats(stats, st);

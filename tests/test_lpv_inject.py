@@ -1,0 +1,262 @@
+"""LPV injection chain: RSM render -> VPL extraction -> VPL injection, the producers of the volumes the LPV overlay
+(a3) gathers from.  CPU: known answers on the oracle.  GPU: HIP against the oracle bit for bit, stage by stage and end to end through
+propagation and the lighting pass."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, mesh, scene, synth
+from tests import util
+
+RES = 128  # r.GI.LPV.RsmResolution default (light_propagation_volume.cpp:55-59)
+CELL = 0.25  # r.GI.LPV.CellSize default
+
+
+def _setup(w=192, h=108):
+    view = scene.SceneView.default(w, h)
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+    lpv = scene.LpvCascades()
+    lpv.update_cascade_transforms(view, sun)
+    return view, sun, lpv
+
+
+def _rsm_arrays(res=RES, layers=4):
+    return {"flux": np.zeros((layers, res, res, 4), np.uint8), "normals": np.zeros((layers, res, res, 4), np.uint8),
+            "depth": np.zeros((layers, res, res), np.uint16)}
+
+
+def _rsm_desc(a):
+    return _abi.RsmTargets(images.volume(a["flux"], _abi.FORMAT_R8G8B8A8_SRGB), images.volume(a["normals"], _abi.FORMAT_R8G8B8A8_UNORM),
+                           images.volume(a["depth"], _abi.FORMAT_D16_UNORM))
+
+
+def _oracle_rsm(arrays, sun, lpv, res=RES):
+    out = _rsm_arrays(res)
+    g = mesh.geometry(mesh.with_counts(arrays), [])
+    d = _rsm_desc(out)
+    assert util.oracle().orc_rsm_render(C.byref(g), C.byref(sun.constants), lpv.matrices, 4, C.byref(d), None) == 0
+    return out
+
+
+def _oracle_extract(rsm, lpv, cascade):
+    res = rsm["depth"].shape[1]
+    vpls = np.zeros(((res // 2) ** 2, 4), np.uint32)
+    count = np.zeros(1, np.uint32)
+    d = _rsm_desc(rsm)
+    assert util.oracle().orc_lpv_extract_vpls(C.byref(d), lpv.matrices, cascade, CELL, vpls.ctypes.data, count.ctypes.data) == 0
+    return vpls, int(count[0])
+
+
+def _oracle_inject(vpls, count, lpv, cascade, vols):
+    cnt = np.array([count], np.uint32)
+    v = (_abi.Volume * 3)(*[images.volume(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in vols])
+    assert util.oracle().orc_lpv_inject_vpls(vpls.ctypes.data, cnt.ctypes.data, vpls.shape[0], lpv.matrices, cascade, 4, v) == 0
+
+
+def _empty_volumes():
+    return [np.zeros((32, 32, 128, 4), np.uint16) for _ in range(3)]
+
+
+def test_oracle_rsm_of_the_atrium():
+    view, sun, lpv = _setup()
+    rsm = _oracle_rsm(mesh.atrium().arrays(), sun, lpv)
+    covered = rsm["depth"] != 0xffff
+    assert 0.3 < covered[0].mean() <= 1.0 and covered.any(axis=(1, 2)).all()
+    # clear values where nothing was drawn (light_propagation_volume.cpp:586-606)
+    assert (rsm["flux"][~covered] == 0).all() and (rsm["normals"][~covered] == np.array([128, 128, 255, 0], np.uint8)).all()
+    # flux = Fd(surface, -sun, normal): zero where the surface faces away from the sun, positive on the sunlit floor; alpha 1
+    lit = covered & (rsm["flux"][..., :3].max(axis=-1) > 0)
+    assert lit.mean() > 0.05 and (rsm["flux"][covered][:, 3] == 255).all()
+    up = lit & (rsm["normals"][..., 1] == 255)  # normal (0, 1, 0) -> (128, 255, 128)
+    assert up.sum() > 100 and (rsm["normals"][up][:, 0] == 128).all()
+
+
+def test_oracle_vpl_extraction_known_answers():
+    _, _, lpv = _setup()
+    rsm = _rsm_arrays()
+    rsm["depth"][:] = 0xffff
+    rsm["normals"][...] = (128, 128, 255, 0)
+    vpls, count = _oracle_extract(rsm, lpv, 0)
+    assert count == 0  # black flux: nothing stored
+    # one bright texel: exactly one light, in the slot of its invocation order, carrying the texel's colour / 1 sample
+    rsm["flux"][1, 40, 60] = (255, 128, 0, 255)
+    rsm["normals"][1, 40, 60] = (128, 255, 128, 255)
+    rsm["depth"][1, 40, 60] = 30000
+    rsm["flux"][1, 10, 20] = (10, 10, 10, 255)
+    rsm["normals"][1, 10, 20] = (255, 128, 128, 255)
+    rsm["depth"][1, 10, 20] = 20000
+    vpls, count = _oracle_extract(rsm, lpv, 1)
+    assert count == 2
+    first, second = vpls[0], vpls[1]  # invocation (10, 5) comes before (30, 20)
+    o = util.oracle()
+    r = np.array([second[1] >> 16], np.uint16).view(np.float16)[0]
+    assert abs(float(r) - 1.0) < 1e-3  # sRGB 255 -> 1.0, one sample in the 2x2 footprint... the dark neighbours share the cell
+    n = [(int(second[3]) >> (8 * k)) & 0xff for k in range(3)]
+    assert n[1] == 127 and abs(np.int8(n[0])) <= 1 and abs(np.int8(n[2])) <= 1  # snorm (0, 1, 0)
+    n0 = [(int(first[3]) >> (8 * k)) & 0xff for k in range(3)]
+    assert n0[0] == 127
+    assert o.orc_f16_to_f32(int(first[1]) >> 16) > 0
+
+
+def test_oracle_vpl_injection_known_answers():
+    _, _, lpv = _setup()
+    m = np.array(lpv.matrices[0].cascade_to_world[:], np.float32).reshape(4, 4)  # [col][row]
+
+    def world(u, v, w):  # cascade UV -> world
+        p = u * m[0] + v * m[1] + w * m[2] + m[3]
+        return p[:3] / p[3]
+
+    def pack(pos, col, nrm):
+        h = lambda x: int(np.array([x], np.float16).view(np.uint16)[0])
+        s = lambda x: int(np.rint(np.clip(x, -1, 1) * 127)) & 0xff
+        return [h(pos[0]) | (h(pos[1]) << 16), h(pos[2]) | (h(col[0]) << 16), h(col[1]) | (h(col[2]) << 16), s(nrm[0]) | (s(nrm[1]) << 8) | (s(nrm[2]) << 16)]
+
+    centre = world((10 + 0.5) / 32, (12 + 0.5) / 32, (7 + 0.5) / 32)
+    lights = np.array([pack(centre, (0.5, 0.5, 0.5), (0, 1, 0)), pack(centre, (0.5, 0.5, 0.5), (0, 1, 0)),
+                       pack(world(5.0, 0.5, 0.5), (1, 1, 1), (0, 1, 0)),          # outside the volume: dropped
+                       pack(centre, (0, 0, 0), (0, 1, 0))], np.uint32)            # black: culled
+    vols = _empty_volumes()
+    _oracle_inject(lights, 4, lpv, 0, vols)
+    touched = [np.argwhere(v.any(axis=-1)) for v in vols]
+    for t in touched:
+        assert len(t) == 1 and tuple(t[0]) == (7, 12, 10)  # (z, y, x) of cascade 0
+    sh = vols[0][7, 12, 10].view(np.float16).astype(np.float32)
+    # grey light: hsv saturation 0, so corrected = colour / 16; two lights: 2 * c0 * (0.5 / 16) / pi, and -c1 * n.y on the second band
+    assert np.isclose(sh[0], 2 * 0.886226925 * (0.5 / 16) / np.pi, rtol=2e-3)
+    assert np.isclose(sh[1], -2 * 1.02332671 * (0.5 / 16) / np.pi, rtol=2e-3) and sh[2] == 0 and sh[3] == 0
+    assert np.array_equal(vols[0], vols[1]) and np.array_equal(vols[0], vols[2])
+    # a light outside its own cascade but inside the volume is NOT dropped: the vertex shader only maps (x + cascade) / num_cascades,
+    # so u = 3.0 of cascade 0 spills into the cells of cascade 3 (vpl_injection.vert:50-56)
+    spill = _empty_volumes()
+    _oracle_inject(np.array([pack(world(3.5 / 1.0, 0.5, 0.5), (1, 1, 1), (0, 1, 0))], np.uint32), 1, lpv, 0, spill)
+    ts = np.argwhere(spill[0].any(axis=-1))
+    assert len(ts) == 1 and 96 <= ts[0][2] < 128
+    # the same two grey lights through cascade 1's matrices land in cascade 1's block of cells
+    vols1 = _empty_volumes()
+    _oracle_inject(lights[:2], 2, lpv, 1, vols1)
+    t1 = np.argwhere(vols1[0].any(axis=-1))
+    assert len(t1) == 1 and 32 <= t1[0][2] < 64
+
+
+# ---- GPU parity ------------------------------------------------------------------------------------------------------------------------
+
+def _hip_rsm(ctx, arrays, sun, lpv, res=RES):
+    import torch
+    dev = mesh.to_device(arrays)
+    keep = []
+    g = mesh.geometry(dev, keep)
+    t = {"flux": torch.full((4, res, res, 4), 9, dtype=torch.uint8, device="cuda"), "normals": torch.full((4, res, res, 4), 9, dtype=torch.uint8, device="cuda"),
+         "depth": torch.full((4, res, res), 9, dtype=torch.int16, device="cuda")}
+    ctx.rsm_render(g, sun.constants, lpv.matrices, 4, _rsm_desc(t))
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["atrium", "soup"])
+def test_hip_rsm_matches_oracle(hip_ctx, scene_name):
+    view, sun, lpv = _setup()
+    arrays = mesh.atrium(2).arrays() if scene_name == "atrium" else mesh.random_soup(31, triangles=800, extent=8.0).arrays()
+    want = _oracle_rsm(arrays, sun, lpv)
+    got = _hip_rsm(hip_ctx, arrays, sun, lpv)
+    for k in ("depth", "flux", "normals"):
+        g = got[k].cpu().numpy()
+        g = g.view(np.uint16) if k == "depth" else g
+        bad = np.argwhere(g != want[k])
+        assert bad.size == 0, f"{k}: {len(bad)} mismatches, first at {bad[0]}: hip {g[tuple(bad[0])]} oracle {want[k][tuple(bad[0])]}"
+    assert (want["depth"] != 0xffff).mean() > 0.2
+
+
+@pytest.mark.gpu
+def test_hip_lpv_injection_chain_matches_oracle(hip_ctx):
+    """RSM -> VPLs -> LPV on the GPU against the same chain on the CPU, then propagation and the lighting pass on the injected volumes"""
+    import torch
+    w, h = 192, 108
+    view, sun, lpv = _setup(w, h)
+    arrays = mesh.atrium(2).arrays()
+    rsm_np = _oracle_rsm(arrays, sun, lpv)
+    rsm_t = _hip_rsm(hip_ctx, arrays, sun, lpv)
+    vols_np = _empty_volumes()
+    vols_t = [torch.zeros((32, 32, 128, 4), dtype=torch.int16, device="cuda") for _ in range(3)]
+    vol_desc = [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols_t]
+    cap = (RES // 2) ** 2
+    total = 0
+    for cascade in range(4):
+        want_vpls, want_count = _oracle_extract(rsm_np, lpv, cascade)
+        list_t = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+        count_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hip_ctx.lpv_extract_vpls(_rsm_desc(rsm_t), lpv.matrices, cascade, CELL, list_t.data_ptr(), count_t.data_ptr())
+        torch.cuda.synchronize()
+        assert int(count_t.item()) == want_count
+        assert np.array_equal(list_t.cpu().numpy().view(np.uint32)[:want_count], want_vpls[:want_count]), f"cascade {cascade}: VPL list differs"
+        total += want_count
+        _oracle_inject(want_vpls, want_count, lpv, cascade, vols_np)
+        hip_ctx.lpv_inject_vpls(list_t.data_ptr(), count_t.data_ptr(), cap, lpv.matrices, cascade, 4, vol_desc)
+    torch.cuda.synchronize()
+    assert total > 500
+    for c in range(3):
+        got = vols_t[c].cpu().numpy().view(np.uint16)
+        bad = np.argwhere(got != vols_np[c])
+        assert bad.size == 0, f"volume {c}: {len(bad)} texels differ, first {bad[0]}: hip {got[tuple(bad[0])]:#x} oracle {vols_np[c][tuple(bad[0])]:#x}"
+    assert sum(int(v.any(axis=-1).sum()) for v in vols_np) > 300  # light went in
+    # propagate the injected light and shade with it: HIP == oracle on the whole chain
+    o = util.oracle()
+    b_np = [np.zeros_like(v) for v in vols_np]
+    a_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols_np])
+    b_v = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in b_np])
+    assert o.orc_lpv_propagate(a_v, b_v, 4, 8) == 0
+    b_t = [torch.zeros_like(t) for t in vols_t]
+    hip_ctx.lpv_propagate(vol_desc, [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in b_t], 4, 8)
+    torch.cuda.synchronize()
+    for c in range(3):
+        assert np.array_equal(vols_t[c].cpu().numpy().view(np.uint16), vols_np[c]), f"propagated volume {c}"
+    fr = util.LightingFrame(w, h, seed=5, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    fr.arrays["lpv_r"], fr.arrays["lpv_g"], fr.arrays["lpv_b"] = [v.view(np.float16) for v in vols_np]
+    d = util.f16_ulp_diff(fr.run_hip(hip_ctx), fr.run_oracle())
+    assert d.max() == 0, util.report_ulp("lit with injected LPV", d)
+
+
+@pytest.mark.gpu
+def test_hip_vpl_stages_on_adversarial_input(hip_ctx):
+    """random RSM contents (NaN-free by construction of the formats, but every code value) and random VPL lists, including lights
+    outside the volume, zero normals and colours, many lights per cell"""
+    import torch
+    _, _, lpv = _setup()
+    g = synth.rng(77)
+    rsm = {"flux": g.integers(0, 256, (4, RES, RES, 4), dtype=np.uint8), "normals": g.integers(0, 256, (4, RES, RES, 4), dtype=np.uint8),
+           "depth": g.integers(0, 65536, (4, RES, RES), dtype=np.uint16)}
+    rsm["flux"][:, ::3] = 0
+    rsm_t = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).cuda() for k, v in rsm.items()}
+    cap = (RES // 2) ** 2
+    for cascade in (0, 3):
+        want, count = _oracle_extract(rsm, lpv, cascade)
+        list_t = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+        count_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hip_ctx.lpv_extract_vpls(_rsm_desc(rsm_t), lpv.matrices, cascade, CELL, list_t.data_ptr(), count_t.data_ptr())
+        torch.cuda.synchronize()
+        assert int(count_t.item()) == count and count > 100
+        assert np.array_equal(list_t.cpu().numpy().view(np.uint32)[:count], want[:count])
+    # random lists: positions as halfs in a box a little larger than cascade 0, all normal / colour bit patterns
+    n = 3000
+    m = np.array(lpv.matrices[0].cascade_to_world[:], np.float32).reshape(4, 4)
+    uvw = g.uniform(-0.1, 1.1, (n, 3)).astype(np.float32)
+    uvw[: n // 2] = (uvw[: n // 2] * 0.05 + 0.4)  # half of them crowd a few cells
+    pos = (uvw[:, 0:1] * m[0] + uvw[:, 1:2] * m[1] + uvw[:, 2:3] * m[2] + m[3])[:, :3].astype(np.float16).view(np.uint16).astype(np.uint32)
+    col = g.uniform(0, 4, (n, 3)).astype(np.float16)
+    col[::7] = 0
+    col = col.view(np.uint16).astype(np.uint32)
+    lights = np.stack([pos[:, 0] | (pos[:, 1] << 16), pos[:, 2] | (col[:, 0] << 16), col[:, 1] | (col[:, 2] << 16),
+                       g.integers(0, 1 << 24, n, dtype=np.uint64).astype(np.uint32)], axis=1).astype(np.uint32)
+    lights[::11, 3] = 0  # zero normal: normalize gives NaN, the light is kept or dropped exactly as the oracle decides
+    vols_np = [g.integers(0, 0x3c00, (32, 32, 128, 4), dtype=np.uint16) for _ in range(3)]  # non-empty volumes: the blend reads them
+    vols_t = [torch.from_numpy(v.view(np.int16).copy()).cuda() for v in vols_np]
+    _oracle_inject(lights, n, lpv, 0, vols_np)
+    list_t = torch.from_numpy(lights.view(np.int32)).cuda()
+    count_t = torch.tensor([n], dtype=torch.int32, device="cuda")
+    hip_ctx.lpv_inject_vpls(list_t.data_ptr(), count_t.data_ptr(), n, lpv.matrices, 0, 4, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols_t])
+    torch.cuda.synchronize()
+    for c in range(3):
+        got = vols_t[c].cpu().numpy().view(np.uint16)
+        bad = np.argwhere(got != vols_np[c])
+        assert bad.size == 0, f"volume {c}: {len(bad)} texels differ, first {bad[0]}"

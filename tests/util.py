@@ -65,6 +65,10 @@ def oracle():
     o.orc_probe_update.argtypes = [C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
     o.orc_shadow_render.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.c_uint32, C.POINTER(_abi.Volume), C.c_void_p]
     o.orc_gbuffer_render.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.GBuffer), C.c_void_p]
+    o.orc_rsm_render.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32,
+                                 C.POINTER(_abi.RsmTargets), C.c_void_p]
+    o.orc_lpv_extract_vpls.argtypes = [C.POINTER(_abi.RsmTargets), C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
+    o.orc_lpv_inject_vpls.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_uint32, C.POINTER(_abi.Volume)]
     _oracle = o
     return o
 
