@@ -346,15 +346,44 @@ public:
 };
 
 // RenderCore/render/gi/light_propagation_volume.{hpp,cpp}: volumes :321-378, cascades :455-546, clear :839-926,
-// propagate :970-1063, overlay :274-306.  RSM raster / VPL injection are outside the hot path: inject() is the seam.
+// propagate :970-1063, overlay :274-306, RSM + VPL extraction + injection :548-760.
 class LightPropagationVolume : public IGlobalIlluminator {
 public:
     explicit LightPropagationVolume(RenderBackend& backend, uint32_t cascades = 4, uint32_t steps = 32) : num_cascades(cascades), num_steps(steps) {
         auto& alloc = backend.get_global_allocator();
         const char* names[7] = {"LPV Red A", "LPV Green A", "LPV Blue A", "LPV Red B", "LPV Green B", "LPV Blue B", "Geometry Volume"};
         for (int i = 0; i < 7; i++) vol[i] = alloc.create_volume_texture(names[i], SAH_FORMAT_R16G16B16A16_SFLOAT, 32 * cascades, 32, 32);
+        // RSM targets and VPL lists, light_propagation_volume.cpp:385-452 (r.GI.LPV.RsmResolution = 128: 4096 lights per cascade)
+        rsm_flux = alloc.create_texture("RSM Flux", SAH_FORMAT_R8G8B8A8_SRGB, rsm_resolution, rsm_resolution, cascades);
+        rsm_normals = alloc.create_texture("RSM Normals", SAH_FORMAT_R8G8B8A8_UNORM, rsm_resolution, rsm_resolution, cascades);
+        rsm_depth = alloc.create_texture("RSM Depth", SAH_FORMAT_D16_UNORM, rsm_resolution, rsm_resolution, cascades);
+        const size_t num_vpls = (size_t)rsm_resolution * rsm_resolution / 4;
+        if (hipMalloc((void**)&vpl_lists, cascades * num_vpls * sizeof(sah_packed_vpl)) != hipSuccess || hipMalloc((void**)&vpl_counts, cascades * sizeof(uint32_t)) != hipSuccess)
+            throw std::runtime_error("LightPropagationVolume: VPL buffers");
     }
-    void update_cascade_transforms(const SceneView& view, const DirectionalLight&) {
+    ~LightPropagationVolume() {
+        if (vpl_lists) (void)hipFree(vpl_lists);
+        if (vpl_counts) (void)hipFree(vpl_counts);
+    }
+    // light_propagation_volume.cpp:548-697: render the RSM of every cascade, extract the VPLs, add them to the A volumes
+    void inject_indirect_sun_light(RenderGraph& graph, const RenderScene& scene) {
+        graph.add_pass({"Render RSM", [this, &scene](sah_ctx* ctx) {
+                            const sah_rsm_targets rsm = {rsm_flux->desc, rsm_normals->desc, rsm_depth->desc};
+                            return sah_rsm_render(ctx, &scene.geometry, &scene.sun.get_constants(), cascades.data(), num_cascades, &rsm, nullptr);
+                        }});
+        for (uint32_t c = 0; c < num_cascades; c++)
+            graph.add_pass({"Extract and inject VPLs", [this, c](sah_ctx* ctx) {
+                                const sah_rsm_targets rsm = {rsm_flux->desc, rsm_normals->desc, rsm_depth->desc};
+                                const uint32_t num_vpls = rsm_resolution * rsm_resolution / 4;
+                                sah_packed_vpl* list = vpl_lists + (size_t)c * num_vpls;
+                                if (int rc = sah_lpv_extract_vpls(ctx, &rsm, cascades.data(), c, 0.25f, list, vpl_counts + c); rc != SAH_OK) return rc;
+                                const sah_volume a[3] = {vol[0]->desc, vol[1]->desc, vol[2]->desc};
+                                return sah_lpv_inject_vpls(ctx, list, vpl_counts + c, num_vpls, cascades.data(), c, num_cascades, a);
+                            }});
+    }
+    void update_cascade_transforms(const SceneView& view, const DirectionalLight& light) {
+        const auto& dir = light.get_constants().direction_and_tan_size;
+        const Vec3 light_dir = v_normalize({dir[0], dir[1], dir[2]});
         for (uint32_t c = 0; c < num_cascades; c++) {
             const float cell = 0.25f * std::pow(2.f, (float)c), size = 32.f * cell;
             const Vec3 p = view.get_position(), f = view.get_forward();
@@ -367,6 +396,14 @@ public:
             }
             std::memcpy(cascades[c].world_to_cascade, m.data(), 64);
             std::memcpy(cascades[c].cascade_to_world, mat_inverse(m).data(), 64);
+            // RSM frustum (:499-531): look at the snapped cascade centre from two cascade sizes up the light direction
+            Vec3 centre{};
+            for (int i = 0; i < 3; i++) centre[i] = std::round((p[i] + f[i] * (size * (0.5f - 0.1f))) / (cell * 2.f)) * cell * 2.f;
+            const float pull = size * 2.f, half = size / 2.f;
+            const Mat4 rsm_view = look_at({centre[0] - light_dir[0] * pull, centre[1] - light_dir[1] * pull, centre[2] - light_dir[2] * pull}, centre, {0.f, 1.f, 0.f});
+            const Mat4 rsm_vp = mat_mul(ortho(-half, half, -half, half, 0.f, pull * 2.f), rsm_view);
+            std::memcpy(cascades[c].rsm_vp, rsm_vp.data(), 64);
+            std::memcpy(cascades[c].inverse_rsm_vp, mat_inverse(rsm_vp).data(), 64);
         }
     }
     void pre_render(RenderGraph& graph, const SceneView&, const RenderScene&, TextureHandle) override {
@@ -391,7 +428,11 @@ public:
 
 private:
     uint32_t num_cascades, num_steps;
+    uint32_t rsm_resolution = 128;
     TextureHandle vol[7]{};
+    TextureHandle rsm_flux = nullptr, rsm_normals = nullptr, rsm_depth = nullptr;
+    sah_packed_vpl* vpl_lists = nullptr;
+    uint32_t* vpl_counts = nullptr;
     std::array<sah_lpv_cascade_matrices, 4> cascades{};
 };
 

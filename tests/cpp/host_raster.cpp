@@ -68,6 +68,11 @@ int main(int argc, char** argv) {
     scene.sun.render_shadows(graph, scene.geometry);
     GbufferPhase gbuffer_phase;
     gbuffer_phase.render(graph, scene, gbuffer, view);
+    // the LPV's own producers: clear, RSM, VPL extraction and injection (light_propagation_volume.cpp:548-697)
+    LightPropagationVolume lpv(backend, 4, 4);
+    lpv.update_cascade_transforms(view, scene.sun);
+    lpv.pre_render(graph, view, scene, nullptr);
+    lpv.inject_indirect_sun_light(graph, scene);
     graph.finish();
     for (const auto& e : graph.get_errors()) fprintf(stderr, "pass failed: %s\n", e.c_str());
     if (!graph.get_errors().empty()) return 1;
@@ -84,6 +89,14 @@ int main(int argc, char** argv) {
         buf.resize((size_t)W * H * p.bpp);
         alloc.download(p.t, buf.data(), W * p.bpp);
         fwrite(buf.data(), 1, buf.size(), out);
+    }
+    sah_gi gi_desc{};
+    lpv.render_to_lit_scene(gi_desc, nullptr, nullptr);
+    fwrite(gi_desc.lpv_cascades, sizeof(sah_lpv_cascade_matrices), 4, out);
+    for (int c = 0; c < 3; c++) {  // injected A volumes
+        std::vector<unsigned char> v((size_t)128 * 32 * 32 * 8);
+        alloc.download(lpv.get_volume(c), v.data(), 128 * 8);
+        fwrite(v.data(), 1, v.size(), out);
     }
     fclose(out);
     return 0;

@@ -139,10 +139,33 @@ def test_producer_passes_through_cpp_facade(tmp_path):
     got = {"color": np.frombuffer(take(W * H * 4), np.uint8).reshape(H, W, 4), "normals": np.frombuffer(take(W * H * 8), np.uint16).reshape(H, W, 4),
            "data": np.frombuffer(take(W * H * 4), np.uint8).reshape(H, W, 4), "emission": np.frombuffer(take(W * H * 4), np.uint8).reshape(H, W, 4),
            "depth": np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)}
+    casc = (_abi.LpvCascadeMatrices * 4).from_buffer_copy(take(1024))
+    lpv_got = [np.frombuffer(take(128 * 32 * 32 * 8), dtype=np.uint16).reshape(32, 32, 128, 4) for _ in range(3)]
     assert off == len(blob)
     o = util.oracle()
     keep = []
     g = mesh.geometry(mesh.with_counts(arrays), keep)
+    # LPV injection chain with the cascades C++ built: RSM -> VPLs -> volumes
+    rsm = {"flux": np.zeros((4, 128, 128, 4), np.uint8), "normals": np.zeros((4, 128, 128, 4), np.uint8), "depth": np.zeros((4, 128, 128), np.uint16)}
+    rd = _abi.RsmTargets(images.volume(rsm["flux"], _abi.FORMAT_R8G8B8A8_SRGB), images.volume(rsm["normals"], _abi.FORMAT_R8G8B8A8_UNORM),
+                         images.volume(rsm["depth"], _abi.FORMAT_D16_UNORM))
+    assert o.orc_rsm_render(C.byref(g), C.byref(sun_c), casc, 4, C.byref(rd), None) == 0
+    lpv_want = [np.zeros((32, 32, 128, 4), np.uint16) for _ in range(3)]
+    vols = (_abi.Volume * 3)(*[images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in lpv_want])
+    injected = 0
+    for c in range(4):
+        vpls, count = np.zeros((4096, 4), np.uint32), np.zeros(1, np.uint32)
+        assert o.orc_lpv_extract_vpls(C.byref(rd), casc, c, 0.25, vpls.ctypes.data, count.ctypes.data) == 0
+        assert o.orc_lpv_inject_vpls(vpls.ctypes.data, count.ctypes.data, 4096, casc, c, 4, vols) == 0
+        injected += int(count[0])
+    assert injected > 200
+    for c in range(3):
+        assert np.array_equal(lpv_got[c], lpv_want[c]), f"injected LPV volume {c}"
+    py_lpv = scene.LpvCascades()
+    py_lpv.update_cascade_transforms(scene.SceneView.default(W, H), scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM))
+    for c in range(4):  # C++ and Python build the same RSM frusta (up to the rounding of their inverses)
+        assert np.allclose(np.array(casc[c].rsm_vp[:]), np.array(py_lpv.matrices[c].rsm_vp[:]), rtol=2e-3, atol=2e-3)
+        assert np.allclose(np.array(casc[c].world_to_cascade[:]), np.array(py_lpv.matrices[c].world_to_cascade[:]), rtol=1e-5, atol=1e-5)
     want_sm = np.zeros_like(sm)
     vol = images.volume(want_sm, _abi.FORMAT_D16_UNORM)
     assert o.orc_shadow_render(C.byref(g), C.byref(sun_c), 4, C.byref(vol), None) == 0
