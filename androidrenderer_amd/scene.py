@@ -253,7 +253,9 @@ class LpvCascades:
             cell = f32(self.base_cell_size) * f32(2.0 ** ci)
             size = f32(self.num_cells) * cell
             offset = view.position + view.forward * (size * offset_scale)
-            snapped = (np.round(offset / (cell * f32(2))) * cell * f32(2)).astype(f32)
+            q = (offset / (cell * f32(2))).astype(f32)
+            rounded = (np.sign(q) * np.floor(np.abs(q) + f32(0.5))).astype(f32)  # glm::round: halves away from zero (np.round goes to even)
+            snapped = (rounded * cell * f32(2)).astype(f32)
             scale = f32(1.0) / size
             w2c = np.eye(4, dtype=f32)
             w2c[0, 0] = w2c[1, 1] = w2c[2, 2] = scale  # glm::scale(I, s)

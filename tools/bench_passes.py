@@ -140,6 +140,31 @@ def main():
             tris = int(arrays["indices"].shape[0] // 3)
             timeit(f"raster gbuffer {tris} tris", lambda: ctx.gbuffer_render(geo, view.gpu_data, gbd), 24 * px)
             timeit(f"raster shadow 4x4096^2 {tris} tris", lambda: ctx.shadow_render(geo, constants, 4, smv), 4 * 4096 * 4096 * 2)
+    # ---- LPV injection chain (f4): RSM 4 x 128^2, VPL extraction and injection for the four cascades ----------------------------------
+    if wanted("lpv inject"):
+        from androidrenderer_amd import mesh, scene
+        view = scene.SceneView.default(W, H)
+        sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+        casc = scene.LpvCascades()
+        casc.update_cascade_transforms(view, sun)
+        arrays = mesh.atrium(24).arrays()
+        dev = mesh.to_device(arrays)
+        geo = mesh.geometry(dev, [])
+        rsm_t = {"flux": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device="cuda"), "normals": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device="cuda"),
+                 "depth": torch.zeros((4, 128, 128), dtype=torch.int16, device="cuda")}
+        rsm = _abi.RsmTargets(images.volume(rsm_t["flux"], _abi.FORMAT_R8G8B8A8_SRGB), images.volume(rsm_t["normals"], _abi.FORMAT_R8G8B8A8_UNORM),
+                              images.volume(rsm_t["depth"], _abi.FORMAT_D16_UNORM))
+        lists = torch.zeros((4, 4096, 4), dtype=torch.int32, device="cuda")
+        counts = torch.zeros(4, dtype=torch.int32, device="cuda")
+        vols_t = [torch.zeros((32, 32, 128, 4), dtype=torch.int16, device="cuda") for _ in range(3)]
+        vd = [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in vols_t]
+        timeit("lpv inject: rsm render 4x128^2", lambda: ctx.rsm_render(geo, sun.constants, casc.matrices, 4, rsm), 4 * 128 * 128 * 10)
+
+        def extract_and_inject():
+            for c in range(4):
+                ctx.lpv_extract_vpls(rsm, casc.matrices, c, 0.25, lists[c].data_ptr(), counts[c:].data_ptr())
+                ctx.lpv_inject_vpls(lists[c].data_ptr(), counts[c:].data_ptr(), 4096, casc.matrices, c, 4, vd)
+        timeit("lpv inject: extract + inject x4", extract_and_inject, 4 * 128 * 128 * 10 + 4 * 4096 * 16)
     if args.json:
         print(json.dumps(results))
 
