@@ -5,7 +5,7 @@
 // is that their results are functions of the input.  The reference appends lights with atomicAdd and lets the blend unit add them
 // in that order; include/sah_hip.h fixes the order to the ascending invocation index, so: the extraction is one workgroup that
 // compacts with a prefix sum, and the injection adds the lights of a cell one after the other in list order, rounding to half after
-// every addition, one thread per occupied cell.  Arithmetic: GLSL fp32, every operator rounded.
+// every addition, one thread per occupied cell (the thread of the cell's first light).  Arithmetic: GLSL fp32, every operator rounded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -192,39 +192,42 @@ SAH_DEV uint32_t inject_one(const InjectArgs& a, const sah_packed_vpl& p, Inject
     return cx + a.rgb[0].width * (cy + a.rgb[0].height * cz);
 }
 
-// One workgroup.  Pass 1: the cell of every light.  Pass 2: the thread of the FIRST light of a cell walks the rest of the list and adds
-// every light of that cell in order (quadratic in the list length, which is at most a few thousand).
-__global__ __launch_bounds__(1024) void k_inject_vpls(const InjectArgs a) {
+// Two launches over the list (the capacity bounds the grid; the count is read on the device).  Pass 1: the cell of every light.
+// Pass 2: the thread of the FIRST light of a cell — no earlier list entry has the same cell — walks the rest of the list and adds
+// every light of that cell in list order.  Quadratic in the list length, which is a few thousand entries of an L2-resident array;
+// every cell has exactly one writer, so there is nothing to synchronise.
+__global__ __launch_bounds__(256) void k_inject_cells(const InjectArgs a) {
     const uint32_t count = min(*a.count, a.capacity);
-    for (uint32_t i = threadIdx.x; i < count; i += 1024) {
-        Injected tmp;
-        a.cells[i] = inject_one(a, a.list[i], tmp);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    Injected tmp;
+    a.cells[i] = inject_one(a, a.list[i], tmp);
+}
+__global__ __launch_bounds__(256) void k_inject_accumulate(const InjectArgs a) {
+    const uint32_t count = min(*a.count, a.capacity);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t cell = a.cells[i];
+    if (cell == ~0u) return;
+    for (uint32_t j = 0; j < i; j++)
+        if (a.cells[j] == cell) return;
+    const uint32_t W = a.rgb[0].width, H = a.rgb[0].height;
+    const uint32_t cx = cell % W, cy = (cell / W) % H, cz = cell / (W * H);
+    float acc[3][4];
+    uint16_t* dst[3];
+    for (int ch = 0; ch < 3; ch++) {
+        dst[ch] = (uint16_t*)(a.rgb[ch].ptr + (size_t)cz * a.rgb[ch].slice_pitch + (size_t)cy * a.rgb[ch].row_pitch + (size_t)cx * 8);
+        for (int k = 0; k < 4; k++) acc[ch][k] = h2f(dst[ch][k]);
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < count; i += 1024) {
-        const uint32_t cell = a.cells[i];
-        if (cell == ~0u) continue;
-        bool first = true;
-        for (uint32_t j = 0; j < i && first; j++) first = a.cells[j] != cell;
-        if (!first) continue;
-        const uint32_t W = a.rgb[0].width, H = a.rgb[0].height;
-        const uint32_t cx = cell % W, cy = (cell / W) % H, cz = cell / (W * H);
-        float acc[3][4];
-        uint16_t* dst[3];
-        for (int ch = 0; ch < 3; ch++) {
-            dst[ch] = (uint16_t*)(a.rgb[ch].ptr + (size_t)cz * a.rgb[ch].slice_pitch + (size_t)cy * a.rgb[ch].row_pitch + (size_t)cx * 8);
-            for (int k = 0; k < 4; k++) acc[ch][k] = h2f(dst[ch][k]);
-        }
-        for (uint32_t j = i; j < count; j++) {
-            if (a.cells[j] != cell) continue;
-            Injected v;
-            inject_one(a, a.list[j], v);
-            for (int ch = 0; ch < 3; ch++)
-                for (int k = 0; k < 4; k++) acc[ch][k] = rh(acc[ch][k] + v.sh[k] * v.corrected[ch] / 3.1415927f);  // blend ONE / ONE, one rounding to half
-        }
+    for (uint32_t j = i; j < count; j++) {
+        if (a.cells[j] != cell) continue;
+        Injected v;
+        inject_one(a, a.list[j], v);
         for (int ch = 0; ch < 3; ch++)
-            for (int k = 0; k < 4; k++) dst[ch][k] = f2h(acc[ch][k]);
+            for (int k = 0; k < 4; k++) acc[ch][k] = rh(acc[ch][k] + v.sh[k] * v.corrected[ch] / 3.1415927f);  // blend ONE / ONE, one rounding to half
     }
+    for (int ch = 0; ch < 3; ch++)
+        for (int k = 0; k < 4; k++) dst[ch][k] = f2h(acc[ch][k]);
 }
 
 }  // namespace
@@ -254,7 +257,10 @@ hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count,
     a.num_cascades_f = (float)num_cascades;
     for (int i = 0; i < 3; i++) a.rgb[i] = rgb[i];
     a.cells = cells_scratch;
-    hipLaunchKernelGGL(k_inject_vpls, dim3(1), dim3(1024), 0, st, a);
+    if (capacity == 0) return hipSuccess;
+    const dim3 grid((capacity + 255) / 256);
+    hipLaunchKernelGGL(k_inject_cells, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_inject_accumulate, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
