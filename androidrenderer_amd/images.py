@@ -1,6 +1,4 @@
 """Describe numpy arrays (host) or torch tensors (device) as sah_plane / sah_volume for the C ABI."""
-import ctypes as C
-
 import numpy as np
 
 from . import _abi

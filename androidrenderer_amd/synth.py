@@ -12,8 +12,6 @@ import math
 
 import numpy as np
 
-from . import _abi
-
 SEED_BASE = 0x5A48
 
 

@@ -86,7 +86,6 @@ def test_point_lights_adversarial_light_data(hip_ctx):
 
 def test_point_lights_on_the_surface(hip_ctx):
     """d2 == 0 for one pixel (light placed at that pixel's reconstructed world position) and d ~ r for many (window near 0)."""
-    import ctypes as C
     base = util.LightingFrame(64, 48, seed=50, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE, flavour="atrium")
     # reconstruct world positions the way directional_light.frag does, in float64 (close is enough for the second part; for the
     # exact hit the light position is refined below with the float32 value the kernel will compute)

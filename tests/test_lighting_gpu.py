@@ -139,7 +139,6 @@ def test_ao_off_mode_clear_equals_no_ao_plane(hip_ctx):
     """a12: AO mode Off clears the AO target to 1.0 (ambient_occlusion_phase.cpp:167-179); the LPV overlay must then give exactly
     what it gives with a constant-one AO plane, on a pitched plane whose padding stays untouched."""
     import torch
-    from androidrenderer_amd import images
     f = util.LightingFrame(160, 90, seed=91, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
     f.arrays["ao"] = np.ones((90, 160), dtype=np.float32)
     want = f.run_oracle()

@@ -4,9 +4,7 @@ algorithmic GB/s next to the 8 TB/s HBM roofline.  Diagnostic companion of bench
     python tools/bench_passes.py [--width 3840 --height 2160 --iters 50]
 """
 import argparse
-import ctypes as C
 import json
-import math
 import os
 import sys
 

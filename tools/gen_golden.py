@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from androidrenderer_amd import _abi, images, scene, synth  # noqa: E402
+from androidrenderer_amd import _abi, images, synth  # noqa: E402
 
 f32 = np.float32
 GOLDEN = os.path.join(ROOT, "tests", "golden")
