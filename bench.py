@@ -32,6 +32,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 WORKLOADS = {
     "4k_deferred_gi": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv"),
     "4k_deferred_gi_scene_shadow": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", shadow="scene"),  # CSM ray-cast from the atrium
+    # inputs made on the GPU by the producer passes (f1, f2, f4): rasterised G-buffer and shadow cascades, LPV from RSM -> VPLs -> propagation
+    "4k_deferred_gi_produced": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", produced=True),
     "4k_deferred_gi_random": dict(res=(3840, 2160), gbuffer="random", sun="csm", gi="lpv"),
     "4k_deferred_only": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none"),
     "1080p_deferred_gi": dict(res=(1920, 1080), gbuffer="atrium", sun="csm", gi="lpv"),
@@ -144,6 +146,29 @@ def main():
         fr.row_begin, fr.row_end = r0, r1
     ctx = lib.Context(device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if wl.get("produced"):  # overwrite the synthetic planes with what the library's own producer passes make of the atrium mesh
+        from androidrenderer_amd import mesh
+        geo_arrays = mesh.to_device(mesh.atrium(8).arrays(), dev)
+        geo = mesh.geometry(geo_arrays, [])
+        ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
+        ctx.shadow_render(geo, fr.sun.constants, 4, images.volume(d_arr["shadowmap"], _abi.FORMAT_D16_UNORM))
+        rsm_t = {"flux": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device=dev), "normals": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device=dev),
+                 "depth": torch.zeros((4, 128, 128), dtype=torch.int16, device=dev)}
+        rsm = _abi.RsmTargets(images.volume(rsm_t["flux"], _abi.FORMAT_R8G8B8A8_SRGB), images.volume(rsm_t["normals"], _abi.FORMAT_R8G8B8A8_UNORM),
+                              images.volume(rsm_t["depth"], _abi.FORMAT_D16_UNORM))
+        ctx.rsm_render(geo, fr.sun.constants, fr.lpv.matrices, 4, rsm)
+        vols = [d_arr[k] for k in ("lpv_r", "lpv_g", "lpv_b")]
+        for v in vols:
+            v.zero_()
+        vd = [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols]
+        vpls = torch.zeros((4096, 4), dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        for c in range(4):
+            ctx.lpv_extract_vpls(rsm, fr.lpv.matrices, c, 0.25, vpls.data_ptr(), count.data_ptr())
+            ctx.lpv_inject_vpls(vpls.data_ptr(), count.data_ptr(), 4096, fr.lpv.matrices, c, 4, vd)
+        scratch = [torch.zeros_like(v) for v in vols]
+        ctx.lpv_propagate(vd, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in scratch], 4, 32)
+        torch.cuda.synchronize()
     gather = use_dist and not args.no_gather
     # N > 1: two lit targets, so that the all-gather of frame i (RCCL's own stream) overlaps the shading of frame i + 1; a target is
     # reused only after its gather has completed (stream-level wait).  Every gather finishes inside the timed region.
@@ -261,7 +286,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {W}x{H} {what}, {wl['gbuffer']} G-buffer",
+                "workload": f"{args.workload}: {W}x{H} {what}, {wl['gbuffer']} G-buffer"
+                            + (" (G-buffer, shadow cascades and LPV made on the GPU by the producer passes)" if wl.get("produced") else ""),
                 "resolution": [W, H],
                 "gbuffer": wl["gbuffer"],
                 "parallelism": "row-shard x%d + RCCL all-gather of lit rows" % world if world > 1 else "single GPU",
