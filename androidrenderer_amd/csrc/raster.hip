@@ -1,11 +1,12 @@
-// Scene rasterisation as compute: the sun shadow cascades and the depth + G-buffer pass.
+// Scene rasterisation as compute: the sun shadow cascades, the depth + G-buffer pass and the LPV's RSM.
 //   reference: RenderCore/render/directional_light.cpp:286-327, RenderCore/render/phase/gbuffer_phase.cpp:27-97,
-//              RenderCore/render/material_pipelines.cpp:13-62,104-140, RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253,
-//              RenderCore/render/render_scene.cpp:196-222 (cull mode / front face)
+//              RenderCore/render/gi/light_propagation_volume.cpp:566-615 (RSM), RenderCore/render/material_pipelines.cpp:13-140,
+//              RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253, RenderCore/render/render_scene.cpp:196-222 (cull mode / front face)
 // The reference uses the fixed-function rasteriser.  Here: a set-up kernel turns every (view, triangle) into window-space records
-// (vertex stage, Sutherland-Hodgman against the depth planes and a guard band, fan, 24.8 snapping, culling), the records are binned
-// to 64x64-pixel tiles (count, scan, fill), and one workgroup per tile resolves visibility in LDS with ds_min_u32 (D16 shadow maps)
-// or ds_max_u64 on (depth, ~draw order) keys (G-buffer), then shades and writes its tile once, coalesced.  Depth tests are
+// (vertex stage, trivial accept or a queue for the clip kernel — Sutherland-Hodgman against the depth planes and a guard band, fan —
+// then 24.8 snapping and culling), the records are binned to 64x64-pixel tiles (count, scan, fill), and one workgroup per tile
+// resolves visibility in LDS with ds_min_u32 (D16 shadow maps) or ds_max_u64 on (depth, ~draw order) keys (G-buffer, RSM), sweeping
+// 8x8 pixel blocks with exact fp64 edge functions, then shades and writes its tile once, coalesced.  Depth tests are
 // order-independent by construction, so the images do not depend on the (nondeterministic) order of the bin lists.  The
 // rasterisation rules — the part the API leaves to the implementation — are DESIGN.md §5d; arithmetic follows §3 (every fp32
 // operator individually rounded; half expressions rounded after every operator).
