@@ -70,7 +70,7 @@ bool geometry_ok(const sah_scene_geometry* g, bool need_attributes) {
     return g->num_primitives < (1u << 24);
 }
 
-// Runs both stages; grows the record buffer and repeats stage 1 when the first guess was too small.
+// Runs both stages; grows the scratch buffers and repeats the pass when a guess was too small.
 int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool gbuffer, uint32_t* stats) {
     auto& r = ctx->raster;
     const uint32_t ntiles = a.tiles_x * a.tiles_y * a.num_views;
@@ -78,15 +78,23 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
     if (int rc = ensure(ctx, S_COUNTERS, 16 * sizeof(uint32_t)); rc != SAH_OK) return rc;
     if (int rc = ensure(ctx, S_TRI_BASE, (size_t)(scene->num_primitives + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
     if (int rc = ensure(ctx, S_TILES, (size_t)ntiles * 3 * sizeof(uint32_t)); rc != SAH_OK) return rc;
-    // first guess: every index triple is drawn once per view and survives; instanced index ranges or clipping can exceed it
+    // First guesses: every index triple is drawn once per view and survives (instanced index ranges or clipping can exceed it); the
+    // bin list and the draw-order table as large as the last call needed.  Both stages are launched back to back and the counters are
+    // read once, at the end: if any buffer turned out too small (the kernels never write past a buffer, they only count), it is grown
+    // and the pass repeated.  From the second frame of a scene on this is one iteration with no idle gap on the GPU.
     size_t want_records = (size_t)(scene->num_indices / 3) * a.num_views + 1024, want_clipped = want_records / 8 + 1024;
-    for (int attempt = 0; attempt < 3; attempt++) {
+    size_t want_pairs = std::max<size_t>(r.bytes[S_PAIRS] / sizeof(uint32_t), 2 * want_records + 4 * (size_t)ntiles);
+    size_t want_seq = gbuffer ? std::max<size_t>(r.bytes[S_SEQ] / sizeof(uint32_t), (size_t)(scene->num_indices / 3) * 8 * a.num_views + 64) : 0;
+    for (int attempt = 0; attempt < 4; attempt++) {
         if (int rc = ensure(ctx, S_CLIPQ, want_clipped * sizeof(uint2)); rc != SAH_OK) return rc;
-        a.clip_queue = (uint2*)r.ptr[S_CLIPQ];
-        a.clip_capacity = (uint32_t)std::min<size_t>(r.bytes[S_CLIPQ] / sizeof(uint2), 0xffffffffu);
         if (int rc = ensure(ctx, S_RECORDS, want_records * sizeof(sah::RasterRecord)); rc != SAH_OK) return rc;
         if (gbuffer)
             if (int rc = ensure(ctx, S_ATTRS, want_records * sizeof(sah::RasterAttr)); rc != SAH_OK) return rc;
+        if (int rc = ensure(ctx, S_PAIRS, want_pairs * sizeof(uint32_t)); rc != SAH_OK) return rc;
+        if (gbuffer)
+            if (int rc = ensure(ctx, S_SEQ, want_seq * sizeof(uint32_t)); rc != SAH_OK) return rc;
+        a.clip_queue = (uint2*)r.ptr[S_CLIPQ];
+        a.clip_capacity = (uint32_t)std::min<size_t>(r.bytes[S_CLIPQ] / sizeof(uint2), 0xffffffffu);
         a.counters = (uint32_t*)r.ptr[S_COUNTERS];
         a.tri_base = (uint32_t*)r.ptr[S_TRI_BASE];
         a.records = (sah::RasterRecord*)r.ptr[S_RECORDS];
@@ -96,26 +104,27 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         a.tile_count = (uint32_t*)r.ptr[S_TILES];
         a.tile_cursor = a.tile_count + ntiles;
         a.tile_offset = a.tile_count + 2 * (size_t)ntiles;
+        a.pairs = (uint32_t*)r.ptr[S_PAIRS];
+        a.pairs_capacity = (uint32_t)std::min<size_t>(r.bytes[S_PAIRS] / sizeof(uint32_t), 0xffffffffu);
+        a.seq_to_record = (uint32_t*)r.ptr[S_SEQ];
+        a.seq_capacity = gbuffer ? r.bytes[S_SEQ] / sizeof(uint32_t) : 0;
         HIP_TRY(ctx, sah::launch_raster_setup(a, gbuffer, ctx->stream));
+        HIP_TRY(ctx, sah::launch_raster_tiles(a, gbuffer, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(r.host_counters, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t total_tris = r.host_counters[0], clipped = r.host_counters[3], pairs = r.host_counters[2];
+        if (total_tris >= (1u << 28)) return fail(ctx, SAH_ERR_UNSUPPORTED, "rasteriser: more than 2^28 triangles in one pass");
         // records: one slot per (view, triangle) plus the appended fans of the clipped ones
-        const size_t need_records = (size_t)r.host_counters[0] * a.num_views + r.host_counters[1];
-        if (need_records <= a.record_capacity && r.host_counters[3] <= a.clip_capacity) break;
-        if (attempt == 2) return fail(ctx, SAH_ERR_HIP, "rasteriser: scratch buffers still too small after regrowing");
-        // a short clip queue also hides records: size both for the worst case of what was seen
-        want_clipped = std::max<size_t>(want_clipped, r.host_counters[3]);
-        want_records = std::max<size_t>(want_records, need_records + 7 * (size_t)r.host_counters[3]);
+        const size_t need_records = total_tris * a.num_views + r.host_counters[1];
+        const size_t need_seq = gbuffer ? total_tris * 8 * a.num_views + 1 : 0;
+        if (need_records <= a.record_capacity && clipped <= a.clip_capacity && pairs <= a.pairs_capacity && need_seq <= a.seq_capacity) break;
+        if (attempt == 3) return fail(ctx, SAH_ERR_HIP, "rasteriser: scratch buffers still too small after regrowing");
+        // a short clip queue hides records and a short record buffer hides bin entries: size for the worst case of what was seen
+        want_clipped = std::max<size_t>(want_clipped, clipped);
+        want_records = std::max<size_t>(want_records, need_records + 7 * clipped);
+        want_pairs = std::max<size_t>(want_pairs, pairs + pairs / 4 + 16);
+        want_seq = std::max<size_t>(want_seq, need_seq);
     }
-    const uint32_t total_tris = r.host_counters[0], pairs = r.host_counters[2];
-    if (total_tris >= (1u << 28)) return fail(ctx, SAH_ERR_UNSUPPORTED, "rasteriser: more than 2^28 triangles in one pass");
-    if (int rc = ensure(ctx, S_PAIRS, (size_t)(pairs + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
-    a.pairs = (uint32_t*)r.ptr[S_PAIRS];
-    if (gbuffer) {
-        if (int rc = ensure(ctx, S_SEQ, ((size_t)total_tris * 8 * a.num_views + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
-        a.seq_to_record = (uint32_t*)r.ptr[S_SEQ];
-    }
-    HIP_TRY(ctx, sah::launch_raster_tiles(a, gbuffer, ctx->stream));
     if (stats) HIP_TRY(ctx, hipMemcpyAsync(stats, a.counters + 4, SAH_RASTER_STATS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     return SAH_OK;
 }

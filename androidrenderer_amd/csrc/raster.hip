@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
         auto visit = [&](uint32_t tile, uint32_t rec_index) {
             if (FILL) {
                 const uint32_t pos = atomicAdd(&a.tile_cursor[tile], 1u);
-                a.pairs[a.tile_offset[tile] + pos] = rec_index;
+                const uint32_t at = a.tile_offset[tile] + pos;
+                if (at < a.pairs_capacity) a.pairs[at] = rec_index;  // a short list is noticed by the host, which grows it and repeats the pass
             } else {
                 atomicAdd(&a.tile_count[tile], 1u);
                 st_pairs++;
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
                 uint32_t first = 0;
                 if ((int)lane == leader) first = atomicAdd(&a.tile_cursor[tile], n);
                 first = __shfl(first, leader, 64);
-                if (mine) a.pairs[a.tile_offset[tile] + first + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull))] = r;
+                const uint32_t at = a.tile_offset[tile] + first + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+                if (mine && at < a.pairs_capacity) a.pairs[at] = r;
             } else {
                 if ((int)lane == leader) atomicAdd(&a.tile_count[tile], n);
                 st_pairs += mine ? 1u : 0u;
@@ -506,7 +508,7 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
             float b[3], lambda[3];
             barycentrics(e, v, b);
             input_barycentrics(at, b, lambda);
-            const sah_material& m = a.materials[at.material];
+            const sah_material& m = a.materials[min(at.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a pass that is being repeated
             const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
             if (tof(alpha) <= m.opacity_threshold) return;
         }
@@ -572,7 +574,7 @@ SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px
     cover(e, px, py, v);
     barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
-    const sah_material& m = a.materials[at.material];
+    const sah_material& m = a.materials[min(at.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a pass that is being repeated
     Hn col[4], N[3], T[4];
     for (int c = 0; c < 4; c++) col[c] = interp_h(at, lambda, c);
     for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
@@ -613,7 +615,7 @@ SAH_DEV void shade_rsm_and_store(const RasterArgs& a, uint32_t rec_index, uint32
     cover(e, px, py, v);
     barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
-    const sah_material& m = a.materials[at.material];
+    const sah_material& m = a.materials[min(at.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a pass that is being repeated
     Hn tinted[3], N[3];
     for (int c = 0; c < 3; c++) tinted[c] = Hn(m.base_color_texel[c]) * interp_h(at, lambda, c) * Hn(m.base_color_tint[c]);
     for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
@@ -661,7 +663,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
 #ifdef SAH_EXP_RASTER_SKIP_LIST  // timing experiment: tile init + write-out only
     const uint32_t begin = 0, count = 0;
 #else
-    const uint32_t begin = a.tile_offset[tile], count = a.tile_count[tile];
+    // (a bin list that does not fit the buffer is not read: the host repeats the pass with a larger one)
+    const uint32_t begin = a.tile_offset[tile], count = (uint64_t)begin + a.tile_count[tile] <= a.pairs_capacity ? a.tile_count[tile] : 0u;
 #endif
     for (uint32_t base = 0; base < count; base += kTileThreads) {
         if (tid == 0) s_nbig = 0;
@@ -766,7 +769,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
                 // the fans of clipped ones were appended and are found through the table
                 const uint32_t seq = 0xffffffffu - (uint32_t)key, total = a.counters[C_TRIS];
                 uint64_t r = (uint64_t)view * total + (seq >> 3);
-                if ((seq & 7u) != 0u || r >= a.record_capacity || is_empty(a.records[r])) r = a.seq_to_record[(uint64_t)view * total * 8u + seq];
+                if ((seq & 7u) != 0u || r >= a.record_capacity || is_empty(a.records[r])) {
+                    const uint64_t slot = (uint64_t)view * total * 8u + seq;
+                    r = slot < a.seq_capacity ? a.seq_to_record[slot] : 0u;
+                    if (r >= a.record_capacity) r = 0;  // only when a scratch buffer was too small: the pass is repeated
+                }
                 if (a.rsm) shade_rsm_and_store(a, (uint32_t)r, view, px, py, 0xffffu - (uint32_t)(key >> 32));
                 else shade_and_store(a, (uint32_t)r, px, py, __uint_as_float((uint32_t)(key >> 32)));
             }
@@ -778,7 +785,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
 __global__ __launch_bounds__(256) void k_seq_table(const RasterArgs a) {
     const uint32_t nrec = record_count(a), first = a.counters[C_TRIS] * a.num_views;
     for (uint32_t r = first + blockIdx.x * 256 + threadIdx.x; r < nrec; r += gridDim.x * 256)
-        a.seq_to_record[(uint64_t)a.records[r].view * a.counters[C_TRIS] * 8u + a.records[r].seq] = r;
+    {
+        const uint64_t slot = (uint64_t)a.records[r].view * a.counters[C_TRIS] * 8u + a.records[r].seq;
+        if (slot < a.seq_capacity) a.seq_to_record[slot] = r;
+    }
 }
 
 }  // namespace

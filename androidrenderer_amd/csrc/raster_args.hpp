@@ -58,7 +58,9 @@ struct RasterArgs {
     uint32_t* tile_cursor;
     uint32_t* tile_offset;
     uint32_t* pairs;
+    uint32_t pairs_capacity;
     uint32_t* seq_to_record;
+    uint64_t seq_capacity;
     const uint8_t* half_to_srgb8;  // 65536 entries: fp16 bit pattern -> sRGB8 code
     // RSM variant of the G-buffer path (sah_rsm_render): per-view clip matrices, D16 LESS, flux / normal targets
     uint32_t rsm;
