@@ -566,15 +566,12 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
 }
 
 // fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_MAIN_VIEW, constant textures)
-SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px, int32_t py, float z) {
-    const RasterAttr& at = a.attrs[rec_index];
-    const EdgeSetup e = edge_setup(a.records[rec_index]);
+SAH_DEV void shade_and_store(const RasterArgs& a, const EdgeSetup& e, const RasterAttr& at, const sah_material& m, int32_t px, int32_t py, float z) {
     double v[3];
     float b[3], lambda[3];
     cover(e, px, py, v);
     barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
-    const sah_material& m = a.materials[min(at.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a pass that is being repeated
     Hn col[4], N[3], T[4];
     for (int c = 0; c < 4; c++) col[c] = interp_h(at, lambda, c);
     for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
@@ -607,15 +604,13 @@ SAH_DEV void shade_and_store(const RasterArgs& a, uint32_t rec_index, int32_t px
 
 // RSM fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_RSM): flux = Fd(surface, -sun direction, normal) with
 // the metalness / roughness this variant leaves at 0, normal * 0.5 + 0.5; the D16 code goes to the depth layer
-SAH_DEV void shade_rsm_and_store(const RasterArgs& a, uint32_t rec_index, uint32_t layer, int32_t px, int32_t py, uint32_t depth_code) {
-    const RasterAttr& at = a.attrs[rec_index];
-    const EdgeSetup e = edge_setup(a.records[rec_index]);
+SAH_DEV void shade_rsm_and_store(const RasterArgs& a, const EdgeSetup& e, const RasterAttr& at, const sah_material& m, uint32_t layer, int32_t px, int32_t py,
+                                 uint32_t depth_code) {
     double v[3];
     float b[3], lambda[3];
     cover(e, px, py, v);
     barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
-    const sah_material& m = a.materials[min(at.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a pass that is being repeated
     Hn tinted[3], N[3];
     for (int c = 0; c < 3; c++) tinted[c] = Hn(m.base_color_texel[c]) * interp_h(at, lambda, c) * Hn(m.base_color_tint[c]);
     for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
@@ -746,6 +741,12 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
             }
         }
     } else {
+        // A thread's pixels are 4 rows apart in one column: consecutive ones usually belong to the same triangle, whose record,
+        // varyings and material (three dependent gathers) are then kept from the previous pixel.
+        uint32_t cached = ~0u;
+        EdgeSetup e_c{};
+        RasterAttr at_c{};
+        sah_material m_c{};
         for (uint32_t i = tid; i < kTile * kTile; i += kTileThreads) {
             const int32_t px = tile_x + (int32_t)(i % kTile), py = tile_y + (int32_t)(i / kTile);
             if ((uint32_t)px >= a.width || (uint32_t)py >= a.height) continue;
@@ -774,8 +775,14 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
                     r = slot < a.seq_capacity ? a.seq_to_record[slot] : 0u;
                     if (r >= a.record_capacity) r = 0;  // only when a scratch buffer was too small: the pass is repeated
                 }
-                if (a.rsm) shade_rsm_and_store(a, (uint32_t)r, view, px, py, 0xffffu - (uint32_t)(key >> 32));
-                else shade_and_store(a, (uint32_t)r, px, py, __uint_as_float((uint32_t)(key >> 32)));
+                if ((uint32_t)r != cached) {
+                    cached = (uint32_t)r;
+                    e_c = edge_setup(a.records[r]);
+                    at_c = a.attrs[r];
+                    m_c = a.materials[min(at_c.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a repeated pass
+                }
+                if (a.rsm) shade_rsm_and_store(a, e_c, at_c, m_c, view, px, py, 0xffffu - (uint32_t)(key >> 32));
+                else shade_and_store(a, e_c, at_c, m_c, px, py, __uint_as_float((uint32_t)(key >> 32)));
             }
         }
     }
