@@ -332,6 +332,20 @@ __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
     block_flush<4>(&a.counters[C_STATS], local, s_acc);
 }
 
+// No pixel centre of the 64x64 tile at pixel (x0, y0) is inside the record's triangle: some edge function is negative even at the
+// tile corner that favours it.  Exact (fp64 on integers below 2^52, see EdgeSetup further down).
+SAH_DEV bool tile_outside(const RasterRecord& rec, int32_t x0, int32_t y0) {
+    for (int i = 0; i < 3; i++) {
+        const int va = (i + 1) % 3, vb = (i + 2) % 3;
+        const int32_t dx = rec.X[vb] - rec.X[va], dy = rec.Y[vb] - rec.Y[va];
+        // E(px, py) = dx ((256 py + 128) - Ya) - dy ((256 px + 128) - Xa): largest where py is at the dx > 0 end and px at the dy < 0 end
+        const int32_t py = dx > 0 ? y0 + kTile - 1 : y0, px = dy < 0 ? x0 + kTile - 1 : x0;
+        const double e = (double)dx * (double)(256 * py + 128 - rec.Y[va]) - (double)dy * (double)(256 * px + 128 - rec.X[va]);
+        if (e < 0.0) return true;
+    }
+    return false;
+}
+
 // ---- K2 / K4: binning -------------------------------------------------------------------------------------------------------------
 // One wave per 64 records.  A record that touches up to 4 tiles is binned by its own lane; wider ones are taken one at a time by the
 // whole wave (ballot + readlane), lanes striding over the tiles of the bounding box.
@@ -395,7 +409,13 @@ __global__ __launch_bounds__(256) void k_bin(const RasterArgs a) {
             wide &= wide - 1;
             const uint32_t bx0 = __shfl(tx0, src, 64), bx1 = __shfl(tx1, src, 64), by0 = __shfl(ty0, src, 64), by1 = __shfl(ty1, src, 64);
             const uint32_t bview = __shfl(view, src, 64), bw = bx1 - bx0 + 1, count = bw * (by1 - by0 + 1);
-            for (uint32_t i = lane; i < count; i += 64) visit((bview * a.tiles_y + by0 + i / bw) * a.tiles_x + bx0 + i % bw, base + (uint32_t)src);
+            // a tile of the bounding box that lies wholly outside one edge gets no entry (about half the tiles of a large triangle);
+            // both binning passes run the same exact test, so count and fill agree
+            const RasterRecord& wrec = a.records[base + (uint32_t)src];
+            for (uint32_t i = lane; i < count; i += 64) {
+                const uint32_t tx = bx0 + i % bw, ty = by0 + i / bw;
+                if (count < 16 || !tile_outside(wrec, (int32_t)(tx * kTile), (int32_t)(ty * kTile))) visit((bview * a.tiles_y + ty) * a.tiles_x + tx, base + (uint32_t)src);
+            }
         }
     }
     __shared__ uint32_t s_acc[1];
