@@ -19,7 +19,7 @@ hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count,
 }  // namespace sah
 
 namespace {
-constexpr uint32_t kTile = 64;
+constexpr uint32_t kTile = sah::kRasterTile;
 constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^24.1
 enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ, S_VPL_CELLS };
 

@@ -19,7 +19,7 @@
 namespace sah {
 namespace {
 
-constexpr int kTile = 64;               // pixels per tile edge
+constexpr int kTile = (int)kRasterTile;  // pixels per tile edge
 constexpr float kGuardBand = 16.0f;     // |x_c|, |y_c| <= kGuardBand * w_c survives clipping
 constexpr float kCoordLimit = 0x1p24f + 4096.0f;  // snapped coordinates beyond this drop the triangle: edge functions stay below 2^52
 constexpr uint32_t kSmallArea = 16;     // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone

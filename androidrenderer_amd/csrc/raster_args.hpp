@@ -6,7 +6,13 @@
 #include "../../include/sah_hip.h"
 #include "params.hpp"
 
+#ifndef SAH_RASTER_TILE
+#define SAH_RASTER_TILE 64  // pixels per tile edge (a multiple of 8, at most 64); 32 measured slower on every scene
+#endif
+
 namespace sah {
+
+constexpr uint32_t kRasterTile = SAH_RASTER_TILE;
 
 // One window-space triangle of one view: clipped, fanned, snapped to 1/256 pixel, oriented so that its area is positive.
 struct RasterRecord {
