@@ -365,6 +365,8 @@ public:
         if (vpl_lists) (void)hipFree(vpl_lists);
         if (vpl_counts) (void)hipFree(vpl_counts);
     }
+    LightPropagationVolume(const LightPropagationVolume&) = delete;  // owns the VPL buffers
+    LightPropagationVolume& operator=(const LightPropagationVolume&) = delete;
     // light_propagation_volume.cpp:548-697: render the RSM of every cascade, extract the VPLs, add them to the A volumes
     void inject_indirect_sun_light(RenderGraph& graph, const RenderScene& scene) {
         graph.add_pass({"Render RSM", [this, &scene](sah_ctx* ctx) {
