@@ -20,6 +20,7 @@
 #include <functional>
 #include <memory>
 #include <optional>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -436,6 +437,89 @@ private:
     sah_packed_vpl* vpl_lists = nullptr;
     uint32_t* vpl_counts = nullptr;
     std::array<sah_lpv_cascade_matrices, 4> cascades{};
+};
+
+// Probe scheduling of the irradiance cache (CPU side) — RenderCore/render/gi/irradiance_cache.hpp:49-105,267-279 and
+// irradiance_cache.cpp:36-60 (grid layout), :351-360 (request_probe_update), :496-583 (find_probes_to_update).  No GPU state: the
+// list it builds is what sah_probe_update consumes.  The draw order of the reference is kept — foreach() runs x, then y, then z,
+// innermost — and so is its random source: `std::default_random_engine{frame_count}` with `std::uniform_real_distribution<float>`,
+// i.e. whatever the C++ standard library of the build defines (minstd_rand0 with libstdc++ and libc++'s minstd_rand give different
+// streams, MSVC uses mt19937): built like the reference, it draws like the reference.  Quirk kept: find_probes_to_update requests
+// the cascade-local index, without the `y + 8 * cascade` offset that place_probes_from_view adds (:405-406 vs :533).
+class ProbeScheduler {
+public:
+    static constexpr uint32_t cascade_size_xz = 32, cascade_size_y = 8, num_cascades = 4;
+    struct Probe {
+        bool is_valid = false;
+        uint32_t last_update_frame = 0;
+    };
+    struct Cascade {
+        float update_priority = 0.1f;
+        std::array<Probe, cascade_size_xz * cascade_size_y * cascade_size_xz> probes{};
+        Probe& at(uint32_t x, uint32_t y, uint32_t z) { return probes[x + y * cascade_size_xz + z * cascade_size_xz * cascade_size_y]; }
+    };
+    using ProbeIndex = std::array<uint32_t, 3>;
+
+    explicit ProbeScheduler(uint32_t probes_per_frame = 1024) : update_budget(probes_per_frame) { probes_to_update.reserve(probes_per_frame); }
+    Cascade& cascade(uint32_t c) { return cascades[c]; }
+    const std::vector<ProbeIndex>& get_probes_to_update() const { return probes_to_update; }
+    void clear_probes_to_update() { probes_to_update.clear(); }  // after dispatch_probe_updates (:722)
+
+    bool request_probe_update(ProbeIndex probe_index) {
+        if (probes_to_update.size() == update_budget) return false;
+        probes_to_update.push_back(probe_index);
+        return true;
+    }
+
+    void find_probes_to_update(uint32_t frame_count) {
+        if (probes_to_update.size() >= update_budget) return;
+        auto rng = std::default_random_engine{frame_count};
+        auto distribution = std::uniform_real_distribution<float>{0.f, 1.f};
+        float total_weight = 0.f;
+        for (const auto& c : cascades) total_weight += c.update_priority;
+        // probes that were never traced or were invalidated
+        for (auto& c : cascades) {
+            const float normalized_priority = c.update_priority / total_weight;
+            foreach (c, [&](ProbeIndex index, Probe& probe) {
+                if (!probe.is_valid) {
+                    const float num = distribution(rng);
+                    if (num < normalized_priority) {
+                        if (!request_probe_update(index)) return false;
+                        probe.is_valid = true;
+                        probe.last_update_frame = frame_count;
+                    }
+                }
+                return true;
+            });
+        }
+        if (probes_to_update.size() >= update_budget) return;
+        // probes that have not been updated in a while: log(seconds since the update) * priority
+        for (auto& c : cascades) {
+            const float normalized_priority = c.update_priority / total_weight;
+            foreach (c, [&](ProbeIndex index, Probe& probe) {
+                const float seconds_since_update = static_cast<float>(frame_count - probe.last_update_frame) / 60.f;
+                const auto update_score = log(seconds_since_update);  // unqualified, as in the reference (:564): the overload the platform's headers pick
+                const float num = distribution(rng);
+                if (num < update_score * normalized_priority) {
+                    if (!request_probe_update(index)) return false;
+                    probe.is_valid = true;
+                    probe.last_update_frame = frame_count;
+                }
+                return true;
+            });
+        }
+    }
+
+private:
+    template <class F> static void foreach (Cascade& c, F func) {
+        for (uint32_t x = 0; x < cascade_size_xz; x++)
+            for (uint32_t y = 0; y < cascade_size_y; y++)
+                for (uint32_t z = 0; z < cascade_size_xz; z++)
+                    if (!func(ProbeIndex{x, y, z}, c.at(x, y, z))) return;
+    }
+    uint32_t update_budget;
+    std::array<Cascade, num_cascades> cascades{};
+    std::vector<ProbeIndex> probes_to_update;
 };
 
 // RenderCore/render/gi/irradiance_cache.{hpp,cpp}: atlases :94-183, cascade placement :298-372, copy_probes_to_new_texture
