@@ -546,6 +546,10 @@ public:
         for (int i = 0; i < 3; i++) { cascades[c].min[i] = min[i]; movement[c][i] = movement_cells[i]; }
         cascades[c].probe_spacing = spacing;
     }
+    // irradiance_cache.cpp:496-583: which probes this frame's budget goes to.  The ray tracer (outside the path) then fills one
+    // 20 x 20 layer of trace results per entry of get_probes_to_update(), in list order, and hands both to set_trace_results().
+    ProbeScheduler& get_scheduler() { return scheduler; }
+    void find_probes_to_update(uint32_t frame_count) { scheduler.find_probes_to_update(frame_count); }
     void set_trace_results(TextureHandle trace_results_in, const uint32_t* probes_to_update_device, uint32_t num_probes_in) {
         trace_results = trace_results_in;
         probes_to_update = probes_to_update_device;
@@ -592,6 +596,7 @@ private:
     float movement[4][3] = {};
     TextureHandle trace_results{};
     const uint32_t* probes_to_update = nullptr;
+    ProbeScheduler scheduler;
     uint32_t num_probes = 0;
 };
 
