@@ -13,7 +13,7 @@ namespace sah {
 hipError_t launch_raster_setup(const RasterArgs& a, bool gbuffer, hipStream_t st);
 hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st);
 hipError_t launch_extract_vpls(const VolumeArg& flux, const VolumeArg& normals, const VolumeArg& depth, const sah_lpv_cascade_matrices& c, uint32_t cascade,
-                               float grid_cell_size, const float* luts, sah_packed_vpl* list, uint32_t* count, hipStream_t st);
+                               float grid_cell_size, const float* luts, sah_packed_vpl* list, uint32_t* count, void* scratch, hipStream_t st);
 hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count, uint32_t capacity, const sah_lpv_cascade_matrices& c, uint32_t cascade,
                               uint32_t num_cascades, const VolumeArg rgb[3], uint32_t* cells_scratch, hipStream_t st);
 }  // namespace sah
@@ -21,7 +21,7 @@ hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count,
 namespace {
 constexpr uint32_t kTile = sah::kRasterTile;
 constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^24.1
-enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ, S_VPL_CELLS };
+enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ, S_VPL_CELLS, S_VPL_CANDIDATES };
 
 int ensure(sah_ctx* ctx, int slot, size_t bytes) {
     auto& r = ctx->raster;
@@ -249,8 +249,10 @@ int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv
         rsm->depth.format != SAH_FORMAT_D16_UNORM)
         return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "lpv_extract_vpls: RSM formats are RGBA8_SRGB / RGBA8_UNORM / D16_UNORM");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t invocations = (size_t)(res / 2) * (res / 2);
+    if (int rc = ensure(ctx, S_VPL_CANDIDATES, invocations * (sizeof(sah_packed_vpl) + sizeof(uint32_t))); rc != SAH_OK) return rc;
     HIP_TRY(ctx, sah::launch_extract_vpls(varg(rsm->flux), varg(rsm->normals), varg(rsm->depth), cascades[cascade_index], cascade_index, grid_cell_size, ctx->luts,
-                                          vpl_list, vpl_count, ctx->stream));
+                                          vpl_list, vpl_count, ctx->raster.ptr[S_VPL_CANDIDATES], ctx->stream));
     return SAH_OK;
 }
 

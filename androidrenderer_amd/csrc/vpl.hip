@@ -3,8 +3,8 @@
 //   "VPL Injection"  RenderCore/shaders/gi/lpv/vpl_injection.{vert,frag} drawn as a point list with additive blending (:699-760)
 // Both are tiny (at most (res/2)^2 = 4096 lights per cascade at the default RSM resolution of 128) and launch bound; what matters
 // is that their results are functions of the input.  The reference appends lights with atomicAdd and lets the blend unit add them
-// in that order; include/sah_hip.h fixes the order to the ascending invocation index, so: the extraction is one workgroup that
-// compacts with a prefix sum, and the injection adds the lights of a cell one after the other in list order, rounding to half after
+// in that order; include/sah_hip.h fixes the order to the ascending invocation index, so: the extraction parks every invocation's
+// light in scratch and one workgroup compacts them with a prefix sum, and the injection adds the lights of a cell one after the other in list order, rounding to half after
 // every addition, one thread per occupied cell (the thread of the cell's first light).  Arithmetic: GLSL fp32, every operator rounded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,6 +35,8 @@ struct ExtractArgs {
     const float* srgb_lut;  // 256 sRGB8 -> linear, then 256 UNORM8 -> float (ctx->luts)
     sah_packed_vpl* list;
     uint32_t* count;
+    sah_packed_vpl* candidates;  // scratch: one per invocation
+    uint32_t* keep;              // scratch: 1 when the invocation stores its light
 };
 
 SAH_DEV Vpl load_rsm_vpl(const ExtractArgs& a, int x, int y) {
@@ -104,8 +106,18 @@ SAH_DEV bool extract_one(const ExtractArgs& a, uint32_t gx, uint32_t gy, sah_pac
     return true;
 }
 
-// One workgroup: invocations in chunks of 1024, stored lights compacted in invocation order.
-__global__ __launch_bounds__(1024) void k_extract_vpls(const ExtractArgs a) {
+// Two launches: every invocation evaluates its 2x2 footprint in parallel and parks its light (and whether it stores one) in scratch;
+// one workgroup then compacts the stored lights in invocation order (ballot + prefix over chunks of 1024).
+__global__ __launch_bounds__(256) void k_extract_candidates(const ExtractArgs a) {
+    const uint32_t half_res = a.res / 2, total = half_res * half_res;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    sah_packed_vpl vpl{};
+    const bool keep = extract_one(a, i % half_res, i / half_res, vpl);
+    a.candidates[i] = vpl;
+    a.keep[i] = keep ? 1u : 0u;
+}
+__global__ __launch_bounds__(1024) void k_extract_compact(const ExtractArgs a) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -114,14 +126,13 @@ __global__ __launch_bounds__(1024) void k_extract_vpls(const ExtractArgs a) {
     __syncthreads();
     for (uint32_t base = 0; base < total; base += 1024) {
         const uint32_t i = base + tid;
-        sah_packed_vpl vpl{};
-        const bool keep = i < total && extract_one(a, i % half_res, i / half_res, vpl);
+        const bool keep = i < total && a.keep[i] != 0u;
         const uint64_t mask = __ballot(keep);
         if (lane == 0) s_wave[wave] = (uint32_t)__builtin_popcountll(mask);
         __syncthreads();
         uint32_t slot = s_carry + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < wave; w++) slot += s_wave[w];
-        if (keep) a.list[slot] = vpl;
+        if (keep) a.list[slot] = a.candidates[i];
         __syncthreads();
         if (tid == 0) {
             uint32_t sum = 0;
@@ -230,10 +241,60 @@ __global__ __launch_bounds__(256) void k_inject_accumulate(const InjectArgs a) {
         for (int k = 0; k < 4; k++) dst[ch][k] = f2h(acc[ch][k]);
 }
 
+// Lists of up to 4096 lights (the default RSM resolution gives exactly that capacity): one workgroup sorts (cell, list index) keys
+// in LDS with a bitonic network — equal cells become contiguous runs in list order — and the thread at the head of each run adds
+// the run to its cell.  Same arithmetic and order as the two-launch form above, without its quadratic scans.
+constexpr uint32_t kSortCapacity = 4096;
+__global__ __launch_bounds__(1024) void k_inject_sorted(const InjectArgs a) {
+    __shared__ unsigned long long s_key[kSortCapacity];
+    const uint32_t count = min(min(*a.count, a.capacity), kSortCapacity);
+    for (uint32_t i = threadIdx.x; i < kSortCapacity; i += 1024) {
+        uint32_t cell = ~0u;
+        if (i < count) {
+            Injected tmp;
+            cell = inject_one(a, a.list[i], tmp);
+        }
+        s_key[i] = ((unsigned long long)cell << 32) | i;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= kSortCapacity; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < kSortCapacity; i += 1024) {
+                const uint32_t partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long x = s_key[i], y = s_key[partner];
+                    const bool ascending = (i & k) == 0;
+                    if ((x > y) == ascending) { s_key[i] = y; s_key[partner] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    const uint32_t W = a.rgb[0].width, H = a.rgb[0].height;
+    for (uint32_t i = threadIdx.x; i < count; i += 1024) {
+        const uint32_t cell = (uint32_t)(s_key[i] >> 32);
+        if (cell == ~0u || (i > 0 && (uint32_t)(s_key[i - 1] >> 32) == cell)) continue;  // dropped light, or not the head of its run
+        const uint32_t cx = cell % W, cy = (cell / W) % H, cz = cell / (W * H);
+        float acc[3][4];
+        uint16_t* dst[3];
+        for (int ch = 0; ch < 3; ch++) {
+            dst[ch] = (uint16_t*)(a.rgb[ch].ptr + (size_t)cz * a.rgb[ch].slice_pitch + (size_t)cy * a.rgb[ch].row_pitch + (size_t)cx * 8);
+            for (int k = 0; k < 4; k++) acc[ch][k] = h2f(dst[ch][k]);
+        }
+        for (uint32_t j = i; j < count && (uint32_t)(s_key[j] >> 32) == cell; j++) {
+            Injected v;
+            inject_one(a, a.list[(uint32_t)s_key[j]], v);
+            for (int ch = 0; ch < 3; ch++)
+                for (int k = 0; k < 4; k++) acc[ch][k] = rh(acc[ch][k] + v.sh[k] * v.corrected[ch] / 3.1415927f);  // blend ONE / ONE, one rounding to half
+        }
+        for (int ch = 0; ch < 3; ch++)
+            for (int k = 0; k < 4; k++) dst[ch][k] = f2h(acc[ch][k]);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_extract_vpls(const VolumeArg& flux, const VolumeArg& normals, const VolumeArg& depth, const sah_lpv_cascade_matrices& c, uint32_t cascade,
-                               float grid_cell_size, const float* luts, sah_packed_vpl* list, uint32_t* count, hipStream_t st) {
+                               float grid_cell_size, const float* luts, sah_packed_vpl* list, uint32_t* count, void* scratch, hipStream_t st) {
     ExtractArgs a{};
     a.flux = flux; a.normals = normals; a.depth = depth;
     for (int i = 0; i < 16; i++) { a.inverse_rsm_vp[i] = c.inverse_rsm_vp[i]; a.world_to_cascade[i] = c.world_to_cascade[i]; }
@@ -244,7 +305,11 @@ hipError_t launch_extract_vpls(const VolumeArg& flux, const VolumeArg& normals, 
     a.srgb_lut = luts;
     a.list = list;
     a.count = count;
-    hipLaunchKernelGGL(k_extract_vpls, dim3(1), dim3(1024), 0, st, a);
+    const uint32_t total = (a.res / 2) * (a.res / 2);
+    a.candidates = (sah_packed_vpl*)scratch;  // total * 16 bytes, then total * 4 bytes of flags
+    a.keep = (uint32_t*)(a.candidates + total);
+    hipLaunchKernelGGL(k_extract_candidates, dim3((total + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_extract_compact, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 
@@ -258,6 +323,10 @@ hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count,
     for (int i = 0; i < 3; i++) a.rgb[i] = rgb[i];
     a.cells = cells_scratch;
     if (capacity == 0) return hipSuccess;
+    if (capacity <= kSortCapacity) {
+        hipLaunchKernelGGL(k_inject_sorted, dim3(1), dim3(1024), 0, st, a);
+        return hipGetLastError();
+    }
     const dim3 grid((capacity + 255) / 256);
     hipLaunchKernelGGL(k_inject_cells, grid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_inject_accumulate, grid, dim3(256), 0, st, a);

@@ -237,26 +237,27 @@ def test_hip_vpl_stages_on_adversarial_input(hip_ctx):
         torch.cuda.synchronize()
         assert int(count_t.item()) == count and count > 100
         assert np.array_equal(list_t.cpu().numpy().view(np.uint32)[:count], want[:count])
-    # random lists: positions as halfs in a box a little larger than cascade 0, all normal / colour bit patterns
-    n = 3000
-    m = np.array(lpv.matrices[0].cascade_to_world[:], np.float32).reshape(4, 4)
-    uvw = g.uniform(-0.1, 1.1, (n, 3)).astype(np.float32)
-    uvw[: n // 2] = (uvw[: n // 2] * 0.05 + 0.4)  # half of them crowd a few cells
-    pos = (uvw[:, 0:1] * m[0] + uvw[:, 1:2] * m[1] + uvw[:, 2:3] * m[2] + m[3])[:, :3].astype(np.float16).view(np.uint16).astype(np.uint32)
-    col = g.uniform(0, 4, (n, 3)).astype(np.float16)
-    col[::7] = 0
-    col = col.view(np.uint16).astype(np.uint32)
-    lights = np.stack([pos[:, 0] | (pos[:, 1] << 16), pos[:, 2] | (col[:, 0] << 16), col[:, 1] | (col[:, 2] << 16),
-                       g.integers(0, 1 << 24, n, dtype=np.uint64).astype(np.uint32)], axis=1).astype(np.uint32)
-    lights[::11, 3] = 0  # zero normal: normalize gives NaN, the light is kept or dropped exactly as the oracle decides
-    vols_np = [g.integers(0, 0x3c00, (32, 32, 128, 4), dtype=np.uint16) for _ in range(3)]  # non-empty volumes: the blend reads them
-    vols_t = [torch.from_numpy(v.view(np.int16).copy()).cuda() for v in vols_np]
-    _oracle_inject(lights, n, lpv, 0, vols_np)
-    list_t = torch.from_numpy(lights.view(np.int32)).cuda()
-    count_t = torch.tensor([n], dtype=torch.int32, device="cuda")
-    hip_ctx.lpv_inject_vpls(list_t.data_ptr(), count_t.data_ptr(), n, lpv.matrices, 0, 4, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols_t])
-    torch.cuda.synchronize()
-    for c in range(3):
-        got = vols_t[c].cpu().numpy().view(np.uint16)
-        bad = np.argwhere(got != vols_np[c])
-        assert bad.size == 0, f"volume {c}: {len(bad)} texels differ, first {bad[0]}"
+    # random lists: positions as halfs in a box a little larger than cascade 0, all normal / colour bit patterns; 3000 lights go through
+    # the sorting kernel (capacity <= 4096), 5000 through the two-launch form
+    for n in (3000, 5000):
+        m = np.array(lpv.matrices[0].cascade_to_world[:], np.float32).reshape(4, 4)
+        uvw = g.uniform(-0.1, 1.1, (n, 3)).astype(np.float32)
+        uvw[: n // 2] = (uvw[: n // 2] * 0.05 + 0.4)  # half of them crowd a few cells
+        pos = (uvw[:, 0:1] * m[0] + uvw[:, 1:2] * m[1] + uvw[:, 2:3] * m[2] + m[3])[:, :3].astype(np.float16).view(np.uint16).astype(np.uint32)
+        col = g.uniform(0, 4, (n, 3)).astype(np.float16)
+        col[::7] = 0
+        col = col.view(np.uint16).astype(np.uint32)
+        lights = np.stack([pos[:, 0] | (pos[:, 1] << 16), pos[:, 2] | (col[:, 0] << 16), col[:, 1] | (col[:, 2] << 16),
+                           g.integers(0, 1 << 24, n, dtype=np.uint64).astype(np.uint32)], axis=1).astype(np.uint32)
+        lights[::11, 3] = 0  # zero normal: normalize gives NaN, the light is kept or dropped exactly as the oracle decides
+        vols_np = [g.integers(0, 0x3c00, (32, 32, 128, 4), dtype=np.uint16) for _ in range(3)]  # non-empty volumes: the blend reads them
+        vols_t = [torch.from_numpy(v.view(np.int16).copy()).cuda() for v in vols_np]
+        _oracle_inject(lights, n, lpv, 0, vols_np)
+        list_t = torch.from_numpy(lights.view(np.int32)).cuda()
+        count_t = torch.tensor([n], dtype=torch.int32, device="cuda")
+        hip_ctx.lpv_inject_vpls(list_t.data_ptr(), count_t.data_ptr(), n, lpv.matrices, 0, 4, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols_t])
+        torch.cuda.synchronize()
+        for c in range(3):
+            got = vols_t[c].cpu().numpy().view(np.uint16)
+            bad = np.argwhere(got != vols_np[c])
+            assert bad.size == 0, f"volume {c}: {len(bad)} texels differ, first {bad[0]}"
