@@ -21,7 +21,7 @@ hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count,
 namespace {
 constexpr uint32_t kTile = sah::kRasterTile;
 constexpr uint32_t kMaxExtent = 8192;  // keeps every snapped coordinate inside the guard band below 2^24.1
-enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ, S_VPL_CELLS, S_VPL_CANDIDATES };
+enum Scratch { S_COUNTERS, S_TRI_BASE, S_RECORDS, S_ATTRS, S_TILES, S_PAIRS, S_SEQ, S_CLIPQ, S_VPL_CELLS, S_VPL_CANDIDATES, S_HEAVY, S_EXTRA, S_TICKETS, S_MERGE };
 
 int ensure(sah_ctx* ctx, int slot, size_t bytes) {
     auto& r = ctx->raster;
@@ -108,6 +108,20 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         a.pairs_capacity = (uint32_t)std::min<size_t>(r.bytes[S_PAIRS] / sizeof(uint32_t), 0xffffffffu);
         a.seq_to_record = (uint32_t*)r.ptr[S_SEQ];
         a.seq_capacity = gbuffer ? r.bytes[S_SEQ] / sizeof(uint32_t) : 0;
+        // long bin lists are cut into parts of 256 entries: at most pairs / 256 further parts, and a merge buffer per split tile (the
+        // number of those is capped: tiles beyond it are processed whole)
+        a.extra_capacity = a.pairs_capacity / 256u + 1u;
+        a.merge_capacity = std::min<uint32_t>(a.extra_capacity, 2048u);
+        const size_t tile_bytes = (size_t)kTile * kTile * (gbuffer ? 8 : 4);
+        if (int rc = ensure(ctx, S_HEAVY, (size_t)ntiles * sizeof(uint32_t)); rc != SAH_OK) return rc;
+        if (int rc = ensure(ctx, S_EXTRA, (size_t)a.extra_capacity * sizeof(uint2)); rc != SAH_OK) return rc;
+        if (int rc = ensure(ctx, S_TICKETS, (size_t)a.merge_capacity * sizeof(uint32_t)); rc != SAH_OK) return rc;
+        if (int rc = ensure(ctx, S_MERGE, (size_t)a.merge_capacity * tile_bytes); rc != SAH_OK) return rc;
+        a.heavy_slot = (uint32_t*)r.ptr[S_HEAVY];
+        a.extra_parts = (uint2*)r.ptr[S_EXTRA];
+        a.tickets = (uint32_t*)r.ptr[S_TICKETS];
+        a.merge_depth = (uint32_t*)r.ptr[S_MERGE];
+        a.merge_keys = (unsigned long long*)r.ptr[S_MERGE];
         HIP_TRY(ctx, sah::launch_raster_setup(a, gbuffer, ctx->stream));
         HIP_TRY(ctx, sah::launch_raster_tiles(a, gbuffer, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(r.host_counters, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -27,8 +27,8 @@ struct sah_ctx {
     uint32_t parity = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds (api_post.cpp)
     struct RasterScratch {             // device buffers of the scene rasteriser, grown on demand (api_raster.cpp)
-        void* ptr[10] = {};
-        size_t bytes[10] = {};
+        void* ptr[16] = {};
+        size_t bytes[16] = {};
         uint8_t* half_to_srgb8 = nullptr;
         uint32_t* host_counters = nullptr;  // pinned, 16 words
     } raster;

@@ -31,7 +31,7 @@ constexpr float kCoordLimit = 0x1p24f + 4096.0f;  // snapped coordinates beyond 
 constexpr uint32_t kSmallArea = SAH_RASTER_SMALL_AREA;    // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone
 constexpr uint32_t kMediumArea = SAH_RASTER_MEDIUM_AREA;  // ... up to which one wave does; above, the whole workgroup
 
-enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4 };  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
+enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4, C_EXTRA = 9, C_HEAVY = 10 };  // the last two are statistics words 5 and 6  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
 
 struct ClipVertex {
     float c[4];
@@ -657,6 +657,7 @@ SAH_DEV void shade_rsm_and_store(const RasterArgs& a, const EdgeSetup& e, const 
 }
 
 constexpr uint32_t kTileThreads = 256;   // 1024 (16 waves per tile, to shorten the densest tiles) measured 1.1x - 2.5x slower
+constexpr uint32_t kSplit = 256;          // bin lists longer than this are cut into parts of this many entries, one workgroup each
 constexpr uint32_t kBigSlots = 64;       // workgroup-cooperative records per round of list entries; the rest fall back to their wave
 struct BigRecord {
     EdgeSetup e;
@@ -668,7 +669,17 @@ template <bool GBUFFER>
 __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs a) {
     __shared__ uint32_t s_depth[GBUFFER ? 1 : kTile * kTile];
     __shared__ unsigned long long s_key[GBUFFER ? kTile * kTile : 1];
-    const uint32_t tile = blockIdx.x;
+    // Workgroups 0 .. ntiles-1 own a tile (and part 0 of its list); the rest take the further parts of the lists that k_split cut
+    // into pieces of kSplit entries: the densest tiles of a scene would otherwise set the duration of the whole kernel.
+    const uint32_t ntiles = a.tiles_x * a.tiles_y * a.num_views;
+    uint32_t tile = blockIdx.x, part = 0;
+    if (blockIdx.x >= ntiles) {
+        const uint32_t k = blockIdx.x - ntiles;
+        if (k >= min(a.counters[C_EXTRA], a.extra_capacity)) return;
+        tile = a.extra_parts[k].x;
+        part = a.extra_parts[k].y;
+        if (tile >= ntiles) return;  // never for a pass whose buffers were large enough (a too-small pass is repeated by the host)
+    }
     const uint32_t tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, view = tile / (a.tiles_x * a.tiles_y);
     const int32_t tile_x = (int32_t)tx * kTile, tile_y = (int32_t)ty * kTile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -682,10 +693,15 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
     __shared__ BigRecord s_big[kBigSlots];
     __shared__ uint32_t s_nbig;
 #ifdef SAH_EXP_RASTER_SKIP_LIST  // timing experiment: tile init + write-out only
-    const uint32_t begin = 0, count = 0;
+    const uint32_t begin = 0, count = 0, parts = 1, slot_of_tile = ~0u;
 #else
     // (a bin list that does not fit the buffer is not read: the host repeats the pass with a larger one)
-    const uint32_t begin = a.tile_offset[tile], count = (uint64_t)begin + a.tile_count[tile] <= a.pairs_capacity ? a.tile_count[tile] : 0u;
+    const uint32_t whole = (uint64_t)a.tile_offset[tile] + a.tile_count[tile] <= a.pairs_capacity ? a.tile_count[tile] : 0u;
+    const uint32_t slot_of_tile = a.heavy_slot[tile] < a.merge_capacity ? a.heavy_slot[tile] : ~0u;  // ~0: the list is not split
+    const uint32_t parts = slot_of_tile != ~0u ? (whole + kSplit - 1) / kSplit : 1u;
+    if (part >= parts) return;
+    const uint32_t first = slot_of_tile != ~0u ? part * kSplit : 0u;
+    const uint32_t begin = a.tile_offset[tile] + first, count = slot_of_tile != ~0u ? min(kSplit, whole - min(whole, first)) : whole;
 #endif
     for (uint32_t base = 0; base < count; base += kTileThreads) {
         if (tid == 0) s_nbig = 0;
@@ -749,6 +765,27 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
         }
     }
     __syncthreads();
+    if (parts > 1) {
+        // min / max are associative: every part folds its tile into the tile's buffer in global memory; the part that arrives last
+        // (ticket) reads the merged tile back and writes the images
+        __shared__ uint32_t s_last;
+        const size_t base_index = (size_t)slot_of_tile * (kTile * kTile);
+        for (uint32_t i = tid; i < kTile * kTile; i += kTileThreads) {
+            if (GBUFFER) { if (s_key[i] != 0ull) atomicMax(&a.merge_keys[base_index + i], s_key[i]); }
+            else { if (s_depth[i] != 0xffffu) atomicMin(&a.merge_depth[base_index + i], s_depth[i]); }
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&a.tickets[slot_of_tile], 1u) == parts - 1u;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        for (uint32_t i = tid; i < kTile * kTile; i += kTileThreads) {
+            if (GBUFFER) s_key[i] = __hip_atomic_load(&a.merge_keys[base_index + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else s_depth[i] = __hip_atomic_load(&a.merge_depth[base_index + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     if (!GBUFFER) {
         // 64 texels of D16 per row = 32 dwords; 256 threads write 8 rows per step
         uint8_t* base = (uint8_t*)a.shadowmap.ptr + (size_t)view * a.shadowmap.slice_pitch;
@@ -814,6 +851,40 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
     }
 }
 
+// Cuts long bin lists into parts: a tile with more than kSplit entries gets a merge buffer (initialised here to the identity of its
+// depth test), a ticket, and one extra workgroup per further part.  Tiles beyond the scratch capacity stay unsplit (slower, not wrong).
+template <bool GBUFFER>
+__global__ __launch_bounds__(256) void k_split(const RasterArgs a) {
+    const uint32_t ntiles = a.tiles_x * a.tiles_y * a.num_views;
+    const uint32_t tile = blockIdx.x;  // one workgroup per tile: the merge buffer of a heavy tile is initialised by all 256 threads
+    __shared__ uint32_t s_slot;
+    if (tile >= ntiles) return;
+    if (threadIdx.x == 0) {
+        uint32_t slot = ~0u;
+        const uint32_t count = a.tile_count[tile];
+        if (count > kSplit && (uint64_t)a.tile_offset[tile] + count <= a.pairs_capacity) {
+            const uint32_t parts = (count + kSplit - 1) / kSplit;
+            const uint32_t h = atomicAdd(&a.counters[C_HEAVY], 1u);
+            if (h < a.merge_capacity) {
+                const uint32_t e = atomicAdd(&a.counters[C_EXTRA], parts - 1u);
+                if ((uint64_t)e + parts - 1u <= a.extra_capacity) {
+                    slot = h;
+                    a.tickets[h] = 0u;
+                    for (uint32_t p = 1; p < parts; p++) a.extra_parts[e + p - 1u] = make_uint2(tile, p);
+                }
+            }
+        }
+        a.heavy_slot[tile] = slot;
+        s_slot = slot;
+    }
+    __syncthreads();
+    if (s_slot == ~0u) return;
+    const size_t base_index = (size_t)s_slot * (kTile * kTile);
+    for (uint32_t i = threadIdx.x; i < kTile * kTile; i += 256) {
+        if (GBUFFER) a.merge_keys[base_index + i] = 0ull; else a.merge_depth[base_index + i] = 0xffffu;
+    }
+}
+
 // seq -> record index for the appended records (fans of clipped triangles; G-buffer resolve)
 __global__ __launch_bounds__(256) void k_seq_table(const RasterArgs a) {
     const uint32_t nrec = record_count(a), first = a.counters[C_TRIS] * a.num_views;
@@ -854,8 +925,11 @@ hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st
         hipLaunchKernelGGL(k_bin<true>, dim3(1024), dim3(256), 0, st, a);
         if (gbuffer) hipLaunchKernelGGL(k_seq_table, dim3(64), dim3(256), 0, st, a);
     }
-    if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, st, a);
-    else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles), dim3(kTileThreads), 0, st, a);
+    // every tile gets its heavy_slot (~0 when its list stays whole), also for an empty scene
+    if (gbuffer) hipLaunchKernelGGL(k_split<true>, dim3(ntiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_split<false>, dim3(ntiles), dim3(256), 0, st, a);
+    if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles + a.extra_capacity), dim3(kTileThreads), 0, st, a);
+    else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles + a.extra_capacity), dim3(kTileThreads), 0, st, a);
     return hipGetLastError();
 }
 

@@ -53,7 +53,7 @@ struct RasterArgs {
     float half_w, half_h;
     uint32_t tiles_x, tiles_y;
     // scratch (device)
-    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats
+    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats (of which [9] extra list parts, [10] split tiles)
     uint32_t* tri_base;  // num_primitives
     RasterRecord* records;
     RasterAttr* attrs;
@@ -67,6 +67,14 @@ struct RasterArgs {
     uint32_t pairs_capacity;
     uint32_t* seq_to_record;
     uint64_t seq_capacity;
+    // long bin lists are cut into parts (k_split): one slot per split tile
+    uint32_t* heavy_slot;   // per tile: slot, or ~0 when its list is processed whole
+    uint2* extra_parts;     // (tile, part) of the parts beyond the first
+    uint32_t extra_capacity;
+    uint32_t* tickets;      // per slot: parts that have merged so far
+    uint32_t* merge_depth;  // per slot: kRasterTile^2 depth codes (shadow cascades)
+    unsigned long long* merge_keys;  // per slot: kRasterTile^2 visibility keys (G-buffer, RSM)
+    uint32_t merge_capacity;
     const uint8_t* half_to_srgb8;  // 65536 entries: fp16 bit pattern -> sRGB8 code
     // RSM variant of the G-buffer path (sah_rsm_render): per-view clip matrices, D16 LESS, flux / normal targets
     uint32_t rsm;

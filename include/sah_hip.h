@@ -338,7 +338,8 @@ typedef struct sah_scene_geometry {
 
 /* Written by both passes when `stats` is not NULL (device memory, 8 x uint32): [0] (view, triangle) pairs processed, [1] culled,
  * degenerate, clipped away or covering no pixel centre, [2] dropped (non-finite or out-of-range coordinates, indices outside the
- * arrays), [3] window-space triangles rasterised (after clipping and fanning), [4] (tile, triangle) bin entries, [5..7] reserved. */
+ * arrays), [3] window-space triangles rasterised (after clipping and fanning), [4] (tile, triangle) bin entries, [5] further parts of bin lists
+ * that were cut into pieces of 256 entries, [6] tiles whose list was cut, [7] reserved. */
 #define SAH_RASTER_STATS_WORDS 8
 
 /* DirectionalLight::render_shadows — RenderCore/render/directional_light.cpp:286-327 with the `_shadow` pipelines of
