@@ -706,7 +706,9 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
     for (uint32_t base = 0; base < count; base += kTileThreads) {
         if (tid == 0) s_nbig = 0;
         __syncthreads();
-        const uint32_t li = base + tid;
+        // consecutive list entries go to different waves: a typical list is shorter than one round, and `base + tid` would hand
+        // all of it to wave 0 (whose medium records are processed one after the other) while the other waves idle
+        const uint32_t li = base + lane * (kTileThreads / 64u) + wave;
         uint32_t rec_index = 0, area = 0;
         int32_t x0 = 1, x1 = 0, y0 = 1, y1 = 0;
         EdgeSetup mine{};
