@@ -108,9 +108,9 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         a.pairs_capacity = (uint32_t)std::min<size_t>(r.bytes[S_PAIRS] / sizeof(uint32_t), 0xffffffffu);
         a.seq_to_record = (uint32_t*)r.ptr[S_SEQ];
         a.seq_capacity = gbuffer ? r.bytes[S_SEQ] / sizeof(uint32_t) : 0;
-        // long bin lists are cut into parts of 256 entries: at most pairs / 256 further parts, and a merge buffer per split tile (the
+        // long bin lists are cut into parts of kRasterSplit entries: at most pairs / kRasterSplit further parts, and a merge buffer per split tile (the
         // number of those is capped: tiles beyond it are processed whole)
-        a.extra_capacity = a.pairs_capacity / 256u + 1u;
+        a.extra_capacity = a.pairs_capacity / sah::kRasterSplit + 1u;
         a.merge_capacity = std::min<uint32_t>(a.extra_capacity, 2048u);
         const size_t tile_bytes = (size_t)kTile * kTile * (gbuffer ? 8 : 4);
         if (int rc = ensure(ctx, S_HEAVY, (size_t)ntiles * sizeof(uint32_t)); rc != SAH_OK) return rc;

@@ -657,7 +657,7 @@ SAH_DEV void shade_rsm_and_store(const RasterArgs& a, const EdgeSetup& e, const 
 }
 
 constexpr uint32_t kTileThreads = 256;   // 1024 (16 waves per tile, to shorten the densest tiles) measured 1.1x - 2.5x slower
-constexpr uint32_t kSplit = 256;          // bin lists longer than this are cut into parts of this many entries, one workgroup each
+constexpr uint32_t kSplit = kRasterSplit;  // bin lists longer than this are cut into parts of this many entries, one workgroup each
 constexpr uint32_t kBigSlots = 64;       // workgroup-cooperative records per round of list entries; the rest fall back to their wave
 struct BigRecord {
     EdgeSetup e;
