@@ -2,37 +2,84 @@
 
     python -m androidrenderer_amd.build [--force]
 
--ffp-contract=off is part of the numerics contract: every fp32 operator is individually rounded.
+One object per source under androidrenderer_amd/_build/ (compiled in parallel, rebuilt when the source, any header of csrc/ or
+include/, or the flags changed), then one link.  -ffp-contract=off is part of the numerics contract: every fp32
+operator is individually rounded unless a kernel opts into contraction locally (the tolerance mode of the Lighting pass does, with
+`#pragma clang fp contract(fast)` around the arithmetic it relaxes).
 """
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(HERE, "..", "include")
+OBJDIR = os.path.join(HERE, "_build")
 OUT = os.environ.get("SAH_HIP_LIBRARY") or os.path.join(HERE, "libsah_hip.so")
-SOURCES = ["api.cpp", "api_post.cpp", "api_raster.cpp", "lighting.hip", "lighting_tiled.hip", "post.hip", "lpv.hip", "probes.hip", "sky_luts.hip",
-           "raster.hip", "vpl.hip"]
+SOURCES = ["api.cpp", "api_post.cpp", "api_raster.cpp", "lighting.hip", "lighting_tiled.hip", "post.hip", "lpv.hip",
+           "probes.hip", "sky_luts.hip", "raster.hip", "vpl.hip"]
 # -fno-slp-vectorize: on MI355X v_pk_{mul,add,fma}_f32 issue in 4 cycles against 2 for the scalar forms (profiles/r1_valu_issue_cost.txt),
 # so the SLP vectoriser's packed pairs gain nothing and cost the register shuffles that feed them.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
 FLAGS += os.environ.get("SAH_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DSAH_EXP_...); never set by the driver
+
+
+def _headers_digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in (CSRC, INCLUDE):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hpp", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def _stale(src, obj, stamp, digest):
+    if not os.path.exists(obj) or not os.path.exists(stamp):
+        return True
+    if open(stamp).read() != digest:
+        return True
+    return os.path.getmtime(src) > os.path.getmtime(obj)
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sah_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    digest = _headers_digest()
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, s + ".o")
+        if _stale(os.path.join(CSRC, s), obj, obj + ".stamp", digest) or os.path.getmtime(obj) > os.path.getmtime(OUT):
+            return True
+    return False
+
+
+def _compile(hipcc, src, obj, verbose):
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT, "-ldl"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    digest = _headers_digest()
+    todo = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s + ".o")
+        if force or _stale(src, obj, obj + ".stamp", digest):
+            todo.append((src, obj))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as ex:
+        for f in [ex.submit(_compile, hipcc, src, obj, verbose) for src, obj in todo]:
+            f.result()
+    for _, obj in todo:
+        open(obj + ".stamp", "w").write(digest)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJDIR, s + ".o") for s in SOURCES] + ["-o", OUT, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

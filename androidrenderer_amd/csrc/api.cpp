@@ -170,7 +170,7 @@ int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_
         sah_destroy(ctx);
         return SAH_ERR_HIP;
     }
-    if (world > 1 && comm_id) {
+    if (comm_id) {  // world == 1 with an id builds a one-rank communicator: the N-rank exchange path, runnable on one GPU
         int rc = sah_comm_init(ctx, comm_id);
         if (rc != SAH_OK) { sah_destroy(ctx); return rc; }
     }
@@ -181,6 +181,8 @@ int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_
     }
     const char* ppt = getenv("SAH_FORCE_PPT");
     if (ppt) ctx->force_ppt = atoi(ppt);
+    const char* mc = getenv("SAH_RASTER_MERGE_CAPACITY");
+    if (mc) ctx->raster_merge_cap = (uint32_t)atoi(mc);
     const char* gen = getenv("SAH_FORCE_GENERAL");
     if (gen) ctx->force_general = atoi(gen) != 0;
     *out = ctx;
@@ -191,6 +193,8 @@ void sah_destroy(sah_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     sah_comm_destroy(ctx);
+    if (ctx->comm_ready) (void)hipEventDestroy(ctx->comm_ready);
+    if (ctx->comm_done) (void)hipEventDestroy(ctx->comm_done);
     if (ctx->luts) (void)hipFree(ctx->luts);
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);

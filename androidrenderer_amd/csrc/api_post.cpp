@@ -1,6 +1,7 @@
 // C ABI: post chain, LPV maintenance and the RCCL row all-gather.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstring>
 
@@ -242,14 +243,9 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
 }
 
 // ---- RCCL (resolved at run time so that a process which already carries an RCCL — e.g. PyTorch's — shares it) ----
-typedef int (*pfn_ncclGetUniqueId)(void*);
-struct sah_nccl_id {  // ncclUniqueId is passed by value: 128 bytes
-    char internal[128];
-};
-typedef int (*pfn_ncclCommInitRank2)(void**, int, sah_nccl_id, int);
-typedef int (*pfn_ncclCommDestroy)(void*);
-typedef int (*pfn_ncclAllGather)(const void*, void*, size_t, int, void*, hipStream_t);
-typedef const char* (*pfn_ncclGetErrorString)(int);
+// The function-pointer types come from <rccl/rccl.h> itself (decltype of the declarations), so a prototype that drifts from the
+// installed library is a compile error, not a silent ABI mismatch; only the symbol lookup is deferred to dlopen / dlsym.
+#define RCCL_SYM(lib, fn) reinterpret_cast<decltype(&fn)>(dlsym(lib, #fn))
 
 static void* open_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -262,48 +258,99 @@ static void* open_rccl() {
 
 int sah_comm_unique_id(void* out) {
     if (!out) return SAH_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(ncclUniqueId) == 128, "sah_comm_unique_id hands out 128 bytes");
     void* h = open_rccl();
     if (!h) return SAH_ERR_COMM;
-    auto f = (pfn_ncclGetUniqueId)dlsym(h, "ncclGetUniqueId");
+    auto f = RCCL_SYM(h, ncclGetUniqueId);
     if (!f) return SAH_ERR_COMM;
-    return f(out) == 0 ? SAH_OK : SAH_ERR_COMM;
+    ncclUniqueId id;
+    if (f(&id) != ncclSuccess) return SAH_ERR_COMM;
+    memcpy(out, &id, sizeof(id));
+    return SAH_OK;
 }
 
 int sah_comm_init(sah_ctx* ctx, const void* comm_id) {
     ctx->rccl = open_rccl();
     if (!ctx->rccl) return fail(ctx, SAH_ERR_COMM, "librccl not found: %s", dlerror());
-    auto init = (pfn_ncclCommInitRank2)dlsym(ctx->rccl, "ncclCommInitRank");
+    auto init = RCCL_SYM(ctx->rccl, ncclCommInitRank);
     if (!init) return fail(ctx, SAH_ERR_COMM, "ncclCommInitRank not found");
-    sah_nccl_id id;
+    ncclUniqueId id;
     memcpy(&id, comm_id, sizeof(id));
     if (hipSetDevice(ctx->device) != hipSuccess) return SAH_ERR_HIP;
-    int rc = init(&ctx->comm, ctx->world, id, ctx->rank);
-    if (rc != 0) return fail(ctx, SAH_ERR_COMM, "ncclCommInitRank failed: %d", rc);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = init(&comm, ctx->world, id, ctx->rank);
+    if (rc != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "ncclCommInitRank failed: %d", (int)rc);
+    ctx->comm = comm;
     return SAH_OK;
 }
 
 void sah_comm_destroy(sah_ctx* ctx) {
     if (ctx->comm && ctx->rccl) {
-        auto f = (pfn_ncclCommDestroy)dlsym(ctx->rccl, "ncclCommDestroy");
-        if (f) f(ctx->comm);
+        auto f = RCCL_SYM(ctx->rccl, ncclCommDestroy);
+        if (f) f((ncclComm_t)ctx->comm);
     }
     ctx->comm = nullptr;
 }
 
-int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank) {
-    if (!ctx || !image || !image->ptr) return SAH_ERR_INVALID_ARGUMENT;
-    if (ctx->world == 1) return SAH_OK;
-    if (!ctx->comm) return fail(ctx, SAH_ERR_COMM, "context was created without a communicator");
-    if ((uint64_t)rows_per_rank * ctx->world > image->height) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rows_per_rank * world > height");
-    auto ag = (pfn_ncclAllGather)dlsym(ctx->rccl, "ncclAllGather");
-    if (!ag) return fail(ctx, SAH_ERR_COMM, "ncclAllGather not found");
-    const size_t bytes = (size_t)rows_per_rank * image->row_pitch_bytes;
-    const uint8_t* send = (const uint8_t*)image->ptr + (size_t)ctx->rank * bytes;
+int sah_comm_set_stream(sah_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // in place: the send buffer is this rank's slot of the receive buffer; ncclUint8 == 1 (ncclChar == 0)
-    int rc = ag(send, image->ptr, bytes, /*ncclUint8*/ 1, ctx->comm, ctx->stream);
-    if (rc != 0) return fail(ctx, SAH_ERR_COMM, "ncclAllGather failed: %d", rc);
+    ctx->comm_stream = (hipStream_t)hip_stream;
+    if (ctx->comm_stream && !ctx->comm_ready) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->comm_ready, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->comm_done, hipEventDisableTiming));
+    }
+    ctx->comm_pending = false;
     return SAH_OK;
+}
+
+int sah_comm_wait(sah_ctx* ctx) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (ctx->comm_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_done, 0));
+        ctx->comm_pending = false;
+    }
+    return SAH_OK;
+}
+
+int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank) {
+    if (!ctx || !buffer) return SAH_ERR_INVALID_ARGUMENT;
+    if (bytes_per_rank == 0) return SAH_OK;
+    if (!ctx->comm) {
+        if (ctx->world == 1) return SAH_OK;  // one rank and no communicator: the buffer already is the gathered result
+        return fail(ctx, SAH_ERR_COMM, "context was created without a communicator");
+    }
+    auto ag = RCCL_SYM(ctx->rccl, ncclAllGather);
+    if (!ag) return fail(ctx, SAH_ERR_COMM, "ncclAllGather not found");
+    const uint8_t* send = (const uint8_t*)buffer + (size_t)ctx->rank * bytes_per_rank;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool side = ctx->comm_stream && ctx->comm_stream != ctx->stream;
+    if (side) {  // the gather runs behind everything enqueued so far on the work stream, and beside whatever is enqueued next
+        HIP_TRY(ctx, hipEventRecord(ctx->comm_ready, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0));
+        st = ctx->comm_stream;
+    }
+    // in place: the send buffer is this rank's slot of the receive buffer
+    const ncclResult_t rc = ag(send, buffer, (size_t)bytes_per_rank, ncclUint8, (ncclComm_t)ctx->comm, st);
+    if (rc != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "ncclAllGather failed: %d", (int)rc);
+    if (side) {
+        HIP_TRY(ctx, hipEventRecord(ctx->comm_done, ctx->comm_stream));
+        ctx->comm_pending = true;
+    }
+    return SAH_OK;
+}
+
+int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows) {
+    if (!ctx || !image || !image->ptr) return SAH_ERR_INVALID_ARGUMENT;
+    const uint64_t slots = (uint64_t)rows_per_rank * ctx->world;
+    if (slots < image->height)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rows_per_rank * world = %llu leaves rows of a %u-row image ungathered", (unsigned long long)slots,
+                    image->height);
+    if (slots > allocated_rows)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the allocation holds %u rows, the gather needs %llu equal slots (pad it to rows_per_rank * world)",
+                    allocated_rows, (unsigned long long)slots);
+    return sah_allgather_bytes(ctx, image->ptr, (uint64_t)rows_per_rank * image->row_pitch_bytes);
 }
 
 }  // extern "C"

@@ -88,8 +88,12 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
     for (int attempt = 0; attempt < 4; attempt++) {
         if (int rc = ensure(ctx, S_CLIPQ, want_clipped * sizeof(uint2)); rc != SAH_OK) return rc;
         if (int rc = ensure(ctx, S_RECORDS, want_records * sizeof(sah::RasterRecord)); rc != SAH_OK) return rc;
+        // shadow pass: the alpha test of CUTOUT primitives needs their vertex colours and materials (lean records, raster_args.hpp)
+        const bool shadow_attrs = !gbuffer && scene->vertex_data && scene->materials && scene->num_materials;
         if (gbuffer)
             if (int rc = ensure(ctx, S_ATTRS, want_records * sizeof(sah::RasterAttr)); rc != SAH_OK) return rc;
+        if (shadow_attrs)
+            if (int rc = ensure(ctx, S_ATTRS, want_records * sizeof(sah::ShadowAttr)); rc != SAH_OK) return rc;
         if (int rc = ensure(ctx, S_PAIRS, want_pairs * sizeof(uint32_t)); rc != SAH_OK) return rc;
         if (gbuffer)
             if (int rc = ensure(ctx, S_SEQ, want_seq * sizeof(uint32_t)); rc != SAH_OK) return rc;
@@ -99,8 +103,10 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         a.tri_base = (uint32_t*)r.ptr[S_TRI_BASE];
         a.records = (sah::RasterRecord*)r.ptr[S_RECORDS];
         a.attrs = (sah::RasterAttr*)r.ptr[S_ATTRS];
+        a.shadow_attrs = shadow_attrs ? (sah::ShadowAttr*)r.ptr[S_ATTRS] : nullptr;
         a.record_capacity = (uint32_t)std::min<size_t>(r.bytes[S_RECORDS] / sizeof(sah::RasterRecord), 0xffffffffu);
         if (gbuffer) a.record_capacity = (uint32_t)std::min<size_t>(a.record_capacity, r.bytes[S_ATTRS] / sizeof(sah::RasterAttr));
+        if (shadow_attrs) a.record_capacity = (uint32_t)std::min<size_t>(a.record_capacity, r.bytes[S_ATTRS] / sizeof(sah::ShadowAttr));
         a.tile_count = (uint32_t*)r.ptr[S_TILES];
         a.tile_cursor = a.tile_count + ntiles;
         a.tile_offset = a.tile_count + 2 * (size_t)ntiles;
@@ -111,7 +117,7 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         // long bin lists are cut into parts of kRasterSplit entries: at most pairs / kRasterSplit further parts, and a merge buffer per split tile (the
         // number of those is capped: tiles beyond it are processed whole)
         a.extra_capacity = a.pairs_capacity / sah::kRasterSplit + 1u;
-        a.merge_capacity = std::min<uint32_t>(a.extra_capacity, 2048u);
+        a.merge_capacity = std::min<uint32_t>(a.extra_capacity, ctx->raster_merge_cap);
         const size_t tile_bytes = (size_t)kTile * kTile * (gbuffer ? 8 : 4);
         if (int rc = ensure(ctx, S_HEAVY, (size_t)ntiles * sizeof(uint32_t)); rc != SAH_OK) return rc;
         if (int rc = ensure(ctx, S_EXTRA, (size_t)a.extra_capacity * sizeof(uint2)); rc != SAH_OK) return rc;
@@ -128,6 +134,9 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const size_t total_tris = r.host_counters[0], clipped = r.host_counters[3], pairs = r.host_counters[2];
         if (total_tris >= (1u << 28)) return fail(ctx, SAH_ERR_UNSUPPORTED, "rasteriser: more than 2^28 triangles in one pass");
+        if (r.host_counters[12])
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadow_render: the scene has CUTOUT primitives (%u triangles): vertex_data and materials are needed "
+                        "for their alpha test (shadow_masked pipeline)", r.host_counters[12]);
         // records: one slot per (view, triangle) plus the appended fans of the clipped ones
         const size_t need_records = total_tris * a.num_views + r.host_counters[1];
         const size_t need_seq = gbuffer ? total_tris * 8 * a.num_views + 1 : 0;

@@ -17,6 +17,9 @@ struct sah_ctx {
     float* luts = nullptr;  // device: 256 sRGB->linear + 256 UNORM8->float
     void* comm = nullptr;   // ncclComm_t
     void* rccl = nullptr;   // dlopen handle
+    hipStream_t comm_stream = nullptr;  // optional side stream of the exchange step (sah_comm_set_stream); not owned
+    hipEvent_t comm_ready = nullptr, comm_done = nullptr;
+    bool comm_pending = false;          // a gather on comm_stream has not been joined by sah_comm_wait yet
     int force_ppt = 0;      // tuning/testing hook: 0 = auto
     bool force_general = false;  // testing hook: always run the general kernel
     sah::FrameState* state = nullptr;  // device
@@ -32,6 +35,7 @@ struct sah_ctx {
         uint8_t* half_to_srgb8 = nullptr;
         uint32_t* host_counters = nullptr;  // pinned, 16 words
     } raster;
+    uint32_t raster_merge_cap = 2048;  // tiles whose bin list may be split (testing hook SAH_RASTER_MERGE_CAPACITY: 0 = every list whole)
     std::string last_error;
 };
 

@@ -31,7 +31,7 @@ constexpr float kCoordLimit = 0x1p24f + 4096.0f;  // snapped coordinates beyond 
 constexpr uint32_t kSmallArea = SAH_RASTER_SMALL_AREA;    // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone
 constexpr uint32_t kMediumArea = SAH_RASTER_MEDIUM_AREA;  // ... up to which one wave does; above, the whole workgroup
 
-enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4, C_EXTRA = 9, C_HEAVY = 10 };  // the last two are statistics words 5 and 6  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
+enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4, C_EXTRA = 9, C_HEAVY = 10, C_CUTOUT_NO_ATTR = 12 };  // the last two are statistics words 5 and 6  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
 
 struct ClipVertex {
     float c[4];
@@ -231,8 +231,26 @@ SAH_DEV void emit_triangle(const RasterArgs& a, SetupStats& st, uint32_t view, u
     rec.view = view;
     rec.x0 = (uint16_t)x0; rec.x1 = (uint16_t)x1; rec.y0 = (uint16_t)y0; rec.y1 = (uint16_t)y1;
     rec.seq = seq;
-    rec.cutout = GBUFFER && prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
+    // masked geometry is alpha-tested in every pass (shadow_masked_pso / rsm_masked_pso / gbuffer_masked_pso, material_pipelines.cpp:47-140)
+    rec.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && (GBUFFER || a.shadow_attrs != nullptr);
     a.records[r] = rec;
+    if (!GBUFFER && prim.type == SAH_PRIMITIVE_TYPE_CUTOUT) {
+        if (a.shadow_attrs) {
+            ShadowAttr sa;
+            sa.inv_w[0] = v0.inv_w; sa.inv_w[1] = v1.inv_w; sa.inv_w[2] = v2.inv_w;
+            for (int k = 0; k < 3; k++) { sa.bary[0][k] = v0.bary[k]; sa.bary[1][k] = v1.bary[k]; sa.bary[2][k] = v2.bary[k]; }
+            for (int k = 0; k < 3; k++) {
+                const sah_vertex_data& vd = a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]];
+                sa.alpha[k] = f2h((float)((vd.color >> 24) & 0xffu) / 255.0f);
+            }
+            sa.pad = 0;
+            sa.material = prim.material;
+            sa.pad2 = 0;
+            a.shadow_attrs[r] = sa;
+        } else {
+            atomicAdd(&a.counters[C_CUTOUT_NO_ATTR], 1u);  // the host turns this into SAH_ERR_INVALID_ARGUMENT (api_raster.cpp)
+        }
+    }
     if (GBUFFER) {
         RasterAttr at;
         at.inv_w[0] = v0.inv_w; at.inv_w[1] = v1.inv_w; at.inv_w[2] = v2.inv_w;
@@ -312,7 +330,8 @@ __global__ __launch_bounds__(256) void k_setup(const RasterArgs a) {
         st.in++;
         if (w < a.record_capacity) mark_empty(a.records[w]);  // overwritten below if the triangle survives unclipped
         // a draw that points outside the index / vertex / material arrays is dropped, never dereferenced
-        bool in_range = (uint64_t)prim.first_index + 3ull * tri + 3ull <= a.num_indices && (!GBUFFER || prim.material < a.num_materials);
+        bool in_range = (uint64_t)prim.first_index + 3ull * tri + 3ull <= a.num_indices &&
+                        (!(GBUFFER || (a.shadow_attrs && prim.type == SAH_PRIMITIVE_TYPE_CUTOUT)) || prim.material < a.num_materials);
         for (int k = 0; k < 3 && in_range; k++) {
             const int64_t v = (int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k];
             in_range = v >= 0 && v < (int64_t)a.num_vertices;
@@ -523,6 +542,20 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
     const float z = fragment_depth(e, px, py);
     const uint32_t slot = (uint32_t)(py - tile_y) * kTile + (uint32_t)(px - tile_x);
     if (!GBUFFER) {
+        if (e.cutout) {  // shadow_masked fragment stage: discard when tinted_base_color.a <= opacity_threshold
+            const ShadowAttr& sa = a.shadow_attrs[rec_index];
+            float b[3];
+            barycentrics(e, v, b);
+            const float q0 = b[0] * sa.inv_w[0], q1 = b[1] * sa.inv_w[1], q2 = b[2] * sa.inv_w[2];
+            const float sum = (q0 + q1) + q2;
+            const float l0 = q0 / sum, l1 = q1 / sum, l2 = q2 / sum;
+            float lambda[3];
+            for (int k = 0; k < 3; k++) lambda[k] = (l0 * sa.bary[0][k] + l1 * sa.bary[1][k]) + l2 * sa.bary[2][k];
+            const Hn va = Hn((lambda[0] * h2f(sa.alpha[0]) + lambda[1] * h2f(sa.alpha[1])) + lambda[2] * h2f(sa.alpha[2]));
+            const sah_material& m = a.materials[min(sa.material, a.num_materials - 1u)];
+            const Hn alpha = Hn(m.base_color_texel[3]) * va * Hn(m.base_color_tint[3]);
+            if (tof(alpha) <= m.opacity_threshold) return;
+        }
         atomicMin(&s_depth[slot], (uint32_t)__builtin_rintf(z * 65535.0f));
     } else {
         // key: the larger wins.  G-buffer: reverse-Z depth bits (GREATER against the cleared 0).  RSM: D16 compare LESS against the
@@ -538,7 +571,13 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
             const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
             if (tof(alpha) <= m.opacity_threshold) return;
         }
-        atomicMax(&s_key[slot], ((unsigned long long)depth_key << 32) | (unsigned long long)(0xffffffffu - e.seq));
+        // low word: who wins among equal depths.  Draw order is all SOLID primitives, then all CUTOUT ones (draw_opaque, draw_masked:
+        // gbuffer_phase.cpp:91-93, light_propagation_volume.cpp:611-613), triangles in list order inside a class: order = (class, seq).
+        // G-buffer: a depth pre-pass (GREATER) settles the depth, the colour pass runs with compare EQUAL and depth writes off
+        // (material_pipelines.cpp gbuffer_pso / gbuffer_masked_pso), so every fragment at the final depth overwrites the targets and
+        // the LAST in draw order stays.  RSM: one pass, LESS with depth writes: the FIRST of equal codes stays.
+        const uint32_t order = (e.cutout << 31) | e.seq;
+        atomicMax(&s_key[slot], ((unsigned long long)depth_key << 32) | (unsigned long long)(a.rsm ? ~order : order));
     }
 }
 template <bool GBUFFER>
@@ -577,7 +616,7 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
             if (!outside && px <= bx1 && py <= by1) {
                 double v[3] = {0.0, 0.0, 0.0};
                 bool covered = all_in;
-                if (!all_in || (GBUFFER && e.cutout)) {
+                if (!all_in || e.cutout) {
                     covered = true;
                     for (int i = 0; i < 3; i++) {
                         v[i] = base[i] + lane_off[i];
@@ -765,8 +804,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
                 if (sx0 <= bx1) sweep<GBUFFER>(a, e, ri, sx0, sx1, bx1, by1, by0 + 8 * (int32_t)(wave & 7u), 64, lane, tile_x, tile_y, s_depth, s_key);
             }
         }
+        // every wave has read s_nbig / s_big of this round before thread 0 resets the counter for the next one (lists left unsplit
+        // take several rounds)
+        __syncthreads();
     }
-    __syncthreads();
     if (parts > 1) {
         // min / max are associative: every part folds its tile into the tile's buffer in global memory; the part that arrives last
         // (ticket) reads the merged tile back and writes the images
@@ -833,7 +874,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
             } else {
                 // an unclipped triangle sits in the slot of its work item (one view: slot = running triangle number = seq / 8);
                 // the fans of clipped ones were appended and are found through the table
-                const uint32_t seq = 0xffffffffu - (uint32_t)key, total = a.counters[C_TRIS];
+                const uint32_t seq = (a.rsm ? ~(uint32_t)key : (uint32_t)key) & 0x7fffffffu, total = a.counters[C_TRIS];
                 uint64_t r = (uint64_t)view * total + (seq >> 3);
                 if ((seq & 7u) != 0u || r >= a.record_capacity || is_empty(a.records[r])) {
                     const uint64_t slot = (uint64_t)view * total * 8u + seq;

@@ -25,7 +25,7 @@ struct RasterRecord {
     uint32_t view;
     uint16_t x0, x1, y0, y1;  // candidate pixels (centres inside the bounding box), clipped to the viewport; x0 > x1: empty slot
     uint32_t seq;             // G-buffer: draw order, (running triangle number) * 8 + fan index
-    uint32_t cutout;          // G-buffer: alpha-tested primitive
+    uint32_t cutout;          // alpha-tested primitive (every pass: the reference draws masked geometry with the *_masked pipelines)
 };
 static_assert(sizeof(RasterRecord) == 56, "RasterRecord layout");
 
@@ -40,6 +40,18 @@ struct RasterAttr {
     uint16_t vout[3][12];  // fp16 varyings of the input triangle's vertices: colour rgba, normal xyz, tangent xyzw, pad
 };
 static_assert(sizeof(RasterAttr) == 136, "RasterAttr layout");
+
+// Shadow pass, CUTOUT records only: what the alpha test of the shadow_masked fragment stage needs (gltf_basic_pbr.slang:181-196 with
+// SAH_DEPTH_ONLY, SAH_MASKED: tinted_base_color.a = texel.a * vertex colour.a * tint.a against the opacity threshold).
+struct ShadowAttr {
+    float inv_w[3];
+    float bary[3][3];
+    uint16_t alpha[3];  // fp16 vertex colour alpha of the input triangle's vertices
+    uint16_t pad;
+    uint32_t material;
+    uint32_t pad2;
+};
+static_assert(sizeof(ShadowAttr) == 64, "ShadowAttr layout");
 
 struct RasterArgs {
     // scene
@@ -57,10 +69,11 @@ struct RasterArgs {
     float half_w, half_h;
     uint32_t tiles_x, tiles_y;
     // scratch (device)
-    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats (of which [9] extra list parts, [10] split tiles)
+    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats (of which [9] extra list parts, [10] split tiles), [12] CUTOUT triangles seen by a shadow pass that has no attributes
     uint32_t* tri_base;  // num_primitives
     RasterRecord* records;
     RasterAttr* attrs;
+    ShadowAttr* shadow_attrs;  // shadow pass: one per record, written for CUTOUT records; null when the scene came without vertex data / materials
     uint32_t record_capacity;
     uint2* clip_queue;  // (view, running triangle number) of the triangles that cross a clipping plane
     uint32_t clip_capacity;

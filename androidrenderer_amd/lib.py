@@ -23,7 +23,7 @@ _lib = None
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
-           "sah_lpv_inject_vpls", "sah_allgather_rows"]
+           "sah_lpv_inject_vpls", "sah_allgather_rows", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
 
 
 def load():
@@ -52,7 +52,10 @@ def load():
     lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
-    lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32]
+    lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
+    lib.sah_allgather_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.sah_comm_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sah_comm_wait.argtypes = [C.c_void_p]
     lib.sah_ao_clear.argtypes = [C.c_void_p, C.POINTER(_abi.Plane)]
     lib.sah_sky_update_luts.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(C.c_float)]
     lib.sah_probe_copy.argtypes =[C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
@@ -160,8 +163,18 @@ class Context:
         self._check(self.lib.sah_lpv_inject_vpls(self.handle, C.c_void_p(vpl_list_ptr), C.c_void_p(vpl_count_ptr), capacity, cascades, cascade_index,
                                                  num_cascades, vols))
 
-    def allgather_rows(self, image, rows_per_rank):
-        self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank))
+    def allgather_rows(self, image, rows_per_rank, allocated_rows=None):
+        """image: _abi.Plane over a buffer of `allocated_rows` (default image.height) rows; in place, on the context's stream."""
+        self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank, image.height if allocated_rows is None else allocated_rows))
+
+    def comm_set_stream(self, hip_stream_handle):
+        self._check(self.lib.sah_comm_set_stream(self.handle, C.c_void_p(hip_stream_handle)))
+
+    def comm_wait(self):
+        self._check(self.lib.sah_comm_wait(self.handle))
+
+    def allgather_bytes(self, device_ptr, bytes_per_rank):
+        self._check(self.lib.sah_allgather_bytes(self.handle, C.c_void_p(device_ptr), bytes_per_rank))
 
     def close(self):
         if getattr(self, "handle", None):

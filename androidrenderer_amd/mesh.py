@@ -185,7 +185,7 @@ def random_soup(seed, triangles=400, extent=6.0, size=(0.05, 3.0), cutout_fracti
         scale = np.exp(g.uniform(np.log(size[0]), np.log(size[1]), (n, 1, 1))).astype(np.float32)
         pos = (centre + scale * g.uniform(-1, 1, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
         if n > 8:
-            pos[3:6] = pos[0:3]          # exact duplicate: the depth tie goes to the earlier triangle
+            pos[3:6] = pos[0:3]          # exact duplicate: a depth tie (G-buffer: the later draw stays; RSM: the earlier one)
             pos[8] = pos[7]              # degenerate
         nrm = g.normal(size=(3 * n, 3)).astype(np.float32)
         tan = np.concatenate([g.normal(size=(3 * n, 3)), g.choice([-1.0, 1.0], (3 * n, 1))], axis=1).astype(np.float32)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SAH_ABI_VERSION 1
+#define SAH_ABI_VERSION 2
 
 typedef enum sah_status {
     SAH_OK = 0,
@@ -217,7 +217,9 @@ int sah_abi_version(void);
 const char* sah_status_string(int status);
 const char* sah_last_error(const sah_ctx* ctx);
 
-/* comm_id: NULL when world == 1; otherwise the 128-byte ncclUniqueId from sah_comm_unique_id(). */
+/* comm_id: the 128-byte ncclUniqueId from sah_comm_unique_id() (the same bytes on every rank), or NULL for a context without a
+ * communicator (world must then be 1).  world == 1 with a comm_id builds a one-rank communicator, so that the exchange entry points
+ * below run through RCCL exactly as they do on N ranks. */
 int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_id);
 void sah_destroy(sah_ctx* ctx);
 int sah_comm_unique_id(void* out_128_bytes);
@@ -329,10 +331,11 @@ typedef struct sah_primitive {
 
 typedef struct sah_scene_geometry {
     const float* vertex_positions;      /* 3 floats per vertex, tightly packed */
-    const sah_vertex_data* vertex_data; /* may be NULL for sah_shadow_render */
+    const sah_vertex_data* vertex_data; /* sah_shadow_render: may be NULL when the scene has no CUTOUT primitive */
     const uint32_t* indices;
-    const sah_primitive* primitives;    /* draw order: lower index wins a depth tie */
-    const sah_material* materials;      /* may be NULL for sah_shadow_render */
+    const sah_primitive* primitives;    /* list order = draw order inside a class; all SOLID primitives are drawn before all CUTOUT ones,
+                                           wherever they sit in the list (RenderScene::draw_opaque, then draw_masked) */
+    const sah_material* materials;      /* sah_shadow_render: may be NULL when the scene has no CUTOUT primitive */
     uint32_t num_vertices, num_indices, num_primitives, num_materials;
 } sah_scene_geometry;
 
@@ -345,7 +348,10 @@ typedef struct sah_scene_geometry {
 /* DirectionalLight::render_shadows — RenderCore/render/directional_light.cpp:286-327 with the `_shadow` pipelines of
  * RenderCore/render/material_pipelines.cpp:31-62 (compare LESS, depth clamp) and the SAH_MULTIVIEW vertex stage of
  * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-146.  Clears every layer of `shadowmap` (D16_UNORM 2D array) to 1.0 and
- * rasterises every primitive into each of the `num_cascades` layers with sun->cascade_matrices[layer]. */
+ * rasterises every primitive into each of the `num_cascades` layers with sun->cascade_matrices[layer].  CUTOUT primitives go through
+ * the `_shadow_masked` fragment stage (Tools/compile_shaders.py:110-112: SAH_DEPTH_ONLY, SAH_MASKED; gltf_basic_pbr.slang:181-196):
+ * a fragment whose tinted_base_color.a <= opacity_threshold writes no depth.  That needs scene->vertex_data and scene->materials; a
+ * scene that has CUTOUT primitives but came without them fails with SAH_ERR_INVALID_ARGUMENT (the image is then undefined). */
 int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_light_constants* sun, uint32_t num_cascades,
                       const sah_volume* shadowmap, uint32_t* stats);
 
@@ -391,9 +397,22 @@ int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv
 int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint32_t* vpl_count, uint32_t capacity,
                         const sah_lpv_cascade_matrices* cascades, uint32_t cascade_index, uint32_t num_cascades, const sah_volume rgb[3]);
 
-/* Multi-GPU: in-place all-gather of row blocks of `image` (rank r owns rows
- * [rows_per_rank*r, rows_per_rank*(r+1))) over RCCL. */
-int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank);
+/* Multi-GPU exchange step (no reference counterpart: the reference drives one device, RenderCore/render/backend/render_backend.cpp:135-153;
+ * BASELINE.json north_star: "RCCL all-gather over xGMI to reassemble the final image").
+ * In-place all-gather of row blocks of `image` over RCCL on the context's stream: rank r owns rows [rows_per_rank*r, rows_per_rank*(r+1))
+ * clipped to image->height.  Slots are equal, so when world does not divide the height the caller pads: rows_per_rank = ceil(height / world)
+ * and the buffer behind image->ptr holds `allocated_rows` >= rows_per_rank * world rows of image->row_pitch_bytes (the rows past
+ * image->height are scratch).  Fails with SAH_ERR_INVALID_ARGUMENT when rows_per_rank * world < height (rows would stay ungathered) or
+ * > allocated_rows.  With one rank and no communicator it is a no-op. */
+int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows);
+/* Optional: run the exchange on a side stream (an externally owned hipStream_t; NULL = back to the work stream).  Each gather then
+ * starts when the work enqueued before it has finished and runs beside the work enqueued after it; sah_comm_wait() makes the work
+ * stream wait for the last gather (call it before touching the gathered buffer again).  Without a side stream gathers are ordinary
+ * entries of the work stream and sah_comm_wait() is a no-op. */
+int sah_comm_set_stream(sah_ctx* ctx, void* hip_stream);
+int sah_comm_wait(sah_ctx* ctx);
+/* Same exchange on a raw DEVICE buffer of world * bytes_per_rank bytes; rank r owns [r * bytes_per_rank, (r+1) * bytes_per_rank). */
+int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank);
 
 #ifdef __cplusplus
 }

@@ -284,6 +284,22 @@ GbufferTexel shade_fragment(const sah_material& m, const VertexOut vo[3], const 
     return out;
 }
 
+// Draw order of a pass: every SOLID primitive, then every CUTOUT one, each class in list order (RenderScene::draw_opaque followed by
+// draw_masked: gbuffer_phase.cpp:91-93, depth_culling_phase.cpp:473-476, directional_light.cpp:318-321, light_propagation_volume.cpp:611-613)
+std::vector<uint32_t> draw_order(const sah_scene_geometry& g) {
+    std::vector<uint32_t> order;
+    for (uint32_t type : {(uint32_t)SAH_PRIMITIVE_TYPE_SOLID, (uint32_t)SAH_PRIMITIVE_TYPE_CUTOUT})
+        for (uint32_t p = 0; p < g.num_primitives; p++)
+            if (g.primitives[p].type == type) order.push_back(p);
+    return order;
+}
+
+// tinted_base_color.a of the *_masked fragment stages (gltf_basic_pbr.slang:181-196): texel.a * vertex colour.a * tint.a in half
+bool alpha_discarded(const sah_material& m, const VertexOut vo[3], const F lambda[3]) {
+    const H a = H(m.base_color_texel[3]) * interpolate(lambda, vo[0].color[3], vo[1].color[3], vo[2].color[3]) * H(m.base_color_tint[3]);
+    return a.v <= m.opacity_threshold;
+}
+
 bool plane_is(const sah_plane& p, uint32_t fmt, uint32_t w, uint32_t h) { return p.ptr && p.format == fmt && p.width == w && p.height == h; }
 
 // ---- RSM fragment stage (gltf_basic_pbr.slang:169-253, SAH_RSM) -------------------------------------------------------------------
@@ -325,6 +341,8 @@ int orc_shadow_render(const sah_scene_geometry* scene, const sah_sun_light_const
     if (!geometry_ok(scene, false) || !sun || !shadowmap || !shadowmap->ptr || shadowmap->format != SAH_FORMAT_D16_UNORM || num_cascades == 0 ||
         num_cascades > 4 || shadowmap->depth < num_cascades || shadowmap->width > 8192 || shadowmap->height > 8192)
         return SAH_ERR_INVALID_ARGUMENT;
+    for (uint32_t p = 0; p < scene->num_primitives; p++)  // masked geometry needs its vertex colours and material for the alpha test
+        if (scene->primitives[p].type == SAH_PRIMITIVE_TYPE_CUTOUT && !geometry_ok(scene, true)) return SAH_ERR_INVALID_ARGUMENT;
     const uint32_t W = shadowmap->width, H = shadowmap->height;
     Stats st;
     for (uint32_t layer = 0; layer < num_cascades; layer++) {
@@ -334,16 +352,22 @@ int orc_shadow_render(const sah_scene_geometry* scene, const sah_sun_light_const
             for (uint32_t x = 0; x < W; x++) row[x] = 0xffffu;  // clear value 1.0 (directional_light.cpp:311)
         }
         const M4 world_to_ndc = load_m4(sun->cascade_matrices[layer]);
-        for (uint32_t p = 0; p < scene->num_primitives; p++) {
+        for (uint32_t p = 0; p < scene->num_primitives; p++) {  // depth only, compare LESS: the image does not depend on the draw order
             const sah_primitive& prim = scene->primitives[p];
-            for (uint32_t tri = 0; tri < prim.index_count / 3; tri++)
+            const bool masked = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;  // shadow_masked_pso: SAH_DEPTH_ONLY + SAH_MASKED fragment stage
+            for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {
+                VertexOut vo[3];
+                if (masked)
+                    for (int k = 0; k < 3; k++) vo[k] = vertex_outputs(*scene, prim, scene->indices[prim.first_index + 3 * tri + k]);
                 process_triangle(*scene, prim, tri, /*clip_depth=*/false, W, H, st, [&](F4 world) { return mul(world_to_ndc, world); },
                                  [&](const Fragment& f, uint32_t) {
+                                     if (masked && alpha_discarded(scene->materials[prim.material], vo, f.lambda)) return;
                                      const F z = nclamp(f.z, F(0.0f), F(1.0f));  // depth clamp; NaN -> 0
                                      const uint32_t code = (uint32_t)std::nearbyint(z.v * 65535.0f);
                                      uint16_t* texel = (uint16_t*)(base + (size_t)f.y * shadowmap->row_pitch_bytes) + f.x;
                                      if (code < *texel) *texel = (uint16_t)code;  // VK_COMPARE_OP_LESS
                                  });
+            }
         }
     }
     write_stats(stats, st);
@@ -370,29 +394,38 @@ int orc_gbuffer_render(const sah_scene_geometry* scene, const sah_view_data* vie
             std::memset(at(out->depth, x, y, 4), 0, 4);
         }
     const M4 V = load_m4(view->view), P = load_m4(view->projection);
-    Stats st;
-    for (uint32_t p = 0; p < scene->num_primitives; p++) {
-        const sah_primitive& prim = scene->primitives[p];
-        const sah_material& mat = scene->materials[prim.material];
-        for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {
-            VertexOut vo[3];
-            for (int k = 0; k < 3; k++) vo[k] = vertex_outputs(*scene, prim, scene->indices[prim.first_index + 3 * tri + k]);
-            process_triangle(*scene, prim, tri, /*clip_depth=*/true, W, H, st, [&](F4 world) { return mul(P, mul(V, world)); },
-                             [&](const Fragment& f, uint32_t) {
-                                 const F z = nclamp(f.z, F(0.0f), F(1.0f));
-                                 float stored;
-                                 std::memcpy(&stored, at(out->depth, f.x, f.y, 4), 4);
-                                 if (!(z.v > stored)) return;  // VK_COMPARE_OP_GREATER: the first of equal depths stays
-                                 const GbufferTexel t = shade_fragment(mat, vo, f.lambda);
-                                 if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && t.discarded) return;
-                                 std::memcpy(at(out->depth, f.x, f.y, 4), &z.v, 4);
-                                 std::memcpy(at(out->color, f.x, f.y, 4), t.color, 4);
-                                 std::memcpy(at(out->normals, f.x, f.y, 8), t.normal, 8);
-                                 std::memcpy(at(out->data, f.x, f.y, 4), t.data, 4);
-                                 std::memcpy(at(out->emission, f.x, f.y, 4), t.emission, 4);
-                             });
+    Stats st, st_second;
+    const std::vector<uint32_t> order = draw_order(*scene);
+    // Two passes over the same draws, as the reference makes them: the depth pre-pass (depth_culling_phase.cpp:455-481: compare GREATER,
+    // depth writes on, masked geometry alpha-tested) and the G-buffer pass (gbuffer_phase.cpp:27-97 with material_pipelines.cpp
+    // gbuffer_pso / gbuffer_masked_pso: compare EQUAL, depth writes off), in which EVERY fragment at the settled depth overwrites the
+    // colour targets — the last one in draw order stays.
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t p : order) {
+            const sah_primitive& prim = scene->primitives[p];
+            const sah_material& mat = scene->materials[prim.material];
+            for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {
+                VertexOut vo[3];
+                for (int k = 0; k < 3; k++) vo[k] = vertex_outputs(*scene, prim, scene->indices[prim.first_index + 3 * tri + k]);
+                process_triangle(*scene, prim, tri, /*clip_depth=*/true, W, H, pass == 0 ? st : st_second, [&](F4 world) { return mul(P, mul(V, world)); },
+                                 [&](const Fragment& f, uint32_t) {
+                                     const F z = nclamp(f.z, F(0.0f), F(1.0f));
+                                     float stored;
+                                     std::memcpy(&stored, at(out->depth, f.x, f.y, 4), 4);
+                                     if (pass == 0 ? !(z.v > stored) : !(z.v == stored && z.v > 0.0f)) return;  // GREATER / EQUAL (never the cleared 0)
+                                     if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && alpha_discarded(mat, vo, f.lambda)) return;
+                                     if (pass == 0) {
+                                         std::memcpy(at(out->depth, f.x, f.y, 4), &z.v, 4);
+                                         return;
+                                     }
+                                     const GbufferTexel t = shade_fragment(mat, vo, f.lambda);
+                                     std::memcpy(at(out->color, f.x, f.y, 4), t.color, 4);
+                                     std::memcpy(at(out->normals, f.x, f.y, 8), t.normal, 8);
+                                     std::memcpy(at(out->data, f.x, f.y, 4), t.data, 4);
+                                     std::memcpy(at(out->emission, f.x, f.y, 4), t.emission, 4);
+                                 });
+            }
         }
-    }
     write_stats(stats, st);
     return SAH_OK;
 }
@@ -420,7 +453,7 @@ int orc_rsm_render(const sah_scene_geometry* scene, const sah_sun_light_constant
                 std::memcpy(at(rsm->depth, layer, x, y, 2), &one, 2);
             }
         const M4 rsm_vp = load_m4(cascades[layer].rsm_vp);
-        for (uint32_t p = 0; p < scene->num_primitives; p++) {
+        for (uint32_t p : draw_order(*scene)) {  // one pass, LESS with depth writes: the first of equal codes in draw order stays
             const sah_primitive& prim = scene->primitives[p];
             const sah_material& mat = scene->materials[prim.material];
             for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {

@@ -144,13 +144,53 @@ def test_near_plane_clipping_and_draw_order_ties():
     # floor strip running from behind the camera to far ahead: crosses w = near and the guard band
     floor = [(-50, 0, -2), (-50, 0, 2), (200, 0, 2), (200, 0, -2)]
     m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), a, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)
-    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), b, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)  # same depth everywhere: loses
+    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), b, ptype=_abi.PRIMITIVE_TYPE_CUTOUT)  # same depth everywhere, drawn later
     out, stats = _oracle_gbuffer(m.arrays(), view, w, h)
     hit = out["depth"] > 0
     assert hit[h - 1].all() or hit[0].all()           # the strip reaches the screen edge nearest the camera
-    assert (out["color"][hit][:, 0] == 255).all() and (out["color"][hit][:, 1] == 0).all()  # first draw wins the tie (GREATER)
+    # the depth pre-pass settles the depth, the G-buffer pass (compare EQUAL, no depth write) lets every fragment at that depth
+    # overwrite the targets: the LAST draw stays (material_pipelines.cpp gbuffer_pso / gbuffer_masked_pso)
+    assert (out["color"][hit][:, 0] == 0).all() and (out["color"][hit][:, 1] == 255).all()
     assert stats[2] == 0 and stats[3] > 4            # clipping made extra triangles, nothing was dropped
     assert np.isfinite(out["depth"]).all() and out["depth"].max() <= 1.0
+    # a SOLID copy listed AFTER the masked ones is still drawn before them (draw_opaque, then draw_masked): the masked draw stays
+    blue = m.add_material(mesh.material(base=(0, 0, 1, 1)))
+    m.add_primitive(floor, [(0, 1, 0)] * 4, (0, 1, 2, 0, 2, 3), blue, ptype=_abi.PRIMITIVE_TYPE_SOLID)
+    out2, _ = _oracle_gbuffer(m.arrays(), view, w, h)
+    assert np.array_equal(out2["color"], out["color"]) and np.array_equal(out2["depth"], out["depth"])
+    # ... unless the masked fragments fail their alpha test: then the solid one is the only fragment at that depth
+    for k in (0, 1):
+        m.materials[k]["opacity_threshold"] = 2.0
+    out3, _ = _oracle_gbuffer(m.arrays(), view, w, h)
+    hit3 = out3["depth"] > 0
+    assert np.array_equal(hit3, hit) and (out3["color"][hit3][:, 2] == 255).all() and (out3["color"][hit3][:, :2] == 0).all()
+
+
+def test_masked_geometry_is_alpha_tested_in_the_shadow_pass():
+    """shadow_masked_pso (material_pipelines.cpp:47-62, SAH_MASKED fragment stage): a cut-out fragment whose alpha is at or below the
+    opacity threshold writes no depth, so foliage-like geometry does not cast a solid shadow"""
+    m = mesh.Mesh()
+    solid = m.add_material(mesh.material())
+    leaf = m.add_material(mesh.material(opacity_threshold=0.5))
+    _quad(m, 0, 8, 0, 8, 0.75, solid)
+    opaque, clear = 0xffffffff, 0x20ffffff  # vertex colour alpha 1.0 / 0.125
+    _quad(m, 1, 4, 1, 4, 0.25, leaf, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=[clear] * 4)   # below the threshold: discarded
+    _quad(m, 4, 7, 4, 7, 0.25, leaf, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=[opaque] * 4)  # above: casts
+    # alpha ramps from 0 (left) to 1 (right) across this one: the right part casts (the two triangles interpolate the same ramp)
+    _quad(m, 0, 8, 5, 6, 0.10, leaf, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=[0x00ffffff, 0xffffffff, 0xffffffff, 0x00ffffff])
+    sm, _ = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
+    far, near = int(np.rint(np.float32(0.75) * np.float32(65535))), int(np.rint(np.float32(0.25) * np.float32(65535)))
+    ramp = int(np.rint(np.float32(0.10) * np.float32(65535)))
+    assert (sm[0, 1:4, 1:4] == far).all() and (sm[0, 4, 4:7] == near).all() and (sm[0, 6, 4:7] == near).all()
+    row = sm[0, 5]
+    assert row[0] == far and row[7] == ramp and (np.diff((row == ramp).astype(int)) >= 0).all() and 2 <= (row == ramp).sum() <= 5
+    # without vertex data / materials the masked pass cannot run: refused, not drawn solid
+    a = mesh.with_counts(m.arrays())
+    keep = []
+    g = mesh.geometry(a, keep)
+    g.vertex_data = None
+    vol = images.volume(np.zeros((1, 8, 8), np.uint16), _abi.FORMAT_D16_UNORM)
+    assert util.oracle().orc_shadow_render(C.byref(g), C.byref(_ortho_sun()), 1, C.byref(vol), None) == _abi.SAH_ERR_INVALID_ARGUMENT
 
 
 def test_oracle_atrium_agrees_with_the_ray_casts():
@@ -283,7 +323,7 @@ def test_hip_raster_edge_cases(hip_ctx):
     _assert_gbuffers_equal(got, want)
     sm, _ = _hip_shadow(hip_ctx, empty, _ortho_sun(2), 2, (70, 40))
     assert (sm == 0xffff).all()
-    # clipped floor strip + exact depth ties (draw order decides), as in the CPU known-answer test
+    # clipped floor strip + exact depth ties (draw order decides: the last masked draw stays), as in the CPU known-answer test
     m = mesh.Mesh()
     a = m.add_material(mesh.material(base=(1, 0, 0, 1)))
     b = m.add_material(mesh.material(base=(0, 1, 0, 1)))
@@ -306,6 +346,57 @@ def test_hip_raster_edge_cases(hip_ctx):
     got, _ = _hip_shadow(hip_ctx, m.arrays(), _ortho_sun(), 1, (8, 8))
     want, _ = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_hip_masked_shadows_and_missing_attributes(hip_ctx):
+    import torch
+    from androidrenderer_amd import lib
+    m = mesh.Mesh()
+    solid = m.add_material(mesh.material())
+    leaf = m.add_material(mesh.material(opacity_threshold=0.5))
+    _quad(m, 0, 8, 0, 8, 0.75, solid)
+    _quad(m, 1, 4, 1, 4, 0.25, leaf, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=[0x20ffffff] * 4)
+    _quad(m, 4, 7, 4, 7, 0.25, leaf, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=[0xffffffff] * 4)
+    _quad(m, 0, 8, 5, 6, 0.10, leaf, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=[0x00ffffff, 0xffffffff, 0xffffffff, 0x00ffffff])
+    got, _ = _hip_shadow(hip_ctx, m.arrays(), _ortho_sun(), 1, (8, 8))
+    want, _ = _oracle_shadow(m.arrays(), _ortho_sun(), 1, (8, 8))
+    assert np.array_equal(got, want)
+    dev = mesh.to_device(m.arrays())
+    g = mesh.geometry(dev, [])
+    g.vertex_data = None
+    sm = torch.zeros((1, 8, 8), dtype=torch.int16, device="cuda")
+    with pytest.raises(lib.SahError) as e:
+        hip_ctx.shadow_render(g, _ortho_sun(), 1, images.volume(sm, _abi.FORMAT_D16_UNORM))
+    assert e.value.status == _abi.SAH_ERR_INVALID_ARGUMENT and "CUTOUT" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_hip_unsplit_bin_lists_take_several_rounds(monkeypatch):
+    """Bin lists that stay whole (more heavy tiles than merge buffers) are walked in rounds of 256 entries by one workgroup, with
+    workgroup-cooperative records (bounding box > 1024 pixels of the tile) in every round: the per-round LDS counter must not be reset
+    while a slower wave still reads it.  SAH_RASTER_MERGE_CAPACITY=0 (testing hook, read at context creation) leaves every list whole."""
+    import torch
+    from androidrenderer_amd import lib
+    monkeypatch.setenv("SAH_RASTER_MERGE_CAPACITY", "0")
+    ctx = lib.Context(device=0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        # 1500 large triangles piled on a 128 x 128 view: every tile's list has > 256 entries and most records are "big"
+        arrays = mesh.random_soup(31, triangles=1500, extent=1.5, size=(1.5, 4.0)).arrays()
+        view = _soup_view(128, 128, 31)
+        want, want_stats = _oracle_gbuffer(arrays, view, 128, 128)
+        got, got_stats = _hip_gbuffer(ctx, arrays, view, 128, 128)
+        _assert_gbuffers_equal(got, want)
+        assert got_stats[5] == 0 and got_stats[6] == 0 and got_stats[4] > 4 * 256  # nothing was split, lists are several rounds long
+        sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+        constants = sun.update_shadow_cascades(view, max_shadow_distance=16.0, resolution=128)
+        want_sm, _ = _oracle_shadow(arrays, constants, 4, (128, 128))
+        got_sm, _ = _hip_shadow(ctx, arrays, constants, 4, (128, 128))
+        assert np.array_equal(got_sm, want_sm)
+    finally:
+        torch.cuda.synchronize()
+        ctx.close()
 
 
 @pytest.mark.gpu
