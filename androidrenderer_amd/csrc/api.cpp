@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/sah_hip.h"
 #include "params.hpp"
@@ -17,7 +18,8 @@ namespace sah {
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                            const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
-hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
+                                   uint32_t row_end, hipStream_t st);
 struct TonemapArgs;
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
@@ -226,6 +228,21 @@ int sah_debug_set(sah_ctx* ctx, int force_general, int force_ppt) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     ctx->force_general = force_general != 0;
     ctx->force_ppt = force_ppt;
+    return SAH_OK;
+}
+
+// Debug / analysis hook: number of pixels the last fast-path sah_lighting call sent to the fix-up kernel (synchronises the stream).
+int sah_debug_deferred_pixels(sah_ctx* ctx, uint64_t* out) {
+    if (!ctx || !out) return SAH_ERR_INVALID_ARGUMENT;
+    *out = 0;
+    if (!ctx->last_seg_count || !ctx->last_num_segments) return SAH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint16_t> counts(ctx->last_num_segments);
+    HIP_TRY(ctx, hipMemcpy(counts.data(), ctx->last_seg_count, counts.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    uint64_t n = 0;
+    for (uint16_t c : counts) n += c;  // (the general list only: sky pixels are not counted)
+    *out = n;
     return SAH_OK;
 }
 
@@ -458,8 +475,13 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
     const bool fast_kind = (gi_kind == SAH_GI_NONE || gi_kind == SAH_GI_LPV) && a.num_lights == 0;
     const bool use_fast = fast_kind && !ctx->force_general && detect_fast_path(d, sun_mode, gi_kind, csm, &fast);
     if (use_fast) {
-        const size_t need = (size_t)W * H * sizeof(uint32_t);
-        if (ctx->list_bytes < need) {  // grow-only workspace for the deferred-pixel list
+        // deferred-pixel segments (params.hpp): one per wave of the fast kernel, 64 * ppt byte codes + a 16-bit count each
+        const uint64_t groups = (uint64_t)(W / (uint32_t)ppt) * (r1 - r0);
+        const uint32_t nseg = (uint32_t)((groups + 63) / 64);
+        const uint32_t seg_stride = 64u * (uint32_t)ppt;
+        const size_t codes_bytes = ((size_t)nseg * seg_stride + 255) & ~(size_t)255;
+        const size_t need = codes_bytes + 2 * (size_t)nseg * sizeof(uint16_t) + 256;  // two counts per segment: general (front), sky (back)
+        if (ctx->list_bytes < need) {  // grow-only workspace
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->list) (void)hipFree(ctx->list);
             ctx->list = nullptr;
@@ -467,6 +489,10 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->list, need));
             ctx->list_bytes = need;
         }
+        fast.seg_list = (uint8_t*)ctx->list;
+        fast.seg_count = (uint16_t*)((uint8_t*)ctx->list + codes_bytes);
+        fast.num_segments = nseg;
+        fast.seg_stride = seg_stride;
         if (gi_kind == SAH_GI_LPV) {  // gather copy of the LPV volumes, rebuilt by k_lpv_pack on every call
             const uint64_t row = (uint64_t)(lpv.red.width + 2 * kLpvPackBorder) * kLpvPackTexel;
             const uint64_t slice = row * (lpv.red.height + 2 * kLpvPackBorder);
@@ -485,14 +511,20 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             fast.pk_slice_pitch = (uint32_t)slice;
         }
         fast.sky_enabled = sky.enabled;
+        fast.tolerance = (d->flags & SAH_LIGHTING_TOLERANCE_1ULP) ? 1u : 0u;
         fast.parity = ctx->parity;
         fast.state = ctx->state;
-        fast.list = ctx->list;
-        fast.fixup_blocks = 1024;
     }
     HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, use_fast ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,
                                  (d->flags & SAH_LIGHTING_BRUTE_FORCE_LIGHTS) != 0, ctx->stream));
-    if (use_fast) ctx->parity ^= 1u;
+    if (use_fast) {
+        ctx->parity ^= 1u;
+        ctx->last_seg_count = fast.seg_count;
+        ctx->last_num_segments = fast.num_segments;
+    } else {
+        ctx->last_seg_count = nullptr;
+        ctx->last_num_segments = 0;
+    }
     return SAH_OK;
 }
 

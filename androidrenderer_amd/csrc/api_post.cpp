@@ -11,7 +11,8 @@
 
 namespace sah {
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
-hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
+                                   uint32_t row_end, hipStream_t st);
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
@@ -72,20 +73,40 @@ int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out) {
     return SAH_OK;
 }
 
-int sah_bloom(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom) {
-    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
-    if (!rgba16f_ok(scene) || !bloom || bloom->num_mips == 0 || bloom->num_mips > SAH_MAX_BLOOM_MIPS)
+static int bloom_range(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, uint32_t first_mip, uint32_t last_mip, uint32_t row_begin,
+                       uint32_t row_end) {
+    if ((first_mip == 0 && !rgba16f_ok(scene)) || !bloom || bloom->num_mips == 0 || bloom->num_mips > SAH_MAX_BLOOM_MIPS)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs an RGBA16F scene and 1..%d mips", SAH_MAX_BLOOM_MIPS);
     for (uint32_t m = 0; m < bloom->num_mips; m++)
         if (!rgba16f_ok(&bloom->mips[m])) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "bloom mip %u must be RGBA16F", m);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const sah_plane* src = scene;
-    for (uint32_t m = 0; m < bloom->num_mips; m++) {  // bloomer.cpp:50-151: scene -> mip0, mip i -> mip i+1
+    for (uint32_t m = first_mip; m <= last_mip && m < bloom->num_mips; m++) {  // bloomer.cpp:50-151: scene -> mip0, mip i -> mip i+1
+        const sah_plane* src = m == 0 ? scene : &bloom->mips[m - 1];
         const sah_plane* dst = &bloom->mips[m];
-        HIP_TRY(ctx, sah::launch_bloom_downsample(parg(src), src->width, src->height, parg(dst), dst->width, dst->height, ctx->stream));
-        src = dst;
+        const uint32_t r0 = m == first_mip ? row_begin : 0u, r1 = m == first_mip ? row_end : dst->height;
+        HIP_TRY(ctx, sah::launch_bloom_downsample(parg(src), src->width, src->height, parg(dst), dst->width, dst->height, r0, r1, ctx->stream));
     }
     return SAH_OK;
+}
+
+int sah_bloom(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!bloom || bloom->num_mips == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips", SAH_MAX_BLOOM_MIPS);
+    return bloom_range(ctx, scene, bloom, 0, bloom->num_mips - 1, 0, bloom->mips[0].height);
+}
+
+int sah_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, uint32_t row_begin, uint32_t row_end) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!bloom || bloom->num_mips == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips", SAH_MAX_BLOOM_MIPS);
+    if (row_end > bloom->mips[0].height || row_begin > row_end) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad mip 0 row range");
+    return bloom_range(ctx, scene, bloom, 0, 0, row_begin, row_end);
+}
+
+int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!bloom || bloom->num_mips == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips", SAH_MAX_BLOOM_MIPS);
+    if (bloom->num_mips == 1) return SAH_OK;
+    return bloom_range(ctx, scene, bloom, 1, bloom->num_mips - 1, 0, bloom->mips[1].height);
 }
 
 int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {

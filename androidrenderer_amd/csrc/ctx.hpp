@@ -28,6 +28,8 @@ struct sah_ctx {
     uint8_t* lpv_packed = nullptr;     // device: per-frame interleaved, zero-bordered copy of the three LPV volumes (lighting.hip)
     size_t lpv_packed_bytes = 0;
     uint32_t parity = 0;
+    const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
+    uint32_t last_num_segments = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds (api_post.cpp)
     struct RasterScratch {             // device buffers of the scene rasteriser, grown on demand (api_raster.cpp)
         void* ptr[16] = {};

@@ -71,22 +71,47 @@ __global__ void __launch_bounds__(256) k_lighting_general(const LightingArgs a, 
     }
 }
 
-// ---- fix-up kernel: general restatement over the deferred-pixel list ------------------------------------------------
-template <int SUN, int GI>
+// ---- fix-up kernel: general restatement over the deferred pixels -------------------------------------------------------------------
+// The fast kernel leaves, per wave, a segment of byte codes (lane * PPT + pixel) and their count (params.hpp: FastArgs).  One
+// workgroup takes kFixupSegs consecutive segments, scans their counts in LDS and deals the listed pixels to its threads, so lanes
+// stay busy whether a segment holds one stray pixel or is all sky.  No atomics, no list clearing: every wave of the fast kernel
+// rewrites its count.
+constexpr uint32_t kFixupSegs = 16;
+template <int SUN, int GI, int PPT>
 __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
                                                         const FastArgs f) {
+    __shared__ uint32_t s_pref[kFixupSegs + 1];
+    const uint32_t seg0 = blockIdx.x * kFixupSegs;
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t c = (lane < kFixupSegs && seg0 + lane < f.num_segments) ? (uint32_t)f.seg_count[seg0 + lane] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < (int)kFixupSegs; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += t;
+        }
+        if (lane < kFixupSegs) s_pref[lane + 1] = incl;
+        if (lane == 0) s_pref[0] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.state->nonfinite[f.parity ^ 1u] = 0u;  // arm the other parity for the next call
+    __syncthreads();
+    const uint32_t total = s_pref[kFixupSegs];
+    if (total == 0) return;
     __shared__ float s_lut[512];
     s_lut[threadIdx.x] = a.luts[threadIdx.x];
     s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
     __syncthreads();
-    const uint32_t count = f.state->count[f.parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // arm the other parity for the next call
-        f.state->count[f.parity ^ 1u] = 0u;
-        f.state->nonfinite[f.parity ^ 1u] = 0u;
-    }
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        const uint32_t idx = f.list[i];
-        const uint32_t y = idx / a.width, x = idx - y * a.width;
+    const uint32_t groups_per_row = a.width / PPT;
+    for (uint32_t i = threadIdx.x; i < total; i += 256u) {
+        uint32_t s = 0;  // last segment whose prefix is <= i (counts are small: a 4-step search over 16 LDS words)
+#pragma unroll
+        for (uint32_t step = kFixupSegs / 2; step >= 1; step >>= 1)
+            if (s_pref[s + step] <= i) s += step;
+        const uint32_t code = f.seg_list[(size_t)(seg0 + s) * f.seg_stride + (i - s_pref[s])];
+        const uint32_t g = (seg0 + s) * 64u + code / PPT;
+        const uint32_t ry = g / groups_per_row;
+        const uint32_t y = a.row_begin + ry, x = (g - ry * groups_per_row) * PPT + code % PPT;
         Px p;
         p.color = *reinterpret_cast<const uint32_t*>(a.color.ptr + (size_t)y * a.color.pitch + (size_t)x * 4);
         p.data = *reinterpret_cast<const uint32_t*>(a.data.ptr + (size_t)y * a.data.pitch + (size_t)x * 4);
@@ -101,6 +126,29 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
                      : 1.0f;
         const uint2 r = shade_pixel_general<SUN, GI>(a, csm, lpv, sky, x, y, p, s_lut);
         *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x * 8) = r;
+    }
+}
+
+// ---- sky kernel: the deferred depth == 0 pixels (back half of the segments) ---------------------------------------------------------
+// ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206), so these pixels need nothing but their
+// coordinates: no G-buffer reads, and none of the surface code's registers (the general fix-up kernel holds the whole restatement).
+template <int PPT>
+__global__ void __launch_bounds__(256) k_lighting_sky(const LightingArgs a, const SkyArgs sky, const FastArgs f) {
+    // one wave per segment: sky pixels come in large coherent regions, whose segments are full (256 entries = 4 rounds of the wave);
+    // wider work items leave most of the chip idle when the sky is a tenth of the frame
+    const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= f.num_segments) return;
+    const uint32_t count = f.seg_count[f.num_segments + seg];
+    const uint32_t groups_per_row = a.width / PPT;
+    const uint8_t* codes = f.seg_list + (size_t)seg * f.seg_stride + (f.seg_stride - 1u);
+    for (uint32_t i = lane; i < count; i += 64u) {
+        const uint32_t code = *(codes - i);
+        const uint32_t g = seg * 64u + code / PPT;
+        const uint32_t ry = g / groups_per_row;
+        const uint32_t y = a.row_begin + ry, x = (g - ry * groups_per_row) * PPT + code % PPT;
+        Hn lit[4];
+        sky_frag(a, sky, x, y, lit);
+        *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x * 8) = pack_lit(lit);
     }
 }
 
@@ -141,7 +189,7 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
 }
 
 // ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
-template <int SUN, int GI, int PPT>
+template <int SUN, int GI, int PPT, bool RELAXED>
 // (106 VGPRs at 4 px/thread = 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 36-44 bytes per lane and is 12-20 %
 // slower, measured.)
 __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const FastArgs f) {
@@ -188,7 +236,7 @@ __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, con
     const float rowy_slang = (Fn(f.p5) * (ty_s * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
 
     uint32_t out[2 * PPT];
-    uint32_t deferred_mask = 0;
+    uint32_t deferred_mask = 0, sky_mask = 0;
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
         if (!active) break;
@@ -211,10 +259,11 @@ __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, con
             const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]);
             colx_slang = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
         }
-        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
+        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI, RELAXED>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
         out[2 * i] = r.lit.x;
         out[2 * i + 1] = r.lit.y;
         if (r.deferred) deferred_mask |= 1u << i;
+        if (p.depth == 0.f) sky_mask |= 1u << i;
     }
     if (active) {
         uint8_t* dst = const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x0 * 8;
@@ -224,24 +273,28 @@ __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, con
             store_words<2 * PPT>(dst, out);
         }
     }
-    // wave-aggregated append of the deferred pixels: one atomic per wave
-    const uint32_t n_mine = __builtin_popcount(deferred_mask);
-    uint32_t prefix = n_mine;  // inclusive scan over the wave
+    // deferred pixels -> this wave's segment (no atomics: the wave owns it).  Slots by ballot + mbcnt, one bit plane per pixel of
+    // the thread; the order inside a segment is irrelevant.  Sky pixels (depth == 0 with a sky bound: all of them are deferred) fill
+    // the segment from its back — k_lighting_sky shades them from their coordinates alone — everything else from the front.
+    const uint32_t seg = gid >> 6, lane = threadIdx.x & 63u;
+    uint32_t front = 0, back = 0;
+    uint8_t* seg_codes = f.seg_list + (size_t)seg * f.seg_stride;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(prefix, d, 64);
-        if ((int)(threadIdx.x & 63) >= d) prefix += t;
-    }
-    const uint32_t total = __shfl(prefix, 63, 64);
-    if (total) {
-        uint32_t base = 0;
-        if ((threadIdx.x & 63) == 63) base = atomicAdd(&f.state->count[f.parity], total);
-        base = __shfl(base, 63, 64);
-        uint32_t slot = base + prefix - n_mine;
-#pragma unroll
-        for (int i = 0; i < PPT; i++) {
-            if (deferred_mask & (1u << i)) f.list[slot++] = y * a.width + x0 + i;
+    for (int i = 0; i < PPT; i++) {
+        const bool mine = (deferred_mask >> i) & 1u, sky_px = (sky_mask >> i) & 1u;
+        const uint64_t m = __ballot(mine);
+        if (m) {
+            const uint64_t ms = __ballot(mine && sky_px), mg = m & ~ms;
+            const uint32_t before_g = __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, 0u));
+            const uint32_t before_s = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+            if (mine) seg_codes[sky_px ? f.seg_stride - 1u - (back + before_s) : front + before_g] = (uint8_t)(lane * PPT + (uint32_t)i);
+            front += (uint32_t)__builtin_popcountll(mg);
+            back += (uint32_t)__builtin_popcountll(ms);
         }
+    }
+    if (lane == 0 && seg < f.num_segments) {
+        f.seg_count[seg] = (uint16_t)front;
+        f.seg_count[f.num_segments + seg] = (uint16_t)back;
     }
 }
 
@@ -270,10 +323,22 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
                            f.pk_slice_pitch, f.state, f.parity);
     }
     const dim3 grid((uint32_t)((groups + 255) / 256)), block(256);
-    if (ppt == 4) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4>), grid, block, 0, st, a, csm, lpv, f);
-    else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 2>), grid, block, 0, st, a, csm, lpv, f);
-    else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 1>), grid, block, 0, st, a, csm, lpv, f);
-    hipLaunchKernelGGL((k_lighting_fixup<SUN, GI>), dim3(f.fixup_blocks), block, 0, st, a, csm, lpv, sky, f);
+    // tolerance mode: only where the relaxed body differs (fp32 BRDF of the CSM sun, LPV overlay products) and for the 4-pixel layout
+    constexpr bool kHasRelaxed = SUN != SAH_SHADOW_MODE_RT && (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV);
+    if (ppt == 4 && kHasRelaxed && f.tolerance) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4, kHasRelaxed>), grid, block, 0, st, a, csm, lpv, f);
+    else if (ppt == 4) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4, false>), grid, block, 0, st, a, csm, lpv, f);
+    else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 2, false>), grid, block, 0, st, a, csm, lpv, f);
+    else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 1, false>), grid, block, 0, st, a, csm, lpv, f);
+    const dim3 fgrid((f.num_segments + kFixupSegs - 1) / kFixupSegs);
+    if (ppt == 4) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 4>), fgrid, block, 0, st, a, csm, lpv, sky, f);
+    else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 2>), fgrid, block, 0, st, a, csm, lpv, sky, f);
+    else hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 1>), fgrid, block, 0, st, a, csm, lpv, sky, f);
+    if (sky.enabled) {
+        const dim3 sgrid((f.num_segments + 3) / 4);
+        if (ppt == 4) hipLaunchKernelGGL((k_lighting_sky<4>), sgrid, block, 0, st, a, sky, f);
+        else if (ppt == 2) hipLaunchKernelGGL((k_lighting_sky<2>), sgrid, block, 0, st, a, sky, f);
+        else hipLaunchKernelGGL((k_lighting_sky<1>), sgrid, block, 0, st, a, sky, f);
+    }
     return hipGetLastError();
 }
 

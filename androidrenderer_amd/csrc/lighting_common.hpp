@@ -466,7 +466,10 @@ SAH_DEV void sky_frag(const LightingArgs& a, const SkyArgs& k, uint32_t x, uint3
             sun = Fn(1.f);
         } else {
             const Fn offset = Fn(k.min_sun_cos) - cosTheta;
-            const Fn gaussianBloom = cr_exp(-offset * Fn(50000.0f)) * Fn(0.5f);
+            // exp(x) rounds to +0 in fp32 for x <= -104 (below half the smallest denormal), which is every pixel more than a few degrees
+            // from the sun: skip the fp64 exp there (the product with 0.5 is then +0 as well)
+            const Fn ex = -offset * Fn(50000.0f);
+            const Fn gaussianBloom = ex.v <= -110.0f ? Fn(0.0f) : cr_exp(ex) * Fn(0.5f);
             const Fn invBloom = Fn(1.0f) / (Fn(0.02f) + offset * Fn(300.0f)) * Fn(0.01f);
             sun = gaussianBloom + invBloom;
         }

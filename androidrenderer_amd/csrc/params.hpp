@@ -74,7 +74,7 @@ struct SkyArgs {
 // Per-context device state shared by consecutive Lighting calls (double-buffered by call parity so that no memset
 // is needed between calls: the fix-up kernel of call k zeroes the slots call k+1 will use).
 struct FrameState {
-    uint32_t count[2];      // number of deferred pixels in `list`
+    uint32_t unused[2];
     uint32_t nonfinite[2];  // != 0 when an LPV volume holds an inf/NaN texel
 };
 
@@ -89,9 +89,15 @@ struct FastArgs {
     uint32_t pos_div_nr;  // view-space position quotients may use the shared-reciprocal divide (lighting_fast.hpp)
     uint32_t sky_enabled;
     uint32_t parity;
-    uint32_t fixup_blocks;
+    uint32_t tolerance;  // SAH_LIGHTING_TOLERANCE_1ULP: the relaxed body (lighting_relaxed.hpp) where it exists
     FrameState* state;
-    uint32_t* list;  // deferred pixel indices (y * width + x), capacity width * height
+    // Deferred pixels, without atomics: the wave that shades thread groups [64 s, 64 s + 64) owns segment s — kSegSize(PPT) byte codes
+    // (lane * PPT + pixel) at seg_list + s * seg_stride — general pixels from the front, sky pixels (depth == 0) from the back — and
+    // their numbers in seg_count[s] / seg_count[num_segments + s], which it always writes (0 included), so nothing has to be cleared
+    // between calls.  The fix-up and sky kernels walk 16 segments per workgroup.
+    uint8_t* seg_list;
+    uint16_t* seg_count;
+    uint32_t num_segments, seg_stride;
     // LPV gather copy (k_lpv_pack): texel (x,y,z) of the three volumes interleaved as 24 bytes {R[4], G[4], B[4]} (fp16) at
     // ((z+2) * pk_slice_pitch + (y+2) * pk_row_pitch + (x+2) * 24), inside a two-texel border of zeros (= CLAMP_TO_BORDER)
     const uint8_t* lpv_packed;

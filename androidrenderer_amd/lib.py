@@ -21,7 +21,7 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_allgather_rows", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
 
@@ -46,9 +46,12 @@ def load():
     lib.sah_comm_unique_id.argtypes = [C.c_void_p]
     lib.sah_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.sah_sync.argtypes = [C.c_void_p]
+    lib.sah_debug_deferred_pixels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.sah_lighting.argtypes = [C.c_void_p, C.POINTER(_abi.LightingDesc)]
     lib.sah_copy_scene.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     lib.sah_bloom.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
+    lib.sah_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32]
+    lib.sah_bloom_from_mip0.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
     lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
@@ -102,6 +105,12 @@ class Context:
         """Testing hook: run the general kernel instead of the fast one / force pixels-per-thread."""
         self._check(self.lib.sah_debug_set(self.handle, int(force_general), int(force_ppt)))
 
+    def deferred_pixels(self):
+        """Analysis hook: pixels the last fast-path lighting call handed to the fix-up kernel (synchronises)."""
+        n = C.c_uint64()
+        self._check(self.lib.sah_debug_deferred_pixels(self.handle, C.byref(n)))
+        return int(n.value)
+
     def sync(self):
         self._check(self.lib.sah_sync(self.handle))
 
@@ -113,6 +122,12 @@ class Context:
 
     def bloom(self, scene, chain):
         self._check(self.lib.sah_bloom(self.handle, C.byref(scene), C.byref(chain)))
+
+    def bloom_mip0_rows(self, scene, chain, row_begin, row_end):
+        self._check(self.lib.sah_bloom_mip0_rows(self.handle, C.byref(scene), C.byref(chain), row_begin, row_end))
+
+    def bloom_from_mip0(self, scene, chain):
+        self._check(self.lib.sah_bloom_from_mip0(self.handle, C.byref(scene), C.byref(chain)))
 
     def tonemap(self, scene, chain, out, row_begin=0, row_end=0):
         self._check(self.lib.sah_tonemap(self.handle, C.byref(scene), C.byref(chain), C.byref(out), row_begin, row_end))

@@ -102,7 +102,15 @@ def test_4k_probe_gi_chain_shards_and_bands(hip_ctx):
     for r0, r1 in ((0, 270), (270, 1081), (1081, H)):
         hip_ctx.tonemap(ap, mc, images.plane(out_sh, _abi.FORMAT_R8G8B8A8_SRGB), r0, r1)
     torch.cuda.synchronize()
-    assert torch.equal(aa, full), "copy scene at render == output resolution is the identity"
+    # "Copy scene" samples at (x + 0.5) * (1 / W): in fp32 that is not always the texel centre, so the copy is NOT the identity at 3840
+    # columns (it is at the 64 x 36 of the golden fixture) — checked against the oracle's copy of the same device image instead
+    full_np = util.from_torch(full, np.uint16)
+    want_aa = np.zeros_like(full_np)
+    assert util.oracle().orc_copy_scene(C.byref(images.plane(full_np, _abi.FORMAT_R16G16B16A16_SFLOAT)),
+                                        C.byref(images.plane(want_aa, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    got_aa = util.from_torch(aa, np.uint16)
+    assert np.array_equal(got_aa, want_aa), "copy scene differs from the oracle"
+    print(f"copy scene at 4K: {int((got_aa != full_np).any(-1).sum())} of {W * H} texels are not bit copies of lit_scene")
     assert torch.equal(out_sh, out_full), "row-sharded tonemap differs from the unsharded one"
     # the oracle's post chain on a crop is not the same computation (bloom is global): check one band of the composite through the
     # oracle's tonemap fed with the DEVICE pyramid — the composite is then a per-pixel function of identical inputs

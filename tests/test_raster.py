@@ -388,7 +388,9 @@ def test_hip_unsplit_bin_lists_take_several_rounds(monkeypatch):
         want, want_stats = _oracle_gbuffer(arrays, view, 128, 128)
         got, got_stats = _hip_gbuffer(ctx, arrays, view, 128, 128)
         _assert_gbuffers_equal(got, want)
-        assert got_stats[5] == 0 and got_stats[6] == 0 and got_stats[4] > 4 * 256  # nothing was split, lists are several rounds long
+        # [6] counts the tiles whose list is longer than one part, [5] the extra parts actually handed out: none, so those lists were
+        # walked whole, in several rounds
+        assert got_stats[5] == 0 and got_stats[6] >= 1 and got_stats[4] > 4 * 256
         sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
         constants = sun.update_shadow_cascades(view, max_shadow_distance=16.0, resolution=128)
         want_sm, _ = _oracle_shadow(arrays, constants, 4, (128, 128))

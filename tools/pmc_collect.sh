@@ -21,8 +21,8 @@ i=0
 for g in "${GROUPS_[@]}"; do
   d="$OUT/g$i"
   echo "pmc group $i: $g"
-  timeout -k 10 150 rocprofv3 --pmc $g -d "$d" -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 "$@" > "$OUT/g$i.log" 2>&1 \
+  timeout -k 10 150 rocprofv3 --pmc $g -d "$d" -o pmc --output-format csv -- python3 ${PMC_SCRIPT:-bench.py} ${PMC_ARGS:---no-cpu-baseline --steps 5 --warmup 1} "$@" > "$OUT/g$i.log" 2>&1 \
     || echo "group $i ($g) failed: $(tail -2 "$OUT/g$i.log" | tr '\n' ' ')"
   i=$((i+1))
 done
-python3 tools/pmc_summary.py "$OUT" k_lighting
+python3 tools/pmc_summary.py "$OUT" ${PMC_KERNEL:-k_lighting}
