@@ -10,7 +10,8 @@
 #include "post_args.hpp"
 
 namespace sah {
-hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st);
+hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
+                             uint32_t row_end, hipStream_t st);
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                                    uint32_t row_end, hipStream_t st);
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
@@ -65,13 +66,17 @@ bool lpv_vol_ok(const sah_volume* v) {
 
 extern "C" {
 
-int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out) {
+int sah_copy_scene_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!rgba16f_ok(lit) || !rgba16f_ok(out)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "copy_scene needs RGBA16F planes");
+    if (row_begin == 0 && row_end == 0) row_end = out->height;
+    if (row_end > out->height || row_begin > row_end) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad row range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sah::launch_copy_scene(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, ctx->stream));
+    HIP_TRY(ctx, sah::launch_copy_scene(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, row_begin, row_end, ctx->stream));
     return SAH_OK;
 }
+
+int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out) { return sah_copy_scene_rows(ctx, lit, out, 0, 0); }
 
 static int bloom_range(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, uint32_t first_mip, uint32_t last_mip, uint32_t row_begin,
                        uint32_t row_end) {
@@ -306,11 +311,13 @@ int sah_comm_init(sah_ctx* ctx, const void* comm_id) {
 }
 
 void sah_comm_destroy(sah_ctx* ctx) {
-    if (ctx->comm && ctx->rccl) {
+    if (ctx->rccl) {
         auto f = RCCL_SYM(ctx->rccl, ncclCommDestroy);
-        if (f) f((ncclComm_t)ctx->comm);
+        if (f && ctx->comm_reversed) f((ncclComm_t)ctx->comm_reversed);
+        if (f && ctx->comm) f((ncclComm_t)ctx->comm);
     }
     ctx->comm = nullptr;
+    ctx->comm_reversed = nullptr;
 }
 
 int sah_comm_set_stream(sah_ctx* ctx, void* hip_stream) {
@@ -334,17 +341,33 @@ int sah_comm_wait(sah_ctx* ctx) {
     return SAH_OK;
 }
 
-int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank) {
+// `reversed`: the exchange runs on a second communicator in which this process has rank world - 1 - rank (made on first use with
+// ncclCommSplit: same devices, key = reversed rank), so that the in-place slot of rank r is block world - 1 - r.
+static int allgather_bytes_impl(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank, bool reversed) {
     if (!ctx || !buffer) return SAH_ERR_INVALID_ARGUMENT;
     if (bytes_per_rank == 0) return SAH_OK;
     if (!ctx->comm) {
         if (ctx->world == 1) return SAH_OK;  // one rank and no communicator: the buffer already is the gathered result
         return fail(ctx, SAH_ERR_COMM, "context was created without a communicator");
     }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    int slot = ctx->rank;
+    if (reversed) {
+        if (!ctx->comm_reversed) {
+            auto split = RCCL_SYM(ctx->rccl, ncclCommSplit);
+            if (!split) return fail(ctx, SAH_ERR_COMM, "ncclCommSplit not found");
+            ncclComm_t rev = nullptr;
+            const ncclResult_t rc = split((ncclComm_t)ctx->comm, 0, ctx->world - 1 - ctx->rank, &rev, nullptr);
+            if (rc != ncclSuccess || !rev) return fail(ctx, SAH_ERR_COMM, "ncclCommSplit failed: %d", (int)rc);
+            ctx->comm_reversed = rev;
+        }
+        comm = (ncclComm_t)ctx->comm_reversed;
+        slot = ctx->world - 1 - ctx->rank;
+    }
     auto ag = RCCL_SYM(ctx->rccl, ncclAllGather);
     if (!ag) return fail(ctx, SAH_ERR_COMM, "ncclAllGather not found");
-    const uint8_t* send = (const uint8_t*)buffer + (size_t)ctx->rank * bytes_per_rank;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint8_t* send = (const uint8_t*)buffer + (size_t)slot * bytes_per_rank;
     hipStream_t st = ctx->stream;
     const bool side = ctx->comm_stream && ctx->comm_stream != ctx->stream;
     if (side) {  // the gather runs behind everything enqueued so far on the work stream, and beside whatever is enqueued next
@@ -353,7 +376,7 @@ int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank) {
         st = ctx->comm_stream;
     }
     // in place: the send buffer is this rank's slot of the receive buffer
-    const ncclResult_t rc = ag(send, buffer, (size_t)bytes_per_rank, ncclUint8, (ncclComm_t)ctx->comm, st);
+    const ncclResult_t rc = ag(send, buffer, (size_t)bytes_per_rank, ncclUint8, comm, st);
     if (rc != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "ncclAllGather failed: %d", (int)rc);
     if (side) {
         HIP_TRY(ctx, hipEventRecord(ctx->comm_done, ctx->comm_stream));
@@ -362,7 +385,9 @@ int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank) {
     return SAH_OK;
 }
 
-int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows) {
+int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank) { return allgather_bytes_impl(ctx, buffer, bytes_per_rank, false); }
+
+static int allgather_rows_impl(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows, bool reversed) {
     if (!ctx || !image || !image->ptr) return SAH_ERR_INVALID_ARGUMENT;
     const uint64_t slots = (uint64_t)rows_per_rank * ctx->world;
     if (slots < image->height)
@@ -371,7 +396,15 @@ int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_r
     if (slots > allocated_rows)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the allocation holds %u rows, the gather needs %llu equal slots (pad it to rows_per_rank * world)",
                     allocated_rows, (unsigned long long)slots);
-    return sah_allgather_bytes(ctx, image->ptr, (uint64_t)rows_per_rank * image->row_pitch_bytes);
+    return allgather_bytes_impl(ctx, image->ptr, (uint64_t)rows_per_rank * image->row_pitch_bytes, reversed);
+}
+
+int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows) {
+    return allgather_rows_impl(ctx, image, rows_per_rank, allocated_rows, false);
+}
+
+int sah_allgather_rows_reversed(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows) {
+    return allgather_rows_impl(ctx, image, rows_per_rank, allocated_rows, true);
 }
 
 }  // extern "C"

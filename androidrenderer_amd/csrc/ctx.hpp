@@ -16,6 +16,7 @@ struct sah_ctx {
     bool own_stream = false;
     float* luts = nullptr;  // device: 256 sRGB->linear + 256 UNORM8->float
     void* comm = nullptr;   // ncclComm_t
+    void* comm_reversed = nullptr;  // ncclComm_t with rank world - 1 - rank (sah_allgather_rows_reversed), made on first use
     void* rccl = nullptr;   // dlopen handle
     hipStream_t comm_stream = nullptr;  // optional side stream of the exchange step (sah_comm_set_stream); not owned
     hipEvent_t comm_ready = nullptr, comm_done = nullptr;

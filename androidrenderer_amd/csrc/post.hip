@@ -8,9 +8,10 @@
 namespace sah {
 
 // ---- a13 -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_copy_scene(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
+__global__ void __launch_bounds__(256) k_copy_scene(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
+                                                     uint32_t row_end) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= row_end) return;
     const float inv_w = 1.0f / (float)dw, inv_h = 1.0f / (float)dh;
     const float u = ((float)x + 0.5f) * inv_w, v = ((float)y + 0.5f) * inv_h;
     const Rgba t = bilinear<ADDR_REPEAT>(src, sw, sh, u, v);
@@ -143,9 +144,11 @@ hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float v
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------
-hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, hipStream_t st) {
-    const dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    hipLaunchKernelGGL(k_copy_scene, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh);
+hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
+                             uint32_t row_end, hipStream_t st) {
+    if (row_end <= row_begin) return hipSuccess;
+    const dim3 grid((dw + 63) / 64, (row_end - row_begin + 3) / 4);
+    hipLaunchKernelGGL(k_copy_scene, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);
     return hipGetLastError();
 }
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,

@@ -21,9 +21,9 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
-           "sah_lpv_inject_vpls", "sah_allgather_rows", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
+           "sah_lpv_inject_vpls", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
 
 
 def load():
@@ -49,6 +49,7 @@ def load():
     lib.sah_debug_deferred_pixels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.sah_lighting.argtypes = [C.c_void_p, C.POINTER(_abi.LightingDesc)]
     lib.sah_copy_scene.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
+    lib.sah_copy_scene_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_bloom.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
     lib.sah_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32]
     lib.sah_bloom_from_mip0.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
@@ -57,6 +58,7 @@ def load():
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
     lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_allgather_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.sah_allgather_rows_reversed.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_comm_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.sah_comm_wait.argtypes = [C.c_void_p]
     lib.sah_ao_clear.argtypes = [C.c_void_p, C.POINTER(_abi.Plane)]
@@ -117,8 +119,8 @@ class Context:
     def lighting(self, desc):
         self._check(self.lib.sah_lighting(self.handle, C.byref(desc)))
 
-    def copy_scene(self, lit, out):
-        self._check(self.lib.sah_copy_scene(self.handle, C.byref(lit), C.byref(out)))
+    def copy_scene(self, lit, out, row_begin=0, row_end=0):
+        self._check(self.lib.sah_copy_scene_rows(self.handle, C.byref(lit), C.byref(out), row_begin, row_end))
 
     def bloom(self, scene, chain):
         self._check(self.lib.sah_bloom(self.handle, C.byref(scene), C.byref(chain)))
@@ -181,6 +183,10 @@ class Context:
     def allgather_rows(self, image, rows_per_rank, allocated_rows=None):
         """image: _abi.Plane over a buffer of `allocated_rows` (default image.height) rows; in place, on the context's stream."""
         self._check(self.lib.sah_allgather_rows(self.handle, C.byref(image), rows_per_rank, image.height if allocated_rows is None else allocated_rows))
+
+    def allgather_rows_reversed(self, image, rows_per_rank, allocated_rows=None):
+        self._check(self.lib.sah_allgather_rows_reversed(self.handle, C.byref(image), rows_per_rank,
+                                                         image.height if allocated_rows is None else allocated_rows))
 
     def comm_set_stream(self, hip_stream_handle):
         self._check(self.lib.sah_comm_set_stream(self.handle, C.c_void_p(hip_stream_handle)))

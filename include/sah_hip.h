@@ -241,6 +241,8 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* desc);
 
 /* "Copy scene" (AA = None) — RenderCore/render/scene_renderer.cpp:502-527 */
 int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* antialiased);
+/* Rows [row_begin, row_end) of the same copy (0, 0 = all); output row j reads lit rows j - 1 .. j + 1. */
+int sah_copy_scene_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* antialiased, uint32_t row_begin, uint32_t row_end);
 
 /* Bloomer::fill_bloom_tex — RenderCore/render/bloomer.hpp:15, bloomer.cpp:38-262 */
 int sah_bloom(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom);
@@ -425,6 +427,10 @@ int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_r
  * entries of the work stream and sah_comm_wait() is a no-op. */
 int sah_comm_set_stream(sah_ctx* ctx, void* hip_stream);
 int sah_comm_wait(sah_ctx* ctx);
+/* As sah_allgather_rows, with the slots in reversed rank order: rank r owns rows [rows_per_rank*(world-1-r), rows_per_rank*(world-r)).
+ * The final composite samples the scene upside down (scene_upsample.frag / fullscreen.vert: v = 1 - (y + 0.5) / H), so the rank
+ * that shaded scene rows near the top produces output rows near the bottom: shard the scene by rank, gather the RGBA8 rows reversed. */
+int sah_allgather_rows_reversed(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows);
 /* Same exchange on a raw DEVICE buffer of world * bytes_per_rank bytes; rank r owns [r * bytes_per_rank, (r+1) * bytes_per_rank). */
 int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank);
 

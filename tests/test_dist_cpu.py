@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def shard_rows(height, world, rank):
-    """Row block of `rank`: ceil(height / world) rows each, clipped to the image (same rule as bench.py): equal-sized
-    gather slots, the last ones possibly short or empty."""
-    per = -(-height // world)
-    r0 = min(rank * per, height)
-    return r0, min(r0 + per, height)
+    """Row block of `rank` (androidrenderer_amd/shard.py, the rule bench.py uses): ceil(height / world) rows each, clipped to the
+    image: equal-sized gather slots, the last ones possibly short or empty."""
+    sys.path.insert(0, ROOT)
+    from androidrenderer_amd import shard
+    return shard.lighting_rows(height, world, rank)
 
 
 def _worker(rank, world, port, height, out_dir):

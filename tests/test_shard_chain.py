@@ -1,0 +1,194 @@
+"""The sharded full chain (androidrenderer_amd/shard.py, chain.py): rows per rank, two exchanges (bloom mip 0 in rank order, final
+RGBA8 image in reversed rank order), result identical to the unsharded frame.
+CPU: plan properties; world-size-2 gloo run with the oracle as the per-rank compute stand-in, every buffer poisoned outside the
+rows the plan says a rank computes.  GPU: the HIP passes with several ranks emulated on one device (slot copies stand in for the
+gathers), and the real exchange through a one-rank RCCL communicator."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from androidrenderer_amd import _abi, images, shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POISON16 = 0x7E01  # an fp16 NaN: any read of a row nobody computed shows in the result
+
+
+def test_plans_cover_the_frame_and_their_dependencies():
+    for H in (1, 2, 7, 36, 37, 270, 1081, 2160, 4320):
+        for N in (1, 2, 3, 4, 8):
+            plans = [shard.chain_plan(H, N, r) for r in range(N)]
+            outs = sorted(p.out_rows for p in plans)
+            assert sum(b - a for a, b in outs) == H and all(x[1] == y[0] or y[1] == y[0] for x, y in zip(outs, outs[1:]))
+            assert sum(p.mip0_rows[1] - p.mip0_rows[0] for p in plans) == max(1, H // 2)
+            for p in plans:
+                assert p.out_rows == shard._clip(p.out_slot * p.rows_per_rank, (p.out_slot + 1) * p.rows_per_rank, H)
+                for y in range(*p.out_rows):  # composite: scene row H - 1 - y and its neighbours (clamped at the edges)
+                    assert p.aa_rows[0] <= max(H - 2 - y, 0) and min(H - y, H - 1) < p.aa_rows[1]
+                for j in range(*p.mip0_rows):
+                    assert p.aa_rows[0] <= max(2 * j - 2, 0) and min(2 * j + 3, H - 1) < p.aa_rows[1]
+                have = set(range(*p.lit_rows)) | set(range(*p.lit_wrap_rows))
+                for j in range(*p.aa_rows):  # the copy's sampler repeats: row -1 is row H - 1, row H is row 0
+                    assert {(j - 1) % H, j, (j + 1) % H} <= have
+
+
+def _oracle_chain_rank(f, plan, gather_mip0, gather_final):
+    """One rank with the oracle as compute: whole-plane oracle passes, then everything outside the rows the plan assigns to this
+    rank is poisoned before the next stage may read it."""
+    from tests import util
+    o = util.oracle()
+    H, W = f.height, f.width
+    lit = np.full((H, W, 4), POISON16, np.uint16)
+    for rows in (plan.lit_rows, plan.lit_wrap_rows):
+        if rows[1] > rows[0]:
+            f.row_begin, f.row_end = rows
+            lit[rows[0]:rows[1]] = f.run_oracle()[rows[0]:rows[1]]
+    f.row_begin = f.row_end = 0
+    aa = np.zeros_like(lit)
+    assert o.orc_copy_scene(C.byref(images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    aa[:plan.aa_rows[0]] = POISON16
+    aa[plan.aa_rows[1]:] = POISON16
+    sizes = images.bloom_mip_sizes(W, H, 6)
+    q = plan.mip0_rows_per_rank
+    mip0_alloc = np.full((q * plan.world, sizes[0][0], 4), POISON16, np.uint16)
+    mip0 = np.zeros((sizes[0][1], sizes[0][0], 4), np.uint16)
+    assert o.orc_bloom_downsample(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(mip0, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    mip0_alloc[plan.mip0_rows[0]:plan.mip0_rows[1]] = mip0[plan.mip0_rows[0]:plan.mip0_rows[1]]
+    gather_mip0(mip0_alloc, q)
+    mips = [np.ascontiguousarray(mip0_alloc[:sizes[0][1]])] + [np.zeros((mh, mw, 4), np.uint16) for (mw, mh) in sizes[1:]]
+    for m in range(1, 6):
+        assert o.orc_bloom_downsample(C.byref(images.plane(mips[m - 1], _abi.FORMAT_R16G16B16A16_SFLOAT)),
+                                      C.byref(images.plane(mips[m], _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    out_alloc = np.full((plan.rows_per_rank * plan.world, W, 4), 0x5A, np.uint8)
+    out = np.zeros((H, W, 4), np.uint8)
+    if plan.out_rows[1] > plan.out_rows[0]:
+        assert o.orc_tonemap(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips)),
+                             C.byref(images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)), plan.out_rows[0], plan.out_rows[1]) == 0
+        out_alloc[plan.out_rows[0]:plan.out_rows[1]] = out[plan.out_rows[0]:plan.out_rows[1]]
+    gather_final(out_alloc, plan.rows_per_rank)
+    return out_alloc[:H]
+
+
+def _frame(height):
+    from tests import util
+    return util.LightingFrame(96, height, seed=19, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+
+
+def _unsharded_oracle(height):
+    plan = shard.chain_plan(height, 1, 0)
+    return _oracle_chain_rank(_frame(height), plan, lambda a, q: None, lambda a, q: None)
+
+
+def _worker(rank, world, port, height, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = shard.chain_plan(height, world, rank)
+
+    def gather(slot_of_rank):
+        def run(alloc, rows):
+            t = torch.from_numpy(alloc.view(np.uint8).reshape(alloc.shape[0], -1))
+            parts = [t[i * rows:(i + 1) * rows] for i in range(world)]
+            mine = slot_of_rank(rank)
+            got = [torch.empty_like(parts[0]) for _ in range(world)]
+            dist.all_gather(got, parts[mine].clone())
+            for r in range(world):  # rank r's contribution is slot slot_of_rank(r)
+                parts[slot_of_rank(r)].copy_(got[r])
+        return run
+    final = _oracle_chain_rank(_frame(height), plan, gather(lambda r: r), gather(lambda r: world - 1 - r))
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), final)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [54, 37])
+def test_sharded_chain_over_gloo_equals_unsharded(tmp_path, height):
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29700 + (os.getpid() % 1500) + height
+    mp.spawn(_worker, args=(world, port, height, str(tmp_path)), nprocs=world, join=True)
+    ref = _unsharded_oracle(height)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), ref), f"rank {r}: final image differs from the unsharded chain"
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_hip_sharded_chain_with_emulated_ranks(hip_ctx, world):
+    """N ranks on one device, one after the other, each with its own poisoned buffers; the two gathers are slot copies."""
+    import torch
+    from androidrenderer_amd import chain
+    from tests import util
+    W, H = 256, 150
+    f = util.LightingFrame(W, H, seed=23, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    dev = f.device_arrays()
+    ref = chain.ShardedChain(hip_ctx, f, dev, 0, 1)
+    ref.step(gather=False)
+    torch.cuda.synchronize()
+    want = ref.out.cpu().numpy()
+    ranks = [chain.ShardedChain(hip_ctx, f, dev, r, world) for r in range(world)]
+    for c in ranks:
+        for t in (c.lit, c.aa, c.mip0_alloc):
+            t.fill_(POISON16)
+        c.out_alloc.fill_(0x5A)
+        c.lighting()
+        c.reduce()
+    for c in ranks:  # exchange 1: rank r's slot r of mip 0 goes to everybody
+        q = c.plan.mip0_rows_per_rank
+        for src in ranks:
+            c.mip0_alloc[src.plan.rank * q:(src.plan.rank + 1) * q] = src.mip0_alloc[src.plan.rank * q:(src.plan.rank + 1) * q]
+    for c in ranks:
+        c.composite()
+    for c in ranks:  # exchange 2: rank r's slot world - 1 - r of the final image
+        per = c.plan.rows_per_rank
+        for src in ranks:
+            s = src.plan.out_slot
+            c.out_alloc[s * per:(s + 1) * per] = src.out_alloc[s * per:(s + 1) * per]
+    torch.cuda.synchronize()
+    for c in ranks:
+        assert np.array_equal(c.out.cpu().numpy(), want), f"rank {c.plan.rank} of {world}: final image differs from the unsharded chain"
+
+
+@pytest.mark.gpu
+def test_hip_chain_through_a_one_rank_communicator():
+    """The real exchange entry points (ncclAllGather on the communicator and on its reversed split) in the chain's order."""
+    import torch
+    from androidrenderer_amd import chain, lib
+    from tests import util
+    ctx = lib.Context(device=0, rank=0, world=1, comm_id=lib.comm_unique_id())
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    try:
+        f = util.LightingFrame(200, 117, seed=29, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_CACHE, flavour="atrium")
+        dev = f.device_arrays()
+        plain = chain.ShardedChain(ctx, f, dev, 0, 1)
+        plain.step(gather=False)
+        torch.cuda.synchronize()
+        want = plain.out.cpu().numpy()
+        ctx.comm_set_stream(side.cuda_stream)
+        c = chain.ShardedChain(ctx, f, dev, 0, 1)
+        c.step(gather=True)
+        ctx.comm_wait()
+        torch.cuda.synchronize()
+        assert np.array_equal(c.out.cpu().numpy(), want)
+        # and against the oracle's unsharded chain
+        o = util.oracle()
+        lit = f.run_oracle()
+        aa = np.zeros_like(lit)
+        assert o.orc_copy_scene(C.byref(images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+        mips = [np.zeros((mh, mw, 4), np.uint16) for (mw, mh) in images.bloom_mip_sizes(200, 117, 6)]
+        assert o.orc_bloom(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips))) == 0
+        out = np.zeros((117, 200, 4), np.uint8)
+        assert o.orc_tonemap(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips)),
+                             C.byref(images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)), 0, 0) == 0
+        assert np.array_equal(want, out)
+    finally:
+        torch.cuda.synchronize()
+        ctx.close()
