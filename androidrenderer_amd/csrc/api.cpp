@@ -2,6 +2,7 @@
 // kernel launches on the context's HIP stream.  Compiled by hipcc with -ffp-contract=off: the fp32 expressions
 // evaluated here are the uniform sub-expressions of the reference shaders and must round exactly as the
 // per-pixel code would.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -125,6 +126,20 @@ bool detect_fast_path(const sah_lighting_desc* d, uint32_t sun_mode, uint32_t gi
 }
 
 }  // namespace
+
+void SahRange::resolve(push_fn& push, pop_fn& pop) {
+    const char* on = getenv("SAH_ROCTX");
+    if (!on || atoi(on) == 0) return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        push = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+    }
+}
 
 extern "C" {
 
@@ -254,6 +269,7 @@ int sah_sync(sah_ctx* ctx) {
 }
 
 int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
+    SAH_RANGE();
     using namespace sah;
     if (!ctx || !d) return SAH_ERR_INVALID_ARGUMENT;
     if (!d->gbuffer || !d->lit || !d->view) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "gbuffer, lit and view are required");

@@ -67,6 +67,7 @@ bool lpv_vol_ok(const sah_volume* v) {
 extern "C" {
 
 int sah_copy_scene_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!rgba16f_ok(lit) || !rgba16f_ok(out)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "copy_scene needs RGBA16F planes");
     if (row_begin == 0 && row_end == 0) row_end = out->height;
@@ -95,12 +96,14 @@ static int bloom_range(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain*
 }
 
 int sah_bloom(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!bloom || bloom->num_mips == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips", SAH_MAX_BLOOM_MIPS);
     return bloom_range(ctx, scene, bloom, 0, bloom->num_mips - 1, 0, bloom->mips[0].height);
 }
 
 int sah_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, uint32_t row_begin, uint32_t row_end) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!bloom || bloom->num_mips == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips", SAH_MAX_BLOOM_MIPS);
     if (row_end > bloom->mips[0].height || row_begin > row_end) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad mip 0 row range");
@@ -108,6 +111,7 @@ int sah_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain
 }
 
 int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!bloom || bloom->num_mips == 0) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips", SAH_MAX_BLOOM_MIPS);
     if (bloom->num_mips == 1) return SAH_OK;
@@ -115,6 +119,7 @@ int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain
 }
 
 int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!rgba16f_ok(scene) || !bloom || bloom->num_mips > SAH_MAX_BLOOM_MIPS || !out || !out->ptr)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "tonemap needs scene, bloom chain and output");
@@ -156,6 +161,7 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom,
 
 int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, const sah_volume* blue, const sah_volume* geometry,
                   uint32_t num_cascades) {
+    SAH_RANGE();
     if (!ctx || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
     const sah_volume* in[4] = {red, green, blue, geometry};
     sah::VolumeArg v[4];
@@ -172,6 +178,7 @@ int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, 
 }
 
 int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades, uint32_t steps) {
+    SAH_RANGE();
     if (!ctx || !a_rgb || !b_rgb || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
     sah::VolumeArg a[3], b[3];
     for (int i = 0; i < 3; i++) {
@@ -192,6 +199,7 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
 
 int sah_sky_update_luts(sah_ctx* ctx, const sah_plane* transmittance, const sah_plane* multiscattering, const sah_plane* sky_view,
                         const float light_vector[3]) {
+    SAH_RANGE();
     if (!ctx || !light_vector) return SAH_ERR_INVALID_ARGUMENT;
     auto ok = [](const sah_plane* p, uint32_t w, uint32_t h) { return rgba16f_ok(p) && p->width == w && p->height == h; };
     if (!ok(transmittance, 256, 64) || !ok(multiscattering, 32, 32) || !ok(sky_view, 200, 200))
@@ -202,6 +210,7 @@ int sah_sky_update_luts(sah_ctx* ctx, const sah_plane* transmittance, const sah_
 }
 
 int sah_ao_clear(sah_ctx* ctx, const sah_plane* ao) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!ao || !ao->ptr || ao->format != SAH_FORMAT_R32_SFLOAT || !ao->width || !ao->height || (uint64_t)ao->row_pitch_bytes < (uint64_t)ao->width * 4 ||
         ((uintptr_t)ao->ptr % 4) || (ao->row_pitch_bytes % 4))
@@ -236,6 +245,7 @@ static int probe_atlases_args(sah_ctx* ctx, const sah_probe_atlases* a, sah::Pro
 }
 
 int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_atlases* dst, const float cascade_movement[4][3]) {
+    SAH_RANGE();
     if (!ctx || !cascade_movement) return SAH_ERR_INVALID_ARGUMENT;
     sah::ProbeAtlasArgs s, d;
     int rc = probe_atlases_args(ctx, src, &s);
@@ -252,6 +262,7 @@ int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_a
 
 int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_volume* trace_results, const uint32_t* probes_to_update,
                      uint32_t num_probes) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     sah::ProbeAtlasArgs a;
     const int rc = probe_atlases_args(ctx, atlases, &a);
@@ -400,10 +411,12 @@ static int allgather_rows_impl(sah_ctx* ctx, const sah_plane* image, uint32_t ro
 }
 
 int sah_allgather_rows(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows) {
+    SAH_RANGE();
     return allgather_rows_impl(ctx, image, rows_per_rank, allocated_rows, false);
 }
 
 int sah_allgather_rows_reversed(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows) {
+    SAH_RANGE();
     return allgather_rows_impl(ctx, image, rows_per_rank, allocated_rows, true);
 }
 

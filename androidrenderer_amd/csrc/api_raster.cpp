@@ -169,6 +169,7 @@ extern "C" {
 
 int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_light_constants* sun, uint32_t num_cascades,
                       const sah_volume* shadowmap, uint32_t* stats) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!geometry_ok(scene, false) || !sun || num_cascades == 0 || num_cascades > 4) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadow_render: bad scene or cascade count");
     if (!shadowmap || !shadowmap->ptr || shadowmap->format != SAH_FORMAT_D16_UNORM) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "shadow_render: the shadow map must be D16_UNORM");
@@ -192,6 +193,7 @@ int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_s
 }
 
 int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_view_data* view, const sah_gbuffer* out, uint32_t* stats) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!geometry_ok(scene, true) || !view || !out) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "gbuffer_render: bad scene, view or targets");
     const uint32_t W = out->depth.width, H = out->depth.height;
@@ -227,6 +229,7 @@ int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_
 
 int sah_rsm_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_light_constants* sun, const sah_lpv_cascade_matrices* cascades,
                    uint32_t num_cascades, const sah_rsm_targets* rsm, uint32_t* stats) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!geometry_ok(scene, true) || !sun || !cascades || !rsm || num_cascades == 0 || num_cascades > 4)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rsm_render: bad scene, sun, cascades or targets");
@@ -262,6 +265,7 @@ int sah_rsm_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_
 
 int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv_cascade_matrices* cascades, uint32_t cascade_index,
                          float grid_cell_size, sah_packed_vpl* vpl_list, uint32_t* vpl_count) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!rsm || !cascades || !vpl_list || !vpl_count || cascade_index >= 4) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "lpv_extract_vpls: null argument or cascade index");
     const uint32_t res = rsm->depth.width;
@@ -281,6 +285,7 @@ int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv
 
 int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint32_t* vpl_count, uint32_t capacity, const sah_lpv_cascade_matrices* cascades,
                         uint32_t cascade_index, uint32_t num_cascades, const sah_volume rgb[3]) {
+    SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!vpl_list || !vpl_count || !cascades || !rgb || num_cascades == 0 || num_cascades > 4 || cascade_index >= num_cascades)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "lpv_inject_vpls: null argument or cascade index");

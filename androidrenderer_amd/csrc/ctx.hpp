@@ -42,6 +42,31 @@ struct sah_ctx {
     std::string last_error;
 };
 
+// roctx range around every C-ABI entry point (the equivalent of the Tracy zones the reference puts around every pass,
+// RenderCore/render/backend/render_graph.cpp:102-103,188): `rocprofv3 --marker-trace` then shows the pass structure of a frame.
+// Opt-in (SAH_ROCTX=1): the marker library is loaded at first use and nothing is linked against it.
+struct SahRange {
+    using push_fn = int (*)(const char*);
+    using pop_fn = int (*)();
+    static void resolve(push_fn& push, pop_fn& pop);
+    explicit SahRange(const char* name) {
+        static push_fn push = nullptr;
+        static pop_fn pop_ = nullptr;
+        static bool tried = false;
+        if (!tried) {
+            tried = true;
+            resolve(push, pop_);
+        }
+        pop = pop_;
+        if (push) push(name);
+    }
+    ~SahRange() {
+        if (pop) pop();
+    }
+    pop_fn pop = nullptr;
+};
+#define SAH_RANGE() SahRange sah_range_(__func__)
+
 inline int fail(sah_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;

@@ -32,10 +32,32 @@ namespace sah {
 // ---- resources (RenderCore/render/backend/handles.hpp:3-5, resource_allocator.hpp) ---------------------------------
 struct Texture {
     std::string name;
-    sah_volume desc{};  // depth == 1 for plain 2D textures
+    sah_volume desc{};      // depth == 1 for plain 2D textures
+    sah_mipchain mips{};    // num_mips > 0: a mipped 2D texture (the bloom chain, bloomer.cpp:268-285); desc describes mip 0
     sah_plane plane() const { return sah_plane{desc.ptr, desc.width, desc.height, desc.row_pitch_bytes, desc.format}; }
 };
 using TextureHandle = Texture*;
+// A buffer is host-visible uniform data here (the view and sun UBOs): the C ABI takes those blocks as host pointers
+struct Buffer {
+    std::string name;
+    const void* data = nullptr;
+    size_t size = 0;
+};
+using BufferHandle = const Buffer*;
+
+// RenderCore/render/backend/texture_usage_token.hpp:9-19, buffer_usage_token.hpp: what a pass declares it touches.  The HIP path is
+// ordered by its one stream, so the tokens are recorded (tests read them back) but no barrier comes out of them.
+struct TextureUsageToken {
+    TextureHandle texture = nullptr;
+    uint64_t stage = 0, access = 0;
+    uint32_t layout = 0;
+};
+struct BufferUsageToken {
+    BufferHandle buffer = nullptr;
+    uint64_t stage = 0, access = 0;
+};
+using TextureUsageList = std::vector<TextureUsageToken>;
+using BufferUsageList = std::vector<BufferUsageToken>;
 
 inline uint32_t format_bytes(uint32_t f) {
     switch (f) {
@@ -86,7 +108,15 @@ struct GBuffer {
     TextureHandle color = nullptr, normals = nullptr, data = nullptr, emission = nullptr, depth = nullptr;
 };
 
-// ---- backend + immediate render graph (RenderCore/render/backend/render_graph.hpp:24-106) --------------------------
+// RenderCore/render/noise_texture.hpp:11-22 (the spatio-temporal blue noise layers; the PNGs are not in the reference tree)
+struct NoiseTexture {
+    std::vector<TextureHandle> layers;
+    uint32_t resolution[2] = {0, 0};
+    uint32_t num_layers = 0;
+    TextureHandle get_layer(uint32_t index) const { return layers.empty() ? nullptr : layers[index % (uint32_t)layers.size()]; }
+};
+
+// ---- backend + immediate render graph (RenderCore/render/backend/render_graph.hpp:24-106, render_pass.hpp:27-130) ----------
 class RenderBackend {
 public:
     explicit RenderBackend(int device = 0) {
@@ -102,30 +132,168 @@ private:
     ResourceAllocator allocator;
 };
 
-struct ComputePass {
-    std::string name;
-    std::function<int(sah_ctx*)> execute;  // returns a sah_status
+// RenderCore/render/backend/command_buffer.hpp:48-275, reduced to what the hot path records.  In the reference the sub-passes of
+// the "Lighting" render pass are draws that blend into lit_scene one after the other; here they are fused into ONE sah_lighting
+// call, so each of them records its part of the sah_lighting_desc into the command buffer (what it would have bound) and the
+// phase submits the descriptor once at the end (LightingPhase::render).
+class CommandBuffer {
+public:
+    explicit CommandBuffer(sah_ctx* ctx_in) : ctx(ctx_in) {}
+    sah_ctx* get_context() const { return ctx; }
+    void begin_label(const std::string&) {}
+    void end_label() {}
+    // status of the sah_* calls made while recording: a failing call is logged and the frame goes on, which is how the reference
+    // treats pipeline failures (pipeline_cache.cpp:166-170)
+    void check(int rc, const std::string& what = "") {
+        if (rc != SAH_OK) errors.push_back((what.empty() ? current_pass : what) + ": " + sah_status_string(rc) + " (" + sah_last_error(ctx) + ")");
+    }
+    std::vector<std::string> errors;
+    std::string current_pass;
+
+    // the Lighting pass being assembled
+    struct LightingRecording {
+        bool open = false;
+        sah_gbuffer gbuffer{};
+        sah_plane lit{}, ao{}, shadow_mask{};
+        sah_volume shadowmap{};
+        sah_gi gi{};
+        sah_sky_luts sky{};
+        const sah_view_data* view = nullptr;
+        const sah_sun_light_constants* sun = nullptr;
+        bool has_ao = false, has_mask = false, has_shadowmap = false, has_gi = false, has_sky = false;
+        uint32_t flags = SAH_LIGHTING_DEFAULT_FLAGS;
+    } lighting;
+    void submit_lighting() {
+        if (!lighting.open) return;
+        sah_lighting_desc d{};
+        d.gbuffer = &lighting.gbuffer;
+        d.lit = &lighting.lit;
+        d.view = lighting.view;
+        d.sun = lighting.sun;
+        if (lighting.has_ao) d.ao = &lighting.ao;
+        if (lighting.has_mask) d.shadow_mask = &lighting.shadow_mask;
+        if (lighting.has_shadowmap) d.shadowmap = &lighting.shadowmap;
+        if (lighting.has_gi) d.gi = &lighting.gi;
+        if (lighting.has_sky) d.sky = &lighting.sky;
+        d.flags = lighting.flags;
+        check(sah_lighting(ctx, &d), "Lighting");
+        lighting = LightingRecording{};
+    }
+
+private:
+    sah_ctx* ctx;
 };
 
-// Passes execute immediately, in the order they are added (render_graph.cpp:85-111); a failing pass is logged and the
-// frame continues, which is how the reference treats pipeline failures (pipeline_cache.cpp:166-170).
+// render_pass.hpp:27-43
+struct ComputePass {
+    std::string name;
+    TextureUsageList textures;
+    BufferUsageList buffers;
+    std::function<void(CommandBuffer&)> execute;
+};
+// A "compute shader" of this backend: what PipelineCache::create_pipeline(path) returns in the reference (pipeline_cache.hpp:23) is a
+// handle to a SPIR-V pipeline; here it is a handle to a launcher over the C ABI (push constants, workgroup counts)
+struct ComputePipeline {
+    std::string name;
+    std::function<int(sah_ctx*, const void* push_constants, const uint32_t num_workgroups[3])> launch;
+};
+using ComputePipelineHandle = const ComputePipeline*;
+// render_pass.hpp:48-79
+template <typename PushConstantsType = uint32_t> struct ComputeDispatch {
+    std::string name;
+    BufferUsageList buffers;
+    PushConstantsType push_constants{};
+    uint32_t num_workgroups[3] = {1, 1, 1};
+    ComputePipelineHandle compute_shader = nullptr;
+};
+// render_pass.hpp (RenderingAttachmentInfo / DynamicRenderingPass): load_op 1 = VK_ATTACHMENT_LOAD_OP_CLEAR
+struct RenderingAttachmentInfo {
+    TextureHandle image = nullptr;
+    uint32_t load_op = 0;
+};
+struct DynamicRenderingPass {
+    std::string name;
+    TextureUsageList textures;
+    BufferUsageList buffers;
+    std::vector<RenderingAttachmentInfo> color_attachments;
+    std::function<void(CommandBuffer&)> execute;
+};
+struct TransitionPass {
+    TextureUsageList textures;
+    BufferUsageList buffers;
+};
+struct ImageCopyPass {
+    std::string name;
+    TextureHandle dst = nullptr, src = nullptr;
+};
+// A pass written as "status = one sah_* call": the form most passes of this file take
+template <class F> ComputePass hip_pass(std::string name, F fn) {
+    ComputePass p;
+    p.name = std::move(name);
+    p.execute = [fn](CommandBuffer& commands) { commands.check(fn(commands.get_context())); };
+    return p;
+}
+
+// Passes execute immediately, in the order they are added (render_graph.cpp:85-111,113-222): the graph owns one command buffer and
+// hands it to every pass.
 class RenderGraph {
 public:
-    explicit RenderGraph(RenderBackend& backend_in) : backend(backend_in) {}
+    explicit RenderGraph(RenderBackend& backend_in) : backend(backend_in), cmds(backend_in.get_context()) {}
+    void add_transition_pass(const TransitionPass& pass) { record_usages(pass.textures, pass.buffers); }  // one stream: ordering is implicit
+    void add_copy_pass(const ImageCopyPass& pass) {  // mip 0 of one image to mip 0 of the other (render_graph.hpp:41-44)
+        cmds.current_pass = pass.name;
+        const sah_volume &d = pass.dst->desc, &s = pass.src->desc;
+        if (d.width != s.width || d.height != s.height || d.format != s.format) {
+            cmds.errors.push_back(pass.name + ": image copy needs matching extents and formats");
+            return;
+        }
+        // the context's stream is not visible through the C ABI: synchronise, then copy on the null stream
+        cmds.check(sah_sync(backend.get_context()));
+        if (hipMemcpy2D(d.ptr, d.row_pitch_bytes, s.ptr, s.row_pitch_bytes, (size_t)s.width * format_bytes(s.format), (size_t)s.height * s.depth,
+                        hipMemcpyDeviceToDevice) != hipSuccess)
+            cmds.errors.push_back(pass.name + ": hipMemcpy2D failed");
+    }
     void add_pass(ComputePass pass) {
-        const int rc = pass.execute(backend.get_context());
-        if (rc != SAH_OK) errors.push_back(pass.name + ": " + sah_status_string(rc) + " (" + sah_last_error(backend.get_context()) + ")");
+        cmds.current_pass = pass.name;
+        record_usages(pass.textures, pass.buffers);
+        if (pass.execute) pass.execute(cmds);
+        num_passes++;
+    }
+    template <typename PushConstantsType = uint32_t> void add_compute_dispatch(const ComputeDispatch<PushConstantsType>& dispatch_info) {
+        cmds.current_pass = dispatch_info.name;
+        record_usages({}, dispatch_info.buffers);
+        if (!dispatch_info.compute_shader) {
+            cmds.errors.push_back(dispatch_info.name + ": null compute shader");  // the reference logs a null pipeline and goes on
+            return;
+        }
+        cmds.check(dispatch_info.compute_shader->launch(backend.get_context(), &dispatch_info.push_constants, dispatch_info.num_workgroups));
+        num_passes++;
+    }
+    void add_render_pass(DynamicRenderingPass pass) {
+        cmds.current_pass = pass.name;
+        record_usages(pass.textures, pass.buffers);
+        if (pass.execute) pass.execute(cmds);
+        num_passes++;
     }
     void begin_label(const std::string&) {}
     void end_label() {}
     void finish() {
-        if (int rc = sah_sync(backend.get_context()); rc != SAH_OK) errors.push_back(std::string("finish: ") + sah_status_string(rc));
+        if (int rc = sah_sync(backend.get_context()); rc != SAH_OK) cmds.errors.push_back(std::string("finish: ") + sah_status_string(rc));
     }
-    const std::vector<std::string>& get_errors() const { return errors; }
+    const std::vector<std::string>& get_errors() const { return cmds.errors; }
+    const TextureUsageList& get_texture_usages() const { return texture_usages; }
+    uint32_t get_num_passes() const { return num_passes; }
 
 private:
+    void record_usages(const TextureUsageList& textures, const BufferUsageList& buffers) {
+        texture_usages.insert(texture_usages.end(), textures.begin(), textures.end());
+        buffer_usages.insert(buffer_usages.end(), buffers.begin(), buffers.end());
+    }
     RenderBackend& backend;
-    std::vector<std::string> errors;
+    CommandBuffer cmds;
+    TextureUsageList texture_usages;
+    BufferUsageList buffer_usages;
+    uint32_t num_passes = 0;
 };
 
 // ---- small column-major matrix helpers (glm stand-ins; inputs to the path, SURVEY §8 "types") -------------------------
@@ -200,6 +368,9 @@ inline Mat4 look_at(Vec3 eye, Vec3 center, Vec3 up) {  // glm::lookAt, right-han
 // ---- SceneView (RenderCore/render/scene_view.cpp:13-27,138-187) --------------------------------------------------------
 class SceneView {
 public:
+    SceneView() = default;
+    SceneView(const SceneView&) = delete;  // `buffer` points at this object's gpu_data
+    SceneView& operator=(const SceneView&) = delete;
     void set_render_resolution(uint32_t w, uint32_t h) { gpu_data.render_resolution[0] = (float)w; gpu_data.render_resolution[1] = (float)h; }
     void set_position(Vec3 p) { position = p; }
     void rotate(float delta_pitch, float delta_yaw) { pitch += delta_pitch; yaw += delta_yaw; }
@@ -210,6 +381,7 @@ public:
     float get_aspect_ratio() const { return aspect; }
     float get_near() const { return near_value; }
     const sah_view_data& get_gpu_data() const { return gpu_data; }
+    BufferHandle get_buffer() const { return &buffer; }  // scene_view.hpp: the ViewDataGPU uniform buffer
     void update_transforms() {
         forward = {std::cos(pitch) * std::sin(yaw), std::sin(pitch), std::cos(pitch) * std::cos(yaw)};
         const float half_pi = 3.14159265358979f / 2.0f;
@@ -233,6 +405,7 @@ private:
     float fov = 75.f, aspect = 16.f / 9.f, near_value = 0.05f, pitch = 0.f, yaw = 0.f;
     Vec3 position{}, forward{};
     sah_view_data gpu_data{};
+    Buffer buffer{"view data", &gpu_data, sizeof(sah_view_data)};
 };
 
 // ---- DirectionalLight (RenderCore/render/directional_light.cpp:232-260, render_scene.cpp:25-27) ------------------------
@@ -297,10 +470,36 @@ public:
     // directional_light.cpp:286-327: the "Sun shadow" pass — every primitive into every cascade layer, depth only
     void render_shadows(RenderGraph& graph, const sah_scene_geometry& geometry, uint32_t num_cascades = 4) const {
         if (get_shadow_mode() != SunShadowMode::CascadedShadowMaps || !shadowmap_handle) return;
-        graph.add_pass({"Sun shadow", [this, &geometry, num_cascades](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("Sun shadow", [this, &geometry, num_cascades](sah_ctx* ctx) {
                             return sah_shadow_render(ctx, &geometry, &constants, num_cascades, &shadowmap_handle->desc, nullptr);
-                        }});
+                        }));
     }
+    // directional_light.cpp:329-370: the CSM-mode sun draw inside the Lighting pass — here: what it binds goes into the recording
+    void render(CommandBuffer& commands, const SceneView& view) const {
+        (void)view;
+        commands.lighting.sun = &constants;
+        if (shadowmap_handle) {
+            commands.lighting.shadowmap = shadowmap_handle->desc;
+            commands.lighting.has_shadowmap = true;
+        }
+    }
+    // directional_light.cpp:372-422: the RT-mode sun dispatch after the Lighting pass.  The ray query itself stays with the renderer and
+    // leaves its visibility fraction in `shadow_mask`; the shading joins the fused Lighting call.
+    void raytrace(RenderGraph& graph, const SceneView& view, const GBuffer& gbuffer, const struct RenderScene& scene, TextureHandle lit_scene,
+                  const NoiseTexture& noise) const {
+        (void)view; (void)gbuffer; (void)scene; (void)lit_scene; (void)noise;
+        ComputePass pass;
+        pass.name = "Raytraced sun (recorded into the Lighting call)";
+        pass.execute = [this](CommandBuffer& commands) {
+            commands.lighting.sun = &constants;
+            if (shadow_mask) {
+                commands.lighting.shadow_mask = shadow_mask->plane();
+                commands.lighting.has_mask = true;
+            }
+        };
+        graph.add_pass(std::move(pass));
+    }
+    BufferHandle get_constant_buffer() const { return &buffer; }
     void set_shadow_mode(SunShadowMode m) { constants.shadow_mode = (uint32_t)m; }
     SunShadowMode get_shadow_mode() const { return (SunShadowMode)constants.shadow_mode; }
     sah_sun_light_constants& get_constants() { return constants; }
@@ -308,8 +507,12 @@ public:
     TextureHandle shadowmap_handle = nullptr;  // D16 array, CSM mode
     TextureHandle shadow_mask = nullptr;       // RT mode: visibility fraction written by the (external) ray query
 
+    DirectionalLight(const DirectionalLight&) = delete;  // `buffer` points at this object's constants
+    DirectionalLight& operator=(const DirectionalLight&) = delete;
+
 private:
     sah_sun_light_constants constants{};
+    Buffer buffer{"sun constants", &constants, sizeof(sah_sun_light_constants)};
 };
 
 // RenderCore/render/procedural_sky.{hpp,cpp}: LUT allocation :31-60, update_sky_luts :75-149; the sky fill reads two of the LUTs
@@ -320,11 +523,19 @@ struct ProceduralSky {
         multiscattering_lut = alloc.create_texture("Multiscattering LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 32, 32);
         sky_view_lut = alloc.create_texture("Sky view LUT", SAH_FORMAT_R16G16B16A16_SFLOAT, 200, 200);
     }
+    // procedural_sky.cpp:151-172: the sky fill inside the Lighting pass (depth == 0 pixels)
+    void render_sky(CommandBuffer& commands, BufferHandle view_buffer, BufferHandle sun_buffer, TextureHandle depth_buffer) const {
+        (void)view_buffer; (void)depth_buffer;
+        if (!sky_view_lut || !transmittance_lut) return;
+        commands.lighting.sky = sah_sky_luts{transmittance_lut->plane(), sky_view_lut->plane()};
+        commands.lighting.has_sky = true;
+        if (sun_buffer && sun_buffer->data && !commands.lighting.sun) commands.lighting.sun = static_cast<const sah_sun_light_constants*>(sun_buffer->data);
+    }
     void update_sky_luts(RenderGraph& graph, const Vec3& light_vector) const {
-        graph.add_pass({"Update sky LUTs", [this, light_vector](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("Update sky LUTs", [this, light_vector](sah_ctx* ctx) {
                             const sah_plane t = transmittance_lut->plane(), m = multiscattering_lut->plane(), s = sky_view_lut->plane();
                             return sah_sky_update_luts(ctx, &t, &m, &s, light_vector.data());
-                        }});
+                        }));
     }
 };
 
@@ -336,15 +547,20 @@ struct RenderScene {  // the slice of RenderCore/render/render_scene.hpp the hot
     ProceduralSky& get_sky() { return sky; }
 };
 
-// ---- GI plugin seam (RenderCore/render/gi/global_illuminator.hpp:18-45) ------------------------------------------------
+// ---- GI plugin seam (RenderCore/render/gi/global_illuminator.hpp:18-45): the five methods, with the reference's signatures --------
 class IGlobalIlluminator {
 public:
     virtual ~IGlobalIlluminator() = default;
     virtual void pre_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, TextureHandle noise_tex) = 0;
     virtual void post_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, const GBuffer& gbuffer, TextureHandle noise_tex) = 0;
-    // Stands in for render_to_lit_scene(): describes what the overlay binds; the Lighting pass draws it.
-    virtual void render_to_lit_scene(sah_gi& gi, TextureHandle ao_tex, TextureHandle noise_tex) const = 0;
+    virtual void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList& buffers) const = 0;
+    // Runs inside the Lighting pass with the G-buffer already bound (lighting_phase.cpp:109,116).  The overlay of the reference binds
+    // its descriptor set and draws a fullscreen triangle; here it records the same bindings into the fused Lighting call.
+    virtual void render_to_lit_scene(CommandBuffer& commands, BufferHandle view_buffer, TextureHandle ao_tex, TextureHandle noise_tex) const = 0;
+    virtual void draw_debug_overlays(RenderGraph& graph, const SceneView& view, const GBuffer& gbuffer, TextureHandle lit_scene_texture) = 0;
 };
+constexpr uint64_t kStageFragmentShader = 0x80ull, kAccessShaderRead = 0x20ull;  // VK_PIPELINE_STAGE_2_FRAGMENT_SHADER_BIT, VK_ACCESS_2_SHADER_READ_BIT
+constexpr uint32_t kLayoutShaderReadOnly = 5;                                    // VK_IMAGE_LAYOUT_SHADER_READ_ONLY_OPTIMAL
 
 // RenderCore/render/gi/light_propagation_volume.{hpp,cpp}: volumes :321-378, cascades :455-546, clear :839-926,
 // propagate :970-1063, overlay :274-306, RSM + VPL extraction + injection :548-760.
@@ -370,19 +586,19 @@ public:
     LightPropagationVolume& operator=(const LightPropagationVolume&) = delete;
     // light_propagation_volume.cpp:548-697: render the RSM of every cascade, extract the VPLs, add them to the A volumes
     void inject_indirect_sun_light(RenderGraph& graph, const RenderScene& scene) {
-        graph.add_pass({"Render RSM", [this, &scene](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("Render RSM", [this, &scene](sah_ctx* ctx) {
                             const sah_rsm_targets rsm = {rsm_flux->desc, rsm_normals->desc, rsm_depth->desc};
                             return sah_rsm_render(ctx, &scene.geometry, &scene.sun.get_constants(), cascades.data(), num_cascades, &rsm, nullptr);
-                        }});
+                        }));
         for (uint32_t c = 0; c < num_cascades; c++)
-            graph.add_pass({"Extract and inject VPLs", [this, c](sah_ctx* ctx) {
+            graph.add_pass(hip_pass("Extract and inject VPLs", [this, c](sah_ctx* ctx) {
                                 const sah_rsm_targets rsm = {rsm_flux->desc, rsm_normals->desc, rsm_depth->desc};
                                 const uint32_t num_vpls = rsm_resolution * rsm_resolution / 4;
                                 sah_packed_vpl* list = vpl_lists + (size_t)c * num_vpls;
                                 if (int rc = sah_lpv_extract_vpls(ctx, &rsm, cascades.data(), c, 0.25f, list, vpl_counts + c); rc != SAH_OK) return rc;
                                 const sah_volume a[3] = {vol[0]->desc, vol[1]->desc, vol[2]->desc};
                                 return sah_lpv_inject_vpls(ctx, list, vpl_counts + c, num_vpls, cascades.data(), c, num_cascades, a);
-                            }});
+                            }));
     }
     void update_cascade_transforms(const SceneView& view, const DirectionalLight& light) {
         const auto& dir = light.get_constants().direction_and_tan_size;
@@ -410,23 +626,36 @@ public:
         }
     }
     void pre_render(RenderGraph& graph, const SceneView&, const RenderScene&, TextureHandle) override {
-        graph.add_pass({"LPV clear", [this](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("LPV clear", [this](sah_ctx* ctx) {
                             return sah_lpv_clear(ctx, &vol[0]->desc, &vol[1]->desc, &vol[2]->desc, &vol[6]->desc, num_cascades);
-                        }});
+                        }));
     }
     void post_render(RenderGraph& graph, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {
-        graph.add_pass({"LPV Propagation", [this](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("LPV Propagation", [this](sah_ctx* ctx) {
                             const sah_volume a[3] = {vol[0]->desc, vol[1]->desc, vol[2]->desc}, b[3] = {vol[3]->desc, vol[4]->desc, vol[5]->desc};
                             return sah_lpv_propagate(ctx, a, b, num_cascades, num_steps);
-                        }});
+                        }));
     }
-    void render_to_lit_scene(sah_gi& gi, TextureHandle, TextureHandle) const override {
+    void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList&) const override {  // light_propagation_volume.cpp:245-272
+        for (int c = 0; c < 3; c++) textures.push_back({vol[c], kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
+    }
+    void render_to_lit_scene(CommandBuffer& commands, BufferHandle view_buffer, TextureHandle ao_tex, TextureHandle) const override {
+        (void)view_buffer;  // the view block of the Lighting pass is the one the overlay reads
+        sah_gi& gi = commands.lighting.gi;
+        gi = sah_gi{};
         gi.kind = SAH_GI_LPV;
         gi.lpv_red = vol[0]->desc; gi.lpv_green = vol[1]->desc; gi.lpv_blue = vol[2]->desc;
         gi.lpv_cascades = cascades.data();
         gi.lpv_num_cascades = num_cascades;
-        gi.lpv_exposure = 3.1415927f * 10.f;  // r.GI.LPV.Exposure
+        gi.lpv_exposure = 3.1415927f * 10.f;  // r.GI.LPV.Exposure, pushed as a constant (:298-299)
+        commands.lighting.has_gi = true;
+        if (ao_tex) {  // the LPV overlay is the one consumer of the AO texture (gi/lpv/overlay.frag:153-155)
+            commands.lighting.ao = ao_tex->plane();
+            commands.lighting.has_ao = true;
+        }
     }
+    void draw_debug_overlays(RenderGraph&, const SceneView&, const GBuffer&, TextureHandle) override {}  // GV / VPL visualisers: debug views, not on the path
+    const sah_lpv_cascade_matrices* get_cascade_matrices() const { return cascades.data(); }
     TextureHandle get_volume(int channel, bool b = false) const { return vol[channel + (b ? 3 : 0)]; }
 
 private:
@@ -561,20 +790,27 @@ public:
     }
     void post_render(RenderGraph&, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {}
     void copy_probes_to_new_texture(RenderGraph& graph) {
-        graph.add_pass({"cascade_copy", [this](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("cascade_copy", [this](sah_ctx* ctx) {
                             const sah_probe_atlases a = atlases(0), b = atlases(1);
                             return sah_probe_copy(ctx, &a, &b, movement);
-                        }});
+                        }));
         std::swap(set[0], set[1]);  // swap_probe_textures(): "a" is the current set again
     }
     void dispatch_probe_updates(RenderGraph& graph) {
         if (num_probes == 0 || trace_results == nullptr) return;  // irradiance_cache.cpp:590-592
-        graph.add_pass({"probe updates", [this](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("probe updates", [this](sah_ctx* ctx) {
                             const sah_probe_atlases a = atlases(0);
                             return sah_probe_update(ctx, &a, &trace_results->desc, probes_to_update, num_probes);
-                        }});
+                        }));
     }
-    void render_to_lit_scene(sah_gi& gi, TextureHandle, TextureHandle) const override {
+    void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList&) const override {
+        for (TextureHandle t : {set[0].rtgi, set[0].depth, set[0].validity}) textures.push_back({t, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
+    }
+    void draw_debug_overlays(RenderGraph&, const SceneView&, const GBuffer&, TextureHandle) override {}  // probe spheres (irradiance_cache.cpp:308-349): debug view
+    void render_to_lit_scene(CommandBuffer& commands, BufferHandle, TextureHandle, TextureHandle) const override {  // add_to_lit_scene, :287-306
+        sah_gi& gi = commands.lighting.gi;
+        gi = sah_gi{};
+        commands.lighting.has_gi = true;
         gi.kind = SAH_GI_CACHE;
         gi.probe_irradiance = set[0].rtgi->desc;
         gi.probe_depth = set[0].depth->desc;
@@ -619,7 +855,15 @@ public:
         cache.pre_render(graph, view, scene, noise_tex);  // rtgi.cpp:60-75: the cache updates first
     }
     void post_render(RenderGraph&, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {}
-    void render_to_lit_scene(sah_gi& gi, TextureHandle, TextureHandle noise_tex) const override {
+    void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList& buffers) const override {
+        cache.get_lighting_resource_usages(textures, buffers);
+        for (TextureHandle t : {ray_texture, ray_irradiance}) textures.push_back({t, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
+    }
+    void draw_debug_overlays(RenderGraph&, const SceneView&, const GBuffer&, TextureHandle) override {}
+    void render_to_lit_scene(CommandBuffer& commands, BufferHandle, TextureHandle, TextureHandle noise_tex) const override {
+        sah_gi& gi = commands.lighting.gi;
+        gi = sah_gi{};
+        commands.lighting.has_gi = true;
         gi.kind = SAH_GI_RTGI;
         gi.ray_buffer = ray_texture->plane();
         gi.ray_irradiance = ray_irradiance->plane();
@@ -640,10 +884,10 @@ private:
 class AmbientOcclusionPhase {
 public:
     void generate_ao(RenderGraph& graph, TextureHandle ao_out) {
-        graph.add_pass({"Clear AO", [ao_out](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("Clear AO", [ao_out](sah_ctx* ctx) {
                             const sah_plane p = ao_out->plane();
                             return sah_ao_clear(ctx, &p);
-                        }});
+                        }));
     }
 };
 
@@ -654,47 +898,59 @@ public:
 class GbufferPhase {
 public:
     void render(RenderGraph& graph, const RenderScene& scene, const GBuffer& gbuffer, const SceneView& player_view) {
-        graph.add_pass({"gbuffer", [&scene, &gbuffer, &player_view](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("gbuffer", [&scene, &gbuffer, &player_view](sah_ctx* ctx) {
                             const sah_gbuffer g = {gbuffer.color->plane(), gbuffer.normals->plane(), gbuffer.data->plane(), gbuffer.emission->plane(),
                                                    gbuffer.depth->plane()};
                             return sah_gbuffer_render(ctx, &scene.geometry, &player_view.get_gpu_data(), &g, nullptr);
-                        }});
+                        }));
     }
 };
 
 class LightingPhase {
 public:
     void set_scene(RenderScene& scene_in) { scene = &scene_in; }
-    void render(RenderGraph& graph, const SceneView& view, const GBuffer& gbuffer, TextureHandle lit_scene_texture, TextureHandle ao_texture,
-                const IGlobalIlluminator* gi, std::optional<TextureHandle> /*vrsaa_shading_rate_image*/ = std::nullopt, TextureHandle noise_2d = nullptr) {
-        if (scene == nullptr) return;  // silent no-op, lighting_phase.cpp:47-49
-        graph.add_pass({"Lighting", [&, lit_scene_texture, ao_texture, gi, noise_2d](sah_ctx* ctx) {
-                            const sah_gbuffer g = {gbuffer.color->plane(), gbuffer.normals->plane(), gbuffer.data->plane(), gbuffer.emission->plane(),
-                                                   gbuffer.depth->plane()};
-                            const sah_plane lit = lit_scene_texture->plane();
-                            sah_plane ao{}, mask{};
-                            sah_gi gi_desc{};
-                            sah_sky_luts sky{};
-                            sah_lighting_desc d{};
-                            d.gbuffer = &g;
-                            d.lit = &lit;
-                            if (ao_texture) { ao = ao_texture->plane(); d.ao = &ao; }
-                            d.view = &view.get_gpu_data();
-                            auto& sun = scene->get_sun_light();
-                            d.sun = &sun.get_constants();
-                            if (sun.shadowmap_handle) d.shadowmap = &sun.shadowmap_handle->desc;
-                            if (sun.shadow_mask) { mask = sun.shadow_mask->plane(); d.shadow_mask = &mask; }
-                            if (gi) { gi->render_to_lit_scene(gi_desc, ao_texture, noise_2d); d.gi = &gi_desc; }
-                            if (scene->get_sky().sky_view_lut && scene->get_sky().transmittance_lut) {
-                                sky = {scene->get_sky().transmittance_lut->plane(), scene->get_sky().sky_view_lut->plane()};
-                                d.sky = &sky;
-                            }
-                            d.flags = SAH_LIGHTING_DEFAULT_FLAGS;
-                            return sah_lighting(ctx, &d);
-                        }});
+    // lighting_phase.hpp:33-43 / lighting_phase.cpp:34-134, same parameters.  The "Lighting" render pass clears lit_scene and runs, in
+    // this order, the CSM-mode sun, the GI overlay, the emissive pass and the sky; the RT-mode sun follows as its own dispatch.  Each of
+    // them records into the command buffer; the fused sah_lighting call (which keeps that order and its fp16 blend roundings) is
+    // submitted at the end.
+    void render(RenderGraph& render_graph, const SceneView& view, const GBuffer& gbuffer, TextureHandle lit_scene_texture, TextureHandle ao_texture,
+                const IGlobalIlluminator* gi, std::optional<TextureHandle> vrsaa_shading_rate_image, const NoiseTexture& noise, TextureHandle noise_2d) {
+        (void)vrsaa_shading_rate_image;  // VRSAA (sampling_rate_calculator.cpp) is AA plumbing outside the path: full rate
+        if (scene == nullptr) return;     // silent no-op, lighting_phase.cpp:47-49
+        auto& sun = scene->get_sun_light();
+        TextureUsageList texture_usages;
+        BufferUsageList buffer_usages;
+        for (TextureHandle t : {gbuffer.color, gbuffer.normals, gbuffer.data, gbuffer.emission, gbuffer.depth})
+            texture_usages.push_back({t, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
+        if (gi) gi->get_lighting_resource_usages(texture_usages, buffer_usages);
+        DynamicRenderingPass pass;
+        pass.name = "Lighting";
+        pass.textures = texture_usages;
+        pass.buffers = buffer_usages;
+        pass.color_attachments = {RenderingAttachmentInfo{lit_scene_texture, /*VK_ATTACHMENT_LOAD_OP_CLEAR*/ 1}};
+        pass.execute = [&, lit_scene_texture, ao_texture, gi, noise_2d](CommandBuffer& commands) {
+            auto& rec = commands.lighting;
+            rec = CommandBuffer::LightingRecording{};
+            rec.open = true;
+            rec.gbuffer = sah_gbuffer{gbuffer.color->plane(), gbuffer.normals->plane(), gbuffer.data->plane(), gbuffer.emission->plane(), gbuffer.depth->plane()};
+            rec.lit = lit_scene_texture->plane();
+            rec.view = static_cast<const sah_view_data*>(view.get_buffer()->data);
+            rec.sun = &sun.get_constants();  // shadow_mode in the constants selects which sun term the fused pass evaluates
+            if (sun.get_shadow_mode() == SunShadowMode::CascadedShadowMaps) sun.render(commands, view);
+            if (gi) gi->render_to_lit_scene(commands, view.get_buffer(), ao_texture, noise_2d);
+            add_emissive_lighting(commands);
+            scene->get_sky().render_sky(commands, view.get_buffer(), sun.get_constant_buffer(), gbuffer.depth);
+        };
+        render_graph.add_render_pass(std::move(pass));
+        if (sun.get_shadow_mode() == SunShadowMode::RayTracing) sun.raytrace(render_graph, view, gbuffer, *scene, lit_scene_texture, noise);
+        ComputePass submit;
+        submit.name = "Lighting (fused HIP dispatch)";
+        submit.execute = [](CommandBuffer& commands) { commands.submit_lighting(); };
+        render_graph.add_pass(std::move(submit));
     }
 
 private:
+    void add_emissive_lighting(CommandBuffer&) const {}  // lighting_phase.cpp:176-186: the emission plane is part of the bound G-buffer; nothing else to bind
     RenderScene* scene = nullptr;
 };
 
@@ -704,12 +960,12 @@ public:
     explicit Bloomer(RenderBackend& backend_in) : backend(backend_in) {}
     void fill_bloom_tex(RenderGraph& graph, TextureHandle scene_color) {
         if (mips.empty()) create_bloom_tex(scene_color);
-        graph.add_pass({"Bloom", [this, scene_color](sah_ctx* ctx) {
+        graph.add_pass(hip_pass("Bloom", [this, scene_color](sah_ctx* ctx) {
                             const sah_plane s = scene_color->plane();
                             return sah_bloom(ctx, &s, &chain);
-                        }});
+                        }));
     }
-    const sah_mipchain& get_bloom_tex() const { return chain; }
+    TextureHandle get_bloom_tex() const { return bloom_tex.get(); }  // bloomer.hpp:17
 
 private:
     void create_bloom_tex(TextureHandle scene_color) {  // bloomer.cpp:268-285: scene/2, six mips, scene format
@@ -722,21 +978,25 @@ private:
             w = w / 2 ? w / 2 : 1;
             h = h / 2 ? h / 2 : 1;
         }
+        bloom_tex = std::make_unique<Texture>();  // one handle for the whole chain, as the reference's mipped "Bloom texture"
+        bloom_tex->name = "Bloom texture";
+        bloom_tex->desc = mips[0]->desc;
+        bloom_tex->mips = chain;
     }
     RenderBackend& backend;
     std::vector<TextureHandle> mips;
     sah_mipchain chain{};
+    std::unique_ptr<Texture> bloom_tex;
 };
 
 // ---- UiPhase::draw_scene_image (RenderCore/render/phase/ui_phase.hpp:27, .cpp:98-113) -------------------------------------
 class UiPhase {
 public:
     void set_resources(TextureHandle scene_color_in, TextureHandle swapchain_in) { scene_color = scene_color_in; swapchain = swapchain_in; }
-    void render(RenderGraph& graph, const SceneView&, const sah_mipchain& bloom_texture) const {
-        graph.add_pass({"UI", [this, &bloom_texture](sah_ctx* ctx) {
-                            const sah_plane s = scene_color->plane(), o = swapchain->plane();
-                            return sah_tonemap(ctx, &s, &bloom_texture, &o, 0, 0);
-                        }});
+    // ui_phase.hpp:27: called from inside the "UI" render pass (scene_renderer.cpp:426-449); draw_scene_image (:98-113) is the part on the path
+    void render(CommandBuffer& commands, const SceneView&, TextureHandle bloom_texture) const {
+        const sah_plane s = scene_color->plane(), o = swapchain->plane();
+        commands.check(sah_tonemap(commands.get_context(), &s, &bloom_texture->mips, &o, 0, 0), "UI");
     }
 
 private:
@@ -745,10 +1005,10 @@ private:
 
 // "Copy scene" (AA = None), RenderCore/render/scene_renderer.cpp:502-527
 inline void evaluate_antialiasing_none(RenderGraph& graph, TextureHandle lit_scene, TextureHandle antialiased_scene) {
-    graph.add_pass({"Copy scene", [lit_scene, antialiased_scene](sah_ctx* ctx) {
+    graph.add_pass(hip_pass("Copy scene", [lit_scene, antialiased_scene](sah_ctx* ctx) {
                         const sah_plane a = lit_scene->plane(), b = antialiased_scene->plane();
                         return sah_copy_scene(ctx, &a, &b);
-                    }});
+                    }));
 }
 
 }  // namespace sah

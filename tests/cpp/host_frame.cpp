@@ -1,6 +1,7 @@
 // Renders one frame through the C++ host façade (include/sah_host.hpp), the way SceneRenderer::render drives the
-// reference's phases (RenderCore/render/scene_renderer.cpp:365-449): GI post_render -> lighting -> copy scene -> bloom
-// -> UI/tonemap.  Inputs come from a file written by tests/test_host_facade_gpu.py; the uniform blocks this program
+// reference's phases (RenderCore/render/scene_renderer.cpp:318-449): GI pre_render / post_render -> AO -> lighting -> copy scene ->
+// bloom -> the "UI" render pass, with the reference's own call signatures (gi->post_render(...), lighting_pass.render(... nine
+// arguments ...), ui_phase.render(commands, view, bloom)) and every RenderGraph verb the reference has.  Inputs come from a file written by tests/test_host_facade_gpu.py; the uniform blocks this program
 // builds are written back with the images so that the test can feed the very same blocks to the oracle.
 //
 //   host_frame <in.bin> <out.bin>
@@ -84,30 +85,65 @@ int main(int argc, char** argv) {
     cache.set_trace_results(trace, probe_ids_dev, 3);
     cache.pre_render(graph, view, scene, nullptr);
 
-    const IGlobalIlluminator* gi = &lpv;
-    lpv.post_render(graph, view, scene, gbuffer, nullptr);
-    lighting.render(graph, view, gbuffer, lit_scene, ao, gi);
+    // scene_renderer.cpp:318-320, 374-401.  (lpv.pre_render() would clear the volumes for the RSM / VPL injection that follows it in the
+    // reference; the uploaded volumes stand in for that injection, so only the cache's maintenance runs before the G-buffer here.)
+    const uint32_t frame_count = 0;
+    NoiseTexture stbn_3d_unitvec, stbn_2d_scalar;  // the blue-noise layers are not in the reference tree: empty
+    IGlobalIlluminator* gi = &lpv;
+    gi->post_render(graph, view, scene, gbuffer, stbn_3d_unitvec.get_layer(frame_count));
+
+    // r.AO.Mode = Off: "clear the AO target to 1" as a compute dispatch on a scratch target (the frame's AO plane is an input of the test)
+    TextureHandle ao_scratch = alloc.create_texture("ao scratch", SAH_FORMAT_R32_SFLOAT, W, H);
+    const ComputePipeline clear_ao{"clear_ao", [ao_scratch](sah_ctx* ctx, const void*, const uint32_t*) {
+                                       const sah_plane p = ao_scratch->plane();
+                                       return sah_ao_clear(ctx, &p);
+                                   }};
+    ComputeDispatch<uint32_t> clear_dispatch;
+    clear_dispatch.name = "Clear AO";
+    clear_dispatch.num_workgroups[0] = (W + 7) / 8;
+    clear_dispatch.num_workgroups[1] = (H + 7) / 8;
+    clear_dispatch.compute_shader = &clear_ao;
+    graph.add_compute_dispatch(clear_dispatch);
+    TransitionPass to_read;
+    to_read.textures.push_back({ao, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
+    graph.add_transition_pass(to_read);
+
+    lighting.render(graph, view, gbuffer, lit_scene, ao, gi, std::nullopt, stbn_3d_unitvec, stbn_2d_scalar.get_layer(frame_count));
+    gi->draw_debug_overlays(graph, view, gbuffer, lit_scene);
     evaluate_antialiasing_none(graph, lit_scene, antialiased);
     bloomer.fill_bloom_tex(graph, antialiased);
-    ui.render(graph, view, bloomer.get_bloom_tex());
+    DynamicRenderingPass ui_pass;  // scene_renderer.cpp:426-449
+    ui_pass.name = "UI";
+    ui_pass.textures = {{antialiased, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly},
+                        {bloomer.get_bloom_tex(), kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly}};
+    ui_pass.color_attachments = {RenderingAttachmentInfo{swapchain, 0}};
+    ui_pass.execute = [&](CommandBuffer& commands) { ui.render(commands, view, bloomer.get_bloom_tex()); };
+    graph.add_render_pass(std::move(ui_pass));
+    // the copy verb: lit_scene into a second image, which is the one written out below
+    TextureHandle lit_copy = alloc.create_texture("lit_scene copy", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    graph.add_copy_pass(ImageCopyPass{"Copy lit scene", lit_copy, lit_scene});
     graph.finish();
     for (const auto& e : graph.get_errors()) fprintf(stderr, "pass failed: %s\n", e.c_str());
     if (!graph.get_errors().empty()) return 1;
+    {
+        std::vector<float> ones((size_t)W * H);
+        alloc.download(ao_scratch, ones.data(), W * 4);
+        for (float v : ones)
+            if (v != 1.0f) { fprintf(stderr, "Clear AO dispatch did not run\n"); return 1; }
+    }
 
     FILE* out = fopen(argv[2], "wb");
     if (!out) { perror("open output"); return 2; }
-    sah_gi gi_desc{};
-    lpv.render_to_lit_scene(gi_desc, ao, nullptr);
     fwrite(&view.get_gpu_data(), sizeof(sah_view_data), 1, out);
     fwrite(&scene.sun.get_constants(), sizeof(sah_sun_light_constants), 1, out);
-    fwrite(gi_desc.lpv_cascades, sizeof(sah_lpv_cascade_matrices), 4, out);
+    fwrite(lpv.get_cascade_matrices(), sizeof(sah_lpv_cascade_matrices), 4, out);
     std::vector<unsigned char> buf((size_t)W * H * 8);
     for (int c = 0; c < 3; c++) {  // propagated LPV (A volumes)
         std::vector<unsigned char> v((size_t)128 * 32 * 32 * 8);
         alloc.download(lpv.get_volume(c), v.data(), 128 * 8);
         fwrite(v.data(), 1, v.size(), out);
     }
-    alloc.download(lit_scene, buf.data(), W * 8);
+    alloc.download(lit_copy, buf.data(), W * 8);
     fwrite(buf.data(), 1, (size_t)W * H * 8, out);
     alloc.download(swapchain, buf.data(), W * 4);
     fwrite(buf.data(), 1, (size_t)W * H * 4, out);

@@ -90,9 +90,7 @@ int main(int argc, char** argv) {
         alloc.download(p.t, buf.data(), W * p.bpp);
         fwrite(buf.data(), 1, buf.size(), out);
     }
-    sah_gi gi_desc{};
-    lpv.render_to_lit_scene(gi_desc, nullptr, nullptr);
-    fwrite(gi_desc.lpv_cascades, sizeof(sah_lpv_cascade_matrices), 4, out);
+    fwrite(lpv.get_cascade_matrices(), sizeof(sah_lpv_cascade_matrices), 4, out);
     for (int c = 0; c < 3; c++) {  // injected A volumes
         std::vector<unsigned char> v((size_t)128 * 32 * 32 * 8);
         alloc.download(lpv.get_volume(c), v.data(), 128 * 8);
