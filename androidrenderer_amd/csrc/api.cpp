@@ -491,6 +491,9 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
     memset(&fast, 0, sizeof(fast));
     const bool fast_kind = (gi_kind == SAH_GI_NONE || gi_kind == SAH_GI_LPV) && a.num_lights == 0;
     const bool use_fast = fast_kind && !ctx->force_general && detect_fast_path(d, sun_mode, gi_kind, csm, &fast);
+    // the tiled kernel (light list, cache / RTGI overlays) borrows the fast kernel's geometry and CSM sun when the uniform blocks allow
+    // (its LPV overlay, if any, stays the general one: the LPV part of the check is skipped)
+    const bool tiled_fast_geom = !fast_kind && !ctx->force_general && detect_fast_path(d, sun_mode, SAH_GI_NONE, csm, &fast);
     if (use_fast) {
         // deferred-pixel segments (params.hpp): one per wave of the fast kernel, 64 * ppt byte codes + a 16-bit count each
         const uint64_t groups = (uint64_t)(W / (uint32_t)ppt) * (r1 - r0);
@@ -532,7 +535,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         fast.parity = ctx->parity;
         fast.state = ctx->state;
     }
-    HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, use_fast ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,
+    HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, (use_fast || tiled_fast_geom) ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,
                                  (d->flags & SAH_LIGHTING_BRUTE_FORCE_LIGHTS) != 0, ctx->stream));
     if (use_fast) {
         ctx->parity ^= 1u;

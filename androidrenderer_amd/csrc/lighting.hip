@@ -355,13 +355,13 @@ static hipError_t launch_gi(const LightingArgs& a, const CsmArgs& csm, const Lpv
 }
 
 hipError_t launch_lighting_tiled(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
-                                 const SkyArgs& sky, int sun_mode, int gi, bool brute_force_lights, hipStream_t st);
+                                 const SkyArgs& sky, int sun_mode, int gi, bool brute_force_lights, const FastArgs* fast, hipStream_t st);
 
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                            const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st) {
     // point lights and the GI overlays without a fast path run in the 16x16-tile kernel (lighting_tiled.hip)
     if (a.num_lights || gi == SAH_GI_CACHE || gi == SAH_GI_RTGI)
-        return launch_lighting_tiled(a, csm, lpv, cache, rtgi, sky, sun_mode, gi, brute_force_lights, st);
+        return launch_lighting_tiled(a, csm, lpv, cache, rtgi, sky, sun_mode, gi, brute_force_lights, fast, st);
     switch (sun_mode) {
         case SAH_SHADOW_MODE_OFF: return launch_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, sky, fast, gi, ppt, st);
         case SAH_SHADOW_MODE_CSM: return launch_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, sky, fast, gi, ppt, st);

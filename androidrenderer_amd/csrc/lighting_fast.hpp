@@ -26,6 +26,155 @@ struct FastPixelOut {
     bool deferred;
 };
 
+// fp32 ("GLSL") geometry shared by the CSM sun, the LPV overlay and the point lights: normalised normal, world-space position with
+// the shader's (x + 1) / W texcoord quirk, view-space depth, and the view vector.  `ok` is cleared when an operand leaves the domain of a
+// restricted-range operator (the caller then evaluates the general restatement for that pixel).
+struct FastGeom {
+    F3 N, ws, V;
+    Fn vsz;
+};
+SAH_DEV FastGeom fast_geometry(const LightingArgs& a, const FastArgs& f, float colx_glsl, float rowy_glsl, float D, const SurfIn& si, float dn,
+                               const float* tab, bool& ok) {
+    FastGeom g;
+    // dn is a sum of squares of fp16 values: 2^-48 <= dn < 2^35 whenever it is positive and finite (checked above), so the
+    // restricted-range sqrt / reciprocal apply (numerics.hpp)
+    const Fn inv = Fn(rcp_nr(sqrt_nr(dn)));
+    g.N = F3{Fn(si.normal[0]) * inv, Fn(si.normal[1]) * inv, Fn(si.normal[2]) * inv};
+    // inverse_projection separable: vs = ((p0*X)+p12, (p5*Y)+p13, (p10*D)+p14, (p11*D)+p15)
+    const Fn vw = Fn(f.p11) * Fn(D) + Fn(f.p15);
+    const Fn vzn = Fn(f.p10) * Fn(D) + Fn(f.p14);
+    Fn vx, vy;
+    if (f.pos_div_nr) {
+        // The three quotients share one refined reciprocal (div_nr with the y1 steps hoisted): 8 + 4 + 3 * 10 cycles instead of
+        // 3 * 34.  Domain: |vw| in [2^-40, 2^40] (checked here), numerators +0 or in [2^-40, 2^40] in magnitude (host:
+        // detect_fast_path bounds p0, p5, p14 and requires p10 == p12 == p13 == +0, so x / y numerators are products of a
+        // bounded coefficient with a multiple of 2^-24 and the z numerator is the constant p14).
+        const float aw = __builtin_fabsf(vw.v);
+        ok = ok && aw >= kDivLo && aw <= kDivHi;
+        const float y0 = __builtin_amdgcn_rcpf(vw.v);
+        const float y1 = __builtin_fmaf(__builtin_fmaf(-vw.v, y0, 1.0f), y0, y0);
+        auto quot = [&](float num) {
+            const float q0 = num * y1;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-vw.v, q0, num), y1, q0);
+            return Fn(__builtin_fmaf(__builtin_fmaf(-vw.v, q1, num), y1, q1));
+        };
+        vx = quot(colx_glsl);
+        vy = quot(rowy_glsl);
+        g.vsz = quot(vzn.v);
+    } else {
+        vx = Fn(colx_glsl) / vw;
+        vy = Fn(rowy_glsl) / vw;
+        g.vsz = vzn / vw;
+    }
+    // inverse_view affine: ws_i = ((v0i*x + v1i*y) + v2i*z) + v3i
+    const float4 mx = *reinterpret_cast<const float4*>(tab + TAB_VIEW), my = *reinterpret_cast<const float4*>(tab + TAB_VIEW + 4u),
+                 mz = *reinterpret_cast<const float4*>(tab + TAB_VIEW + 8u);  // rows of inverse_view (LDS broadcast reads)
+    g.ws.x = Fn(mx.x) * vx + Fn(mx.y) * vy + Fn(mx.z) * g.vsz + Fn(mx.w);
+    g.ws.y = Fn(my.x) * vx + Fn(my.y) * vy + Fn(my.z) * g.vsz + Fn(my.w);
+    g.ws.z = Fn(mz.x) * vx + Fn(mz.y) * vy + Fn(mz.z) * g.vsz + Fn(mz.w);
+    const F3 d = g.ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])};
+    const Fn d2 = dot(d, d);
+    // 2^-80 <= d2 <= 2^80 implies finite ws (view_pos is finite: host check) and puts sqrt / reciprocal in their domain
+    ok = ok && d2.v >= 0x1p-80f && d2.v <= 0x1p+80f;
+    g.V = d * Fn(rcp_nr(sqrt_nr(d2.v)));
+    return g;
+}
+
+// a1: the CSM-mode sun term of one pixel, sc = direct * exposure per channel (0 when unlit or shadowed).  direct = ((ndotl * brdf) *
+// colour) * shadow is exactly 0 (or NaN, which the shader's guard turns into 0) whenever ndotl == 0 or shadow == 0, so both the PCF
+// lookup and the BRDF are skipped when no lane of the wave needs them (wave-uniform votes: no divergent branches).
+template <bool RELAXED>
+SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float* tab, const F3& N, const F3& ws, const Fn vsz, const F3& V, const F3& L,
+                          const Surface<Fn>& s, const SurfIn& si, bool sky_px, bool& ok, Fn (&sc)[3]) {
+    const Fn ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
+    sc[0] = sc[1] = sc[2] = Fn(0.f);
+    if (__any(ok && !sky_px && ndotl_sun.v > 0.f)) {
+        uint32_t cascade = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
+        const uint32_t cc = cascade > 3u ? 3u : cascade;  // cascade 4 means "no shadow map": keep the address legal
+        // 1 - ndotl^2 is 0 or >= 2^-24 (ndotl in [0,1]); 0.0005 * sqrt(.) is +0 or in [2^-24, 2^-10]; ndotl needs a lower bound
+        const Fn bias_num = Fn(0.0005f) * Fn(sqrt_nr0((Fn(1.0f) - ndotl_sun * ndotl_sun).v));
+        const Fn bias = Fn(div_nr(bias_num.v, ndotl_sun.v));
+        ok = ok && !(ndotl_sun.v > 0.f && ndotl_sun.v < kDivLo);
+        // affine shadow matrix: sp.w == 1, so the perspective divide is the identity; rows come from the LDS table
+        const float4 rx = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u);
+        const float4 ry = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 4u);
+        const float4 rz = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 8u);
+        const Fn spx = Fn(rx.x) * ws.x + Fn(rx.y) * ws.y + Fn(rx.z) * ws.z + Fn(rx.w);
+        const Fn spy = Fn(ry.x) * ws.x + Fn(ry.y) * ws.y + Fn(ry.z) * ws.z + Fn(ry.w);
+        const Fn spz = Fn(rz.x) * ws.x + Fn(rz.y) * ws.y + Fn(rz.z) * ws.z + Fn(rz.w);
+        // !(any(sp < 0) || any(sp > 1)) via min3 / max3; sp is finite for every pixel that is not deferred (see inside())
+        const float sp_mn = __builtin_fminf(__builtin_fminf(spx.v, spy.v), spz.v), sp_mx = __builtin_fmaxf(__builtin_fmaxf(spx.v, spy.v), spz.v);
+        const bool sp_inside = !(sp_mn < 0.f || sp_mx > 1.f);
+        float pcf_ref = (spz - bias).v;
+        pcf_ref = pcf_ref < 0.f ? 0.f : (pcf_ref > 1.f ? 1.f : pcf_ref);  // D16: D_ref clamped to [0,1]
+        const VolumeArg& sm = csm.shadowmap;
+        const float px = spx.v * (float)sm.width - 0.5f, py = spy.v * (float)sm.height - 0.5f;
+        const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+        const float pcf_fx = px - fx0, pcf_fy = py - fy0;
+        const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0);
+        const int wm1 = (int)sm.width - 1, hm1 = (int)sm.height - 1;
+        const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * 2u, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * 2u;
+        const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
+        const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
+#ifdef SAH_EXP_UNIFORM_PCF  // experiment: divergent addresses folded into the first 64 KiB of the map (always cache resident)
+        const uint32_t pcf_off[4] = {(lo + ra + xa) & 0xfffeu, (lo + ra + xb) & 0xfffeu, (lo + rb + xa) & 0xfffeu, (lo + rb + xb) & 0xfffeu};
+#else
+        const uint32_t pcf_off[4] = {lo + ra + xa, lo + ra + xb, lo + rb + xa, lo + rb + xb};
+#endif
+        // PCF taps (compare LESS, then filter); the fast path is D16_UNORM only (anything else: general kernel)
+        float dtap[4];
+        uint16_t raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint16_t*>(sm.ptr + pcf_off[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float v = (float)raw[k];
+            const float q = v * csm.d16_recip;  // host-verified 3-flop v / 65535 (see shadow_pcf)
+            dtap[k] = __builtin_fmaf(__builtin_fmaf(-q, 65535.0f, v), csm.d16_recip, q);
+        }
+        const float wx0 = 1.0f - pcf_fx, wy0 = 1.0f - pcf_fy;
+        float pcf = __builtin_fmaf(wx0 * wy0, (pcf_ref < dtap[0]) ? 1.0f : 0.0f, 0.0f);
+        pcf = __builtin_fmaf(pcf_fx * wy0, (pcf_ref < dtap[1]) ? 1.0f : 0.0f, pcf);
+        pcf = __builtin_fmaf(wx0 * pcf_fy, (pcf_ref < dtap[2]) ? 1.0f : 0.0f, pcf);
+        pcf = __builtin_fmaf(pcf_fx * pcf_fy, (pcf_ref < dtap[3]) ? 1.0f : 0.0f, pcf);
+        // ndotl > 0 ? (cascade > 3 ? 0 : (outside ? 1 : pcf)) : 1
+        float shadow = sp_inside ? pcf : 1.0f;
+        shadow = cascade > 3u ? 0.0f : shadow;
+        shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
+        if (__any(ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f)) {
+            if constexpr (RELAXED) {
+                const float base[3] = {si.color[0], si.color[1], si.color[2]};
+                float b[3], dden, dh, dvis;
+                brdf_relaxed(base, si.metal, si.rough, N, L, V, ndotl_sun.v, b, dden, dh, dvis);
+                const bool lit_px = ndotl_sun.v > 0.f && shadow != 0.0f;  // else direct is exactly 0 (or NaN -> 0) in the shader
+                const float t = (ndotl_sun.v * shadow) * 0.00031415927f;
+                // G2: the error of 1 - NoH^2 (about 2^-22 absolute) reaches brdf() as 2^-21 / dden times the specular share
+                // D Vis F / brdf <= D Vis / min(brdf): kept small by D Vis <= dden min(brdf) / kTolG2.  NaN operands fail the test.
+                const float bmin = __builtin_fminf(__builtin_fminf(b[0], b[1]), b[2]);
+                ok = ok && !(lit_px && !(dden * bmin >= kTolG2 * dvis && dh >= 0.25f));
+                sc[0] = Fn(lit_px ? (b[0] * (a.sun_color[0] * t)) : 0.0f);
+                sc[1] = Fn(lit_px ? (b[1] * (a.sun_color[1] * t)) : 0.0f);
+                sc[2] = Fn(lit_px ? (b[2] * (a.sun_color[2] * t)) : 0.0f);
+            } else {
+            bool brdf_out_of_domain;
+            const F3 b = brdf_fast(s, L, V, brdf_out_of_domain);
+            const F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
+            // `if (any(isnan(direct))) direct = 0`: a NaN component (inf * 0 after an overflow; rare) sends the pixel to the
+            // fix-up kernel instead of paying three compare + select pairs here.  x + y + z is NaN iff a component is NaN
+            // or two are opposite infinities (then the pixel is deferred needlessly, which is harmless).
+            const float nan_probe = (direct.x + direct.y + direct.z).v;
+            ok = ok && !brdf_out_of_domain && nan_probe == nan_probe;
+            const Fn exposure = Fn(0.00031415927f);
+            sc[0] = direct.x * exposure;
+            sc[1] = direct.y * exposure;
+            sc[2] = direct.z * exposure;
+            }
+        }
+    }
+}
+
 // RELAXED = SAH_LIGHTING_TOLERANCE_1ULP (sah_hip.h): the BRDF evaluation and the overlay's final products run as fused / hardware
 // arithmetic (numerics.hpp: brdf_relaxed); everything that decides something or is ill-conditioned stays the strict sequence below.
 // Guards (all lead to `deferred`, i.e. to the strict restatement in the fix-up kernel):
@@ -55,47 +204,11 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     F3 N, ws, V;
     Fn vsz;
     if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) {
-        // dn is a sum of squares of fp16 values: 2^-48 <= dn < 2^35 whenever it is positive and finite (checked above), so the
-        // restricted-range sqrt / reciprocal apply (numerics.hpp)
-        const Fn inv = Fn(rcp_nr(sqrt_nr(dn)));
-        N = F3{Fn(si.normal[0]) * inv, Fn(si.normal[1]) * inv, Fn(si.normal[2]) * inv};
-        // inverse_projection separable: vs = ((p0*X)+p12, (p5*Y)+p13, (p10*D)+p14, (p11*D)+p15)
-        const Fn vw = Fn(f.p11) * Fn(D) + Fn(f.p15);
-        const Fn vzn = Fn(f.p10) * Fn(D) + Fn(f.p14);
-        Fn vx, vy;
-        if (f.pos_div_nr) {
-            // The three quotients share one refined reciprocal (div_nr with the y1 steps hoisted): 8 + 4 + 3 * 10 cycles instead of
-            // 3 * 34.  Domain: |vw| in [2^-40, 2^40] (checked here), numerators +0 or in [2^-40, 2^40] in magnitude (host:
-            // detect_fast_path bounds p0, p5, p14 and requires p10 == p12 == p13 == +0, so x / y numerators are products of a
-            // bounded coefficient with a multiple of 2^-24 and the z numerator is the constant p14).
-            const float aw = __builtin_fabsf(vw.v);
-            ok = ok && aw >= kDivLo && aw <= kDivHi;
-            const float y0 = __builtin_amdgcn_rcpf(vw.v);
-            const float y1 = __builtin_fmaf(__builtin_fmaf(-vw.v, y0, 1.0f), y0, y0);
-            auto quot = [&](float num) {
-                const float q0 = num * y1;
-                const float q1 = __builtin_fmaf(__builtin_fmaf(-vw.v, q0, num), y1, q0);
-                return Fn(__builtin_fmaf(__builtin_fmaf(-vw.v, q1, num), y1, q1));
-            };
-            vx = quot(colx_glsl);
-            vy = quot(rowy_glsl);
-            vsz = quot(vzn.v);
-        } else {
-            vx = Fn(colx_glsl) / vw;
-            vy = Fn(rowy_glsl) / vw;
-            vsz = vzn / vw;
-        }
-        // inverse_view affine: ws_i = ((v0i*x + v1i*y) + v2i*z) + v3i
-        const float4 mx = *reinterpret_cast<const float4*>(tab + TAB_VIEW), my = *reinterpret_cast<const float4*>(tab + TAB_VIEW + 4u),
-                     mz = *reinterpret_cast<const float4*>(tab + TAB_VIEW + 8u);  // rows of inverse_view (LDS broadcast reads)
-        ws.x = Fn(mx.x) * vx + Fn(mx.y) * vy + Fn(mx.z) * vsz + Fn(mx.w);
-        ws.y = Fn(my.x) * vx + Fn(my.y) * vy + Fn(my.z) * vsz + Fn(my.w);
-        ws.z = Fn(mz.x) * vx + Fn(mz.y) * vy + Fn(mz.z) * vsz + Fn(mz.w);
-        const F3 d = ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])};
-        const Fn d2 = dot(d, d);
-        // 2^-80 <= d2 <= 2^80 implies finite ws (view_pos is finite: host check) and puts sqrt / reciprocal in their domain
-        ok = ok && d2.v >= 0x1p-80f && d2.v <= 0x1p+80f;
-        V = d * Fn(rcp_nr(sqrt_nr(d2.v)));
+        const FastGeom g = fast_geometry(a, f, colx_glsl, rowy_glsl, D, si, dn, tab, ok);
+        N = g.N;
+        ws = g.ws;
+        V = g.V;
+        vsz = g.vsz;
     }
 
     Surface<Fn> s;
@@ -155,93 +268,8 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     // ndotl == 0 or shadow == 0, so both the PCF lookup and the BRDF are skipped when no lane of the wave needs them.
     // The votes are wave-uniform: the body stays free of divergent branches.
     if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
-        const Fn ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
-        Fn sc[3] = {Fn(0.f), Fn(0.f), Fn(0.f)};
-        if (__any(ok && !sky_px && ndotl_sun.v > 0.f)) {
-            uint32_t cascade = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
-            const uint32_t cc = cascade > 3u ? 3u : cascade;  // cascade 4 means "no shadow map": keep the address legal
-            // 1 - ndotl^2 is 0 or >= 2^-24 (ndotl in [0,1]); 0.0005 * sqrt(.) is +0 or in [2^-24, 2^-10]; ndotl needs a lower bound
-            const Fn bias_num = Fn(0.0005f) * Fn(sqrt_nr0((Fn(1.0f) - ndotl_sun * ndotl_sun).v));
-            const Fn bias = Fn(div_nr(bias_num.v, ndotl_sun.v));
-            ok = ok && !(ndotl_sun.v > 0.f && ndotl_sun.v < kDivLo);
-            // affine shadow matrix: sp.w == 1, so the perspective divide is the identity; rows come from the LDS table
-            const float4 rx = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u);
-            const float4 ry = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 4u);
-            const float4 rz = *reinterpret_cast<const float4*>(tab + TAB_CSM + cc * 12u + 8u);
-            const Fn spx = Fn(rx.x) * ws.x + Fn(rx.y) * ws.y + Fn(rx.z) * ws.z + Fn(rx.w);
-            const Fn spy = Fn(ry.x) * ws.x + Fn(ry.y) * ws.y + Fn(ry.z) * ws.z + Fn(ry.w);
-            const Fn spz = Fn(rz.x) * ws.x + Fn(rz.y) * ws.y + Fn(rz.z) * ws.z + Fn(rz.w);
-            // !(any(sp < 0) || any(sp > 1)) via min3 / max3; sp is finite for every pixel that is not deferred (see inside())
-            const float sp_mn = __builtin_fminf(__builtin_fminf(spx.v, spy.v), spz.v), sp_mx = __builtin_fmaxf(__builtin_fmaxf(spx.v, spy.v), spz.v);
-            const bool sp_inside = !(sp_mn < 0.f || sp_mx > 1.f);
-            float pcf_ref = (spz - bias).v;
-            pcf_ref = pcf_ref < 0.f ? 0.f : (pcf_ref > 1.f ? 1.f : pcf_ref);  // D16: D_ref clamped to [0,1]
-            const VolumeArg& sm = csm.shadowmap;
-            const float px = spx.v * (float)sm.width - 0.5f, py = spy.v * (float)sm.height - 0.5f;
-            const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-            const float pcf_fx = px - fx0, pcf_fy = py - fy0;
-            const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0);
-            const int wm1 = (int)sm.width - 1, hm1 = (int)sm.height - 1;
-            const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * 2u, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * 2u;
-            const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
-            const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
-#ifdef SAH_EXP_UNIFORM_PCF  // experiment: divergent addresses folded into the first 64 KiB of the map (always cache resident)
-            const uint32_t pcf_off[4] = {(lo + ra + xa) & 0xfffeu, (lo + ra + xb) & 0xfffeu, (lo + rb + xa) & 0xfffeu, (lo + rb + xb) & 0xfffeu};
-#else
-            const uint32_t pcf_off[4] = {lo + ra + xa, lo + ra + xb, lo + rb + xa, lo + rb + xb};
-#endif
-            // PCF taps (compare LESS, then filter); the fast path is D16_UNORM only (anything else: general kernel)
-            float dtap[4];
-            uint16_t raw[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint16_t*>(sm.ptr + pcf_off[k]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float v = (float)raw[k];
-                const float q = v * csm.d16_recip;  // host-verified 3-flop v / 65535 (see shadow_pcf)
-                dtap[k] = __builtin_fmaf(__builtin_fmaf(-q, 65535.0f, v), csm.d16_recip, q);
-            }
-            const float wx0 = 1.0f - pcf_fx, wy0 = 1.0f - pcf_fy;
-            float pcf = __builtin_fmaf(wx0 * wy0, (pcf_ref < dtap[0]) ? 1.0f : 0.0f, 0.0f);
-            pcf = __builtin_fmaf(pcf_fx * wy0, (pcf_ref < dtap[1]) ? 1.0f : 0.0f, pcf);
-            pcf = __builtin_fmaf(wx0 * pcf_fy, (pcf_ref < dtap[2]) ? 1.0f : 0.0f, pcf);
-            pcf = __builtin_fmaf(pcf_fx * pcf_fy, (pcf_ref < dtap[3]) ? 1.0f : 0.0f, pcf);
-            // ndotl > 0 ? (cascade > 3 ? 0 : (outside ? 1 : pcf)) : 1
-            float shadow = sp_inside ? pcf : 1.0f;
-            shadow = cascade > 3u ? 0.0f : shadow;
-            shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
-            if (__any(ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f)) {
-                if constexpr (RELAXED) {
-                    const float base[3] = {si.color[0], si.color[1], si.color[2]};
-                    float b[3], dden, dh, dvis;
-                    brdf_relaxed(base, si.metal, si.rough, N, L, V, ndotl_sun.v, b, dden, dh, dvis);
-                    const bool lit_px = ndotl_sun.v > 0.f && shadow != 0.0f;  // else direct is exactly 0 (or NaN -> 0) in the shader
-                    const float t = (ndotl_sun.v * shadow) * 0.00031415927f;
-                    // G2: the error of 1 - NoH^2 (about 2^-22 absolute) reaches brdf() as 2^-21 / dden times the specular share
-                    // D Vis F / brdf <= D Vis / min(brdf): kept small by D Vis <= dden min(brdf) / kTolG2.  NaN operands fail the test.
-                    const float bmin = __builtin_fminf(__builtin_fminf(b[0], b[1]), b[2]);
-                    ok = ok && !(lit_px && !(dden * bmin >= kTolG2 * dvis && dh >= 0.25f));
-                    sc[0] = Fn(lit_px ? (b[0] * (a.sun_color[0] * t)) : 0.0f);
-                    sc[1] = Fn(lit_px ? (b[1] * (a.sun_color[1] * t)) : 0.0f);
-                    sc[2] = Fn(lit_px ? (b[2] * (a.sun_color[2] * t)) : 0.0f);
-                } else {
-                bool brdf_out_of_domain;
-                const F3 b = brdf_fast(s, L, V, brdf_out_of_domain);
-                const F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
-                // `if (any(isnan(direct))) direct = 0`: a NaN component (inf * 0 after an overflow; rare) sends the pixel to the
-                // fix-up kernel instead of paying three compare + select pairs here.  x + y + z is NaN iff a component is NaN
-                // or two are opposite infinities (then the pixel is deferred needlessly, which is harmless).
-                const float nan_probe = (direct.x + direct.y + direct.z).v;
-                ok = ok && !brdf_out_of_domain && nan_probe == nan_probe;
-                const Fn exposure = Fn(0.00031415927f);
-                sc[0] = direct.x * exposure;
-                sc[1] = direct.y * exposure;
-                sc[2] = direct.z * exposure;
-                }
-            }
-        }
+        Fn sc[3];
+        fast_csm_sun<RELAXED>(a, csm, tab, N, ws, vsz, V, L, s, si, sky_px, ok, sc);
         const bool quirk = (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) != 0;
         // quirk: dst is the cleared target, s*s + 0*0 == s*s, alpha 1*0 + 0*0 == 0; otherwise plain additive
         float x1[3];

@@ -14,6 +14,7 @@
 
 #include "../../include/sah_hip.h"
 #include "lighting_common.hpp"
+#include "lighting_fast.hpp"
 #include "lighting_gi_ext.hpp"
 #include "numerics.hpp"
 #include "params.hpp"
@@ -35,8 +36,20 @@ SAH_DEV float wave_max(float v) {
 
 template <int SUN, int GI, bool LIGHTS>
 __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const CacheArgs cache,
-                                                        const RtgiArgs rtgi, const SkyArgs sky, const uint32_t brute_force) {
-    __shared__ float s_lut[512];
+                                                        const RtgiArgs rtgi, const SkyArgs sky, const uint32_t brute_force, const FastArgs f,
+                                                        const uint32_t fast_geom) {
+    // `fast_geom`: the uniform blocks have the structure the fast kernel's geometry and CSM sun rely on (api.cpp: detect_fast_path);
+    // then the fp32 geometry (normal, position, view vector) and the CSM sun come from lighting_fast.hpp — the same bits at a third of
+    // the instructions — and only pixels outside their domains take the general restatement.
+    __shared__ __attribute__((aligned(16))) float s_lut[TAB_SIZE];
+    if (SUN == SAH_SHADOW_MODE_CSM && threadIdx.x < 48) {  // [cascade][row x,y,z][col 0..3] of biasMat * cascade_matrices
+        const uint32_t c = threadIdx.x / 12u, j = threadIdx.x % 12u;
+        s_lut[TAB_CSM + threadIdx.x] = csm.biased[c][(j & 3u) * 4u + (j >> 2)];
+    }
+    if (threadIdx.x >= 128 && threadIdx.x < 140) {  // rows x,y,z of the (affine) inverse view matrix
+        const uint32_t t = threadIdx.x - 128u;
+        s_lut[TAB_VIEW + t] = a.inv_view[(t & 3u) * 4u + (t >> 2)];
+    }
     __shared__ float s_box[4][6];
     __shared__ uint32_t s_wave_count[4];
     __shared__ uint16_t s_list[kMaxTileLights];
@@ -71,34 +84,65 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
 
     Hn lit[4] = {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
 
+    // fp32 geometry of the GLSL passes (CSM sun, point lights): fast form where its preconditions hold
+    constexpr bool kNeedsGeom = SUN == SAH_SHADOW_MODE_CSM || LIGHTS;
+    bool geom_ok = false;
+    FastGeom g;
+    Surface<Fn> s;
+    if constexpr (kNeedsGeom) {
+        if (fast_geom) {
+            const float dn = (si.normal[0] * si.normal[0] + si.normal[1] * si.normal[1]) + si.normal[2] * si.normal[2];
+            geom_ok = surface && finite_f(p.depth) && dn > 0.f && finite_f(dn);
+            const Fn tx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]), ty = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
+            const float colx_glsl = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v, rowy_glsl = (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+            g = fast_geometry(a, f, colx_glsl, rowy_glsl, p.depth, si, dn, s_lut, geom_ok);
+        }
+        s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
+        s.normal = g.N;
+        s.roughness = Fn(si.rough);
+        s.metalness = Fn(si.metal);
+        if (__any(surface && !geom_ok)) {  // general restatement of the same quantities (IEEE operators) for the pixels that need it
+            if (surface && !geom_ok) {
+                s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});
+                const F3 vs = viewspace_position_glsl(a, x, y, p.depth);
+                const F4 ws4 = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(1.0f)});
+                g.N = s.normal;
+                g.ws = {ws4.x, ws4.y, ws4.z};
+                g.vsz = vs.z;
+                g.V = normalize(g.ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])});
+            }
+        }
+    }
+
     // (2) sun, CSM mode
     if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
+        Fn sc[4] = {Fn(0.f), Fn(0.f), Fn(0.f), Fn(1.0f)};
+        bool sun_ok = geom_ok;
+        if (fast_geom) {
+            const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
+            Fn sc3[3];
+            fast_csm_sun<false>(a, csm, s_lut, g.N, g.ws, g.vsz, g.V, L, s, si, !surface, sun_ok, sc3);
+            sc[0] = sc3[0]; sc[1] = sc3[1]; sc[2] = sc3[2];
+        }
+        if (__any(surface && !sun_ok)) {
+            if (surface && !sun_ok) sun_frag(a, csm, x, y, p, si, sc);
+        }
         if (surface) {
-            Fn s[4];
-            sun_frag(a, csm, x, y, p, si, s);
             if (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) lit[i] = Hn((s[i] * s[i] + Fn(tof(lit[i])) * Fn(tof(lit[i]))).v);
-                lit[3] = Hn((s[3] * Fn(0.f) + Fn(tof(lit[3])) * Fn(0.f)).v);
+                for (int i = 0; i < 3; i++) lit[i] = Hn((sc[i] * sc[i] + Fn(tof(lit[i])) * Fn(tof(lit[i]))).v);
+                lit[3] = Hn((sc[3] * Fn(0.f) + Fn(tof(lit[3])) * Fn(0.f)).v);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
+                for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + sc[i].v);
             }
         }
     }
 
     // (2b) point lights
     if constexpr (LIGHTS) {
-        // shading inputs as the a9 spec builds them: the sun fragment's fp32 surface, N, V and position
-        Surface<Fn> s;
-        s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
-        s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});
-        s.roughness = Fn(si.rough);
-        s.metalness = Fn(si.metal);
-        const F3 vs = viewspace_position_glsl(a, x, y, p.depth);
-        const F4 ws4 = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(1.0f)});
-        const F3 ws = {ws4.x, ws4.y, ws4.z};
-        const F3 V = normalize(ws - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])});
+        // shading inputs as the a9 spec builds them: the sun fragment's fp32 surface, N, V and position (above)
+        const F3 ws = g.ws, V = g.V;
         const PointLightDev* lights = reinterpret_cast<const PointLightDev*>(a.lights);
 
         // tile bound: box of the positions of the surface pixels (non-finite positions get 0 from every light anyway)
@@ -244,33 +288,35 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
 
 template <int SUN, int GI>
 static hipError_t launch_tiled_lights(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
-                                      const SkyArgs& sky, bool brute, hipStream_t st) {
+                                      const SkyArgs& sky, bool brute, const FastArgs* fast, hipStream_t st) {
+    const FastArgs f = fast ? *fast : FastArgs{};
+    const uint32_t fast_geom = fast ? 1u : 0u;
     const uint32_t rows = a.row_end - a.row_begin;
     if (rows == 0 || a.width == 0) return hipSuccess;
     const dim3 grid((a.width + 15) / 16, (rows + 15) / 16), block(256);
-    if (a.num_lights) hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, true>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, brute ? 1u : 0u);
-    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, 0u);
+    if (a.num_lights) hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, true>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, brute ? 1u : 0u, f, fast_geom);
+    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, 0u, f, fast_geom);
     return hipGetLastError();
 }
 
 template <int SUN>
 static hipError_t launch_tiled_gi(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
-                                  const SkyArgs& sky, int gi, bool brute, hipStream_t st) {
+                                  const SkyArgs& sky, int gi, bool brute, const FastArgs* fast, hipStream_t st) {
     switch (gi) {
-        case SAH_GI_NONE: return launch_tiled_lights<SUN, SAH_GI_NONE>(a, csm, lpv, cache, rtgi, sky, brute, st);
-        case SAH_GI_LPV: return launch_tiled_lights<SUN, SAH_GI_LPV>(a, csm, lpv, cache, rtgi, sky, brute, st);
-        case SAH_GI_CACHE: return launch_tiled_lights<SUN, SAH_GI_CACHE>(a, csm, lpv, cache, rtgi, sky, brute, st);
-        case SAH_GI_RTGI: return launch_tiled_lights<SUN, SAH_GI_RTGI>(a, csm, lpv, cache, rtgi, sky, brute, st);
+        case SAH_GI_NONE: return launch_tiled_lights<SUN, SAH_GI_NONE>(a, csm, lpv, cache, rtgi, sky, brute, fast, st);
+        case SAH_GI_LPV: return launch_tiled_lights<SUN, SAH_GI_LPV>(a, csm, lpv, cache, rtgi, sky, brute, fast, st);
+        case SAH_GI_CACHE: return launch_tiled_lights<SUN, SAH_GI_CACHE>(a, csm, lpv, cache, rtgi, sky, brute, fast, st);
+        case SAH_GI_RTGI: return launch_tiled_lights<SUN, SAH_GI_RTGI>(a, csm, lpv, cache, rtgi, sky, brute, fast, st);
         default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_lighting_tiled(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
-                                 const SkyArgs& sky, int sun_mode, int gi, bool brute_force_lights, hipStream_t st) {
+                                 const SkyArgs& sky, int sun_mode, int gi, bool brute_force_lights, const FastArgs* fast, hipStream_t st) {
     switch (sun_mode) {
-        case SAH_SHADOW_MODE_OFF: return launch_tiled_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, st);
-        case SAH_SHADOW_MODE_CSM: return launch_tiled_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, st);
-        case SAH_SHADOW_MODE_RT: return launch_tiled_gi<SAH_SHADOW_MODE_RT>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, st);
+        case SAH_SHADOW_MODE_OFF: return launch_tiled_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, fast, st);
+        case SAH_SHADOW_MODE_CSM: return launch_tiled_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, fast, st);
+        case SAH_SHADOW_MODE_RT: return launch_tiled_gi<SAH_SHADOW_MODE_RT>(a, csm, lpv, cache, rtgi, sky, gi, brute_force_lights, fast, st);
         default: return hipErrorInvalidValue;
     }
 }
