@@ -1,5 +1,6 @@
 #!/bin/bash
-# (TA_* / TCP_* derived counters are left out: that group made rocprofv3 abort and stall on this pool.)
+# (The derived TA_* / TCP_* counters are not in these groups: eight of them in ONE pass made rocprofv3 abort in round 1 — too many
+#  hardware counter slots for one pass; one or two per pass collect fine, see tools/refresh_profiles.sh and profiles/r2_pmc_ta_tcp_probe.txt.)
 # Collect hardware counters for one bench.py workload, one rocprofv3 --pmc pass per counter group (never combined with tracing),
 # and print the per-kernel means.   usage: tools/pmc_collect.sh <out-dir> [bench.py args...]
 set -u
