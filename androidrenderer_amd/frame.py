@@ -121,13 +121,10 @@ class LightingInputs:
                 gi.probe_irradiance = images.volume(arrays["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
                 gi.probe_depth = images.volume(arrays["probe_depth"], _abi.FORMAT_R16G16_SFLOAT)
                 gi.probe_validity = images.volume(arrays["probe_val"], _abi.FORMAT_R8_UNORM)
-                pos = self.view.position
-                for c in range(4):
-                    spacing = 0.5 * (2.0 ** c)  # stand-in placement: cascades centred on the camera
+                for c, (cmin, spacing) in enumerate(self.probe_cascades()):
                     gi.probe_cascades[c].probe_spacing = spacing
-                    ext = (32 * spacing, 8 * spacing, 32 * spacing)
                     for i in range(3):
-                        gi.probe_cascades[c].min[i] = float(pos[i]) - ext[i] / 2.0 + 0.013 * (c + 1)
+                        gi.probe_cascades[c].min[i] = cmin[i]
                 gi.probe_size[0], gi.probe_size[1] = 5, 6  # irradiance_cache.cpp:298-299
                 gi.cache_debug_mode = self.cache_debug_mode
             elif self.gi_kind == _abi.GI_RTGI:
@@ -148,6 +145,17 @@ class LightingInputs:
         d.row_begin, d.row_end = self.row_begin, self.row_end
         keep.append(arrays)
         return d, keep
+
+    def probe_cascades(self):
+        """Stand-in placement of the four irradiance-cache cascades: centred on the camera, spacing 0.5 m doubling per cascade.
+        Returns [(min xyz, spacing)] as Python floats (the ABI struct rounds them to fp32)."""
+        pos = self.view.position
+        out = []
+        for c in range(4):
+            spacing = 0.5 * (2.0 ** c)
+            ext = (32 * spacing, 8 * spacing, 32 * spacing)
+            out.append(([float(pos[i]) - ext[i] / 2.0 + 0.013 * (c + 1) for i in range(3)], spacing))
+        return out
 
     def inputs_sha256(self):
         m = hashlib.sha256()

@@ -11,12 +11,14 @@ from androidrenderer_amd import _abi, images, synth
 from tests import util
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-LIGHTING = ("lighting_csm_lpv", "lighting_rt", "lighting_csm", "lighting_rt_rtgi", "lighting_csm_lights")
+LIGHTING = ("lighting_csm_lpv", "lighting_rt", "lighting_csm", "lighting_rt_rtgi", "lighting_csm_lights",
+            "lighting_rt_cache_sky",   # a4 irradiance-cache gather + a6 sky fill: the reference's default configuration
+            "lighting_csm_lpv_sky")    # a6 on the fast path (its own sky kernel)
 
 
 def _frame(name):
     g = np.load(os.path.join(GOLDEN, f"{name}_64x36.npz"))
-    f = util.golden_lighting_frame(64, 36, int(g["seed"]), int(g["sun_mode"]), int(g["gi"]))
+    f = util.golden_lighting_frame(64, 36, int(g["seed"]), int(g["sun_mode"]), int(g["gi"]), sky=bool(int(g["sky"])) if "sky" in g.files else False)
     assert f.inputs_sha256() == str(g["inputs_sha256"]), "synthetic input generators drifted: re-run tools/gen_golden.py"
     if "lights" in g.files:  # point-light list of the a9 fixture (stored with the image)
         f.lights = np.ascontiguousarray(g["lights"], dtype=np.float32)
@@ -27,6 +29,20 @@ def _frame(name):
 def _lpv_fixture():
     g = np.load(os.path.join(GOLDEN, "lpv_propagate_2c_3steps.npz"))
     return [g[f"in{i}"].copy() for i in range(3)], [g[f"out{i}"] for i in range(3)]
+
+
+def _probe_update_fixture():
+    """Inputs (regenerated from the seed) and the expected atlases: the inputs with the golden's changed texels applied."""
+    g = np.load(os.path.join(GOLDEN, "probe_update_48.npz"))
+    atl, trace, ids = synth.probe_maintenance_inputs(seed=int(g["seed"]), num_probes=int(g["num_probes"]))
+    want = {}
+    for k, v in atl.items():
+        w = (v.view(np.uint16) if v.dtype == np.float16 else v).copy()
+        idx = tuple(g[f"{k}_idx"].T.astype(np.int64))
+        w[idx] = g[f"{k}_val"]
+        assert len(idx[0]) > 0
+        want[k] = w
+    return atl, trace, ids, want
 
 
 def _post_inputs():
@@ -128,3 +144,28 @@ def test_hip_matches_golden_copy_scene_and_lpv_propagate(hip_ctx):
     assert np.array_equal(util.from_torch(o_t, np.uint16), want)
     for c in range(3):
         assert np.array_equal(util.from_torch(b_t[c], np.uint16), want_b[c]), f"lpv channel {c}"
+
+
+def test_oracle_matches_golden_probe_update():
+    atl, trace, ids, want = _probe_update_fixture()
+    o = util.oracle()
+    a = util.probe_atlases_desc(atl)
+    tv = images.volume(trace.view(np.uint16), _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_probe_update(C.byref(a), C.byref(tv), ids.ctypes.data, len(ids)) == 0
+    for k, w in want.items():
+        got = atl[k].view(np.uint16) if atl[k].dtype == np.float16 else atl[k]
+        assert np.array_equal(got, w), f"atlas {k}: {int((got != w).sum())} words differ"
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_probe_update(hip_ctx):
+    import torch
+    atl, trace, ids, want = _probe_update_fixture()
+    a_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in atl.items()}
+    tr_t = util.to_torch(trace.view(np.uint16))
+    ids_t = torch.from_numpy(ids.view(np.int32)).cuda()
+    hip_ctx.probe_update(util.probe_atlases_desc(a_t), images.volume(tr_t, _abi.FORMAT_R16G16B16A16_SFLOAT), ids_t.data_ptr(), len(ids))
+    torch.cuda.synchronize()
+    for k, w in want.items():
+        got = a_t[k].cpu().numpy()
+        assert np.array_equal(got.view(w.dtype).reshape(w.shape), w), f"atlas {k} differs"

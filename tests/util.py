@@ -122,10 +122,10 @@ class LightingFrame(frame.LightingInputs):
         return lit
 
 
-def golden_lighting_frame(width, height, seed, sun_mode, gi):
+def golden_lighting_frame(width, height, seed, sun_mode, gi, sky=False):
     """The inputs behind tests/golden/lighting_*.npz (tools/gen_golden.py): atrium G-buffer, no sky LUTs, a 128² CSM, and
     roughness bytes >= 1 so the LPV specular quirk term is exactly zero (the golden generator does not model it)."""
-    f = LightingFrame(width, height, seed=seed, sun_mode=sun_mode, gi=gi, flavour="atrium", sky=False, shadowmap_res=128)
+    f = LightingFrame(width, height, seed=seed, sun_mode=sun_mode, gi=gi, flavour="atrium", sky=sky, shadowmap_res=128)
     f.arrays["data"] = f.arrays["data"].copy()
     f.arrays["data"][..., 1] = np.maximum(f.arrays["data"][..., 1], 1)
     return f

@@ -139,12 +139,66 @@ def trilinear_border(vol, u, v, w):
     return acc
 
 
+def bilinear_repeat(img, u, v, layer=None):
+    """img (H, W, C) or (L, H, W, C) fp32; REPEAT addressing; weights and fma chain as bilinear_clamp."""
+    H, W = img.shape[-3], img.shape[-2]
+    x0, wx0, fx = axis(u, W)
+    y0, wy0, fy = axis(v, H)
+    acc = np.zeros(u.shape + (img.shape[-1],), dtype=f32)
+    for (dy, dx, w) in ((0, 0, F(wx0 * wy0)), (0, 1, F(fx * wy0)), (1, 0, F(wx0 * fy)), (1, 1, F(fx * fy))):
+        yy, xx = np.mod(y0 + dy, H), np.mod(x0 + dx, W)
+        t = img[yy, xx] if layer is None else img[layer, yy, xx]
+        acc = fma(w[..., None], t, acc)
+    return acc
+
+
+def unpack_b10g11r11(words):
+    """B10G11R11_UFLOAT_PACK32: r = bits 0-10 (5 exponent, 6 mantissa), g = bits 11-21, b = bits 22-31 (5 exponent, 5 mantissa);
+    unsigned small floats with the fp16 exponent bias, so each is an fp16 bit pattern with the low mantissa bits zero."""
+    w = words.astype(np.uint32)
+    r = ((w & 0x7FF) << 4).astype(np.uint16).view(np.float16)
+    g = (((w >> 11) & 0x7FF) << 4).astype(np.uint16).view(np.float16)
+    b = (((w >> 22) & 0x3FF) << 5).astype(np.uint16).view(np.float16)
+    return np.stack([r, g, b], axis=-1).astype(f32)
+
+
+def length3(v, rnd=F):
+    return rnd(np.sqrt(rnd(rnd(rnd(v[0] * v[0]) + rnd(v[1] * v[1])) + rnd(v[2] * v[2]))))
+
+
+def cross3(a, b):
+    return [F(F(a[1] * b[2]) - F(b[1] * a[2])), F(F(a[2] * b[0]) - F(b[2] * a[0])), F(F(a[0] * b[1]) - F(b[0] * a[1]))]
+
+
+def octahedral_coordinates(d):
+    """common/octahedral.slangi:56-63."""
+    l1 = F(F(np.abs(d[0]) + np.abs(d[1])) + np.abs(d[2]))
+    inv = F(f32(1) / l1)
+    u, v = F(d[0] * inv), F(d[1] * inv)
+    su, sv = np.where(u >= 0, f32(1), f32(-1)), np.where(v >= 0, f32(1), f32(-1))
+    fu, fv = F(F(f32(1) - np.abs(v)) * su), F(F(f32(1) - np.abs(u)) * sv)
+    neg = d[2] < 0
+    return np.where(neg, fu, u), np.where(neg, fv, v)
+
+
+def probe_uv(pidx, oct_uv, n):
+    """common/octahedral.slangi:65-74 -> (u, v); the layer is pidx[2]."""
+    out = []
+    for i in range(2):
+        total = F(f32(n[i]) + f32(2))
+        size = F(total * f32(32))
+        c = F(F(pidx[i].astype(f32) * total) + F(total * f32(0.5)))
+        c = F(c + F(oct_uv[i] * F(f32(n[i]) * f32(0.5))))
+        out.append(F(c / size))
+    return out
+
+
 # ---- the Lighting pass, per sub-pass --------------------------------------------------------------------------------------
 class Frame:
-    def __init__(self, W, Hh, seed, sun_mode, gi):
+    def __init__(self, W, Hh, seed, sun_mode, gi, sky=False):
         self.W, self.H = W, Hh
         from tests import util  # only its input builder is used here, never the oracle
-        self.f = util.golden_lighting_frame(W, Hh, seed, sun_mode, gi)
+        self.f = util.golden_lighting_frame(W, Hh, seed, sun_mode, gi, sky=sky)
         a = self.f.arrays
         self.view, self.sun = self.f.view.gpu_data, self.f.sun.constants
         lut = srgb_lut()
@@ -328,9 +382,166 @@ class Frame:
             total = [F(total[i] + np.where(bad, f32(0), c[i])) for i in range(3)]
         return [F(t * f32(0.00031415927)) for t in total]
 
+    def cache_overlay(self):
+        """gi/cache/overlay.frag.slang:46-118 + probe_sampling.slangi:6-106 (debug_mode 0). Returns (rgb, drawn): the fragment is
+        blended for every surface pixel, with colour 0 outside all cascades."""
+        _, ws = self.position(False)
+        loc = ws[:3]
+        shape = self.depth.shape
+        view = np.array(self.view.view[:], dtype=f32)
+        cam = [F(-view[12 + i]) for i in range(3)]
+        Nh = normalize3([h(n) for n in self.nrm], h)
+        with np.errstate(invalid="ignore"):
+            V = [h(x) for x in normalize3([F(loc[i] - cam[i]) for i in range(3)])]
+        cascades = [([f32(m) for m in cmin], f32(sp)) for (cmin, sp) in self.f.probe_cascades()]
+        ci = np.full(shape, 5, dtype=np.int64)
+        for i in (3, 2, 1, 0):  # first match wins
+            cmin, sp = cascades[i]
+            cmax = [F(cmin[k] + F(f32(e) * sp)) for k, e in enumerate((32, 8, 32))]
+            inside = np.ones(shape, dtype=bool)
+            for k in range(3):
+                inside &= (loc[k] > cmin[k]) & (loc[k] < cmax[k])
+            ci = np.where(inside, i, ci)
+        has = ci <= 3
+        cs = np.where(has, ci, 0)
+        spacing = np.array([c[1] for c in cascades], dtype=f32)[cs]
+        cmin = [np.array([c[0][k] for c in cascades], dtype=f32)[cs] for k in range(3)]
+
+        irr_atlas = unpack_b10g11r11(self.f.arrays["probe_irr"])          # (32, 256, 224, 3)
+        depth_atlas = self.f.arrays["probe_depth"].astype(f32)             # (32, 384, 384, 2)
+        validity = self.f.arrays["probe_val"]                              # (32, 32, 32) u8
+        psize = (5, 6)                                                     # irradiance_cache.cpp:298-299
+
+        ps = [F(F(loc[k] - cmin[k]) / spacing) for k in range(3)]
+        mp = [np.floor(p) for p in ps]
+        alpha = [clamp01(F(ps[k] - mp[k])) for k in range(3)]
+        irr = [np.zeros(shape, dtype=f32) for _ in range(3)]
+        weight = np.zeros(shape, dtype=f32)
+        ioct = octahedral_coordinates(Nh)
+        for i in range(8):
+            off = [f32(i & 1), f32((i >> 1) & 1), f32((i >> 2) & 1)]
+            pl = [F(mp[k] + off[k]) for k in range(3)]
+            to_probe = [F(pl[k] - ps[k]) for k in range(3)]
+            dist = F(length3(to_probe) * spacing)
+            pf = [pl[0], F(pl[1] + F(cs.astype(f32) * f32(8))), pl[2]]
+            with np.errstate(invalid="ignore"):
+                pidx = [np.where(p > 0, p, f32(0)).astype(np.int64) for p in pf]   # float -> uint: NaN / negative -> 0
+            inr = (pidx[0] < 32) & (pidx[1] < 32) & (pidx[2] < 32)
+            val = np.where(inr, validity[np.minimum(pidx[2], 31), np.minimum(pidx[1], 31), np.minimum(pidx[0], 31)], 0)
+            live = val != 0
+            tri = [np.maximum(f32(0.001), F(F(F(f32(1) - alpha[k]) * F(f32(1) - off[k])) + F(alpha[k] * off[k]))) for k in range(3)]
+            tw = F(F(tri[0] * tri[1]) * tri[2])
+            layer = np.minimum(pidx[2], 31)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                doct = octahedral_coordinates([F(-t) for t in to_probe])
+                duv = probe_uv(pidx, doct, (10, 10))
+                dt = h(bilinear_repeat(depth_atlas, np.nan_to_num(duv[0]), np.nan_to_num(duv[1]), layer))
+                dx, dy = dt[..., 0], dt[..., 1]
+                variance = np.abs(h(h(dx * dx) - dy))
+                v = F(dist - dx)
+                cheb = F(variance / F(variance + F(v * v)))
+                cheb = np.maximum(F(F(cheb * cheb) * cheb), f32(0))
+                cheb = np.where(dist > dx, cheb, f32(1))
+                pw = np.maximum(f32(0.05), cheb)
+                pw = np.maximum(f32(0.000001), pw)
+                k_crush = F(f32(1) / F(f32(0.2) * f32(0.2)))
+                pw = np.where(pw < f32(0.2), F(pw * F(F(pw * pw) * k_crush)), pw)
+                pw = F(pw * tw)
+                iuv = probe_uv(pidx, ioct, psize)
+                it = h(bilinear_repeat(irr_atlas, iuv[0], iuv[1], layer))
+                for c in range(3):
+                    irr[c] = np.where(live, F(irr[c] + F(it[..., c] * pw)), irr[c])
+                weight = np.where(live, F(weight + pw), weight)
+        pi_h = h(f32(3.1415927))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            irr = [np.where(weight == 0, f32(0), F(F(F(irr[c] / weight) * f32(2)) * pi_h)) for c in range(3)]
+        irr_h = [h(x) for x in irr]
+        b = brdf([h(c) for c in self.base], Nh, h(self.rough), h(self.metal), Nh, V, h)
+        ex = np.float64(0.314159).astype(np.float16).astype(f32)
+        col = [h(h(b[c] * irr_h[c]) * ex) for c in range(3)]
+        bad = np.isnan(col[0]) | np.isnan(col[1]) | np.isnan(col[2])
+        return [np.where(bad | ~has, f32(0), c) for c in col]
+
+    def sky_fill(self):
+        """sky/sky_unified.slang:185-206 (main_fs) with :54-166; transcendentals in fp64 rounded to fp32. Returns half rgb."""
+        v = self.view
+        res = (f32(v.render_resolution[0]), f32(v.render_resolution[1]))
+        sx, sy = F(F(F(self.xs + f32(0.5)) + f32(0.5)) / res[0]), F(F(F(self.ys + f32(0.5)) + f32(0.5)) / res[1])   # fragcoord.xy + 0.5
+        one = np.ones_like(sx)
+        ip = np.array(v.inverse_projection[:], dtype=f32)
+        iv = np.array(v.inverse_view[:], dtype=f32)
+        vs = mat_vec(ip, [sx, sy, one, one])                     # clip xy is the [0,1] screen location (not remapped)
+        vs = [F(vs[i] / vs[3]) for i in range(4)]
+        wv = mat_vec(iv, [vs[0], vs[1], vs[2], np.zeros_like(sx)])
+        n = normalize3(wv[:3])
+        ray = [F(-n[0]), F(F(-n[1]) * f32(-1)), F(-n[2])]
+        sd = np.array(self.sun.direction_and_tan_size[:3], dtype=f32)
+        sn = normalize3([sd[0], sd[1], sd[2]])
+        sun = [F(-x) for x in sn]
+        lut_v = self.f.arrays["sky_v"].astype(f32)
+        lut_t = self.f.arrays["sky_t"].astype(f32)
+
+        PI = f32(3.14159265358)
+        ground, atmosphere = f32(6.360), f32(6.460)
+        view_pos = [f32(0), F(ground + f32(0.0002)), f32(0)]
+        acos = lambda x: np.arccos(np.asarray(x, np.float64)).astype(f32)
+        # getValFromSkyLUT :80-109
+        height = length3(view_pos)
+        up = [F(p / height) for p in view_pos]
+        horizon = acos(clamp_s(F(np.sqrt(F(F(height * height) - F(ground * ground))) / height), f32(-1), f32(1)))
+        ru = dot3_r(ray, up)
+        altitude = F(horizon - acos(ru))
+        right = cross3(sun, up)
+        forward = cross3(up, right)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            proj = normalize3([F(ray[i] - F(up[i] * ru)) for i in range(3)])
+            sin_t, cos_t = dot3_r(proj, right), dot3_r(proj, forward)
+            az = F(np.arctan(np.asarray(F(cos_t / sin_t), np.float64)).astype(f32) + PI)
+        az = np.where(np.abs(altitude) > F(F(f32(0.5) * PI) - f32(0.0001)), f32(0), az)
+        sgn = np.sign(altitude).astype(f32)
+        vv = F(f32(0.5) + F(F(f32(0.5) * sgn) * F(np.sqrt(F(F(np.abs(altitude) * f32(2.0)) / PI)))))
+        uu = F(az / F(f32(2.0) * PI))
+        lum = bilinear_repeat(lut_v, uu, vv)
+        # sunWithBloom :120-135
+        solid = F(F(f32(0.53) * PI) / f32(180.0))
+        min_cos = f32(np.cos(np.float64(solid)))
+        cos_theta = dot3_r(ray, sun)
+        offset = F(min_cos - cos_theta)
+        gauss = F(np.exp(np.asarray(F(F(-offset) * f32(50000.0)), np.float64)).astype(f32) * f32(0.5))
+        inv = F(F(f32(1.0) / F(f32(0.02) + F(offset * f32(300.0)))) * f32(0.01))
+        s = np.where(cos_theta >= min_cos, f32(1), F(gauss + inv))
+        # smoothstep(0.002h, 1.0h, .) :143
+        e0, e1 = np.float64(0.002).astype(np.float16).astype(f32), f32(1.0)
+        t = clamp01(F(F(s - e0) / F(e1 - e0)))
+        s = F(F(t * t) * F(f32(3.0) - F(f32(2.0) * t)))
+        # :144-155
+        applied = length3([s, s, s]) > 0
+        b = dot3_r(view_pos, ray)
+        c = F(dot3_r(view_pos, view_pos) - F(ground * ground))
+        discr = F(F(b * b) - c)
+        with np.errstate(invalid="ignore"):
+            root = np.sqrt(discr)
+            hit_t = np.where(discr > F(b * b), F(F(-b) + root), F(F(-b) - root))
+        hit_t = np.where(discr < 0, f32(-1), hit_t)
+        hit_t = np.where((c > 0) & (b > 0), f32(-1), hit_t)
+        # getValFromTLUT :111-118 at viewPos
+        sun_cos = dot3_r(sun, up)
+        tu = clamp_s(F(f32(0.5) + F(f32(0.5) * sun_cos)), f32(0), f32(1))
+        tv = np.maximum(f32(0), np.minimum(f32(1), F(F(height - ground) / F(atmosphere - ground))))
+        trans = bilinear_repeat(lut_t, np.full_like(sx, tu), np.full_like(sx, tv))
+        out = []
+        for ch in range(3):
+            sl = np.where(applied, np.where(hit_t >= 0, f32(0), F(s * trans[..., ch])), s)
+            out.append(h(F(F(F(lum[..., ch] + sl) * f32(20.0)) * f32(1.0))))
+        return out
+
 
 def dot3_r(a, b):
     return F(F(F(a[0] * b[0]) + F(a[1] * b[1])) + F(a[2] * b[2]))
+
+
+def clamp_s(x, lo, hi):
+    return np.minimum(np.maximum(x, lo), hi)
 
 
 def brdf_fd_nn(base, n, rough, metal):
@@ -361,8 +572,8 @@ def compose(fr, sun_mode, gi, lights=None):
         for i in range(3):
             lit[i] = np.where(surf, h(F(lit[i] + pl[i])), lit[i])
         lit[3] = np.where(surf, h(F(lit[3] + f32(1))), lit[3])
-    if gi in (_abi.GI_LPV, _abi.GI_RTGI):
-        g = fr.lpv_overlay() if gi == _abi.GI_LPV else fr.rtgi_overlay()
+    if gi in (_abi.GI_LPV, _abi.GI_RTGI, _abi.GI_CACHE):
+        g = fr.lpv_overlay() if gi == _abi.GI_LPV else fr.rtgi_overlay() if gi == _abi.GI_RTGI else fr.cache_overlay()
         for i in range(3):
             lit[i] = np.where(surf, h(F(lit[i] + g[i])), lit[i])
         lit[3] = np.where(surf, h(F(lit[3] + f32(1))), lit[3])
@@ -370,6 +581,11 @@ def compose(fr, sun_mode, gi, lights=None):
     for i in range(3):
         lit[i] = h(F(lit[i] + e[i]))
     lit[3] = h(F(lit[3] + f32(1)))
+    if fr.f.has_sky:  # procedural_sky.cpp:151-172: depth == 0 pixels are overwritten (no blending)
+        sky = fr.sky_fill()
+        for i in range(3):
+            lit[i] = np.where(surf, lit[i], sky[i])
+        lit[3] = np.where(surf, lit[3], f32(1))
     if sun_mode == _abi.SHADOW_MODE_RT:
         a = fr.sun_rt()
         for i in range(3):
@@ -523,6 +739,118 @@ def lpv_propagate(vols, steps, num_cascades=1):
     return cur
 
 
+# ---- irradiance-cache probe update (a11) ------------------------------------------------------------------------------------
+def pack_b10g11r11(rgb_half):
+    """half3 -> B10G11R11 as a storage-image write does it under the contract (round toward zero, negatives -> 0):
+    the unsigned small floats are the leading bits of the fp16 pattern."""
+    b = np.asarray(rgb_half, dtype=np.float16).view(np.uint16).astype(np.uint32)
+    b = np.where(b & 0x8000, 0, b)
+    return int(((b[0] >> 4) & 0x7FF) | (((b[1] >> 4) & 0x7FF) << 11) | (((b[2] >> 5) & 0x3FF) << 22))
+
+
+def texel_octahedral_direction(tx, ty, nx, ny):
+    """common/octahedral.slangi:25-39 then :44-50, fp32."""
+    cx = F(F(F(F(f32(tx % nx) + f32(0.5)) / f32(nx)) * f32(2)) - f32(1))
+    cy = F(F(F(F(f32(ty % ny) + f32(0.5)) / f32(ny)) * f32(2)) - f32(1))
+    d = [cx, cy, F(F(f32(1) - np.abs(cx)) - np.abs(cy))]
+    if d[2] < 0:
+        sx, sy = (f32(1) if d[0] >= 0 else f32(-1)), (f32(1) if d[1] >= 0 else f32(-1))
+        d[0], d[1] = F(F(f32(1) - np.abs(cy)) * sx), F(F(f32(1) - np.abs(cx)) * sy)
+    return normalize3(d)
+
+
+def border_targets(rx, ry, pid, tx, ty):
+    """probe_update.slangi:4-37: the texels one invocation stores its value to, in program order (x, y, layer)."""
+    bx, by, bz = int(pid[0]) * (rx + 2), int(pid[1]) * (ry + 2), int(pid[2])
+    sgn = lambda v: (v > 0) - (v < 0)
+    ge0 = lambda v: 1 if v >= 0 else 0
+    edge_x, edge_y = tx in (0, rx - 1), ty in (0, ry - 1)
+    mx, my = tx - rx // 2, ty - ry // 2
+    mx, my = mx + ge0(mx), my + ge0(my)
+    out = [(tx + bx, ty + by, bz)]
+    if edge_x and edge_y:
+        dx, dy = -mx - ge0(mx) + rx // 2, -my - ge0(my) + ry // 2
+        out.append((dx + bx, dy + by, bz))
+    if edge_x:
+        ex, ey = mx + sgn(mx), -my
+        ex, ey = ex - ge0(ex) + rx // 2, ey - ge0(ey) + ry // 2
+        out.append((ex + bx, ey + by, bz))
+    if edge_y:
+        ex, ey = -mx, my + sgn(my)
+        ex, ey = ex - ge0(ex) + rx // 2, ey - ge0(ey) + ry // 2
+        out.append((ex + bx, ey + by, bz))
+    return out
+
+
+def probe_update(atl, trace, ids):
+    """probe_depth_update / probe_light_cache_update / probe_rtgi_update / probe_finalize (.comp.slang), one workgroup per listed
+    probe, with the order include/sah_hip.h defines where the shaders race: invocations in ascending linear index, stores in program
+    order, the wave sum in lane order in fp16.  atl: dict of the five atlases (modified in place); trace (P, 20, 20, 4) fp16."""
+    H16 = np.float16
+    tr = trace.astype(H16)
+
+    def fetch(p, x, y):  # out-of-range image loads return 0
+        return tr[p, y, x] if (0 <= x < 20 and 0 <= y < 20) else np.zeros(4, H16)
+
+    def store(img, targets, value):
+        L, Hh, W = img.shape[:3]
+        for (x, y, z) in targets:
+            if 0 <= x < W and 0 <= y < Hh and 0 <= z < L:
+                img[z, y, x] = value
+
+    with np.errstate(over="ignore", invalid="ignore"):
+        for p, pid in enumerate(ids):          # depth moments, 10 x 10 threads
+            for ty in range(10):
+                for tx in range(10):
+                    depth, n = H16(0), H16(0)
+                    for i in range(4):
+                        d = fetch(p, tx * 2 + i % 2, ty * 2 + i // 2)[3]
+                        if d > 0:
+                            depth, n = H16(depth + d), H16(n + H16(1))
+                    depth = H16(depth / n) if n > 0 else H16(0)
+                    store(atl["depth"], border_targets(10, 10, pid, tx, ty), np.array([depth, H16(depth * depth)], H16))
+        for p, pid in enumerate(ids):          # light cache, 11 x 11 threads, filter = ceil(20 / 11) = 2
+            for ty in range(11):
+                for tx in range(11):
+                    direction = [np.float32(H16(c)) for c in texel_octahedral_direction(tx, ty, 11, 11)]
+                    light, n = np.zeros(3, H16), H16(0)
+                    for i in range(4):
+                        rx, ry = tx * 2 + i % 2, ty * 2 + i // 2
+                        t = fetch(p, rx, ry)
+                        if t[3] > 0:
+                            w = H16(dot3_r(direction, texel_octahedral_direction(rx, ry, 20, 20)))   # dot(half3, float3) is a float dot
+                            light = np.array([H16(H16(t[c] * w) + light[c]) for c in range(3)], H16)
+                            n = H16(n + H16(1))
+                    light = np.array([H16(c / n) for c in light], H16) if n > 0 else np.zeros(3, H16)
+                    store(atl["light_cache"], border_targets(11, 11, pid, tx, ty), pack_b10g11r11(light))
+        for p, pid in enumerate(ids):          # irradiance, 5 x 6 threads, filter = 20 / 5 = 4 (in x AND y: rows 0..23)
+            for ty in range(6):
+                for tx in range(5):
+                    light, n = np.zeros(3, H16), H16(0)
+                    for i in range(16):
+                        t = fetch(p, tx * 4 + i % 4, ty * 4 + i // 4)
+                        if t[3] > 0:
+                            light = np.array([H16(light[c] + t[c]) for c in range(3)], H16)
+                            n = H16(n + H16(1))
+                    light = np.array([H16(c / n) for c in light], H16) if n > 0 else np.zeros(3, H16)
+                    store(atl["rtgi"], border_targets(5, 6, pid, tx, ty), pack_b10g11r11(light))
+        for p, pid in enumerate(ids):          # finalize: 64 lanes, every lane tests texels idx = 0 and idx = 64 (the loop ignores the lane)
+            x0, y0, z0 = int(pid[0]), int(pid[1]), int(pid[2])
+            valid = 0
+            for idx in (0, 64):
+                d = atl["depth"][z0, y0 * 12 + idx // 10 + 1, x0 * 12 + idx % 10 + 1, 0]
+                if d > 0:
+                    valid += 64
+            v = np.float32(H16(H16(valid) / H16(100)))
+            atl["validity"][z0, y0, x0] = 255 if v >= 1 else (0 if not v > 0 else int(F(F(v * f32(255)) + f32(0.5))))
+            total = None
+            for lane in range(30):             # x = lane % 5, y = lane / 6 (sic)
+                t = unpack_b10g11r11(atl["rtgi"][z0, y0 * 8 + lane // 6 + 1, x0 * 7 + lane % 5 + 1]).astype(H16)
+                total = t if total is None else np.array([H16(total[c] + t[c]) for c in range(3)], H16)
+            atl["average"][z0, y0, x0] = pack_b10g11r11(np.array([H16(c / H16(30)) for c in total], H16))
+    return atl
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -553,6 +881,15 @@ def main():
     np.savez_compressed(os.path.join(GOLDEN, f"lighting_csm_lights_{W}x{Hh}.npz"), lit=lit, seed=106, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE,
                         lights=lights, inputs_sha256=inputs_digest(fr.f.arrays))
     print("lighting_csm_lights ok")
+    # irradiance-cache gather (a4) and sky fill (a6): the reference's default configuration (RT sun + probe GI + sky), and the
+    # fast path's sky (CSM + LPV + sky)
+    for name, sun_mode, gi, seed in (("lighting_rt_cache_sky", _abi.SHADOW_MODE_RT, _abi.GI_CACHE, 109),
+                                     ("lighting_csm_lpv_sky", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, 110)):
+        fr = Frame(W, Hh, seed, sun_mode, gi, sky=True)
+        lit = compose(fr, sun_mode, gi)
+        np.savez_compressed(os.path.join(GOLDEN, f"{name}_{W}x{Hh}.npz"), lit=lit, seed=seed, sun_mode=sun_mode, gi=gi, sky=1,
+                            inputs_sha256=inputs_digest(fr.f.arrays))
+        print(name, "ok", "sky pixels:", int((fr.depth == 0).sum()))
     # copy scene (a13) of the CSM + LPV image
     src = np.load(os.path.join(GOLDEN, f"lighting_csm_lpv_{W}x{Hh}.npz"))["lit"]
     np.savez_compressed(os.path.join(GOLDEN, f"copy_scene_{W}x{Hh}.npz"), out=copy_scene(src))
@@ -568,6 +905,20 @@ def main():
     np.savez_compressed(os.path.join(GOLDEN, "lpv_propagate_2c_3steps.npz"), **{f"in{i}": vols[i].view(np.uint16) for i in range(3)},
                         **{f"out{i}": out[i].view(np.uint16) for i in range(3)})
     print("lpv_propagate ok")
+
+    # probe maintenance (a11): 48 probes incl. the grid corners, an all-miss and an all-hit probe; stored as the changed texels
+    atl, trace, ids = synth.probe_maintenance_inputs(seed=111, num_probes=48)
+    before = {k: v.copy() for k, v in atl.items()}
+    probe_update(atl, trace, ids)
+    sparse = {}
+    for k in atl:
+        a, b = atl[k], before[k]
+        changed = (a != b) if a.ndim == 3 else (a.view(np.uint16) != b.view(np.uint16)).any(axis=-1)
+        idx = np.argwhere(changed).astype(np.int16)
+        sparse[f"{k}_idx"] = idx
+        sparse[f"{k}_val"] = a[tuple(idx.T.astype(np.int64))] if a.dtype != np.float16 else a.view(np.uint16)[tuple(idx.T.astype(np.int64))]
+        print("probe_update", k, len(idx), "texels changed")
+    np.savez_compressed(os.path.join(GOLDEN, "probe_update_48.npz"), seed=111, num_probes=48, **sparse)
 
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
