@@ -412,6 +412,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         }
         cache.probe_size[0] = gi.probe_size[0];
         cache.probe_size[1] = gi.probe_size[1];
+        for (int i = 0; i < 2; i++) cache.inv_tex[i] = 1.0f / (((float)gi.probe_size[i] + 2.0f) * 32.0f);
         cache.debug_mode = gi.cache_debug_mode;
         auto bytes = [](const sah_volume& v) { return (uint64_t)v.slice_pitch_bytes * v.depth; };
         cache.hot_ok = bytes(gi.probe_irradiance) < (1ull << 32) && bytes(gi.probe_depth) < (1ull << 32) && bytes(gi.probe_validity) < (1ull << 32) &&

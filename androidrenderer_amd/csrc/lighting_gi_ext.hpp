@@ -226,51 +226,115 @@ SAH_DEV F2 octahedral_coordinates_nr(F3 dir, bool& bad) {
     return {fold ? r.x : uv.x, fold ? r.y : uv.y};
 }
 
+// a / b for a divisor known on the host: z = RN(1 / b).  One correction step is exact for every b = 32 (n + 2), n = 1..30, and every
+// fp32 a in [0.5, b] (tools/microbench/div_const_check.c, exhaustive) — the range probe texcoords live in; other operands belong to
+// pixels that are re-evaluated anyway.
+SAH_DEV float div_const(float a, float b, float z) {
+    const float q0 = a * z;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r0, z, q0);
+}
+// One axis of bilinear_setup_probe(): texel offset of the first tap (clamped as there) and the two weights.
+struct ProbeAxis {
+    uint32_t off;  // x0 * 4 or y0 * row_pitch
+    float w0, w1;
+};
+SAH_DEV ProbeAxis probe_axis(float u, uint32_t size, uint32_t stride) {
+    const float p = u * (float)size - 0.5f;
+    const float f0 = __builtin_floorf(p);
+    const float f = p - f0;
+    const int i0 = min(max(clamp_to_int(f0), 0), (int)size - 2);
+    return {(uint32_t)i0 * stride, 1.0f - f, f};
+}
+
+// Everything that depends on one axis only (probe_location, its distance term, index, trilinear weight, the irradiance texcoord
+// and its bilinear set-up: the shading normal's octahedral direction is probe independent) is evaluated for the two probes of that
+// axis instead of for all eight: the same operators on the same operands, so the same bits.  mix(1 - a, a, offset) with offset 0 / 1
+// is (1 - a) * 1 + a * 0 and (1 - a) * 0 + a * 1: 1 - a and a for the finite alpha in [0, 1] the clamp leaves.
 SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index, const float* lut, bool& bad) {
     const Fn spacing = Fn(c.spacing[cascade_index]);
     const F3 rel = location - F3{Fn(c.cascade_min[cascade_index][0]), Fn(c.cascade_min[cascade_index][1]), Fn(c.cascade_min[cascade_index][2])};
     const F3 ps = rel / spacing;
-    const F3 min_probe = {Fn(__builtin_floorf(ps.x.v)), Fn(__builtin_floorf(ps.y.v)), Fn(__builtin_floorf(ps.z.v))};
-    const F3 alpha = {nclamp(ps.x - min_probe.x, Fn(0.f), Fn(1.f)), nclamp(ps.y - min_probe.y, Fn(0.f), Fn(1.f)),
-                      nclamp(ps.z - min_probe.z, Fn(0.f), Fn(1.f))};
+    const Fn psa[3] = {ps.x, ps.y, ps.z};
     const F2 irr_oct = octahedral_coordinates(direction);  // probe independent (IEEE form: once per pixel)
     const bool irr_oct_ok = __builtin_fabsf(irr_oct.x.v) <= 1.0f && __builtin_fabsf(irr_oct.y.v) <= 1.0f;  // false for NaN
     bad = bad || !irr_oct_ok;
+
+    Fn dp[3][2], sq[3][2], tri[3][2];
+    uint32_t pidx[3][2];
+    const Fn cascade_row = Fn((float)cascade_index) * Fn(8.f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const Fn mp = Fn(__builtin_floorf(psa[k].v));
+        const Fn alpha = nclamp(psa[k] - mp, Fn(0.f), Fn(1.f));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const Fn pl = mp + Fn((float)j);
+            dp[k][j] = pl - psa[k];
+            sq[k][j] = dp[k][j] * dp[k][j];
+            pidx[k][j] = f2uint((k == 1 ? pl + cascade_row : pl + Fn(0.f)).v);
+            tri[k][j] = nmax(Fn(0.001f), j ? alpha : Fn(1.f) - alpha);
+        }
+    }
+    // texcoord terms per axis: idx * total + total / 2 (depth atlas: 10 + 2 texels), and the whole irradiance axis
+    Fn dbase[2][2];
+    ProbeAxis iax[2][2];
+    const Fn oct[2] = {irr_oct.x, irr_oct.y};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const Fn total = Fn((float)c.probe_size[k]) + Fn(2.f);
+        const Fn tex_size = total * Fn(32.f);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            dbase[k][j] = Fn((float)pidx[k][j]) * Fn(12.f) + Fn(12.f) * Fn(0.5f);
+            Fn u = Fn((float)pidx[k][j]) * total + total * Fn(0.5f);
+            u = u + oct[k] * (Fn((float)c.probe_size[k]) * Fn(0.5f));
+            const float uv = div_const(u.v, tex_size.v, c.inv_tex[k]);
+            iax[k][j] = k == 0 ? probe_axis(uv, c.irradiance.width, 4u) : probe_axis(uv, c.irradiance.height, c.irradiance.row_pitch);
+        }
+    }
+    uint32_t dlayer[2], ilayer[2], vlayer[2];
+    bool zin[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        dlayer[j] = (uint32_t)array_layer((float)pidx[2][j], c.depth.depth) * c.depth.slice_pitch;
+        ilayer[j] = (uint32_t)array_layer((float)pidx[2][j], c.irradiance.depth) * c.irradiance.slice_pitch;
+        vlayer[j] = pidx[2][j] * c.validity.slice_pitch;
+        zin[j] = pidx[2][j] < c.validity.depth;
+    }
+
     F3 irradiance = F3(Fn(0.f));
     Fn weight = Fn(0.f);
-#pragma unroll 2
+#pragma unroll
     for (uint32_t i = 0; i < 8; i++) {
-        const F3 off = {Fn((float)(i & 1u)), Fn((float)((i >> 1) & 1u)), Fn((float)((i >> 2) & 1u))};
-        const F3 probe_location = min_probe + off;
-        const F3 dir_to_probe = probe_location - ps;
-        const Fn d2 = dot(dir_to_probe, dir_to_probe);
-        const F3 pidx_f = probe_location + F3{Fn(0.f), Fn((float)cascade_index) * Fn(8.f), Fn(0.f)};
-        const uint32_t pidx[3] = {f2uint(pidx_f.x.v), f2uint(pidx_f.y.v), f2uint(pidx_f.z.v)};
+        const int jx = i & 1u, jy = (i >> 1) & 1u, jz = (i >> 2) & 1u;
         float validity = 0.f;  // Texture2DArray<half>[uint3]: out-of-range loads return 0
-        if (pidx[0] < c.validity.width && pidx[1] < c.validity.height && pidx[2] < c.validity.depth) {
-            const uint8_t b = c.validity.ptr[pidx[2] * c.validity.slice_pitch + pidx[1] * c.validity.row_pitch + pidx[0]];
+        if (pidx[0][jx] < c.validity.width && pidx[1][jy] < c.validity.height && zin[jz]) {
+            const uint8_t b = c.validity.ptr[vlayer[jz] + pidx[1][jy] * c.validity.row_pitch + pidx[0][jx]];
             validity = rh(lut[256u + b]);  // lut[256 + b] == (float)b / 255.0f (api.cpp)
         }
         if (validity == 0.f) continue;
         // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
+        const F3 dir_to_probe = {dp[0][jx], dp[1][jy], dp[2][jz]};
+        const Fn d2 = sq[0][jx] + sq[1][jy] + sq[2][jz];
         bool pbad = !(d2.v == 0.f || (d2.v >= 0x1p-80f && d2.v <= 0x1p+80f));
         const Fn dist = Fn(sqrt_nr0(d2.v)) * spacing;
-        const F3 tri = {nmax(Fn(0.001f), mix(Fn(1.f) - alpha.x, alpha.x, off.x)), nmax(Fn(0.001f), mix(Fn(1.f) - alpha.y, alpha.y, off.y)),
-                        nmax(Fn(0.001f), mix(Fn(1.f) - alpha.z, alpha.z, off.z))};
-        const Fn trilinear_weight = tri.x * tri.y * tri.z;
+        const Fn trilinear_weight = tri[0][jx] * tri[1][jy] * tri[2][jz];
         Fn probe_weight = Fn(1.f);
 
         const F2 depth_oct = octahedral_coordinates_nr(-dir_to_probe, pbad);
-        float duv[2];
-        probe_uv_nr(pidx, depth_oct, 10u, 10u, duv);
-        const BilinearTaps dtaps = bilinear_setup_probe(c.depth, duv[0], duv[1], array_layer((float)pidx[2], c.depth.depth));
-        const uint2 d0 = load_pair(c.depth.ptr, dtaps.row0), d1 = load_pair(c.depth.ptr, dtaps.row1);
+        const float du = div_const((dbase[0][jx] + depth_oct.x * (Fn(10.f) * Fn(0.5f))).v, 384.0f, 1.0f / 384.0f);
+        const float dv = div_const((dbase[1][jy] + depth_oct.y * (Fn(10.f) * Fn(0.5f))).v, 384.0f, 1.0f / 384.0f);
+        const ProbeAxis dxa = probe_axis(du, c.depth.width, 4u), dya = probe_axis(dv, c.depth.height, c.depth.row_pitch);
+        const uint32_t drow0 = dlayer[jz] + dya.off + dxa.off;
+        const uint2 d0 = load_pair(c.depth.ptr, drow0), d1 = load_pair(c.depth.ptr, drow0 + c.depth.row_pitch);
         const uint32_t dw[4] = {d0.x, d0.y, d1.x, d1.y};  // tap order (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+        const float dwt[4] = {dxa.w0 * dya.w0, dxa.w1 * dya.w0, dxa.w0 * dya.w1, dxa.w1 * dya.w1};
         float dt0 = 0.f, dt1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            dt0 = fma_mix_lo(dtaps.w[k], dw[k], dt0);
-            dt1 = fma_mix_hi(dtaps.w[k], dw[k], dt1);
+            dt0 = fma_mix_lo(dwt[k], dw[k], dt0);
+            dt1 = fma_mix_hi(dwt[k], dw[k], dt1);
         }
         const Hn dx = Hn(dt0), dy = Hn(dt1);  // Sampler2DArray<half2>
         const Fn variance = Fn(tof(nabs(dx * dx - dy)));
@@ -288,20 +352,20 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         probe_weight = probe_weight.v < crush.v ? crushed : probe_weight;
         probe_weight = probe_weight * trilinear_weight;
 
-        float iuv[2];
-        probe_uv_nr(pidx, irr_oct, c.probe_size[0], c.probe_size[1], iuv);
-        const BilinearTaps itaps = bilinear_setup_probe(c.irradiance, iuv[0], iuv[1], array_layer((float)pidx[2], c.irradiance.depth));
-        const uint2 i0 = load_pair(c.irradiance.ptr, itaps.row0), i1 = load_pair(c.irradiance.ptr, itaps.row1);
+        const ProbeAxis ixa = iax[0][jx], iya = iax[1][jy];
+        const uint32_t irow0 = ilayer[jz] + iya.off + ixa.off;
+        const uint2 i0 = load_pair(c.irradiance.ptr, irow0), i1 = load_pair(c.irradiance.ptr, irow0 + c.irradiance.row_pitch);
         const uint32_t iw[4] = {i0.x, i0.y, i1.x, i1.y};
+        const float iwt[4] = {ixa.w0 * iya.w0, ixa.w1 * iya.w0, ixa.w0 * iya.w1, ixa.w1 * iya.w1};
         float ir = 0.f, ig = 0.f, ib = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t wrd = iw[k];
             const uint32_t rg = ((wrd << 4) & 0x7ff0u) | ((wrd << 9) & 0x7ff00000u);  // fp16(R) | fp16(G) << 16
             const uint32_t bb = (wrd >> 17) & 0x7fe0u;                                // fp16(B)
-            ir = fma_mix_lo(itaps.w[k], rg, ir);
-            ig = fma_mix_hi(itaps.w[k], rg, ig);
-            ib = fma_mix_lo(itaps.w[k], bb, ib);
+            ir = fma_mix_lo(iwt[k], rg, ir);
+            ig = fma_mix_hi(iwt[k], rg, ig);
+            ib = fma_mix_lo(iwt[k], bb, ib);
         }
         const H3 pi = {Hn(ir), Hn(ig), Hn(ib)};  // Sampler2DArray<half3>
         irradiance = irradiance + to_f(pi) * probe_weight;

@@ -34,6 +34,7 @@ struct CacheArgs {
     float cascade_max[4][3];  // min + (32,8,32) * spacing
     float spacing[4];
     uint32_t probe_size[2];
+    float inv_tex[2];  // RN(1 / (32 * (probe_size + 2))): the irradiance atlas extent in texels, for div_const()
     uint32_t debug_mode;
     uint32_t hot_ok;  // atlases < 4 GiB, probe grid <= 64 per axis, probe texel counts <= 30: sample_cascade_fast() applies
 };
