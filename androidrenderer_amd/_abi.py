@@ -66,10 +66,30 @@ class Primitive(C.Structure):  # sah_primitive, 96 bytes
                 ("type", C.c_uint32), ("material", C.c_uint32), ("padding", C.c_uint32 * 3)]
 
 
+FILTER_NEAREST, FILTER_LINEAR = 0, 1
+ADDRESS_REPEAT, ADDRESS_MIRRORED_REPEAT, ADDRESS_CLAMP_TO_EDGE = 0, 1, 2
+MAX_TEXTURE_MIPS = 14
+TEXTURE_NONE = 0xFFFFFFFF
+
+
+class Sampler(C.Structure):  # sah_sampler, 32 bytes
+    _fields_ = [("mag_filter", C.c_uint32), ("min_filter", C.c_uint32), ("mipmap_mode", C.c_uint32), ("address_u", C.c_uint32),
+                ("address_v", C.c_uint32), ("mip_lod_bias", C.c_float), ("min_lod", C.c_float), ("max_lod", C.c_float)]
+
+
+class Texture(C.Structure):  # sah_texture, 376 bytes
+    _fields_ = [("mips", Plane * MAX_TEXTURE_MIPS), ("num_mips", C.c_uint32), ("padding", C.c_uint32), ("sampler", Sampler)]
+
+
+class MaterialTextures(C.Structure):  # sah_material_textures, 16 bytes
+    _fields_ = [("base_color", C.c_uint32), ("normal", C.c_uint32), ("data", C.c_uint32), ("emission", C.c_uint32)]
+
+
 class SceneGeometry(C.Structure):  # sah_scene_geometry
     _fields_ = [("vertex_positions", C.c_void_p), ("vertex_data", C.c_void_p), ("indices", C.c_void_p), ("primitives", C.c_void_p),
                 ("materials", C.c_void_p), ("num_vertices", C.c_uint32), ("num_indices", C.c_uint32), ("num_primitives", C.c_uint32),
-                ("num_materials", C.c_uint32)]
+                ("num_materials", C.c_uint32), ("textures", C.c_void_p), ("material_textures", C.c_void_p), ("num_textures", C.c_uint32),
+                ("padding", C.c_uint32)]
 
 
 class RsmTargets(C.Structure):  # sah_rsm_targets

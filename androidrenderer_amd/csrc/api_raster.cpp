@@ -134,6 +134,9 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const size_t total_tris = r.host_counters[0], clipped = r.host_counters[3], pairs = r.host_counters[2];
         if (total_tris >= (1u << 28)) return fail(ctx, SAH_ERR_UNSUPPORTED, "rasteriser: more than 2^28 triangles in one pass");
+        if (r.host_counters[13])
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "rasteriser: %u invalid texture slots or bindings (index beyond the table, more than %d levels, a level "
+                        "that is not R8G8B8A8_UNORM / _SRGB, a sampler enum out of range)", r.host_counters[13], SAH_MAX_TEXTURE_MIPS);
         if (r.host_counters[12])
             return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadow_render: the scene has CUTOUT primitives (%u triangles): vertex_data and materials are needed "
                         "for their alpha test (shadow_masked pipeline)", r.host_counters[12]);
@@ -152,7 +155,8 @@ int run(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene, bool 
     return SAH_OK;
 }
 
-void fill_scene(sah::RasterArgs& a, const sah_scene_geometry* scene) {
+void fill_scene(sah_ctx* ctx, sah::RasterArgs& a, const sah_scene_geometry* scene) {
+    a.luts = ctx->luts;
     a.positions = scene->vertex_positions;
     a.vertex_data = scene->vertex_data;
     a.indices = scene->indices;
@@ -162,6 +166,11 @@ void fill_scene(sah::RasterArgs& a, const sah_scene_geometry* scene) {
     a.num_indices = scene->num_indices;
     a.num_vertices = scene->num_vertices;
     a.num_materials = scene->num_materials;
+    const bool textured = scene->textures && scene->material_textures && scene->num_textures;
+    a.textures = textured ? scene->textures : nullptr;
+    a.material_textures = textured ? scene->material_textures : nullptr;
+    a.num_textures = textured ? scene->num_textures : 0;
+    a.shader_mip_bias = 0.0f;
 }
 }  // namespace
 
@@ -179,7 +188,7 @@ int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_s
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadow_render: shadow map extent (1..%u), layers or pitches", kMaxExtent);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     sah::RasterArgs a{};
-    fill_scene(a, scene);
+    fill_scene(ctx, a, scene);
     a.num_views = num_cascades;
     for (uint32_t c = 0; c < num_cascades; c++) std::memcpy(a.clip_matrix[c], sun->cascade_matrices[c], 64);
     a.width = shadowmap->width;
@@ -208,8 +217,9 @@ int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = ensure_srgb_table(ctx); rc != SAH_OK) return rc;
     sah::RasterArgs a{};
-    fill_scene(a, scene);
+    fill_scene(ctx, a, scene);
     a.num_views = 1;
+    a.shader_mip_bias = view->material_texture_mip_bias;
     std::memcpy(a.view_matrix, view->view, 64);
     std::memcpy(a.clip_matrix[0], view->projection, 64);
     a.width = W;
@@ -245,7 +255,7 @@ int sah_rsm_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = ensure_srgb_table(ctx); rc != SAH_OK) return rc;
     sah::RasterArgs a{};
-    fill_scene(a, scene);
+    fill_scene(ctx, a, scene);
     a.num_views = num_cascades;
     for (uint32_t c = 0; c < num_cascades; c++) std::memcpy(a.clip_matrix[c], cascades[c].rsm_vp, 64);
     a.width = W;

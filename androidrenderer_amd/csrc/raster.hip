@@ -31,7 +31,7 @@ constexpr float kCoordLimit = 0x1p24f + 4096.0f;  // snapped coordinates beyond 
 constexpr uint32_t kSmallArea = SAH_RASTER_SMALL_AREA;    // (bbox ∩ tile) pixel count up to which one lane walks a triangle alone
 constexpr uint32_t kMediumArea = SAH_RASTER_MEDIUM_AREA;  // ... up to which one wave does; above, the whole workgroup
 
-enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4, C_EXTRA = 9, C_HEAVY = 10, C_CUTOUT_NO_ATTR = 12 };  // the last two are statistics words 5 and 6  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
+enum Counter { C_TRIS = 0, C_RECORDS = 1, C_PAIRS = 2, C_CLIPPED = 3, C_STATS = 4, C_EXTRA = 9, C_HEAVY = 10, C_CUTOUT_NO_ATTR = 12, C_BAD_TEXTURE = 13 };  // the last two are statistics words 5 and 6  // C_STATS .. C_STATS+7 mirror SAH_RASTER_STATS_WORDS
 
 struct ClipVertex {
     float c[4];
@@ -246,6 +246,12 @@ SAH_DEV void emit_triangle(const RasterArgs& a, SetupStats& st, uint32_t view, u
             sa.pad = 0;
             sa.material = prim.material;
             sa.pad2 = 0;
+            for (int k = 0; k < 3; k++) {
+                const sah_vertex_data& vd = a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]];
+                sa.uv[k][0] = vd.texcoord[0];
+                sa.uv[k][1] = vd.texcoord[1];
+            }
+            sa.pad3[0] = sa.pad3[1] = 0;
             a.shadow_attrs[r] = sa;
         } else {
             atomicAdd(&a.counters[C_CUTOUT_NO_ATTR], 1u);  // the host turns this into SAH_ERR_INVALID_ARGUMENT (api_raster.cpp)
@@ -259,8 +265,12 @@ SAH_DEV void emit_triangle(const RasterArgs& a, SetupStats& st, uint32_t view, u
         at.material = prim.material;
         at.seq = seq;
         at.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
-        for (int k = 0; k < 3; k++)
-            vertex_outputs(prim, a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]], at.vout[k]);
+        for (int k = 0; k < 3; k++) {
+            const sah_vertex_data& vd = a.vertex_data[(int64_t)prim.vertex_offset + a.indices[prim.first_index + 3 * tri + k]];
+            vertex_outputs(prim, vd, at.vout[k]);
+            at.uv[k][0] = vd.texcoord[0];
+            at.uv[k][1] = vd.texcoord[1];
+        }
         a.attrs[r] = at;
     }
 }
@@ -535,8 +545,156 @@ SAH_DEV uint32_t unorm8_of(float c) {  // floor(c * 255 + 0.5) in fp32, clamped,
     return (uint32_t)(c * 255.0f + 0.5f);
 }
 
+// ---- material textures: textures[index].SampleBias(texcoord, mip_bias), gltf_basic_pbr.slang:177-226 ------------------------------------
+// The rules include/sah_hip.h lists under sah_texture (level of detail from fine quad derivatives, bias and clamps, level selection,
+// filters, address modes, decode).
+SAH_DEV int wrap_texel(int i, int n, uint32_t mode) {
+    if (mode == SAH_ADDRESS_CLAMP_TO_EDGE) return min(max(i, 0), n - 1);
+    if (mode == SAH_ADDRESS_MIRRORED_REPEAT) {
+        int m = i % (2 * n);
+        if (m < 0) m += 2 * n;
+        return m < n ? m : 2 * n - 1 - m;
+    }
+    const int m = i % n;
+    return m < 0 ? m + n : m;
+}
+SAH_DEV void fetch_rgba8(const RasterArgs& a, const sah_plane& p, int x, int y, float out[4]) {
+    uint32_t w;
+    __builtin_memcpy(&w, (const uint8_t*)p.ptr + (size_t)y * p.row_pitch_bytes + (size_t)x * 4, 4);
+    const uint32_t rgb_table = p.format == SAH_FORMAT_R8G8B8A8_SRGB ? 0u : 256u;  // luts: 256 sRGB8 -> linear, 256 UNORM8 -> float
+    for (int c = 0; c < 3; c++) out[c] = a.luts[rgb_table + ((w >> (8 * c)) & 0xffu)];
+    out[3] = a.luts[256u + (w >> 24)];
+}
+SAH_DEV int floor_to_int(float f) { return (int)__builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f); }  // f is integral
+SAH_DEV void sample_level(const RasterArgs& a, const sah_plane& p, const sah_sampler& s, uint32_t filter, float u, float v, float out[4]) {
+    const int w = (int)p.width, h = (int)p.height;
+    if (filter == SAH_FILTER_NEAREST) {
+        const float px = u * (float)w, py = v * (float)h;
+        if (px != px || py != py) { for (int c = 0; c < 4; c++) out[c] = __builtin_nanf(""); return; }
+        fetch_rgba8(a, p, wrap_texel(floor_to_int(__builtin_floorf(px)), w, s.address_u), wrap_texel(floor_to_int(__builtin_floorf(py)), h, s.address_v), out);
+        return;
+    }
+    const float px = u * (float)w - 0.5f, py = v * (float)h - 0.5f;
+    if (px != px || py != py) { for (int c = 0; c < 4; c++) out[c] = __builtin_nanf(""); return; }
+    const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    const float fx = px - fx0, fy = py - fy0;
+    const int x0 = floor_to_int(fx0), y0 = floor_to_int(fy0);
+    const int xa = wrap_texel(x0, w, s.address_u), xb = wrap_texel(x0 + 1, w, s.address_u);
+    const int ya = wrap_texel(y0, h, s.address_v), yb = wrap_texel(y0 + 1, h, s.address_v);
+    float t00[4], t10[4], t01[4], t11[4];
+    fetch_rgba8(a, p, xa, ya, t00); fetch_rgba8(a, p, xb, ya, t10); fetch_rgba8(a, p, xa, yb, t01); fetch_rgba8(a, p, xb, yb, t11);
+    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    const float w00 = wx0 * wy0, w10 = fx * wy0, w01 = wx0 * fy, w11 = fx * fy;
+    for (int c = 0; c < 4; c++) {
+        float acc = __builtin_fmaf(w00, t00[c], 0.0f);
+        acc = __builtin_fmaf(w10, t10[c], acc);
+        acc = __builtin_fmaf(w01, t01[c], acc);
+        acc = __builtin_fmaf(w11, t11[c], acc);
+        out[c] = acc;
+    }
+}
+SAH_DEV void sample_texture(const RasterArgs& a, const sah_texture& T, const float uv[2], const float ddx[2], const float ddy[2], float shader_bias, float out[4]) {
+    const sah_sampler s = T.sampler;
+    const float W0 = (float)T.mips[0].width, H0 = (float)T.mips[0].height;
+    const float mxx = ddx[0] * W0, mxy = ddx[1] * H0, myx = ddy[0] * W0, myy = ddy[1] * H0;
+    const float rx = mxx * mxx + mxy * mxy, ry = myx * myx + myy * myy;
+    const float rho2 = __builtin_fmaxf(rx, ry);
+    float lambda = rho2 > 0.0f ? 0.5f * (float)log2((double)rho2) : -__builtin_inff();
+    lambda = lambda + (s.mip_lod_bias + shader_bias);
+    lambda = __builtin_fminf(__builtin_fmaxf(lambda, s.min_lod), s.max_lod);
+    const uint32_t filter = lambda <= 0.0f ? s.mag_filter : s.min_filter;
+    const int q = (int)T.num_mips - 1;
+    if (s.mipmap_mode == SAH_FILTER_NEAREST) {
+        int level = 0;
+        if (!(lambda <= 0.5f)) level = !(lambda < (float)q) ? q : min((int)__builtin_ceilf(lambda + 0.5f) - 1, q);
+        sample_level(a, T.mips[level], s, filter, uv[0], uv[1], out);
+        return;
+    }
+    const float d = __builtin_fminf(__builtin_fmaxf(lambda, 0.0f), (float)q);
+    const float hi_f = __builtin_floorf(d);
+    const int hi = (int)hi_f, lo = min(hi + 1, q);
+    const float delta = d - hi_f;
+    float ta[4], tb[4];
+    sample_level(a, T.mips[hi], s, filter, uv[0], uv[1], ta);
+    sample_level(a, T.mips[lo], s, filter, uv[0], uv[1], tb);
+    const float one_minus = 1.0f - delta;
+    for (int c = 0; c < 4; c++) out[c] = one_minus * ta[c] + delta * tb[c];
+}
+
+// perspective-correct barycentrics of pixel (px, py) in the input triangle — also for a pixel the triangle does not cover (the other
+// pixels of a fragment's quad)
+SAH_DEV void lambda_at(const EdgeSetup& e, const float inv_w[3], const float (&bary)[3][3], int32_t px, int32_t py, float lambda[3]) {
+    double v[3];
+    float b[3];
+    cover(e, px, py, v);
+    barycentrics(e, v, b);
+    const float q0 = b[0] * inv_w[0], q1 = b[1] * inv_w[1], q2 = b[2] * inv_w[2];
+    const float s = (q0 + q1) + q2;
+    const float l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
+    for (int k = 0; k < 3; k++) lambda[k] = (l0 * bary[0][k] + l1 * bary[1][k]) + l2 * bary[2][k];
+}
+struct TexCoord {
+    float t[2], ddx[2], ddy[2];
+};
+// the texcoord varying at the fragment and its fine derivatives over the 2x2 quad at even window coordinates
+SAH_DEV TexCoord texcoord_of(const EdgeSetup& e, const float inv_w[3], const float (&bary)[3][3], const float (&uv)[3][2], int32_t px, int32_t py,
+                             const float lambda[3]) {
+    float lx[3], ly[3];
+    lambda_at(e, inv_w, bary, px ^ 1, py, lx);
+    lambda_at(e, inv_w, bary, px, py ^ 1, ly);
+    TexCoord r;
+    for (int c = 0; c < 2; c++) {
+        const float t = (lambda[0] * uv[0][c] + lambda[1] * uv[1][c]) + lambda[2] * uv[2][c];
+        const float tx = (lx[0] * uv[0][c] + lx[1] * uv[1][c]) + lx[2] * uv[2][c];
+        const float ty = (ly[0] * uv[0][c] + ly[1] * uv[1][c]) + ly[2] * uv[2][c];
+        r.t[c] = t;
+        r.ddx[c] = (px & 1) ? t - tx : tx - t;
+        r.ddy[c] = (py & 1) ? t - ty : ty - t;
+    }
+    return r;
+}
+SAH_DEV sah_material_textures textures_of(const RasterArgs& a, uint32_t material) {
+    if (!a.material_textures) return {SAH_TEXTURE_NONE, SAH_TEXTURE_NONE, SAH_TEXTURE_NONE, SAH_TEXTURE_NONE};
+    return a.material_textures[min(material, a.num_materials - 1u)];
+}
+SAH_DEV bool any_texture(const RasterArgs& a, const sah_material_textures& mt) {
+    return mt.base_color < a.num_textures || mt.normal < a.num_textures || mt.data < a.num_textures || mt.emission < a.num_textures;
+}
+// (half4) of one material slot: the sampled texture, or the material's constant texel (an index beyond the table — reported through
+// C_BAD_TEXTURE by k_check_textures — is never dereferenced)
+SAH_DEV void material_texel(const RasterArgs& a, uint32_t index, const float (&constant)[4], const TexCoord& tc, Hn out[4]) {
+    if (index >= a.num_textures || a.counters[C_BAD_TEXTURE] != 0u) {  // (a bad table fails the call: nothing of it is dereferenced)
+        for (int c = 0; c < 4; c++) out[c] = Hn(constant[c]);
+        return;
+    }
+    float texel[4];
+    sample_texture(a, a.textures[index], tc.t, tc.ddx, tc.ddy, a.shader_mip_bias, texel);
+    for (int c = 0; c < 4; c++) out[c] = Hn(texel[c]);
+}
+
+// one thread per texture slot and per material: anything the fragment stages could not sample safely is counted, and the host fails the call
+__global__ __launch_bounds__(256) void k_check_textures(const RasterArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < a.num_textures) {
+        const sah_texture& T = a.textures[i];
+        bad = T.num_mips < 1 || T.num_mips > SAH_MAX_TEXTURE_MIPS || T.sampler.mag_filter > 1 || T.sampler.min_filter > 1 || T.sampler.mipmap_mode > 1 ||
+              T.sampler.address_u > 2 || T.sampler.address_v > 2;
+        for (uint32_t l = 0; !bad && l < T.num_mips; l++) {
+            const sah_plane& p = T.mips[l];
+            bad = !p.ptr || p.width == 0 || p.height == 0 || p.width > 16384 || p.height > 16384 || p.format != T.mips[0].format ||
+                  (p.format != SAH_FORMAT_R8G8B8A8_UNORM && p.format != SAH_FORMAT_R8G8B8A8_SRGB) || p.row_pitch_bytes < p.width * 4u;
+        }
+    } else if (i - a.num_textures < a.num_materials) {
+        const sah_material_textures mt = a.material_textures[i - a.num_textures];
+        const uint32_t idx[4] = {mt.base_color, mt.normal, mt.data, mt.emission};
+        for (int k = 0; k < 4; k++) bad = bad || (idx[k] != SAH_TEXTURE_NONE && idx[k] >= a.num_textures);
+    }
+    if (bad) atomicAdd(&a.counters[C_BAD_TEXTURE], 1u);
+}
+
 // depth test of a covered pixel; v = its edge functions (read by cutout fragments only)
-template <bool GBUFFER>
+template <bool GBUFFER, bool TEX>
 SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t px, int32_t py, const double v[3], int32_t tile_x, int32_t tile_y,
                            uint32_t* s_depth, unsigned long long* s_key) {
     const float z = fragment_depth(e, px, py);
@@ -553,7 +711,10 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
             for (int k = 0; k < 3; k++) lambda[k] = (l0 * sa.bary[0][k] + l1 * sa.bary[1][k]) + l2 * sa.bary[2][k];
             const Hn va = Hn((lambda[0] * h2f(sa.alpha[0]) + lambda[1] * h2f(sa.alpha[1])) + lambda[2] * h2f(sa.alpha[2]));
             const sah_material& m = a.materials[min(sa.material, a.num_materials - 1u)];
-            const Hn alpha = Hn(m.base_color_texel[3]) * va * Hn(m.base_color_tint[3]);
+            Hn texel[4] = {Hn(0.f), Hn(0.f), Hn(0.f), Hn(m.base_color_texel[3])};
+            const uint32_t tex = TEX ? textures_of(a, sa.material).base_color : SAH_TEXTURE_NONE;
+            if (TEX && tex < a.num_textures) material_texel(a, tex, m.base_color_texel, texcoord_of(e, sa.inv_w, sa.bary, sa.uv, px, py, lambda), texel);
+            const Hn alpha = texel[3] * va * Hn(m.base_color_tint[3]);
             if (tof(alpha) <= m.opacity_threshold) return;
         }
         atomicMin(&s_depth[slot], (uint32_t)__builtin_rintf(z * 65535.0f));
@@ -568,7 +729,10 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
             barycentrics(e, v, b);
             input_barycentrics(at, b, lambda);
             const sah_material& m = a.materials[min(at.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a pass that is being repeated
-            const Hn alpha = Hn(m.base_color_texel[3]) * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
+            Hn texel[4] = {Hn(0.f), Hn(0.f), Hn(0.f), Hn(m.base_color_texel[3])};
+            const uint32_t tex = TEX ? textures_of(a, at.material).base_color : SAH_TEXTURE_NONE;
+            if (TEX && tex < a.num_textures) material_texel(a, tex, m.base_color_texel, texcoord_of(e, at.inv_w, at.bary, at.uv, px, py, lambda), texel);
+            const Hn alpha = texel[3] * interp_h(at, lambda, 3) * Hn(m.base_color_tint[3]);
             if (tof(alpha) <= m.opacity_threshold) return;
         }
         // low word: who wins among equal depths.  Draw order is all SOLID primitives, then all CUTOUT ones (draw_opaque, draw_masked:
@@ -580,17 +744,17 @@ SAH_DEV void emit_fragment(const RasterArgs& a, const EdgeSetup& e, uint32_t rec
         atomicMax(&s_key[slot], ((unsigned long long)depth_key << 32) | (unsigned long long)(a.rsm ? ~order : order));
     }
 }
-template <bool GBUFFER>
+template <bool GBUFFER, bool TEX>
 SAH_DEV void test_pixel(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t px, int32_t py, int32_t tile_x, int32_t tile_y, uint32_t* s_depth,
                         unsigned long long* s_key) {
     double v[3];
-    if (cover(e, px, py, v)) emit_fragment<GBUFFER>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
+    if (cover(e, px, py, v)) emit_fragment<GBUFFER, TEX>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
 }
 
 // One wave sweeps rows first_row, first_row + row_step, ... of 8x8 pixel blocks over the clipped bounding box, lanes as the pixels of
 // a block.  Per block the edge functions advance by one fp64 add each (exact: integers below 2^52); a block whose most favourable
 // corner is outside an edge is skipped, one whose least favourable corner is inside all three needs no per-pixel coverage test.
-template <bool GBUFFER>
+template <bool GBUFFER, bool TEX>
 SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, int32_t sx0, int32_t sx1, int32_t bx1, int32_t by1, int32_t first_row,
                    int32_t row_step, uint32_t lane, int32_t tile_x, int32_t tile_y, uint32_t* s_depth, unsigned long long* s_key) {
     // blocks start at x = sx0, sx0 + 8, ... <= sx1; pixels beyond (bx1, by1) are outside the record's clipped bounding box
@@ -623,7 +787,7 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
                         covered = covered && (v[i] > 0.0 || (v[i] == 0.0 && ((e.tl >> i) & 1u)));
                     }
                 }
-                if (covered) emit_fragment<GBUFFER>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
+                if (covered) emit_fragment<GBUFFER, TEX>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
             }
             for (int i = 0; i < 3; i++) base[i] += step_x[i];
         }
@@ -631,28 +795,46 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
 }
 
 // fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_MAIN_VIEW, constant textures)
-SAH_DEV void shade_and_store(const RasterArgs& a, const EdgeSetup& e, const RasterAttr& at, const sah_material& m, int32_t px, int32_t py, float z) {
+template <bool TEX>
+SAH_DEV void shade_and_store(const RasterArgs& a, const EdgeSetup& e, const RasterAttr& at, const sah_material& m, const sah_material_textures& mt, int32_t px,
+                             int32_t py, float z) {
     double v[3];
     float b[3], lambda[3];
     cover(e, px, py, v);
     barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
+    Hn base_texel[4], normal_texel[4], data_texel[4], emission_texel[4];
+    if (TEX) {
+        TexCoord tc{};
+        if (any_texture(a, mt)) tc = texcoord_of(e, at.inv_w, at.bary, at.uv, px, py, lambda);
+        material_texel(a, mt.base_color, m.base_color_texel, tc, base_texel);
+        material_texel(a, mt.normal, m.normal_texel, tc, normal_texel);
+        material_texel(a, mt.data, m.data_texel, tc, data_texel);
+        material_texel(a, mt.emission, m.emission_texel, tc, emission_texel);
+    } else {
+        for (int c = 0; c < 4; c++) {
+            base_texel[c] = Hn(m.base_color_texel[c]);
+            normal_texel[c] = Hn(m.normal_texel[c]);
+            data_texel[c] = Hn(m.data_texel[c]);
+            emission_texel[c] = Hn(m.emission_texel[c]);
+        }
+    }
     Hn col[4], N[3], T[4];
     for (int c = 0; c < 4; c++) col[c] = interp_h(at, lambda, c);
     for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
     for (int c = 0; c < 4; c++) T[c] = interp_h(at, lambda, 7 + c);
     Hn tinted[4];
-    for (int c = 0; c < 4; c++) tinted[c] = Hn(m.base_color_texel[c]) * col[c] * Hn(m.base_color_tint[c]);
+    for (int c = 0; c < 4; c++) tinted[c] = base_texel[c] * col[c] * Hn(m.base_color_tint[c]);
     // bitangent = cross(normal, tangent.xyz) * tangent.w; normal = normal_sample * TBN (:197-207)
     const Hn B[3] = {(N[1] * T[2] - N[2] * T[1]) * T[3], (N[2] * T[0] - N[0] * T[2]) * T[3], (N[0] * T[1] - N[1] * T[0]) * T[3]};
     Hn ns[3], n_out[3];
-    for (int c = 0; c < 3; c++) ns[c] = Hn(m.normal_texel[c]) * Hn::lit(2.0f) - Hn::lit(1.0f);
+    for (int c = 0; c < 3; c++) ns[c] = normal_texel[c] * Hn::lit(2.0f) - Hn::lit(1.0f);
     for (int c = 0; c < 3; c++) n_out[c] = ns[0] * T[c] + ns[1] * B[c] + ns[2] * N[c];
     const float factor[4] = {0.0f, m.roughness_factor, m.metalness_factor, 0.0f};
     uint32_t color_bits = 0, data_bits = 0, emission_bits = 0;
     for (int c = 0; c < 4; c++) {
-        const Hn d = Hn(m.data_texel[c]) * Hn(factor[c]);
-        const Hn em = Hn(m.emission_texel[c]) * Hn(m.emission_factor[c]);
+        const Hn d = data_texel[c] * Hn(factor[c]);
+        const Hn em = emission_texel[c] * Hn(m.emission_factor[c]);
         data_bits |= unorm8_of(tof(d)) << (8 * c);
         emission_bits |= (c < 3 ? (uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, em.v)] : unorm8_of(tof(em))) << (8 * c);
         color_bits |= (c < 3 ? (uint32_t)a.half_to_srgb8[__builtin_bit_cast(uint16_t, tinted[c].v)] : unorm8_of(tof(tinted[c]))) << (8 * c);
@@ -669,15 +851,24 @@ SAH_DEV void shade_and_store(const RasterArgs& a, const EdgeSetup& e, const Rast
 
 // RSM fragment stage of the winning triangle (gltf_basic_pbr.slang:169-253, SAH_RSM): flux = Fd(surface, -sun direction, normal) with
 // the metalness / roughness this variant leaves at 0, normal * 0.5 + 0.5; the D16 code goes to the depth layer
-SAH_DEV void shade_rsm_and_store(const RasterArgs& a, const EdgeSetup& e, const RasterAttr& at, const sah_material& m, uint32_t layer, int32_t px, int32_t py,
-                                 uint32_t depth_code) {
+template <bool TEX>
+SAH_DEV void shade_rsm_and_store(const RasterArgs& a, const EdgeSetup& e, const RasterAttr& at, const sah_material& m, const sah_material_textures& mt, uint32_t layer,
+                                 int32_t px, int32_t py, uint32_t depth_code) {
     double v[3];
     float b[3], lambda[3];
     cover(e, px, py, v);
     barycentrics(e, v, b);
     input_barycentrics(at, b, lambda);
+    Hn base_texel[4];
+    if (TEX) {
+        TexCoord tc{};
+        if (mt.base_color < a.num_textures) tc = texcoord_of(e, at.inv_w, at.bary, at.uv, px, py, lambda);
+        material_texel(a, mt.base_color, m.base_color_texel, tc, base_texel);
+    } else {
+        for (int c = 0; c < 4; c++) base_texel[c] = Hn(m.base_color_texel[c]);
+    }
     Hn tinted[3], N[3];
-    for (int c = 0; c < 3; c++) tinted[c] = Hn(m.base_color_texel[c]) * interp_h(at, lambda, c) * Hn(m.base_color_tint[c]);
+    for (int c = 0; c < 3; c++) tinted[c] = base_texel[c] * interp_h(at, lambda, c) * Hn(m.base_color_tint[c]);
     for (int c = 0; c < 3; c++) N[c] = interp_h(at, lambda, 4 + c);
     Surface<Hn> s;
     s.base_color = {tinted[0], tinted[1], tinted[2]};
@@ -704,8 +895,8 @@ struct BigRecord {
     int32_t x0, x1, y0, y1;
 };
 
-template <bool GBUFFER>
-__global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs a) {
+template <bool GBUFFER, bool TEX>
+__global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_raster_tiles(const RasterArgs a) {
     __shared__ uint32_t s_depth[GBUFFER ? 1 : kTile * kTile];
     __shared__ unsigned long long s_key[GBUFFER ? kTile * kTile : 1];
     // Workgroups 0 .. ntiles-1 own a tile (and part 0 of its list); the rest take the further parts of the lists that k_split cut
@@ -762,7 +953,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
             medium_rec = area > kSmallArea && area <= kMediumArea;
             if (area <= kSmallArea) {
                 for (int32_t py = y0; py <= y1; py++)
-                    for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER>(a, mine, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
+                    for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER, TEX>(a, mine, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
             } else if (area > kMediumArea) {
                 const uint32_t slot = atomicAdd(&s_nbig, 1u);
                 if (slot < kBigSlots) {
@@ -784,7 +975,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
             const int32_t bx0 = (int32_t)readlane((uint32_t)x0, src), bx1 = (int32_t)readlane((uint32_t)x1, src);
             const int32_t by0 = (int32_t)readlane((uint32_t)y0, src), by1 = (int32_t)readlane((uint32_t)y1, src);
             const EdgeSetup e = broadcast(mine, src);
-            sweep<GBUFFER>(a, e, ri, bx0, bx1, bx1, by1, by0, 8, lane, tile_x, tile_y, s_depth, s_key);
+            sweep<GBUFFER, TEX>(a, e, ri, bx0, bx1, bx1, by1, by0, 8, lane, tile_x, tile_y, s_depth, s_key);
         }
         __syncthreads();
 #ifdef SAH_EXP_RASTER_SKIP_BIG  // timing experiment: no workgroup-cooperative records
@@ -797,11 +988,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
             const uint32_t ri = s_big[k].rec_index;
             const int32_t bx0 = s_big[k].x0, bx1 = s_big[k].x1, by0 = s_big[k].y0, by1 = s_big[k].y1;
             if constexpr (kTileThreads == 256) {  // 4 waves: alternate block rows
-                sweep<GBUFFER>(a, e, ri, bx0, bx1, bx1, by1, by0 + 8 * (int32_t)wave, 32, lane, tile_x, tile_y, s_depth, s_key);
+                sweep<GBUFFER, TEX>(a, e, ri, bx0, bx1, bx1, by1, by0 + 8 * (int32_t)wave, 32, lane, tile_x, tile_y, s_depth, s_key);
             } else {  // 16 waves: block row (wave % 8) of the at most 8, left or right half of the block columns (wave / 8)
                 const int32_t half = (((bx1 - bx0) >> 3) + 2) >> 1;
                 const int32_t sx0 = bx0 + 8 * half * (int32_t)(wave >> 3), sx1 = min(bx1, sx0 + 8 * half - 1);
-                if (sx0 <= bx1) sweep<GBUFFER>(a, e, ri, sx0, sx1, bx1, by1, by0 + 8 * (int32_t)(wave & 7u), 64, lane, tile_x, tile_y, s_depth, s_key);
+                if (sx0 <= bx1) sweep<GBUFFER, TEX>(a, e, ri, sx0, sx1, bx1, by1, by0 + 8 * (int32_t)(wave & 7u), 64, lane, tile_x, tile_y, s_depth, s_key);
             }
         }
         // every wave has read s_nbig / s_big of this round before thread 0 resets the counter for the next one (lists left unsplit
@@ -853,6 +1044,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
         EdgeSetup e_c{};
         RasterAttr at_c{};
         sah_material m_c{};
+        sah_material_textures mt_c{};
         for (uint32_t i = tid; i < kTile * kTile; i += kTileThreads) {
             const int32_t px = tile_x + (int32_t)(i % kTile), py = tile_y + (int32_t)(i / kTile);
             if ((uint32_t)px >= a.width || (uint32_t)py >= a.height) continue;
@@ -886,9 +1078,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster_tiles(const RasterArgs 
                     e_c = edge_setup(a.records[r]);
                     at_c = a.attrs[r];
                     m_c = a.materials[min(at_c.material, a.num_materials - 1u)];  // k_setup validated it; the clamp only matters for stale slots of a repeated pass
+                    if (TEX) mt_c = textures_of(a, at_c.material);
                 }
-                if (a.rsm) shade_rsm_and_store(a, e_c, at_c, m_c, view, px, py, 0xffffu - (uint32_t)(key >> 32));
-                else shade_and_store(a, e_c, at_c, m_c, px, py, __uint_as_float((uint32_t)(key >> 32)));
+                if (a.rsm) shade_rsm_and_store<TEX>(a, e_c, at_c, m_c, mt_c, view, px, py, 0xffffu - (uint32_t)(key >> 32));
+                else shade_and_store<TEX>(a, e_c, at_c, m_c, mt_c, px, py, __uint_as_float((uint32_t)(key >> 32)));
             }
         }
     }
@@ -948,6 +1141,7 @@ hipError_t launch_raster_setup(const RasterArgs& a, bool gbuffer, hipStream_t st
     e = hipMemsetAsync(a.tile_count, 0, (size_t)ntiles * 2 * sizeof(uint32_t), st);  // tile_count and tile_cursor are adjacent
     if (e != hipSuccess) return e;
     if (a.num_primitives == 0) return hipSuccess;
+    if (a.textures) hipLaunchKernelGGL(k_check_textures, dim3((a.num_textures + a.num_materials + 255u) / 256u), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, a.primitives, (const uint32_t*)nullptr, a.num_primitives, a.tri_base, &a.counters[C_TRIS]);
     if (gbuffer) {
         hipLaunchKernelGGL(k_setup<true>, dim3(1024), dim3(256), 0, st, a);
@@ -971,8 +1165,12 @@ hipError_t launch_raster_tiles(const RasterArgs& a, bool gbuffer, hipStream_t st
     // every tile gets its heavy_slot (~0 when its list stays whole), also for an empty scene
     if (gbuffer) hipLaunchKernelGGL(k_split<true>, dim3(ntiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_split<false>, dim3(ntiles), dim3(256), 0, st, a);
-    if (gbuffer) hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntiles + a.extra_capacity), dim3(kTileThreads), 0, st, a);
-    else hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntiles + a.extra_capacity), dim3(kTileThreads), 0, st, a);
+    // (the texture-sampling fragment stages are their own instantiations: 30-45 more VGPRs, which would cost the plain ones a wave per SIMD)
+    const dim3 grid(ntiles + a.extra_capacity);
+    if (gbuffer && a.textures) hipLaunchKernelGGL((k_raster_tiles<true, true>), grid, dim3(kTileThreads), 0, st, a);
+    else if (gbuffer) hipLaunchKernelGGL((k_raster_tiles<true, false>), grid, dim3(kTileThreads), 0, st, a);
+    else if (a.textures && a.shadow_attrs) hipLaunchKernelGGL((k_raster_tiles<false, true>), grid, dim3(kTileThreads), 0, st, a);
+    else hipLaunchKernelGGL((k_raster_tiles<false, false>), grid, dim3(kTileThreads), 0, st, a);
     return hipGetLastError();
 }
 

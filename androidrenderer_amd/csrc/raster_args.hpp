@@ -38,8 +38,9 @@ struct RasterAttr {
     uint32_t seq;          // draw order: (running triangle number) * 8 + fan index
     uint32_t cutout;
     uint16_t vout[3][12];  // fp16 varyings of the input triangle's vertices: colour rgba, normal xyz, tangent xyzw, pad
+    float uv[3][2];        // the float2 texcoord varying
 };
-static_assert(sizeof(RasterAttr) == 136, "RasterAttr layout");
+static_assert(sizeof(RasterAttr) == 160, "RasterAttr layout");
 
 // Shadow pass, CUTOUT records only: what the alpha test of the shadow_masked fragment stage needs (gltf_basic_pbr.slang:181-196 with
 // SAH_DEPTH_ONLY, SAH_MASKED: tinted_base_color.a = texel.a * vertex colour.a * tint.a against the opacity threshold).
@@ -50,8 +51,10 @@ struct ShadowAttr {
     uint16_t pad;
     uint32_t material;
     uint32_t pad2;
+    float uv[3][2];     // texcoords (the alpha may come from the base-colour texture)
+    uint32_t pad3[2];
 };
-static_assert(sizeof(ShadowAttr) == 64, "ShadowAttr layout");
+static_assert(sizeof(ShadowAttr) == 96, "ShadowAttr layout");
 
 struct RasterArgs {
     // scene
@@ -61,6 +64,11 @@ struct RasterArgs {
     const sah_primitive* primitives;
     const sah_material* materials;
     uint32_t num_primitives, num_indices, num_vertices, num_materials;
+    const sah_texture* textures;                     // null: every slot is the material's constant texel
+    const sah_material_textures* material_textures;
+    uint32_t num_textures;
+    float shader_mip_bias;                           // view->material_texture_mip_bias in the G-buffer pass, 0 in the shadow and RSM passes
+    const float* luts;                               // 256 sRGB8 -> linear, then 256 UNORM8 -> float
     // views
     uint32_t num_views;
     float view_matrix[16];     // G-buffer: world -> view
@@ -69,7 +77,7 @@ struct RasterArgs {
     float half_w, half_h;
     uint32_t tiles_x, tiles_y;
     // scratch (device)
-    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats (of which [9] extra list parts, [10] split tiles), [12] CUTOUT triangles seen by a shadow pass that has no attributes
+    uint32_t* counters;  // 16 words: [0] triangles, [1] records, [2] pairs, [3] clip queue, [4..11] stats (of which [9] extra list parts, [10] split tiles), [12] CUTOUT triangles seen by a shadow pass that has no attributes, [13] invalid texture slots / bindings
     uint32_t* tri_base;  // num_primitives
     RasterRecord* records;
     RasterAttr* attrs;

@@ -22,6 +22,19 @@ assert PRIMITIVE.itemsize == C.sizeof(_abi.Primitive) == 96
 IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
 
 
+def sampler(mag=_abi.FILTER_LINEAR, min=_abi.FILTER_LINEAR, mipmap=_abi.FILTER_LINEAR, address_u=_abi.ADDRESS_REPEAT, address_v=_abi.ADDRESS_REPEAT,
+            bias=0.0, min_lod=0.0, max_lod=1000.0):
+    """sah_sampler; the defaults are what gltf_model.cpp:520-586 makes of a glTF sampler with linear filters (VK_LOD_CLAMP_NONE = 1000)."""
+    return _abi.Sampler(mag, min, mipmap, address_u, address_v, bias, min_lod, max_lod)
+
+
+def mip_sizes(width, height, count=None):
+    out = [(width, height)]
+    while (out[-1] != (1, 1)) and (count is None or len(out) < count):
+        out.append((max(out[-1][0] // 2, 1), max(out[-1][1] // 2, 1)))
+    return out
+
+
 def material(base=(1, 1, 1, 1), rough=0.5, metal=0.0, emission=(0, 0, 0, 0), opacity_threshold=0.0, normal_texel=(0.5, 0.5, 1.0, 1.0)):
     m = np.zeros((), dtype=MATERIAL)
     m["base_color_tint"] = base
@@ -39,13 +52,23 @@ class Mesh:
 
     def __init__(self):
         self.positions, self.vertex_data, self.indices, self.primitives, self.materials = [], [], [], [], []
+        self.textures, self.material_textures = [], []
 
-    def add_material(self, m):
+    def add_material(self, m, base_color=_abi.TEXTURE_NONE, normal=_abi.TEXTURE_NONE, data=_abi.TEXTURE_NONE, emission=_abi.TEXTURE_NONE):
+        """`m` from material(); the four keyword arguments are indices returned by add_texture (default: the constant texel of `m`)."""
         self.materials.append(m)
+        self.material_textures.append((base_color, normal, data, emission))
         return len(self.materials) - 1
 
+    def add_texture(self, mips, srgb=False, smp=None):
+        """mips: list of (h, w, 4) uint8 arrays, level 0 first."""
+        assert 1 <= len(mips) <= _abi.MAX_TEXTURE_MIPS
+        self.textures.append(([np.ascontiguousarray(m, dtype=np.uint8) for m in mips], _abi.FORMAT_R8G8B8A8_SRGB if srgb else _abi.FORMAT_R8G8B8A8_UNORM,
+                              smp if smp is not None else sampler()))
+        return len(self.textures) - 1
+
     def add_primitive(self, positions, normals, indices, material_index, model=IDENTITY, ptype=_abi.PRIMITIVE_TYPE_SOLID, colors=None,
-                      tangents=None):
+                      tangents=None, texcoords=None):
         positions = np.asarray(positions, dtype=np.float32).reshape(-1, 3)
         n = positions.shape[0]
         vd = np.zeros(n, dtype=VERTEX_DATA)
@@ -58,6 +81,8 @@ class Mesh:
             tangents = np.concatenate([t, np.ones((n, 1), np.float32)], axis=1)
         vd["tangent"] = np.asarray(tangents, dtype=np.float32).reshape(-1, 4)
         vd["color"] = 0xffffffff if colors is None else np.asarray(colors, dtype=np.uint32)
+        if texcoords is not None:
+            vd["texcoord"] = np.asarray(texcoords, dtype=np.float32).reshape(-1, 2)
         first_vertex = sum(p.shape[0] for p in self.positions)
         first_index = sum(i.shape[0] for i in self.indices)
         self.positions.append(positions)
@@ -79,10 +104,11 @@ class Mesh:
             p["material"] = material_index
         self.primitives.append(p)
 
-    def add_box(self, bmin, bmax, material_index, subdiv=1, **kw):
-        """Axis-aligned box, outward normals, every face a grid of subdiv x subdiv quads."""
+    def add_box(self, bmin, bmax, material_index, subdiv=1, uv_scale=0.25, **kw):
+        """Axis-aligned box, outward normals, every face a grid of subdiv x subdiv quads; texcoords = the two in-face world
+        coordinates * uv_scale (tiling textures)."""
         bmin, bmax = np.asarray(bmin, np.float32), np.asarray(bmax, np.float32)
-        pos, nrm, idx = [], [], []
+        pos, nrm, idx, uvs = [], [], [], []
         n1 = subdiv + 1
         for axis in range(3):
             for sign in (-1.0, 1.0):
@@ -99,6 +125,7 @@ class Mesh:
                         c[u], c[v] = tu[i], tv[j]
                         pos.append(c)
                         nrm.append(n)
+                        uvs.append((np.float32(tu[i]) * np.float32(uv_scale), np.float32(tv[j]) * np.float32(uv_scale)))
                 # counter-clockwise seen from outside in the right-handed y-up world (glTF); the projection has no y flip, so these
                 # arrive clockwise in window coordinates (front faces, render_scene.cpp:196-197)
                 quad = (0, 1, 2, 0, 2, 3) if sign > 0 else (0, 2, 1, 0, 3, 2)
@@ -106,7 +133,7 @@ class Mesh:
                     for i in range(subdiv):
                         corners = (base + j * n1 + i, base + j * n1 + i + 1, base + (j + 1) * n1 + i + 1, base + (j + 1) * n1 + i)
                         idx += [corners[q] for q in quad]
-        return self.add_primitive(pos, nrm, idx, material_index, **kw)
+        return self.add_primitive(pos, nrm, idx, material_index, texcoords=uvs, **kw)
 
     def arrays(self):
         def cat(parts, dtype, shape_tail=()):
@@ -114,15 +141,19 @@ class Mesh:
         return {"positions": cat(self.positions, np.float32, (3,)), "vertex_data": cat(self.vertex_data, VERTEX_DATA),
                 "indices": cat(self.indices, np.uint32),
                 "primitives": np.array(self.primitives, dtype=PRIMITIVE) if self.primitives else np.zeros(0, PRIMITIVE),
-                "materials": np.array(self.materials, dtype=MATERIAL) if self.materials else np.zeros(0, MATERIAL)}
+                "materials": np.array(self.materials, dtype=MATERIAL) if self.materials else np.zeros(0, MATERIAL),
+                "textures": list(self.textures),
+                "material_textures": np.array(self.material_textures, dtype=np.uint32).reshape(-1, 4)}
 
 
 def geometry(arrays, keep=None):
     """sah_scene_geometry over `arrays` (numpy arrays -> host addresses for the oracle; torch uint8 tensors -> device addresses).
     `keep` collects the objects that must outlive the descriptor."""
     g = _abi.SceneGeometry()
+    g._alive = []  # everything the descriptor points to lives as long as the descriptor itself
 
     def addr(a):
+        g._alive.append(a)
         if keep is not None:
             keep.append(a)
         if hasattr(a, "data_ptr"):
@@ -132,6 +163,26 @@ def geometry(arrays, keep=None):
     g.primitives, g.materials = addr(arrays["primitives"]), addr(arrays["materials"])
     g.num_vertices, g.num_indices = arrays["counts"]["vertices"], arrays["counts"]["indices"]
     g.num_primitives, g.num_materials = arrays["counts"]["primitives"], arrays["counts"]["materials"]
+    textures = arrays.get("textures") or []
+    if textures:
+        table = (_abi.Texture * len(textures))()
+        on_device = False
+        for t, (mips, fmt, smp) in zip(table, textures):
+            t.num_mips, t.sampler = len(mips), smp
+            for i, m in enumerate(mips):
+                on_device = on_device or hasattr(m, "data_ptr")
+                h, w = int(m.shape[0]), int(m.shape[1])
+                t.mips[i] = _abi.Plane(addr(m), w, h, w * 4, fmt)
+        if on_device:  # the kernels read the table itself: it has to live in device memory too
+            import torch
+            dev = textures[0][0][0].device
+            table_t = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+            g.textures = addr(table_t)
+        else:
+            g._alive.append(table)
+            g.textures = C.addressof(table)
+        g.num_textures = len(textures)
+        g.material_textures = addr(arrays["material_textures"])
     return g
 
 
@@ -147,9 +198,12 @@ def to_device(arrays, device="cuda"):
     import torch
     host = with_counts(arrays)
     out = {"counts": host["counts"]}
-    for k in ("positions", "vertex_data", "indices", "primitives", "materials"):
+    for k in ("positions", "vertex_data", "indices", "primitives", "materials", "material_textures"):
+        if k not in arrays:
+            continue
         raw = np.frombuffer(np.ascontiguousarray(arrays[k]).tobytes(), dtype=np.uint8)
         out[k] = torch.from_numpy(raw.copy()).to(device)
+    out["textures"] = [([torch.from_numpy(m.copy()).to(device) for m in mips], fmt, smp) for (mips, fmt, smp) in arrays.get("textures", [])]
     return out
 
 
@@ -170,14 +224,43 @@ def atrium(subdiv=1):
     return m
 
 
-def random_soup(seed, triangles=400, extent=6.0, size=(0.05, 3.0), cutout_fraction=0.3, instances=3):
+def random_texture(g, width, height, levels=None, srgb=False, smp=None, alpha=(0, 256)):
+    """(mips, srgb, sampler) with INDEPENDENT random content per level, so that a wrong level selection cannot hide."""
+    mips = []
+    for (w, h) in mip_sizes(width, height, levels):
+        t = g.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        t[..., 3] = g.integers(alpha[0], alpha[1], (h, w), dtype=np.uint8)
+        mips.append(t)
+    return mips, srgb, smp
+
+
+def random_sampler(g):
+    return sampler(mag=int(g.integers(0, 2)), min=int(g.integers(0, 2)), mipmap=int(g.integers(0, 2)), address_u=int(g.integers(0, 3)),
+                   address_v=int(g.integers(0, 3)), bias=float(g.choice([0.0, 0.0, -0.75, 0.5, 1.25])), min_lod=float(g.choice([0.0, 0.0, 1.0])),
+                   max_lod=float(g.choice([1000.0, 1000.0, 2.5, 0.25])))
+
+
+def random_soup(seed, triangles=400, extent=6.0, size=(0.05, 3.0), cutout_fraction=0.3, instances=3, textured=False):
     """Triangle soup for parity tests: sizes from sub-pixel to screen-filling, random vertex colours (alpha drives the cutout
-    test), random normals / tangents, a few instanced draws with rotated model matrices, degenerate and duplicate triangles."""
+    test), random normals / tangents, a few instanced draws with rotated model matrices, degenerate and duplicate triangles.
+    textured: random texcoords in [-2, 3]^2 and every material slot bound to one of eight random textures (sizes 1x1 .. 97x33, full
+    or truncated mip chains, every filter / mipmap mode / address mode / LOD clamp combination the sampler struct can express)."""
     g = synth.rng(seed)
     m = Mesh()
+    tex = []
+    if textured:
+        for (w, h, levels, srgb) in ((64, 64, None, True), (97, 33, None, False), (1, 1, None, True), (16, 128, 3, False), (256, 256, None, True),
+                                     (8, 8, 1, False), (5, 3, None, True), (32, 16, None, False)):
+            tex.append(m.add_texture(*random_texture(g, w, h, levels, srgb, random_sampler(g))))
+
+    def slots():
+        if not textured:
+            return {}
+        pick = lambda: int(g.choice(tex)) if g.uniform() < 0.85 else _abi.TEXTURE_NONE
+        return dict(base_color=pick(), normal=pick(), data=pick(), emission=pick())
     mats = [m.add_material(material(base=tuple(g.uniform(0.2, 1.0, 3)) + (1.0,), rough=float(g.uniform(0.05, 1)), metal=float(g.uniform(0, 1)),
                                     emission=tuple(g.uniform(0, 2, 3)) + (0.0,), opacity_threshold=0.5,
-                                    normal_texel=tuple(g.uniform(0.3, 0.7, 2)) + (1.0, 1.0))) for _ in range(4)]
+                                    normal_texel=tuple(g.uniform(0.3, 0.7, 2)) + (1.0, 1.0)), **slots()) for _ in range(4)]
     prims = []
     for chunk in range(4):
         n = triangles // 4
@@ -192,7 +275,8 @@ def random_soup(seed, triangles=400, extent=6.0, size=(0.05, 3.0), cutout_fracti
         col = g.integers(0, 1 << 32, 3 * n, dtype=np.uint64).astype(np.uint32)
         ptype = _abi.PRIMITIVE_TYPE_CUTOUT if g.uniform() < cutout_fraction or chunk == 3 else _abi.PRIMITIVE_TYPE_SOLID
         idx = g.permutation(3 * n).astype(np.uint32) if chunk == 1 else np.arange(3 * n, dtype=np.uint32)
-        prims.append(m.add_primitive(pos, nrm, idx, mats[chunk], ptype=ptype, colors=col, tangents=tan))
+        uv = g.uniform(-2.0, 3.0, (3 * n, 2)).astype(np.float32) if textured else None
+        prims.append(m.add_primitive(pos, nrm, idx, mats[chunk], ptype=ptype, colors=col, tangents=tan, texcoords=uv))
     for k in range(instances):
         a = float(g.uniform(0, 2 * np.pi))
         model = np.eye(4, dtype=np.float32)

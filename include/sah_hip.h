@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SAH_ABI_VERSION 2
+#define SAH_ABI_VERSION 3
 
 typedef enum sah_status {
     SAH_OK = 0,
@@ -323,14 +323,59 @@ typedef struct sah_vertex_data {
 } sah_vertex_data;
 
 /* BasicPbrMaterialGpu — RenderCore/shared/basic_pbr_material.hpp:6-19, with each bindless texture index replaced by the
- * texel a 1x1 texture of that slot would return (the glTF assets are not part of the tree; mip-biased sampling of real textures is
- * the renderer's side of the seam). */
+ * texel a 1x1 texture of that slot would return; real textures are bound per material through sah_material_textures below. */
 typedef struct sah_material {
     float base_color_tint[4];
     float emission_factor[4];
     float metalness_factor, roughness_factor, opacity_threshold, padding1;
     float base_color_texel[4], normal_texel[4], data_texel[4], emission_texel[4];
 } sah_material;
+
+/* ---- material textures: `textures[material.*_texture_index].SampleBias(vertex.texcoord, mip_bias)`, gltf_basic_pbr.slang:177-226 ----
+ * A bindless slot is an R8G8B8A8 image with its mip chain and the sampler it is bound with (gltf_model.cpp:229-279, 520-586; the
+ * default sampler of render_backend.cpp:1129-1134 is all-NEAREST / REPEAT).  Vulkan leaves the level-of-detail arithmetic, the
+ * derivative quads and anisotropic footprints to the implementation; this library fixes them as follows (DESIGN.md §5d "Sampling"):
+ *   texcoord   the float2 varying, perspective-correct in fp32: (l0 t0 + l1 t1) + l2 t2 with the input-triangle barycentrics l;
+ *   d/dx, d/dy fine quad differences: quads are the 2x2 pixel blocks at even window coordinates, d/dx = t(x | 1, y) - t(x & ~1, y),
+ *              d/dy likewise; the varying of the other pixel is the same triangle's, extrapolated when it is not covered;
+ *   lod        rho2 = fmax(mx.x^2 + mx.y^2, my.x^2 + my.y^2), m = derivative * size of level 0 (every operator fp32);
+ *              lambda = rho2 > 0 ? 0.5 * RN32(log2 evaluated in double) : -inf;  lambda += (sampler.mip_lod_bias + shader bias);
+ *              lambda = fmin(fmax(lambda, min_lod), max_lod);  maxAnisotropy is ignored (isotropic footprint);
+ *   filter     lambda <= 0 ? mag_filter : min_filter;
+ *   level      mipmap NEAREST: lambda <= 0.5 ? 0 : min(ceil(lambda + 0.5) - 1, q), q = num_mips - 1;
+ *              mipmap LINEAR:  d = clamp(lambda, 0, q), hi = floor(d), lo = min(hi + 1, q), delta = d - hi,
+ *                              result = (1 - delta) * tau(hi) + delta * tau(lo), every operator rounded;
+ *   tau        LINEAR: the bilinear weighted sum of the other samplers of this library (u * w - 0.5, fma chain from +0 in the order
+ *              (i,j) (i+1,j) (i,j+1) (i+1,j+1)); NEAREST: texel (floor(u * w), floor(v * h)); indices wrapped per address mode;
+ *              a NaN coordinate yields NaN in every channel;
+ *   texel      UNORM: byte / 255 in fp32; SRGB: rgb through the exact sRGB decode rounded to fp32, alpha as UNORM.
+ * The shader bias is view->material_texture_mip_bias in the G-buffer pass and 0 in the shadow and RSM passes (:175-178). */
+#define SAH_FILTER_NEAREST 0 /* VkFilter / VkSamplerMipmapMode values */
+#define SAH_FILTER_LINEAR 1
+#define SAH_ADDRESS_REPEAT 0 /* VkSamplerAddressMode values */
+#define SAH_ADDRESS_MIRRORED_REPEAT 1
+#define SAH_ADDRESS_CLAMP_TO_EDGE 2
+#define SAH_MAX_TEXTURE_MIPS 14
+#define SAH_TEXTURE_NONE 0xffffffffu
+
+typedef struct sah_sampler {
+    uint32_t mag_filter, min_filter, mipmap_mode;
+    uint32_t address_u, address_v;
+    float mip_lod_bias, min_lod, max_lod;
+} sah_sampler;
+
+typedef struct sah_texture {
+    sah_plane mips[SAH_MAX_TEXTURE_MIPS]; /* level 0 first; R8G8B8A8_UNORM or R8G8B8A8_SRGB, every level the same format */
+    uint32_t num_mips;                    /* 1 .. SAH_MAX_TEXTURE_MIPS */
+    uint32_t padding;
+    sah_sampler sampler;
+} sah_texture;
+
+/* The four texture indices of BasicPbrMaterialGpu (basic_pbr_material.hpp:15-18), one record per material; SAH_TEXTURE_NONE selects
+ * the constant texel of sah_material for that slot. */
+typedef struct sah_material_textures {
+    uint32_t base_color, normal, data, emission;
+} sah_material_textures;
 
 #define SAH_PRIMITIVE_TYPE_SOLID 0  /* back faces culled (render_scene.cpp:196-197) */
 #define SAH_PRIMITIVE_TYPE_CUTOUT 1 /* no culling, alpha test against opacity_threshold (render_scene.cpp:221-222) */
@@ -353,6 +398,9 @@ typedef struct sah_scene_geometry {
                                            wherever they sit in the list (RenderScene::draw_opaque, then draw_masked) */
     const sah_material* materials;      /* sah_shadow_render: may be NULL when the scene has no CUTOUT primitive */
     uint32_t num_vertices, num_indices, num_primitives, num_materials;
+    const sah_texture* textures;                    /* num_textures slots, or NULL */
+    const sah_material_textures* material_textures; /* num_materials records, or NULL: every slot of every material is its constant texel */
+    uint32_t num_textures, padding;
 } sah_scene_geometry;
 
 /* Written by both passes when `stats` is not NULL (device memory, 8 x uint32): [0] (view, triangle) pairs processed, [1] culled,
@@ -373,7 +421,8 @@ int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_s
 
 /* Depth pre-pass + G-buffer pass — RenderCore/render/phase/gbuffer_phase.cpp:27-97 (clear values :66-87), pipelines
  * RenderCore/render/material_pipelines.cpp:13-29,104-140 (reverse-Z GREATER, then EQUAL), shaders
- * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253 (SAH_MAIN_VIEW).  Writes all five planes of `out`. */
+ * RenderCore/shaders/materials/gltf_basic_pbr.slang:110-253 (SAH_MAIN_VIEW).  Writes all five planes of `out`.  A texture index
+ * outside scene->textures, or a texture whose levels are not R8G8B8A8, fails with SAH_ERR_INVALID_ARGUMENT. */
 int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_view_data* view, const sah_gbuffer* out, uint32_t* stats);
 
 /* ---- LPV injection chain: RSM -> VPL list -> LPV (SURVEY.md §8-f4 and the producers of a3's volumes) -------------------------

@@ -15,6 +15,7 @@
 #include "codec.hpp"
 #include "brdf.hpp"
 #include "math.hpp"
+#include "texture.hpp"
 
 namespace orc {
 namespace {
@@ -93,6 +94,9 @@ struct Fragment {
     int x, y;
     F z;
     F lambda[3];  // perspective-correct barycentrics in the input triangle
+    // the same at the other pixel of the fragment's 2x2 quad row / column (quads sit at even window coordinates), extrapolated when that
+    // pixel is not covered: what the derivatives of the texture coordinates are formed from
+    F lambda_qx[3], lambda_qy[3];
 };
 
 struct Stats {
@@ -154,12 +158,22 @@ void raster_triangle(RasterVertex v0, RasterVertex v1, RasterVertex v2, bool cul
             Fragment f;
             f.x = (int)px;
             f.y = (int)py;
-            const F b0 = F((float)e[0]) * inv_area, b1 = F((float)e[1]) * inv_area, b2 = F((float)e[2]) * inv_area;
             f.z = F((float)std::fma((double)py, zy, std::fma((double)px, zx, zc)));
-            const F q0 = b0 * v0.inv_w, q1 = b1 * v1.inv_w, q2 = b2 * v2.inv_w;
-            const F s = q0 + q1 + q2;
-            const F l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
-            for (int k = 0; k < 3; k++) f.lambda[k] = l0 * v0.bary[k] + l1 * v1.bary[k] + l2 * v2.bary[k];
+            auto lambda_at = [&](int64_t qx, int64_t qy, F out[3]) {
+                const int64_t ccx = qx * 256 + 128, ccy = qy * 256 + 128;
+                F b[3];
+                for (int i = 0; i < 3; i++) {
+                    const RasterVertex &a = *v[(i + 1) % 3], &bb = *v[(i + 2) % 3];
+                    b[i] = F((float)((bb.X - a.X) * (ccy - a.Y) - (bb.Y - a.Y) * (ccx - a.X))) * inv_area;
+                }
+                const F q0 = b[0] * v0.inv_w, q1 = b[1] * v1.inv_w, q2 = b[2] * v2.inv_w;
+                const F s = q0 + q1 + q2;
+                const F l0 = q0 / s, l1 = q1 / s, l2 = q2 / s;
+                for (int k = 0; k < 3; k++) out[k] = l0 * v0.bary[k] + l1 * v1.bary[k] + l2 * v2.bary[k];
+            };
+            lambda_at(px, py, f.lambda);
+            lambda_at(px ^ 1, py, f.lambda_qx);
+            lambda_at(px, py ^ 1, f.lambda_qy);
             emit(f);
         }
 }
@@ -202,6 +216,16 @@ void write_stats(uint32_t* out, const Stats& st) {
 bool geometry_ok(const sah_scene_geometry* g, bool need_attributes) {
     if (!g || (g->num_primitives && !g->primitives)) return false;
     if (need_attributes && g->num_primitives && (!g->vertex_data || !g->materials)) return false;
+    if (need_attributes && g->material_textures) {
+        if (g->num_textures && !g->textures) return false;
+        for (uint32_t t = 0; t < g->num_textures; t++)
+            if (!texture_ok(g->textures[t])) return false;
+        for (uint32_t m = 0; m < g->num_materials; m++) {
+            const sah_material_textures& mt = g->material_textures[m];
+            for (uint32_t idx : {mt.base_color, mt.normal, mt.data, mt.emission})
+                if (idx != SAH_TEXTURE_NONE && idx >= g->num_textures) return false;
+        }
+    }
     for (uint32_t p = 0; p < g->num_primitives; p++) {
         const sah_primitive& pr = g->primitives[p];
         if (pr.index_count % 3 || (uint64_t)pr.first_index + pr.index_count > g->num_indices) return false;
@@ -220,6 +244,7 @@ struct VertexOut {  // the half-precision varyings of VertexOutput (:83-96), hel
     H color[4];
     H normal[3];
     H tangent[4];
+    F uv[2];  // float2 texcoord
 };
 
 VertexOut vertex_outputs(const sah_scene_geometry& g, const sah_primitive& prim, uint32_t index) {
@@ -238,10 +263,45 @@ VertexOut vertex_outputs(const sah_scene_geometry& g, const sah_primitive& prim,
     o.normal[0] = H(n.x.v); o.normal[1] = H(n.y.v); o.normal[2] = H(n.z.v);
     o.tangent[0] = H(t.x.v); o.tangent[1] = H(t.y.v); o.tangent[2] = H(t.z.v);
     o.tangent[3] = H(vd.tangent[3]);
+    o.uv[0] = F(vd.texcoord[0]);
+    o.uv[1] = F(vd.texcoord[1]);
     return o;
 }
 
 H interpolate(const F lambda[3], H a, H b, H c) { return H((lambda[0] * F(a.v) + lambda[1] * F(b.v) + lambda[2] * F(c.v)).v); }
+
+// `(half4)textures[index].SampleBias(vertex.texcoord, mip_bias)` of one material slot (0 base colour, 1 normal, 2 data, 3 emission), or the
+// material's constant texel when the slot has no texture
+struct TexEnv {
+    const sah_scene_geometry* g;
+    uint32_t material;
+    float shader_bias;
+};
+void material_texel(const TexEnv& env, int slot, const float constant[4], const VertexOut vo[3], const Fragment& f, H out[4]) {
+    uint32_t index = SAH_TEXTURE_NONE;
+    if (env.g->material_textures) {
+        const sah_material_textures& mt = env.g->material_textures[env.material];
+        index = slot == 0 ? mt.base_color : slot == 1 ? mt.normal : slot == 2 ? mt.data : mt.emission;
+    }
+    if (index == SAH_TEXTURE_NONE) {
+        for (int k = 0; k < 4; k++) out[k] = H(constant[k]);
+        return;
+    }
+    auto texcoord = [&](const F lambda[3], float t[2]) {
+        for (int c = 0; c < 2; c++) t[c] = (lambda[0] * vo[0].uv[c] + lambda[1] * vo[1].uv[c] + lambda[2] * vo[2].uv[c]).v;
+    };
+    float t[2], tx[2], ty[2], ddx[2], ddy[2];
+    texcoord(f.lambda, t);
+    texcoord(f.lambda_qx, tx);
+    texcoord(f.lambda_qy, ty);
+    for (int c = 0; c < 2; c++) {  // fine derivatives: odd pixel minus even pixel of the quad
+        ddx[c] = (f.x & 1) ? (F(t[c]) - F(tx[c])).v : (F(tx[c]) - F(t[c])).v;
+        ddy[c] = (f.y & 1) ? (F(t[c]) - F(ty[c])).v : (F(ty[c]) - F(t[c])).v;
+    }
+    float texel[4];
+    sample_texture(env.g->textures[index], t, ddx, ddy, env.shader_bias, texel);
+    for (int k = 0; k < 4; k++) out[k] = H(texel[k]);
+}
 
 struct GbufferTexel {
     uint8_t color[4];
@@ -253,29 +313,35 @@ struct GbufferTexel {
 
 uint8_t srgb8(H v) { return float_to_unorm8(linear_to_srgb_f(v.v)); }
 
-GbufferTexel shade_fragment(const sah_material& m, const VertexOut vo[3], const F lambda[3]) {
+GbufferTexel shade_fragment(const TexEnv& env, const sah_material& m, const VertexOut vo[3], const Fragment& f) {
     GbufferTexel out{};
+    const F* lambda = f.lambda;
+    H base_texel[4], normal_texel[4], data_texel[4], emission_texel[4];
+    material_texel(env, 0, m.base_color_texel, vo, f, base_texel);
+    material_texel(env, 1, m.normal_texel, vo, f, normal_texel);
+    material_texel(env, 2, m.data_texel, vo, f, data_texel);
+    material_texel(env, 3, m.emission_texel, vo, f, emission_texel);
     H color[4], normal[3], tangent[4];
     for (int k = 0; k < 4; k++) color[k] = interpolate(lambda, vo[0].color[k], vo[1].color[k], vo[2].color[k]);
     for (int k = 0; k < 3; k++) normal[k] = interpolate(lambda, vo[0].normal[k], vo[1].normal[k], vo[2].normal[k]);
     for (int k = 0; k < 4; k++) tangent[k] = interpolate(lambda, vo[0].tangent[k], vo[1].tangent[k], vo[2].tangent[k]);
     // base colour (:181-189)
     H tinted[4];
-    for (int k = 0; k < 4; k++) tinted[k] = H(m.base_color_texel[k]) * color[k] * H(m.base_color_tint[k]);
+    for (int k = 0; k < 4; k++) tinted[k] = base_texel[k] * color[k] * H(m.base_color_tint[k]);
     out.discarded = tinted[3].v <= m.opacity_threshold;
     // normals (:197-207)
     const H3 N{normal[0], normal[1], normal[2]}, T{tangent[0], tangent[1], tangent[2]};
     const H3 B = cross(N, T) * tangent[3];
     H ns[3];
-    for (int k = 0; k < 3; k++) ns[k] = H(m.normal_texel[k]) * H(2.0f) - H(1.0f);
+    for (int k = 0; k < 3; k++) ns[k] = normal_texel[k] * H(2.0f) - H(1.0f);
     const H nx = ns[0] * T.x + ns[1] * B.x + ns[2] * N.x;
     const H ny = ns[0] * T.y + ns[1] * B.y + ns[2] * N.y;
     const H nz = ns[0] * T.z + ns[1] * B.z + ns[2] * N.z;
     // data (:213-218) and emission (:221-226)
     const H factor[4] = {H(0.0f), H(m.roughness_factor), H(m.metalness_factor), H(0.0f)};
     for (int k = 0; k < 4; k++) {
-        const H d = H(m.data_texel[k]) * factor[k];
-        const H e = H(m.emission_texel[k]) * H(m.emission_factor[k]);
+        const H d = data_texel[k] * factor[k];
+        const H e = emission_texel[k] * H(m.emission_factor[k]);
         out.data[k] = float_to_unorm8(d.v);
         out.emission[k] = k < 3 ? srgb8(e) : float_to_unorm8(e.v);
         out.color[k] = k < 3 ? srgb8(tinted[k]) : float_to_unorm8(tinted[k].v);
@@ -295,8 +361,10 @@ std::vector<uint32_t> draw_order(const sah_scene_geometry& g) {
 }
 
 // tinted_base_color.a of the *_masked fragment stages (gltf_basic_pbr.slang:181-196): texel.a * vertex colour.a * tint.a in half
-bool alpha_discarded(const sah_material& m, const VertexOut vo[3], const F lambda[3]) {
-    const H a = H(m.base_color_texel[3]) * interpolate(lambda, vo[0].color[3], vo[1].color[3], vo[2].color[3]) * H(m.base_color_tint[3]);
+bool alpha_discarded(const TexEnv& env, const sah_material& m, const VertexOut vo[3], const Fragment& f) {
+    H base_texel[4];
+    material_texel(env, 0, m.base_color_texel, vo, f, base_texel);
+    const H a = base_texel[3] * interpolate(f.lambda, vo[0].color[3], vo[1].color[3], vo[2].color[3]) * H(m.base_color_tint[3]);
     return a.v <= m.opacity_threshold;
 }
 
@@ -309,13 +377,16 @@ struct RsmTexel {
     uint8_t flux[4], normal[4];
     bool discarded;
 };
-RsmTexel shade_rsm_fragment(const sah_material& m, const VertexOut vo[3], const F lambda[3], const float sun_direction[3]) {
+RsmTexel shade_rsm_fragment(const TexEnv& env, const sah_material& m, const VertexOut vo[3], const Fragment& f, const float sun_direction[3]) {
     RsmTexel out{};
+    const F* lambda = f.lambda;
+    H base_texel[4];
+    material_texel(env, 0, m.base_color_texel, vo, f, base_texel);
     H color[4], normal[3];
     for (int k = 0; k < 4; k++) color[k] = interpolate(lambda, vo[0].color[k], vo[1].color[k], vo[2].color[k]);
     for (int k = 0; k < 3; k++) normal[k] = interpolate(lambda, vo[0].normal[k], vo[1].normal[k], vo[2].normal[k]);
     H tinted[4];
-    for (int k = 0; k < 4; k++) tinted[k] = H(m.base_color_texel[k]) * color[k] * H(m.base_color_tint[k]);
+    for (int k = 0; k < 4; k++) tinted[k] = base_texel[k] * color[k] * H(m.base_color_tint[k]);
     out.discarded = tinted[3].v <= m.opacity_threshold;
     Surface<H> s;
     s.base_color = {tinted[0], tinted[1], tinted[2]};
@@ -361,7 +432,7 @@ int orc_shadow_render(const sah_scene_geometry* scene, const sah_sun_light_const
                     for (int k = 0; k < 3; k++) vo[k] = vertex_outputs(*scene, prim, scene->indices[prim.first_index + 3 * tri + k]);
                 process_triangle(*scene, prim, tri, /*clip_depth=*/false, W, H, st, [&](F4 world) { return mul(world_to_ndc, world); },
                                  [&](const Fragment& f, uint32_t) {
-                                     if (masked && alpha_discarded(scene->materials[prim.material], vo, f.lambda)) return;
+                                     if (masked && alpha_discarded(TexEnv{scene, prim.material, 0.0f}, scene->materials[prim.material], vo, f)) return;
                                      const F z = nclamp(f.z, F(0.0f), F(1.0f));  // depth clamp; NaN -> 0
                                      const uint32_t code = (uint32_t)std::nearbyint(z.v * 65535.0f);
                                      uint16_t* texel = (uint16_t*)(base + (size_t)f.y * shadowmap->row_pitch_bytes) + f.x;
@@ -413,12 +484,13 @@ int orc_gbuffer_render(const sah_scene_geometry* scene, const sah_view_data* vie
                                      float stored;
                                      std::memcpy(&stored, at(out->depth, f.x, f.y, 4), 4);
                                      if (pass == 0 ? !(z.v > stored) : !(z.v == stored && z.v > 0.0f)) return;  // GREATER / EQUAL (never the cleared 0)
-                                     if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && alpha_discarded(mat, vo, f.lambda)) return;
+                                     const TexEnv env{scene, prim.material, view->material_texture_mip_bias};
+                                     if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && alpha_discarded(env, mat, vo, f)) return;
                                      if (pass == 0) {
                                          std::memcpy(at(out->depth, f.x, f.y, 4), &z.v, 4);
                                          return;
                                      }
-                                     const GbufferTexel t = shade_fragment(mat, vo, f.lambda);
+                                     const GbufferTexel t = shade_fragment(env, mat, vo, f);
                                      std::memcpy(at(out->color, f.x, f.y, 4), t.color, 4);
                                      std::memcpy(at(out->normals, f.x, f.y, 8), t.normal, 8);
                                      std::memcpy(at(out->data, f.x, f.y, 4), t.data, 4);
@@ -466,7 +538,7 @@ int orc_rsm_render(const sah_scene_geometry* scene, const sah_sun_light_constant
                                      uint16_t stored;
                                      std::memcpy(&stored, at(rsm->depth, layer, f.x, f.y, 2), 2);
                                      if (!(code < stored)) return;  // VK_COMPARE_OP_LESS on the D16 code: the first of equal codes stays
-                                     const RsmTexel t = shade_rsm_fragment(mat, vo, f.lambda, sun->direction_and_tan_size);
+                                     const RsmTexel t = shade_rsm_fragment(TexEnv{scene, prim.material, 0.0f}, mat, vo, f, sun->direction_and_tan_size);
                                      if (prim.type == SAH_PRIMITIVE_TYPE_CUTOUT && t.discarded) return;
                                      const uint16_t c16 = (uint16_t)code;
                                      std::memcpy(at(rsm->depth, layer, f.x, f.y, 2), &c16, 2);
