@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/sah_hip.h"
@@ -318,6 +319,16 @@ int sah_comm_init(sah_ctx* ctx, const void* comm_id) {
     const ncclResult_t rc = init(&comm, ctx->world, id, ctx->rank);
     if (rc != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "ncclCommInitRank failed: %d", (int)rc);
     ctx->comm = comm;
+    // The reversed-rank communicator of sah_allgather_rows_reversed is made here, while nothing is in flight on the parent (a split
+    // is a collective over the parent and must not overlap its other operations).  If the installed RCCL cannot split, the reversed
+    // exchange falls back to grouped point-to-point transfers on the parent communicator.
+    ctx->comm_reversed = nullptr;
+    const char* no_split = getenv("SAH_COMM_NO_SPLIT");
+    auto split = RCCL_SYM(ctx->rccl, ncclCommSplit);
+    if (split && !(no_split && no_split[0] == '1')) {
+        ncclComm_t rev = nullptr;
+        if (split(comm, 0, ctx->world - 1 - ctx->rank, &rev, nullptr) == ncclSuccess && rev) ctx->comm_reversed = rev;
+    }
     return SAH_OK;
 }
 
@@ -352,8 +363,9 @@ int sah_comm_wait(sah_ctx* ctx) {
     return SAH_OK;
 }
 
-// `reversed`: the exchange runs on a second communicator in which this process has rank world - 1 - rank (made on first use with
-// ncclCommSplit: same devices, key = reversed rank), so that the in-place slot of rank r is block world - 1 - r.
+// `reversed`: the exchange runs on a second communicator in which this process has rank world - 1 - rank (made by sah_comm_init with
+// ncclCommSplit: same devices, key = reversed rank), so that the in-place slot of rank r is block world - 1 - r.  Without that
+// communicator the same blocks travel as grouped ncclSend / ncclRecv pairs on the parent.
 static int allgather_bytes_impl(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank, bool reversed) {
     if (!ctx || !buffer) return SAH_ERR_INVALID_ARGUMENT;
     if (bytes_per_rank == 0) return SAH_OK;
@@ -364,16 +376,9 @@ static int allgather_bytes_impl(sah_ctx* ctx, void* buffer, uint64_t bytes_per_r
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     int slot = ctx->rank;
+    const bool p2p = reversed && !ctx->comm_reversed;
     if (reversed) {
-        if (!ctx->comm_reversed) {
-            auto split = RCCL_SYM(ctx->rccl, ncclCommSplit);
-            if (!split) return fail(ctx, SAH_ERR_COMM, "ncclCommSplit not found");
-            ncclComm_t rev = nullptr;
-            const ncclResult_t rc = split((ncclComm_t)ctx->comm, 0, ctx->world - 1 - ctx->rank, &rev, nullptr);
-            if (rc != ncclSuccess || !rev) return fail(ctx, SAH_ERR_COMM, "ncclCommSplit failed: %d", (int)rc);
-            ctx->comm_reversed = rev;
-        }
-        comm = (ncclComm_t)ctx->comm_reversed;
+        if (ctx->comm_reversed) comm = (ncclComm_t)ctx->comm_reversed;
         slot = ctx->world - 1 - ctx->rank;
     }
     auto ag = RCCL_SYM(ctx->rccl, ncclAllGather);
@@ -386,9 +391,25 @@ static int allgather_bytes_impl(sah_ctx* ctx, void* buffer, uint64_t bytes_per_r
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0));
         st = ctx->comm_stream;
     }
-    // in place: the send buffer is this rank's slot of the receive buffer
-    const ncclResult_t rc = ag(send, buffer, (size_t)bytes_per_rank, ncclUint8, comm, st);
-    if (rc != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "ncclAllGather failed: %d", (int)rc);
+    if (p2p) {
+        auto gs = RCCL_SYM(ctx->rccl, ncclGroupStart);
+        auto ge = RCCL_SYM(ctx->rccl, ncclGroupEnd);
+        auto snd = RCCL_SYM(ctx->rccl, ncclSend);
+        auto rcv = RCCL_SYM(ctx->rccl, ncclRecv);
+        if (!gs || !ge || !snd || !rcv) return fail(ctx, SAH_ERR_COMM, "ncclSend / ncclRecv / ncclGroup* not found");
+        ncclResult_t rc = gs();
+        for (int p = 0; p < ctx->world && rc == ncclSuccess; p++) {
+            if (p == ctx->rank) continue;  // this rank's block is already in its slot
+            rc = snd(send, (size_t)bytes_per_rank, ncclUint8, p, comm, st);
+            if (rc == ncclSuccess) rc = rcv((uint8_t*)buffer + (size_t)(ctx->world - 1 - p) * bytes_per_rank, (size_t)bytes_per_rank, ncclUint8, p, comm, st);
+        }
+        const ncclResult_t rc_end = ge();
+        if (rc != ncclSuccess || rc_end != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "grouped ncclSend / ncclRecv failed: %d / %d", (int)rc, (int)rc_end);
+    } else {
+        // in place: the send buffer is this rank's slot of the receive buffer
+        const ncclResult_t rc = ag(send, buffer, (size_t)bytes_per_rank, ncclUint8, comm, st);
+        if (rc != ncclSuccess) return fail(ctx, SAH_ERR_COMM, "ncclAllGather failed: %d", (int)rc);
+    }
     if (side) {
         HIP_TRY(ctx, hipEventRecord(ctx->comm_done, ctx->comm_stream));
         ctx->comm_pending = true;

@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="4k_deferred_gi", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: 4k_deferred_gi on one GPU (the headline pass); 4k_lpv_gi_chain at N > 1 (the same lighting + post chain, "
+                         "row-sharded, final RGBA8 image gathered)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
@@ -128,6 +130,8 @@ def main():
     elif torch_pg:
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29511", rank=0, world_size=1, device_id=dev)
 
+    if args.workload is None:
+        args.workload = "4k_lpv_gi_chain" if world > 1 else "4k_deferred_gi"
     wl = WORKLOADS[args.workload]
     W, H = wl["res"]
     sun_mode = {"off": _abi.SHADOW_MODE_OFF, "csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}[wl["sun"]]
@@ -155,12 +159,30 @@ def main():
             comm_id = box[0]
         else:
             comm_id = lib.comm_unique_id()
-    ctx = lib.Context(device=local_rank, rank=rank, world=world, comm_id=comm_id)
+    comm_note = None
+    try:
+        ctx = lib.Context(device=local_rank, rank=rank, world=world, comm_id=comm_id)
+        ok = 1
+    except Exception as err:  # the communicator could not be built on this rank: every rank falls back together, and the line says so
+        ctx, ok, comm_note = None, 0, str(err)
+    if world > 1 and lib_gather:
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        if not lib_gather:
+            raise SystemExit(f"sah_create failed: {comm_note}")
+        print(f"[bench] rank {rank}: library communicator unavailable ({comm_note}); all ranks use torch.distributed for the exchange", file=sys.stderr)
+        lib_gather = False
+        del ctx
+        ctx = lib.Context(device=local_rank, rank=rank, world=world, comm_id=None)
+        comm_note = comm_note or "another rank failed to build the library communicator"
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     comm_stream = None
-    if lib_gather and not args.no_overlap and not chain:
+    if lib_gather and not args.no_overlap:
         comm_stream = torch.cuda.Stream(device=dev)
-        ctx.comm_set_stream(comm_stream.cuda_stream)
+        if not chain:
+            ctx.comm_set_stream(comm_stream.cuda_stream)
 
     # row shard of this rank: ceil(H / world) rows per gather slot, clipped to the image (androidrenderer_amd/shard.py)
     rows_per = -(-H // world)
@@ -191,7 +213,20 @@ def main():
         ctx.lpv_propagate(vd, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in scratch], 4, 32)
         torch.cuda.synchronize()
 
-    if chain:
+    pipelined = chain and gather and lib_gather and comm_stream is not None
+    if pipelined:
+        # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
+        pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream)
+        sc = pc.sets[0]
+
+        def step(i, e0=None, e1=None):
+            pc.submit((e0, e1) if e0 is not None else None)
+
+        def drain():
+            pc.flush()
+            ctx.comm_wait()
+        my_px = W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
+    elif chain:
         # the whole frame, sharded (chain.py): every exchange goes through the library (torch path only with --torch-gather)
         sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world)
         q, per = sc.plan.mip0_rows_per_rank, sc.plan.rows_per_rank
@@ -328,8 +363,8 @@ def main():
                 "gbuffer": wl["gbuffer"],
                 "parallelism": par,
                 "gather": bool(gather),
-                "gather_through": ("sah_allgather_rows (library, RCCL)" if lib_gather else "torch.distributed") if gather else None,
-                "gather_overlapped_with_next_frame": bool(gather and not chain and not args.no_overlap),
+                "gather_through": ("sah_allgather_rows (library, RCCL)" if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
+                "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
             },
             "roofline": {
                 "bound": "hbm",

@@ -192,3 +192,52 @@ def test_hip_chain_through_a_one_rank_communicator():
     finally:
         torch.cuda.synchronize()
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_split", [False, True])
+def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split):
+    """Two frames in flight (chain.PipelinedChain: both exchanges on the side stream of a one-rank communicator), a different AO plane
+    per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's."""
+    import torch
+    from androidrenderer_amd import chain, lib
+    from tests import util
+    if no_split:  # the reversed exchange without ncclCommSplit (grouped point-to-point on the parent communicator)
+        monkeypatch.setenv("SAH_COMM_NO_SPLIT", "1")
+    ctx = lib.Context(device=0, rank=0, world=1, comm_id=lib.comm_unique_id())
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    try:
+        f = util.LightingFrame(160, 90, seed=33, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium", shadowmap_res=256)
+        dev = f.device_arrays()
+        g = torch.Generator(device="cpu").manual_seed(5)
+        ao = [torch.rand((90, 160), generator=g).cuda() for _ in range(7)]
+        plain = chain.ShardedChain(ctx, f, dev, 0, 1)
+        want = []
+        for a in ao:
+            dev["ao"].copy_(a)
+            plain.step(gather=False)
+            torch.cuda.synchronize()
+            want.append(plain.out.cpu().numpy().copy())
+        assert not np.array_equal(want[0], want[1])
+        pc = chain.PipelinedChain(ctx, f, dev, 0, 1, side)
+        got = {}
+        for i, a in enumerate(ao):
+            dev["ao"].copy_(a)             # on the work stream: ordered with the frames around it
+            pc.submit()
+            if i in (2, 4):                # warm-up boundary as in bench.py: flush, then carry on
+                pc.flush()
+                torch.cuda.synchronize()
+                got[i] = pc.image(i).cpu().numpy().copy()
+                got[i - 1] = pc.image(i - 1).cpu().numpy().copy()
+        pc.flush()
+        ctx.comm_wait()
+        torch.cuda.synchronize()
+        got[6] = pc.image(6).cpu().numpy().copy()
+        got[5] = pc.image(5).cpu().numpy().copy()
+        for i, img in sorted(got.items()):
+            assert np.array_equal(img, want[i]), f"frame {i}"
+        assert pc.finished == pc.submitted == 7
+    finally:
+        torch.cuda.synchronize()
+        ctx.close()
