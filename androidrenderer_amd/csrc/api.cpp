@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -494,7 +495,8 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
     const bool use_fast = fast_kind && !ctx->force_general && detect_fast_path(d, sun_mode, gi_kind, csm, &fast);
     // the tiled kernel (light list, cache / RTGI overlays) borrows the fast kernel's geometry and CSM sun when the uniform blocks allow
     // (its LPV overlay, if any, stays the general one: the LPV part of the check is skipped)
-    const bool tiled_fast_geom = !fast_kind && !ctx->force_general && detect_fast_path(d, sun_mode, SAH_GI_NONE, csm, &fast);
+    static const bool no_tiled_fast_geom = getenv("SAH_TILED_GENERAL_GEOMETRY") != nullptr;  // A/B switch (tools/ab.sh)
+    const bool tiled_fast_geom = !fast_kind && !ctx->force_general && !no_tiled_fast_geom && detect_fast_path(d, sun_mode, SAH_GI_NONE, csm, &fast);
     if (use_fast) {
         // deferred-pixel segments (params.hpp): one per wave of the fast kernel, 64 * ppt byte codes + a 16-bit count each
         const uint64_t groups = (uint64_t)(W / (uint32_t)ppt) * (r1 - r0);

@@ -140,6 +140,8 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom,
         if (!rgba16f_ok(&bloom->mips[m])) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "bloom mip %u must be RGBA16F", m);
         t.mips[m] = parg(&bloom->mips[m]);
         t.mip_w[m] = bloom->mips[m].width;
+        t.mip_inv_w[m] = 1.0f / (float)bloom->mips[m].width;
+        t.mip_inv_h[m] = 1.0f / (float)bloom->mips[m].height;
         t.mip_h[m] = bloom->mips[m].height;
     }
     if (!ctx->tm_thresholds) {  // built once per context (~15k libm pow calls)

@@ -10,6 +10,7 @@ struct TonemapArgs {
     uint32_t scene_w, scene_h;
     PlaneArg mips[8];
     uint32_t mip_w[8], mip_h[8];
+    float mip_inv_w[8], mip_inv_h[8];  // 1.0f / (float)mip_w, 1.0f / (float)mip_h (IEEE on the host: the shader's `1.0 / textureSize`)
     uint32_t num_mips;
     PlaneArg out;
     uint32_t out_w, out_h;
