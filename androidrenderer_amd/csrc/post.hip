@@ -31,27 +31,35 @@ __global__ void __launch_bounds__(256) k_bloom_downsample(PlaneArg src, uint32_t
 }
 
 // ---- a7, LDS-staged --------------------------------------------------------------------------------------------------------------
-// A 256-thread workgroup produces a 64x8 tile of the destination mip (two texels per thread).  The source rectangle the tile's 20
-// taps per texel can touch (2x the tile plus 3 texels either side) is copied to LDS once — every source texel was fetched about 20
-// times from the vector cache before — and the 6 + 6 axis set-ups of every tile column / row are tabulated once per workgroup.
-// The 5 boxes x 4 bilinear taps of bloom_downsample.comp:16-52 use only 6 distinct x and 6 distinct y coordinates (u -+ ix, and those
-// -+ ix again); same taps, same order, same operators as k_bloom_downsample: bit-identical.  A tile whose rectangle does not fit (extreme
-// aspect ratios) takes the global-memory form.  `row_begin/row_end`: destination rows to produce (row-sharded pyramids).
-constexpr int kBlW = 64, kBlH = 8, kBlTexels = 136 * 24;
-SAH_DEV C3 bloom_texel(const char* tex, const AxisE* col, const AxisE* row) {  // col[k * kBlW], row[k * kBlH], k = 0..5
-    auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {
-        const C3 s = tap_lds(tex, xl, yt) + tap_lds(tex, xr, yt) + tap_lds(tex, xl, yb) + tap_lds(tex, xr, yb);
-        return s * 0.25f;
-    };
-    const AxisE xa = col[0], xb = col[kBlW], xaa = col[2 * kBlW], xab = col[3 * kBlW], xba = col[4 * kBlW], xbb = col[5 * kBlW];
-    const AxisE yc = row[0], yd = row[kBlH], ycc = row[2 * kBlH], ycd = row[3 * kBlH], ydc = row[4 * kBlH], ydd = row[5 * kBlH];
-    return box(xa, xb, yc, yd) * 0.5f + box(xaa, xab, ycc, ycd) * 0.125f + box(xba, xbb, ycc, ycd) * 0.125f + box(xaa, xab, ydc, ydd) * 0.125f +
-           box(xba, xbb, ydc, ydd) * 0.125f;
+// A 256-thread workgroup produces a 64 x (4 PPT) tile of the destination mip (PPT texels of one column per thread).  The source rectangle
+// the tile's 20 taps per texel can touch (2x the tile plus 3 texels either side) is copied to LDS once, with the clamp-to-edge
+// replication applied (cell j holds texel clamp(j)), so the two columns of a bilinear tap are adjacent cells (one 16-byte LDS read)
+// and no tap clamps an index; the 6 + 6 axis set-ups of every tile column / row are tabulated once per workgroup (one thread per
+// column / row: its coordinate costs one divide for all six).  The 5 boxes x 4 bilinear taps of bloom_downsample.comp:16-52 use only
+// 6 distinct x and 6 distinct y coordinates (u -+ ix, and those -+ ix again); same taps, same order, same operators as
+// k_bloom_downsample: bit-identical.  A tile whose rectangle does not fit (extreme aspect ratios) takes the global-memory form.
+// `row_begin/row_end`: destination rows to produce (row-sharded pyramids).
+// (PPT = SAH_BLOOM_PPT for the large mips; small mips take PPT = 1 — 64x4 tiles — so that their few texels spread over more
+// workgroups with shorter dependency chains: 10.5 -> 5 us per launch for the 240x135 mip and below)
+constexpr int kBlW = 64, kBlPitch = 136;
+// one bilinear tap from the staged rectangle: columns ax.o0 and ax.o0 + 8 bytes, rows ay.o0 and ay.o1
+SAH_DEV C3 tap_rep(const char* tex, const AxisE& ax, const AxisE& ay) {
+    const uint2* r0 = reinterpret_cast<const uint2*>(tex + (ay.o0 + ax.o0));
+    const uint2* r1 = reinterpret_cast<const uint2*>(tex + (ay.o1 + ax.o0));
+    const uint2 t00 = r0[0], t10 = r0[1], t01 = r1[0], t11 = r1[1];
+    const float w00 = ax.w0 * ay.w0, w10 = ax.w1 * ay.w0, w01 = ax.w0 * ay.w1, w11 = ax.w1 * ay.w1;
+    C3 c;
+    c.r = fma_mix_lo(w11, t11.x, fma_mix_lo(w01, t01.x, fma_mix_lo(w10, t10.x, fma_mix_lo(w00, t00.x, 0.0f))));
+    c.g = fma_mix_hi(w11, t11.x, fma_mix_hi(w01, t01.x, fma_mix_hi(w10, t10.x, fma_mix_hi(w00, t00.x, 0.0f))));
+    c.b = fma_mix_lo(w11, t11.y, fma_mix_lo(w01, t01.y, fma_mix_lo(w10, t10.y, fma_mix_lo(w00, t00.y, 0.0f))));
+    return c;
 }
+template <int kBlPpt>
 __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh,
                                                                uint32_t row_begin, uint32_t row_end) {
+    constexpr int kBlH = 4 * kBlPpt, kBlRows = 2 * kBlH + 8, kBlTexels = kBlPitch * kBlRows;
     __shared__ uint2 s_tex[kBlTexels];
-    __shared__ AxisE s_ax[6 * kBlW + 6 * kBlH];
+    __shared__ AxisE s_ax[6 * kBlW + 6 * kBlH];  // [k * 64 + column] (o0 = column offset, o1 unused), [384 + k * 16 + row]
     __shared__ int s_rect[4];
     __shared__ int s_bad;
     const uint32_t tid = threadIdx.x;
@@ -62,50 +70,77 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
     if (tid == 0) {
         const float pu0 = ((float)bx + 0.5f) / (float)dw * (float)sw - 0.5f, pu1 = ((float)x_last + 0.5f) / (float)dw * (float)sw - 0.5f;
         const float pv0 = ((float)by + 0.5f) / (float)dh * (float)sh - 0.5f, pv1 = ((float)y_last + 0.5f) / (float)dh * (float)sh - 0.5f;
-        const int x0 = max((int)__builtin_floorf(pu0 - 3.0f), 0), x1 = min((int)__builtin_floorf(pu1 + 3.0f) + 1, (int)sw - 1);
-        const int y0 = max((int)__builtin_floorf(pv0 - 3.0f), 0), y1 = min((int)__builtin_floorf(pv1 + 3.0f) + 1, (int)sh - 1);
+        const int x0 = (int)__builtin_floorf(pu0 - 3.0f), x1 = (int)__builtin_floorf(pu1 + 3.0f) + 1;  // cells beyond the image replicate its edge
+        const int y0 = (int)__builtin_floorf(pv0 - 3.0f), y1 = (int)__builtin_floorf(pv1 + 3.0f) + 1;
         const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-        const bool fits = w > 0 && h > 0 && w * h <= kBlTexels;
+        const bool fits = w > 0 && h > 0 && w <= kBlPitch && h <= kBlRows;
         s_rect[0] = x0; s_rect[1] = y0; s_rect[2] = fits ? w : 0; s_rect[3] = fits ? h : 0;
         s_bad = fits ? 0 : 1;
     }
     __syncthreads();
     const int rx0 = s_rect[0], ry0 = s_rect[1], rw = s_rect[2], rh = s_rect[3];
-    for (int i = (int)tid; i < rw * rh; i += 256) {
-        const int ty = i / rw, tx = i - ty * rw;
-        s_tex[i] = *reinterpret_cast<const uint2*>(src.ptr + (size_t)(ry0 + ty) * src.pitch + (size_t)(rx0 + tx) * 8);
+    // fixed LDS pitch: the row / column split is a division by a constant.  Fully unrolled with the loads first: a thread has its
+    // (up to 22) texels in flight together instead of one round trip to memory per cell
+    constexpr int kIters = (kBlTexels + 255) / 256;
+    uint2 staged[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+        const int i = (int)tid + it * 256;
+        const int ty = i / kBlPitch, tx = i - ty * kBlPitch;
+        const int sx = min(max(rx0 + tx, 0), (int)sw - 1), sy = min(max(ry0 + ty, 0), (int)sh - 1);  // CLAMP_TO_EDGE, once per cell
+        staged[it] = make_uint2(0u, 0u);
+        if (ty < rh && tx < rw) staged[it] = *reinterpret_cast<const uint2*>(src.ptr + (size_t)sy * src.pitch + (size_t)sx * 8);
     }
-    for (uint32_t e = tid; e < (uint32_t)(6 * kBlW + 6 * kBlH); e += 256) {
-        Axis a;
-        AxisE en;
-        bool inside;
-        if (e < 6u * kBlW) {
-            const uint32_t k = e / kBlW, x = min(bx + e % kBlW, x_last);
-            const float u = ((float)x + 0.5f) / (float)dw, ua = u + ox, ub = u + oz;
-            a = axis_setup(k == 0 ? ua : k == 1 ? ub : k == 2 ? ua + ox : k == 3 ? ua + oz : k == 4 ? ub + ox : ub + oz, sw);
-            en = AxisE{(a.i0 - rx0) * 8, (a.i1 - rx0) * 8, a.w0, a.w1};
-            inside = a.i0 >= rx0 && a.i1 < rx0 + rw;
-        } else {
-            const uint32_t j = e - 6u * kBlW, k = j / kBlH, y = min(by + j % kBlH, y_last);
-            const float v = ((float)y + 0.5f) / (float)dh, vc = v + oy, vd = v + ow;
-            a = axis_setup(k == 0 ? vc : k == 1 ? vd : k == 2 ? vc + oy : k == 3 ? vc + ow : k == 4 ? vd + oy : vd + ow, sh);
-            en = AxisE{(a.i0 - ry0) * rw * 8, (a.i1 - ry0) * rw * 8, a.w0, a.w1};
-            inside = a.i0 >= ry0 && a.i1 < ry0 + rh;
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+        const int i = (int)tid + it * 256;
+        if (i < kBlTexels) s_tex[i] = staged[it];
+    }
+    if (tid < (uint32_t)(kBlW + kBlH)) {  // one thread per tile column / row: six set-ups from one coordinate
+        const bool is_x = tid < (uint32_t)kBlW;
+        const uint32_t j = is_x ? tid : tid - kBlW;
+        const float c = is_x ? ((float)min(bx + j, x_last) + 0.5f) / (float)dw : ((float)min(by + j, y_last) + 0.5f) / (float)dh;
+        const float lo = is_x ? ox : oy, hi = is_x ? oz : ow;
+        const float ca = c + lo, cb = c + hi;
+        const float coords[6] = {ca, cb, ca + lo, ca + hi, cb + lo, cb + hi};
+        bool inside = true;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const AxisU a = axis_unclamped(coords[k], is_x ? sw : sh);
+            if (is_x) {
+                s_ax[k * kBlW + j] = AxisE{(a.i - rx0) * 8, 0, a.w0, a.w1};
+                inside = inside && a.i >= rx0 && a.i + 1 < rx0 + rw;
+            } else {
+                s_ax[6 * kBlW + k * kBlH + j] = AxisE{(a.i - ry0) * kBlPitch * 8, (a.i + 1 - ry0) * kBlPitch * 8, a.w0, a.w1};
+                inside = inside && a.i >= ry0 && a.i + 1 < ry0 + rh;
+            }
         }
-        s_ax[e] = en;
         if (!inside) s_bad = 1;
     }
     __syncthreads();
     const uint32_t col = tid & 63u, x = bx + col;
     if (x >= dw) return;
     const bool bad = s_bad != 0;
+    const char* lds = reinterpret_cast<const char*>(s_tex);
+    AxisE xs[6];
+    if (!bad) {
 #pragma unroll
-    for (uint32_t half = 0; half < 2; half++) {
-        const uint32_t row = (tid >> 6) + 4u * half, y = by + row;
+        for (int k = 0; k < 6; k++) xs[k] = s_ax[k * kBlW + col];
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < (uint32_t)kBlPpt; q++) {
+        const uint32_t row = (tid >> 6) + 4u * q, y = by + row;
         if (y >= row_end) break;
         C3 s;
         if (!bad) {
-            s = bloom_texel(reinterpret_cast<const char*>(s_tex), s_ax + col, s_ax + 6 * kBlW + row);
+            const AxisE* rowp = s_ax + 6 * kBlW + row;
+            const AxisE yc = rowp[0], yd = rowp[kBlH], ycc = rowp[2 * kBlH], ycd = rowp[3 * kBlH], ydc = rowp[4 * kBlH], ydd = rowp[5 * kBlH];
+            auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {
+                const C3 b = tap_rep(lds, xl, yt) + tap_rep(lds, xr, yt) + tap_rep(lds, xl, yb) + tap_rep(lds, xr, yb);
+                return b * 0.25f;
+            };
+            s = box(xs[0], xs[1], yc, yd) * 0.5f + box(xs[2], xs[3], ycc, ycd) * 0.125f + box(xs[4], xs[5], ycc, ycd) * 0.125f +
+                box(xs[2], xs[3], ydc, ydd) * 0.125f + box(xs[4], xs[5], ydc, ydd) * 0.125f;
         } else {  // global-memory form: the same 6 + 6 set-ups, computed per texel
             const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
             const int pitch = (int)src.pitch;
@@ -155,8 +190,16 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
                                    uint32_t row_end, hipStream_t st) {
     if (row_end <= row_begin) return hipSuccess;
     if ((uint64_t)src.pitch * sh < (1ull << 31)) {
-        const dim3 grid((dw + kBlW - 1) / kBlW, (row_end - row_begin + kBlH - 1) / kBlH);
-        hipLaunchKernelGGL(k_bloom_downsample_lds, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);
+        const uint32_t cols = (dw + kBlW - 1) / kBlW, rows = row_end - row_begin;
+#ifndef SAH_BLOOM_PPT
+#define SAH_BLOOM_PPT 2  // texels per thread in the large mips; 2 and 4 measured alike (0.094 / 0.096 ms for the 4K chain)
+#endif
+        constexpr int kBig = SAH_BLOOM_PPT;
+        if ((uint64_t)cols * ((rows + 15) / 16) >= 1024) {  // enough 64x16 tiles for four per CU
+            hipLaunchKernelGGL(k_bloom_downsample_lds<kBig>, dim3(cols, (rows + 4 * kBig - 1) / (4 * kBig)), dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);
+        } else {
+            hipLaunchKernelGGL(k_bloom_downsample_lds<1>, dim3(cols, (rows + 3) / 4), dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);
+        }
     } else {  // planes of 2 GiB and more: 64-bit addressing, one texel per thread (whole mip: the row range only saves work)
         const dim3 grid((dw + 63) / 64, (dh + 3) / 4);
         hipLaunchKernelGGL(k_bloom_downsample, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh);

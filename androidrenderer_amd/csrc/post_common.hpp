@@ -124,6 +124,18 @@ SAH_DEV Axis axis_setup(float coord, uint32_t size) {
     return a;
 }
 
+// unclamped axis set-up: floor index (cells staged in LDS carry the clamp-to-edge replication) and the two weights
+struct AxisU {
+    int i;
+    float w0, w1;
+};
+SAH_DEV AxisU axis_unclamped(float coord, uint32_t size) {
+    const float p = coord * (float)size - 0.5f;
+    const float f0 = __builtin_floorf(p);
+    const float f = p - f0;
+    return {(int)__builtin_fminf(__builtin_fmaxf(f0, -1.0e9f), 1.0e9f), 1.0f - f, f};
+}
+
 // Axis set-up as the LDS tap loop consumes it: byte offsets of the two (clamped) texel columns / rows inside the staged
 // rectangle and the two weights.  Built once per workgroup for the 32 columns x 4 x-variants and 8 rows x 4 y-variants of
 // every mip (tile-shared), instead of 8 set-ups per mip per pixel.

@@ -34,17 +34,6 @@ SAH_DEV C3 tap_rep(const char* tex, int xo, float xw0, float xw1, const AxisE& a
     return c;
 }
 
-// unclamped axis set-up: floor index (the staged cells carry the clamp) and the two weights
-struct AxisU {
-    int i;
-    float w0, w1;
-};
-SAH_DEV AxisU axis_unclamped(float coord, uint32_t size) {
-    const float p = coord * (float)size - 0.5f;
-    const float f0 = __builtin_floorf(p);
-    const float f = p - f0;
-    return {(int)__builtin_fminf(__builtin_fmaxf(f0, -1.0e9f), 1.0e9f), 1.0f - f, f};
-}
 
 __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
     __shared__ uint2 s_tex[kTmLdsTexels];
