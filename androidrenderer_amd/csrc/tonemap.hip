@@ -18,6 +18,7 @@ namespace sah {
 // takes the global-memory path for that mip.  Same operator sequence per tap as tent_blur(): results are bit-identical.
 constexpr int kTmTileW = 32, kTmTileH = 32, kTmPpt = 4, kTmRowStep = kTmTileH / kTmPpt;
 constexpr int kTmMipTexels[6] = {704, 320, 192, 192, 192, 192};
+constexpr int kTmMaxRows[6] = {32, 24, 16, 16, 16, 16};  // staged rectangles are at most 32 cells wide and this many rows high
 constexpr int kTmLdsTexels = 704 + 320 + 4 * 192;
 constexpr int kTmAxisPerMip = 4 * kTmTileW + 4 * kTmTileH;
 
@@ -61,31 +62,44 @@ __global__ void __launch_bounds__(256) k_tonemap(TonemapArgs t) {
             const int x0 = (int)__builtin_floorf(pu0 - reach_x), x1 = (int)__builtin_floorf(pu1 + reach_x) + 1;
             const int y0 = (int)__builtin_floorf(pv0 - reach_y), y1 = (int)__builtin_floorf(pv1 + reach_y) + 1;
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-            if (w > 0 && h > 0 && w * h <= kTmMipTexels[m]) {
+            if (w > 0 && h > 0 && w <= 32 && h <= kTmMaxRows[m] && w * h <= kTmMipTexels[m]) {
                 r[0] = x0; r[1] = y0; r[2] = w; r[3] = h;
             }
         }
         s_bad[m] = r[2] == 0;
     }
     __syncthreads();
-    // staging: a thread owns column tid % 32 of the rectangle (they are at most 32 cells wide) and every 8th row
-    for (uint32_t m = 0; m < 6 && m < t.num_mips; m++) {
-        const int x0 = s_rect[m][0], y0 = s_rect[m][1], w = s_rect[m][2], h = s_rect[m][3], off = s_rect[m][4];
-        const int wmax = (int)t.mip_w[m] - 1, hmax = (int)t.mip_h[m] - 1;
-        const int tx = threadIdx.x & 31;
-        if (w <= 32) {
-            if (tx < w) {
-                const int sx = min(max(x0 + tx, 0), wmax);  // CLAMP_TO_EDGE, once per cell
-                for (int ty = threadIdx.x >> 5; ty < h; ty += 8) {
-                    const int sy = min(max(y0 + ty, 0), hmax);
-                    s_tex[off + ty * w + tx] = *reinterpret_cast<const uint2*>(t.mips[m].ptr + (size_t)sy * t.mips[m].pitch + (size_t)sx * 8);
-                }
+    // staging: a thread owns column tid % 32 of the rectangle (they are at most 32 cells wide) and every 8th row; all of a thread's
+    // (up to 15) texels are requested before the first is stored, instead of one round trip to memory per cell
+    {
+        constexpr int kIters[6] = {(kTmMaxRows[0] + 7) / 8, (kTmMaxRows[1] + 7) / 8, (kTmMaxRows[2] + 7) / 8, (kTmMaxRows[3] + 7) / 8, (kTmMaxRows[4] + 7) / 8,
+                                   (kTmMaxRows[5] + 7) / 8};
+        constexpr int kTotal = kIters[0] + kIters[1] + kIters[2] + kIters[3] + kIters[4] + kIters[5];
+        uint2 staged[kTotal];
+        const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+        int n = 0;
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            const bool live = (uint32_t)m < t.num_mips;
+            const int x0 = s_rect[m][0], y0 = s_rect[m][1], w = live ? s_rect[m][2] : 0, h = s_rect[m][3];
+            const int wmax = (int)t.mip_w[m] - 1, hmax = (int)t.mip_h[m] - 1;
+            const int sx = min(max(x0 + tx, 0), wmax);  // CLAMP_TO_EDGE, once per cell
+#pragma unroll
+            for (int j = 0; j < kIters[m]; j++, n++) {
+                const int ty = ty0 + 8 * j;
+                const int sy = min(max(y0 + ty, 0), hmax);
+                staged[n] = make_uint2(0u, 0u);
+                if (tx < w && ty < h) staged[n] = *reinterpret_cast<const uint2*>(t.mips[m].ptr + (size_t)sy * t.mips[m].pitch + (size_t)sx * 8);
             }
-        } else {
-            for (int i = threadIdx.x; i < w * h; i += 256) {
-                const int ty = i / w, cx = i - ty * w;
-                const int sx = min(max(x0 + cx, 0), wmax), sy = min(max(y0 + ty, 0), hmax);
-                s_tex[off + i] = *reinterpret_cast<const uint2*>(t.mips[m].ptr + (size_t)sy * t.mips[m].pitch + (size_t)sx * 8);
+        }
+        n = 0;
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            const int w = (uint32_t)m < t.num_mips ? s_rect[m][2] : 0, h = s_rect[m][3], off = s_rect[m][4];
+#pragma unroll
+            for (int j = 0; j < kIters[m]; j++, n++) {
+                const int ty = ty0 + 8 * j;
+                if (tx < w && ty < h) s_tex[off + ty * w + tx] = staged[n];
             }
         }
     }
