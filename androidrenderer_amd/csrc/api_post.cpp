@@ -18,6 +18,7 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+hipError_t launch_lpv_build_tables(hipStream_t st);
 hipError_t launch_sky_luts(const PlaneArg& transmittance, const PlaneArg& multiscattering, const PlaneArg& sky_view, const float light_vector[3], hipStream_t st);
 hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st);
 hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
@@ -193,7 +194,14 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         b[i] = varg(b_rgb[i]);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (uint32_t s = 0; s < steps; s++) {  // light_propagation_volume.cpp:1016-1034
+    if (!ctx->lpv_tables_built) {  // the 30 direction pairs' SH / lobe vectors, into this device's constant memory, once per context
+        HIP_TRY(ctx, sah::launch_lpv_build_tables(ctx->stream));
+        ctx->lpv_tables_built = true;
+    }
+    // light_propagation_volume.cpp:1016-1034: `steps` dispatches ping-ponging A -> B -> A ...  (Two steps per launch — 8^3 bricks with
+    // their halo in LDS, bit-identical — were measured: 28 us per pair against 2 x 9.3 us, 1.5x the arithmetic in longer dependency
+    // chains; not kept.)
+    for (uint32_t s = 0; s < steps; s++) {
         if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, ctx->stream));
         else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, ctx->stream));
     }

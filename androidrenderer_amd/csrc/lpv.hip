@@ -75,7 +75,8 @@ struct PropArgs {
     uint32_t num_cascades;
 };
 
-// tables of the 30 direction pairs, built by every block into LDS
+// tables of the 30 direction pairs: built once per context into device memory (k_build_prop_tables) and read by the propagate kernels
+// through uniform (scalar) loads — as LDS tables they cost every cell 45 16-byte LDS reads and every workgroup a build + barrier
 SAH_DEV void build_prop_tables(PropTables& T) {
     if (threadIdx.x < 24) {
         const int n = threadIdx.x >> 2, s = threadIdx.x & 3;
@@ -92,25 +93,14 @@ SAH_DEV void build_prop_tables(PropTables& T) {
     }
 }
 
-// one propagation step of one cell: lpv_propagate.comp.slang:76-156
-// (one colour volume per call: the three channels are independent and run as separate workgroups, blockIdx.y, which triples the
-// number of waves in flight — with one thread per cell doing all three the step was bound by its own dependency chains)
-SAH_DEV void propagate_cell(const PropTables& T, const VolumeArg& src, const VolumeArg& dst, uint32_t idx) {
+__global__ void k_build_prop_tables(PropTables* out) { build_prop_tables(*out); }
+// filled once per context by k_build_prop_tables through the symbol's address; constant address space: uniform reads are scalar loads
+__constant__ PropTables c_prop_tables;
+
+// the 30 direction pairs of one cell from its six neighbours' coefficients: lpv_propagate.comp.slang:96-152
+SAH_DEV H4 propagate_from(const PropTables& T, const H4 (&coef)[6]) {
     const Hn direct_sa = Hn(tof(Hn::lit(0.4006696846f)) / 3.1415927f);
     const Hn side_sa = Hn(tof(Hn::lit(0.4234413544f)) / 3.1415927f);
-    const int cx = idx & 31, cy = (idx >> 5) & 31, cz = (idx >> 10) & 31, cascade = idx >> 15;
-    const int xoff = cascade * 32;
-    // All 18 neighbour texels are fetched before any arithmetic (one latency phase instead of six: with two waves per SIMD the
-    // step was latency bound).  A neighbour the shader skips (`continue`, the asymmetric [-1, 31] test) is given zero coefficients
-    // instead: max(0, dot(0, sh)) == +0 and acc + (sa * 0) * lobe == acc + (+-0) == acc for every acc this loop can hold (acc starts
-    // at +0 and +0 + -0 == +0, so it is never -0).
-    H4 coef[6];
-#pragma unroll
-    for (int n = 0; n < 6; n++) {
-        const int nx = cx - kDir[n][0], ny = cy - kDir[n][1], nz = cz - kDir[n][2];
-        const bool skipped = nx < -1 || ny < -1 || nz < -1 || nx > 31 || ny > 31 || nz > 31;
-        coef[n] = load_h4(src, skipped ? -1 : nx + xoff, ny, nz);
-    }
     // (Hn::lit: compile-time constants.  geo_volume_factor == 1: x * 1.0h is x for every x, the compiler folds it.)
     const Hn zero = Hn::lit(0.f), geo_volume_factor = Hn::lit(1.f);
     H4 acc = {zero, zero, zero, zero};
@@ -124,13 +114,31 @@ SAH_DEV void propagate_cell(const PropTables& T, const VolumeArg& src, const Vol
         const Hn m = nmax(zero, dot4h(coef[n], from_q(T.cur_sh[n])));
         acc = acc + (direct_sa * m) * from_q(T.cur_lobe[n]) * geo_volume_factor;
     }
-    store_h4(dst, cx + xoff, cy, cz, acc);
+    return acc;
+}
+
+// one propagation step of one cell: lpv_propagate.comp.slang:76-156
+// (one colour volume per call: the three channels are independent and run as separate workgroups, blockIdx.y, which triples the
+// number of waves in flight — with one thread per cell doing all three the step was bound by its own dependency chains)
+SAH_DEV void propagate_cell(const PropTables& T, const VolumeArg& src, const VolumeArg& dst, uint32_t idx) {
+    const int cx = idx & 31, cy = (idx >> 5) & 31, cz = (idx >> 10) & 31, cascade = idx >> 15;
+    const int xoff = cascade * 32;
+    // All 18 neighbour texels are fetched before any arithmetic (one latency phase instead of six: with two waves per SIMD the
+    // step was latency bound).  A neighbour the shader skips (`continue`, the asymmetric [-1, 31] test) is given zero coefficients
+    // instead: max(0, dot(0, sh)) == +0 and acc + (sa * 0) * lobe == acc + (+-0) == acc for every acc this loop can hold (acc starts
+    // at +0 and +0 + -0 == +0, so it is never -0).
+    H4 coef[6];
+#pragma unroll
+    for (int n = 0; n < 6; n++) {
+        const int nx = cx - kDir[n][0], ny = cy - kDir[n][1], nz = cz - kDir[n][2];
+        const bool skipped = nx < -1 || ny < -1 || nz < -1 || nx > 31 || ny > 31 || nz > 31;
+        coef[n] = load_h4(src, skipped ? -1 : nx + xoff, ny, nz);
+    }
+    store_h4(dst, cx + xoff, cy, cz, propagate_from(T, coef));
 }
 
 __global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
-    __shared__ PropTables T;
-    build_prop_tables(T);
-    __syncthreads();
+    const PropTables& T = c_prop_tables;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= a.num_cascades * 32768u) return;
     const uint32_t c = blockIdx.y;  // colour volume
@@ -160,6 +168,14 @@ hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades,
     a.num_cascades = num_cascades;
     for (int i = 0; i < n; i++) a.v[i] = vols[i];
     hipLaunchKernelGGL(k_lpv_clear, dim3(num_cascades * 128), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lpv_build_tables(hipStream_t st) {  // on the current device
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(c_prop_tables));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_build_prop_tables, dim3(1), dim3(64), 0, st, (PropTables*)sym);
     return hipGetLastError();
 }
 

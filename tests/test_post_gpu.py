@@ -98,7 +98,7 @@ def test_copy_scene(hip_ctx):
             assert (util.f16_ulp_diff(got, scene) <= 1).mean() > 0.99
 
 
-@pytest.mark.parametrize("steps", [4, 5, 1])
+@pytest.mark.parametrize("steps", [4, 5, 1, 9, 32])
 def test_lpv_propagate_and_clear(hip_ctx, steps):
     import torch
     o = util.oracle()
