@@ -14,6 +14,8 @@
 //                       structure the fast kernel needs, and as the in-library cross-check of the fast path.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/sah_hip.h"
 #include "lighting_common.hpp"
 #include "lighting_fast.hpp"
@@ -130,28 +132,6 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
 }
 
 // ---- sky kernel: the deferred depth == 0 pixels (back half of the segments) ---------------------------------------------------------
-// ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206), so these pixels need nothing but their
-// coordinates: no G-buffer reads, and none of the surface code's registers (the general fix-up kernel holds the whole restatement).
-template <int PPT>
-__global__ void __launch_bounds__(256) k_lighting_sky(const LightingArgs a, const SkyArgs sky, const FastArgs f) {
-    // one wave per segment: sky pixels come in large coherent regions, whose segments are full (256 entries = 4 rounds of the wave);
-    // wider work items leave most of the chip idle when the sky is a tenth of the frame
-    const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (seg >= f.num_segments) return;
-    const uint32_t count = f.seg_count[f.num_segments + seg];
-    const uint32_t groups_per_row = a.width / PPT;
-    const uint8_t* codes = f.seg_list + (size_t)seg * f.seg_stride + (f.seg_stride - 1u);
-    for (uint32_t i = lane; i < count; i += 64u) {
-        const uint32_t code = *(codes - i);
-        const uint32_t g = seg * 64u + code / PPT;
-        const uint32_t ry = g / groups_per_row;
-        const uint32_t y = a.row_begin + ry, x = (g - ry * groups_per_row) * PPT + code % PPT;
-        Hn lit[4];
-        sky_frag(a, sky, x, y, lit);
-        *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x * 8) = pack_lit(lit);
-    }
-}
-
 // ---- LPV gather copy + finiteness scan -----------------------------------------------------------------------------------
 // Once per Lighting pass (3 MiB in, 4 MiB out, L2 resident): interleaves the three RGBA16F volumes into 24-byte texels
 // {R[4], G[4], B[4]} surrounded by a two-texel border of zeros, and flags inf / NaN texels (feeds the "specular quirk is inert"
@@ -188,11 +168,47 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&state->nonfinite[parity], 1u);
 }
 
+#ifndef SAH_SKY_RATIO
+#define SAH_SKY_RATIO 4
+#endif
+constexpr uint32_t kSkyRatio = SAH_SKY_RATIO;  // surface workgroups per sky workgroup
+
 // ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
-template <int SUN, int GI, int PPT, bool RELAXED>
+template <int SUN, int GI, int PPT, bool RELAXED, bool SKY>
 // (106 VGPRs at 4 px/thread = 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 36-44 bytes per lane and is 12-20 %
 // slower, measured.)
-__global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const FastArgs f) {
+// (With the sky path in the kernel the allocator would take 137 VGPRs = 3 waves per SIMD for every wave; the bound keeps the surface
+// path's 4 — the sky path, 4 % of the frame, spills the difference.)
+__global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
+                                                                                 const FastArgs f) {
+    // Sky.  ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206): those pixels need their
+    // coordinates and two fp64 transcendentals each, nothing of the surface code.  With a sky bound, one workgroup in kSkyRatio + 1
+    // is a sky workgroup: it reads the depth of the pixels of the kSkyRatio surface workgroups before it and shades the sky among them;
+    // surface workgroups leave those pixels alone.  Interleaved like this the sky's arithmetic fills issue slots the surface waves leave
+    // idle (as a kernel of its own behind this one it cost 20 us on the 4 % of sky in the atrium frame: one busy wave per SIMD, in series).
+    uint32_t block_id = blockIdx.x;
+    if (SKY) {
+        if (blockIdx.x % (kSkyRatio + 1u) == kSkyRatio) {
+            const uint32_t groups_per_row = a.width / PPT, total = groups_per_row * (a.row_end - a.row_begin);
+#pragma unroll 1
+            for (uint32_t k = 0; k < kSkyRatio; k++) {
+                const uint32_t gid = ((blockIdx.x / (kSkyRatio + 1u)) * kSkyRatio + k) * 256u + threadIdx.x;
+                if (gid >= total) break;
+                const uint32_t ry = gid / groups_per_row, y = a.row_begin + ry, x0 = (gid - ry * groups_per_row) * PPT;
+                uint32_t wz[PPT];
+                load_words<PPT>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x0 * 4, wz);
+#pragma unroll 1
+                for (int i = 0; i < PPT; i++) {
+                    if (__uint_as_float(wz[i]) != 0.f) continue;
+                    Hn lit[4];
+                    sky_frag(a, sky, x0 + (uint32_t)i, y, lit);
+                    *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)(x0 + i) * 8) = pack_lit(lit);
+                }
+            }
+            return;
+        }
+        block_id = blockIdx.x - blockIdx.x / (kSkyRatio + 1u);
+    }
     __shared__ __attribute__((aligned(16))) float s_lut[TAB_SIZE];
     s_lut[threadIdx.x] = a.luts[threadIdx.x];
     s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
@@ -211,7 +227,7 @@ __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, con
     __syncthreads();
 
     const uint32_t groups_per_row = a.width / PPT;
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gid = block_id * 256u + threadIdx.x;
     const uint32_t rows = a.row_end - a.row_begin;
     const bool active = gid < groups_per_row * rows;
     const uint32_t ry = active ? gid / groups_per_row : 0u;
@@ -267,35 +283,32 @@ __global__ void __launch_bounds__(256) k_lighting_fast(const LightingArgs a, con
     }
     if (active) {
         uint8_t* dst = const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x0 * 8;
-        if constexpr (PPT == 1) {
+        if (SKY && sky_mask != 0u) {  // the sky workgroup owns these pixels: per-pixel stores around them
+#pragma unroll
+            for (int i = 0; i < PPT; i++)
+                if (!((sky_mask >> i) & 1u)) *reinterpret_cast<uint2*>(dst + 8 * i) = make_uint2(out[2 * i], out[2 * i + 1]);
+        } else if constexpr (PPT == 1) {
             *reinterpret_cast<uint2*>(dst) = make_uint2(out[0], out[1]);
         } else {
             store_words<2 * PPT>(dst, out);
         }
     }
     // deferred pixels -> this wave's segment (no atomics: the wave owns it).  Slots by ballot + mbcnt, one bit plane per pixel of
-    // the thread; the order inside a segment is irrelevant.  Sky pixels (depth == 0 with a sky bound: all of them are deferred) fill
-    // the segment from its back — k_lighting_sky shades them from their coordinates alone — everything else from the front.
+    // the thread; the order inside a segment is irrelevant.  (Sky pixels are not listed: the sky workgroups find them by their depth.)
     const uint32_t seg = gid >> 6, lane = threadIdx.x & 63u;
-    uint32_t front = 0, back = 0;
+    uint32_t front = 0;
     uint8_t* seg_codes = f.seg_list + (size_t)seg * f.seg_stride;
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
-        const bool mine = (deferred_mask >> i) & 1u, sky_px = (sky_mask >> i) & 1u;
+        const bool mine = ((deferred_mask >> i) & 1u) && !(SKY && ((sky_mask >> i) & 1u));
         const uint64_t m = __ballot(mine);
         if (m) {
-            const uint64_t ms = __ballot(mine && sky_px), mg = m & ~ms;
-            const uint32_t before_g = __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, 0u));
-            const uint32_t before_s = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
-            if (mine) seg_codes[sky_px ? f.seg_stride - 1u - (back + before_s) : front + before_g] = (uint8_t)(lane * PPT + (uint32_t)i);
-            front += (uint32_t)__builtin_popcountll(mg);
-            back += (uint32_t)__builtin_popcountll(ms);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (mine) seg_codes[front + before] = (uint8_t)(lane * PPT + (uint32_t)i);
+            front += (uint32_t)__builtin_popcountll(m);
         }
     }
-    if (lane == 0 && seg < f.num_segments) {
-        f.seg_count[seg] = (uint16_t)front;
-        f.seg_count[f.num_segments + seg] = (uint16_t)back;
-    }
+    if (lane == 0 && seg < f.num_segments) f.seg_count[seg] = (uint16_t)front;
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------
@@ -322,23 +335,24 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
         hipLaunchKernelGGL(k_lpv_pack, dim3(prows), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, const_cast<uint8_t*>(f.lpv_packed), f.pk_row_pitch,
                            f.pk_slice_pitch, f.state, f.parity);
     }
-    const dim3 grid((uint32_t)((groups + 255) / 256)), block(256);
+    const uint32_t blocks = (uint32_t)((groups + 255) / 256);
+    const dim3 block(256);
     // tolerance mode: only where the relaxed body differs (fp32 BRDF of the CSM sun, LPV overlay products) and for the 4-pixel layout
     constexpr bool kHasRelaxed = SUN != SAH_SHADOW_MODE_RT && (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV);
-    if (ppt == 4 && kHasRelaxed && f.tolerance) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4, kHasRelaxed>), grid, block, 0, st, a, csm, lpv, f);
-    else if (ppt == 4) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 4, false>), grid, block, 0, st, a, csm, lpv, f);
-    else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 2, false>), grid, block, 0, st, a, csm, lpv, f);
-    else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, 1, false>), grid, block, 0, st, a, csm, lpv, f);
+    auto launch = [&](auto ppt_c, auto relaxed_c) {
+        constexpr int P = decltype(ppt_c)::value;
+        constexpr bool R = decltype(relaxed_c)::value;
+        if (sky.enabled) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, R, true>), dim3((kSkyRatio + 1u) * ((blocks + kSkyRatio - 1u) / kSkyRatio)), block, 0, st, a, csm, lpv, sky, f);
+        else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, R, false>), dim3(blocks), block, 0, st, a, csm, lpv, sky, f);
+    };
+    if (ppt == 4 && kHasRelaxed && f.tolerance) launch(std::integral_constant<int, 4>{}, std::integral_constant<bool, kHasRelaxed>{});
+    else if (ppt == 4) launch(std::integral_constant<int, 4>{}, std::false_type{});
+    else if (ppt == 2) launch(std::integral_constant<int, 2>{}, std::false_type{});
+    else launch(std::integral_constant<int, 1>{}, std::false_type{});
     const dim3 fgrid((f.num_segments + kFixupSegs - 1) / kFixupSegs);
     if (ppt == 4) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 4>), fgrid, block, 0, st, a, csm, lpv, sky, f);
     else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 2>), fgrid, block, 0, st, a, csm, lpv, sky, f);
     else hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 1>), fgrid, block, 0, st, a, csm, lpv, sky, f);
-    if (sky.enabled) {
-        const dim3 sgrid((f.num_segments + 3) / 4);
-        if (ppt == 4) hipLaunchKernelGGL((k_lighting_sky<4>), sgrid, block, 0, st, a, sky, f);
-        else if (ppt == 2) hipLaunchKernelGGL((k_lighting_sky<2>), sgrid, block, 0, st, a, sky, f);
-        else hipLaunchKernelGGL((k_lighting_sky<1>), sgrid, block, 0, st, a, sky, f);
-    }
     return hipGetLastError();
 }
 
