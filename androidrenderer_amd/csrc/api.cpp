@@ -534,6 +534,10 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             fast.pk_slice_pitch = (uint32_t)slice;
         }
         fast.sky_enabled = sky.enabled;
+        {  // thread index -> (row, group in row) by a multiply-high: exact while gid * groups_per_row < 2^32 (magic = floor(2^32 / d) + 1)
+            const uint64_t gpr = W / (uint32_t)ppt, threads = (gpr * (r1 - r0) + 255) / 256 * 256;
+            fast.row_magic = (gpr >= 2 && threads * gpr < (1ull << 32)) ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u;
+        }
         fast.tolerance = (d->flags & SAH_LIGHTING_TOLERANCE_1ULP) ? 1u : 0u;
         fast.parity = ctx->parity;
         fast.state = ctx->state;

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
     const uint32_t gid = block_id * 256u + threadIdx.x;
     const uint32_t rows = a.row_end - a.row_begin;
     const bool active = gid < groups_per_row * rows;
-    const uint32_t ry = active ? gid / groups_per_row : 0u;
+    const uint32_t ry = active ? (f.row_magic ? __umulhi(gid, f.row_magic) : gid / groups_per_row) : 0u;
     const uint32_t y = a.row_begin + ry;
     const uint32_t x0 = active ? (gid - ry * groups_per_row) * PPT : 0u;
     const bool lpv_bad = (GI == SAH_GI_LPV) ? (f.state->nonfinite[f.parity] != 0u) : false;

@@ -89,6 +89,7 @@ struct FastArgs {
     uint32_t ncasc_pow2;
     uint32_t pos_div_nr;  // view-space position quotients may use the shared-reciprocal divide (lighting_fast.hpp)
     uint32_t sky_enabled;
+    uint32_t row_magic;  // floor(2^32 / groups per row) + 1 when mulhi(gid, row_magic) == gid / groups_per_row for every thread of the call, else 0
     uint32_t parity;
     uint32_t tolerance;  // SAH_LIGHTING_TOLERANCE_1ULP: the relaxed body (lighting_relaxed.hpp) where it exists
     FrameState* state;

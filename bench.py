@@ -378,7 +378,7 @@ def main():
                 "kernel": "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast",
                 "kernel_ms_mean": round(kernel_ms_mean, 5),
                 "kernel_ms_min": round(kernel_ms[0], 5),
-                "kernel_ms_scope": "HIP events around one sah_lighting call on its stream (k_lpv_pack + main kernel + fix-up + sky kernels)",
+                "kernel_ms_scope": "HIP events around one sah_lighting call on its stream (k_lpv_pack + main kernel, sky workgroups included + fix-up)",
                 "algorithmic_bytes_per_launch": bytes_per_pixel * my_px,
             },
         }
