@@ -505,7 +505,7 @@ SAH_DEV F3 point_light_contribution(const Surface<Fn>& s, F3 ws, F3 V, const Poi
 // light, uniformly): restricted-range sqrt / reciprocal / divide (numerics.hpp) and the shared-subexpression BRDF of the fast
 // path.  `bad` is set when an operand leaves a domain or the result holds a NaN (the spec turns that into 0): the caller then
 // evaluates the general form for the pixel.
-SAH_DEV F3 point_light_contribution_fast(const Surface<Fn>& s, F3 lv, Fn d2, F3 V, const PointLightDev& pl, bool& bad) {
+SAH_DEV F3 point_light_contribution_fast(const Surface<Fn>& s, const BrdfPixel& bp, F3 lv, Fn d2, F3 V, const PointLightDev& pl, bool& bad) {
     const Fn dist = Fn(sqrt_nr(d2.v));
     const F3 L = lv * Fn(rcp_nr(dist.v));
     const Fn ndotl = nclamp(dot(s.normal, L), Fn(0.f), Fn(1.f));
@@ -516,7 +516,7 @@ SAH_DEV F3 point_light_contribution_fast(const Surface<Fn>& s, F3 lv, Fn d2, F3 
     const Fn ww = w * w;
     const Fn att = Fn(div_nr(ww.v, __builtin_fmaxf(d2.v, 1e-4f)));
     bool brdf_bad;
-    const F3 b = brdf_fast(s, L, V, brdf_bad);
+    const F3 b = brdf_fast_light(s, bp, L, V, brdf_bad);
     const F3 c = ndotl * b * F3{Fn(pl.cr), Fn(pl.cg), Fn(pl.cb)} * (Fn(pl.intensity) * att);
     const float nan_probe = (c.x + c.y + c.z).v;
     bad = brdf_bad || !(d2.v >= 0x1p-80f && d2.v <= 0x1p+40f) || !(ww.v == 0.f || ww.v >= kDivLo) || !(nan_probe == nan_probe);

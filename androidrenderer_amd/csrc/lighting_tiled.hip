@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         }
 
         F3 sum = F3(Fn(0.f));
+        const BrdfPixel bp = brdf_fast_pixel(s, V);  // the light-independent half of the BRDF, once per pixel
         for (uint32_t batch = 0; batch < a.num_lights; batch += kMaxTileLights) {
             const uint32_t batch_n = min(kMaxTileLights, a.num_lights - batch);
             uint32_t count = 0;  // lights kept so far in this batch (uniform)
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
                                       __builtin_fabsf(pl.cb) < inf && __builtin_fabsf(pl.intensity) < inf;
                 F3 c = F3(Fn(0.f));
                 bool redo = !light_ok;
-                if (light_ok) c = point_light_contribution_fast(s, lv, d2, V, pl, redo);
+                if (light_ok) c = point_light_contribution_fast(s, bp, lv, d2, V, pl, redo);
                 if (__any(near && redo)) {
                     const F3 cg = point_light_contribution(s, ws, V, pl);
                     c = redo ? cg : c;

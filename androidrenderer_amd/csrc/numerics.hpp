@@ -321,6 +321,64 @@ SAH_DEV F3 brdf_fast(const Surface<Fn>& s, F3 l, F3 v, bool& out_of_domain) {
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
 
+// brdf_fast() split for loops over lights: everything that depends on the surface and the view vector only (f0, the diffuse colour,
+// NoV and its Schlick power, the view half of the Smith term) is evaluated once per pixel; the per-light part applies the same
+// operators to the same operands as brdf_fast(), so the same bits.
+struct BrdfPixel {
+    F3 f0, diffuse_color;
+    Fn NoV, a2, argV, sqrtV, powV;  // |N.V + 1e-5|, a^2, the view-side Smith argument and its root, pow5(clamp(1 - NoV))
+};
+SAH_DEV BrdfPixel brdf_fast_pixel(const Surface<Fn>& s, F3 v) {
+    const Fn one = Fn(1.0f), zero = Fn(0.0f);
+    const Fn dielectric_f0 = Fn(0.04f);
+    BrdfPixel p;
+    p.f0 = mix(F3(dielectric_f0), s.base_color, s.metalness);
+    p.diffuse_color = s.base_color * (one - dielectric_f0) * (one - s.metalness);
+    p.NoV = nabs(dot(s.normal, v) + Fn(1e-5f));
+    const Fn a = s.roughness;
+    p.a2 = a * a;
+    p.argV = (-p.NoV * p.a2 + p.NoV) * p.NoV + p.a2;
+    p.sqrtV = Fn(sqrt_nr(p.argV.v));  // (garbage outside the domain: brdf_fast_light() reports it)
+    p.powV = npow5(nclamp(one - p.NoV, zero, one));
+    return p;
+}
+SAH_DEV F3 brdf_fast_light(const Surface<Fn>& s, const BrdfPixel& p, F3 l, F3 v, bool& out_of_domain) {
+    const Fn one = Fn(1.0f), zero = Fn(0.0f);
+    const F3 vl = v + l;
+    const Fn dh = dot(vl, vl);  // <= 4 + eps
+    const F3 h = vl * Fn(rcp_nr(sqrt_nr(dh.v)));
+    Fn NoL = dot(s.normal, l);
+    const Fn NoH = nclamp(dot(s.normal, h), zero, one);
+    const Fn VoH = nclamp(dot(v, h), zero, one);
+    const bool dark = NoL.v <= 0.f;
+    NoL = nclamp(NoL, zero, one);
+    const Fn LoH = nclamp(dot(l, h), zero, one);
+    // Fd_Burley(NoV, NoL, LoH, roughness): F_Schlick(u, 1, f90) = 1 + (f90 - 1) * pow5(clamp(1 - u)), the same in every channel
+    const Fn f90 = Fn(0.5f) + Fn(2.0f) * s.roughness * LoH * LoH;
+    const Fn light_scatter = one + (f90 - one) * npow5(nclamp(one - NoL, zero, one));
+    const Fn view_scatter = one + (f90 - one) * p.powV;
+    const Fn burley = light_scatter * view_scatter * (one / brdf_pi<Fn>());
+    const F3 fd = p.diffuse_color * F3(burley);
+    // D_GGX
+    const Fn a = s.roughness;
+    const Fn dden = one - NoH * NoH + a * a;
+    const Fn k = Fn(div_nr(a.v, dden.v));
+    const Fn D = k * k * (one / brdf_pi<Fn>());
+    const F3 Fv = F_Schlick(VoH, p.f0, one);
+    // V_SmithGGXCorrelated
+    const Fn argL = (-NoL * p.a2 + NoL) * NoL + p.a2;
+    const Fn GGXL = p.NoV * Fn(sqrt_nr(argL.v));
+    const Fn GGXV = NoL * p.sqrtV;
+    const Fn vden = GGXV + GGXL;
+    const Fn Vis = Fn(div_nr(0.5f, vden.v));
+    const F3 fr = (D * Vis) * Fv;
+    const F3 sum = fd + fr;
+    const float lo_sqrt = __builtin_fminf(__builtin_fminf(dh.v, argL.v), p.argV.v);
+    const float lo_div = __builtin_fminf(dden.v, vden.v);
+    out_of_domain = !dark && !(lo_sqrt >= 0x1p-80f && lo_div >= kDivLo);
+    return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
+}
+
 // ---- tolerance mode (SAH_LIGHTING_TOLERANCE_1ULP): the fp32 brdf() of brdf.glsl:29-121 for the fast kernel -------------------------
 // Inputs are the strict (exact) unit vectors; the evaluation uses explicit FMAs, v_rsq / v_rcp / v_sqrt (1 ulp) and x^5 as three
 // multiplies.  Every term is a product or a sum of non-negative quantities except 1 - NoH^2 + a^2, whose error is bounded by the caller's
