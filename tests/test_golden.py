@@ -169,3 +169,29 @@ def test_hip_matches_golden_probe_update(hip_ctx):
     for k, w in want.items():
         got = a_t[k].cpu().numpy()
         assert np.array_equal(got.view(w.dtype).reshape(w.shape), w), f"atlas {k} differs"
+
+
+def _raster_golden():
+    g = np.load(os.path.join(GOLDEN, "raster_gbuffer_64x36.npz"))
+    return {k: g[k] for k in ("color", "normals", "data", "emission", "depth")}
+
+
+def test_oracle_matches_golden_textured_gbuffer():
+    """f1: the depth pre-pass + G-buffer pass with material textures against the independent numpy rasteriser of tools/gen_golden.py"""
+    from tests.test_raster import _oracle_gbuffer
+    m, view = util.golden_raster_scene()
+    got, stats = _oracle_gbuffer(m.arrays(), view, 64, 36)
+    want = _raster_golden()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"
+    assert (want["depth"] > 0).sum() > 400 and stats[1] == 2  # the two triangles with the opposite winding are culled
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_textured_gbuffer(hip_ctx):
+    from tests.test_raster import _hip_gbuffer
+    m, view = util.golden_raster_scene()
+    got, _ = _hip_gbuffer(hip_ctx, m.arrays(), view, 64, 36)
+    want = _raster_golden()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"

@@ -6,7 +6,7 @@ import subprocess
 
 import numpy as np
 
-from androidrenderer_amd import _abi, frame
+from androidrenderer_amd import _abi, frame, synth
 from androidrenderer_amd.frame import from_torch, to_torch  # noqa: F401  (re-exported for the tests)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -129,3 +129,42 @@ def golden_lighting_frame(width, height, seed, sun_mode, gi, sky=False):
     f.arrays["data"] = f.arrays["data"].copy()
     f.arrays["data"][..., 1] = np.maximum(f.arrays["data"][..., 1], 1)
     return f
+
+
+def golden_raster_scene():
+    """The scene behind tests/golden/raster_gbuffer_64x36.npz (tools/gen_golden.py): a textured, alpha-tested wall seen at an angle
+    (two CUTOUT triangles, every material slot bound to a texture with its own sampler), a SOLID triangle in front of it drawn twice
+    at the same depth with two materials (the later draw stays) and once with the opposite winding (culled), random vertex colours,
+    normals and tangents.  Returns (mesh.Mesh, scene.SceneView); nothing is clipped."""
+    from androidrenderer_amd import mesh, scene
+    g = synth.rng(120)
+    view = scene.SceneView.default(64, 36)  # at (-7, 1, 0) looking along +x
+    view.gpu_data.material_texture_mip_bias = 0.25
+    m = mesh.Mesh()
+    tex = [m.add_texture(*mesh.random_texture(g, 32, 32, None, True, mesh.sampler(), alpha=(0, 256))),                  # base colour: trilinear REPEAT
+           m.add_texture(*mesh.random_texture(g, 16, 8, None, False, mesh.sampler(mag=0, min=1, mipmap=0,
+                                                                                     address_u=_abi.ADDRESS_MIRRORED_REPEAT, address_v=_abi.ADDRESS_CLAMP_TO_EDGE))),
+           m.add_texture(*mesh.random_texture(g, 64, 64, 3, False, mesh.sampler(mag=1, min=0, mipmap=1, bias=-0.5, max_lod=1.5))),
+           m.add_texture(*mesh.random_texture(g, 8, 8, None, True, mesh.sampler(mag=0, min=0, mipmap=0, min_lod=1.0)))]
+    wall = m.add_material(mesh.material(base=(0.9, 0.8, 1.0, 1.0), rough=0.7, metal=0.4, emission=(1.5, 0.5, 2.0, 0.0), opacity_threshold=0.35),
+                          base_color=tex[0], normal=tex[1], data=tex[2], emission=tex[3])
+    red = m.add_material(mesh.material(base=(1.0, 0.1, 0.1, 1.0), rough=0.2, metal=0.9))
+    blue = m.add_material(mesh.material(base=(0.1, 0.1, 1.0, 1.0), rough=0.9, metal=0.0, normal_texel=(0.4, 0.6, 1.0, 1.0)), data=tex[2])
+
+    def attrs(n):
+        nrm = g.normal(size=(n, 3)).astype(np.float32)
+        tan = np.concatenate([g.normal(size=(n, 3)), g.choice([-1.0, 1.0], (n, 1))], axis=1).astype(np.float32)
+        col = g.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        return nrm, tan, col
+    # the wall: x from -3 to -1 across its width (perspective: texcoords are not affine in window space), texcoords 0..3 / 0..2
+    pos = np.array([(-3.0, -2.0, -3.0), (-1.0, -2.0, 3.5), (-1.0, 4.0, 3.5), (-3.0, 4.0, -3.0)], np.float32)
+    uv = np.array([(0.0, 0.0), (3.0, 0.0), (3.0, 2.0), (0.0, 2.0)], np.float32)
+    nrm, tan, col = attrs(4)
+    col |= np.uint32(0x60000000)  # keep vertex alpha away from zero: the texture's alpha decides
+    m.add_primitive(pos, nrm, (0, 1, 2, 0, 2, 3), wall, ptype=_abi.PRIMITIVE_TYPE_CUTOUT, colors=col, tangents=tan, texcoords=uv)
+    tri = np.array([(-4.5, 0.0, -1.0), (-4.5, 0.0, 1.0), (-4.5, 2.0, 0.0)], np.float32)
+    nrm, tan, col = attrs(3)
+    uv3 = np.array([(0.1, 0.2), (0.9, 0.3), (0.5, 0.8)], np.float32)
+    for mat, order in ((red, (0, 1, 2)), (blue, (0, 1, 2)), (red, (0, 2, 1)), (blue, (0, 2, 1))):
+        m.add_primitive(tri, nrm, order, mat, colors=col, tangents=tan, texcoords=uv3)
+    return m, view

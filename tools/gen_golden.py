@@ -851,6 +851,244 @@ def probe_update(atl, trace, ids):
     return atl
 
 
+# ---- scene rasteriser: depth pre-pass + G-buffer pass with material textures (f1) ---------------------------------------------------
+# Written from include/sah_hip.h / DESIGN.md §5d (the rules Vulkan leaves open) and gltf_basic_pbr.slang:110-253 (SAH_MAIN_VIEW), for
+# geometry that needs no clipping: vertex stage, 24.8 window coordinates, integer edge functions with the top-left rule, clockwise
+# front faces, screen-linear depth from fp64 plane coefficients, perspective-correct varyings, fine quad derivatives, SampleBias.
+from fractions import Fraction
+
+
+def _fma64(a, b, c):
+    """fp64 fused multiply-add, exactly rounded."""
+    return float(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+
+def _srgb_encode8(v):
+    """half value (as fp32) -> sRGB8 code of an R8G8B8A8_SRGB store: OETF in fp64 rounded to fp32, then floor(s * 255 + 0.5) in fp32"""
+    v = np.asarray(v, f32)
+    d = v.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        s = np.where(d <= 0.0031308, 12.92 * d, 1.055 * np.power(np.maximum(d, 0.0), 1.0 / 2.4) - 0.055).astype(f32)
+    s = np.where(v >= 1, f32(1), np.where(v > 0, s, f32(0)))  # NaN and non-positive values encode to 0
+    return _unorm8(s)
+
+
+def _unorm8(c):
+    c = np.asarray(c, f32)
+    with np.errstate(invalid="ignore"):
+        q = np.floor(F(F(c * f32(255)) + f32(0.5)))
+    return np.where(c >= 1, 255, np.where(c > 0, q, 0)).astype(np.uint8)
+
+
+def _wrap(i, n, mode):
+    if mode == _abi.ADDRESS_CLAMP_TO_EDGE:
+        return np.clip(i, 0, n - 1)
+    if mode == _abi.ADDRESS_MIRRORED_REPEAT:
+        m = np.mod(i, 2 * n)
+        return np.where(m < n, m, 2 * n - 1 - m)
+    return np.mod(i, n)
+
+
+def _texel_values(level, srgb):
+    t = level.astype(np.float64) / 255.0
+    out = (level.astype(f32) / f32(255.0)).astype(f32)
+    if srgb:
+        out[..., :3] = np.where(t[..., :3] <= 0.04045, t[..., :3] / 12.92, ((t[..., :3] + 0.055) / 1.055) ** 2.4).astype(f32)
+    return out
+
+
+def _sample_level(level, srgb, smp, filt, u, v):
+    tex = _texel_values(level, srgb)
+    hgt, wid = level.shape[:2]
+    if filt == _abi.FILTER_NEAREST:
+        x = _wrap(np.floor(F(u * f32(wid))).astype(np.int64), wid, smp.address_u)
+        y = _wrap(np.floor(F(v * f32(hgt))).astype(np.int64), hgt, smp.address_v)
+        return tex[y, x]
+    x0, wx0, fx = axis(u, wid)
+    y0, wy0, fy = axis(v, hgt)
+    acc = np.zeros(u.shape + (4,), f32)
+    for (dy, dx, w) in ((0, 0, F(wx0 * wy0)), (0, 1, F(fx * wy0)), (1, 0, F(wx0 * fy)), (1, 1, F(fx * fy))):
+        t = tex[_wrap(y0 + dy, hgt, smp.address_v), _wrap(x0 + dx, wid, smp.address_u)]
+        acc = fma(w[..., None], t, acc)
+    return acc
+
+
+def sample_bias(texture, uv, ddx, ddy, shader_bias):
+    """textures[i].SampleBias(uv, bias) under the rules of include/sah_hip.h (sah_texture); uv, ddx, ddy: pairs of fp32 arrays"""
+    mips, fmt, smp = texture
+    srgb = fmt == _abi.FORMAT_R8G8B8A8_SRGB
+    w0, h0 = f32(mips[0].shape[1]), f32(mips[0].shape[0])
+    mxx, mxy, myx, myy = F(ddx[0] * w0), F(ddx[1] * h0), F(ddy[0] * w0), F(ddy[1] * h0)
+    rho2 = np.fmax(F(F(mxx * mxx) + F(mxy * mxy)), F(F(myx * myx) + F(myy * myy)))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lam = np.where(rho2 > 0, F(f32(0.5) * np.log2(rho2.astype(np.float64)).astype(f32)), f32(-np.inf))
+    lam = F(lam + F(f32(smp.mip_lod_bias) + f32(shader_bias)))
+    lam = np.fmin(np.fmax(lam, f32(smp.min_lod)), f32(smp.max_lod))
+    q = len(mips) - 1
+    out = np.zeros(uv[0].shape + (4,), f32)
+    mag = lam <= 0
+
+    def level_sample(level):
+        a = _sample_level(mips[level], srgb, smp, smp.mag_filter, uv[0], uv[1])
+        b = _sample_level(mips[level], srgb, smp, smp.min_filter, uv[0], uv[1])
+        return np.where(mag[..., None], a, b)
+    if smp.mipmap_mode == _abi.FILTER_NEAREST:
+        level = np.where(lam <= 0.5, 0, np.where(lam < q, np.minimum(np.ceil(F(lam + f32(0.5))) - 1, q), q)).astype(np.int64)
+        for k in range(q + 1):
+            out = np.where((level == k)[..., None], level_sample(k), out)
+        return out
+    d = np.fmin(np.fmax(lam, f32(0)), f32(q))
+    hi = np.floor(d).astype(np.int64)
+    lo = np.minimum(hi + 1, q)
+    delta = F(d - np.floor(d))
+    ta, tb = np.zeros_like(out), np.zeros_like(out)
+    for k in range(q + 1):
+        sk = level_sample(k)
+        ta = np.where((hi == k)[..., None], sk, ta)
+        tb = np.where((lo == k)[..., None], sk, tb)
+    return F(F(F(f32(1) - delta)[..., None] * ta) + F(delta[..., None] * tb))
+
+
+def raster_gbuffer(m, view, W, Hh):
+    """sah_gbuffer_render of mesh.Mesh `m` (every triangle inside the frustum)."""
+    vd_all = np.concatenate(m.vertex_data)
+    pos_all = np.concatenate(m.positions)
+    idx_all = np.concatenate(m.indices)
+    Vm = np.array(view.gpu_data.view[:], f32)
+    Pm = np.array(view.gpu_data.projection[:], f32)
+    bias = view.gpu_data.material_texture_mip_bias
+    ys, xs = np.meshgrid(np.arange(Hh, dtype=np.int64), np.arange(W, dtype=np.int64), indexing="ij")
+    # draw order: SOLID primitives, then CUTOUT ones, list order inside a class
+    prims = [p for t in (_abi.PRIMITIVE_TYPE_SOLID, _abi.PRIMITIVE_TYPE_CUTOUT) for p in m.primitives if int(p["type"]) == t]
+    frags = []  # per triangle: coverage mask, depth, the shaded G-buffer texel arrays, alpha discard
+    for p in prims:
+        model = np.array(p["model"], f32)
+        mat = m.materials[int(p["material"])]
+        slots = m.material_textures[int(p["material"])]
+        first, count, voff = int(p["first_index"]), int(p["index_count"]), int(p["vertex_offset"])
+        for t in range(count // 3):
+            ids = [voff + int(idx_all[first + 3 * t + k]) for k in range(3)]
+            # vertex stage :126-141
+            clip, vo = [], []
+            for i in ids:
+                world = mat_vec(model, [f32(pos_all[i][0]), f32(pos_all[i][1]), f32(pos_all[i][2]), f32(1)])
+                clip.append(mat_vec(Pm, mat_vec(Vm, world)))
+                vd = vd_all[i]
+                rot = lambda v: [F(F(F(model[0 + r] * v[0]) + F(model[4 + r] * v[1])) + F(model[8 + r] * v[2])) for r in range(3)]
+                n3 = [h(c) for c in normalize3(rot(vd["normal"]))]
+                t3 = [h(c) for c in normalize3(rot(vd["tangent"][:3]))]
+                col = [h(F(f32((int(vd["color"]) >> (8 * c)) & 0xFF) / f32(255))) for c in range(4)]
+                vo.append({"color": col, "normal": n3, "tangent": t3 + [h(f32(vd["tangent"][3]))], "uv": [f32(vd["texcoord"][0]), f32(vd["texcoord"][1])]})
+            # window coordinates: 8 sub-pixel bits, round to nearest even
+            hw, hh = f32(W * 0.5), f32(Hh * 0.5)
+            X, Y, Z, IW = [], [], [], []
+            for c in clip:
+                X.append(int(np.rint(F(F(F(c[0] / c[3]) * hw + hw) * f32(256)))))
+                Y.append(int(np.rint(F(F(F(c[1] / c[3]) * hh + hh) * f32(256)))))
+                Z.append(F(c[2] / c[3]))
+                IW.append(F(f32(1) / c[3]))
+            order = [0, 1, 2]
+            area = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0])
+            if area == 0 or (area < 0 and int(p["type"]) == _abi.PRIMITIVE_TYPE_SOLID):
+                continue  # degenerate, or a back face of a culled primitive (clockwise in window space = front)
+            if area < 0:
+                order, area = [0, 2, 1], -area
+            Xo, Yo, Zo, Wo = [X[k] for k in order], [Y[k] for k in order], [Z[k] for k in order], [IW[k] for k in order]
+            inv_area = F(f32(1) / f32(area))
+
+            def edges(px, py):
+                cx, cy = px * 256 + 128, py * 256 + 128
+                out = []
+                for i in range(3):
+                    a, b = (i + 1) % 3, (i + 2) % 3
+                    dx, dy = Xo[b] - Xo[a], Yo[b] - Yo[a]
+                    out.append((dx * (cy - Yo[a]) - dy * (cx - Xo[a]), dx, dy))
+                return out
+
+            def lambdas(px, py):
+                e = edges(px, py)
+                with np.errstate(all="ignore"):
+                    b = [F(e[i][0].astype(f32) * inv_area) for i in range(3)]
+                    q = [F(b[i] * Wo[i]) for i in range(3)]
+                    s = F(F(q[0] + q[1]) + q[2])
+                    l = [F(q[i] / s) for i in range(3)]
+                lam = [None, None, None]
+                for w_i, in_i in enumerate(order):  # back to the input triangle's vertex order
+                    lam[in_i] = l[w_i]
+                return lam
+            e = edges(xs, ys)
+            cover = np.ones((Hh, W), bool)
+            for (val, dx, dy) in e:
+                cover &= (val > 0) | ((val == 0) & ((dy < 0) or (dy == 0 and dx > 0)))
+            if not cover.any():
+                continue
+            # depth plane in fp64, every operator rounded; z(px, py) = fma(py, zy, fma(px, zx, zc))
+            ea, eb, ec = [], [], []
+            for i in range(3):
+                a, b = (i + 1) % 3, (i + 2) % 3
+                dx, dy = float(Xo[b] - Xo[a]), float(Yo[b] - Yo[a])
+                ea.append(-256.0 * dy)
+                eb.append(256.0 * dx)
+                ec.append(dx * float(128 - Yo[a]) - dy * float(128 - Xo[a]))
+            inv = 1.0 / float(area)
+            z64 = [float(z) for z in Zo]
+            zc = ((ec[0] * z64[0] + ec[1] * z64[1]) + ec[2] * z64[2]) * inv
+            zx = ((ea[0] * z64[0] + ea[1] * z64[1]) + ea[2] * z64[2]) * inv
+            zy = ((eb[0] * z64[0] + eb[1] * z64[1]) + eb[2] * z64[2]) * inv
+            depth = np.zeros((Hh, W), f32)
+            for (py, px) in np.argwhere(cover):
+                depth[py, px] = f32(_fma64(py, zy, _fma64(px, zx, zc)))
+            depth = np.clip(depth, f32(0), f32(1))
+            # fragment stage :169-228
+            lam = lambdas(xs, ys)
+            lam_x, lam_y = lambdas(xs ^ 1, ys), lambdas(xs, ys ^ 1)
+            interp_h = lambda key, c: h(F(F(F(lam[0] * vo[0][key][c]) + F(lam[1] * vo[1][key][c])) + F(lam[2] * vo[2][key][c])))
+            interp_uv = lambda lm, c: F(F(F(lm[0] * vo[0]["uv"][c]) + F(lm[1] * vo[1]["uv"][c])) + F(lm[2] * vo[2]["uv"][c]))
+            with np.errstate(all="ignore"):
+                uv = [interp_uv(lam, c) for c in range(2)]
+                uvx, uvy = [interp_uv(lam_x, c) for c in range(2)], [interp_uv(lam_y, c) for c in range(2)]
+                ddx = [np.where(xs & 1, F(uv[c] - uvx[c]), F(uvx[c] - uv[c])) for c in range(2)]
+                ddy = [np.where(ys & 1, F(uv[c] - uvy[c]), F(uvy[c] - uv[c])) for c in range(2)]
+
+                def slot(index, constant):
+                    if int(index) == _abi.TEXTURE_NONE:
+                        return [np.broadcast_to(h(f32(constant[c])), (Hh, W)) for c in range(4)]
+                    t4 = sample_bias(m.textures[int(index)], uv, ddx, ddy, bias)
+                    return [h(t4[..., c]) for c in range(4)]
+                base = slot(slots[0], mat["base_color_texel"])
+                nmap = slot(slots[1], mat["normal_texel"])
+                data = slot(slots[2], mat["data_texel"])
+                emis = slot(slots[3], mat["emission_texel"])
+                col = [interp_h("color", c) for c in range(4)]
+                N = [interp_h("normal", c) for c in range(3)]
+                T = [interp_h("tangent", c) for c in range(4)]
+                tinted = [h(h(base[c] * col[c]) * h(f32(mat["base_color_tint"][c]))) for c in range(4)]
+                discard = (int(p["type"]) == _abi.PRIMITIVE_TYPE_CUTOUT) & (tinted[3] <= f32(mat["opacity_threshold"]))
+                cr = [h(h(N[1] * T[2]) - h(N[2] * T[1])), h(h(N[2] * T[0]) - h(N[0] * T[2])), h(h(N[0] * T[1]) - h(N[1] * T[0]))]
+                B = [h(cr[c] * T[3]) for c in range(3)]
+                ns = [h(h(nmap[c] * h(f32(2))) - h(f32(1))) for c in range(3)]
+                nout = [h(h(h(ns[0] * T[c]) + h(ns[1] * B[c])) + h(ns[2] * N[c])) for c in range(3)]
+                factor = [h(f32(0)), h(f32(mat["roughness_factor"])), h(f32(mat["metalness_factor"])), h(f32(0))]
+                dat = [h(data[c] * factor[c]) for c in range(4)]
+                em = [h(emis[c] * h(f32(mat["emission_factor"][c]))) for c in range(4)]
+            texel = {"color": np.stack([_srgb_encode8(tinted[c]) if c < 3 else _unorm8(tinted[c]) for c in range(4)], -1),
+                     "normals": np.stack([x.astype(np.float16).view(np.uint16) for x in nout] + [np.zeros((Hh, W), np.uint16)], -1),
+                     "data": np.stack([_unorm8(d) for d in dat], -1),
+                     "emission": np.stack([_srgb_encode8(em[c]) if c < 3 else _unorm8(em[c]) for c in range(4)], -1)}
+            frags.append((cover & ~discard & (depth > 0), depth, texel))
+    # pass 1: depth (GREATER against the cleared 0); pass 2: EQUAL, every fragment at the settled depth overwrites: the last one stays
+    out = {"color": np.zeros((Hh, W, 4), np.uint8), "normals": np.zeros((Hh, W, 4), np.uint16), "data": np.zeros((Hh, W, 4), np.uint8),
+           "emission": np.zeros((Hh, W, 4), np.uint8), "depth": np.zeros((Hh, W), f32)}
+    out["normals"][...] = np.array([0x3800, 0x3800, 0x3C00, 0], np.uint16)  # clear values gbuffer_phase.cpp:66-87
+    for (mask, depth, _) in frags:
+        out["depth"] = np.where(mask & (depth > out["depth"]), depth, out["depth"])
+    for (mask, depth, texel) in frags:
+        hit = mask & (depth == out["depth"])
+        for k in texel:
+            out[k] = np.where(hit[..., None], texel[k], out[k])
+    return out
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -919,6 +1157,13 @@ def main():
         sparse[f"{k}_val"] = a[tuple(idx.T.astype(np.int64))] if a.dtype != np.float16 else a.view(np.uint16)[tuple(idx.T.astype(np.int64))]
         print("probe_update", k, len(idx), "texels changed")
     np.savez_compressed(os.path.join(GOLDEN, "probe_update_48.npz"), seed=111, num_probes=48, **sparse)
+
+    # scene rasteriser with material textures (f1): depth pre-pass + G-buffer pass of tests/util.py: golden_raster_scene()
+    from tests import util
+    rm, rview = util.golden_raster_scene()
+    gb = raster_gbuffer(rm, rview, W, Hh)
+    np.savez_compressed(os.path.join(GOLDEN, f"raster_gbuffer_{W}x{Hh}.npz"), **gb)
+    print("raster_gbuffer ok: covered", int((gb["depth"] > 0).sum()), "of", W * Hh)
 
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
