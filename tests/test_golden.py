@@ -195,3 +195,24 @@ def test_hip_matches_golden_textured_gbuffer(hip_ctx):
     want = _raster_golden()
     for k in want:
         assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"
+
+
+def test_oracle_matches_golden_shadow_cascades():
+    """f2: two sun shadow cascades of the same scene (D16, LESS, texture-alpha cutouts) against the numpy rasteriser"""
+    from tests.test_raster import _oracle_shadow
+    m, view = util.golden_raster_scene()
+    sun = util.golden_raster_sun(view)
+    got, _ = _oracle_shadow(m.arrays(), sun.constants, 2, (48, 48))
+    want = np.load(os.path.join(GOLDEN, "raster_shadow_2x48.npz"))["shadowmap"]
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert (want != 0xFFFF).sum() > 100
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_shadow_cascades(hip_ctx):
+    from tests.test_raster import _hip_shadow
+    m, view = util.golden_raster_scene()
+    sun = util.golden_raster_sun(view)
+    got, _ = _hip_shadow(hip_ctx, m.arrays(), sun.constants, 2, (48, 48))
+    want = np.load(os.path.join(GOLDEN, "raster_shadow_2x48.npz"))["shadowmap"]
+    assert np.array_equal(got, want), int((got != want).sum())

@@ -168,3 +168,11 @@ def golden_raster_scene():
     for mat, order in ((red, (0, 1, 2)), (blue, (0, 1, 2)), (red, (0, 2, 1)), (blue, (0, 2, 1))):
         m.add_primitive(tri, nrm, order, mat, colors=col, tangents=tan, texcoords=uv3)
     return m, view
+
+
+def golden_raster_sun(view):
+    """Sun whose cascades are fitted to `view` (directional_light.cpp:164-260 through scene.DirectionalLight)."""
+    from androidrenderer_amd import scene
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
+    sun.update_shadow_cascades(view, resolution=48)
+    return sun

@@ -949,14 +949,12 @@ def sample_bias(texture, uv, ddx, ddy, shader_bias):
     return F(F(F(f32(1) - delta)[..., None] * ta) + F(delta[..., None] * tb))
 
 
-def raster_gbuffer(m, view, W, Hh):
-    """sah_gbuffer_render of mesh.Mesh `m` (every triangle inside the frustum)."""
+def raster_fragments(m, to_clip, W, Hh, bias, shade=True):
+    """Every triangle of mesh.Mesh `m` (all of them inside the clip volume) in draw order, through `to_clip(world) -> clip`:
+    yields (kept fragments mask, depth, G-buffer texels or None)."""
     vd_all = np.concatenate(m.vertex_data)
     pos_all = np.concatenate(m.positions)
     idx_all = np.concatenate(m.indices)
-    Vm = np.array(view.gpu_data.view[:], f32)
-    Pm = np.array(view.gpu_data.projection[:], f32)
-    bias = view.gpu_data.material_texture_mip_bias
     ys, xs = np.meshgrid(np.arange(Hh, dtype=np.int64), np.arange(W, dtype=np.int64), indexing="ij")
     # draw order: SOLID primitives, then CUTOUT ones, list order inside a class
     prims = [p for t in (_abi.PRIMITIVE_TYPE_SOLID, _abi.PRIMITIVE_TYPE_CUTOUT) for p in m.primitives if int(p["type"]) == t]
@@ -972,7 +970,7 @@ def raster_gbuffer(m, view, W, Hh):
             clip, vo = [], []
             for i in ids:
                 world = mat_vec(model, [f32(pos_all[i][0]), f32(pos_all[i][1]), f32(pos_all[i][2]), f32(1)])
-                clip.append(mat_vec(Pm, mat_vec(Vm, world)))
+                clip.append(to_clip(world))
                 vd = vd_all[i]
                 rot = lambda v: [F(F(F(model[0 + r] * v[0]) + F(model[4 + r] * v[1])) + F(model[8 + r] * v[2])) for r in range(3)]
                 n3 = [h(c) for c in normalize3(rot(vd["normal"]))]
@@ -1075,7 +1073,16 @@ def raster_gbuffer(m, view, W, Hh):
                      "normals": np.stack([x.astype(np.float16).view(np.uint16) for x in nout] + [np.zeros((Hh, W), np.uint16)], -1),
                      "data": np.stack([_unorm8(d) for d in dat], -1),
                      "emission": np.stack([_srgb_encode8(em[c]) if c < 3 else _unorm8(em[c]) for c in range(4)], -1)}
-            frags.append((cover & ~discard & (depth > 0), depth, texel))
+            frags.append((cover & ~discard, depth, texel))
+    return frags
+
+
+def raster_gbuffer(m, view, W, Hh):
+    """sah_gbuffer_render of mesh.Mesh `m` (every triangle inside the frustum)."""
+    Vm = np.array(view.gpu_data.view[:], f32)
+    Pm = np.array(view.gpu_data.projection[:], f32)
+    frags = [(mask & (depth > 0), depth, texel)
+             for (mask, depth, texel) in raster_fragments(m, lambda world: mat_vec(Pm, mat_vec(Vm, world)), W, Hh, view.gpu_data.material_texture_mip_bias)]
     # pass 1: depth (GREATER against the cleared 0); pass 2: EQUAL, every fragment at the settled depth overwrites: the last one stays
     out = {"color": np.zeros((Hh, W, 4), np.uint8), "normals": np.zeros((Hh, W, 4), np.uint16), "data": np.zeros((Hh, W, 4), np.uint8),
            "emission": np.zeros((Hh, W, 4), np.uint8), "depth": np.zeros((Hh, W), f32)}
@@ -1088,6 +1095,17 @@ def raster_gbuffer(m, view, W, Hh):
             out[k] = np.where(hit[..., None], texel[k], out[k])
     return out
 
+
+
+def raster_shadow(m, sun, num_cascades, res):
+    """sah_shadow_render: D16 cascades, compare LESS against the cleared 1.0, masked geometry alpha-tested (texture mip bias 0)."""
+    out = np.full((num_cascades, res, res), 0xFFFF, np.uint16)
+    for c in range(num_cascades):
+        M = np.array(sun.cascade_matrices[c][:], f32)
+        for (mask, depth, _) in raster_fragments(m, lambda world: mat_vec(M, world), res, res, 0.0):
+            code = np.rint(F(depth * f32(65535))).astype(np.int64)
+            out[c] = np.where(mask & (code < out[c]), code, out[c]).astype(np.uint16)
+    return out
 
 def inputs_digest(arrays):
     m = hashlib.sha256()
@@ -1164,6 +1182,11 @@ def main():
     gb = raster_gbuffer(rm, rview, W, Hh)
     np.savez_compressed(os.path.join(GOLDEN, f"raster_gbuffer_{W}x{Hh}.npz"), **gb)
     print("raster_gbuffer ok: covered", int((gb["depth"] > 0).sum()), "of", W * Hh)
+    # sun shadow cascades of the same scene (f2): two cascades fitted to the camera, 48^2 texels each
+    rsun = util.golden_raster_sun(rview)
+    sm = raster_shadow(rm, rsun.constants, 2, 48)
+    np.savez_compressed(os.path.join(GOLDEN, "raster_shadow_2x48.npz"), shadowmap=sm)
+    print("raster_shadow ok: covered", int((sm != 0xFFFF).sum()), "of", sm.size)
 
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
