@@ -216,3 +216,30 @@ def test_hip_matches_golden_shadow_cascades(hip_ctx):
     got, _ = _hip_shadow(hip_ctx, m.arrays(), sun.constants, 2, (48, 48))
     want = np.load(os.path.join(GOLDEN, "raster_shadow_2x48.npz"))["shadowmap"]
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+def _rsm_of_golden_scene():
+    m, view = util.golden_raster_scene()
+    sun = util.golden_raster_sun(view)
+    return m, sun, util.golden_raster_lpv(view, sun), np.load(os.path.join(GOLDEN, "raster_rsm_4x32.npz"))
+
+
+def test_oracle_matches_golden_rsm():
+    """f4 (first stage): the LPV's reflective shadow map of the same scene against the numpy rasteriser"""
+    from tests.test_lpv_inject import _oracle_rsm
+    m, sun, lpv, want = _rsm_of_golden_scene()
+    got = _oracle_rsm(m.arrays(), sun, lpv, res=32)
+    for k in ("depth", "flux", "normals"):
+        assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"
+    assert (want["depth"] != 0xFFFF).sum() > 100
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_rsm(hip_ctx):
+    from tests.test_lpv_inject import _hip_rsm
+    m, sun, lpv, want = _rsm_of_golden_scene()
+    got = _hip_rsm(hip_ctx, m.arrays(), sun, lpv, res=32)
+    for k in ("depth", "flux", "normals"):
+        g = got[k].cpu().numpy()
+        g = g.view(np.uint16) if k == "depth" else g
+        assert np.array_equal(g, want[k]), f"{k}: {int((g != want[k]).sum())} values differ"

@@ -176,3 +176,10 @@ def golden_raster_sun(view):
     sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
     sun.update_shadow_cascades(view, resolution=48)
     return sun
+
+
+def golden_raster_lpv(view, sun):
+    from androidrenderer_amd import scene
+    lpv = scene.LpvCascades()
+    lpv.update_cascade_transforms(view, sun)
+    return lpv

@@ -1073,6 +1073,7 @@ def raster_fragments(m, to_clip, W, Hh, bias, shade=True):
                      "normals": np.stack([x.astype(np.float16).view(np.uint16) for x in nout] + [np.zeros((Hh, W), np.uint16)], -1),
                      "data": np.stack([_unorm8(d) for d in dat], -1),
                      "emission": np.stack([_srgb_encode8(em[c]) if c < 3 else _unorm8(em[c]) for c in range(4)], -1)}
+            texel["_tinted"], texel["_normal"] = tinted, N  # half values, for the RSM variant of the fragment stage
             frags.append((cover & ~discard, depth, texel))
     return frags
 
@@ -1091,10 +1092,54 @@ def raster_gbuffer(m, view, W, Hh):
         out["depth"] = np.where(mask & (depth > out["depth"]), depth, out["depth"])
     for (mask, depth, texel) in frags:
         hit = mask & (depth == out["depth"])
-        for k in texel:
-            out[k] = np.where(hit[..., None], texel[k], out[k])
+        for k in out:
+            if k != "depth":
+                out[k] = np.where(hit[..., None], texel[k], out[k])
     return out
 
+
+
+def fd_half(base, n, l, v):
+    """Fd(surface, l, v) of brdf.slangi:59-83 in half precision for metalness = roughness = 0 (the RSM variant leaves gbuffer.data 0)."""
+    r = h
+    one = r(f32(1.0))
+    diff = [r(r(base[i] * r(one - r(f32(0.04)))) * r(one - r(f32(0)))) for i in range(3)]
+    hv = normalize3([r(v[i] + l[i]) for i in range(3)], r)
+    dn = lambda a, b: r(r(r(a[0] * b[0]) + r(a[1] * b[1])) + r(a[2] * b[2]))
+    NoV = np.abs(r(dn(n, v) + r(f32(1e-5))))
+    NoL = dn(n, l)
+    dark = NoL <= 0
+    NoL = clamp01(NoL)
+    LoH = clamp01(dn(l, hv))
+    f90 = r(r(f32(0.5)) + r(r(r(r(f32(2.0)) * r(f32(0))) * LoH) * LoH))
+    schlick1 = lambda u: r(one + r(r(f90 - one) * pow5(clamp01(r(one - u)), r)))
+    fdv = r(r(schlick1(NoL) * schlick1(NoV)) * r(one / r(f32(3.1415927))))
+    return [np.where(dark, f32(0), r(diff[i] * fdv)) for i in range(3)]
+
+
+def raster_rsm(m, sun, cascades, num_cascades, res):
+    """sah_rsm_render: flux (sRGB8), normal * 0.5 + 0.5 (UNORM8) and depth (D16, LESS: the first of equal codes in draw order stays)."""
+    flux = np.zeros((num_cascades, res, res, 4), np.uint8)
+    normals = np.zeros((num_cascades, res, res, 4), np.uint8)
+    normals[...] = np.array([128, 128, 255, 0], np.uint8)  # clear (0.5, 0.5, 1, 0), light_propagation_volume.cpp:596-600
+    depth = np.full((num_cascades, res, res), 0xFFFF, np.uint16)
+    sd = np.array(sun.direction_and_tan_size[:3], f32)
+    l = [h(F(-h(sd[i]))) for i in range(3)]
+    for c in range(num_cascades):
+        M = np.array(cascades[c].rsm_vp[:], f32)
+        for (mask, z, texel) in raster_fragments(m, lambda world: mat_vec(M, world), res, res, 0.0):
+            code = np.rint(F(z * f32(65535))).astype(np.int64)
+            win = mask & (code < depth[c])
+            N = texel["_normal"]
+            with np.errstate(all="ignore"):
+                fl = fd_half(texel["_tinted"][:3], N, l, N)
+                nb = [_unorm8(h(h(N[i] * h(f32(0.5))) + h(f32(0.5)))) for i in range(3)]
+            ft = np.stack([_srgb_encode8(fl[i]) for i in range(3)] + [np.full((res, res), 255, np.uint8)], -1)
+            nt = np.stack(nb + [np.full((res, res), 255, np.uint8)], -1)
+            flux[c] = np.where(win[..., None], ft, flux[c])
+            normals[c] = np.where(win[..., None], nt, normals[c])
+            depth[c] = np.where(win, code, depth[c]).astype(np.uint16)
+    return {"flux": flux, "normals": normals, "depth": depth}
 
 
 def raster_shadow(m, sun, num_cascades, res):
@@ -1187,6 +1232,11 @@ def main():
     sm = raster_shadow(rm, rsun.constants, 2, 48)
     np.savez_compressed(os.path.join(GOLDEN, "raster_shadow_2x48.npz"), shadowmap=sm)
     print("raster_shadow ok: covered", int((sm != 0xFFFF).sum()), "of", sm.size)
+    # the LPV's reflective shadow map of the same scene (f4): four cascades of 32^2 texels
+    rlpv = util.golden_raster_lpv(rview, rsun)
+    rsm = raster_rsm(rm, rsun.constants, rlpv.matrices, 4, 32)
+    np.savez_compressed(os.path.join(GOLDEN, "raster_rsm_4x32.npz"), **rsm)
+    print("raster_rsm ok: covered", int((rsm["depth"] != 0xFFFF).sum()), "of", rsm["depth"].size)
 
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
