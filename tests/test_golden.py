@@ -243,3 +243,52 @@ def test_hip_matches_golden_rsm(hip_ctx):
         g = got[k].cpu().numpy()
         g = g.view(np.uint16) if k == "depth" else g
         assert np.array_equal(g, want[k]), f"{k}: {int((g != want[k]).sum())} values differ"
+
+
+def _inject_golden():
+    g = np.load(os.path.join(GOLDEN, "lpv_inject_4x32.npz"))
+    want = [np.zeros((32, 32, 128, 4), np.uint16) for _ in range(3)]
+    at = tuple(g["cells"].T.astype(np.int64))
+    for i in range(3):
+        want[i][at] = g[f"vol_{i}"]
+    return [g[f"vpls_{c}"] for c in range(4)], want
+
+
+def test_oracle_matches_golden_vpl_extraction_and_injection():
+    """f4: VPL lists of the golden RSM (ascending invocation index) and the volumes after injecting them, cascade by cascade"""
+    from tests.test_lpv_inject import _empty_volumes, _oracle_extract, _oracle_inject
+    _, _, lpv, rsm = _rsm_of_golden_scene()
+    rsm = {k: rsm[k] for k in ("flux", "normals", "depth")}
+    lists, want = _inject_golden()
+    vols = _empty_volumes()
+    for c in range(4):
+        vpls, count = _oracle_extract(rsm, lpv, c)
+        assert count == len(lists[c]) and np.array_equal(vpls[:count], lists[c]), f"cascade {c}"
+        _oracle_inject(vpls, count, lpv, c, vols)
+    for i in range(3):
+        assert np.array_equal(vols[i], want[i]), f"volume {i}: {int((vols[i] != want[i]).sum())} values differ"
+    assert sum(len(l) for l in lists) > 40
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_vpl_extraction_and_injection(hip_ctx):
+    import torch
+    from tests.test_lpv_inject import CELL, _rsm_desc
+    _, _, lpv, rsm = _rsm_of_golden_scene()
+    rsm_t = {"flux": torch.from_numpy(rsm["flux"]).cuda(), "normals": torch.from_numpy(rsm["normals"]).cuda(),
+             "depth": torch.from_numpy(rsm["depth"].view(np.int16)).cuda()}
+    lists, want = _inject_golden()
+    vols_t = [torch.zeros((32, 32, 128, 4), dtype=torch.int16, device="cuda") for _ in range(3)]
+    vol_desc = [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols_t]
+    cap = 16 * 16
+    for c in range(4):
+        list_t = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+        count_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hip_ctx.lpv_extract_vpls(_rsm_desc(rsm_t), lpv.matrices, c, CELL, list_t.data_ptr(), count_t.data_ptr())
+        torch.cuda.synchronize()
+        n = int(count_t.item())
+        assert n == len(lists[c]) and np.array_equal(list_t.cpu().numpy().view(np.uint32)[:n], lists[c]), f"cascade {c}"
+        hip_ctx.lpv_inject_vpls(list_t.data_ptr(), count_t.data_ptr(), cap, lpv.matrices, c, 4, vol_desc)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert np.array_equal(vols_t[i].cpu().numpy().view(np.uint16), want[i]), f"volume {i}"

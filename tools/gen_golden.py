@@ -1152,6 +1152,122 @@ def raster_shadow(m, sun, num_cascades, res):
             out[c] = np.where(mask & (code < out[c]), code, out[c]).astype(np.uint16)
     return out
 
+# ---- LPV injection chain behind the RSM (f4): rsm_generate_vpls.comp:44-139, vpl_injection.vert:27-66, vpl_injection.frag:13-52 ----------
+def length3_f(v):
+    return F(np.sqrt(F(F(F(v[0] * v[0]) + F(v[1] * v[1])) + F(v[2] * v[2]))))
+
+
+def extract_vpls(rsm, mats, cascade, cell_size):
+    """One invocation per 2x2 RSM texels of layer `cascade`; the list in ascending invocation index (the order include/sah_hip.h fixes).
+    Returns the packed lights (n, 4) uint32."""
+    res = rsm["depth"].shape[1]
+    half = res // 2
+    inv_vp = np.array(mats.inverse_rsm_vp[:], f32)
+    w2c = np.array(mats.world_to_cascade[:], f32)
+    gy, gx = np.meshgrid(np.arange(half), np.arange(half), indexing="ij")
+    lut = srgb_lut()
+
+    def load(dx, dy):
+        x, y = gx * 2 + dx, gy * 2 + dy
+        depth = F(rsm["depth"][cascade][y, x].astype(f32) / f32(65535.0))
+        tx, ty = F(F(x.astype(f32) + f32(0.5)) / f32(res)), F(F(y.astype(f32) + f32(0.5)) / f32(res))
+        ws = mat_vec(inv_vp, [F(F(tx * f32(2)) - f32(1)), F(F(ty * f32(2)) - f32(1)), depth, np.ones_like(depth)])
+        with np.errstate(all="ignore"):
+            pos = [F(ws[i] / ws[3]) for i in range(3)]
+        col = [lut[rsm["flux"][cascade][y, x, i]] for i in range(3)]
+        nrm = [F(F(F(rsm["normals"][cascade][y, x, i].astype(f32) / f32(255.0)) * f32(2)) - f32(1)) for i in range(3)]
+        return pos, col, nrm
+
+    def cell_of(pos):
+        cp = mat_vec(w2c, [pos[0], pos[1], pos[2], np.ones_like(pos[0])])
+        side = F(f32(cell_size) * f32(32.0))
+        with np.errstate(all="ignore"):
+            return [np.rint(F(F(cp[0] + f32(cascade)) * side)), np.rint(F(cp[1] * side)), np.rint(F(cp[2] * side))]
+    texels = [load(dx, dy) for dy in range(2) for dx in range(2)]   # loop order y outer, x inner
+    cells = [cell_of(t[0]) for t in texels]
+    brightest = np.zeros((half, half), f32)
+    chosen = [np.zeros((half, half), f32) for _ in range(3)]
+    for (pos, col, nrm), cell in zip(texels, cells):
+        luma = F(F(F(col[0] * f32(0.2126)) + F(col[1] * f32(0.7152))) + F(col[2] * f32(0.0722)))
+        better = luma > brightest
+        brightest = np.where(better, luma, brightest)
+        chosen = [np.where(better, cell[i], chosen[i]) for i in range(3)]
+    acc = {k: [np.zeros((half, half), f32) for _ in range(3)] for k in ("pos", "col", "nrm")}
+    n = np.zeros((half, half), f32)
+    for (pos, col, nrm), cell in zip(texels, cells):
+        with np.errstate(all="ignore"):
+            d = [F(cell[i] - chosen[i]) for i in range(3)]
+            near = F(F(F(d[0] * d[0]) + F(d[1] * d[1])) + F(d[2] * d[2])) < 3
+        for key, val in (("pos", pos), ("col", col), ("nrm", nrm)):
+            acc[key] = [np.where(near, F(acc[key][i] + val[i]), acc[key][i]) for i in range(3)]
+        n = np.where(near, F(n + f32(1)), n)
+    with np.errstate(all="ignore"):
+        has = n > 0
+        pos = [np.where(has, F(acc["pos"][i] / n), acc["pos"][i]) for i in range(3)]
+        col = [np.where(has, F(acc["col"][i] / n), acc["col"][i]) for i in range(3)]
+        nav = [F(acc["nrm"][i] / n) for i in range(3)]
+        nn = normalize3(nav)
+        nrm = [np.where(has, nn[i], acc["nrm"][i]) for i in range(3)]
+        keep = (length3_f(col) > 0) & (length3_f(nrm) > 0)
+    half16 = lambda a: a.astype(np.float16).view(np.uint16).astype(np.uint32)
+    snorm = lambda a: (np.rint(F(np.fmin(np.fmax(a, f32(-1)), f32(1)) * f32(127))).astype(np.int64) & 0xFF).astype(np.uint32)
+    with np.errstate(all="ignore"):
+        data = np.stack([half16(pos[0]) | (half16(pos[1]) << 16), half16(pos[2]) | (half16(col[0]) << 16), half16(col[1]) | (half16(col[2]) << 16),
+                         snorm(nrm[0]) | (snorm(nrm[1]) << 8) | (snorm(nrm[2]) << 16)], axis=-1)
+    return data[keep]  # boolean indexing walks the groups in row-major order = ascending invocation index
+
+
+def inject_vpls(vpls, mats, cascade, num_cascades, vols):
+    """Points of size 1 blended ONE / ONE into the three RGBA16F volumes (fp16 arrays (32, 32, 32 * cascades, 4), modified in place), in
+    list order with one rounding to half per addition."""
+    D, Hh, W = vols[0].shape[:3]
+    w2c = np.array(mats.world_to_cascade[:], f32)
+    mixf = lambda x, y, a: F(F(x * F(f32(1) - a)) + F(y * a))
+    for p in vpls:
+        hf = lambda bits: f32(np.array([bits & 0xFFFF], np.uint16).view(np.float16)[0])
+        pos = [hf(int(p[0])), hf(int(p[0]) >> 16), hf(int(p[1]))]
+        col = [hf(int(p[1]) >> 16), hf(int(p[2])), hf(int(p[2]) >> 16)]
+        sn = lambda b: max(f32(np.int8(np.uint8(b & 0xFF))) / f32(127.0), f32(-1.0))
+        with np.errstate(all="ignore"):
+            nrm = normalize3([F(sn(int(p[3]))), F(sn(int(p[3]) >> 8)), F(sn(int(p[3]) >> 16))])
+            cp = mat_vec(w2c, [pos[0], pos[1], pos[2], f32(1)])
+            px = F(F(cp[0] + f32(cascade)) / f32(num_cascades))
+            ndc = [F(F(px * f32(2)) - f32(1)), F(F(cp[1] * f32(2)) - f32(1))]
+            layer = F(cp[2] * f32(32))
+            if length3_f(nrm) < 1 or length3_f(col) == 0:
+                continue
+            xf, yf = F(F(ndc[0] * f32(W * 0.5)) + f32(W * 0.5)), F(F(ndc[1] * f32(Hh * 0.5)) + f32(Hh * 0.5))
+            if not (0 <= xf < W and 0 <= yf < Hh and -1 < layer < D):
+                continue
+            cx, cy, cz = int(np.floor(xf)), int(np.floor(yf)), int(layer)
+            sc = [F(F(c * f32(1024)) / f32(16384)) for c in col]
+            # rgb2hsv :13-22
+            Kx, Ky, Kz, Kw = f32(0), F(f32(-1) / f32(3)), F(f32(2) / f32(3)), f32(-1)
+            step = lambda edge, x: f32(0) if x < edge else f32(1)
+            s1 = step(sc[2], sc[1])
+            P = [mixf(sc[2], sc[1], s1), mixf(sc[1], sc[2], s1), mixf(Kw, Kx, s1), mixf(Kz, Ky, s1)]
+            s2 = step(P[0], sc[0])
+            Q = [mixf(P[0], sc[0], s2), mixf(P[1], P[1], s2), mixf(P[3], P[2], s2), mixf(sc[0], P[0], s2)]
+            d = F(Q[0] - np.fmin(Q[3], Q[1]))
+            e = f32(1.0e-10)
+            hsv = [np.abs(F(Q[2] + F(F(Q[3] - Q[1]) / F(F(f32(6) * d) + e)))), F(d / F(Q[0] + e)), Q[0]]
+            hsv[1] = F(hsv[1] * f32(2))
+            # hsv2rgb :24-29
+            K = [f32(1), F(f32(2) / f32(3)), F(f32(1) / f32(3)), f32(3)]
+            corrected = []
+            for k in range(3):
+                t = F(hsv[0] + K[k])
+                pk = np.abs(F(F(F(t - np.floor(t)) * f32(6)) - K[3]))
+                corrected.append(F(hsv[2] * mixf(K[0], np.fmin(np.fmax(F(pk - K[0]), f32(0)), f32(1)), hsv[1])))
+            c0, c1 = f32(0.886226925), f32(1.02332671)
+            sh = [c0, F(F(-c1) * nrm[1]), F(c1 * nrm[2]), F(F(-c1) * nrm[0])]
+            for ch in range(3):
+                for k in range(4):
+                    src = F(F(sh[k] * corrected[ch]) / f32(3.1415927))
+                    vols[ch][cz, cy, cx, k] = np.float16(F(f32(vols[ch][cz, cy, cx, k]) + src))
+    return vols
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -1237,6 +1353,16 @@ def main():
     rsm = raster_rsm(rm, rsun.constants, rlpv.matrices, 4, 32)
     np.savez_compressed(os.path.join(GOLDEN, "raster_rsm_4x32.npz"), **rsm)
     print("raster_rsm ok: covered", int((rsm["depth"] != 0xFFFF).sum()), "of", rsm["depth"].size)
+    # VPL extraction and injection of that RSM (f4): the four lists, and the non-zero cells of the three volumes
+    vols = [np.zeros((32, 32, 128, 4), np.float16) for _ in range(3)]
+    lists = {}
+    for c in range(4):
+        lists[f"vpls_{c}"] = extract_vpls(rsm, rlpv.matrices[c], c, 0.25)
+        inject_vpls(lists[f"vpls_{c}"], rlpv.matrices[c], c, 4, vols)
+    cells = np.argwhere(np.any([v.view(np.uint16).any(axis=-1) for v in vols], axis=0)).astype(np.int16)
+    at = tuple(cells.T.astype(np.int64))
+    np.savez_compressed(os.path.join(GOLDEN, "lpv_inject_4x32.npz"), cells=cells, **lists, **{f"vol_{i}": vols[i].view(np.uint16)[at] for i in range(3)})
+    print("lpv_inject ok:", [len(lists[f"vpls_{c}"]) for c in range(4)], "lights,", len(cells), "cells lit")
 
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
