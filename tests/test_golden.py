@@ -292,3 +292,27 @@ def test_hip_matches_golden_vpl_extraction_and_injection(hip_ctx):
     torch.cuda.synchronize()
     for i in range(3):
         assert np.array_equal(vols_t[i].cpu().numpy().view(np.uint16), want[i]), f"volume {i}"
+
+
+def _check_sky_luts(t, m, s):
+    g = np.load(os.path.join(GOLDEN, "sky_luts.npz"))
+    assert np.array_equal(t[::4], g["transmittance_rows"]), "transmittance LUT"
+    assert np.array_equal(m, g["multiscattering"]), "multiple-scattering LUT"
+    assert np.array_equal(s[::4], g["sky_view_rows"]), "sky-view LUT"
+
+
+def test_oracle_matches_golden_sky_luts():
+    """f3: the three sky LUT generators against their numpy restatement (tools/gen_golden.py)"""
+    from tests.test_sky_luts import _oracle_luts
+    g = np.load(os.path.join(GOLDEN, "sky_luts.npz"))
+    _check_sky_luts(*_oracle_luts(tuple(float(c) for c in g["light"])))
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_sky_luts(hip_ctx):
+    import torch
+    g = np.load(os.path.join(GOLDEN, "sky_luts.npz"))
+    t, m, s = (torch.zeros(shape, dtype=torch.int16, device="cuda") for shape in ((64, 256, 4), (32, 32, 4), (200, 200, 4)))
+    hip_ctx.sky_update_luts(*[images.plane(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in (t, m, s)], tuple(float(c) for c in g["light"]))
+    torch.cuda.synchronize()
+    _check_sky_luts(*[a.cpu().numpy().view(np.uint16) for a in (t, m, s)])

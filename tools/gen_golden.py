@@ -1268,6 +1268,207 @@ def inject_vpls(vpls, mats, cascade, num_cascades, vols):
     return vols
 
 
+# ---- sky LUT generators (f3): sky/common.glsl:8-110, transmittance_lut.comp, multiscattering_lut.comp, sky_view_lut.comp ----------------
+# GLSL fp32, every operator rounded, constant expressions too; exp / sin / cos / acos / pow through fp64 rounded to fp32; rgba16f stores.
+SKY_PI = f32(3.14159265358)
+SKY_GROUND, SKY_ATMOSPHERE = f32(6.360), f32(6.460)
+
+
+def _t64(fn, x):
+    return fn(np.asarray(x, np.float64)).astype(f32)
+
+
+def _len3(v):
+    return F(np.sqrt(F(F(F(v[0] * v[0]) + F(v[1] * v[1])) + F(v[2] * v[2]))))
+
+
+def _dot3(a, b):
+    return F(F(F(a[0] * b[0]) + F(a[1] * b[1])) + F(a[2] * b[2]))
+
+
+def sky_ray_sphere(ro, rd, rad):
+    """common.glsl:76-90"""
+    b = _dot3(ro, rd)
+    c = F(_dot3(ro, ro) - F(rad * rad))
+    discr = F(F(b * b) - c)
+    with np.errstate(invalid="ignore"):
+        root = F(np.sqrt(discr))
+        t = np.where(discr > F(b * b), F(F(-b) + root), F(F(-b) - root))
+    t = np.where(discr < 0, f32(-1), t)
+    return np.where((c > 0) & (b > 0), f32(-1), t)
+
+
+def sky_scattering_values(pos):
+    """common.glsl:51-70 -> rayleigh scattering (3), mie scattering, extinction (3)"""
+    alt = F(np.maximum(f32(0), F(_len3(pos) - SKY_GROUND)) * f32(1000.0))
+    ray_d = _t64(np.exp, F(F(-alt) / f32(8.0)))
+    mie_d = _t64(np.exp, F(F(-alt) / f32(1.2)))
+    ray = [F(f32(k) * ray_d) for k in (6.6, 12.3, 29.4)]
+    ray_abs = F(f32(0.0) * ray_d)
+    mie = F(f32(3.996) * mie_d)
+    mie_abs = F(f32(4.4) * mie_d)
+    oz_f = np.maximum(f32(0.0), F(f32(1.0) - F(np.abs(F(alt - f32(25.0))) / f32(15.0))))
+    ozone = [F(f32(k) * oz_f) for k in (2.26, 1.54, 0.0)]
+    ext = [F(F(F(F(ray[i] + ray_abs) + mie) + mie_abs) + ozone[i]) for i in range(3)]
+    return ray, mie, ext
+
+
+def sky_mie_phase(cos_t):
+    g = f32(0.8)
+    scale = F(f32(3.0) / F(f32(8.0) * SKY_PI))
+    num = F(F(f32(1.0) - F(g * g)) * F(f32(1.0) + F(cos_t * cos_t)))
+    base = F(F(f32(1.0) + F(g * g)) - F(F(f32(2.0) * g) * cos_t))
+    denom = F(F(f32(2.0) + F(g * g)) * np.power(base.astype(np.float64), np.float64(f32(1.5))).astype(f32))
+    return F(F(scale * num) / denom)
+
+
+def sky_rayleigh_phase(cos_t):
+    k = F(f32(3.0) / F(f32(16.0) * SKY_PI))
+    return F(k * F(f32(1.0) + F(cos_t * cos_t)))
+
+
+def sky_lut_value(lut, pos, sun):
+    """getValFromTLUT / getValFromMultiScattLUT (common.glsl:94-110): linear, REPEAT"""
+    height = _len3(pos)
+    up = [F(p / height) for p in pos]
+    cz = _dot3(sun, up)
+    u = np.minimum(np.maximum(F(f32(0.5) + F(f32(0.5) * cz)), f32(0)), f32(1))
+    v = np.maximum(f32(0.0), np.minimum(f32(1.0), F(F(height - SKY_GROUND) / F(SKY_ATMOSPHERE - SKY_GROUND))))
+    t = bilinear_repeat(lut, u, v)
+    return [t[..., i] for i in range(3)]
+
+
+def sky_sun_dir_of_texel(xs, ys, w, hgt):
+    u, v = F(xs.astype(f32) / f32(w)), F(ys.astype(f32) / f32(hgt))
+    cos_t = F(F(f32(2.0) * u) - f32(1.0))
+    theta = _t64(np.arccos, np.minimum(np.maximum(cos_t, f32(-1)), f32(1)))
+    height = F(F(SKY_GROUND * F(f32(1) - v)) + F(SKY_ATMOSPHERE * v))  # mix(ground, atmosphere, v)
+    pos = [np.zeros_like(height), height, np.zeros_like(height)]
+    sd = [np.zeros_like(height), cos_t, F(-_t64(np.sin, theta))]
+    ln = _len3(sd)
+    inv = F(f32(1) / ln)   # normalize = v * (1 / length) (DESIGN.md §3)
+    return pos, [F(c * inv) for c in sd]
+
+
+def sky_transmittance_lut():
+    ys, xs = np.meshgrid(np.arange(64), np.arange(256), indexing="ij")
+    pos, sun = sky_sun_dir_of_texel(xs, ys, 256, 64)
+    blocked = sky_ray_sphere(pos, sun, SKY_GROUND) > 0
+    atmo = sky_ray_sphere(pos, sun, SKY_ATMOSPHERE)
+    t = np.zeros_like(atmo)
+    tr = [np.ones_like(atmo) for _ in range(3)]
+    for i in range(40):
+        new_t = F(F(F(f32(i) + f32(0.3)) / f32(40.0)) * atmo)
+        dt = F(new_t - t)
+        t = new_t
+        npos = [F(pos[k] + F(t * sun[k])) for k in range(3)]
+        _, _, ext = sky_scattering_values(npos)
+        tr = [F(tr[k] * _t64(np.exp, F(F(-dt) * ext[k]))) for k in range(3)]
+    tr = [np.where(blocked, f32(0), c) for c in tr]
+    return np.stack(tr + [np.ones_like(atmo)], -1).astype(np.float16)
+
+
+def sky_multiscattering_lut(tlut16):
+    tlut = tlut16.astype(f32)
+    ys, xs = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
+    pos, sun = sky_sun_dir_of_texel(xs, ys, 32, 32)
+    lum_total = [np.zeros(xs.shape, f32) for _ in range(3)]
+    fms = [np.zeros(xs.shape, f32) for _ in range(3)]
+    inv_samples = F(f32(1.0) / f32(64))
+    albedo = f32(0.3)
+    for i in range(8):
+        for j in range(8):
+            theta = F(F(SKY_PI * F(f32(i) + f32(0.5))) / f32(8))
+            phi = _t64(np.arccos, np.minimum(np.maximum(F(f32(1.0) - F(F(f32(2.0) * F(f32(j) + f32(0.5))) / f32(8))), f32(-1)), f32(1)))
+            cp, sp, ct, st = _t64(np.cos, phi), _t64(np.sin, phi), _t64(np.cos, theta), _t64(np.sin, theta)
+            ray = [np.full(xs.shape, F(sp * st)), np.full(xs.shape, cp), np.full(xs.shape, F(sp * ct))]
+            atmo = sky_ray_sphere(pos, ray, SKY_ATMOSPHERE)
+            ground = sky_ray_sphere(pos, ray, SKY_GROUND)
+            t_max = np.where(ground > 0, ground, atmo)
+            cos_t = _dot3(ray, sun)
+            mie_p, ray_p = sky_mie_phase(cos_t), sky_rayleigh_phase(F(-cos_t))
+            lum = [np.zeros(xs.shape, f32) for _ in range(3)]
+            lum_factor = [np.zeros(xs.shape, f32) for _ in range(3)]
+            tr = [np.ones(xs.shape, f32) for _ in range(3)]
+            t = np.zeros(xs.shape, f32)
+            for step in range(20):
+                new_t = F(F(F(f32(step) + f32(0.3)) / f32(20.0)) * t_max)
+                dt = F(new_t - t)
+                t = new_t
+                npos = [F(pos[k] + F(t * ray[k])) for k in range(3)]
+                rs, ms, ext = sky_scattering_values(npos)
+                st_k = [_t64(np.exp, F(F(-dt) * ext[k])) for k in range(3)]
+                sun_tr = sky_lut_value(tlut, npos, sun)
+                for k in range(3):
+                    no_phase = F(rs[k] + ms)
+                    sc_f = F(F(no_phase - F(no_phase * st_k[k])) / ext[k])
+                    lum_factor[k] = F(lum_factor[k] + F(tr[k] * sc_f))
+                    in_sc = F(F(F(rs[k] * ray_p) + F(ms * mie_p)) * sun_tr[k])
+                    integral = F(F(in_sc - F(in_sc * st_k[k])) / ext[k])
+                    lum[k] = F(lum[k] + F(integral * tr[k]))
+                    tr[k] = F(tr[k] * st_k[k])
+            hit = [F(pos[k] + F(ground * ray[k])) for k in range(3)]
+            ln = _len3(hit)
+            with np.errstate(all="ignore"):
+                inv = F(f32(1) / ln)
+                hit_n = [F(F(hit[k] * inv) * SKY_GROUND) for k in range(3)]
+                ground_tr = sky_lut_value(tlut, hit_n, sun)
+            lit = (ground > 0) & (_dot3(pos, sun) > 0)
+            for k in range(3):
+                lum[k] = np.where(lit, F(lum[k] + F(F(tr[k] * albedo) * ground_tr[k])), lum[k])
+                fms[k] = F(fms[k] + F(lum_factor[k] * inv_samples))
+                lum_total[k] = F(lum_total[k] + F(lum[k] * inv_samples))
+    psi = [F(lum_total[k] / F(f32(1.0) - fms[k])) for k in range(3)]
+    return np.stack(psi + [np.ones(xs.shape, f32)], -1).astype(np.float16)
+
+
+def sky_view_lut(tlut16, mslut16, light_dir):
+    tlut, mslut = tlut16.astype(f32), mslut16.astype(f32)
+    ys, xs = np.meshgrid(np.arange(200), np.arange(200), indexing="ij")
+    u, v = F(xs.astype(f32) / f32(200)), F(ys.astype(f32) / f32(200))
+    azimuth = F(F(F(u - f32(0.5)) * f32(2.0)) * SKY_PI)
+    c_lo, c_hi = F(f32(1.0) - F(f32(2.0) * v)), F(F(v * f32(2.0)) - f32(1.0))
+    adj_v = np.where(v < 0.5, F(F(-c_lo) * c_lo), F(c_hi * c_hi))
+    view_pos = [f32(0), F(SKY_GROUND + f32(0.0002)), f32(0)]
+    height = _len3(view_pos)
+    up = [F(p / height) for p in view_pos]
+    ratio = F(F(np.sqrt(F(F(height * height) - F(SKY_GROUND * SKY_GROUND)))) / height)
+    horizon = F(_t64(np.arccos, np.minimum(np.maximum(ratio, f32(-1)), f32(1))) - F(f32(0.5) * SKY_PI))
+    altitude = F(F(F(adj_v * f32(0.5)) * SKY_PI) - horizon)
+    cos_alt = _t64(np.cos, altitude)
+    ray = [F(cos_alt * _t64(np.sin, azimuth)), _t64(np.sin, altitude), F(F(-cos_alt) * _t64(np.cos, azimuth))]
+    ld = [f32(c) for c in light_dir]
+    sun_alt = F(F(f32(0.5) * SKY_PI) - _t64(np.arccos, _dot3([F(-c) for c in ld], up)))
+    sun = [np.zeros(xs.shape, f32), np.full(xs.shape, _t64(np.sin, sun_alt)), np.full(xs.shape, F(-_t64(np.cos, sun_alt)))]
+    vp = [np.full(xs.shape, c) for c in view_pos]
+    atmo = sky_ray_sphere(vp, ray, SKY_ATMOSPHERE)
+    ground = sky_ray_sphere(vp, ray, SKY_GROUND)
+    t_max = np.where(ground < 0, atmo, ground)
+    # raymarchScattering :17-56
+    cos_t = _dot3(ray, sun)
+    mie_p, ray_p = sky_mie_phase(cos_t), sky_rayleigh_phase(F(-cos_t))
+    lum = [np.zeros(xs.shape, f32) for _ in range(3)]
+    tr = [np.ones(xs.shape, f32) for _ in range(3)]
+    t = np.zeros(xs.shape, f32)
+    for i in range(32):
+        new_t = F(F(F(f32(i) + f32(0.3)) / f32(32.0)) * t_max)
+        dt = F(new_t - t)
+        t = new_t
+        npos = [F(vp[k] + F(t * ray[k])) for k in range(3)]
+        rs, ms, ext = sky_scattering_values(npos)
+        st_k = [_t64(np.exp, F(F(-dt) * ext[k])) for k in range(3)]
+        sun_tr = sky_lut_value(tlut, npos, sun)
+        psi = sky_lut_value(mslut, npos, sun)
+        for k in range(3):
+            ray_in = F(rs[k] * F(F(ray_p * sun_tr[k]) + psi[k]))
+            mie_in = F(ms * F(F(mie_p * sun_tr[k]) + psi[k]))
+            in_sc = F(ray_in + mie_in)
+            integral = F(F(in_sc - F(in_sc * st_k[k])) / ext[k])
+            lum[k] = F(lum[k] + F(integral * tr[k]))
+            tr[k] = F(tr[k] * st_k[k])
+    return np.stack(lum + [np.ones(xs.shape, f32)], -1).astype(np.float16)
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -1363,6 +1564,16 @@ def main():
     at = tuple(cells.T.astype(np.int64))
     np.savez_compressed(os.path.join(GOLDEN, "lpv_inject_4x32.npz"), cells=cells, **lists, **{f"vol_{i}": vols[i].view(np.uint16)[at] for i in range(3)})
     print("lpv_inject ok:", [len(lists[f"vpls_{c}"]) for c in range(4)], "lights,", len(cells), "cells lit")
+
+    # sky LUT generators (f3) for the sun direction of tests/test_sky_luts.py; every fourth row of the two larger LUTs is kept
+    light = (0.3, -0.8, 0.52)
+    with np.errstate(all="ignore"):
+        tl = sky_transmittance_lut()
+        msl = sky_multiscattering_lut(tl)
+        svl = sky_view_lut(tl, msl, light)
+    np.savez_compressed(os.path.join(GOLDEN, "sky_luts.npz"), light=np.array(light, np.float32), transmittance_rows=tl.view(np.uint16)[::4],
+                        multiscattering=msl.view(np.uint16), sky_view_rows=svl.view(np.uint16)[::4])
+    print("sky_luts ok")
 
     scene_img = synth.hdr_scene(W, Hh, seed=104).view(np.uint16)
     mips, src = [], scene_img
