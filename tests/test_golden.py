@@ -316,3 +316,34 @@ def test_hip_matches_golden_sky_luts(hip_ctx):
     hip_ctx.sky_update_luts(*[images.plane(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in (t, m, s)], tuple(float(c) for c in g["light"]))
     torch.cuda.synchronize()
     _check_sky_luts(*[a.cpu().numpy().view(np.uint16) for a in (t, m, s)])
+
+
+def _probe_copy_fixture():
+    import hashlib
+    g = np.load(os.path.join(GOLDEN, "probe_copy.npz"))
+    src, _, _ = synth.probe_maintenance_inputs(seed=int(g["seed"]), num_probes=4)
+    dst = {k: np.full_like(v, 0x55 if v.dtype == np.uint8 else 0x3555 if v.dtype == np.uint32 else 7.0) for k, v in src.items()}
+    want = {k: str(g[f"sha256_{k}"]) for k in src}
+    digest = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return src, dst, [[float(c) for c in row] for row in g["movement"]], want, digest
+
+
+def test_oracle_matches_golden_probe_copy():
+    """a11: the probe scroll (copy_cascades) against the sequential numpy restatement; the fixture holds the digest of every atlas"""
+    from tests.test_probes import _oracle_copy
+    src, dst, movement, want, digest = _probe_copy_fixture()
+    _oracle_copy(src, dst, movement)
+    for k in want:
+        assert digest(dst[k]) == want[k], f"atlas {k}"
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_probe_copy(hip_ctx):
+    import torch
+    src, dst, movement, want, digest = _probe_copy_fixture()
+    s_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in src.items()}
+    d_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in dst.items()}
+    hip_ctx.probe_copy(util.probe_atlases_desc(s_t), util.probe_atlases_desc(d_t), movement)
+    torch.cuda.synchronize()
+    for k in want:
+        assert digest(d_t[k].cpu().numpy()) == want[k], f"atlas {k}"

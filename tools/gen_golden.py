@@ -1469,6 +1469,33 @@ def sky_view_lut(tlut16, mslut16, light_dir):
     return np.stack(lum + [np.ones(xs.shape, f32)], -1).astype(np.float16)
 
 
+def probe_copy(src, dst, movement):
+    """copy_cascades.comp.slang:22-99 — one invocation per probe cell of the 32^3 grid, in ascending linear invocation index (x fastest):
+    cells whose source (cell - (int3)movement[cascade], cascade = y / 8) lies in the same cascade copy their blocks, the others are
+    initialised — with the depth clear at LIGHT-CACHE offsets (:39-45), which lands on other cells' depth blocks: the later write stays."""
+    mv = [[int(np.trunc(c)) for c in row] for row in movement]
+    for z in range(32):
+        for y in range(32):
+            cas = y // 8
+            for x in range(32):
+                sx, sy, sz = x - mv[cas][0], y - mv[cas][1], z - mv[cas][2]
+                if 0 <= sx < 32 and 8 * cas <= sy < 8 * (cas + 1) and 0 <= sz < 32:
+                    dst["rtgi"][z, y * 8:y * 8 + 8, x * 7:x * 7 + 7] = src["rtgi"][sz, sy * 8:sy * 8 + 8, sx * 7:sx * 7 + 7]
+                    dst["light_cache"][z, y * 13:y * 13 + 13, x * 13:x * 13 + 13] = src["light_cache"][sz, sy * 13:sy * 13 + 13, sx * 13:sx * 13 + 13]
+                    dst["depth"][z, y * 12:y * 12 + 12, x * 12:x * 12 + 12] = src["depth"][sz, sy * 12:sy * 12 + 12, sx * 12:sx * 12 + 12]
+                    dst["average"][z, y, x] = src["average"][sz, sy, sx]
+                    v = np.float16(f32(src["validity"][sz, sy, sx]) / f32(255))            # Texture2DArray<half> load of an R8_UNORM texel
+                    dst["validity"][z, y, x] = _unorm8(f32(v))                             # and the store back
+                else:
+                    dst["rtgi"][z, y * 8:y * 8 + 8, x * 7:x * 7 + 7] = 0
+                    dst["light_cache"][z, y * 13:y * 13 + 13, x * 13:x * 13 + 13] = 0
+                    blk = dst["depth"][z, y * 13:y * 13 + 12, x * 13:x * 13 + 12]          # clipped at the atlas edge: stores outside are dropped
+                    blk[...] = 0
+                    dst["average"][z, y, x] = 0
+                    dst["validity"][z, y, x] = 255
+    return dst
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -1565,6 +1592,14 @@ def main():
     np.savez_compressed(os.path.join(GOLDEN, "lpv_inject_4x32.npz"), cells=cells, **lists, **{f"vol_{i}": vols[i].view(np.uint16)[at] for i in range(3)})
     print("lpv_inject ok:", [len(lists[f"vpls_{c}"]) for c in range(4)], "lights,", len(cells), "cells lit")
 
+    # probe scroll (a11, copy_cascades): mixed movements, the last cascade at rest; the fixture is the digest of every atlas
+    src_atl, _, _ = synth.probe_maintenance_inputs(seed=112, num_probes=4)
+    dst_atl = {k: np.full_like(v, 0x55 if v.dtype == np.uint8 else 0x3555 if v.dtype == np.uint32 else 7.0) for k, v in src_atl.items()}
+    movement = [[1.0, 0.0, -2.0], [0.0, 1.7, 0.0], [-3.2, -1.0, 2.9], [0.0, 0.0, 0.0]]
+    probe_copy(src_atl, dst_atl, movement)
+    np.savez_compressed(os.path.join(GOLDEN, "probe_copy.npz"), seed=112, movement=np.array(movement, np.float32),
+                        **{f"sha256_{k}": hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in dst_atl.items()})
+    print("probe_copy ok")
     # sky LUT generators (f3) for the sun direction of tests/test_sky_luts.py; every fourth row of the two larger LUTs is kept
     light = (0.3, -0.8, 0.52)
     with np.errstate(all="ignore"):
