@@ -309,7 +309,8 @@ int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint
         v[c] = varg(rgb[c]);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = ensure(ctx, S_VPL_CELLS, ((size_t)capacity + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
+    // cell index per light, then (16-byte aligned) the 12 blend sources of up to 4096 sorted lights (vpl.hip: k_inject_sorted)
+    if (int rc = ensure(ctx, S_VPL_CELLS, ((size_t)capacity + 8) * sizeof(uint32_t) + (size_t)4096 * 12 * sizeof(float)); rc != SAH_OK) return rc;
     HIP_TRY(ctx, sah::launch_inject_vpls(vpl_list, vpl_count, capacity, cascades[cascade_index], cascade_index, num_cascades, v,
                                          (uint32_t*)ctx->raster.ptr[S_VPL_CELLS], ctx->stream));
     return SAH_OK;

@@ -152,6 +152,7 @@ struct InjectArgs {
     float cascade_f, num_cascades_f;
     VolumeArg rgb[3];
     uint32_t* cells;  // scratch: cell index per light, ~0 when the light is dropped
+    float* terms;     // scratch: 12 blend sources per light in sorted order (k_inject_sorted), 16-byte aligned
 };
 
 struct Injected {
@@ -245,49 +246,102 @@ __global__ __launch_bounds__(256) void k_inject_accumulate(const InjectArgs a) {
 // in LDS with a bitonic network — equal cells become contiguous runs in list order — and the thread at the head of each run adds
 // the run to its cell.  Same arithmetic and order as the two-launch form above, without its quadratic scans.
 constexpr uint32_t kSortCapacity = 4096;
+// Bitonic network over 4096 keys held four per thread (key r of thread t is element r * 1024 + t), so that only the exchanges between
+// waves go through LDS: partners 1024 or 2048 apart are two registers of one thread, partners less than 64 apart are two lanes of one
+// wave (a shuffle), and the distances in between (64 .. 512: 18 of the 78 stages) take one LDS round trip each, ping-ponging two
+// buffers.  As plain LDS compare-exchanges with a barrier per stage the sort was 120 of the kernel's 165 us.
+SAH_DEV unsigned long long exch(unsigned long long x, unsigned long long y, bool keep_min) { return ((x < y) == keep_min) ? x : y; }
 __global__ __launch_bounds__(1024) void k_inject_sorted(const InjectArgs a) {
-    __shared__ unsigned long long s_key[kSortCapacity];
+    __shared__ unsigned long long s_buf[2][kSortCapacity];
     const uint32_t count = min(min(*a.count, a.capacity), kSortCapacity);
-    for (uint32_t i = threadIdx.x; i < kSortCapacity; i += 1024) {
+    const uint32_t t = threadIdx.x;
+    unsigned long long key[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) {
+        const uint32_t i = r * 1024u + t;
         uint32_t cell = ~0u;
         if (i < count) {
             Injected tmp;
             cell = inject_one(a, a.list[i], tmp);
         }
-        s_key[i] = ((unsigned long long)cell << 32) | i;
+        key[r] = ((unsigned long long)cell << 32) | i;
     }
-    __syncthreads();
-    for (uint32_t k = 2; k <= kSortCapacity; k <<= 1)
+    uint32_t flip = 0;
+    for (uint32_t k = 2; k <= kSortCapacity; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < kSortCapacity; i += 1024) {
-                const uint32_t partner = i ^ j;
-                if (partner > i) {
-                    const unsigned long long x = s_key[i], y = s_key[partner];
-                    const bool ascending = (i & k) == 0;
-                    if ((x > y) == ascending) { s_key[i] = y; s_key[partner] = x; }
+            if (j >= 1024u) {  // rows of one thread: (0,1)(2,3) for j = 1024, (0,2)(1,3) for j = 2048
+                const uint32_t d = j >> 10;
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) {
+                    if (r & d) continue;
+                    const bool ascending = (((r * 1024u + t) & k) == 0u);
+                    const unsigned long long x = key[r], y = key[r | d];
+                    key[r] = exch(x, y, ascending);
+                    key[r | d] = exch(y, x, !ascending);  // the other one (keys are distinct: the index is part of them)
+                }
+            } else if (j < 64u) {  // lanes of one wave
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) {
+                    const uint32_t i = r * 1024u + t;
+                    const unsigned long long y = __shfl_xor(key[r], (int)j, 64);
+                    const bool ascending = (i & k) == 0u, lower = (i & j) == 0u;
+                    key[r] = exch(key[r], y, lower == ascending);
+                }
+            } else {  // other waves: one LDS round trip
+                unsigned long long* buf = s_buf[flip];
+                flip ^= 1u;
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) buf[r * 1024u + t] = key[r];
+                __syncthreads();
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) {
+                    const uint32_t i = r * 1024u + t;
+                    const unsigned long long y = buf[i ^ j];
+                    const bool ascending = (i & k) == 0u, lower = (i & j) == 0u;
+                    key[r] = exch(key[r], y, lower == ascending);
                 }
             }
-            __syncthreads();
         }
+    }
+    unsigned long long* s_key = s_buf[flip];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) s_key[r * 1024u + t] = key[r];
+    __syncthreads();
+    // The twelve blend sources of every light (sh[k] * corrected[ch] / pi), evaluated in parallel and stored in SORTED order: the serial
+    // part left to the thread at the head of a run is then one 48-byte record and twelve add-and-round per light, read in sequence.
+    // (With the fragment stage re-evaluated inside the run loop the accumulation was 97 of the kernel's 130 us.)
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) {
+        const uint32_t i = r * 1024u + t;
+        if (i < count && (uint32_t)(s_key[i] >> 32) != ~0u) {
+            Injected v;
+            inject_one(a, a.list[(uint32_t)s_key[i]], v);
+            float* rec = a.terms + (size_t)i * 12u;
+            for (int ch = 0; ch < 3; ch++)
+                for (int k = 0; k < 4; k++) rec[ch * 4 + k] = v.sh[k] * v.corrected[ch] / 3.1415927f;
+        }
+    }
+    __syncthreads();
     const uint32_t W = a.rgb[0].width, H = a.rgb[0].height;
     for (uint32_t i = threadIdx.x; i < count; i += 1024) {
         const uint32_t cell = (uint32_t)(s_key[i] >> 32);
         if (cell == ~0u || (i > 0 && (uint32_t)(s_key[i - 1] >> 32) == cell)) continue;  // dropped light, or not the head of its run
         const uint32_t cx = cell % W, cy = (cell / W) % H, cz = cell / (W * H);
-        float acc[3][4];
+        float acc[12];
         uint16_t* dst[3];
         for (int ch = 0; ch < 3; ch++) {
             dst[ch] = (uint16_t*)(a.rgb[ch].ptr + (size_t)cz * a.rgb[ch].slice_pitch + (size_t)cy * a.rgb[ch].row_pitch + (size_t)cx * 8);
-            for (int k = 0; k < 4; k++) acc[ch][k] = h2f(dst[ch][k]);
+            for (int k = 0; k < 4; k++) acc[ch * 4 + k] = h2f(dst[ch][k]);
         }
         for (uint32_t j = i; j < count && (uint32_t)(s_key[j] >> 32) == cell; j++) {
-            Injected v;
-            inject_one(a, a.list[(uint32_t)s_key[j]], v);
-            for (int ch = 0; ch < 3; ch++)
-                for (int k = 0; k < 4; k++) acc[ch][k] = rh(acc[ch][k] + v.sh[k] * v.corrected[ch] / 3.1415927f);  // blend ONE / ONE, one rounding to half
+            const float4* rec = reinterpret_cast<const float4*>(a.terms + (size_t)j * 12u);
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            const float src[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+            for (int c = 0; c < 12; c++) acc[c] = rh(acc[c] + src[c]);  // blend ONE / ONE, one rounding to half
         }
         for (int ch = 0; ch < 3; ch++)
-            for (int k = 0; k < 4; k++) dst[ch][k] = f2h(acc[ch][k]);
+            for (int k = 0; k < 4; k++) dst[ch][k] = f2h(acc[ch * 4 + k]);
     }
 }
 
@@ -322,6 +376,7 @@ hipError_t launch_inject_vpls(const sah_packed_vpl* list, const uint32_t* count,
     a.num_cascades_f = (float)num_cascades;
     for (int i = 0; i < 3; i++) a.rgb[i] = rgb[i];
     a.cells = cells_scratch;
+    a.terms = reinterpret_cast<float*>(cells_scratch + (((size_t)capacity + 1 + 3) & ~(size_t)3));  // 16-byte aligned, kSortCapacity * 12 floats
     if (capacity == 0) return hipSuccess;
     if (capacity <= kSortCapacity) {
         hipLaunchKernelGGL(k_inject_sorted, dim3(1), dim3(1024), 0, st, a);
