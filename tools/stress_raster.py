@@ -20,6 +20,7 @@ from tests import util  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--textured", action="store_true", help="random textures, samplers and texcoords on every material slot (clipped triangles included)")
     args = ap.parse_args()
     import torch
     ctx = lib.Context(0)
@@ -31,13 +32,15 @@ def main():
         w, h = [(320, 180), (257, 131), (64, 64), (511, 77), (96, 200)][case % 5]
         extent = float(g.choice([1.5, 6.0, 40.0]))
         size = (0.01, float(g.choice([0.5, 5.0, 60.0])))
-        arrays = mesh.random_soup(100 + case, triangles=int(g.choice([200, 800, 3000])), extent=extent, size=size).arrays()
+        arrays = mesh.random_soup(100 + case, triangles=int(g.choice([200, 800, 3000])), extent=extent, size=size, textured=args.textured).arrays()
         view = scene.SceneView()
         view.rotate(float(g.uniform(-1.2, 1.2)), float(g.uniform(0, 2 * math.pi)))
         view.set_position(g.uniform(-extent, extent, 3))
         view.set_render_resolution(w, h)
         view.set_perspective_projection(float(g.choice([40.0, 75.0, 110.0])), w / h, float(g.choice([0.05, 0.5])))
         view.update_transforms()
+        if args.textured:
+            view.gpu_data.material_texture_mip_bias = float(g.choice([0.0, -1.0, 0.75]))
         sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)
         sun.set_direction(g.normal(size=3))
         res = int(g.choice([64, 200, 512]))
