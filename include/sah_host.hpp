@@ -132,6 +132,60 @@ private:
     ResourceAllocator allocator;
 };
 
+// RenderCore/render/backend/texture_descriptor_pool.hpp:15-33 — the bindless texture set the material shaders index
+// (`textures[material.base_color_texture_index]`, gltf_basic_pbr.slang:80,177-226).  A slot is a mipped R8G8B8A8 image and the sampler
+// it is bound with; the pool keeps the table the rasteriser reads (sah_scene_geometry::textures) in device memory.  The reference passes a
+// VkImage with its mip chain and a VkSampler object; here: the levels as textures of the allocator (mip 0 first) and the VkSamplerCreateInfo
+// fields the sampling rules of sah_hip.h use.
+class TextureDescriptorPool {
+public:
+    explicit TextureDescriptorPool(RenderBackend& backend_in) : backend(backend_in) {}
+    ~TextureDescriptorPool() {
+        if (device_table) (void)hipFree(device_table);
+    }
+    TextureDescriptorPool(const TextureDescriptorPool&) = delete;
+    uint32_t create_texture_srv(const std::vector<TextureHandle>& levels, const sah_sampler& sampler) {
+        if (levels.empty() || levels.size() > SAH_MAX_TEXTURE_MIPS) throw std::runtime_error("create_texture_srv: 1.." + std::to_string(SAH_MAX_TEXTURE_MIPS) + " levels");
+        sah_texture t{};
+        for (size_t i = 0; i < levels.size(); i++) t.mips[i] = levels[i]->plane();
+        t.num_mips = (uint32_t)levels.size();
+        t.sampler = sampler;
+        uint32_t handle;
+        if (!available_handles.empty()) {
+            handle = available_handles.back();
+            available_handles.pop_back();
+            table[handle] = t;
+        } else {
+            handle = (uint32_t)table.size();
+            table.push_back(t);
+        }
+        dirty = true;
+        return handle;
+    }
+    void free_descriptor(uint32_t handle) { available_handles.push_back(handle); }
+    // "Commits pending descriptor writes.  Should be called at start of frame": uploads the table if it changed
+    void commit_descriptors() {
+        if (!dirty) return;
+        if (device_table) (void)hipFree(device_table);
+        device_table = nullptr;
+        if (!table.empty()) {
+            if (hipMalloc((void**)&device_table, table.size() * sizeof(sah_texture)) != hipSuccess ||
+                hipMemcpy(device_table, table.data(), table.size() * sizeof(sah_texture), hipMemcpyHostToDevice) != hipSuccess)
+                throw std::runtime_error("texture descriptor table upload failed");
+        }
+        dirty = false;
+    }
+    const sah_texture* get_descriptor_set() const { return device_table; }
+    uint32_t size() const { return (uint32_t)table.size(); }
+
+private:
+    RenderBackend& backend;
+    std::vector<sah_texture> table;
+    std::vector<uint32_t> available_handles;
+    sah_texture* device_table = nullptr;
+    bool dirty = false;
+};
+
 // RenderCore/render/backend/command_buffer.hpp:48-275, reduced to what the hot path records.  In the reference the sub-passes of
 // the "Lighting" render pass are draws that blend into lit_scene one after the other; here they are fused into ONE sah_lighting
 // call, so each of them records its part of the sah_lighting_desc into the command buffer (what it would have bound) and the

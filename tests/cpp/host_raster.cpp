@@ -6,6 +6,8 @@
 //   host_raster <in.bin> <out.bin>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "sah_host.hpp"
@@ -26,8 +28,8 @@ int main(int argc, char** argv) {
     if (argc != 3) { fprintf(stderr, "usage: host_raster in.bin out.bin\n"); return 2; }
     FILE* in = fopen(argv[1], "rb");
     if (!in) { perror("open input"); return 2; }
-    uint32_t hdr[7];  // W, H, shadow resolution, vertices, indices, primitives, materials
-    if (fread(hdr, 4, 7, in) != 7) return 2;
+    uint32_t hdr[8];  // W, H, shadow resolution, vertices, indices, primitives, materials, textures
+    if (fread(hdr, 4, 8, in) != 8) return 2;
     const uint32_t W = hdr[0], H = hdr[1], R = hdr[2];
 
     using namespace sah;
@@ -44,6 +46,32 @@ int main(int argc, char** argv) {
     scene.geometry.indices = (const uint32_t*)to_device(read_blob(in, (size_t)hdr[4] * 4));
     scene.geometry.primitives = (const sah_primitive*)to_device(read_blob(in, (size_t)hdr[5] * sizeof(sah_primitive)));
     scene.geometry.materials = (const sah_material*)to_device(read_blob(in, (size_t)hdr[6] * sizeof(sah_material)));
+    // bindless textures (texture_descriptor_pool.hpp): per texture {format, levels, sampler (8 words)}, then per level {w, h} + texels;
+    // then one sah_material_textures per material
+    TextureDescriptorPool texture_pool(backend);
+    for (uint32_t t = 0; t < hdr[7]; t++) {
+        uint32_t th[10];
+        if (fread(th, 4, 10, in) != 10) return 2;
+        sah_sampler smp;
+        static_assert(sizeof(smp) == 32, "sampler words");
+        memcpy(&smp, th + 2, 32);
+        std::vector<TextureHandle> levels;
+        for (uint32_t l = 0; l < th[1]; l++) {
+            uint32_t wh[2];
+            if (fread(wh, 4, 2, in) != 2) return 2;
+            TextureHandle level = alloc.create_texture("material texture " + std::to_string(t) + " mip " + std::to_string(l), th[0], wh[0], wh[1]);
+            const auto texels = read_blob(in, (size_t)wh[0] * wh[1] * 4);
+            alloc.upload(level, texels.data(), wh[0] * 4);
+            levels.push_back(level);
+        }
+        if (texture_pool.create_texture_srv(levels, smp) != t) return 4;
+    }
+    if (hdr[7]) {
+        texture_pool.commit_descriptors();  // "should be called at start of frame"
+        scene.geometry.textures = texture_pool.get_descriptor_set();
+        scene.geometry.num_textures = texture_pool.size();
+        scene.geometry.material_textures = (const sah_material_textures*)to_device(read_blob(in, (size_t)hdr[6] * sizeof(sah_material_textures)));
+    }
     fclose(in);
 
     SceneView view;  // start-up camera of the reference: scene_renderer.cpp:53-54,105-116

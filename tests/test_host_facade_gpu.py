@@ -116,13 +116,27 @@ def test_producer_passes_through_cpp_facade(tmp_path):
     from androidrenderer_amd import mesh
     _build_raster()
     W, H, R = 160, 90, 256
-    arrays = mesh.atrium(2).arrays()
+    m = mesh.atrium(2)
+    # material textures through the facade's TextureDescriptorPool: base colour / normal / data on every material, emission on the lamps
+    from androidrenderer_amd import synth
+    g = synth.rng(78)
+    tex = [m.add_texture(*mesh.random_texture(g, 64, 64, None, srgb, mesh.sampler())) for srgb in (True, False, False, True)]
+    m.material_textures = [(tex[0], tex[1], tex[2], tex[3] if i == 5 else _abi.TEXTURE_NONE) for i in range(len(m.materials))]
+    arrays = m.arrays()
     counts = mesh.with_counts(arrays)["counts"]
     inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(inp, "wb") as f:
-        f.write(np.array([W, H, R, counts["vertices"], counts["indices"], counts["primitives"], counts["materials"]], dtype=np.uint32).tobytes())
+        f.write(np.array([W, H, R, counts["vertices"], counts["indices"], counts["primitives"], counts["materials"], len(arrays["textures"])],
+                         dtype=np.uint32).tobytes())
         for k in ("positions", "vertex_data", "indices", "primitives", "materials"):
             f.write(np.ascontiguousarray(arrays[k]).tobytes())
+        for (mips, fmt, smp) in arrays["textures"]:
+            f.write(np.array([fmt, len(mips)], np.uint32).tobytes())
+            f.write(bytes(smp))
+            for level in mips:
+                f.write(np.array([level.shape[1], level.shape[0]], np.uint32).tobytes())
+                f.write(np.ascontiguousarray(level).tobytes())
+        f.write(np.ascontiguousarray(arrays["material_textures"], dtype=np.uint32).tobytes())
     subprocess.check_call([RASTER_EXE, str(inp), str(outp)])
     blob = open(outp, "rb").read()
     off = 0
