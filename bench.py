@@ -301,6 +301,37 @@ def main():
                     pending[k] = None
         my_px = W * (r1 - r0) if world > 1 else W * H
 
+    # N > 1: the same workload unsharded on this rank's GPU, timed before the sharded loop — strong scaling of ONE workload can then be
+    # read off this line alone (the driver's N = 1 run measures the headline lighting pass, not necessarily this workload)
+    single_gpu = None
+    if world > 1 or (args.force_gather and chain):
+        if chain:
+            ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1)
+            ref_step = lambda: ref.step(gather=False)
+        else:
+            ref_lit = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+            saved_rows = (fr.row_begin, fr.row_end)
+            fr.row_begin = fr.row_end = 0
+            ref_desc, ref_keep = fr.describe(d_arr, ref_lit)
+            fr.row_begin, fr.row_end = saved_rows
+            ref_step = lambda: ctx.lighting(ref_desc)
+        for _ in range(5):
+            ref_step()
+        torch.cuda.synchronize()
+        r_e0, r_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r_e0.record()
+        for _ in range(30):
+            ref_step()
+        r_e1.record()
+        torch.cuda.synchronize()
+        ref_ms = r_e0.elapsed_time(r_e1) / 30
+        single_gpu = {"ms_per_step": round(ref_ms, 5), "value": round(W * H / (ref_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                      "note": "the same workload unsharded on rank 0's GPU, 30 steps, GPU time between two events"}
+        del ref_step
+        if chain:
+            del ref
+        torch.cuda.empty_cache()
+
     for i in range(args.warmup):
         step(i)
     drain()
@@ -365,6 +396,7 @@ def main():
                 "gather": bool(gather),
                 "gather_through": ("sah_allgather_rows (library, RCCL)" if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
                 "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
+                "same_workload_on_one_gpu": single_gpu,
             },
             "roofline": {
                 "bound": "hbm",
