@@ -90,8 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: 4k_deferred_gi on one GPU (the headline pass); 4k_lpv_gi_chain at N > 1 (the same lighting + post chain, "
-                         "row-sharded, final RGBA8 image gathered)")
+                    help="default: 4k_deferred_gi on one GPU (the headline pass); 4k_probe_gi_chain at N > 1 (BASELINE.json configs[3]: probe-GI "
+                         "lighting + post chain, row-sharded, final RGBA8 image gathered)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
@@ -131,7 +131,7 @@ def main():
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29511", rank=0, world_size=1, device_id=dev)
 
     if args.workload is None:
-        args.workload = "4k_lpv_gi_chain" if world > 1 else "4k_deferred_gi"
+        args.workload = "4k_probe_gi_chain" if world > 1 else "4k_deferred_gi"
     wl = WORKLOADS[args.workload]
     W, H = wl["res"]
     sun_mode = {"off": _abi.SHADOW_MODE_OFF, "csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}[wl["sun"]]
