@@ -215,6 +215,7 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->comm_ready) (void)hipEventDestroy(ctx->comm_ready);
     if (ctx->comm_done) (void)hipEventDestroy(ctx->comm_done);
     if (ctx->luts) (void)hipFree(ctx->luts);
+    if (ctx->probe_slots) (void)hipFree(ctx->probe_slots);
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);
     if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);

@@ -22,7 +22,8 @@ hipError_t launch_lpv_build_tables(hipStream_t st);
 hipError_t launch_sky_luts(const PlaneArg& transmittance, const PlaneArg& multiscattering, const PlaneArg& sky_view, const float light_vector[3], hipStream_t st);
 hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st);
 hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
-hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, hipStream_t st);
+hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, uint32_t* slots,
+                               hipStream_t st);
 }  // namespace sah
 
 namespace {
@@ -286,7 +287,11 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
         (trace_results->row_pitch_bytes % 8) || (trace_results->slice_pitch_bytes % 8))
         return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "trace_results must be R16G16B16A16_SFLOAT 20 x 20 x >= num_probes, 8-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sah::launch_probe_update(a, varg(*trace_results), probes_to_update, num_probes, ctx->stream));
+    if (!ctx->probe_slots) {  // probe cell -> position in the update list (probes.hip: ordered_stores); all zero between calls
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->probe_slots, 32 * 32 * 32 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->probe_slots, 0, 32 * 32 * 32 * sizeof(uint32_t), ctx->stream));
+    }
+    HIP_TRY(ctx, sah::launch_probe_update(a, varg(*trace_results), probes_to_update, num_probes, ctx->probe_slots, ctx->stream));
     return SAH_OK;
 }
 

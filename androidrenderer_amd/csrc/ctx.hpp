@@ -15,6 +15,7 @@ struct sah_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     float* luts = nullptr;  // device: 256 sRGB->linear + 256 UNORM8->float
+    uint32_t* probe_slots = nullptr;  // device, 32^3 words (sah_probe_update)
     bool lpv_tables_built = false;  // lpv.hip: c_prop_tables of this device filled (first sah_lpv_propagate)
     void* comm = nullptr;   // ncclComm_t
     void* comm_reversed = nullptr;  // ncclComm_t with rank world - 1 - rank (sah_allgather_rows_reversed), made on first use

@@ -136,6 +136,7 @@ struct UpdateArgs {
     VolumeArg trace;          // RGBA16F 20 x 20 x P
     const uint32_t* probes;   // P x uint3
     uint32_t num_probes;
+    const uint32_t* slots;    // 32^3: list position + 1 of the listed probes (ordered_stores)
 };
 SAH_DEV void load_trace(const VolumeArg& t, int x, int y, int p, Hn (&o)[4]) {
     uint2 q = make_uint2(0u, 0u);  // out-of-range loads return 0
@@ -203,24 +204,62 @@ SAH_DEV int border_targets(int rx, int ry, int tx, int ty, int (&ox)[4], int (&o
     }
     return n;
 }
-// One thread replays the stores of the whole workgroup in ascending invocation order (ty * RX + tx), program order inside.
-template <int RX, int RY> SAH_DEV void replay_stores(const VolumeArg& dst, const uint32_t* id, const uint32_t* values) {
-    const int bx = (int)id[0] * (RX + 2), by = (int)id[1] * (RY + 2), bz = (int)id[2];
-    for (int t = 0; t < RX * RY; t++) {
-        int ox[4], oy[4];
-        const int n = border_targets(RX, RY, t % RX, t / RX, ox, oy);
-        for (int k = 0; k < n; k++) {
-            const int x = ox[k] + bx, y = oy[k] + by;
-            if (in_vol(dst, x, y, bz)) *reinterpret_cast<uint32_t*>(vol_ptr(dst, x, y, bz, 4)) = values[t];
-        }
+// The stores of a dispatch take effect in ascending linear invocation index — workgroup (list position of the probe) first, then
+// ty * RX + tx, program order inside an invocation — so the LAST store to a cell is the one that stays.
+//   inside a workgroup: every invocation announces its (up to four) stores with an LDS atomicMax of the order key invocation * 4 + k
+//     on the cell and, after a barrier, performs only the ones whose key came out on top (one thread used to replay all ~300 stores in
+//     order: 20 us per dispatch);
+//   between workgroups: the cells of a probe's (R + 2)-wide block reach from -2 to R for the odd sizes (5, 11), so the block of a
+//     neighbouring probe writes some of the same cells.  `slots` maps a probe cell to its position in the list + 1 (0: not listed;
+//     filled by k_probe_slots before the updates, cleared by it after them); a store is dropped when a neighbour that is listed LATER
+//     writes the same cell — it does if its own pattern, which is this workgroup's pattern shifted by one block, covers the cell.
+// Same image as replaying every store of the dispatch in order.
+constexpr int kProbeGrid = 32;  // probe cells per axis (validity atlas extent)
+template <int RX, int RY>
+SAH_DEV void ordered_stores(const VolumeArg& dst, const uint32_t* id, uint32_t list_pos, const uint32_t* slots, bool active, uint32_t value,
+                            uint32_t* s_owner) {
+    constexpr int kW = RX + 3, kH = RY + 3, kCells = kW * kH;  // relative cells -2 .. R
+    for (int c = threadIdx.x; c < kCells; c += blockDim.x) s_owner[c] = 0u;
+    __syncthreads();
+    int ox[4], oy[4], n = 0;
+    const int t = (int)threadIdx.x;
+    if (active) {
+        n = border_targets(RX, RY, t % RX, t / RX, ox, oy);
+        for (int k = 0; k < n; k++) atomicMax(&s_owner[(oy[k] + 2) * kW + (ox[k] + 2)], (uint32_t)(t * 4 + k) + 1u);
     }
+    __syncthreads();
+    const int px = (int)id[0], py = (int)id[1], bz = (int)id[2];
+    const int bx = px * (RX + 2), by = py * (RY + 2);
+    for (int k = 0; k < n; k++) {
+        if (s_owner[(oy[k] + 2) * kW + (ox[k] + 2)] != (uint32_t)(t * 4 + k) + 1u) continue;  // a later invocation of this probe stores there
+        const int x = ox[k] + bx, y = oy[k] + by;
+        bool beaten = false;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int qx = px + dx, qy = py + dy;
+                if ((dx == 0 && dy == 0) || qx < 0 || qy < 0 || qx >= kProbeGrid || qy >= kProbeGrid || bz < 0 || bz >= kProbeGrid) continue;
+                const int rx = x - qx * (RX + 2), ry = y - qy * (RY + 2);  // the cell as the neighbour's block sees it
+                if (rx < -2 || rx > RX || ry < -2 || ry > RY || s_owner[(ry + 2) * kW + (rx + 2)] == 0u) continue;  // the neighbour never writes it
+                const uint32_t slot = slots[(bz * kProbeGrid + qy) * kProbeGrid + qx];
+                beaten = beaten || (slot != 0u && slot - 1u > list_pos);
+            }
+        if (!beaten && in_vol(dst, x, y, bz)) *reinterpret_cast<uint32_t*>(vol_ptr(dst, x, y, bz, 4)) = value;
+    }
+}
+// list position + 1 of every probe of the list into `slots` (set), or 0 again (clear)
+__global__ void __launch_bounds__(256) k_probe_slots(const uint32_t* probes, uint32_t num_probes, uint32_t* slots, uint32_t set) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= num_probes) return;
+    const uint32_t x = probes[3u * i], y = probes[3u * i + 1u], z = probes[3u * i + 2u];
+    if (x < (uint32_t)kProbeGrid && y < (uint32_t)kProbeGrid && z < (uint32_t)kProbeGrid) slots[(z * kProbeGrid + y) * kProbeGrid + x] = set ? i + 1u : 0u;
 }
 
 // probe_depth_update.comp.slang:11-49 — one workgroup per probe, 10 x 10 texels
 __global__ void __launch_bounds__(128) k_probe_depth_update(UpdateArgs a) {
-    __shared__ uint32_t s_val[100];
+    __shared__ uint32_t s_owner[13 * 13];
     const uint32_t p = blockIdx.x;
     const uint32_t* id = a.probes + 3u * p;
+    uint32_t value = 0u;
     if (threadIdx.x < 100) {
         const int tx = threadIdx.x % 10, ty = threadIdx.x / 10;
         Hn depth = Hn::lit(0.f), n = Hn::lit(0.f);
@@ -235,17 +274,17 @@ __global__ void __launch_bounds__(128) k_probe_depth_update(UpdateArgs a) {
         }
         depth = tof(n) > 0.f ? depth / n : Hn::lit(0.f);
         const Hn d2 = depth * depth;
-        s_val[threadIdx.x] = (uint32_t)__builtin_bit_cast(uint16_t, depth.v) | ((uint32_t)__builtin_bit_cast(uint16_t, d2.v) << 16);
+        value = (uint32_t)__builtin_bit_cast(uint16_t, depth.v) | ((uint32_t)__builtin_bit_cast(uint16_t, d2.v) << 16);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) replay_stores<10, 10>(a.atl.depth, id, s_val);
+    ordered_stores<10, 10>(a.atl.depth, id, p, a.slots, threadIdx.x < 100, value, s_owner);
 }
 
 // probe_light_cache_update.comp.slang:13-53 — 11 x 11 texels, 2 x 2 trace texels each (filter = ceil(20 / 11))
 __global__ void __launch_bounds__(128) k_probe_light_cache_update(UpdateArgs a) {
-    __shared__ uint32_t s_val[121];
+    __shared__ uint32_t s_owner[14 * 14];
     const uint32_t p = blockIdx.x;
     const uint32_t* id = a.probes + 3u * p;
+    uint32_t value = 0u;
     if (threadIdx.x < 121) {
         const uint32_t tx = threadIdx.x % 11, ty = threadIdx.x / 11;
         const H3 direction = to_h(octahedral_direction(normalized_octahedral_coordinates(tx, ty, 11, 11)));
@@ -266,17 +305,17 @@ __global__ void __launch_bounds__(128) k_probe_light_cache_update(UpdateArgs a) 
         }
         if (tof(n) > 0.f) light = light / n;
         else light = {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
-        s_val[threadIdx.x] = encode_r11g11b10(light.x, light.y, light.z);
+        value = encode_r11g11b10(light.x, light.y, light.z);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) replay_stores<11, 11>(a.atl.light_cache, id, s_val);
+    ordered_stores<11, 11>(a.atl.light_cache, id, p, a.slots, threadIdx.x < 121, value, s_owner);
 }
 
 // probe_rtgi_update.comp.slang:13-53 — 5 x 6 texels, 4 x 4 trace texels each (filter = 20 / 5)
 __global__ void __launch_bounds__(64) k_probe_rtgi_update(UpdateArgs a) {
-    __shared__ uint32_t s_val[30];
+    __shared__ uint32_t s_owner[8 * 9];
     const uint32_t p = blockIdx.x;
     const uint32_t* id = a.probes + 3u * p;
+    uint32_t value = 0u;
     if (threadIdx.x < 30) {
         const uint32_t tx = threadIdx.x % 5, ty = threadIdx.x / 5;
         H3 light = {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
@@ -291,10 +330,9 @@ __global__ void __launch_bounds__(64) k_probe_rtgi_update(UpdateArgs a) {
         }
         if (tof(n) > 0.f) light = light / n;
         else light = {Hn::lit(0.f), Hn::lit(0.f), Hn::lit(0.f)};
-        s_val[threadIdx.x] = encode_r11g11b10(light.x, light.y, light.z);
+        value = encode_r11g11b10(light.x, light.y, light.z);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) replay_stores<5, 6>(a.atl.rtgi, id, s_val);
+    ordered_stores<5, 6>(a.atl.rtgi, id, p, a.slots, threadIdx.x < 30, value, s_owner);
 }
 
 // probe_finalize.comp.slang:13-74 — validity from depth texels 0 and 64 (every lane tests the same two), average of 30 rtgi texels
@@ -346,17 +384,21 @@ hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& ds
     return hipGetLastError();
 }
 
-hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, hipStream_t st) {
+hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, uint32_t* slots,
+                               hipStream_t st) {
     if (num_probes == 0) return hipSuccess;
     UpdateArgs a;
     a.atl = atl;
     a.trace = trace;
     a.probes = probes;
     a.num_probes = num_probes;
+    a.slots = slots;
+    hipLaunchKernelGGL(k_probe_slots, dim3((num_probes + 255) / 256), dim3(256), 0, st, probes, num_probes, slots, 1u);
     hipLaunchKernelGGL(k_probe_depth_update, dim3(num_probes), dim3(128), 0, st, a);
     hipLaunchKernelGGL(k_probe_light_cache_update, dim3(num_probes), dim3(128), 0, st, a);
     hipLaunchKernelGGL(k_probe_rtgi_update, dim3(num_probes), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_probe_finalize, dim3(num_probes), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_probe_slots, dim3((num_probes + 255) / 256), dim3(256), 0, st, probes, num_probes, slots, 0u);  // all zero again
     return hipGetLastError();
 }
 

@@ -148,3 +148,27 @@ def test_hip_probe_update_matches_oracle(hip_ctx, num_probes):
         assert np.array_equal(got.view(ref.dtype).reshape(ref.shape), ref), f"atlas {k} differs"
     # something was written
     assert not np.array_equal(want["depth"].view(np.uint16), atl["depth"].view(np.uint16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [(0, 1, 2, 3, 4, 5, 6, 7), (7, 6, 5, 4, 3, 2, 1, 0), (3, 0, 6, 1, 7, 4, 2, 5)])
+def test_hip_probe_update_with_adjacent_probes_in_one_list(hip_ctx, order):
+    """Probes that touch: the blocks of odd size (rtgi 5 x 6, light cache 11 x 11) store into cells their neighbours store into as well,
+    so the result depends on the position of the probes in the list — later stores stay (include/sah_hip.h).  A 2 x 2 x 1 clump plus a
+    row of three, in three list orders, against the oracle's sequential replay."""
+    import torch
+    atl, trace, _ = synth.probe_maintenance_inputs(seed=29, num_probes=8)
+    clump = np.array([(5, 5, 3), (6, 5, 3), (5, 6, 3), (6, 6, 3), (20, 9, 30), (21, 9, 30), (22, 9, 30), (0, 0, 0)], dtype=np.uint32)
+    ids = np.ascontiguousarray(clump[list(order)])
+    want = _copy_arrays(atl)
+    _oracle_update(want, trace, ids)
+    a_t = {k: util.to_torch(v.view(np.uint16) if v.dtype == np.float16 else v) for k, v in atl.items()}
+    tr_t = util.to_torch(trace.view(np.uint16))
+    ids_t = torch.from_numpy(ids.view(np.int32)).cuda()
+    for _ in range(2):  # twice: the slot table must be clean again after a call
+        hip_ctx.probe_update(util.probe_atlases_desc(a_t), images.volume(tr_t, _abi.FORMAT_R16G16B16A16_SFLOAT), ids_t.data_ptr(), len(ids))
+    torch.cuda.synchronize()
+    for k in want:
+        got = a_t[k].cpu().numpy()
+        ref = want[k].view(np.uint16) if want[k].dtype == np.float16 else want[k]
+        assert np.array_equal(got.view(ref.dtype).reshape(ref.shape), ref), f"atlas {k} differs"
