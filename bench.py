@@ -304,7 +304,7 @@ def main():
     # N > 1: the same workload unsharded on this rank's GPU, timed before the sharded loop — strong scaling of ONE workload can then be
     # read off this line alone (the driver's N = 1 run measures the headline lighting pass, not necessarily this workload)
     single_gpu = None
-    if world > 1 or (args.force_gather and chain):
+    if world > 1 or args.force_gather:
         if chain:
             ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1)
             ref_step = lambda: ref.step(gather=False)
