@@ -438,7 +438,15 @@ def cpu_baseline(fr, target_s):
     flags = "g++ -O2 (oracle/liboracle.so: the -O3 -march=native build failed)"
     so = os.path.join(ROOT, "oracle", "liboracle_native.so")
     try:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # -march=native code must not travel: the build is tied to this machine's CPU (model + feature flags) and redone anywhere else
+        import hashlib
+        cpu = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+        key = hashlib.sha1("".join(cpu).encode()).hexdigest()
+        key_file = os.path.join(ROOT, "oracle", "liboracle_native.cpu")
+        same_cpu = os.path.exists(so) and os.path.exists(key_file) and open(key_file).read().strip() == key
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")] + ([] if same_cpu else ["-B"]) + ["native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        open(key_file, "w").write(key)
         flags = open(os.path.join(ROOT, "oracle", "liboracle_native.flags")).read().strip()
     except Exception:
         so = os.path.join(ROOT, "oracle", "liboracle.so")
