@@ -146,6 +146,11 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom,
         t.mip_inv_h[m] = 1.0f / (float)bloom->mips[m].height;
         t.mip_h[m] = bloom->mips[m].height;
     }
+    for (uint32_t m = bloom->num_mips; m < 6; m++) {  // the kernel's staging loads are unconditional: absent mips alias the scene (nothing of them is used)
+        t.mips[m] = t.scene;
+        t.mip_w[m] = scene->width;
+        t.mip_h[m] = scene->height;
+    }
     if (!ctx->tm_thresholds) {  // built once per context (~15k libm pow calls)
         float thr[256];
         build_tonemap_thresholds(thr);
