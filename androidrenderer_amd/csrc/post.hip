@@ -44,9 +44,11 @@ __global__ void __launch_bounds__(256) k_bloom_downsample(PlaneArg src, uint32_t
 constexpr int kBlW = 64, kBlPitch = 136;
 // one bilinear tap from the staged rectangle: columns ax.o0 and ax.o0 + 8 bytes, rows ay.o0 and ay.o1
 SAH_DEV C3 tap_rep(const char* tex, const AxisE& ax, const AxisE& ay) {
-    const uint2* r0 = reinterpret_cast<const uint2*>(tex + (ay.o0 + ax.o0));
-    const uint2* r1 = reinterpret_cast<const uint2*>(tex + (ay.o1 + ax.o0));
-    const uint2 t00 = r0[0], t10 = r0[1], t01 = r1[0], t11 = r1[1];
+    // four ds_read_b64 (kept apart by `volatile`): merged into two ds_read2_b64 they are serviced at half the bytes per clock
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const volatile v2u* LdsTexel;
+    const LdsTexel r0 = (LdsTexel)(tex + (ay.o0 + ax.o0)), r1 = (LdsTexel)(tex + (ay.o1 + ax.o0));
+    const v2u t00 = r0[0], t10 = r0[1], t01 = r1[0], t11 = r1[1];
     const float w00 = ax.w0 * ay.w0, w10 = ax.w1 * ay.w0, w01 = ax.w0 * ay.w1, w11 = ax.w1 * ay.w1;
     C3 c;
     c.r = fma_mix_lo(w11, t11.x, fma_mix_lo(w01, t01.x, fma_mix_lo(w10, t10.x, fma_mix_lo(w00, t00.x, 0.0f))));
