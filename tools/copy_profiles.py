@@ -1,0 +1,31 @@
+"""Copies what tools/refresh_profiles.sh left under gpurun_out/refresh/ into profiles/ (the tracked, judged copies), named per round.
+usage: python tools/copy_profiles.py [round-prefix, default r2]"""
+import json
+import os
+import shutil
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r2"
+SRC, DST = "gpurun_out/refresh", "profiles"
+shutil.copy(f"{SRC}/bench.json", f"{DST}/{R}_bench_4k_deferred_gi.json")
+shutil.copy(f"{SRC}/ktrace/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_deferred_gi.csv")
+shutil.copy(f"{SRC}/pmc.txt", f"{DST}/{R}_pmc_4k_deferred_gi.txt")
+shutil.copy(f"{SRC}/passes.txt", f"{DST}/{R}_passes_4k.txt")
+shutil.copy(f"{SRC}/ta_probe.txt", f"{DST}/{R}_pmc_ta_tcp_probe.txt")
+# other workloads: replace the lines of the workloads that were re-run, keep the rest (the 8K ones come from their own run)
+path = f"{DST}/{R}_bench_other_workloads.jsonl"
+old = {}
+if os.path.exists(path):
+    for line in open(path):
+        if line.strip().startswith("{"):
+            d = json.loads(line)
+            old[d["config"]["workload"].split(":")[0]] = line.strip()
+for f in sorted(os.listdir(SRC)):
+    if f.startswith("bench_") and f.endswith(".json"):
+        line = open(f"{SRC}/{f}").read().strip()
+        if line.startswith("{"):
+            old[json.loads(line)["config"]["workload"].split(":")[0]] = line
+with open(path, "w") as out:
+    for k in old:
+        out.write(old[k] + "\n")
+print("copied; workloads:", list(old))
