@@ -71,32 +71,41 @@ class ShardedChain:
 class PipelinedChain:
     """Two frames in flight on one rank, so that both exchanges run beside compute (bench.py, N > 1).  Frame i is split at its first
     exchange: A(i) = lighting + copy + bloom mip 0 rows, then the mip-0 gather is queued on the communicator's side stream; B(i) = bloom
-    mips 1.. + tonemap, then the gather of the final rows.  The work stream runs A(0) | A(1) B(0) | A(2) B(1) | ... : the mip-0 gather
-    of frame i travels while A(i + 1) computes, the final gather of frame i while A(i + 2) and B(i + 1) do.  Every buffer a frame
-    writes exists twice (two ShardedChain sets); what orders a set's re-use is stated where the waits are."""
+    mips 1.. + tonemap, then the gather of the final rows.  Enqueue order: A(0) | A(1) B(0) | A(2) B(1) | ... : the mip-0 gather
+    of frame i travels while A(i + 1) computes, the final gather of frame i while A(i + 2) and B(i + 1) do.  With `second_stream` the
+    B halves run on that stream, beside the A half of the next frame: B is mostly the replicated small mips of the bloom pyramid —
+    launches of a few hundred texels that leave the chip idle — and at 8 ranks a quarter of a rank's frame (one rank's compute of
+    `4k_probe_gi_chain` at N = 8, emulated on one GPU: 0.176 -> 0.166 ms per frame, tools/experiments/chain_two_streams.py).
+    Every buffer a frame writes exists twice (two ShardedChain sets); what orders a set's re-use is stated where the waits are."""
 
-    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream):
+    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream, second_stream=None):
         import torch
         self.ctx, self.comm_stream, self.torch = ctx, comm_stream, torch
+        self.work = torch.cuda.current_stream()
+        self.work2 = second_stream
         self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world) for _ in range(2)]
         self.plan = self.sets[0].plan
         self.mip0_done = [None, None]   # event behind the mip-0 gather of the frame that last used the set
         self.final_done = [None, None]  # ... behind its final-image gather
+        self.b_done = [None, None]      # ... behind its B half (second stream only)
         self.submitted = 0
         self.finished = 0
+        ctx.set_stream(self.work.cuda_stream)
         ctx.comm_set_stream(comm_stream.cuda_stream)
 
     def submit(self, lighting_events=None):
         """Enqueue A(i) and the mip-0 exchange of the next frame, then B(i - 1) and the final exchange of the previous one."""
         i = self.submitted
         s = self.sets[i % 2]
-        # A(i) overwrites the set's lit / antialiased / own mip-0 rows: their last readers were B(i - 2) (same stream, earlier) and the
-        # mip-0 gather of frame i - 2 (B(i - 2) waited for it before it ran)
+        # A(i) overwrites the set's lit / antialiased / own mip-0 rows: their last readers were B(i - 2) — same stream and earlier, or
+        # waited for here — and the mip-0 gather of frame i - 2 (B(i - 2) waited for it before it ran)
+        if self.work2 is not None and self.b_done[i % 2] is not None:
+            self.work.wait_event(self.b_done[i % 2])
         if lighting_events is not None:
-            lighting_events[0].record()
+            lighting_events[0].record(self.work)
         s.lighting()
         if lighting_events is not None:
-            lighting_events[1].record()
+            lighting_events[1].record(self.work)
         s.reduce()
         self.ctx.allgather_rows(s.mip0_p, s.plan.mip0_rows_per_rank, s.plan.mip0_rows_per_rank * s.world)  # side stream, behind A(i)
         self.mip0_done[i % 2] = self.comm_stream.record_event()
@@ -106,23 +115,27 @@ class PipelinedChain:
 
     def _finish(self, j):
         s = self.sets[j % 2]
-        work = self.torch.cuda.current_stream()
-        work.wait_event(self.mip0_done[j % 2])       # mips 1.. read every rank's rows of mip 0
-        if self.final_done[j % 2] is not None:      # the final gather of frame j - 2 still reads / writes this set's image
-            work.wait_event(self.final_done[j % 2])
+        st = self.work2 if self.work2 is not None else self.work
+        if self.work2 is not None:
+            self.ctx.set_stream(st.cuda_stream)      # the library enqueues B(j), and orders its gather, on the second stream
+        st.wait_event(self.mip0_done[j % 2])         # mips 1.. read every rank's rows of mip 0 (and the gather ran behind A(j))
+        if self.final_done[j % 2] is not None:       # the final gather of frame j - 2 still reads / writes this set's image
+            st.wait_event(self.final_done[j % 2])
         s.composite()
         self.ctx.allgather_rows_reversed(s.out_p, s.plan.rows_per_rank, s.plan.rows_per_rank * s.world)
         self.final_done[j % 2] = self.comm_stream.record_event()
+        if self.work2 is not None:
+            self.b_done[j % 2] = st.record_event()
+            self.ctx.set_stream(self.work.cuda_stream)
         self.finished += 1
 
     def flush(self):
-        """Complete every submitted frame; the work stream then waits for the last gathers."""
+        """Complete every submitted frame; the work stream then waits for the last gathers (and B halves)."""
         while self.finished < self.submitted:
             self._finish(self.finished)
-        work = self.torch.cuda.current_stream()
-        for ev in self.final_done:
+        for ev in self.final_done + self.b_done:
             if ev is not None:
-                work.wait_event(ev)
+                self.work.wait_event(ev)
 
     def image(self, frame_index):
         return self.sets[frame_index % 2].out

@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
+    ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
@@ -216,7 +217,7 @@ def main():
     pipelined = chain and gather and lib_gather and comm_stream is not None
     if pipelined:
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
-        pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream)
+        pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev))
         sc = pc.sets[0]
 
         def step(i, e0=None, e1=None):
@@ -396,6 +397,7 @@ def main():
                 "gather": bool(gather),
                 "gather_through": ("sah_allgather_rows (library, RCCL)" if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
                 "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
+                "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
                 "same_workload_on_one_gpu": single_gpu,
             },
             "roofline": {

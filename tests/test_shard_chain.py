@@ -195,10 +195,11 @@ def test_hip_chain_through_a_one_rank_communicator():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("no_split", [False, True])
-def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split):
+@pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True)])
+def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_streams):
     """Two frames in flight (chain.PipelinedChain: both exchanges on the side stream of a one-rank communicator), a different AO plane
-    per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's."""
+    per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's.
+    `two_streams`: the B halves (mips 1.., tonemap, final exchange) on a second work stream beside the next frame's lighting."""
     import torch
     from androidrenderer_amd import chain, lib
     from tests import util
@@ -220,7 +221,7 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split):
             torch.cuda.synchronize()
             want.append(plain.out.cpu().numpy().copy())
         assert not np.array_equal(want[0], want[1])
-        pc = chain.PipelinedChain(ctx, f, dev, 0, 1, side)
+        pc = chain.PipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None)
         got = {}
         for i, a in enumerate(ao):
             dev["ao"].copy_(a)             # on the work stream: ordered with the frames around it
