@@ -139,3 +139,31 @@ def test_bloom_in_two_steps_equals_bloom(hip_ctx):
     torch.cuda.synchronize()
     for a, b in zip(mips, want):
         assert np.array_equal(util.from_torch(a, np.uint16), b)
+
+
+@pytest.mark.parametrize("case", ["no_mips", "one_mip", "three_mips", "output_2x", "output_smaller", "wide_21_9"])
+def test_tonemap_unusual_chains(hip_ctx, case):
+    """Fewer than six bloom mips (the kernel's staging loads are unconditional: absent mips alias the scene), an output that is not
+    the scene's resolution (a smaller one leaves the staged rectangles: whole-workgroup fallback to the per-pixel filter) and an
+    aspect ratio beyond the staged reach."""
+    import torch
+    o = util.oracle()
+    w, h = (336, 144) if case == "wide_21_9" else (192, 108)
+    ow, oh = {"output_2x": (384, 216), "output_smaller": (120, 70)}.get(case, (w, h))
+    n = {"no_mips": 0, "one_mip": 1, "three_mips": 3}.get(case, 6)
+    scene = synth.hdr_scene(w, h, seed=29).view(np.uint16)
+    full = _mips_np(w, h)
+    sp = images.plane(scene, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_bloom(C.byref(sp), C.byref(images.mipchain(full))) == 0
+    mips = full[:n]
+    ref = np.zeros((oh, ow, 4), dtype=np.uint8)
+    assert o.orc_tonemap(C.byref(sp), C.byref(images.mipchain(mips)), C.byref(images.plane(ref, _abi.FORMAT_R8G8B8A8_SRGB)), 0, 0) == 0
+    tm = [util.to_torch(m) for m in mips]
+    out = torch.zeros((oh, ow, 4), dtype=torch.uint8, device="cuda")
+    sc = util.to_torch(scene)
+    hip_ctx.tonemap(images.plane(sc, _abi.FORMAT_R16G16B16A16_SFLOAT), images.mipchain(tm), images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    if n:
+        assert not np.array_equal(ref, np.zeros_like(ref))
+    assert np.array_equal(got, ref), f"{case}: {int((got != ref).sum())} of {got.size} codes differ"

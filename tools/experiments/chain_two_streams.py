@@ -57,6 +57,7 @@ for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("one
     torch.cuda.synchronize()
     t = time.perf_counter()
     fn()
+    host = (time.perf_counter() - t) / N
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / N
-    print(f"world {world} rank {rank}: {name:12s} {dt * 1e3:.4f} ms per frame")
+    print(f"world {world} rank {rank}: {name:12s} {dt * 1e3:.4f} ms per frame (host enqueue {host * 1e3:.4f} ms)")
