@@ -42,13 +42,19 @@ __global__ void __launch_bounds__(256) k_bloom_downsample(PlaneArg src, uint32_t
 // (PPT = SAH_BLOOM_PPT for the large mips; small mips take PPT = 1 — 64x4 tiles — so that their few texels spread over more
 // workgroups with shorter dependency chains: 10.5 -> 5 us per launch for the 240x135 mip and below)
 constexpr int kBlW = 64, kBlPitch = 136;
-// one bilinear tap from the staged rectangle: columns ax.o0 and ax.o0 + 8 bytes, rows ay.o0 and ay.o1
+// LDS row layout: texel tx of a staged row sits in cell tx + tx / 32 (one empty cell after every 32).  Adjacent destination columns
+// read source texels two apart, 16 bytes: with the plain layout lanes i and i + 16 of a ds_read_b64 hit the same two banks (44 % of
+// the kernel's LDS cycles were bank conflicts); the gap moves the second sixteen lanes on by two banks.
+constexpr int kBlPitchCells = kBlPitch + (kBlPitch - 1) / 32 + 1;
+SAH_DEV int bl_cell(int tx) { return tx + (tx >> 5); }
+// one bilinear tap from the staged rectangle: columns ax.o0 and ax.o1 (byte offsets inside a row), rows ay.o0 and the one below it
 SAH_DEV C3 tap_rep(const char* tex, const AxisE& ax, const AxisE& ay) {
     // four ds_read_b64 (kept apart by `volatile`): merged into two ds_read2_b64 they are serviced at half the bytes per clock
     typedef uint32_t v2u __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const volatile v2u* LdsTexel;
-    const LdsTexel r0 = (LdsTexel)(tex + (ay.o0 + ax.o0)), r1 = (LdsTexel)(tex + (ay.o1 + ax.o0));
-    const v2u t00 = r0[0], t10 = r0[1], t01 = r1[0], t11 = r1[1];
+    constexpr int kRow = kBlPitchCells;  // in cells: the second row is an immediate offset
+    const LdsTexel c0 = (LdsTexel)(tex + (ay.o0 + ax.o0)), c1 = (LdsTexel)(tex + (ay.o0 + ax.o1));
+    const v2u t00 = c0[0], t10 = c1[0], t01 = c0[kRow], t11 = c1[kRow];
     const float w00 = ax.w0 * ay.w0, w10 = ax.w1 * ay.w0, w01 = ax.w0 * ay.w1, w11 = ax.w1 * ay.w1;
     C3 c;
     c.r = fma_mix_lo(w11, t11.x, fma_mix_lo(w01, t01.x, fma_mix_lo(w10, t10.x, fma_mix_lo(w00, t00.x, 0.0f))));
@@ -60,7 +66,7 @@ template <int kBlPpt>
 __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh,
                                                                uint32_t row_begin, uint32_t row_end) {
     constexpr int kBlH = 4 * kBlPpt, kBlRows = 2 * kBlH + 8, kBlTexels = kBlPitch * kBlRows;
-    __shared__ uint2 s_tex[kBlTexels];
+    __shared__ uint2 s_tex[kBlPitchCells * kBlRows];
     __shared__ AxisE s_ax[6 * kBlW + 6 * kBlH];  // [k * 64 + column] (o0 = column offset, o1 unused), [384 + k * 16 + row]
     __shared__ int s_rect[4];
     __shared__ int s_bad;
@@ -96,7 +102,8 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
 #pragma unroll
     for (int it = 0; it < kIters; it++) {
         const int i = (int)tid + it * 256;
-        if (i < kBlTexels) s_tex[i] = staged[it];
+        const int ty = i / kBlPitch, tx = i - ty * kBlPitch;
+        if (i < kBlTexels) s_tex[ty * kBlPitchCells + bl_cell(tx)] = staged[it];
     }
     if (tid < (uint32_t)(kBlW + kBlH)) {  // one thread per tile column / row: six set-ups from one coordinate
         const bool is_x = tid < (uint32_t)kBlW;
@@ -110,10 +117,13 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
         for (int k = 0; k < 6; k++) {
             const AxisU a = axis_unclamped(coords[k], is_x ? sw : sh);
             if (is_x) {
-                s_ax[k * kBlW + j] = AxisE{(a.i - rx0) * 8, 0, a.w0, a.w1};
+                s_ax[k * kBlW + j] = AxisE{bl_cell(a.i - rx0) * 8, bl_cell(a.i + 1 - rx0) * 8, a.w0, a.w1};
                 inside = inside && a.i >= rx0 && a.i + 1 < rx0 + rw;
             } else {
-                s_ax[6 * kBlW + k * kBlH + j] = AxisE{(a.i - ry0) * kBlPitch * 8, (a.i + 1 - ry0) * kBlPitch * 8, a.w0, a.w1};
+                // box weights folded in (powers of two commute with every rounding; nothing comes near the denormals): the centre box
+                // (set-ups 0, 1) carries 0.25 * 0.5, the four outer boxes 0.25 * 0.125
+                const float scale = k < 2 ? 0.125f : 0.03125f;
+                s_ax[6 * kBlW + k * kBlH + j] = AxisE{(a.i - ry0) * kBlPitchCells * 8, 0, a.w0 * scale, a.w1 * scale};
                 inside = inside && a.i >= ry0 && a.i + 1 < ry0 + rh;
             }
         }
@@ -137,12 +147,11 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
         if (!bad) {
             const AxisE* rowp = s_ax + 6 * kBlW + row;
             const AxisE yc = rowp[0], yd = rowp[kBlH], ycc = rowp[2 * kBlH], ycd = rowp[3 * kBlH], ydc = rowp[4 * kBlH], ydd = rowp[5 * kBlH];
-            auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {
-                const C3 b = tap_rep(lds, xl, yt) + tap_rep(lds, xr, yt) + tap_rep(lds, xl, yb) + tap_rep(lds, xr, yb);
-                return b * 0.25f;
+            auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {  // (weights pre-scaled: see the table)
+                return tap_rep(lds, xl, yt) + tap_rep(lds, xr, yt) + tap_rep(lds, xl, yb) + tap_rep(lds, xr, yb);
             };
-            s = box(xs[0], xs[1], yc, yd) * 0.5f + box(xs[2], xs[3], ycc, ycd) * 0.125f + box(xs[4], xs[5], ycc, ycd) * 0.125f +
-                box(xs[2], xs[3], ydc, ydd) * 0.125f + box(xs[4], xs[5], ydc, ydd) * 0.125f;
+            s = box(xs[0], xs[1], yc, yd) + box(xs[2], xs[3], ycc, ycd) + box(xs[4], xs[5], ycc, ycd) + box(xs[2], xs[3], ydc, ydd) +
+                box(xs[4], xs[5], ydc, ydd);
         } else {  // global-memory form: the same 6 + 6 set-ups, computed per texel
             const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
             const int pitch = (int)src.pitch;
