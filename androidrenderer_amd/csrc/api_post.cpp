@@ -60,6 +60,33 @@ void build_tonemap_thresholds(float thr[256]) {
         memcpy(&thr[k], &hi, 4);
     }
 }
+// First-level table of the device's code search: bucket b holds the positive floats whose bit pattern >> kTmBucketShift equals
+// base + b (16 buckets per octave, from thr[1] to thr[255]); first[b] = min(code(first float of the bucket), 252).  A bucket spans at
+// most three codes (checked), so code(x) = first[b] + [x >= thr[first + 1]] + [x >= thr[first + 2]] + [x >= thr[first + 3]].
+bool build_tonemap_buckets(const float thr[256], uint8_t first[sah::kTmMaxBuckets], uint32_t* base, uint32_t* count) {
+    uint32_t tb[256];
+    memcpy(tb, thr, sizeof(tb));
+    const uint32_t b0 = tb[1] >> sah::kTmBucketShift, b1 = tb[255] >> sah::kTmBucketShift;
+    const uint32_t n = b1 - b0 + 1;
+    if (n > sah::kTmMaxBuckets) return false;
+    auto code_of_bits = [&](uint32_t bits) {  // number of thresholds <= the float
+        uint32_t c = 0;
+        for (uint32_t k = 1; k < 256; k++) c += tb[k] <= bits ? 1u : 0u;
+        return c;
+    };
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t start = (b0 + b) << sah::kTmBucketShift, end = ((b0 + b + 1) << sah::kTmBucketShift) - 1u;
+        // bucket 0 also takes everything below thr[1] (clamped there by the kernel): code 0
+        const uint32_t lo = b == 0 ? 0u : code_of_bits(start);
+        const uint32_t f = lo < 252u ? lo : 252u;
+        if (code_of_bits(end) - f > 3u) return false;
+        first[b] = (uint8_t)f;
+    }
+    for (uint32_t b = n; b < sah::kTmMaxBuckets; b++) first[b] = 252;
+    *base = b0;
+    *count = n;
+    return true;
+}
 bool lpv_vol_ok(const sah_volume* v) {
     return v && v->ptr && v->format == SAH_FORMAT_R16G16B16A16_SFLOAT && (uint64_t)v->row_pitch_bytes >= (uint64_t)v->width * 8 &&
            (uint64_t)v->slice_pitch_bytes >= (uint64_t)v->row_pitch_bytes * v->height && ((uintptr_t)v->ptr % 8) == 0 &&
@@ -152,13 +179,23 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom,
         t.mip_h[m] = scene->height;
     }
     if (!ctx->tm_thresholds) {  // built once per context (~15k libm pow calls)
-        float thr[256];
-        build_tonemap_thresholds(thr);
+        struct {
+            float thr[256];
+            uint8_t first[sah::kTmMaxBuckets];
+        } tab;
+        build_tonemap_thresholds(tab.thr);
+        if (!build_tonemap_buckets(tab.thr, tab.first, &ctx->tm_bucket_base, &ctx->tm_bucket_count))
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "tonemap code table: a bucket spans more than three codes (internal)");
+        ctx->tm_thr_lo = tab.thr[1];
+        ctx->tm_thr_hi = tab.thr[255];
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_thresholds, sizeof(thr)));
-        HIP_TRY(ctx, hipMemcpy(ctx->tm_thresholds, thr, sizeof(thr), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_thresholds, sizeof(tab)));
+        HIP_TRY(ctx, hipMemcpy(ctx->tm_thresholds, &tab, sizeof(tab), hipMemcpyHostToDevice));
     }
     t.thresholds = ctx->tm_thresholds;
+    t.bucket_base = ctx->tm_bucket_base;
+    t.thr_lo = ctx->tm_thr_lo;
+    t.thr_hi = ctx->tm_thr_hi;
     t.out = parg(out);
     t.out_w = out->width;
     t.out_h = out->height;

@@ -33,7 +33,9 @@ struct sah_ctx {
     uint32_t parity = 0;
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;
-    float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds (api_post.cpp)
+    float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds + the first-level bucket table (api_post.cpp)
+    uint32_t tm_bucket_base = 0, tm_bucket_count = 0;
+    float tm_thr_lo = 0.f, tm_thr_hi = 0.f;
     struct RasterScratch {             // device buffers of the scene rasteriser, grown on demand (api_raster.cpp)
         void* ptr[16] = {};
         size_t bytes[16] = {};

@@ -15,7 +15,11 @@ struct TonemapArgs {
     PlaneArg out;
     uint32_t out_w, out_h;
     uint32_t row_begin, row_end;
-    const float* thresholds;  // device, 256 floats: see api_post.cpp tonemap_code()
+    const float* thresholds;  // device, 256 floats then kTmMaxBuckets bytes: see api_post.cpp tonemap_code(), build_tonemap_buckets()
+    uint32_t bucket_base;     // bit pattern >> kTmBucketShift of thresholds[1]
+    float thr_lo, thr_hi;     // thresholds[1], thresholds[255]
 };
+
+constexpr uint32_t kTmBucketShift = 19, kTmMaxBuckets = 512;
 
 }  // namespace sah

@@ -128,7 +128,9 @@ __global__ void __launch_bounds__(256, SAH_TONEMAP_MIN_BLOCKS) k_tonemap(Tonemap
     __shared__ int s_rect[6][4];              // x0, y0 (may be negative: replicated cells), w, h in cells (w == 0: not staged)
     __shared__ int s_bad[6];                  // 1: some set-up of mip m leaves the staged rectangle -> global path
     __shared__ float s_thr[256];              // s_thr[k] = smallest x whose output code is >= k (k = 1..255); s_thr[0] unused
+    __shared__ uint32_t s_first[kTmMaxBuckets / 4];  // first-level table of the code search, one byte per bucket
     s_thr[threadIdx.x] = t.thresholds[threadIdx.x];
+    if (threadIdx.x < kTmMaxBuckets / 4) s_first[threadIdx.x] = reinterpret_cast<const uint32_t*>(t.thresholds + 256)[threadIdx.x];
     const uint32_t bx = blockIdx.x * kTmTileW, by = t.row_begin + blockIdx.y * kTmTileH;
     const uint32_t x_last = min(bx + kTmTileW - 1, t.out_w - 1), y_last = min(by + kTmTileH - 1, t.row_end - 1);
     if (threadIdx.x < 6) {
@@ -294,19 +296,20 @@ __global__ void __launch_bounds__(256, SAH_TONEMAP_MIN_BLOCKS) k_tonemap(Tonemap
         const float factor = luma / (luma + 1.f);
         const C3 mapped = c * factor;
         // pow(x, 1/2.2) -> sRGB OETF -> UNORM8 is a monotone map from fp32 to 256 codes: the host tabulates, by bisection on the
-        // exact composite (api_post.cpp: tonemap_code), the smallest input that reaches each code; the device counts thresholds.
-        // Two fp64 pow() per channel (~600 issue slots) become an 8-step binary search in LDS.
+        // exact composite (api_post.cpp: tonemap_code), the smallest input that reaches each code; the code of x is the number of
+        // thresholds <= x.  Two fp64 pow() per channel (~600 issue slots) become a two-level look-up: the float's exponent and top
+        // four mantissa bits select a bucket whose first code is tabulated and which spans at most three codes, then three
+        // thresholds are counted.  x below thresholds[1], negative or NaN lands in bucket 0 (first code 0) through the clamp — fmaxf
+        // returns its non-NaN operand — and every comparison of the original x is then false: code 0, as the shader's result.
         const float rgb[3] = {mapped.r, mapped.g, mapped.b};
         uint32_t code[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            uint32_t lo4 = 0;  // 4 * lo; invariant: threshold[lo] <= x, with threshold[0] = -inf; NaN compares false everywhere -> code 0
-#pragma unroll
-            for (uint32_t step4 = 512; step4 >= 4; step4 >>= 1) {
-                const float thr = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_thr) + lo4 + step4);
-                lo4 = (rgb[ch] >= thr) ? lo4 + step4 : lo4;
-            }
-            code[ch] = lo4 >> 2;
+            const float xc = __builtin_fminf(__builtin_fmaxf(rgb[ch], t.thr_lo), t.thr_hi);
+            const uint32_t b = (__builtin_bit_cast(uint32_t, xc) >> kTmBucketShift) - t.bucket_base;
+            const uint32_t first = reinterpret_cast<const uint8_t*>(s_first)[b];
+            const float* th = s_thr + first;
+            code[ch] = first + (rgb[ch] >= th[1] ? 1u : 0u) + (rgb[ch] >= th[2] ? 1u : 0u) + (rgb[ch] >= th[3] ? 1u : 0u);
         }
         const uint32_t px = code[0] | (code[1] << 8) | (code[2] << 16) | (255u << 24);
         *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(t.out.ptr) + (size_t)y * t.out.pitch + (size_t)x * 4) = px;
