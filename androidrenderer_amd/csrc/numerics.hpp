@@ -47,6 +47,16 @@ struct Fn {
 SAH_DEV Fn operator+(Fn a, Fn b) { return Fn(a.v + b.v); }
 SAH_DEV Fn operator-(Fn a, Fn b) { return Fn(a.v - b.v); }
 SAH_DEV Fn operator*(Fn a, Fn b) { return Fn(a.v * b.v); }
+#ifdef SAH_EXP_APPROX_MATH  // experiment (tools/experiments/approx_math_bound.md): every divide / sqrt / pow5 at hardware precision (1 ulp v_rcp / v_rsq
+                           // / v_sqrt, fp32 powers) — NOT the contract; an upper bound on what any tolerance mode could gain
+SAH_DEV Fn operator/(Fn a, Fn b) { return Fn(a.v * __builtin_amdgcn_rcpf(b.v)); }
+SAH_DEV Fn operator-(Fn a) { return Fn(-a.v); }
+SAH_DEV Fn nsqrt(Fn a) { return Fn(__builtin_amdgcn_sqrtf(a.v)); }
+SAH_DEV Fn npow5(Fn a) {
+    const float d2 = a.v * a.v;
+    return Fn(d2 * d2 * a.v);
+}
+#else
 SAH_DEV Fn operator/(Fn a, Fn b) { return Fn(a.v / b.v); }
 SAH_DEV Fn operator-(Fn a) { return Fn(-a.v); }
 SAH_DEV Fn nsqrt(Fn a) { return Fn(__builtin_sqrtf(a.v)); }
@@ -54,6 +64,7 @@ SAH_DEV Fn npow5(Fn a) {
     double d = (double)a.v;
     return Fn((float)(d * d * d * d * d));
 }
+#endif
 SAH_DEV float tof(Fn a) { return a.v; }
 
 // ---- correctly rounded sqrt / reciprocal / divide for operands of KNOWN range ----------------------------------------------
@@ -68,6 +79,12 @@ SAH_DEV float tof(Fn a) { return a.v; }
 constexpr float kNrLo = 0x1p-100f, kNrHi = 0x1p+100f;  // domain of sqrt_nr / rcp_nr (magnitudes)
 constexpr float kDivLo = 0x1p-40f, kDivHi = 0x1p+40f;  // domain of div_nr (|a|, |b|; a may also be +0)
 
+#ifdef SAH_EXP_APPROX_MATH
+SAH_DEV float sqrt_nr(float x) { return __builtin_amdgcn_sqrtf(x); }
+SAH_DEV float sqrt_nr0(float x) { return __builtin_amdgcn_sqrtf(x); }
+SAH_DEV float rcp_nr(float x) { return __builtin_amdgcn_rcpf(x); }
+SAH_DEV float div_nr(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
 // x in [2^-100, 2^100] -> RN(sqrt(x))
 SAH_DEV float sqrt_nr(float x) {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -106,6 +123,7 @@ SAH_DEV float div_nr(float a, float b) {
     const float r1 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(r1, y1, q1);
 }
+#endif
 
 // An fp32 value is hidden from the optimiser before it is rounded to fp16.  Without this LLVM (a) narrows
 // fptrunc(fdiv(fpext, fpext)) to a half fdiv whose v_rcp_f16 expansion is not correctly rounded, and (b) fuses
