@@ -221,6 +221,15 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
                 const Fn d2 = dot(lv, lv);
                 const bool near = surface && d2.v <= far2;
                 if (!__any(near)) continue;
+                // A light behind the surface (N.L <= 0) contributes ndotl * (...) with ndotl = +0: +-0, or NaN -> 0 — nothing, in the hot
+                // form and in the general one alike (both evaluate L = lv / |lv| with the same bits while d2 is inside the domain of
+                // the restricted-range root and reciprocal).  Waves whose reachable pixels all face away skip the light.
+                {
+                    const bool d2_ok = d2.v >= 0x1p-80f && d2.v <= 0x1p+40f;
+                    const F3 Le = lv * Fn(rcp_nr(sqrt_nr(d2.v)));
+                    const bool facing = !(d2_ok && dot(s.normal, Le).v <= 0.f);
+                    if (!__any(near && facing)) continue;
+                }
                 // per-light (uniform) precondition of the hot form; anything else takes the general form
                 const bool light_ok = pl.radius >= kDivLo && pl.radius <= kDivHi && __builtin_fabsf(pl.cr) < inf && __builtin_fabsf(pl.cg) < inf &&
                                       __builtin_fabsf(pl.cb) < inf && __builtin_fabsf(pl.intensity) < inf;
