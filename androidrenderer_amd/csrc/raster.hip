@@ -951,6 +951,10 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
             area = (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1));
             mine = edge_setup(rec);  // every lane sets up its own record: 64 set-ups for the price of one
             medium_rec = area > kSmallArea && area <= kMediumArea;
+#ifdef SAH_EXP_RASTER_SKIP_SMALL  // timing experiment: lane-walked records dropped
+            if (area <= kSmallArea) {
+            } else
+#endif
             if (area <= kSmallArea) {
                 for (int32_t py = y0; py <= y1; py++)
                     for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER, TEX>(a, mine, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
@@ -967,7 +971,11 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
         }
         // medium records: one at a time by the wave that read them, lanes as an 8x8 block sweeping the clipped bounding box; the
         // owner lane's set-up moves to scalar registers with v_readlane (no memory round trip per record)
+#ifdef SAH_EXP_RASTER_SKIP_MEDIUM  // timing experiment: wave-swept records dropped
+        uint64_t medium = 0;
+#else
         uint64_t medium = __ballot(medium_rec);
+#endif
         while (medium) {
             const int src = __builtin_ctzll(medium);
             medium &= medium - 1;
