@@ -47,7 +47,7 @@ struct Fn {
 SAH_DEV Fn operator+(Fn a, Fn b) { return Fn(a.v + b.v); }
 SAH_DEV Fn operator-(Fn a, Fn b) { return Fn(a.v - b.v); }
 SAH_DEV Fn operator*(Fn a, Fn b) { return Fn(a.v * b.v); }
-#ifdef SAH_EXP_APPROX_MATH  // experiment (tools/experiments/approx_math_bound.md): every divide / sqrt / pow5 at hardware precision (1 ulp v_rcp / v_rsq
+#ifdef SAH_EXP_APPROX_MATH  // experiment (profiles/r2_approx_math_bound.txt, tools/experiments/approx_bound.py): every divide / sqrt / pow5 at hardware precision (1 ulp v_rcp / v_rsq
                            // / v_sqrt, fp32 powers) — NOT the contract; an upper bound on what any tolerance mode could gain
 SAH_DEV Fn operator/(Fn a, Fn b) { return Fn(a.v * __builtin_amdgcn_rcpf(b.v)); }
 SAH_DEV Fn operator-(Fn a) { return Fn(-a.v); }
