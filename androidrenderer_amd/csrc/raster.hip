@@ -108,17 +108,25 @@ SAH_DEV int32_t last_px(int32_t hi, uint32_t size) {
 }
 
 // ---- K0: exclusive scan (single workgroup, chunked) ------------------------------------------------------------------------------
-// mode 0: in[i] = primitives[i].index_count / 3; mode 1: in[i] = values[i]
+// mode 0: in[i] = primitives[i].index_count / 3; mode 1: in[i] = values[i].  Eight consecutive elements per thread and round (the
+// tile counts of four 4096^2 cascades are 16 K elements: 2 rounds instead of 16, 18 -> 5 us).
 __global__ __launch_bounds__(1024) void k_exclusive_scan(const sah_primitive* prims, const uint32_t* values, uint32_t n, uint32_t* out, uint32_t* total) {
+    constexpr uint32_t kPer = 8;
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n ? (prims ? prims[i].index_count / 3u : values[i]) : 0u;
-        uint32_t incl = v;
+    for (uint32_t base = 0; base < n; base += 1024 * kPer) {
+        const uint32_t i0 = base + tid * kPer;
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            const uint32_t i = i0 + k;
+            v[k] = i < n ? (prims ? prims[i].index_count / 3u : values[i]) : 0u;
+            sum += v[k];
+        }
+        uint32_t incl = sum;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d, 64);
             if ((int)lane >= d) incl += up;
@@ -128,9 +136,14 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const sah_primitive* pr
         uint32_t wave_base = 0;
         for (uint32_t w = 0; w < wave; w++) wave_base += s_wave[w];
         const uint32_t carry = s_carry;
-        if (i < n) out[i] = carry + wave_base + incl - v;
+        uint32_t run = carry + wave_base + incl - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
-        if (tid == 1023) s_carry = carry + wave_base + incl;
+        if (tid == 1023) s_carry = run;
         __syncthreads();
     }
     if (tid == 0) *total = s_carry;
