@@ -57,6 +57,7 @@ class ShardedChain:
 
     def exchange_final(self):
         self.ctx.allgather_rows_reversed(self.out_p, self.plan.rows_per_rank, self.plan.rows_per_rank * self.world)
+        self.ctx.comm_wait()  # with a side stream set, readers of `out` on the work stream must come behind the gather
 
     def step(self, gather=True):
         self.lighting()

@@ -230,10 +230,10 @@ void sah_destroy(sah_ctx* ctx) {
 
 int sah_set_stream(sah_ctx* ctx, void* hip_stream) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
-    if (ctx->own_stream && ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    // work in flight on the old stream (e.g. the clear pass behind a sah_probe_update) must not overlap what the next call enqueues on
+    // the new one: switching streams is rare, so it simply drains the old one
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return SAH_OK;
@@ -418,7 +418,9 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         cache.debug_mode = gi.cache_debug_mode;
         auto bytes = [](const sah_volume& v) { return (uint64_t)v.slice_pitch_bytes * v.depth; };
         cache.hot_ok = bytes(gi.probe_irradiance) < (1ull << 32) && bytes(gi.probe_depth) < (1ull << 32) && bytes(gi.probe_validity) < (1ull << 32) &&
-                       gi.probe_validity.width <= 64 && gi.probe_validity.height <= 64 && gi.probe_validity.depth <= 64 &&
+                       // div_const() is proven bit-exact for probe indices below 32 only (tools/microbench/div_const_check.c); the
+                       // reference's grid is exactly 32 x 32 x 32 (irradiance_cache.cpp:94-183)
+                       gi.probe_validity.width <= 32 && gi.probe_validity.height <= 32 && gi.probe_validity.depth <= 32 &&
                        gi.probe_size[0] >= 1 && gi.probe_size[0] <= 30 && gi.probe_size[1] >= 1 && gi.probe_size[1] <= 30 &&
                        // atlases exactly 32 blocks wide, as get_probe_uv assumes: texcoords then never reach the REPEAT seam
                        gi.probe_irradiance.width == 32u * (gi.probe_size[0] + 2u) && gi.probe_irradiance.height == 32u * (gi.probe_size[1] + 2u) &&
@@ -539,7 +541,9 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             const uint64_t gpr = W / (uint32_t)ppt, threads = (gpr * (r1 - r0) + 255) / 256 * 256;
             fast.row_magic = (gpr >= 2 && threads * gpr < (1ull << 32)) ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u;
         }
-        fast.tolerance = (d->flags & SAH_LIGHTING_TOLERANCE_1ULP) ? 1u : 0u;
+#ifdef SAH_EXP_TOLERANCE_1ULP
+        fast.tolerance = (d->flags & sah::kExpLightingTolerance1Ulp) ? 1u : 0u;
+#endif
         fast.parity = ctx->parity;
         fast.state = ctx->state;
     }

@@ -382,14 +382,48 @@ int sah_comm_init(sah_ctx* ctx, const void* comm_id) {
     ctx->comm_reversed = nullptr;
     const char* no_split = getenv("SAH_COMM_NO_SPLIT");
     auto split = RCCL_SYM(ctx->rccl, ncclCommSplit);
+    ncclComm_t rev = nullptr;
     if (split && !(no_split && no_split[0] == '1')) {
-        ncclComm_t rev = nullptr;
-        if (split(comm, 0, ctx->world - 1 - ctx->rank, &rev, nullptr) == ncclSuccess && rev) ctx->comm_reversed = rev;
+        if (split(comm, 0, ctx->world - 1 - ctx->rank, &rev, nullptr) != ncclSuccess) rev = nullptr;
+    }
+    // Which path the reversed exchange takes must be ONE decision for the whole job: a rank on the split communicator and a rank on
+    // the send / recv fallback would wait for each other forever.  So the ranks agree (minimum of "my split succeeded" over the parent
+    // communicator) and the reversed communicator is used only if every rank has one.
+    int mine = rev ? 1 : 0, all = 0;
+    int* d_flag = nullptr;
+    auto allreduce = RCCL_SYM(ctx->rccl, ncclAllReduce);
+    bool agreed = false;
+    if (allreduce && hipMalloc((void**)&d_flag, sizeof(int)) == hipSuccess) {
+        if (hipMemcpy(d_flag, &mine, sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+            allreduce(d_flag, d_flag, 1, ncclInt32, ncclMin, comm, ctx->stream) == ncclSuccess &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(&all, d_flag, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+            agreed = true;
+        (void)hipFree(d_flag);
+    }
+    if (!agreed) {
+        if (rev) {
+            auto destroy = RCCL_SYM(ctx->rccl, ncclCommDestroy);
+            if (destroy) destroy(rev);
+        }
+        return fail(ctx, SAH_ERR_COMM, "the ranks could not agree on the reversed-exchange path (ncclAllReduce on the parent communicator failed)");
+    }
+    if (all == 1) {
+        ctx->comm_reversed = rev;
+        ctx->last_error = "reversed exchange: split communicator";
+    } else {
+        if (rev) {
+            auto destroy = RCCL_SYM(ctx->rccl, ncclCommDestroy);
+            if (destroy) destroy(rev);
+        }
+        ctx->last_error = "reversed exchange: grouped ncclSend / ncclRecv on the parent communicator";
     }
     return SAH_OK;
 }
 
 void sah_comm_destroy(sah_ctx* ctx) {
+    // nothing of this context may still be in flight on either stream when the communicators and events go away
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->rccl) {
         auto f = RCCL_SYM(ctx->rccl, ncclCommDestroy);
         if (f && ctx->comm_reversed) f((ncclComm_t)ctx->comm_reversed);
@@ -402,6 +436,10 @@ void sah_comm_destroy(sah_ctx* ctx) {
 int sah_comm_set_stream(sah_ctx* ctx, void* hip_stream) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm_pending) {  // a gather is still in flight on the old side stream: the work stream joins it before the streams change
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_done, 0));
+        ctx->comm_pending = false;
+    }
     ctx->comm_stream = (hipStream_t)hip_stream;
     if (ctx->comm_stream && !ctx->comm_ready) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->comm_ready, hipEventDisableTiming));

@@ -337,16 +337,19 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     }
     const uint32_t blocks = (uint32_t)((groups + 255) / 256);
     const dim3 block(256);
-    // tolerance mode: only where the relaxed body differs (fp32 BRDF of the CSM sun, LPV overlay products) and for the 4-pixel layout
-    constexpr bool kHasRelaxed = SUN != SAH_SHADOW_MODE_RT && (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV);
+    // tolerance experiment (params.hpp: kExpLightingTolerance1Ulp): only where the relaxed body differs (fp32 BRDF of the CSM sun, LPV overlay products) and for the 4-pixel layout
+    [[maybe_unused]] constexpr bool kHasRelaxed = SUN != SAH_SHADOW_MODE_RT && (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV);
     auto launch = [&](auto ppt_c, auto relaxed_c) {
         constexpr int P = decltype(ppt_c)::value;
         constexpr bool R = decltype(relaxed_c)::value;
         if (sky.enabled) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, R, true>), dim3((kSkyRatio + 1u) * ((blocks + kSkyRatio - 1u) / kSkyRatio)), block, 0, st, a, csm, lpv, sky, f);
         else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, R, false>), dim3(blocks), block, 0, st, a, csm, lpv, sky, f);
     };
+#ifdef SAH_EXP_TOLERANCE_1ULP
     if (ppt == 4 && kHasRelaxed && f.tolerance) launch(std::integral_constant<int, 4>{}, std::integral_constant<bool, kHasRelaxed>{});
-    else if (ppt == 4) launch(std::integral_constant<int, 4>{}, std::false_type{});
+    else
+#endif
+    if (ppt == 4) launch(std::integral_constant<int, 4>{}, std::false_type{});
     else if (ppt == 2) launch(std::integral_constant<int, 2>{}, std::false_type{});
     else launch(std::integral_constant<int, 1>{}, std::false_type{});
     const dim3 fgrid((f.num_segments + kFixupSegs - 1) / kFixupSegs);

@@ -175,7 +175,7 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
     }
 }
 
-// RELAXED = SAH_LIGHTING_TOLERANCE_1ULP (sah_hip.h): the BRDF evaluation and the overlay's final products run as fused / hardware
+// RELAXED = the tolerance experiment (params.hpp: kExpLightingTolerance1Ulp; instantiated only with -DSAH_EXP_TOLERANCE_1ULP): the BRDF evaluation and the overlay's final products run as fused / hardware
 // arithmetic (numerics.hpp: brdf_relaxed); everything that decides something or is ill-conditioned stays the strict sequence below.
 // Guards (all lead to `deferred`, i.e. to the strict restatement in the fix-up kernel):
 //   G1  sun term: an fp32 value within kTieMargin ulps of an fp16 rounding tie, in fp16's denormal range, or >= 65000 — the blend

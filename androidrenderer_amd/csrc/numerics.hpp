@@ -397,7 +397,7 @@ SAH_DEV F3 brdf_fast_light(const Surface<Fn>& s, const BrdfPixel& p, F3 l, F3 v,
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
 
-// ---- tolerance mode (SAH_LIGHTING_TOLERANCE_1ULP): the fp32 brdf() of brdf.glsl:29-121 for the fast kernel -------------------------
+// ---- tolerance experiment (-DSAH_EXP_TOLERANCE_1ULP, params.hpp): the fp32 brdf() of brdf.glsl:29-121 for the fast kernel -------------------------
 // Inputs are the strict (exact) unit vectors; the evaluation uses explicit FMAs, v_rsq / v_rcp / v_sqrt (1 ulp) and x^5 as three
 // multiplies.  Every term is a product or a sum of non-negative quantities except 1 - NoH^2 + a^2, whose error is bounded by the caller's
 // guard on `dden` (the D_GGX denominator): a relative error of about 2^-22 / dden in D.  Returns fd + fr for a lit pixel (NoL > 0);

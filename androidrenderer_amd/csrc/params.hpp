@@ -91,7 +91,7 @@ struct FastArgs {
     uint32_t sky_enabled;
     uint32_t row_magic;  // floor(2^32 / groups per row) + 1 when mulhi(gid, row_magic) == gid / groups_per_row for every thread of the call, else 0
     uint32_t parity;
-    uint32_t tolerance;  // SAH_LIGHTING_TOLERANCE_1ULP: the relaxed body (lighting_relaxed.hpp) where it exists
+    uint32_t tolerance;  // experiment builds only (-DSAH_EXP_TOLERANCE_1ULP): run the relaxed body where it exists; always 0 otherwise
     FrameState* state;
     // Deferred pixels, without atomics: the wave that shades thread groups [64 s, 64 s + 64) owns segment s — kSegSize(PPT) byte codes
     // (lane * PPT + pixel) at seg_list + s * seg_stride — general pixels from the front, sky pixels (depth == 0) from the back — and
@@ -106,6 +106,10 @@ struct FastArgs {
     uint32_t pk_row_pitch, pk_slice_pitch;
 };
 constexpr uint32_t kLpvPackTexel = 24, kLpvPackBorder = 2;
+// Experiment (round 2, profiles/r2_tolerance_mode_v1.txt): a "within 1 fp16 ULP" mode of the fast kernel.  2.4x SLOWER than the strict
+// kernel (its guards send 36-50 % of the pixels through both paths), so it is not part of the ABI: the flag bit exists only in a
+// library built with SAH_EXTRA_HIPCC_FLAGS=-DSAH_EXP_TOLERANCE_1ULP, which is what tests/test_tolerance_gpu.py asks for.
+constexpr uint32_t kExpLightingTolerance1Ulp = 1u << 2;
 
 struct LightingArgs {
     PlaneArg color, normals, data, emission, depth, ao, shadow_mask, lit;

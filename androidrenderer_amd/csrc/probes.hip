@@ -230,6 +230,9 @@ SAH_DEV void ordered_stores(const VolumeArg& dst, const uint32_t* id, uint32_t l
     __syncthreads();
     const int px = (int)id[0], py = (int)id[1], bz = (int)id[2];
     const int bx = px * (RX + 2), by = py * (RY + 2);
+    if (px >= 0 && py >= 0 && bz >= 0 && px < kProbeGrid && py < kProbeGrid && bz < kProbeGrid &&
+        slots[(bz * kProbeGrid + py) * kProbeGrid + px] != list_pos + 1u)
+        return;  // listed again later: that workgroup's stores are the ones that stay (uniform over the workgroup, after its last barrier)
     for (int k = 0; k < n; k++) {
         if (s_owner[(oy[k] + 2) * kW + (ox[k] + 2)] != (uint32_t)(t * 4 + k) + 1u) continue;  // a later invocation of this probe stores there
         const int x = ox[k] + bx, y = oy[k] + by;
@@ -251,7 +254,12 @@ __global__ void __launch_bounds__(256) k_probe_slots(const uint32_t* probes, uin
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= num_probes) return;
     const uint32_t x = probes[3u * i], y = probes[3u * i + 1u], z = probes[3u * i + 2u];
-    if (x < (uint32_t)kProbeGrid && y < (uint32_t)kProbeGrid && z < (uint32_t)kProbeGrid) slots[(z * kProbeGrid + y) * kProbeGrid + x] = set ? i + 1u : 0u;
+    if (x < (uint32_t)kProbeGrid && y < (uint32_t)kProbeGrid && z < (uint32_t)kProbeGrid) {
+        // a probe listed twice (the ABI asks for distinct probes; cheap to survive): the LATER listing owns the cell — under the store order
+        // above it overwrites everything the earlier one stored — and the earlier workgroup stores nothing (ordered_stores)
+        if (set) atomicMax(&slots[(z * kProbeGrid + y) * kProbeGrid + x], i + 1u);
+        else slots[(z * kProbeGrid + y) * kProbeGrid + x] = 0u;
+    }
 }
 
 // probe_depth_update.comp.slang:11-49 — one workgroup per probe, 10 x 10 texels

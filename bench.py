@@ -84,6 +84,59 @@ def light_stats(torch, fr, d_arr, lights_np, dev):
             "lights_shaded_per_pixel_mean": round(float(per_px[surf].mean()) if bool(surf.any()) else 0.0, 3)}
 
 
+VALU_PEAK_TFLOPS = 157.3   # same guide: FP32 vector peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
+SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
+
+
+def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope, algorithmic_bytes, my_px, kernel):
+    """The metric's roofline is HBM (BASELINE.json: "achieved HBM GB/s vs roofline"): achieved / peak / frac are that one, measured
+    live.  `bound` names the roofline that actually binds the workload, and the other two are carried beside it:
+      valu_issue  VALU issue cycles of one launch (SQ_ACTIVE_INST_VALU x 4, summed over the SIMDs) / (1024 SIMDs x 2.4 GHz x the
+                  LIVE kernel time) — the counter is from a separate rocprofv3 --pmc pass of the same build and workload
+                  (profiles/roofline_static.json says which file), because PMC counters cannot be read from inside a run;
+      fp32        algorithmic FLOP per pixel (counted once from the per-pixel operator list) x pixels / LIVE kernel time
+                  against the 157.3 TFLOP/s vector peak.
+    `traffic` is the measured HBM traffic per launch of that same static pass (FETCH_SIZE doubled per the guide's gfx950 correction +
+    WRITE_SIZE), scaled by this rank's share of the pixels; null when the workload has no static record."""
+    st = {}
+    try:
+        st = json.load(open(os.path.join(ROOT, "profiles", "roofline_static.json"))).get(workload, {})
+    except Exception:
+        pass
+    t = kernel_ms_mean * 1e-3
+    share = my_px / st["pixels"] if st.get("pixels") else 1.0
+    hbm_frac = achieved_gbs / HBM_PEAK_GBS
+    out = {
+        "bound": "hbm",
+        "achieved": round(achieved_gbs, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(hbm_frac, 4),
+        "traffic": None,
+        "kernel": kernel,
+        "kernel_ms_mean": round(kernel_ms_mean, 5),
+        "kernel_ms_min": None if kernel_ms_min is None else round(kernel_ms_min, 5),
+        "kernel_ms_scope": scope,
+        "algorithmic_bytes_per_launch": algorithmic_bytes,
+    }
+    fracs = {"hbm": hbm_frac}
+    if st.get("hbm_traffic_bytes_per_launch"):
+        out["traffic"] = int(st["hbm_traffic_bytes_per_launch"] * share)
+        out["traffic_source"] = f"{st['source']} (static: separate --pmc passes of this build, not this run)"
+    if st.get("valu_active_cycles_per_launch"):
+        f = st["valu_active_cycles_per_launch"] * share / (SIMDS * MAX_CLOCK_HZ * t)
+        fracs["valu"] = f
+        out["valu_issue"] = {"frac": round(f, 4), "insts_per_px": round(st["valu_wave_insts_per_launch"] * 64 / st["pixels"], 1),
+                             "active_cycles_per_launch": int(st["valu_active_cycles_per_launch"] * share), "peak": "1024 SIMDs x 2.4 GHz",
+                             "source": f"{st['source']} (static)"}
+    if st.get("flops_per_px"):
+        tf = st["flops_per_px"] * my_px / t / 1e12
+        out["fp32"] = {"achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 4),
+                       "flops_per_px": st["flops_per_px"], "source": "DESIGN.md §7c operator count (static)"}
+    out["bound"] = max(fracs, key=fracs.get)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,18 +393,45 @@ def main():
     if torch_pg:
         dist.barrier()
         torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # GPU time of the timed region: ONE pair of HIP events on the launch stream around all K steps (round 2 recorded a pair per step:
+    # each record is a barrier packet of ~10 us on the queue, 20 us per 190 us step that were measurement, not work —
+    # profiles/r3_trace_bench20_gaps.txt).  Created and recorded once before t0 so that their lazy creation is outside the region.
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record()
+    g1.record()
+    torch.cuda.synchronize()
+    # chain workloads: the roofline is the Lighting kernel's, one pass of several in a step, so those keep a pair per step around the
+    # sah_lighting call (2 x ~10 us on a ~0.9 ms step); created and recorded before t0 as well
+    ev = []
+    if chain:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a_, b_ in ev:
+            a_.record()
+            b_.record()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
+    g0.record()
     for i in range(args.steps):
-        step(i, ev[i][0], ev[i][1])
+        if chain:
+            step(i, ev[i][0], ev[i][1])
+        else:
+            step(i)
     drain()
+    g1.record()
     torch.cuda.synchronize()
     if torch_pg:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    kernel_ms_mean = sum(kernel_ms) / len(kernel_ms)
+    loop_ms = g0.elapsed_time(g1) / args.steps
+    if chain:
+        per_step = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
+        kernel_ms_mean, kernel_ms_min = sum(per_step) / len(per_step), per_step[0]
+        kernel_scope = "HIP events around each sah_lighting call of the timed region, on its stream (main kernel + fix-up)"
+    else:
+        kernel_ms_mean, kernel_ms_min = loop_ms, None
+        kernel_scope = ("one pair of HIP events on the launch stream around all K steps of the timed region, / K: everything a sah_lighting call "
+                        "enqueues (main kernel with its sky workgroups + fix-up) and the gaps between launches")
     if torch_pg:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -400,21 +480,8 @@ def main():
                 "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
                 "same_workload_on_one_gpu": single_gpu,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # HBM bytes per launch from the PMC counters are collected by a separate rocprofv3 --pmc run (tools/pmc_collect.sh;
-                # profiles/r2_pmc_*.txt): a bench run cannot read them, and a constant copied from a file would only look measured
-                "traffic": None,
-                "kernel": "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast",
-                "kernel_ms_mean": round(kernel_ms_mean, 5),
-                "kernel_ms_min": round(kernel_ms[0], 5),
-                "kernel_ms_scope": "HIP events around one sah_lighting call on its stream (k_lpv_pack + main kernel, sky workgroups included + fix-up)",
-                "algorithmic_bytes_per_launch": bytes_per_pixel * my_px,
-            },
+            "roofline": roofline(args.workload, world, achieved, kernel_ms_mean, kernel_ms_min, kernel_scope, bytes_per_pixel * my_px, my_px,
+                                 "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),
         }
         if n_lights:
             out["config"].update(light_stats(torch, fr, d_arr, lights, dev))

@@ -190,15 +190,6 @@ typedef struct sah_light_list {
 /* flags */
 #define SAH_LIGHTING_QUIRK_SUN_BLEND (1u << 0) /* reproduce the SRC_COLOR/DST_COLOR sun blend (squares the sun term) */
 #define SAH_LIGHTING_BRUTE_FORCE_LIGHTS (1u << 1) /* shade every light for every pixel (no tile culling) */
-/* Tolerance mode (BASELINE.json north_star: "within 1 ULP per channel" of the stored RGBA16F value).  Default (flag clear) is the
- * strict mode: every operator of the shaders individually rounded, results bit-identical to the oracle.  With the flag, the smooth
- * arithmetic of the fp32 BRDF and of the overlay's final products is evaluated with fused multiply-adds, hardware rcp / rsq / sqrt and
- * pow(x, 5) as three multiplies, while every discrete decision (depth == 0, cascade selection, box tests, the four PCF compares,
- * N.L <= 0) and every ill-conditioned chain (positions, shadow and LPV texture coordinates and weights, the trilinear sums) keeps the
- * strict operator sequence.  Guard bands on the fp16 roundings, on cancellation and on the D_GGX denominator send every pixel whose
- * result could differ by more than 1 fp16 ULP to the strict restatement (DESIGN.md "Tolerance mode").  Honoured by the fast kernel
- * (sun off / CSM, GI none / LPV, no light list); every other configuration runs strict whatever the flag says. */
-#define SAH_LIGHTING_TOLERANCE_1ULP (1u << 2)
 #define SAH_LIGHTING_DEFAULT_FLAGS (SAH_LIGHTING_QUIRK_SUN_BLEND)
 
 /* One "Lighting" pass: RenderCore/render/phase/lighting_phase.cpp:34-134

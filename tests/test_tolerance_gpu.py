@@ -1,4 +1,4 @@
-"""GPU: the tolerance mode of the Lighting pass (SAH_LIGHTING_TOLERANCE_1ULP, include/sah_hip.h) against the strict mode — and the
+"""GPU, experiment builds only: the "within 1 ULP" mode of the Lighting pass (csrc/params.hpp: kExpLightingTolerance1Ulp) against the strict mode — and the
 strict mode is the one the oracle pins bit for bit (tests/test_lighting_gpu.py).  Bar: every channel of every pixel within 1 ULP of
 the stored fp16 value (BASELINE.json north_star); any pixel beyond that is a bug in a guard band, not noise.  The ULP histogram and
 the share of pixels the guards send to the strict restatement are printed for profiles/."""
@@ -8,17 +8,22 @@ import pytest
 from androidrenderer_amd import _abi, synth
 from tests import util
 
-pytestmark = pytest.mark.gpu
+import os
+
+# The mode is 2.4x slower than the strict kernel (profiles/r2_tolerance_mode_v1.txt) and therefore not in the ABI; the relaxed body is
+# compiled only with SAH_EXTRA_HIPCC_FLAGS=-DSAH_EXP_TOLERANCE_1ULP (python -m androidrenderer_amd.build --force), and these tests run
+# only when SAH_EXP_TOLERANCE_1ULP=1 says the library under test is such a build.
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SAH_EXP_TOLERANCE_1ULP") != "1", reason="needs an experiment build (-DSAH_EXP_TOLERANCE_1ULP)")]
 
 
 def _both(ctx, f, dev=None):
     dev = dev or f.device_arrays()
     strict = f.run_hip(ctx, dev)
     n_strict = ctx.deferred_pixels()
-    f.flags |= _abi.LIGHTING_TOLERANCE_1ULP
+    f.flags |= _abi.EXP_LIGHTING_TOLERANCE_1ULP
     relaxed = f.run_hip(ctx, dev)
     n_relaxed = ctx.deferred_pixels()
-    f.flags &= ~_abi.LIGHTING_TOLERANCE_1ULP
+    f.flags &= ~_abi.EXP_LIGHTING_TOLERANCE_1ULP
     return strict, relaxed, n_strict, n_relaxed
 
 
@@ -47,7 +52,7 @@ def test_tolerance_mode_within_one_ulp(hip_ctx, flavour, sun_mode, gi, flags):
 def test_tolerance_mode_matches_the_oracle_within_one_ulp(hip_ctx):
     f = util.LightingFrame(320, 180, seed=7, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
     ref = f.run_oracle()
-    f.flags |= _abi.LIGHTING_TOLERANCE_1ULP
+    f.flags |= _abi.EXP_LIGHTING_TOLERANCE_1ULP
     got = f.run_hip(hip_ctx)
     d = util.f16_ulp_diff(got, ref)
     print(util.report_ulp("tolerance mode vs oracle", d))

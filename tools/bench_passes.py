@@ -70,11 +70,7 @@ def main():
 
     lighting_case("lighting CSM+LPV atrium (fast)", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, "atrium", 36)
     lighting_case("lighting CSM+LPV random (fast)", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, "random", 36)
-    tol = _abi.LIGHTING_DEFAULT_FLAGS | _abi.LIGHTING_TOLERANCE_1ULP
-    lighting_case("lighting CSM+LPV atrium (fast, tolerance 1 ulp)", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, "atrium", 36, flags=tol)
-    lighting_case("lighting CSM+LPV random (fast, tolerance 1 ulp)", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, "random", 36, flags=tol)
     lighting_case("lighting CSM only atrium (fast)", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, "atrium", 32)
-    lighting_case("lighting CSM only atrium (fast, tolerance 1 ulp)", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, "atrium", 32, flags=tol)
     lighting_case("lighting RT only atrium (fast)", _abi.SHADOW_MODE_RT, _abi.GI_NONE, "atrium", 36)
     lighting_case("lighting RT+LPV atrium (fast)", _abi.SHADOW_MODE_RT, _abi.GI_LPV, "atrium", 40)
     lighting_case("lighting off/none atrium (fast)", _abi.SHADOW_MODE_OFF, _abi.GI_NONE, "atrium", 32)
