@@ -222,6 +222,8 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
     for (void* p : ctx->raster.ptr)
         if (p) (void)hipFree(p);
+    for (void* p : ctx->rt.ptr)
+        if (p) (void)hipFree(p);
     if (ctx->raster.half_to_srgb8) (void)hipFree(ctx->raster.half_to_srgb8);
     if (ctx->raster.host_counters) (void)hipHostFree(ctx->raster.host_counters);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

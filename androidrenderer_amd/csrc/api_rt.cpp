@@ -1,0 +1,214 @@
+// C ABI: ray tracing — sah_rt_build, sah_rtao, sah_sun_shadow_mask (include/sah_hip.h "ray tracing"; kernels in rt.hip).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/sah_hip.h"
+#include "ctx.hpp"
+#include "rt_args.hpp"
+
+namespace sah {
+hipError_t launch_rt_scan(const sah_primitive* prims, uint32_t n, uint32_t* tri_base, RtBuildState* st, hipStream_t s);
+hipError_t launch_rt_world(const RtScene& sc, const uint32_t* tri_base, uint32_t total, RtTriangle* out, RtBuildState* st, hipStream_t s);
+hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsigned long long* keys, uint32_t padded, hipStream_t s);
+hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNode* nodes, const RtBvh& bvh, hipStream_t s);
+hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
+hipError_t launch_sun_shadow_mask(const ShadowMaskArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
+}  // namespace sah
+
+namespace {
+enum Slot { R_TRI_BASE, R_STATE, R_UNSORTED, R_SORTED, R_KEYS, R_NODES };
+
+int ensure(sah_ctx* ctx, int slot, size_t bytes) {
+    auto& r = ctx->rt;
+    if (r.bytes[slot] >= bytes && r.ptr[slot]) return SAH_OK;
+    if (r.ptr[slot]) (void)hipFree(r.ptr[slot]);
+    r.ptr[slot] = nullptr;
+    r.bytes[slot] = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(ctx, hipMalloc(&r.ptr[slot], want));
+    r.bytes[slot] = want;
+    return SAH_OK;
+}
+
+bool plane_fmt(const sah_plane* p, uint32_t fmt, uint32_t bpp) {
+    return p && p->ptr && p->format == fmt && p->width && p->height && (uint64_t)p->row_pitch_bytes >= (uint64_t)p->width * bpp &&
+           ((uintptr_t)p->ptr % bpp) == 0 && (p->row_pitch_bytes % bpp) == 0;
+}
+}  // namespace
+
+extern "C" {
+
+int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats) {
+    SAH_RANGE();
+    using namespace sah;
+    if (!ctx || !scene) return SAH_ERR_INVALID_ARGUMENT;
+    auto& rt = ctx->rt;
+    rt.built = false;
+    if (scene->num_primitives && (!scene->primitives || !scene->indices || !scene->vertex_positions))
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "scene arrays are null");
+    if (scene->num_primitives >= (1u << 24)) return fail(ctx, SAH_ERR_UNSUPPORTED, "too many primitives");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RtScene sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.positions = scene->vertex_positions;
+    sc.vertex_data = scene->vertex_data;
+    sc.indices = scene->indices;
+    sc.primitives = scene->primitives;
+    sc.materials = scene->materials;
+    sc.num_primitives = scene->num_primitives;
+    sc.num_indices = scene->num_indices;
+    sc.num_vertices = scene->num_vertices;
+    sc.num_materials = scene->num_materials;
+    sc.textures = scene->num_textures ? scene->textures : nullptr;
+    sc.material_textures = (scene->num_textures && scene->textures) ? scene->material_textures : nullptr;
+    sc.num_textures = scene->num_textures;
+    sc.luts = ctx->luts;
+    RtBvh bvh;
+    memset(&bvh, 0, sizeof(bvh));
+    RtBuildState host;
+    memset(&host, 0, sizeof(host));
+    if (scene->num_primitives) {
+        if (int rc = ensure(ctx, R_TRI_BASE, (size_t)(scene->num_primitives + 1) * sizeof(uint32_t)); rc != SAH_OK) return rc;
+        if (int rc = ensure(ctx, R_STATE, sizeof(RtBuildState)); rc != SAH_OK) return rc;
+        auto* st = (RtBuildState*)rt.ptr[R_STATE];
+        HIP_TRY(ctx, launch_rt_scan(scene->primitives, scene->num_primitives, (uint32_t*)rt.ptr[R_TRI_BASE], st, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t total = host.total;
+        if (total >= kRtMaxTriangles) return fail(ctx, SAH_ERR_UNSUPPORTED, "%u triangles: the structure holds fewer than %u", total, kRtMaxTriangles);
+        if (total) {
+            uint32_t padded = kRtSortChunk;
+            while (padded < total) padded <<= 1;
+            if (int rc = ensure(ctx, R_UNSORTED, (size_t)total * sizeof(RtTriangle)); rc != SAH_OK) return rc;
+            if (int rc = ensure(ctx, R_SORTED, (size_t)total * sizeof(RtTriangle)); rc != SAH_OK) return rc;
+            if (int rc = ensure(ctx, R_KEYS, (size_t)padded * sizeof(unsigned long long)); rc != SAH_OK) return rc;
+            HIP_TRY(ctx, launch_rt_world(sc, (const uint32_t*)rt.ptr[R_TRI_BASE], total, (RtTriangle*)rt.ptr[R_UNSORTED], st, ctx->stream));
+            HIP_TRY(ctx, launch_rt_sort((const RtTriangle*)rt.ptr[R_UNSORTED], st, (unsigned long long*)rt.ptr[R_KEYS], padded, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            bvh.num_tris = host.kept;
+            float S;
+            memcpy(&S, &host.max_abs_bits, 4);
+            bvh.pad = S * 0x1p-16f;
+            uint32_t count = (bvh.num_tris + kRtFanout - 1) / kRtFanout, offset = 0, levels = 0;
+            while (bvh.num_tris) {
+                bvh.level_offset[levels] = offset;
+                bvh.level_count[levels] = count;
+                offset += count;
+                levels++;
+                if (count == 1) break;
+                count = (count + kRtFanout - 1) / kRtFanout;
+            }
+            bvh.num_levels = levels;
+            if (bvh.num_tris) {
+                if (int rc = ensure(ctx, R_NODES, (size_t)offset * sizeof(RtNode)); rc != SAH_OK) return rc;
+                bvh.tris = (const RtTriangle*)rt.ptr[R_SORTED];
+                bvh.nodes = (const RtNode*)rt.ptr[R_NODES];
+                HIP_TRY(ctx, launch_rt_nodes((const RtTriangle*)rt.ptr[R_UNSORTED], (const unsigned long long*)rt.ptr[R_KEYS], (RtTriangle*)rt.ptr[R_SORTED],
+                                             (RtNode*)rt.ptr[R_NODES], bvh, ctx->stream));
+            }
+        }
+    }
+    rt.bvh = bvh;
+    rt.scene = sc;
+    rt.built = true;
+    if (stats) {
+        stats[0] = bvh.num_tris;
+        stats[1] = host.dropped;
+        stats[2] = bvh.num_levels;
+        stats[3] = 0;
+    }
+    return SAH_OK;
+}
+
+static int check_cutout_inputs(sah_ctx* ctx) {
+    // the any-hit stage reads vertex colours, texcoords and materials: a structure built without them cannot shade CUTOUT candidates
+    const sah::RtScene& sc = ctx->rt.scene;
+    if (ctx->rt.bvh.num_tris && (!sc.vertex_data || !sc.materials || sc.num_materials == 0))
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the scene given to sah_rt_build has no vertex data / materials (needed by the any-hit stage)");
+    return SAH_OK;
+}
+
+int sah_rtao(sah_ctx* ctx, const sah_view_data* view, const sah_plane* depth, const sah_plane* normals, const sah_plane* noise,
+             uint32_t samples_per_pixel, float max_ray_distance, const sah_plane* ao_out) {
+    SAH_RANGE();
+    using namespace sah;
+    if (!ctx || !view) return SAH_ERR_INVALID_ARGUMENT;
+    if (!ctx->rt.built) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_rt_build has not been called on this context");
+    if (!plane_fmt(ao_out, SAH_FORMAT_R32_SFLOAT, 4)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "ao_out must be an R32_SFLOAT plane");
+    const uint32_t W = ao_out->width, H = ao_out->height;
+    if (!plane_fmt(depth, depth ? depth->format : 0, 4) || (depth->format != SAH_FORMAT_D32_SFLOAT && depth->format != SAH_FORMAT_R32_SFLOAT) ||
+        depth->width != W || depth->height != H)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "depth must be D32_SFLOAT of ao_out's extent");
+    if (!plane_fmt(normals, SAH_FORMAT_R16G16B16A16_SFLOAT, 8) || normals->width != W || normals->height != H)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "normals must be R16G16B16A16_SFLOAT of ao_out's extent");
+    if (!plane_fmt(noise, SAH_FORMAT_R8G8B8A8_UNORM, 4) || noise->width > 65535 || noise->height > 65535)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "noise must be R8G8B8A8_UNORM with an extent that fits uint16");
+    if (samples_per_pixel > 4096) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "samples_per_pixel > 4096");
+    RtaoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.depth = parg(depth);
+    a.normals = parg(normals);
+    a.noise = parg(noise);
+    a.out = parg(ao_out);
+    a.width = W;
+    a.height = H;
+    a.noise_w = noise->width;
+    a.noise_h = noise->height;
+    memcpy(a.inv_proj, view->inverse_projection, 64);
+    memcpy(a.inv_view, view->inverse_view, 64);
+    a.res[0] = view->render_resolution[0];
+    a.res[1] = view->render_resolution[1];
+    a.samples = samples_per_pixel;
+    a.max_distance = max_ray_distance;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_rtao(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_plane* depth,
+                        const sah_plane* normals, const sah_plane* noise, const sah_plane* mask_out) {
+    SAH_RANGE();
+    using namespace sah;
+    if (!ctx || !view || !sun) return SAH_ERR_INVALID_ARGUMENT;
+    if (!ctx->rt.built) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_rt_build has not been called on this context");
+    if (int rc = check_cutout_inputs(ctx); rc != SAH_OK) return rc;
+    if (!plane_fmt(mask_out, SAH_FORMAT_R32_SFLOAT, 4)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "mask_out must be an R32_SFLOAT plane");
+    const uint32_t W = mask_out->width, H = mask_out->height;
+    if (!plane_fmt(depth, depth ? depth->format : 0, 4) || (depth->format != SAH_FORMAT_D32_SFLOAT && depth->format != SAH_FORMAT_R32_SFLOAT) ||
+        depth->width != W || depth->height != H)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "depth must be D32_SFLOAT of mask_out's extent");
+    if (!plane_fmt(normals, SAH_FORMAT_R16G16B16A16_SFLOAT, 8) || normals->width != W || normals->height != H)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "normals must be R16G16B16A16_SFLOAT of mask_out's extent");
+    if (!plane_fmt(noise, SAH_FORMAT_R8G8B8A8_UNORM, 4) || noise->width < 128 || noise->height < 128)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "noise must be R8G8B8A8_UNORM, at least 128 x 128");
+    if (!(sun->num_shadow_samples >= 0.0f && sun->num_shadow_samples <= 4096.0f))
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "num_shadow_samples must be in [0, 4096]");
+    ShadowMaskArgs a;
+    memset(&a, 0, sizeof(a));
+    a.depth = parg(depth);
+    a.normals = parg(normals);
+    a.noise = parg(noise);
+    a.out = parg(mask_out);
+    a.width = W;
+    a.height = H;
+    memcpy(a.inv_proj, view->inverse_projection, 64);
+    memcpy(a.inv_view, view->inverse_view, 64);
+    a.res[0] = view->render_resolution[0];
+    a.res[1] = view->render_resolution[1];
+    {  // normalize(-direction): x * (1 / sqrt(dot)), every operator rounded (this file is built with -ffp-contract=off)
+        const float n[3] = {-sun->direction_and_tan_size[0], -sun->direction_and_tan_size[1], -sun->direction_and_tan_size[2]};
+        const float d = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+        const float inv = 1.0f / std::sqrt(d);
+        for (int i = 0; i < 3; i++) a.L[i] = n[i] * inv;
+    }
+    a.tan_size = sun->direction_and_tan_size[3];
+    a.num_samples = sun->num_shadow_samples;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_sun_shadow_mask(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
+    return SAH_OK;
+}
+
+}  // extern "C"

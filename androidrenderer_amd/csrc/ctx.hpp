@@ -8,6 +8,7 @@
 
 #include "../../include/sah_hip.h"
 #include "params.hpp"
+#include "rt_args.hpp"
 
 struct sah_ctx {
     int device = 0;
@@ -42,6 +43,13 @@ struct sah_ctx {
         uint8_t* half_to_srgb8 = nullptr;
         uint32_t* host_counters = nullptr;  // pinned, 16 words
     } raster;
+    struct RtState {                   // acceleration structure of sah_rt_build (api_rt.cpp); buffers grow on demand
+        void* ptr[6] = {};             // tri_base, build state, unsorted triangles, sorted triangles, keys, nodes
+        size_t bytes[6] = {};
+        sah::RtBvh bvh = {};
+        sah::RtScene scene = {};
+        bool built = false;
+    } rt;
     uint32_t raster_merge_cap = 2048;  // tiles whose bin list may be split (testing hook SAH_RASTER_MERGE_CAPACITY: 0 = every list whole)
     std::string last_error;
 };

@@ -1,0 +1,82 @@
+// Argument blocks of the ray tracer (rt.hip, api_rt.cpp): the scene arrays captured by sah_rt_build, the acceleration structure, and
+// the two ray generators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sah_hip.h"
+#include "params.hpp"
+
+namespace sah {
+
+constexpr uint32_t kRtFanout = 4;       // children per node, triangles per leaf node
+constexpr uint32_t kRtMaxLevels = 14;   // 4^14 leaves' worth: more than kRtMaxTriangles needs
+constexpr uint32_t kRtMaxTriangles = 1u << 26;  // stack entries carry (level << 28 | index)
+constexpr uint32_t kRtSortChunk = 2048; // keys one workgroup sorts in LDS
+
+// One world-space triangle, as the traversal reads it: three 16-byte words
+//   {v0.xyz, primitive} {v1.xyz, triangle-in-primitive} {v2.xyz, flags}      flags bit 0: CUTOUT primitive
+struct RtTriangle {
+    float v0[3];
+    uint32_t primitive;
+    float v1[3];
+    uint32_t triangle;
+    float v2[3];
+    uint32_t flags;
+};
+static_assert(sizeof(RtTriangle) == 48, "RtTriangle layout");
+
+struct RtNode {  // padded box of a group of kRtFanout children
+    float lo[3], hi0;  // hi0 = hi[0]
+    float hi1, hi2, pad0, pad1;
+};
+static_assert(sizeof(RtNode) == 32, "RtNode layout");
+
+struct RtScene {  // device pointers of the sah_scene_geometry given to sah_rt_build
+    const float* positions;
+    const sah_vertex_data* vertex_data;
+    const uint32_t* indices;
+    const sah_primitive* primitives;
+    const sah_material* materials;
+    uint32_t num_primitives, num_indices, num_vertices, num_materials;
+    const sah_texture* textures;
+    const sah_material_textures* material_textures;
+    uint32_t num_textures;
+    const float* luts;  // 256 sRGB8 -> linear, 256 UNORM8 -> float
+};
+
+struct RtBvh {
+    const RtTriangle* tris;  // Morton order
+    const RtNode* nodes;     // level 0 first: level L starts at level_offset[L] and has level_count[L] nodes; the top level has one
+    uint32_t num_tris, num_levels;
+    uint32_t level_offset[kRtMaxLevels], level_count[kRtMaxLevels];
+    float pad;  // S * 2^-16 (sah_hip.h "pad")
+};
+
+// device scalars of a build: [0] running triangles kept, [1] left out, [2] max |coordinate| bits, [3..5] min / [6..8] max of the triangle
+// box centres as order-preserving integers
+struct RtBuildState {
+    uint32_t kept, dropped, max_abs_bits;
+    uint32_t cmin[3], cmax[3];
+    uint32_t total;  // triangles of all primitives (scan total)
+};
+
+struct RtaoArgs {
+    PlaneArg depth, normals, noise, out;
+    uint32_t width, height, noise_w, noise_h;
+    float inv_proj[16], inv_view[16];
+    float res[2];
+    uint32_t samples;
+    float max_distance;
+};
+
+struct ShadowMaskArgs {
+    PlaneArg depth, normals, noise, out;
+    uint32_t width, height;
+    float inv_proj[16], inv_view[16];
+    float res[2];
+    float L[3];  // normalize(-direction), fp32
+    float tan_size, num_samples;
+};
+
+}  // namespace sah

@@ -23,7 +23,7 @@ _lib = None
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
-           "sah_lpv_inject_vpls", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
+           "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
 
 
 def load():
@@ -74,6 +74,11 @@ def load():
                                          C.c_void_p]
     lib.sah_lpv_inject_vpls.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_uint32,
                                         C.POINTER(_abi.Volume)]
+    lib.sah_rt_build.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(C.c_uint32)]
+    lib.sah_rtao.argtypes = [C.c_void_p, C.POINTER(_abi.ViewData), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.c_uint32, C.c_float,
+                             C.POINTER(_abi.Plane)]
+    lib.sah_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane),
+                                        C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
@@ -179,6 +184,21 @@ class Context:
         vols = (_abi.Volume * 3)(*rgb)
         self._check(self.lib.sah_lpv_inject_vpls(self.handle, C.c_void_p(vpl_list_ptr), C.c_void_p(vpl_count_ptr), capacity, cascades, cascade_index,
                                                  num_cascades, vols))
+
+    def rt_build(self, scene):
+        """(Re)builds the context's acceleration structure over `scene` (_abi.SceneGeometry of device addresses, which must stay alive while
+        rays are traced); returns [triangles kept, left out, levels, 0]."""
+        stats = (C.c_uint32 * _abi.RT_STATS_WORDS)()
+        self._check(self.lib.sah_rt_build(self.handle, C.byref(scene), stats))
+        self._rt_scene = scene  # keeps the descriptor's arrays alive
+        return list(stats)
+
+    def rtao(self, view, depth, normals, noise, samples_per_pixel, max_ray_distance, ao_out):
+        self._check(self.lib.sah_rtao(self.handle, C.byref(view), C.byref(depth), C.byref(normals), C.byref(noise), samples_per_pixel, max_ray_distance,
+                                      C.byref(ao_out)))
+
+    def sun_shadow_mask(self, view, sun, depth, normals, noise, mask_out):
+        self._check(self.lib.sah_sun_shadow_mask(self.handle, C.byref(view), C.byref(sun), C.byref(depth), C.byref(normals), C.byref(noise), C.byref(mask_out)))
 
     def allgather_rows(self, image, rows_per_rank, allocated_rows=None):
         """image: _abi.Plane over a buffer of `allocated_rows` (default image.height) rows; in place, on the context's stream."""

@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
+    ap.add_argument("--ramp-ms", type=float, default=200.0, help="untimed: run the step back to back for this long before the W warm-up steps, so that the "
+                    "timed region does not start in the GPU's idle power state (reported in config.clock_ramp_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
     args = ap.parse_args()
@@ -386,6 +388,15 @@ def main():
             del ref
         torch.cuda.empty_cache()
 
+    if args.ramp_ms > 0:
+        t_ramp = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            for _ in range(8):
+                step(k)
+                k += 1
+            drain()
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     drain()
@@ -472,6 +483,7 @@ def main():
                 "workload": f"{args.workload}: {W}x{H} {what}, {wl['gbuffer']} G-buffer"
                             + (" (G-buffer, shadow cascades and LPV made on the GPU by the producer passes)" if wl.get("produced") else ""),
                 "resolution": [W, H],
+                "clock_ramp_ms": args.ramp_ms,
                 "gbuffer": wl["gbuffer"],
                 "parallelism": par,
                 "gather": bool(gather),

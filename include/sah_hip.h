@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SAH_ABI_VERSION 3
+#define SAH_ABI_VERSION 4
 
 typedef enum sah_status {
     SAH_OK = 0,
@@ -452,6 +452,67 @@ int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv
  * added in list order, each sum rounded to half (what the blend unit does in primitive order). */
 int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint32_t* vpl_count, uint32_t capacity,
                         const sah_lpv_cascade_matrices* cascades, uint32_t cascade_index, uint32_t num_cascades, const sah_volume rgb[3]);
+
+/* ---- ray tracing: the acceleration structure and the two generators whose outputs sah_lighting consumes ----------
+ * The reference traces against a Vulkan TLAS with one instance per primitive (RenderCore/render/raytracing_scene.cpp:15-43: transform
+ * = primitive.model, SOLID -> FORCE_OPAQUE, CUTOUT -> FORCE_NO_OPAQUE, both faces hit) over per-mesh BLASes.  What a ray hits is then
+ * the implementation's business (traversal order, intersection arithmetic, watertightness).  This library fixes it:
+ *
+ *   triangles   world space: vertex k = model * (p_k, 1), each row ((m0 x + m1 y) + m2 z) + m3 in fp32 (the rasteriser's vertex stage);
+ *               a triangle with a non-finite world vertex, or an index outside the arrays, is not in the structure.
+ *   pad         S * 2^-16, S = the largest |coordinate| of the world vertices in the structure (fp32 product).
+ *   box test    box(T) = [min_k v_k - pad, max_k v_k + pad] per axis (fp32).  slab(ray, box): per axis inv = 1 / d (IEEE, +-inf for
+ *               +-0), t0 = (lo - o) * inv, t1 = (hi - o) * inv, near = minNum(t0, t1), far = maxNum(t0, t1) (a NaN operand is ignored);
+ *               passes iff maxNum(maxNum(maxNum(near_x, near_y), near_z), tmin) <= minNum(minNum(minNum(far_x, far_y), far_z), tmax).
+ *   triangle    Woop / Benthin / Wald 2013, every operator an fp32 operation: kz = axis of the largest |d| (first of equals), kx, ky
+ *               the next two axes cyclically, swapped when d[kz] < 0; Sx = d[kx] / d[kz], Sy = d[ky] / d[kz], Sz = 1 / d[kz];
+ *               A = v0 - o (likewise B, C), Ax = A[kx] - Sx * A[kz], Ay = A[ky] - Sy * A[kz];
+ *               U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax; when one of them is exactly 0 all three are
+ *               recomputed in fp64 from the same fp32 operands (exact products, one rounding) and rounded to fp32;
+ *               miss when (U < 0 or V < 0 or W < 0) and (U > 0 or V > 0 or W > 0); det = (U + V) + W, miss when det == 0;
+ *               T = (U * (Sz * A[kz]) + V * (Sz * B[kz])) + W * (Sz * C[kz]);  t = T / det;  barycentrics (V / det, W / det) are the
+ *               weights of v1 and v2 (the `barycentrics` attribute of the hit shaders).
+ *   hit         candidate(ray, T) <=> slab(ray, box(T)) passes and the triangle test gives tmin < t < tmax (NaN compares false).
+ *               Making the padded box part of the DEFINITION is what lets a box hierarchy cull exactly: slab() is monotone under box
+ *               inclusion in fp32, so a parent box never rejects a ray its child accepts, and the result is the same as testing
+ *               every triangle — which is what the oracle does.
+ *   any hit     an occlusion ray asks "is there an accepted candidate": a candidate on a SOLID primitive is accepted; one on a CUTOUT
+ *               primitive runs the any-hit stage of RenderCore/shaders/materials/gltf_basic_pbr.slang:291-318 — texcoord
+ *               (b0 t0 + b1 t1) + b2 t2 with b0 = (1 - b1) - b2 in fp32, vertex colour through unpackUnorm4x8ToHalf / packUnorm4x8
+ *               (half arithmetic, truncating pack), base-colour texture at level 0 (SampleLevel: lambda = 0 + sampler bias, clamped,
+ *               then the rules of sah_texture), alpha = (texel.a * tint.a) * colour.a in fp32 — and is ignored when
+ *               alpha <= opacity_threshold.  Existence does not depend on the order in which candidates are found.
+ * The structure itself (an implicit 4-wide hierarchy over Morton-sorted triangles, built on the GPU) is an implementation detail. */
+
+/* RaytracingScene::add_primitive / commit_tlas_builds — RenderCore/render/raytracing_scene.cpp:15-170 (and the BLAS builds behind
+ * mesh->blas): (re)builds the context's acceleration structure over every primitive of `scene`.  The arrays `scene` points to must stay
+ * valid and unchanged while rays are traced (the any-hit stage reads vertex_data, materials and textures).  Synchronises the context's
+ * stream once (the triangle count is read back).  stats: HOST pointer to 4 words or NULL — [0] triangles in the structure, [1] triangles
+ * left out (non-finite, bad indices), [2] hierarchy levels, [3] reserved. */
+#define SAH_RT_STATS_WORDS 4
+int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats);
+
+/* AmbientOcclusionPhase::evaluate_rtao — RenderCore/render/phase/ambient_occlusion_phase.cpp:357-397 with
+ * RenderCore/shaders/ao/rtao.comp.slang:54-102: one invocation per texel of ao_out (R32_SFLOAT).  Ray origin = the Slang world-space
+ * position of the pixel ((pixel + 0.5) / render_resolution, every component divided by w), direction = normalize(noise[pixel % noise
+ * extent].rgb * 2 - 1) flipped into the hemisphere of normalize((half3)normal), [0.01, max_ray_distance], RAY_FLAG_ACCEPT_FIRST_HIT_AND_
+ * END_SEARCH | RAY_FLAG_CULL_NON_OPAQUE (CUTOUT primitives are invisible to it); ao = (spp - hits) / spp.  Kept quirks: every one of
+ * the samples_per_pixel rays reads the same noise texel, so they are one ray; no depth == 0 test (a sky pixel's origin is not finite,
+ * nothing is hit, ao = 1); the unused rotation matrix.  noise: R8G8B8A8_UNORM (a blue-noise layer, RenderCore/render/noise_texture.cpp),
+ * extent <= 65535; samples_per_pixel <= 4096.  depth: D32_SFLOAT, normals: R16G16B16A16_SFLOAT, both of ao_out's extent. */
+int sah_rtao(sah_ctx* ctx, const sah_view_data* view, const sah_plane* depth, const sah_plane* normals, const sah_plane* noise,
+             uint32_t samples_per_pixel, float max_ray_distance, const sah_plane* ao_out);
+
+/* The shadow rays of DirectionalLight::raytrace — RenderCore/render/directional_light.cpp:372-422 with
+ * RenderCore/shaders/lighting/directional_light.rt.slang:91-125 and the occlusion hit groups of gltf_basic_pbr.slang:291-325 / the
+ * occlusion miss shader of sky_unified.slang:210-215: writes shadow / num_shadow_samples, the factor the raygen shader multiplies the sun
+ * radiance with, to mask_out (R32_SFLOAT) — the `shadow_mask` plane of sah_lighting's RT mode, which evaluates the rest of that shader.
+ * For sample i the ray leaves the pixel's world-space position towards normalize(L + noise_i * tan_size), L = normalize(-direction),
+ * noise_i = normalize(noise[(pixel + round(r0(i) * 128)) % 128].rgb * 2 - 1), r0(i) = (fract(2 + i / PHI), fract(3 + i / PHI)) with
+ * PHI = 1.618033988749895 as fp32, round() to nearest even; [0.01, 100000]; shadow counts the rays that hit nothing.  Pixels the shader
+ * does not trace for (depth == 0, or (half)clamp(dot(L, normal), 0, 1) == 0) get 1.0.  noise: R8G8B8A8_UNORM, at least 128 x 128. */
+int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_plane* depth,
+                        const sah_plane* normals, const sah_plane* noise, const sah_plane* mask_out);
 
 /* Multi-GPU exchange step (no reference counterpart: the reference drives one device, RenderCore/render/backend/render_backend.cpp:135-153;
  * BASELINE.json north_star: "RCCL all-gather over xGMI to reassemble the final image").

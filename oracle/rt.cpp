@@ -1,0 +1,276 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// CPU restatement of the ray-tracing half of SURVEY.md §8-f4, first slice:
+//   RTAO               RenderCore/shaders/ao/rtao.comp.slang:54-102 (host: render/phase/ambient_occlusion_phase.cpp:357-397)
+//   sun shadow rays    RenderCore/shaders/lighting/directional_light.rt.slang:91-125 (host: render/directional_light.cpp:372-422)
+//   occlusion hit group / miss  RenderCore/shaders/materials/gltf_basic_pbr.slang:291-325, shaders/sky/sky_unified.slang:210-215
+//   instances          RenderCore/render/raytracing_scene.cpp:15-43 (transform = model, SOLID opaque, CUTOUT non-opaque, no face culling)
+// What a ray hits is the implementation's business in Vulkan; include/sah_hip.h ("ray tracing") fixes it.  This file tests EVERY
+// triangle against every ray — no acceleration structure — which the definition makes equivalent to any box hierarchy.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/sah_hip.h"
+#include "codec.hpp"
+#include "math.hpp"
+#include "texture.hpp"
+
+namespace orc {
+F3 worldspace_location_slang(const sah_view_data& view, int x, int y, float depth);  // lighting.cpp
+
+namespace {
+
+struct WorldTriangle {
+    float v[3][3];
+    uint32_t primitive, triangle;
+    bool cutout;
+};
+struct RtStructure {
+    std::vector<WorldTriangle> tris;
+    float pad = 0.0f;
+    uint32_t dropped = 0;
+};
+
+bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+// world = model * (p, 1), rows ((m0 x + m1 y) + m2 z) + m3 (the rasteriser's vertex stage, raster.cpp: process_triangle)
+RtStructure build(const sah_scene_geometry& g) {
+    RtStructure s;
+    float S = 0.0f;
+    for (uint32_t p = 0; p < g.num_primitives; p++) {
+        const sah_primitive& prim = g.primitives[p];
+        for (uint32_t tri = 0; tri < prim.index_count / 3; tri++) {
+            WorldTriangle w;
+            bool ok = (uint64_t)prim.first_index + 3ull * tri + 2ull < (uint64_t)g.num_indices;
+            for (int k = 0; k < 3 && ok; k++) {
+                const int64_t vi = (int64_t)prim.vertex_offset + (int64_t)g.indices[prim.first_index + 3 * tri + k];
+                ok = vi >= 0 && vi < (int64_t)g.num_vertices;
+                if (!ok) break;
+                const float* pos = g.vertex_positions + 3 * vi;
+                const float* m = prim.model;
+                for (int c = 0; c < 3; c++) w.v[k][c] = ((F(m[c]) * F(pos[0]) + F(m[4 + c]) * F(pos[1])) + F(m[8 + c]) * F(pos[2]) + F(m[12 + c])).v;
+                ok = finite3(w.v[k]);
+            }
+            if (!ok) { s.dropped++; continue; }
+            w.primitive = p;
+            w.triangle = tri;
+            w.cutout = prim.type == SAH_PRIMITIVE_TYPE_CUTOUT;
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < 3; c++) S = std::fmax(S, std::fabs(w.v[k][c]));
+            s.tris.push_back(w);
+        }
+    }
+    s.pad = S * 0x1p-16f;
+    return s;
+}
+
+struct Ray {
+    float o[3], d[3], inv[3], tmin, tmax;
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+    bool finite;
+};
+Ray make_ray(const float o[3], const float d[3], float tmin, float tmax) {
+    Ray r;
+    for (int c = 0; c < 3; c++) { r.o[c] = o[c]; r.d[c] = d[c]; r.inv[c] = 1.0f / d[c]; }
+    r.tmin = tmin; r.tmax = tmax;
+    r.finite = finite3(o) && finite3(d);
+    int kz = 0;
+    float am = std::fabs(d[0]);
+    if (std::fabs(d[1]) > am) { kz = 1; am = std::fabs(d[1]); }
+    if (std::fabs(d[2]) > am) { kz = 2; }
+    int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
+    if (d[kz] < 0.0f) std::swap(kx, ky);
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = d[kx] / d[kz];
+    r.Sy = d[ky] / d[kz];
+    r.Sz = 1.0f / d[kz];
+    return r;
+}
+
+bool slab(const Ray& r, const float lo[3], const float hi[3]) {
+    float tn = r.tmin, tf = r.tmax;
+    for (int c = 0; c < 3; c++) {
+        const float t0 = (lo[c] - r.o[c]) * r.inv[c], t1 = (hi[c] - r.o[c]) * r.inv[c];
+        tn = std::fmax(tn, std::fmin(t0, t1));
+        tf = std::fmin(tf, std::fmax(t0, t1));
+    }
+    return tn <= tf;
+}
+
+struct Hit { float t, b1, b2; };
+bool woop(const Ray& r, const WorldTriangle& w, Hit& h) {
+    float A[3], B[3], C[3];
+    for (int c = 0; c < 3; c++) { A[c] = w.v[0][c] - r.o[c]; B[c] = w.v[1][c] - r.o[c]; C[c] = w.v[2][c] - r.o[c]; }
+    const float Ax = A[r.kx] - r.Sx * A[r.kz], Ay = A[r.ky] - r.Sy * A[r.kz];
+    const float Bx = B[r.kx] - r.Sx * B[r.kz], By = B[r.ky] - r.Sy * B[r.kz];
+    const float Cx = C[r.kx] - r.Sx * C[r.kz], Cy = C[r.ky] - r.Sy * C[r.kz];
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * A[r.kz], Bz = r.Sz * B[r.kz], Cz = r.Sz * C[r.kz];
+    const float T = (U * Az + V * Bz) + W * Cz;
+    const float t = T / det;
+    if (!(t > r.tmin && t < r.tmax)) return false;
+    h.t = t; h.b1 = V / det; h.b2 = W / det;
+    return true;
+}
+
+H unpack_alpha(uint32_t packed) { return H((float)(packed >> 24)) / H::lit(255.0); }
+uint32_t to_uint_sat(float f) { return f > 0.0f ? (f >= 4294967296.0f ? 0xffffffffu : (uint32_t)f) : 0u; }
+
+// gltf_basic_pbr.slang:291-318 (SAH_RT_OCCLUSION, SAH_MASKED any-hit): true = accepted
+bool cutout_accepts(const sah_scene_geometry& g, const WorldTriangle& w, const Hit& h) {
+    const sah_primitive& prim = g.primitives[w.primitive];
+    const uint32_t* idx = g.indices + prim.first_index + 3 * w.triangle;
+    const sah_vertex_data& a = g.vertex_data[(int64_t)prim.vertex_offset + idx[0]];
+    const sah_vertex_data& b = g.vertex_data[(int64_t)prim.vertex_offset + idx[1]];
+    const sah_vertex_data& c = g.vertex_data[(int64_t)prim.vertex_offset + idx[2]];
+    const F b0 = (F(1.0f) - F(h.b1)) - F(h.b2), b1 = F(h.b1), b2 = F(h.b2);  // float3(1.f - bary.x - bary.y, bary.x, bary.y)
+    float uv[2];
+    for (int k = 0; k < 2; k++) uv[k] = ((b0 * F(a.texcoord[k]) + b1 * F(b.texcoord[k])) + b2 * F(c.texcoord[k])).v;
+    const F ca = (b0 * F(unpack_alpha(a.color).v) + b1 * F(unpack_alpha(b.color).v)) + b2 * F(unpack_alpha(c.color).v);
+    const uint32_t alpha_byte = to_uint_sat((H(ca.v) * H::lit(255.0)).v) & 0xffu;  // packUnorm4x8: (uint)(value.w * 255.h)
+    const H colour_a = H((float)alpha_byte) / H::lit(255.0);                        // unpackUnorm4x8ToHalf(v.color).w
+    const sah_material& m = g.materials[prim.material];
+    float texel_a = m.base_color_texel[3];
+    if (g.material_textures && g.textures && g.num_textures) {
+        const uint32_t ti = g.material_textures[prim.material].base_color;
+        if (ti != SAH_TEXTURE_NONE) {
+            float texel[4];
+            sample_texture_lod(g.textures[ti], uv, 0.0f, 0.0f, texel);
+            texel_a = texel[3];
+        }
+    }
+    const F alpha = (F(texel_a) * F(m.base_color_tint[3])) * F(colour_a.v);
+    return !(alpha.v <= m.opacity_threshold);
+}
+
+bool any_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, bool cull_non_opaque) {
+    if (!r.finite) return false;
+    for (const WorldTriangle& w : s.tris) {
+        if (cull_non_opaque && w.cutout) continue;
+        float lo[3], hi[3];
+        for (int c = 0; c < 3; c++) {
+            lo[c] = std::fmin(std::fmin(w.v[0][c], w.v[1][c]), w.v[2][c]) - s.pad;
+            hi[c] = std::fmax(std::fmax(w.v[0][c], w.v[1][c]), w.v[2][c]) + s.pad;
+        }
+        if (!slab(r, lo, hi)) continue;
+        Hit h;
+        if (!woop(r, w, h)) continue;
+        if (!w.cutout || cutout_accepts(g, w, h)) return true;
+    }
+    return false;
+}
+
+bool scene_ok(const sah_scene_geometry* g) {
+    if (!g) return false;
+    if (g->num_primitives && (!g->primitives || !g->indices || !g->vertex_positions)) return false;
+    return true;
+}
+bool plane_is(const sah_plane* p, uint32_t fmt) { return p && p->ptr && p->format == fmt; }
+
+H3 load_normal(const sah_plane& p, int x, int y) {
+    uint16_t h[4];
+    std::memcpy(h, (const uint8_t*)p.ptr + (size_t)y * p.row_pitch_bytes + (size_t)x * 8, 8);
+    return normalize(H3{H::raw(f16_to_f32(h[0])), H::raw(f16_to_f32(h[1])), H::raw(f16_to_f32(h[2]))});
+}
+F3 load_noise(const sah_plane& p, uint32_t x, uint32_t y) {
+    const uint8_t* t = (const uint8_t*)p.ptr + (size_t)y * p.row_pitch_bytes + (size_t)x * 4;
+    const F3 v = {F(unorm8_to_float(t[0])) * F(2.0f) - F(1.0f), F(unorm8_to_float(t[1])) * F(2.0f) - F(1.0f), F(unorm8_to_float(t[2])) * F(2.0f) - F(1.0f)};
+    return normalize(v);
+}
+float load_f32(const sah_plane& p, int x, int y) {
+    float f;
+    std::memcpy(&f, (const uint8_t*)p.ptr + (size_t)y * p.row_pitch_bytes + (size_t)x * 4, 4);
+    return f;
+}
+
+}  // namespace
+}  // namespace orc
+
+extern "C" {
+
+// stats (4 words, may be null): triangles kept, left out, 0, 0
+int orc_rt_stats(const sah_scene_geometry* scene, uint32_t* stats, float* pad) {
+    using namespace orc;
+    if (!scene_ok(scene)) return SAH_ERR_INVALID_ARGUMENT;
+    const RtStructure s = build(*scene);
+    if (stats) { stats[0] = (uint32_t)s.tris.size(); stats[1] = s.dropped; stats[2] = 0; stats[3] = 0; }
+    if (pad) *pad = s.pad;
+    return SAH_OK;
+}
+
+int orc_rtao(const sah_scene_geometry* scene, const sah_view_data* view, const sah_plane* depth, const sah_plane* normals, const sah_plane* noise,
+             uint32_t samples_per_pixel, float max_ray_distance, const sah_plane* ao_out) {
+    using namespace orc;
+    if (!scene_ok(scene) || !view || !plane_is(ao_out, SAH_FORMAT_R32_SFLOAT) || !depth || !depth->ptr || !plane_is(normals, SAH_FORMAT_R16G16B16A16_SFLOAT) ||
+        !plane_is(noise, SAH_FORMAT_R8G8B8A8_UNORM) || samples_per_pixel > 4096)
+        return SAH_ERR_INVALID_ARGUMENT;
+    const RtStructure s = build(*scene);
+    const int W = (int)ao_out->width, Hh = (int)ao_out->height;
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < Hh; y++)
+        for (int x = 0; x < W; x++) {
+            const F3 pos = worldspace_location_slang(*view, x, y, load_f32(*depth, x, y));  // rtao.comp.slang:27-36
+            const H3 normal = load_normal(*normals, x, y);
+            F3 n = load_noise(*noise, (uint32_t)x % noise->width, (uint32_t)y % noise->height);
+            if (dot(n, to_f(normal)).v < 0.0f) n = n * F(-1.0f);
+            const float o[3] = {pos.x.v, pos.y.v, pos.z.v}, d[3] = {n.x.v, n.y.v, n.z.v};
+            float ao = (float)samples_per_pixel;
+            for (uint32_t i = 0; i < samples_per_pixel; i++)  // the same noise texel every time: the same ray
+                if (any_hit(*scene, s, make_ray(o, d, 0.01f, max_ray_distance), /*cull_non_opaque=*/true)) ao -= 1.0f;
+            ao /= (float)samples_per_pixel;
+            std::memcpy((uint8_t*)ao_out->ptr + (size_t)y * ao_out->row_pitch_bytes + (size_t)x * 4, &ao, 4);
+        }
+    return SAH_OK;
+}
+
+int orc_sun_shadow_mask(const sah_scene_geometry* scene, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_plane* depth,
+                        const sah_plane* normals, const sah_plane* noise, const sah_plane* mask_out) {
+    using namespace orc;
+    if (!scene_ok(scene) || !view || !sun || !plane_is(mask_out, SAH_FORMAT_R32_SFLOAT) || !depth || !depth->ptr ||
+        !plane_is(normals, SAH_FORMAT_R16G16B16A16_SFLOAT) || !plane_is(noise, SAH_FORMAT_R8G8B8A8_UNORM) || noise->width < 128 || noise->height < 128 ||
+        !(sun->num_shadow_samples >= 0.0f && sun->num_shadow_samples <= 4096.0f))
+        return SAH_ERR_INVALID_ARGUMENT;
+    const RtStructure s = build(*scene);
+    const int W = (int)mask_out->width, Hh = (int)mask_out->height;
+    const F3 L = normalize(F3{-F(sun->direction_and_tan_size[0]), -F(sun->direction_and_tan_size[1]), -F(sun->direction_and_tan_size[2])});
+    const F phi = F(1.618033988749895f);
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < Hh; y++)
+        for (int x = 0; x < W; x++) {
+            float mask = 1.0f;
+            const float depth_v = load_f32(*depth, x, y);
+            const H3 normal = load_normal(*normals, x, y);
+            const H ndotl = H(nclamp(dot(L, to_f(normal)), F(0.0f), F(1.0f)).v);
+            if (depth_v != 0.0f && ndotl.v > 0.0f) {
+                const F3 pos = worldspace_location_slang(*view, x, y, depth_v);
+                const float o[3] = {pos.x.v, pos.y.v, pos.z.v};
+                F shadow = F(0.0f);
+                for (uint32_t i = 0; (float)i < sun->num_shadow_samples; i++) {
+                    const F q = F((float)i) / phi;
+                    const F r0x = F(2.0f) + q, r0y = F(3.0f) + q;
+                    const F fx = r0x - F(std::floor(r0x.v)), fy = r0y - F(std::floor(r0y.v));
+                    const float offx = std::nearbyint((fx * F(128.0f)).v), offy = std::nearbyint((fy * F(128.0f)).v);
+                    const uint32_t nx = to_uint_sat((F((float)x) + F(offx)).v) % 128u, ny = to_uint_sat((F((float)y) + F(offy)).v) % 128u;
+                    const F3 n = load_noise(*noise, nx, ny);
+                    const F3 dir = normalize(L + n * F(sun->direction_and_tan_size[3]));
+                    const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
+                    shadow = shadow + F(any_hit(*scene, s, make_ray(o, d, 0.01f, 100000.0f), /*cull_non_opaque=*/false) ? 0.0f : 1.0f);
+                }
+                mask = (shadow / F(sun->num_shadow_samples)).v;
+            }
+            std::memcpy((uint8_t*)mask_out->ptr + (size_t)y * mask_out->row_pitch_bytes + (size_t)x * 4, &mask, 4);
+        }
+    return SAH_OK;
+}
+
+}  // extern "C"

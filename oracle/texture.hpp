@@ -62,14 +62,10 @@ inline void sample_level(const sah_plane& p, const sah_sampler& s, uint32_t filt
     }
 }
 
-// SampleBias: uv and its quad derivatives in, four fp32 channels out
-inline void sample_texture(const sah_texture& T, const float uv[2], const float ddx[2], const float ddy[2], float shader_bias, float out[4]) {
-    const float W0 = (float)T.mips[0].width, H0 = (float)T.mips[0].height;
-    const float mxx = ddx[0] * W0, mxy = ddx[1] * H0, myx = ddy[0] * W0, myy = ddy[1] * H0;
-    const float rx = mxx * mxx + mxy * mxy, ry = myx * myx + myy * myy;
-    const float rho2 = std::fmax(rx, ry);
-    float lambda = rho2 > 0.0f ? 0.5f * (float)std::log2((double)rho2) : -INFINITY;
-    lambda = lambda + (T.sampler.mip_lod_bias + shader_bias);
+// The sampling operation behind the LOD computation: lambda_base is what the derivatives give (SampleBias) or the explicit level
+// (SampleLevel, gltf_basic_pbr.slang:309: the any-hit stage of the ray tracer)
+inline void sample_texture_lod(const sah_texture& T, const float uv[2], float lambda_base, float shader_bias, float out[4]) {
+    float lambda = lambda_base + (T.sampler.mip_lod_bias + shader_bias);
     lambda = std::fmin(std::fmax(lambda, T.sampler.min_lod), T.sampler.max_lod);
     const uint32_t filter = lambda <= 0.0f ? T.sampler.mag_filter : T.sampler.min_filter;
     const int q = (int)T.num_mips - 1;
@@ -88,6 +84,16 @@ inline void sample_texture(const sah_texture& T, const float uv[2], const float 
     sample_level(T.mips[lo], T.sampler, filter, uv[0], uv[1], b);
     const float one_minus = 1.0f - delta;
     for (int c = 0; c < 4; c++) out[c] = one_minus * a[c] + delta * b[c];
+}
+
+// SampleBias: uv and its quad derivatives in, four fp32 channels out
+inline void sample_texture(const sah_texture& T, const float uv[2], const float ddx[2], const float ddy[2], float shader_bias, float out[4]) {
+    const float W0 = (float)T.mips[0].width, H0 = (float)T.mips[0].height;
+    const float mxx = ddx[0] * W0, mxy = ddx[1] * H0, myx = ddy[0] * W0, myy = ddy[1] * H0;
+    const float rx = mxx * mxx + mxy * mxy, ry = myx * myx + myy * myy;
+    const float rho2 = std::fmax(rx, ry);
+    const float lambda = rho2 > 0.0f ? 0.5f * (float)std::log2((double)rho2) : -INFINITY;
+    sample_texture_lod(T, uv, lambda, shader_bias, out);
 }
 
 inline bool texture_ok(const sah_texture& T) {

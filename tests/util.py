@@ -69,6 +69,11 @@ def oracle():
                                  C.POINTER(_abi.RsmTargets), C.c_void_p]
     o.orc_lpv_extract_vpls.argtypes = [C.POINTER(_abi.RsmTargets), C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
     o.orc_lpv_inject_vpls.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_abi.LpvCascadeMatrices), C.c_uint32, C.c_uint32, C.POINTER(_abi.Volume)]
+    o.orc_rt_stats.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+    o.orc_rtao.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.c_uint32,
+                           C.c_float, C.POINTER(_abi.Plane)]
+    o.orc_sun_shadow_mask.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.Plane),
+                                      C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     _oracle = o
     return o
 
