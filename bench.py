@@ -47,6 +47,9 @@ WORKLOADS = {
     "4k_256_lights": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none", lights=256, radius=4.0),             # configs[2]
     "4k_probe_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True),                     # configs[3]
     "4k_lpv_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", chain=True),
+    # configs[3] with nothing synthetic between the mesh and the image: the G-buffer rasterised from the atrium mesh, the AO plane and the sun's
+    # shadow mask traced every step against the structure sah_rt_build made of the same mesh (reference defaults: 1 AO ray of 8 m, 8 shadow rays)
+    "4k_probe_gi_chain_traced": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True, traced=True),
     "8k_1024_lights_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv", lights=1024, radius=3.0),         # configs[4]
 }
 
@@ -269,6 +272,40 @@ def main():
         ctx.lpv_propagate(vd, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in scratch], 4, 32)
         torch.cuda.synchronize()
 
+    traced = None
+    if wl.get("traced"):
+        if world > 1:
+            raise SystemExit("the traced workload is a one-GPU workload (the ray generators are not part of the sharded chain yet)")
+        from androidrenderer_amd import mesh
+        geo_arrays = mesh.to_device(mesh.atrium(8).arrays(), dev)
+        geo = mesh.geometry(geo_arrays, [])
+        ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
+        noise_t = torch.from_numpy(synth.rng(31).integers(0, 256, (128, 128, 4), dtype=np.uint8)).to(dev)
+        planes_rt = (images.plane(d_arr["depth"], _abi.FORMAT_D32_SFLOAT), images.plane(d_arr["normals"], _abi.FORMAT_R16G16B16A16_SFLOAT),
+                     images.plane(noise_t, _abi.FORMAT_R8G8B8A8_UNORM), images.plane(d_arr["ao"], _abi.FORMAT_R32_SFLOAT),
+                     images.plane(d_arr["shadow_mask"], _abi.FORMAT_R32_SFLOAT))
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        torch.cuda.synchronize()
+        e[0].record()
+        rt_stats = ctx.rt_build(geo)
+        e[1].record()
+
+        def trace_planes():
+            ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
+            ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
+        trace_planes()  # warm
+        torch.cuda.synchronize()
+        e[2].record()
+        ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
+        e[3].record()
+        ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
+        e[4].record()
+        torch.cuda.synchronize()
+        traced = {"triangles": rt_stats[0], "levels": rt_stats[2], "rt_build_ms": round(e[0].elapsed_time(e[1]), 4), "rtao_ms": round(e[2].elapsed_time(e[3]), 4),
+                  "sun_shadow_mask_ms": round(e[3].elapsed_time(e[4]), 4),
+                  "shadow_samples": float(fr.sun.constants.num_shadow_samples), "ao_unoccluded_fraction": round(float((d_arr["ao"] == 1).float().mean()), 4),
+                  "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4)}
+
     pipelined = chain and gather and lib_gather and comm_stream is not None
     if pipelined:
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
@@ -290,6 +327,8 @@ def main():
         mip0_slot_bytes, out_slot_bytes = q * sc.mip0_alloc.shape[1] * 8, per * W * 4
 
         def step(i, e0=None, e1=None):
+            if traced is not None:
+                trace_planes()
             if e0 is not None:
                 e0.record()
             sc.lighting()
@@ -491,6 +530,7 @@ def main():
                 "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
                 "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
                 "same_workload_on_one_gpu": single_gpu,
+                "traced": traced,
             },
             "roofline": roofline(args.workload, world, achieved, kernel_ms_mean, kernel_ms_min, kernel_scope, bytes_per_pixel * my_px, my_px,
                                  "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),

@@ -537,11 +537,20 @@ public:
             commands.lighting.has_shadowmap = true;
         }
     }
-    // directional_light.cpp:372-422: the RT-mode sun dispatch after the Lighting pass.  The ray query itself stays with the renderer and
-    // leaves its visibility fraction in `shadow_mask`; the shading joins the fused Lighting call.
+    // directional_light.cpp:372-422: the RT-mode sun dispatch after the Lighting pass.  The shadow rays of the raygen shader
+    // (directional_light.rt.slang:91-125) are traced here into `shadow_mask` (sah_sun_shadow_mask, against the structure
+    // RaytracingScene::finalize built) whenever a noise layer is given; the shading half of that shader joins the fused Lighting call.
+    // Without a noise layer `shadow_mask` is taken as it is (a mask made elsewhere).
     void raytrace(RenderGraph& graph, const SceneView& view, const GBuffer& gbuffer, const struct RenderScene& scene, TextureHandle lit_scene,
-                  const NoiseTexture& noise) const {
-        (void)view; (void)gbuffer; (void)scene; (void)lit_scene; (void)noise;
+                  const NoiseTexture& noise) {
+        (void)scene; (void)lit_scene;
+        if (TextureHandle layer = noise.get_layer(frame_index); layer && shadow_mask && gbuffer.depth && gbuffer.normals) {
+            graph.add_pass(hip_pass("ray_traced_sun: shadow rays", [this, &view, &gbuffer, layer](sah_ctx* ctx) {
+                                const sah_plane d = gbuffer.depth->plane(), n = gbuffer.normals->plane(), z = layer->plane(), m = shadow_mask->plane();
+                                return sah_sun_shadow_mask(ctx, &view.get_gpu_data(), &constants, &d, &n, &z, &m);
+                            }));
+        }
+        frame_index++;  // :392
         ComputePass pass;
         pass.name = "Raytraced sun (recorded into the Lighting call)";
         pass.execute = [this](CommandBuffer& commands) {
@@ -559,7 +568,8 @@ public:
     sah_sun_light_constants& get_constants() { return constants; }
     const sah_sun_light_constants& get_constants() const { return constants; }
     TextureHandle shadowmap_handle = nullptr;  // D16 array, CSM mode
-    TextureHandle shadow_mask = nullptr;       // RT mode: visibility fraction written by the (external) ray query
+    TextureHandle shadow_mask = nullptr;       // RT mode: visibility fraction, shadow / num_shadow_samples (R32_SFLOAT)
+    uint32_t frame_index = 0;                  // selects the noise layer (directional_light.hpp)
 
     DirectionalLight(const DirectionalLight&) = delete;  // `buffer` points at this object's constants
     DirectionalLight& operator=(const DirectionalLight&) = delete;
@@ -593,13 +603,38 @@ struct ProceduralSky {
     }
 };
 
+// RenderCore/render/raytracing_scene.{hpp,cpp}: the TLAS over one instance per primitive.  add_primitive marks the scene dirty
+// (:15-43: the instance's transform, mask and opacity flags are already in sah_primitive), finalize() commits the pending build
+// (:45-170) — here one sah_rt_build over the scene's geometry pool.
+class RaytracingScene {
+public:
+    explicit RaytracingScene(struct RenderScene& scene_in) : scene(scene_in) {}
+    void add_primitive(uint32_t /*primitive index in scene.geometry.primitives*/) { is_dirty = true; }
+    void finalize(RenderGraph& graph);
+    bool is_built() const { return built; }
+
+private:
+    struct RenderScene& scene;
+    bool is_dirty = false, built = false;
+};
+
 struct RenderScene {  // the slice of RenderCore/render/render_scene.hpp the hot path touches
     DirectionalLight sun;
     ProceduralSky sky;
     sah_scene_geometry geometry{};  // device-side mesh pool + primitive buffer (render_scene.hpp: get_meshes(), get_primitive_buffer())
+    RaytracingScene raytracing_scene{*this};
     DirectionalLight& get_sun_light() { return sun; }
     ProceduralSky& get_sky() { return sky; }
+    RaytracingScene& get_raytracing_scene() { return raytracing_scene; }
+    const RaytracingScene& get_raytracing_scene() const { return raytracing_scene; }
 };
+
+inline void RaytracingScene::finalize(RenderGraph& graph) {
+    if (!is_dirty) return;  // commit_tlas_builds: nothing to do
+    graph.add_pass(hip_pass("Build TLAS", [this](sah_ctx* ctx) { return sah_rt_build(ctx, &scene.geometry, nullptr); }));
+    is_dirty = false;
+    built = true;
+}
 
 // ---- GI plugin seam (RenderCore/render/gi/global_illuminator.hpp:18-45): the five methods, with the reference's signatures --------
 class IGlobalIlluminator {
@@ -933,16 +968,34 @@ private:
     float extra_ray_radius = 16.f;
 };
 
-// RenderCore/render/phase/ambient_occlusion_phase.cpp:157-189.  Only r.AO.Mode = Off is on this side of the boundary (the target
-// is cleared to 1.0, :167-179); RTAO and CACAO need the BVH / the Vulkan SDK and hand their result over as the AO plane.
+// RenderCore/render/phase/ambient_occlusion_phase.cpp:157-189: r.AO.Mode = Off clears the target to 1.0 (:167-179), RTAO traces one
+// occlusion ray per pixel (evaluate_rtao, :357-397); CACAO is a vendor SDK and hands its result over as the AO plane.
+enum class AoTechnique { Off = 0, CACAO = 1, RTAO = 2 };
 class AmbientOcclusionPhase {
 public:
-    void generate_ao(RenderGraph& graph, TextureHandle ao_out) {
+    AoTechnique technique = AoTechnique::RTAO;  // r.AO (ambient_occlusion_phase.cpp:15-17: RTAO is the reference's default)
+    uint32_t rtao_samples = 1;                  // r.AO.RTAO.SamplesPerPixel (:19-21)
+    float ao_radius = 8.0f;                     // r.AO.MaxRayDistance (:23-25)
+    void generate_ao(RenderGraph& graph, TextureHandle ao_out) {  // the Off path (no scene needed)
         graph.add_pass(hip_pass("Clear AO", [ao_out](sah_ctx* ctx) {
                             const sah_plane p = ao_out->plane();
                             return sah_ao_clear(ctx, &p);
                         }));
     }
+    // ambient_occlusion_phase.hpp: generate_ao(graph, view, scene, noise, gbuffer_normals, gbuffer_depth, ao_out)
+    void generate_ao(RenderGraph& graph, const SceneView& view, const RenderScene& scene, const NoiseTexture& noise, TextureHandle gbuffer_normals,
+                     TextureHandle gbuffer_depth, TextureHandle ao_out) {
+        if (technique != AoTechnique::RTAO || !scene.get_raytracing_scene().is_built()) return generate_ao(graph, ao_out);
+        TextureHandle layer = noise.get_layer(frame_index);
+        frame_index++;
+        graph.add_pass(hip_pass("Ray traced ambient occlusion", [this, &view, layer, gbuffer_normals, gbuffer_depth, ao_out](sah_ctx* ctx) {
+                            const sah_plane d = gbuffer_depth->plane(), n = gbuffer_normals->plane(), z = layer->plane(), o = ao_out->plane();
+                            return sah_rtao(ctx, &view.get_gpu_data(), &d, &n, &z, rtao_samples, ao_radius, &o);
+                        }));
+    }
+
+private:
+    uint32_t frame_index = 0;
 };
 
 // ---- LightingPhase (RenderCore/render/phase/lighting_phase.hpp:17-57, .cpp:34-134) -------------------------------------

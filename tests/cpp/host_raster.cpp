@@ -66,6 +66,16 @@ int main(int argc, char** argv) {
         }
         if (texture_pool.create_texture_srv(levels, smp) != t) return 4;
     }
+    // one 128 x 128 blue-noise layer (RenderCore/render/noise_texture.cpp; the PNGs are not in the reference tree: the test sends noise)
+    NoiseTexture stbn_3d_unitvec;
+    {
+        TextureHandle layer = alloc.create_texture("stbn_unitvec3_2Dx1D_128x128x64_0", SAH_FORMAT_R8G8B8A8_UNORM, 128, 128);
+        const auto texels = read_blob(in, 128 * 128 * 4);
+        alloc.upload(layer, texels.data(), 128 * 4);
+        stbn_3d_unitvec.layers.push_back(layer);
+        stbn_3d_unitvec.resolution[0] = stbn_3d_unitvec.resolution[1] = 128;
+        stbn_3d_unitvec.num_layers = 1;
+    }
     if (hdr[7]) {
         texture_pool.commit_descriptors();  // "should be called at start of frame"
         scene.geometry.textures = texture_pool.get_descriptor_set();
@@ -101,6 +111,17 @@ int main(int argc, char** argv) {
     lpv.update_cascade_transforms(view, scene.sun);
     lpv.pre_render(graph, view, scene, nullptr);
     lpv.inject_indirect_sun_light(graph, scene);
+    // ray tracing (scene_renderer.cpp:247-251, 383-401): TLAS over the scene's primitives, RTAO, and the shadow rays of the RT-mode sun
+    for (uint32_t p = 0; p < scene.geometry.num_primitives; p++) scene.get_raytracing_scene().add_primitive(p);
+    scene.get_raytracing_scene().finalize(graph);
+    TextureHandle ao = alloc.create_texture("ao", SAH_FORMAT_R32_SFLOAT, W, H);
+    AmbientOcclusionPhase ao_phase;
+    ao_phase.technique = AoTechnique::RTAO;
+    ao_phase.generate_ao(graph, view, scene, stbn_3d_unitvec, gbuffer.normals, gbuffer.depth, ao);
+    scene.sun.shadow_mask = alloc.create_texture("sun shadow mask", SAH_FORMAT_R32_SFLOAT, W, H);
+    TextureHandle lit_scene = alloc.create_texture("lit_scene", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    scene.sun.get_constants().num_shadow_samples = 2.0f;
+    scene.sun.raytrace(graph, view, gbuffer, scene, lit_scene, stbn_3d_unitvec);
     graph.finish();
     for (const auto& e : graph.get_errors()) fprintf(stderr, "pass failed: %s\n", e.c_str());
     if (!graph.get_errors().empty()) return 1;
@@ -123,6 +144,11 @@ int main(int argc, char** argv) {
         std::vector<unsigned char> v((size_t)128 * 32 * 32 * 8);
         alloc.download(lpv.get_volume(c), v.data(), 128 * 8);
         fwrite(v.data(), 1, v.size(), out);
+    }
+    for (TextureHandle t : {ao, scene.sun.shadow_mask}) {
+        buf.resize((size_t)W * H * 4);
+        alloc.download(t, buf.data(), W * 4);
+        fwrite(buf.data(), 1, buf.size(), out);
     }
     fclose(out);
     return 0;

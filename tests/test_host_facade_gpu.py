@@ -136,6 +136,8 @@ def test_producer_passes_through_cpp_facade(tmp_path):
             for level in mips:
                 f.write(np.array([level.shape[1], level.shape[0]], np.uint32).tobytes())
                 f.write(np.ascontiguousarray(level).tobytes())
+        noise = g.integers(0, 256, (128, 128, 4), dtype=np.uint8)
+        f.write(noise.tobytes())  # (read before the material-texture table: see host_raster.cpp)
         f.write(np.ascontiguousarray(arrays["material_textures"], dtype=np.uint32).tobytes())
     subprocess.check_call([RASTER_EXE, str(inp), str(outp)])
     blob = open(outp, "rb").read()
@@ -155,6 +157,8 @@ def test_producer_passes_through_cpp_facade(tmp_path):
            "depth": np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)}
     casc = (_abi.LpvCascadeMatrices * 4).from_buffer_copy(take(1024))
     lpv_got = [np.frombuffer(take(128 * 32 * 32 * 8), dtype=np.uint16).reshape(32, 32, 128, 4) for _ in range(3)]
+    ao_got = np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)
+    mask_got = np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)
     assert off == len(blob)
     o = util.oracle()
     keep = []
@@ -192,6 +196,19 @@ def test_producer_passes_through_cpp_facade(tmp_path):
     for k in want:
         assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), k
     assert (want["depth"] > 0).mean() > 0.9
+    # ray tracing through the facade (RaytracingScene::finalize, AmbientOcclusionPhase::generate_ao in RTAO mode, DirectionalLight::raytrace)
+    # against the oracle's brute-force loop over every triangle, on the G-buffer checked above
+    ao_want, mask_want = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+    sun_rt = _abi.SunLightConstants.from_buffer_copy(bytes(sun_c))
+    sun_rt.num_shadow_samples = 2.0
+    pd, pn = images.plane(want["depth"], _abi.FORMAT_D32_SFLOAT), images.plane(want["normals"], _abi.FORMAT_R16G16B16A16_SFLOAT)
+    pz = images.plane(noise, _abi.FORMAT_R8G8B8A8_UNORM)
+    pa, pm = images.plane(ao_want, _abi.FORMAT_R32_SFLOAT), images.plane(mask_want, _abi.FORMAT_R32_SFLOAT)
+    assert o.orc_rtao(C.byref(g), C.byref(view_c), C.byref(pd), C.byref(pn), C.byref(pz), 1, 8.0, C.byref(pa)) == 0
+    assert o.orc_sun_shadow_mask(C.byref(g), C.byref(view_c), C.byref(sun_rt), C.byref(pd), C.byref(pn), C.byref(pz), C.byref(pm)) == 0
+    assert np.array_equal(ao_got.view(np.uint32), ao_want.view(np.uint32)), "RTAO through the facade"
+    assert np.array_equal(mask_got.view(np.uint32), mask_want.view(np.uint32)), "sun shadow mask through the facade"
+    assert (ao_want == 0).any() and (mask_want < 1).any()
     # cascade fitting: same algorithm as scene.py (glm restated twice); the inverses differ in rounding, so compare loosely
     view = scene.SceneView.default(W, H)
     sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)

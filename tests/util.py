@@ -175,6 +175,21 @@ def golden_raster_scene():
     return m, view
 
 
+def golden_rt_scene():
+    """The scene behind tests/golden/rt_64x36.npz (tools/gen_golden.py): golden_raster_scene() with a floor under it and a SOLID slab
+    above the floor (so that rays leave from, and end on, opaque and alpha-tested geometry), a sun from above-left with three shadow
+    samples, and a seeded 128 x 128 stand-in for the blue-noise layer.  Returns (mesh, view, sun, noise)."""
+    from androidrenderer_amd import mesh, scene
+    m, view = golden_raster_scene()
+    grey = m.add_material(mesh.material(base=(0.5, 0.5, 0.5, 1.0)))
+    m.add_primitive([(-5, -2, -6), (4, -2, -6), (4, -2, 6), (-5, -2, 6)], [(0, 1, 0)] * 4, (0, 2, 1, 0, 3, 2), grey)
+    m.add_primitive([(-5, 0.5, -6), (0, 0.5, -6), (0, 0.5, -1), (-5, 0.5, -1)], [(0, -1, 0)] * 4, (0, 1, 2, 0, 2, 3, 0, 2, 1, 0, 3, 2), grey)
+    sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_RT, num_shadow_samples=3.0)
+    sun.set_direction([0.5, -1.0, 0.3])
+    noise = synth.rng(121).integers(0, 256, (128, 128, 4), dtype=np.uint8)
+    return m, view, sun, noise
+
+
 def golden_raster_sun(view):
     """Sun whose cascades are fitted to `view` (directional_light.cpp:164-260 through scene.DirectionalLight)."""
     from androidrenderer_amd import scene

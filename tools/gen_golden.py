@@ -913,15 +913,19 @@ def _sample_level(level, srgb, smp, filt, u, v):
     return acc
 
 
-def sample_bias(texture, uv, ddx, ddy, shader_bias):
-    """textures[i].SampleBias(uv, bias) under the rules of include/sah_hip.h (sah_texture); uv, ddx, ddy: pairs of fp32 arrays"""
+def sample_bias(texture, uv, ddx, ddy, shader_bias, explicit_lod=None):
+    """textures[i].SampleBias(uv, bias) under the rules of include/sah_hip.h (sah_texture); uv, ddx, ddy: pairs of fp32 arrays.
+    explicit_lod: SampleLevel(uv, lod) instead — the level of detail is given, not derived (ddx / ddy unused)."""
     mips, fmt, smp = texture
     srgb = fmt == _abi.FORMAT_R8G8B8A8_SRGB
-    w0, h0 = f32(mips[0].shape[1]), f32(mips[0].shape[0])
-    mxx, mxy, myx, myy = F(ddx[0] * w0), F(ddx[1] * h0), F(ddy[0] * w0), F(ddy[1] * h0)
-    rho2 = np.fmax(F(F(mxx * mxx) + F(mxy * mxy)), F(F(myx * myx) + F(myy * myy)))
-    with np.errstate(divide="ignore", invalid="ignore"):
-        lam = np.where(rho2 > 0, F(f32(0.5) * np.log2(rho2.astype(np.float64)).astype(f32)), f32(-np.inf))
+    if explicit_lod is not None:
+        lam = np.full(uv[0].shape, f32(explicit_lod), f32)
+    else:
+        w0, h0 = f32(mips[0].shape[1]), f32(mips[0].shape[0])
+        mxx, mxy, myx, myy = F(ddx[0] * w0), F(ddx[1] * h0), F(ddy[0] * w0), F(ddy[1] * h0)
+        rho2 = np.fmax(F(F(mxx * mxx) + F(mxy * mxy)), F(F(myx * myx) + F(myy * myy)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lam = np.where(rho2 > 0, F(f32(0.5) * np.log2(rho2.astype(np.float64)).astype(f32)), f32(-np.inf))
     lam = F(lam + F(f32(smp.mip_lod_bias) + f32(shader_bias)))
     lam = np.fmin(np.fmax(lam, f32(smp.min_lod)), f32(smp.max_lod))
     q = len(mips) - 1
@@ -1496,6 +1500,170 @@ def probe_copy(src, dst, movement):
     return dst
 
 
+# ---- ray tracing (f4, first slice): the hit rules of include/sah_hip.h ("ray tracing"), RTAO (ao/rtao.comp.slang:54-102), the shadow rays
+# of the RT-mode sun (lighting/directional_light.rt.slang:91-125) and the occlusion any-hit stage (materials/gltf_basic_pbr.slang:291-318).
+# Every ray against every triangle, vectorised over rays; written from the header and the shader text, not from oracle/rt.cpp.
+def rt_world_triangles(arrays):
+    """world-space triangles of every primitive: vertex = model * (p, 1), rows ((m0 x + m1 y) + m2 z) + m3; non-finite ones left out"""
+    tris = []
+    for p, prim in enumerate(arrays["primitives"]):
+        mdl = prim["model"].astype(f32)
+        for t in range(int(prim["index_count"]) // 3):
+            idx = arrays["indices"][int(prim["first_index"]) + 3 * t:int(prim["first_index"]) + 3 * t + 3].astype(np.int64) + int(prim["vertex_offset"])
+            v = np.zeros((3, 3), f32)
+            for k in range(3):
+                x, y, z = arrays["positions"][idx[k]].astype(f32)
+                for c in range(3):
+                    v[k, c] = F(F(F(F(mdl[c] * x) + F(mdl[4 + c] * y)) + F(mdl[8 + c] * z)) + mdl[12 + c])
+            if np.isfinite(v).all():
+                tris.append({"v": v, "primitive": p, "triangle": t, "vertices": idx, "cutout": int(prim["type"]) == _abi.PRIMITIVE_TYPE_CUTOUT})
+    S = max([f32(0)] + [np.abs(t["v"]).max() for t in tris])
+    return tris, F(f32(S) * f32(2.0 ** -16))
+
+
+def _pick(v, k):  # v: (N, 3), k: (N,) -> (N,)
+    return np.take_along_axis(v, k[:, None], axis=1)[:, 0]
+
+
+def rt_any_hit(arrays, tris, pad, o, d, tmin, tmax, cull_non_opaque):
+    """o, d: (N, 3) fp32; returns (N,) bool: is there an accepted candidate"""
+    n = o.shape[0]
+    hit = np.zeros(n, bool)
+    finite = np.isfinite(o).all(axis=1) & np.isfinite(d).all(axis=1)
+    with np.errstate(all="ignore"):
+        inv = F(f32(1) / d)
+        ad = np.abs(d)
+        kz = np.zeros(n, np.int64)
+        am = ad[:, 0].copy()
+        kz = np.where(ad[:, 1] > am, 1, kz)
+        am = np.where(ad[:, 1] > am, ad[:, 1], am)
+        kz = np.where(ad[:, 2] > am, 2, kz)
+        kx = (kz + 1) % 3
+        ky = (kx + 1) % 3
+        neg = _pick(d, kz) < 0
+        kx, ky = np.where(neg, ky, kx), np.where(neg, kx, ky)
+        dz = _pick(d, kz)
+        Sx, Sy, Sz = F(_pick(d, kx) / dz), F(_pick(d, ky) / dz), F(f32(1) / dz)
+        for t in tris:
+            if cull_non_opaque and t["cutout"]:
+                continue
+            v = t["v"]
+            lo, hi = F(v.min(axis=0) - pad), F(v.max(axis=0) + pad)
+            tn, tf = np.full(n, f32(tmin)), np.full(n, f32(tmax))
+            for c in range(3):
+                t0, t1 = F(F(lo[c] - o[:, c]) * inv[:, c]), F(F(hi[c] - o[:, c]) * inv[:, c])
+                tn = np.fmax(tn, np.fmin(t0, t1))
+                tf = np.fmin(tf, np.fmax(t0, t1))
+            box = tn <= tf
+            A, B, C = F(v[0][None, :] - o), F(v[1][None, :] - o), F(v[2][None, :] - o)
+            Akz, Bkz, Ckz = _pick(A, kz), _pick(B, kz), _pick(C, kz)
+            Ax, Ay = F(_pick(A, kx) - F(Sx * Akz)), F(_pick(A, ky) - F(Sy * Akz))
+            Bx, By = F(_pick(B, kx) - F(Sx * Bkz)), F(_pick(B, ky) - F(Sy * Bkz))
+            Cx, Cy = F(_pick(C, kx) - F(Sx * Ckz)), F(_pick(C, ky) - F(Sy * Ckz))
+            U, V, Wd = F(F(Cx * By) - F(Cy * Bx)), F(F(Ax * Cy) - F(Ay * Cx)), F(F(Bx * Ay) - F(By * Ax))
+            zero = (U == 0) | (V == 0) | (Wd == 0)
+            d64 = lambda a, b, c2, e: (a.astype(np.float64) * b.astype(np.float64) - c2.astype(np.float64) * e.astype(np.float64)).astype(f32)
+            U, V, Wd = np.where(zero, d64(Cx, By, Cy, Bx), U), np.where(zero, d64(Ax, Cy, Ay, Cx), V), np.where(zero, d64(Bx, Ay, By, Ax), Wd)
+            mixed = ((U < 0) | (V < 0) | (Wd < 0)) & ((U > 0) | (V > 0) | (Wd > 0))
+            det = F(F(U + V) + Wd)
+            T = F(F(F(U * F(Sz * Akz)) + F(V * F(Sz * Bkz))) + F(Wd * F(Sz * Ckz)))
+            tt = F(T / det)
+            cand = finite & box & ~mixed & (det != 0) & (tt > f32(tmin)) & (tt < f32(tmax))
+            if t["cutout"] and cand.any():
+                cand = cand & rt_cutout_accepts(arrays, t, F(V / det), F(Wd / det))
+            hit |= cand
+    return hit
+
+
+def rt_cutout_accepts(arrays, t, b1, b2):
+    """any-hit stage of the occlusion hit group (gltf_basic_pbr.slang:291-318), vectorised over the candidate rays"""
+    prim = arrays["primitives"][t["primitive"]]
+    mat = arrays["materials"][int(prim["material"])]
+    vd = arrays["vertex_data"][t["vertices"]]
+    b0 = F(F(f32(1) - b1) - b2)
+    uv = [F(F(F(b0 * vd["texcoord"][0][k]) + F(b1 * vd["texcoord"][1][k])) + F(b2 * vd["texcoord"][2][k])) for k in range(2)]
+    ua = [h(h(f32(int(c) >> 24)) / h(255.0)) for c in vd["color"]]                       # unpackUnorm4x8ToHalf(v.color).w
+    ca = F(F(F(b0 * ua[0]) + F(b1 * ua[1])) + F(b2 * ua[2]))                             # float * half4, summed in fp32
+    with np.errstate(invalid="ignore"):
+        byte = np.where(h(ca) * f32(255) > 0, np.floor(h(h(ca) * h(255.0))), 0).astype(np.int64) & 0xff  # packUnorm4x8: (uint)(value.w * 255.h)
+    colour_a = h(h(byte.astype(f32)) / h(255.0))
+    texel_a = np.full(b1.shape, f32(mat["base_color_texel"][3]), f32)
+    mt = arrays.get("material_textures")
+    if mt is not None and len(arrays.get("textures", [])):
+        ti = int(mt[int(prim["material"])][0])
+        if ti != _abi.TEXTURE_NONE:
+            texel_a = sample_bias(arrays["textures"][ti], uv, None, None, 0.0, explicit_lod=0.0)[..., 3]
+    alpha = F(F(texel_a * f32(mat["base_color_tint"][3])) * colour_a)
+    return ~(alpha <= f32(mat["opacity_threshold"]))
+
+
+def rt_world_position(view, W, Hh, depth):
+    """get_worldspace_position (rtao.comp.slang:27-36): (pixel + 0.5) / render_resolution, every component divided by w"""
+    ys, xs = np.meshgrid(np.arange(Hh, dtype=f32), np.arange(W, dtype=f32), indexing="ij")
+    with np.errstate(all="ignore"):
+        tx, ty = F(F(xs + f32(0.5)) / f32(view.render_resolution[0])), F(F(ys + f32(0.5)) / f32(view.render_resolution[1]))
+        ndc = [F(F(tx * f32(2)) - f32(1)), F(F(ty * f32(2)) - f32(1)), F(depth), np.ones_like(tx)]
+        vs = mat_vec(np.array(view.inverse_projection[:], f32), ndc)
+        vs = [F(vs[0] / vs[3]), F(vs[1] / vs[3]), F(vs[2] / vs[3]), F(vs[3] / vs[3])]
+        ws = mat_vec(np.array(view.inverse_view[:], f32), vs)
+    return np.stack(ws[:3], axis=-1)
+
+
+def rt_noise(noise, xs, ys):
+    t = noise[ys, xs].astype(f32)
+    c = [F(F(F(t[..., k] / f32(255)) * f32(2)) - f32(1)) for k in range(3)]
+    return np.stack(normalize3(c), axis=-1)
+
+
+def rtao(arrays, view, depth, normals16, noise, spp, radius):
+    Hh, W = depth.shape
+    tris, pad = rt_world_triangles(arrays)
+    pos = rt_world_position(view, W, Hh, depth).reshape(-1, 3)
+    nh = normals16.view(np.float16).astype(f32)[..., :3]
+    with np.errstate(all="ignore"):
+        n = np.stack(normalize3([nh[..., 0], nh[..., 1], nh[..., 2]], rnd=h), axis=-1).reshape(-1, 3)
+        ys, xs = np.meshgrid(np.arange(Hh), np.arange(W), indexing="ij")
+        d = rt_noise(noise, xs % noise.shape[1], ys % noise.shape[0]).reshape(-1, 3)
+        flip = F(F(F(d[:, 0] * n[:, 0]) + F(d[:, 1] * n[:, 1])) + F(d[:, 2] * n[:, 2])) < 0
+        d = np.where(flip[:, None], F(d * f32(-1)), d)
+    hit = rt_any_hit(arrays, tris, pad, pos, d, 0.01, radius, cull_non_opaque=True)
+    ao = np.full(W * Hh, f32(spp), f32)
+    for _ in range(spp):  # the same ray every time (one noise texel per pixel)
+        ao = np.where(hit, F(ao - f32(1)), ao)
+    with np.errstate(all="ignore"):
+        return F(ao / f32(spp)).reshape(Hh, W)
+
+
+def sun_shadow_mask(arrays, view, sun, depth, normals16, noise):
+    Hh, W = depth.shape
+    tris, pad = rt_world_triangles(arrays)
+    L = normalize3([F(-f32(sun.direction_and_tan_size[k])) for k in range(3)])
+    nh = normals16.view(np.float16).astype(f32)[..., :3]
+    with np.errstate(all="ignore"):
+        n = normalize3([nh[..., 0], nh[..., 1], nh[..., 2]], rnd=h)
+        ndotl = h(np.fmin(np.fmax(F(F(F(L[0] * n[0]) + F(L[1] * n[1])) + F(L[2] * n[2])), f32(0)), f32(1)))
+    traced = ((depth != 0) & (ndotl > 0)).reshape(-1)
+    pos = rt_world_position(view, W, Hh, depth).reshape(-1, 3)
+    ys, xs = np.meshgrid(np.arange(Hh, dtype=f32), np.arange(W, dtype=f32), indexing="ij")
+    shadow = np.zeros(W * Hh, f32)
+    phi = f32(1.618033988749895)
+    i = 0
+    while f32(i) < f32(sun.num_shadow_samples):
+        q = F(f32(i) / phi)
+        fx, fy = F(F(f32(2) + q) - np.floor(F(f32(2) + q))), F(F(f32(3) + q) - np.floor(F(f32(3) + q)))
+        offx, offy = np.rint(F(fx * f32(128))), np.rint(F(fy * f32(128)))  # round half to even
+        nx, ny = F(xs + offx).astype(np.int64) % 128, F(ys + offy).astype(np.int64) % 128
+        nz = rt_noise(noise, nx, ny).reshape(-1, 3)
+        with np.errstate(all="ignore"):
+            dirv = np.stack(normalize3([F(L[k] + F(nz[:, k] * f32(sun.direction_and_tan_size[3]))) for k in range(3)]), axis=-1)
+        hit = rt_any_hit(arrays, tris, pad, pos, dirv, 0.01, 100000.0, cull_non_opaque=False)
+        shadow = F(shadow + np.where(hit, f32(0), f32(1)))
+        i += 1
+    with np.errstate(all="ignore"):
+        mask = F(shadow / f32(sun.num_shadow_samples))
+    return np.where(traced, mask, f32(1)).astype(f32).reshape(Hh, W)
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -1504,8 +1672,25 @@ def inputs_digest(arrays):
     return m.hexdigest()
 
 
+def golden_rt():
+    """RTAO and the sun shadow mask of tests/util.py: golden_raster_scene() (a textured CUTOUT wall behind a SOLID triangle) plus a floor and
+    an occluder above it, on the golden G-buffer's depth and normal planes"""
+    from tests import util
+    W, Hh = 64, 36
+    m, view, sun, noise = util.golden_rt_scene()
+    gb = raster_gbuffer(m, view, W, Hh)
+    arrays = m.arrays()
+    ao = rtao(arrays, view.gpu_data, gb["depth"], gb["normals"], noise, 2, 3.0)
+    mask = sun_shadow_mask(arrays, view.gpu_data, sun.constants, gb["depth"], gb["normals"], noise)
+    np.savez_compressed(os.path.join(GOLDEN, f"rt_{W}x{Hh}.npz"), ao=ao, mask=mask, depth=gb["depth"], normals=gb["normals"])
+    print("rt ok: occluded", int((ao == 0).sum()), "of", ao.size, "; shadow mask values", np.unique(mask))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    if "--only-rt" in sys.argv:
+        return golden_rt()
+    golden_rt()
     W, Hh = 64, 36
     for name, sun_mode, gi, seed in (("lighting_csm_lpv", _abi.SHADOW_MODE_CSM, _abi.GI_LPV, 101), ("lighting_rt", _abi.SHADOW_MODE_RT, _abi.GI_NONE, 102),
                                      ("lighting_csm", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, 103)):
