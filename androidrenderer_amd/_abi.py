@@ -30,6 +30,7 @@ LIGHTING_BRUTE_FORCE_LIGHTS = 1 << 1
 EXP_LIGHTING_TOLERANCE_1ULP = 1 << 2  # experiment builds only (-DSAH_EXP_TOLERANCE_1ULP); not in include/sah_hip.h
 LIGHTING_DEFAULT_FLAGS = LIGHTING_QUIRK_SUN_BLEND
 MAX_BLOOM_MIPS = 8
+TONEMAP_TOLERANCE_1CODE = 1 << 0
 
 
 class Plane(C.Structure):
@@ -136,7 +137,7 @@ class GI(C.Structure):
                 ("probe_irradiance", Volume), ("probe_depth", Volume), ("probe_validity", Volume),
                 ("probe_cascades", ProbeCascade * 4), ("probe_size", C.c_uint32 * 2), ("cache_debug_mode", C.c_uint32),
                 ("ray_buffer", Plane), ("ray_irradiance", Plane), ("noise", Plane), ("num_extra_rays", C.c_uint32),
-                ("extra_ray_radius", C.c_float)]
+                ("extra_ray_radius", C.c_float), ("lpv_generation", C.c_uint32)]
 
 
 class SkyLuts(C.Structure):

@@ -5,9 +5,10 @@ from . import _abi, images, shard
 
 
 class ShardedChain:
-    def __init__(self, ctx, frame, device_arrays, rank, world, num_mips=6):
+    def __init__(self, ctx, frame, device_arrays, rank, world, num_mips=6, tonemap_flags=0):
         import torch
         self.ctx, self.frame, self.dev = ctx, frame, device_arrays
+        self.tonemap_flags = tonemap_flags  # 0 = strict, _abi.TONEMAP_TOLERANCE_1CODE = within one code of it (include/sah_hip.h)
         W, H = frame.width, frame.height
         self.plan = shard.chain_plan(H, world, rank)
         dev = device_arrays["depth"].device
@@ -53,7 +54,7 @@ class ShardedChain:
     def composite(self):
         self.ctx.bloom_from_mip0(self.aa_p, self.mc)
         if self.plan.out_rows[1] > self.plan.out_rows[0]:
-            self.ctx.tonemap(self.aa_p, self.mc, self.out_p, *self.plan.out_rows)
+            self.ctx.tonemap(self.aa_p, self.mc, self.out_p, *self.plan.out_rows, flags=self.tonemap_flags)
 
     def exchange_final(self):
         self.ctx.allgather_rows_reversed(self.out_p, self.plan.rows_per_rank, self.plan.rows_per_rank * self.world)
@@ -79,12 +80,12 @@ class PipelinedChain:
     `4k_probe_gi_chain` at N = 8, emulated on one GPU: 0.176 -> 0.166 ms per frame, tools/experiments/chain_two_streams.py).
     Every buffer a frame writes exists twice (two ShardedChain sets); what orders a set's re-use is stated where the waits are."""
 
-    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream, second_stream=None):
+    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream, second_stream=None, tonemap_flags=0):
         import torch
         self.ctx, self.comm_stream, self.torch = ctx, comm_stream, torch
         self.work = torch.cuda.current_stream()
         self.work2 = second_stream
-        self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world) for _ in range(2)]
+        self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world, tonemap_flags=tonemap_flags) for _ in range(2)]
         self.plan = self.sets[0].plan
         self.mip0_done = [None, None]   # event behind the mip-0 gather of the frame that last used the set
         self.final_done = [None, None]  # ... behind its final-image gather

@@ -19,6 +19,7 @@
 namespace sah {
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                            const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
+hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, hipStream_t st);
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                              uint32_t row_end, hipStream_t st);
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
@@ -219,7 +220,9 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);
     if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
+    if (ctx->colx_table) (void)hipFree(ctx->colx_table);
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
+    if (ctx->tm_axis) (void)hipFree(ctx->tm_axis);
     for (void* p : ctx->raster.ptr)
         if (p) (void)hipFree(p);
     for (void* p : ctx->rt.ptr)
@@ -533,10 +536,44 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
                 ctx->lpv_packed_bytes = 0;
                 HIP_TRY(ctx, hipMalloc((void**)&ctx->lpv_packed, total));
                 ctx->lpv_packed_bytes = total;
+                ctx->lpv_pack_generation = 0;
             }
             fast.lpv_packed = ctx->lpv_packed;
             fast.pk_row_pitch = (uint32_t)row;
             fast.pk_slice_pitch = (uint32_t)slice;
+            // the copy of the previous call is kept when the caller's change counter says the volumes are the ones it was made from
+            const sah::VolumeArg src[3] = {lpv.red, lpv.green, lpv.blue};
+            const uint32_t gen = d->gi->lpv_generation;
+            const bool reuse = gen != 0 && gen == ctx->lpv_pack_generation && memcmp(src, ctx->lpv_pack_source, sizeof(src)) == 0;
+            fast.repack = reuse ? 0u : 1u;
+            if (!reuse) {
+                ctx->lpv_pack_serial++;
+                ctx->lpv_pack_generation = gen;
+                memcpy(ctx->lpv_pack_source, src, sizeof(src));
+            }
+            fast.pack_serial = ctx->lpv_pack_serial;
+        }
+        // per-column numerators of the view-space x (4 IEEE divides per thread otherwise): a function of the width, the render resolution
+        // and two entries of the inverse projection — rebuilt when one of them changes
+        if (ppt == 4 && (sun_mode != SAH_SHADOW_MODE_OFF || gi_kind == SAH_GI_LPV)) {
+            const float key[3] = {a.res[0], fast.p0, fast.p12};
+            const uint32_t stride = (W + 63u) & ~63u;
+            if (ctx->colx_capacity < 2 * stride) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->colx_table) (void)hipFree(ctx->colx_table);
+                ctx->colx_table = nullptr;
+                ctx->colx_capacity = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->colx_table, (size_t)2 * stride * sizeof(float)));
+                ctx->colx_capacity = 2 * stride;
+                ctx->colx_width = 0;
+            }
+            if (ctx->colx_width != W || memcmp(key, ctx->colx_key, sizeof(key)) != 0) {
+                HIP_TRY(ctx, launch_colx_table(a, fast, ctx->colx_table, stride, ctx->stream));
+                ctx->colx_width = W;
+                memcpy(ctx->colx_key, key, sizeof(key));
+            }
+            fast.colx_tab = ctx->colx_table;
+            fast.colx_stride = stride;
         }
         fast.sky_enabled = sky.enabled;
         {  // thread index -> (row, group in row) by a multiply-high: exact while gid * groups_per_row < 2^32 (magic = floor(2^32 / d) + 1)
@@ -546,13 +583,11 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
 #ifdef SAH_EXP_TOLERANCE_1ULP
         fast.tolerance = (d->flags & sah::kExpLightingTolerance1Ulp) ? 1u : 0u;
 #endif
-        fast.parity = ctx->parity;
         fast.state = ctx->state;
     }
     HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, (use_fast || tiled_fast_geom) ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,
                                  (d->flags & SAH_LIGHTING_BRUTE_FORCE_LIGHTS) != 0, ctx->stream));
     if (use_fast) {
-        ctx->parity ^= 1u;
         ctx->last_seg_count = fast.seg_count;
         ctx->last_num_segments = fast.num_segments;
     } else {

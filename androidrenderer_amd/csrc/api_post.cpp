@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -16,6 +17,8 @@ hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, cons
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                                    uint32_t row_end, hipStream_t st);
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
+hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st);
+hipError_t launch_tonemap_axis_tables(const TonemapArgs& t, TmAxis* out, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
 hipError_t launch_lpv_build_tables(hipStream_t st);
@@ -149,8 +152,14 @@ int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain
 }
 
 int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
+    return sah_tonemap_ex(ctx, scene, bloom, out, row_begin, row_end, 0u);
+}
+
+int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end,
+                   uint32_t flags) {
     SAH_RANGE();
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (flags & ~SAH_TONEMAP_TOLERANCE_1CODE) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "unknown tonemap flags %#x", flags);
     if (!rgba16f_ok(scene) || !bloom || bloom->num_mips > SAH_MAX_BLOOM_MIPS || !out || !out->ptr)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "tonemap needs scene, bloom chain and output");
     if (out->format != SAH_FORMAT_R8G8B8A8_SRGB && out->format != SAH_FORMAT_R8G8B8A8_UNORM)
@@ -202,13 +211,41 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom,
     t.row_begin = row_begin;
     t.row_end = row_end;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sah::launch_tonemap(t, ctx->stream));
+    if (flags & SAH_TONEMAP_TOLERANCE_1CODE) {
+        // per-column / per-row axis set-ups: a function of the extents only, kept across calls
+        uint32_t key[2 + 2 * 8 + 1] = {out->width, out->height};
+        for (uint32_t m = 0; m < bloom->num_mips; m++) {
+            key[2 + 2 * m] = bloom->mips[m].width;
+            key[3 + 2 * m] = bloom->mips[m].height;
+        }
+        key[18] = bloom->num_mips;
+        t.axis_stride = (std::max(out->width, out->height) + 63u) & ~63u;
+        const size_t need = (size_t)6 * 2 * 4 * t.axis_stride * sizeof(sah::TmAxis);
+        const bool rebuild = !ctx->tm_axis || ctx->tm_axis_bytes < need || memcmp(key, ctx->tm_axis_key, sizeof(key)) != 0;
+        if (!ctx->tm_axis || ctx->tm_axis_bytes < need) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->tm_axis) (void)hipFree(ctx->tm_axis);
+            ctx->tm_axis = nullptr;
+            ctx->tm_axis_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->tm_axis, need));
+            ctx->tm_axis_bytes = need;
+        }
+        t.axis_tables = (const sah::TmAxis*)ctx->tm_axis;
+        if (rebuild) {
+            HIP_TRY(ctx, sah::launch_tonemap_axis_tables(t, (sah::TmAxis*)ctx->tm_axis, ctx->stream));
+            memcpy(ctx->tm_axis_key, key, sizeof(key));
+        }
+        HIP_TRY(ctx, sah::launch_tonemap_tol(t, ctx->stream));
+    } else {
+        HIP_TRY(ctx, sah::launch_tonemap(t, ctx->stream));
+    }
     return SAH_OK;
 }
 
 int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, const sah_volume* blue, const sah_volume* geometry,
                   uint32_t num_cascades) {
     SAH_RANGE();
+    if (ctx) ctx->lpv_pack_generation = 0;  // the volumes change: the Lighting pass's gather copy of them is stale
     if (!ctx || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
     const sah_volume* in[4] = {red, green, blue, geometry};
     sah::VolumeArg v[4];
@@ -226,6 +263,7 @@ int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, 
 
 int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades, uint32_t steps) {
     SAH_RANGE();
+    if (ctx) ctx->lpv_pack_generation = 0;  // the volumes change: the Lighting pass's gather copy of them is stale
     if (!ctx || !a_rgb || !b_rgb || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
     sah::VolumeArg a[3], b[3];
     for (int i = 0; i < 3; i++) {

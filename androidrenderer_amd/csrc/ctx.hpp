@@ -31,12 +31,20 @@ struct sah_ctx {
     size_t list_bytes = 0;
     uint8_t* lpv_packed = nullptr;     // device: per-frame interleaved, zero-bordered copy of the three LPV volumes (lighting.hip)
     size_t lpv_packed_bytes = 0;
-    uint32_t parity = 0;
+    uint32_t lpv_pack_serial = 0;      // number of the last k_lpv_pack run (FrameState::nonfinite_tag)
+    uint32_t lpv_pack_generation = 0;  // sah_gi::lpv_generation the gather copy was built for (0: not reusable)
+    sah::VolumeArg lpv_pack_source[3] = {};
+    float* colx_table = nullptr;       // device: per-column view-space x numerators of the fast kernel, two flavours (lighting.hip: k_colx_table)
+    uint32_t colx_capacity = 0, colx_width = 0;
+    float colx_key[3] = {};            // render_resolution.x, p0, p12 the table was built for
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds + the first-level bucket table (api_post.cpp)
     uint32_t tm_bucket_base = 0, tm_bucket_count = 0;
     float tm_thr_lo = 0.f, tm_thr_hi = 0.f;
+    void* tm_axis = nullptr;           // device: axis set-ups of the tolerance-mode composite (tonemap_tol.hip), rebuilt when the extents change
+    size_t tm_axis_bytes = 0;
+    uint32_t tm_axis_key[2 + 2 * 8 + 1] = {};  // output extent, mip extents, number of mips
     struct RasterScratch {             // device buffers of the scene rasteriser, grown on demand (api_raster.cpp)
         void* ptr[16] = {};
         size_t bytes[16] = {};

@@ -96,7 +96,6 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
         if (lane < kFixupSegs) s_pref[lane + 1] = incl;
         if (lane == 0) s_pref[0] = 0;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) f.state->nonfinite[f.parity ^ 1u] = 0u;  // arm the other parity for the next call
     __syncthreads();
     const uint32_t total = s_pref[kFixupSegs];
     if (total == 0) return;
@@ -139,7 +138,7 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
 // 4-5 cache lines, instead of 24 dwordx2 loads over three allocations, and CLAMP_TO_BORDER needs no per-tap masking: border
 // texels are real zeros.
 __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const VolumeArg g, const VolumeArg b, uint8_t* packed, uint32_t pk_row_pitch,
-                                                  uint32_t pk_slice_pitch, FrameState* state, uint32_t parity) {
+                                                  uint32_t pk_slice_pitch, FrameState* state, uint32_t serial) {
     const uint32_t prow = blockIdx.x;  // one block per padded (z, y) row
     const uint32_t ph = r.height + 2 * kLpvPackBorder;
     const uint32_t pz = prow / ph, py = prow - pz * ph;
@@ -165,7 +164,25 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
         dst[1] = t[1];
         dst[2] = t[2];
     }
-    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&state->nonfinite[parity], 1u);
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicMax(&state->nonfinite_tag, serial * 2u + 1u);
+}
+
+// per-column numerator of the view-space x (inverse_projection separable: vs.x = p0 * ndc.x + p12), with the two texcoord conventions:
+// GLSL ((x + 0.5) + 0.5) / W (gl_FragCoord already carries the half), Slang (x + 0.5) / W
+SAH_DEV float colx_glsl_of(const LightingArgs& a, const FastArgs& f, uint32_t x) {
+    const Fn tx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]);
+    return (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+}
+SAH_DEV float colx_slang_of(const LightingArgs& a, const FastArgs& f, uint32_t x) {
+    const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]);
+    return (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+}
+// the same values for every column, once per (width, render resolution, p0, p12): the kernel then loads PPT of them instead of dividing
+__global__ void __launch_bounds__(256) k_colx_table(const LightingArgs a, const FastArgs f, float* out, uint32_t stride) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= a.width) return;
+    out[x] = colx_glsl_of(a, f, x);
+    out[stride + x] = colx_slang_of(a, f, x);
 }
 
 #ifndef SAH_SKY_RATIO
@@ -209,6 +226,40 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
         }
         block_id = blockIdx.x - blockIdx.x / (kSkyRatio + 1u);
     }
+    // the thread's plane loads are requested first: the LUT staging and its barrier below then overlap their latency
+    const uint32_t groups_per_row = a.width / PPT;
+    const uint32_t gid = block_id * 256u + threadIdx.x;
+    const uint32_t rows = a.row_end - a.row_begin;
+    const bool active = gid < groups_per_row * rows;
+    const uint32_t ry = active ? (f.row_magic ? __umulhi(gid, f.row_magic) : gid / groups_per_row) : 0u;
+    const uint32_t y = a.row_begin + ry;
+    const uint32_t x0 = active ? (gid - ry * groups_per_row) * PPT : 0u;
+    const bool lpv_bad = (GI == SAH_GI_LPV) ? (f.state->nonfinite_tag == f.pack_serial * 2u + 1u) : false;
+
+    uint32_t wc[PPT], wd[PPT], we[PPT], wz[PPT], wn[2 * PPT], wao[PPT], wm[PPT];
+    float colx_g[PPT], colx_s[PPT];
+    if (active) {
+        load_words<PPT>(a.color.ptr + (size_t)y * a.color.pitch + (size_t)x0 * 4, wc);
+        load_words<PPT>(a.data.ptr + (size_t)y * a.data.pitch + (size_t)x0 * 4, wd);
+        load_words<PPT>(a.emission.ptr + (size_t)y * a.emission.pitch + (size_t)x0 * 4, we);
+        load_words<PPT>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x0 * 4, wz);
+        load_words<2 * PPT>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x0 * 8, wn);
+        if (GI == SAH_GI_LPV && a.has_ao) load_words<PPT>(a.ao.ptr + (size_t)y * a.ao.pitch + (size_t)x0 * 4, wao);
+        if (SUN == SAH_SHADOW_MODE_RT && a.has_mask) load_words<PPT>(a.shadow_mask.ptr + (size_t)y * a.shadow_mask.pitch + (size_t)x0 * 4, wm);
+        if (f.colx_tab) {  // (uniform) the per-column numerators of the view-space x: one load instead of PPT IEEE divides
+            uint32_t t[PPT];
+            if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) {
+                load_words<PPT>(reinterpret_cast<const uint8_t*>(f.colx_tab + x0), t);
+#pragma unroll
+                for (int i = 0; i < PPT; i++) colx_g[i] = __uint_as_float(t[i]);
+            }
+            if (SUN == SAH_SHADOW_MODE_RT) {
+                load_words<PPT>(reinterpret_cast<const uint8_t*>(f.colx_tab + f.colx_stride + x0), t);
+#pragma unroll
+                for (int i = 0; i < PPT; i++) colx_s[i] = __uint_as_float(t[i]);
+            }
+        }
+    }
     __shared__ __attribute__((aligned(16))) float s_lut[TAB_SIZE];
     s_lut[threadIdx.x] = a.luts[threadIdx.x];
     s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
@@ -226,25 +277,6 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
     }
     __syncthreads();
 
-    const uint32_t groups_per_row = a.width / PPT;
-    const uint32_t gid = block_id * 256u + threadIdx.x;
-    const uint32_t rows = a.row_end - a.row_begin;
-    const bool active = gid < groups_per_row * rows;
-    const uint32_t ry = active ? (f.row_magic ? __umulhi(gid, f.row_magic) : gid / groups_per_row) : 0u;
-    const uint32_t y = a.row_begin + ry;
-    const uint32_t x0 = active ? (gid - ry * groups_per_row) * PPT : 0u;
-    const bool lpv_bad = (GI == SAH_GI_LPV) ? (f.state->nonfinite[f.parity] != 0u) : false;
-
-    uint32_t wc[PPT], wd[PPT], we[PPT], wz[PPT], wn[2 * PPT], wao[PPT], wm[PPT];
-    if (active) {
-        load_words<PPT>(a.color.ptr + (size_t)y * a.color.pitch + (size_t)x0 * 4, wc);
-        load_words<PPT>(a.data.ptr + (size_t)y * a.data.pitch + (size_t)x0 * 4, wd);
-        load_words<PPT>(a.emission.ptr + (size_t)y * a.emission.pitch + (size_t)x0 * 4, we);
-        load_words<PPT>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x0 * 4, wz);
-        load_words<2 * PPT>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x0 * 8, wn);
-        if (GI == SAH_GI_LPV && a.has_ao) load_words<PPT>(a.ao.ptr + (size_t)y * a.ao.pitch + (size_t)x0 * 4, wao);
-        if (SUN == SAH_SHADOW_MODE_RT && a.has_mask) load_words<PPT>(a.shadow_mask.ptr + (size_t)y * a.shadow_mask.pitch + (size_t)x0 * 4, wm);
-    }
     // per-row / per-column terms of the view-space position (two texcoord conventions, see lighting_common.hpp)
     const Fn ty_g = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
     const float rowy_glsl = (Fn(f.p5) * (ty_g * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
@@ -267,13 +299,12 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
         p.mask = (SUN == SAH_SHADOW_MODE_RT && a.has_mask) ? __uint_as_float(wm[i]) : 1.0f;
         const uint32_t x = x0 + i;
         float colx_glsl = 0.f, colx_slang = 0.f;
-        if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) {
-            const Fn tx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]);
-            colx_glsl = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
-        }
-        if (SUN == SAH_SHADOW_MODE_RT) {
-            const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]);
-            colx_slang = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+        if (f.colx_tab) {
+            if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) colx_glsl = colx_g[i];
+            if (SUN == SAH_SHADOW_MODE_RT) colx_slang = colx_s[i];
+        } else {
+            if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) colx_glsl = colx_glsl_of(a, f, x);
+            if (SUN == SAH_SHADOW_MODE_RT) colx_slang = colx_slang_of(a, f, x);
         }
         const FastPixelOut r = shade_pixel_fast_sl<SUN, GI, RELAXED>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
         out[2 * i] = r.lit.x;
@@ -330,10 +361,10 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     const uint32_t rows = a.row_end - a.row_begin;
     const uint64_t groups = (uint64_t)(a.width / ppt) * rows;
     if (groups == 0) return hipSuccess;
-    if (GI == SAH_GI_LPV) {
+    if (GI == SAH_GI_LPV && f.repack) {
         const uint32_t prows = (lpv.red.height + 2 * kLpvPackBorder) * (lpv.red.depth + 2 * kLpvPackBorder);
         hipLaunchKernelGGL(k_lpv_pack, dim3(prows), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, const_cast<uint8_t*>(f.lpv_packed), f.pk_row_pitch,
-                           f.pk_slice_pitch, f.state, f.parity);
+                           f.pk_slice_pitch, f.state, f.pack_serial);
     }
     const uint32_t blocks = (uint32_t)((groups + 255) / 256);
     const dim3 block(256);
@@ -369,6 +400,11 @@ static hipError_t launch_gi(const LightingArgs& a, const CsmArgs& csm, const Lpv
             return f ? launch_fast_ppt<SUN, SAH_GI_LPV>(a, csm, lpv, sky, *f, ppt, st) : launch_general_ppt<SUN, SAH_GI_LPV>(a, csm, lpv, sky, ppt, st);
         default: return hipErrorNotSupported;
     }
+}
+
+hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_colx_table, dim3((a.width + 255u) / 256u), dim3(256), 0, st, a, f, out, stride);
+    return hipGetLastError();
 }
 
 hipError_t launch_lighting_tiled(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,

@@ -75,8 +75,11 @@ struct SkyArgs {
 // Per-context device state shared by consecutive Lighting calls (double-buffered by call parity so that no memset
 // is needed between calls: the fix-up kernel of call k zeroes the slots call k+1 will use).
 struct FrameState {
-    uint32_t unused[2];
-    uint32_t nonfinite[2];  // != 0 when an LPV volume holds an inf/NaN texel
+    uint32_t unused[3];
+    // serial * 2 + 1 of the last k_lpv_pack run that met an inf / NaN texel (atomicMax; packs are numbered from 1 per context): the gather
+    // copy of pack number n holds a non-finite texel iff this word equals n * 2 + 1 — nothing to clear between packs, and a copy that is
+    // kept over several Lighting calls (sah_gi::lpv_generation) keeps its verdict
+    uint32_t nonfinite_tag;
 };
 
 // What the fast kernel may assume, established by the host (api.cpp: detect_fast_path):
@@ -90,7 +93,10 @@ struct FastArgs {
     uint32_t pos_div_nr;  // view-space position quotients may use the shared-reciprocal divide (lighting_fast.hpp)
     uint32_t sky_enabled;
     uint32_t row_magic;  // floor(2^32 / groups per row) + 1 when mulhi(gid, row_magic) == gid / groups_per_row for every thread of the call, else 0
-    uint32_t parity;
+    uint32_t pack_serial;  // number of the k_lpv_pack run that made (or makes, in this call) the gather copy
+    uint32_t repack;       // 1: this call rebuilds the gather copy first
+    const float* colx_tab; // per-column view-space x numerators (k_colx_table): [0, width) the GLSL flavour, [colx_stride, ..) the Slang one; or null
+    uint32_t colx_stride;
     uint32_t tolerance;  // experiment builds only (-DSAH_EXP_TOLERANCE_1ULP): run the relaxed body where it exists; always 0 otherwise
     FrameState* state;
     // Deferred pixels, without atomics: the wave that shades thread groups [64 s, 64 s + 64) owns segment s — kSegSize(PPT) byte codes

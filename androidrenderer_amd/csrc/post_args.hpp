@@ -18,6 +18,16 @@ struct TonemapArgs {
     const float* thresholds;  // device, 256 floats then kTmMaxBuckets bytes: see api_post.cpp tonemap_code(), build_tonemap_buckets()
     uint32_t bucket_base;     // bit pattern >> kTmBucketShift of thresholds[1]
     float thr_lo, thr_hi;     // thresholds[1], thresholds[255]
+    // tolerance mode only (tonemap_tol.hip): the axis set-ups of every output column / row, built once per (output extent, chain extents) by
+    // k_tonemap_axis_tables: entry [(mip * 2 + axis) * 4 + variant][column or row], axis 0 = x, stride `axis_stride` entries
+    const struct TmAxis* axis_tables;
+    uint32_t axis_stride;
+};
+
+struct TmAxis {  // texel index of the first of the two taps (unclamped) and the two weights (y: divided by 16)
+    int i;
+    float w0, w1;
+    int pad;
 };
 
 constexpr uint32_t kTmBucketShift = 19, kTmMaxBuckets = 512;

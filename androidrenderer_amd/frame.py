@@ -117,6 +117,7 @@ class LightingInputs:
                 gi.lpv_cascades = C.cast(self.lpv.matrices, C.POINTER(_abi.LpvCascadeMatrices))
                 gi.lpv_num_cascades = 4
                 gi.lpv_exposure = float(np.float32(math.pi) * np.float32(10.0))
+                gi.lpv_generation = getattr(self, "lpv_generation", 0)  # 0: the library rebuilds its gather copy of the volumes on every call
             elif self.gi_kind == _abi.GI_CACHE:
                 gi.probe_irradiance = images.volume(arrays["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
                 gi.probe_depth = images.volume(arrays["probe_depth"], _abi.FORMAT_R16G16_SFLOAT)

@@ -21,7 +21,7 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
 
@@ -54,6 +54,7 @@ def load():
     lib.sah_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32]
     lib.sah_bloom_from_mip0.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
     lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
+    lib.sah_tonemap_ex.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32, C.c_uint32]
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
     lib.sah_lpv_propagate.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.POINTER(_abi.Volume), C.c_uint32, C.c_uint32]
     lib.sah_allgather_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
@@ -136,8 +137,9 @@ class Context:
     def bloom_from_mip0(self, scene, chain):
         self._check(self.lib.sah_bloom_from_mip0(self.handle, C.byref(scene), C.byref(chain)))
 
-    def tonemap(self, scene, chain, out, row_begin=0, row_end=0):
-        self._check(self.lib.sah_tonemap(self.handle, C.byref(scene), C.byref(chain), C.byref(out), row_begin, row_end))
+    def tonemap(self, scene, chain, out, row_begin=0, row_end=0, flags=0):
+        """flags: 0 = strict (bit-identical to the oracle), _abi.TONEMAP_TOLERANCE_1CODE = within one code of it, about twice as fast"""
+        self._check(self.lib.sah_tonemap_ex(self.handle, C.byref(scene), C.byref(chain), C.byref(out), row_begin, row_end, flags))
 
     def lpv_clear(self, red, green, blue, geometry, num_cascades):
         null = C.POINTER(_abi.Volume)()

@@ -155,6 +155,11 @@ def main():
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
     ap.add_argument("--ramp-ms", type=float, default=200.0, help="untimed: run the step back to back for this long before the W warm-up steps, so that the "
                     "timed region does not start in the GPU's idle power state (reported in config.clock_ramp_ms)")
+    ap.add_argument("--repack-lpv", action="store_true", help="LPV workloads: lpv_generation = 0, i.e. the library rebuilds its gather copy of the LPV on every "
+                    "step (5 us + a launch), as it must when the volumes change every frame; default: the volumes of this benchmark never change, so "
+                    "their change counter stays at 1 and the copy made by the first step is kept (config.lpv_gather_copy says which)")
+    ap.add_argument("--strict-tonemap", action="store_true", help="chain workloads: the strict composite (codes bit-identical to the oracle) instead of "
+                    "SAH_TONEMAP_TOLERANCE_1CODE (within one R8G8B8A8 code of it: north_star's tolerance for the final image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
     args = ap.parse_args()
@@ -204,6 +209,7 @@ def main():
         lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, wl["radius"], seed=8)
     fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
                               synth_device=str(dev), shadow=wl.get("shadow", "noise"))
+    fr.lpv_generation = 0 if args.repack_lpv else 1
     d_arr = fr.device_arrays(dev)
     bytes_per_pixel = fr.bytes_per_pixel()
 
@@ -306,10 +312,12 @@ def main():
                   "shadow_samples": float(fr.sun.constants.num_shadow_samples), "ao_unoccluded_fraction": round(float((d_arr["ao"] == 1).float().mean()), 4),
                   "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4)}
 
+    tm_flags = 0 if args.strict_tonemap else _abi.TONEMAP_TOLERANCE_1CODE
     pipelined = chain and gather and lib_gather and comm_stream is not None
     if pipelined:
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
-        pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev))
+        pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev),
+                                      tonemap_flags=tm_flags)
         sc = pc.sets[0]
 
         def step(i, e0=None, e1=None):
@@ -321,7 +329,7 @@ def main():
         my_px = W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
     elif chain:
         # the whole frame, sharded (chain.py): every exchange goes through the library (torch path only with --torch-gather)
-        sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world)
+        sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world, tonemap_flags=tm_flags)
         q, per = sc.plan.mip0_rows_per_rank, sc.plan.rows_per_rank
         mip0_bytes, out_bytes = sc.mip0_alloc.view(torch.uint8).view(-1), sc.out_alloc.view(-1)
         mip0_slot_bytes, out_slot_bytes = q * sc.mip0_alloc.shape[1] * 8, per * W * 4
@@ -401,7 +409,7 @@ def main():
     single_gpu = None
     if world > 1 or args.force_gather:
         if chain:
-            ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1)
+            ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1, tonemap_flags=tm_flags)
             ref_step = lambda: ref.step(gather=False)
         else:
             ref_lit = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
@@ -523,6 +531,9 @@ def main():
                             + (" (G-buffer, shadow cascades and LPV made on the GPU by the producer passes)" if wl.get("produced") else ""),
                 "resolution": [W, H],
                 "clock_ramp_ms": args.ramp_ms,
+                "tonemap": None if not chain else ("strict" if args.strict_tonemap else "SAH_TONEMAP_TOLERANCE_1CODE (within one code of the strict composite)"),
+                "lpv_gather_copy": None if gi_kind != _abi.GI_LPV else ("rebuilt every step (lpv_generation 0)" if args.repack_lpv else
+                                                                          "kept across steps (lpv_generation 1: the LPV volumes of this benchmark never change)"),
                 "gbuffer": wl["gbuffer"],
                 "parallelism": par,
                 "gather": bool(gather),

@@ -166,6 +166,13 @@ typedef struct sah_gi {
     sah_plane noise;          /* RGBA8_UNORM 128x128 blue-noise layer */
     uint32_t num_extra_rays;  /* r.GI.Reconstruction.NumSamples */
     float extra_ray_radius;   /* r.GI.Reconstruction.Size */
+
+    /* LPV: change counter of the three volumes, kept by whoever writes them (the reference re-propagates once per frame:
+     * light_propagation_volume.cpp:970-1063).  The fast Lighting kernel gathers from an interleaved copy of the volumes that it otherwise
+     * rebuilds on every call (5 us + a launch); with a non-zero counter the copy is rebuilt only when the counter or one of the three
+     * volume descriptors differs from the previous sah_lighting call of this context.  0 = rebuild every call.  sah_lpv_clear,
+     * sah_lpv_propagate and sah_lpv_inject_vpls on this context drop the copy regardless. */
+    uint32_t lpv_generation;
 } sah_gi;
 
 /* Sky LUTs sampled by the sky fill (RenderCore/render/procedural_sky.cpp:13-42,151-172). */
@@ -247,6 +254,14 @@ int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene_color, const sah_mi
  * Rows [row_begin,row_end) of the output are written (0,0 = all). */
 int sah_tonemap(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, const sah_plane* out_rgba8,
                 uint32_t row_begin, uint32_t row_end);
+/* The same pass with flags.  0 = sah_tonemap: strict, every operator of the shader individually rounded in the shader's order, codes
+ * bit-identical to the oracle.  SAH_TONEMAP_TOLERANCE_1CODE: the same real-number expression evaluated in another order (the nine tent
+ * taps of a mip as one column pass per tile and four row interpolations per pixel, fused multiply-adds) — every channel of every pixel
+ * within ONE R8G8B8A8 code of the strict result (BASELINE.json north_star: 1 ULP of the stored format), identical on all but the few
+ * pixels whose value lies within ~2^-20 relative of a code threshold; about half the time of the strict pass. */
+#define SAH_TONEMAP_TOLERANCE_1CODE (1u << 0)
+int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, const sah_plane* out_rgba8,
+                   uint32_t row_begin, uint32_t row_end, uint32_t flags);
 
 /* LightPropagationVolume::clear_volume / propagate_lighting —
  * RenderCore/render/gi/light_propagation_volume.cpp:839-926, 970-1063.

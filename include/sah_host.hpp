@@ -728,6 +728,9 @@ public:
     void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList&) const override {  // light_propagation_volume.cpp:245-272
         for (int c = 0; c < 3; c++) textures.push_back({vol[c], kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
     }
+    // to be called by anything that writes the volumes behind the library's back (an upload, another API): sah_gi::lpv_generation
+    void mark_volumes_written() { generation = generation == 0xffffffffu ? 1u : generation + 1u; }
+    uint32_t generation = 1;
     void render_to_lit_scene(CommandBuffer& commands, BufferHandle view_buffer, TextureHandle ao_tex, TextureHandle) const override {
         (void)view_buffer;  // the view block of the Lighting pass is the one the overlay reads
         sah_gi& gi = commands.lighting.gi;
@@ -737,6 +740,7 @@ public:
         gi.lpv_cascades = cascades.data();
         gi.lpv_num_cascades = num_cascades;
         gi.lpv_exposure = 3.1415927f * 10.f;  // r.GI.LPV.Exposure, pushed as a constant (:298-299)
+        gi.lpv_generation = generation;       // the library's own writers (clear / inject / propagate) drop its gather copy themselves
         commands.lighting.has_gi = true;
         if (ao_tex) {  // the LPV overlay is the one consumer of the AO texture (gi/lpv/overlay.frag:153-155)
             commands.lighting.ao = ao_tex->plane();

@@ -167,3 +167,67 @@ def test_tonemap_unusual_chains(hip_ctx, case):
     if n:
         assert not np.array_equal(ref, np.zeros_like(ref))
     assert np.array_equal(got, ref), f"{case}: {int((got != ref).sum())} of {got.size} codes differ"
+
+
+# ---- tolerance mode of the composite (SAH_TONEMAP_TOLERANCE_1CODE): within one code of the strict kernel, which the oracle pins ------
+def _both_modes(ctx, scene_u16, mips_np, ow, oh, rows=None):
+    import torch
+    sc = util.to_torch(scene_u16)
+    tm = [util.to_torch(m) for m in mips_np]
+    sp, mc = images.plane(sc, _abi.FORMAT_R16G16B16A16_SFLOAT), images.mipchain(tm)
+    outs = []
+    for flags in (0, _abi.TONEMAP_TOLERANCE_1CODE):
+        out = torch.zeros((oh, ow, 4), dtype=torch.uint8, device="cuda")
+        op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
+        for r0, r1 in (rows or [(0, 0)]):
+            ctx.tonemap(sp, mc, op, r0, r1, flags=flags)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    return outs
+
+
+def _code_histogram(name, strict, tol):
+    d = np.abs(strict.astype(np.int32) - tol.astype(np.int32))
+    hist = np.bincount(np.minimum(d.reshape(-1), 3), minlength=4)
+    print(f"{name}: |code difference| histogram [0, 1, 2, >=3] = {hist.tolist()} ({100.0 * hist[1] / d.size:.4f} % at 1)")
+    return d
+
+
+@pytest.mark.parametrize("size", [(256, 144), (250, 130), (1920, 1080), (333, 187), (64, 36), (40, 24), (9, 5), (2048, 96), (97, 512)])
+def test_tonemap_tolerance_mode_within_one_code(hip_ctx, size):
+    w, h = size
+    scene = synth.hdr_scene(w, h, seed=21)
+    if size == (333, 187):  # signed, huge, inf and NaN texels
+        f = scene.view(np.float16).reshape(h, w, 4)
+        rng = np.random.default_rng(3)
+        ys, xs = rng.integers(0, h, 400), rng.integers(0, w, 400)
+        f[ys[:150], xs[:150], :3] *= np.float16(-1.0)
+        f[ys[150:300], xs[150:300], :3] = np.float16(60000.0)
+        f[ys[300:350], xs[300:350], 0] = np.float16(np.inf)
+        f[ys[350:], xs[350:], 1] = np.float16(np.nan)
+    ref_mips, ref_out = _run_post_oracle(scene.view(np.uint16), w, h)
+    strict, tol = _both_modes(hip_ctx, scene.view(np.uint16), ref_mips, w, h)
+    assert np.array_equal(strict, ref_out)  # strict is the oracle's image
+    d = _code_histogram(f"tonemap tolerance {w}x{h}", strict, tol)
+    if size == (333, 187):
+        # the bound is stated for finite texels.  An inf / NaN texel poisons the pixels whose taps reach it in both modes, but which products
+        # meet a zero weight (0 * inf = NaN) depends on the order of evaluation, so the rim of a poisoned region may differ
+        assert (d <= 1).mean() > 0.97
+    else:
+        assert d.max() <= 1
+        assert (d == 1).mean() < 0.01
+
+
+def test_tonemap_tolerance_mode_rows_and_unusual_chains(hip_ctx):
+    o = util.oracle()
+    for case, (w, h), (ow, oh), n in (("rows", (200, 117), (200, 117), 6), ("one_mip", (192, 108), (192, 108), 1), ("three_mips", (192, 108), (192, 108), 3),
+                                      ("output_2x", (192, 108), (384, 216), 6), ("output_smaller", (192, 108), (120, 70), 6), ("wide_21_9", (336, 144), (336, 144), 6),
+                                      ("no_mips", (192, 108), (192, 108), 0)):
+        scene = synth.hdr_scene(w, h, seed=29).view(np.uint16)
+        full = _mips_np(w, h)
+        sp = images.plane(scene, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        assert o.orc_bloom(C.byref(sp), C.byref(images.mipchain(full))) == 0
+        rows = [(0, 27), (27, 54), (54, 85), (85, 117)] if case == "rows" else None
+        strict, tol = _both_modes(hip_ctx, scene, full[:n], ow, oh, rows=rows)
+        d = _code_histogram(f"tonemap tolerance {case}", strict, tol)
+        assert d.max() <= 1, case

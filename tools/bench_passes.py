@@ -93,6 +93,7 @@ def main():
     out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
     op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
     timeit("tonemap composite", lambda: ctx.tonemap(sp, chain, op), int((8 + 4 + 2.667) * px))
+    timeit("tonemap composite, tolerance 1 code", lambda: ctx.tonemap(sp, chain, op, flags=_abi.TONEMAP_TOLERANCE_1CODE), int((8 + 4 + 2.667) * px))
 
     # ---- LPV maintenance ----------------------------------------------------------------------------------
     vols = synth.lpv_volumes(4, 5)
