@@ -50,6 +50,7 @@ class ProbeAtlases(C.Structure):  # sah_probe_atlases
 PRIMITIVE_TYPE_SOLID, PRIMITIVE_TYPE_CUTOUT = 0, 1
 RASTER_STATS_WORDS = 8
 RT_STATS_WORDS = 4
+IPC_HANDLE_BYTES = 128
 
 
 class VertexData(C.Structure):  # sah_vertex_data, 40 bytes

@@ -4,6 +4,12 @@ row arithmetic).  Plumbing shared by bench.py and tests/: buffers are torch tens
 from . import _abi, images, shard
 
 
+def connect_direct_exchange(ctx, allgather):
+    """Joins the context to the direct (IPC) exchange of its job.  allgather(b: bytes) -> [bytes of rank 0, bytes of rank 1, ...]: the
+    caller's channel between the ranks (torch.distributed.all_gather_object, MPI, files ...)."""
+    ctx.ipc_connect(allgather(ctx.ipc_open()))
+
+
 class ShardedChain:
     def __init__(self, ctx, frame, device_arrays, rank, world, num_mips=6, tonemap_flags=0):
         import torch
@@ -34,6 +40,13 @@ class ShardedChain:
             self.descs.append(frame.describe(device_arrays, self.lit))
         frame.row_begin = frame.row_end = 0
         self.world = world
+
+    def register_direct_exchange(self, allgather):
+        """Makes the two gathered buffers of this chain (bloom mip 0, final image) visible to the peers: their exchanges then go straight
+        into every peer's copy (sah_ipc_register) instead of through RCCL.  Every rank must register its chains in the same order."""
+        for t in (self.mip0_alloc, self.out_alloc):
+            nbytes = t.numel() * t.element_size()
+            self.ctx.ipc_register(t.data_ptr(), nbytes, allgather(self.ctx.ipc_export(t.data_ptr(), nbytes)))
 
     # the three local stages; `exchange_*` are the two gathers (replaceable: tests emulate several ranks on one device)
     def lighting(self):
@@ -94,6 +107,10 @@ class PipelinedChain:
         self.finished = 0
         ctx.set_stream(self.work.cuda_stream)
         ctx.comm_set_stream(comm_stream.cuda_stream)
+
+    def register_direct_exchange(self, allgather):
+        for s in self.sets:
+            s.register_direct_exchange(allgather)
 
     def submit(self, lighting_events=None):
         """Enqueue A(i) and the mip-0 exchange of the next frame, then B(i - 1) and the final exchange of the previous one."""

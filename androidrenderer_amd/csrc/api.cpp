@@ -164,6 +164,7 @@ const char* sah_last_error(const sah_ctx* ctx) { return ctx ? ctx->last_error.c_
 
 int sah_comm_init(sah_ctx* ctx, const void* comm_id);
 void sah_comm_destroy(sah_ctx* ctx);
+void sah_ipc_destroy(sah_ctx* ctx);
 
 int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_id) {
     if (!out || world < 1 || rank < 0 || rank >= world) return SAH_ERR_INVALID_ARGUMENT;
@@ -212,11 +213,13 @@ int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_
 void sah_destroy(sah_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    sah_comm_destroy(ctx);
+    sah_comm_destroy(ctx);  // (synchronises both streams first)
+    sah_ipc_destroy(ctx);
     if (ctx->comm_ready) (void)hipEventDestroy(ctx->comm_ready);
     if (ctx->comm_done) (void)hipEventDestroy(ctx->comm_done);
     if (ctx->luts) (void)hipFree(ctx->luts);
     if (ctx->probe_slots) (void)hipFree(ctx->probe_slots);
+    if (ctx->probe_done) (void)hipEventDestroy(ctx->probe_done);
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);
     if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
@@ -235,10 +238,12 @@ void sah_destroy(sah_ctx* ctx) {
 
 int sah_set_stream(sah_ctx* ctx, void* hip_stream) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
-    // work in flight on the old stream (e.g. the clear pass behind a sah_probe_update) must not overlap what the next call enqueues on
-    // the new one: switching streams is rare, so it simply drains the old one
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    // (switching streams does not order them: callers that pipeline two work streams switch per frame, androidrenderer_amd/chain.py.  The
+    // one piece of context-wide device state that a switch could expose — the probe-slot table of sah_probe_update — orders itself.)
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return SAH_OK;

@@ -1,0 +1,196 @@
+// C ABI: the direct exchange backend (include/sah_hip.h "direct exchange"; kernels in ipc.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/sah_hip.h"
+#include "ctx.hpp"
+
+namespace sah {
+struct IpcPeers {
+    uint32_t* slot[SAH_IPC_MAX_WORLD];
+};
+hipError_t launch_ipc_signal(const IpcPeers& peers, uint32_t value, hipStream_t st);
+hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* timed_out, hipStream_t st);
+}  // namespace sah
+
+namespace {
+constexpr uint32_t kMagic = 0x53414849u;  // "SAHI"
+constexpr uint32_t kMailboxWords = 2 * SAH_IPC_MAX_BUFFERS * SAH_IPC_MAX_WORLD;
+
+struct Handle {  // SAH_IPC_HANDLE_BYTES
+    hipIpcMemHandle_t mem;  // 64 bytes: the allocation the buffer lies in
+    uint64_t offset, bytes;
+    uint32_t magic, rank, device, pad;
+    uint8_t reserved[128 - 64 - 16 - 16];
+};
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+static_assert(sizeof(Handle) == SAH_IPC_HANDLE_BYTES, "handle layout");
+
+int export_range(sah_ctx* ctx, const void* ptr, uint64_t bytes, Handle* h) {
+    void* base = nullptr;
+    size_t size = 0;
+    HIP_TRY(ctx, hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)ptr));
+    const uint64_t off = (uint64_t)((const uint8_t*)ptr - (const uint8_t*)base);
+    if (off + bytes > size) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the buffer leaves its allocation (%llu + %llu > %zu)", (unsigned long long)off, (unsigned long long)bytes, size);
+    memset(h, 0, sizeof(*h));
+    HIP_TRY(ctx, hipIpcGetMemHandle(&h->mem, base));
+    h->offset = off;
+    h->bytes = bytes;
+    h->magic = kMagic;
+    h->rank = (uint32_t)ctx->rank;
+    h->device = (uint32_t)ctx->device;
+    return SAH_OK;
+}
+
+// maps the allocation behind a peer's handle (once per allocation) and returns the buffer's address in this process
+int open_range(sah_ctx* ctx, const Handle& h, uint8_t** out) {
+    for (const auto& m : ctx->ipc.mappings)
+        if (memcmp(m.handle, &h.mem, 64) == 0) {
+            *out = (uint8_t*)m.base + h.offset;
+            return SAH_OK;
+        }
+    void* base = nullptr;
+    HIP_TRY(ctx, hipIpcOpenMemHandle(&base, h.mem, hipIpcMemLazyEnablePeerAccess));
+    sah_ctx::IpcState::Mapping m;
+    memcpy(m.handle, &h.mem, 64);
+    m.base = base;
+    ctx->ipc.mappings.push_back(m);
+    *out = (uint8_t*)base + h.offset;
+    return SAH_OK;
+}
+}  // namespace
+
+extern "C" void sah_ipc_destroy(sah_ctx* ctx) {
+    auto& s = ctx->ipc;
+    for (const auto& m : s.mappings) (void)hipIpcCloseMemHandle(m.base);
+    s.mappings.clear();
+    if (s.mailbox) (void)hipFree(s.mailbox);
+    if (s.timed_out) (void)hipHostFree(s.timed_out);
+    s.mailbox = nullptr;
+    s.timed_out = nullptr;
+    s.open = s.connected = false;
+    s.num_buffers = 0;
+}
+
+// the gather itself: called by allgather_bytes_impl (api_post.cpp) when `buffer` lies inside a registered buffer
+int sah_ipc_gather(sah_ctx* ctx, uint32_t id, uint8_t* buffer, uint64_t bytes_per_rank, bool reversed, hipStream_t st) {
+    using namespace sah;
+    auto& s = ctx->ipc;
+    auto& b = s.buffers[id];
+    if (*s.timed_out) return fail(ctx, SAH_ERR_COMM, "direct exchange: a peer did not arrive within 2 s (an earlier gather gave up)");
+    const uint64_t off = (uint64_t)(buffer - b.local);
+    if (off + (uint64_t)ctx->world * bytes_per_rank > b.bytes) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the gather leaves the registered buffer");
+    const uint32_t n = ++b.seq;
+    const int slot = reversed ? ctx->world - 1 - ctx->rank : ctx->rank;
+    IpcPeers ready_out{}, ready_in{}, done_out{}, done_in{};
+    for (int p = 0; p < ctx->world; p++) {
+        if (p == ctx->rank) continue;
+        ready_out.slot[p] = s.peer_mailbox[p] + id * SAH_IPC_MAX_WORLD + ctx->rank;
+        ready_in.slot[p] = s.mailbox + id * SAH_IPC_MAX_WORLD + p;
+        done_out.slot[p] = s.peer_mailbox[p] + (SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + ctx->rank;
+        done_in.slot[p] = s.mailbox + (SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + p;
+    }
+    // 1. my rows are written (stream order) and my copy of the buffer may be overwritten; 2. so may every peer's
+    HIP_TRY(ctx, launch_ipc_signal(ready_out, n, st));
+    HIP_TRY(ctx, launch_ipc_wait(ready_in, n, s.timed_out, st));
+    // 3. one hop per peer
+    const uint64_t slot_off = off + (uint64_t)slot * bytes_per_rank;
+    for (int p = 0; p < ctx->world; p++)
+        if (p != ctx->rank) HIP_TRY(ctx, hipMemcpyAsync(b.peer[p] + slot_off, b.local + slot_off, bytes_per_rank, hipMemcpyDeviceToDevice, st));
+    // 4. my rows have landed everywhere; 5. so have everybody's here
+    HIP_TRY(ctx, launch_ipc_signal(done_out, n, st));
+    HIP_TRY(ctx, launch_ipc_wait(done_in, n, s.timed_out, st));
+    return SAH_OK;
+}
+
+// index of the registered buffer that holds [ptr, ptr + bytes), or -1
+int sah_ipc_find(const sah_ctx* ctx, const void* ptr, uint64_t bytes) {
+    const auto& s = ctx->ipc;
+    if (!s.connected) return -1;
+    for (uint32_t i = 0; i < s.num_buffers; i++) {
+        const uint8_t* p = (const uint8_t*)ptr;
+        if (p >= s.buffers[i].local && p + bytes <= s.buffers[i].local + s.buffers[i].bytes) return (int)i;
+    }
+    return -1;
+}
+
+extern "C" {
+
+int sah_ipc_open(sah_ctx* ctx, void* out_handle) {
+    if (!ctx || !out_handle) return SAH_ERR_INVALID_ARGUMENT;
+    if (ctx->world > SAH_IPC_MAX_WORLD) return fail(ctx, SAH_ERR_UNSUPPORTED, "direct exchange: at most %d ranks", SAH_IPC_MAX_WORLD);
+    auto& s = ctx->ipc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s.open) {
+        // fine-grained: peers' system-scope stores become visible to the polling wave without a kernel boundary
+        if (hipExtMallocWithFlags((void**)&s.mailbox, kMailboxWords * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(ctx, hipMalloc((void**)&s.mailbox, kMailboxWords * sizeof(uint32_t)));
+        }
+        HIP_TRY(ctx, hipMemset(s.mailbox, 0, kMailboxWords * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s.timed_out, 64));
+        *s.timed_out = 0;
+        s.open = true;
+    }
+    Handle h;
+    if (int rc = export_range(ctx, s.mailbox, kMailboxWords * sizeof(uint32_t), &h); rc != SAH_OK) return rc;
+    memcpy(out_handle, &h, sizeof(h));
+    return SAH_OK;
+}
+
+int sah_ipc_connect(sah_ctx* ctx, const void* all_handles) {
+    if (!ctx || !all_handles) return SAH_ERR_INVALID_ARGUMENT;
+    auto& s = ctx->ipc;
+    if (!s.open) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_ipc_open first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Handle* hs = (const Handle*)all_handles;
+    for (int p = 0; p < ctx->world; p++) {
+        if (hs[p].magic != kMagic || (int)hs[p].rank != p || hs[p].bytes != kMailboxWords * sizeof(uint32_t))
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "handle %d is not rank %d's mailbox", p, p);
+        if (p == ctx->rank) {
+            s.peer_mailbox[p] = s.mailbox;
+            continue;
+        }
+        uint8_t* ptr = nullptr;
+        if (int rc = open_range(ctx, hs[p], &ptr); rc != SAH_OK) return rc;
+        s.peer_mailbox[p] = (uint32_t*)ptr;
+    }
+    s.connected = true;
+    return SAH_OK;
+}
+
+int sah_ipc_export(sah_ctx* ctx, const void* buffer, uint64_t bytes, void* out_handle) {
+    if (!ctx || !buffer || !bytes || !out_handle) return SAH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Handle h;
+    if (int rc = export_range(ctx, buffer, bytes, &h); rc != SAH_OK) return rc;
+    memcpy(out_handle, &h, sizeof(h));
+    return SAH_OK;
+}
+
+int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all_handles) {
+    if (!ctx || !buffer || !bytes || !all_handles) return SAH_ERR_INVALID_ARGUMENT;
+    auto& s = ctx->ipc;
+    if (!s.connected) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_ipc_connect first");
+    if (s.num_buffers == SAH_IPC_MAX_BUFFERS) return fail(ctx, SAH_ERR_UNSUPPORTED, "at most %d registered buffers", SAH_IPC_MAX_BUFFERS);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Handle* hs = (const Handle*)all_handles;
+    auto& b = s.buffers[s.num_buffers];
+    b = {};
+    b.local = (uint8_t*)buffer;
+    b.bytes = bytes;
+    for (int p = 0; p < ctx->world; p++) {
+        if (hs[p].magic != kMagic || (int)hs[p].rank != p || hs[p].bytes != bytes)
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "handle %d does not describe rank %d's copy of a %llu-byte buffer", p, p, (unsigned long long)bytes);
+        if (p == ctx->rank) {
+            b.peer[p] = b.local;
+            continue;
+        }
+        if (int rc = open_range(ctx, hs[p], &b.peer[p]); rc != SAH_OK) return rc;
+    }
+    s.num_buffers++;
+    return SAH_OK;
+}
+
+}  // extern "C"

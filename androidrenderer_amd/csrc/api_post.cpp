@@ -97,6 +97,9 @@ bool lpv_vol_ok(const sah_volume* v) {
 }
 }  // namespace
 
+int sah_ipc_find(const sah_ctx* ctx, const void* ptr, uint64_t bytes);
+int sah_ipc_gather(sah_ctx* ctx, uint32_t id, uint8_t* buffer, uint64_t bytes_per_rank, bool reversed, hipStream_t st);
+
 extern "C" {
 
 int sah_copy_scene_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
@@ -371,7 +374,12 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
         HIP_TRY(ctx, hipMalloc((void**)&ctx->probe_slots, 32 * 32 * 32 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->probe_slots, 0, 32 * 32 * 32 * sizeof(uint32_t), ctx->stream));
     }
+    // the slot table is context-wide: an update enqueued on another stream than the previous one starts behind that one's clear pass
+    if (!ctx->probe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->probe_done, hipEventDisableTiming));
+    if (ctx->probe_stream && ctx->probe_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->probe_done, 0));
     HIP_TRY(ctx, sah::launch_probe_update(a, varg(*trace_results), probes_to_update, num_probes, ctx->probe_slots, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->probe_done, ctx->stream));
+    ctx->probe_stream = ctx->stream;
     return SAH_OK;
 }
 
@@ -502,6 +510,23 @@ int sah_comm_wait(sah_ctx* ctx) {
 static int allgather_bytes_impl(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank, bool reversed) {
     if (!ctx || !buffer) return SAH_ERR_INVALID_ARGUMENT;
     if (bytes_per_rank == 0) return SAH_OK;
+    if (const int id = sah_ipc_find(ctx, buffer, (uint64_t)ctx->world * bytes_per_rank); id >= 0) {
+        // direct exchange (api_ipc.cpp): same stream discipline as the RCCL path below
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const bool side = ctx->comm_stream && ctx->comm_stream != ctx->stream;
+        if (side) {
+            HIP_TRY(ctx, hipEventRecord(ctx->comm_ready, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0));
+            st = ctx->comm_stream;
+        }
+        if (int rc = sah_ipc_gather(ctx, (uint32_t)id, (uint8_t*)buffer, bytes_per_rank, reversed, st); rc != SAH_OK) return rc;
+        if (side) {
+            HIP_TRY(ctx, hipEventRecord(ctx->comm_done, ctx->comm_stream));
+            ctx->comm_pending = true;
+        }
+        return SAH_OK;
+    }
     if (!ctx->comm) {
         if (ctx->world == 1) return SAH_OK;  // one rank and no communicator: the buffer already is the gathered result
         return fail(ctx, SAH_ERR_COMM, "context was created without a communicator");

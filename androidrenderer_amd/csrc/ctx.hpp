@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/sah_hip.h"
 #include "params.hpp"
@@ -17,6 +18,8 @@ struct sah_ctx {
     bool own_stream = false;
     float* luts = nullptr;  // device: 256 sRGB->linear + 256 UNORM8->float
     uint32_t* probe_slots = nullptr;  // device, 32^3 words (sah_probe_update)
+    hipEvent_t probe_done = nullptr;  // behind the last sah_probe_update (its clear pass leaves probe_slots all zero again)
+    hipStream_t probe_stream = nullptr;  // the stream that update ran on: an update on another stream waits for probe_done first
     bool lpv_tables_built = false;  // lpv.hip: c_prop_tables of this device filled (first sah_lpv_propagate)
     void* comm = nullptr;   // ncclComm_t
     void* comm_reversed = nullptr;  // ncclComm_t with rank world - 1 - rank (sah_allgather_rows_reversed), made on first use
@@ -58,6 +61,24 @@ struct sah_ctx {
         sah::RtScene scene = {};
         bool built = false;
     } rt;
+    struct IpcState {                  // direct exchange (api_ipc.cpp): mailboxes and peer mappings
+        bool open = false, connected = false;
+        uint32_t* mailbox = nullptr;   // own: ready[SAH_IPC_MAX_BUFFERS][SAH_IPC_MAX_WORLD] then done[..][..], fine-grained device memory
+        uint32_t* peer_mailbox[SAH_IPC_MAX_WORLD] = {};
+        uint32_t* timed_out = nullptr; // pinned host word the wait kernel raises
+        struct Mapping {               // one opened IPC handle (an allocation of a peer)
+            unsigned char handle[64];
+            void* base;
+        };
+        std::vector<Mapping> mappings;
+        struct Buffer {
+            uint8_t* local = nullptr;
+            uint64_t bytes = 0;
+            uint8_t* peer[SAH_IPC_MAX_WORLD] = {};
+            uint32_t seq = 0;          // gathers made on this buffer
+        } buffers[SAH_IPC_MAX_BUFFERS];
+        uint32_t num_buffers = 0;
+    } ipc;
     uint32_t raster_merge_cap = 2048;  // tiles whose bin list may be split (testing hook SAH_RASTER_MERGE_CAPACITY: 0 = every list whole)
     std::string last_error;
 };

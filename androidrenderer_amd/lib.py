@@ -23,7 +23,8 @@ _lib = None
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
-           "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait"]
+           "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
+           "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register"]
 
 
 def load():
@@ -80,6 +81,10 @@ def load():
                              C.POINTER(_abi.Plane)]
     lib.sah_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane),
                                         C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
+    lib.sah_ipc_open.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sah_ipc_connect.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sah_ipc_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.sah_ipc_register.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
@@ -215,6 +220,25 @@ class Context:
 
     def comm_wait(self):
         self._check(self.lib.sah_comm_wait(self.handle))
+
+    # ---- direct exchange (include/sah_hip.h): handles are plain bytes that the caller carries between the ranks
+    def ipc_open(self):
+        buf = C.create_string_buffer(_abi.IPC_HANDLE_BYTES)
+        self._check(self.lib.sah_ipc_open(self.handle, buf))
+        return buf.raw
+
+    def ipc_connect(self, handles):
+        """handles: every rank's ipc_open() result, in rank order"""
+        self._check(self.lib.sah_ipc_connect(self.handle, C.create_string_buffer(b"".join(handles), len(handles) * _abi.IPC_HANDLE_BYTES)))
+
+    def ipc_export(self, device_ptr, nbytes):
+        buf = C.create_string_buffer(_abi.IPC_HANDLE_BYTES)
+        self._check(self.lib.sah_ipc_export(self.handle, C.c_void_p(device_ptr), nbytes, buf))
+        return buf.raw
+
+    def ipc_register(self, device_ptr, nbytes, handles):
+        self._check(self.lib.sah_ipc_register(self.handle, C.c_void_p(device_ptr), nbytes,
+                                              C.create_string_buffer(b"".join(handles), len(handles) * _abi.IPC_HANDLE_BYTES)))
 
     def allgather_bytes(self, device_ptr, bytes_per_rank):
         self._check(self.lib.sah_allgather_bytes(self.handle, C.c_void_p(device_ptr), bytes_per_rank))

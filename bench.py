@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
+    ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
+                    "exchange over peer-mapped memory (sah_ipc_*: every rank copies its rows straight into every peer's buffer; handles go through torch.distributed)")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
     ap.add_argument("--ramp-ms", type=float, default=200.0, help="untimed: run the step back to back for this long before the W warm-up steps, so that the "
                     "timed region does not start in the GPU's idle power state (reported in config.clock_ramp_ms)")
@@ -217,7 +219,8 @@ def main():
     gather = exchange and not args.no_gather
     lib_gather = gather and not args.torch_gather
     comm_id = None
-    if lib_gather:
+    use_ipc = lib_gather and args.exchange == "ipc" and world > 1
+    if lib_gather and not use_ipc:
         if world > 1:  # rank 0's ncclUniqueId to everybody
             box = [lib.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
@@ -243,6 +246,13 @@ def main():
         ctx = lib.Context(device=local_rank, rank=rank, world=world, comm_id=None)
         comm_note = comm_note or "another rank failed to build the library communicator"
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def allgather_handles(b):  # the channel the direct exchange's IPC handles travel over
+        out_h = [None] * world
+        dist.all_gather_object(out_h, b)
+        return out_h
+    if use_ipc:
+        chain_mod.connect_direct_exchange(ctx, allgather_handles)
     comm_stream = None
     if lib_gather and not args.no_overlap:
         comm_stream = torch.cuda.Stream(device=dev)
@@ -318,6 +328,8 @@ def main():
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
         pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev),
                                       tonemap_flags=tm_flags)
+        if use_ipc:
+            pc.register_direct_exchange(allgather_handles)
         sc = pc.sets[0]
 
         def step(i, e0=None, e1=None):
@@ -330,6 +342,8 @@ def main():
     elif chain:
         # the whole frame, sharded (chain.py): every exchange goes through the library (torch path only with --torch-gather)
         sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world, tonemap_flags=tm_flags)
+        if use_ipc:
+            sc.register_direct_exchange(allgather_handles)
         q, per = sc.plan.mip0_rows_per_rank, sc.plan.rows_per_rank
         mip0_bytes, out_bytes = sc.mip0_alloc.view(torch.uint8).view(-1), sc.out_alloc.view(-1)
         mip0_slot_bytes, out_slot_bytes = q * sc.mip0_alloc.shape[1] * 8, per * W * 4
@@ -367,6 +381,8 @@ def main():
             lf = torch.zeros((rows_per * world, W, 4), dtype=torch.int16, device=dev)  # equal slots for the all-gather
             desc_b, keep_b = fr.describe(d_arr, lf[:H])
             lb = lf.view(torch.uint8).view(-1)  # RCCL has no int16: the rows travel as bytes
+            if use_ipc:
+                ctx.ipc_register(lf.data_ptr(), lf.numel() * 2, allgather_handles(ctx.ipc_export(lf.data_ptr(), lf.numel() * 2)))
             bufs.append({"lit": lf[:H], "desc": desc_b, "keep": keep_b, "bytes": lb, "slot": lb[rank * shard_bytes:(rank + 1) * shard_bytes],
                          "plane": images.plane(lf[:H], _abi.FORMAT_R16G16B16A16_SFLOAT)})
         pending = [None] * nbuf
@@ -537,7 +553,7 @@ def main():
                 "gbuffer": wl["gbuffer"],
                 "parallelism": par,
                 "gather": bool(gather),
-                "gather_through": ("sah_allgather_rows (library, RCCL)" if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
+                "gather_through": (("sah_allgather_rows (library, direct exchange over peer-mapped memory)" if use_ipc else "sah_allgather_rows (library, RCCL)") if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
                 "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
                 "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
                 "same_workload_on_one_gpu": single_gpu,

@@ -224,8 +224,8 @@ int sah_abi_version(void);
 const char* sah_status_string(int status);
 const char* sah_last_error(const sah_ctx* ctx);
 
-/* comm_id: the 128-byte ncclUniqueId from sah_comm_unique_id() (the same bytes on every rank), or NULL for a context without a
- * communicator (world must then be 1).  world == 1 with a comm_id builds a one-rank communicator, so that the exchange entry points
+/* comm_id: the 128-byte ncclUniqueId from sah_comm_unique_id() (the same bytes on every rank), or NULL for a context without an RCCL
+ * communicator (world > 1 then needs the direct exchange below: sah_ipc_open / sah_ipc_connect).  world == 1 with a comm_id builds a one-rank communicator, so that the exchange entry points
  * below run through RCCL exactly as they do on N ranks. */
 int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_id);
 void sah_destroy(sah_ctx* ctx);
@@ -549,6 +549,31 @@ int sah_comm_wait(sah_ctx* ctx);
 int sah_allgather_rows_reversed(sah_ctx* ctx, const sah_plane* image, uint32_t rows_per_rank, uint32_t allocated_rows);
 /* Same exchange on a raw DEVICE buffer of world * bytes_per_rank bytes; rank r owns [r * bytes_per_rank, (r+1) * bytes_per_rank). */
 int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank);
+
+/* ---- direct exchange: the same gathers as one hop per peer over peer-mapped memory, without RCCL -------------------------------
+ * The gathers of this path move 4-33 MB per frame between the 8 GPUs of one node, whose xGMI links are point to point: every rank
+ * can store its rows straight into every peer's image ("a direct one-shot exchange over the 7 links").  The ranks are
+ * processes of one node; buffers are made visible to each other with HIP IPC handles, which the CALLER carries between the ranks
+ * over whatever channel it has (the handles are plain bytes):
+ *   1. every rank: sah_ipc_open(ctx, my_handle);           the rank's mailbox (arrival counters in fine-grained device memory)
+ *   2. all-gather the handles;  sah_ipc_connect(ctx, all_handles)                         — world * SAH_IPC_HANDLE_BYTES, rank order
+ *   3. per gathered buffer, in the same order on every rank:
+ *        sah_ipc_export(ctx, buffer, bytes, my_handle);  all-gather;  sah_ipc_register(ctx, buffer, bytes, all_handles)
+ * From then on sah_allgather_rows / _rows_reversed / _bytes on memory inside a registered buffer take this path (a context may have
+ * an RCCL communicator as well: unregistered buffers keep using it).  One gather = signal "my rows are ready and my copy of the buffer
+ * may be overwritten" to every peer, wait for theirs, copy the own slot into every peer's buffer (hipMemcpyAsync on the exchange stream),
+ * signal "done", wait for theirs — counters only ever grow, so nothing is reset between frames, and sah_comm_set_stream /
+ * sah_comm_wait order it against the work stream exactly as they do the RCCL path.  A peer that does not arrive within two seconds
+ * makes the waiting kernel give up and every later call on the context fail with SAH_ERR_COMM (no kernel spins forever).
+ * The context may be created with comm_id == NULL and world > 1 for this path.  buffer may lie inside a larger allocation (a caching
+ * allocator's block): the handle carries the offset. */
+#define SAH_IPC_HANDLE_BYTES 128
+#define SAH_IPC_MAX_WORLD 16
+#define SAH_IPC_MAX_BUFFERS 16
+int sah_ipc_open(sah_ctx* ctx, void* out_handle);
+int sah_ipc_connect(sah_ctx* ctx, const void* all_handles);
+int sah_ipc_export(sah_ctx* ctx, const void* buffer, uint64_t bytes, void* out_handle);
+int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all_handles);
 
 #ifdef __cplusplus
 }

@@ -86,3 +86,56 @@ def test_two_rank_gather_equals_unsharded(tmp_path, height):
     ref = util.LightingFrame(160, height, seed=21, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium").run_oracle()
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), ref), f"rank {r}: gathered frame differs from the oracle's unsharded frame"
+
+
+@pytest.mark.parametrize("height", [97])
+def test_two_ranks_on_one_gpu_direct_exchange(tmp_path, height):
+    """A REAL two-rank run on the one-GPU box: two fresh child processes share GPU 0 (HIP IPC allows what RCCL refuses) and exchange bloom
+    mip 0 and the final image by storing their rows straight into the peer's buffers (sah_ipc_*).  Every rank's gathered image must equal
+    the unsharded chain — the HIP one for all frames, and the oracle's for the first."""
+    import ctypes as C
+    import torch
+    from androidrenderer_amd import chain
+    port = 29300 + (os.getpid() % 500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_child.py"), str(r), "2", str(height), str(tmp_path), str(port)], env=env)
+             for r in range(2)]
+    rcs = [p.wait(timeout=300) for p in procs]
+    assert rcs == [0, 0], rcs
+    # the unsharded chain in this process
+    ctx = lib.Context(device=0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        f = util.LightingFrame(160, height, seed=37, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_CACHE, flavour="atrium")
+        dev = f.device_arrays()
+        plain = chain.ShardedChain(ctx, f, dev, 0, 1)
+        plain.step(gather=False)
+        torch.cuda.synchronize()
+        want_step = plain.out.cpu().numpy().copy()
+        g = torch.Generator(device="cpu").manual_seed(11)
+        masks = [torch.rand((height, 160), generator=g).cuda() for _ in range(5)]
+        want = {}
+        for i, m in enumerate(masks):
+            dev["shadow_mask"].copy_(m)
+            plain.step(gather=False)
+            torch.cuda.synchronize()
+            want[i] = plain.out.cpu().numpy().copy()
+    finally:
+        torch.cuda.synchronize()
+        ctx.close()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}_step.npy"), want_step), f"rank {r}: stepwise chain"
+        for i in (1, 2, 3, 4):
+            assert np.array_equal(np.load(tmp_path / f"rank{r}_frame{i}.npy"), want[i]), f"rank {r}: pipelined frame {i}"
+    assert not np.array_equal(want[1], want[2])
+    # the first image against the oracle's unsharded chain
+    o = util.oracle()
+    lit = f.run_oracle()
+    aa = np.zeros_like(lit)
+    assert o.orc_copy_scene(C.byref(images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    mips = [np.zeros((mh, mw, 4), np.uint16) for (mw, mh) in images.bloom_mip_sizes(160, height, 6)]
+    assert o.orc_bloom(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips))) == 0
+    out = np.zeros((height, 160, 4), np.uint8)
+    assert o.orc_tonemap(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips)),
+                         C.byref(images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)), 0, 0) == 0
+    assert np.array_equal(want_step, out)
