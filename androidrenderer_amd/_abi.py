@@ -165,3 +165,10 @@ assert C.sizeof(SunLightConstants) == 640
 assert C.sizeof(LpvCascadeMatrices) == 256
 assert C.sizeof(ProbeCascade) == 16
 assert C.sizeof(PointLight) == 32
+
+
+class ProbeTraceDesc(C.Structure):  # sah_probe_trace_desc
+    _fields_ = [("cascades", ProbeCascade * 4), ("probes_to_update", C.c_void_p), ("num_probes", C.c_uint32),
+                ("sun", C.POINTER(SunLightConstants)), ("sky", C.POINTER(SkyLuts)), ("noise", C.POINTER(Plane)),
+                ("probe_irradiance", Volume), ("probe_depth", Volume), ("probe_validity", Volume), ("probe_size", C.c_uint32 * 2),
+                ("trace_results", Volume)]

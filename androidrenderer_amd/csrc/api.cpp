@@ -456,38 +456,12 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
     SkyArgs sky;
     memset(&sky, 0, sizeof(sky));
     if (d->sky) {
-        const sah_sky_luts& s = *d->sky;
-        if (!s.transmittance.ptr || !s.sky_view.ptr || s.transmittance.format != SAH_FORMAT_R16G16B16A16_SFLOAT ||
-            s.sky_view.format != SAH_FORMAT_R16G16B16A16_SFLOAT)
-            return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "sky LUTs must be RGBA16F");
-        sky.enabled = 1;
-        sky.transmittance = parg(&s.transmittance);
-        sky.sky_view = parg(&s.sky_view);
-        sky.t_w = s.transmittance.width;
-        sky.t_h = s.transmittance.height;
-        sky.s_w = s.sky_view.width;
-        sky.s_h = s.sky_view.height;
-        // uniform sub-expressions of sky_unified.slang:80-135,185-206
-        const float sky_pi = 3.14159265358f;
-        const float ground = 6.360f;
+        // the sky fill's sun direction: -normalize(direction) (sky_unified.slang:199)
         const float dirn[3] = {d->sun->direction_and_tan_size[0], d->sun->direction_and_tan_size[1], d->sun->direction_and_tan_size[2]};
         float nd[3];
         normalize3(dirn, nd);
-        for (int i = 0; i < 3; i++) sky.sun_dir[i] = -nd[i];
-        sky.view_pos_y = 6.360f + 0.0002f;
-        sky.height = std::sqrt((0.0f * 0.0f + sky.view_pos_y * sky.view_pos_y) + 0.0f * 0.0f);
-        sky.up_y = sky.view_pos_y / sky.height;
-        {
-            float q = std::sqrt(sky.height * sky.height - ground * ground) / sky.height;
-            q = std::fmin(std::fmax(q, -1.0f), 1.0f);
-            sky.horizon_angle = (float)std::acos((double)q);
-        }
-        sky.azimuth_limit = 0.5f * sky_pi - .0001f;
-        sky.min_sun_cos = (float)std::cos((double)(0.53f * sky_pi / 180.0f));
-        const float up[3] = {0.0f / sky.height, sky.up_y, 0.0f / sky.height};
-        cross3(sky.sun_dir, up, sky.right);
-        cross3(up, sky.right, sky.forward);
-        sky.smooth_e0 = round_to_half(0.002f);
+        const float sun_dir[3] = {-nd[0], -nd[1], -nd[2]};
+        if (!fill_sky_args(*d->sky, sun_dir, &sky)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "sky LUTs must be RGBA16F");
     }
 
     // pixels per thread: 4 (16 B/lane plane loads) whenever pitches and width allow (measured on MI355X, DESIGN.md §7: with the

@@ -15,6 +15,8 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
 hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNode* nodes, const RtBvh& bvh, hipStream_t s);
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 hipError_t launch_sun_shadow_mask(const ShadowMaskArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
+hipError_t launch_probe_trace(const ProbeTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
+hipError_t launch_rtgi_trace(const RtgiTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 }  // namespace sah
 
 namespace {
@@ -208,6 +210,91 @@ int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_l
     a.num_samples = sun->num_shadow_samples;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_sun_shadow_mask(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
+    return SAH_OK;
+}
+
+// what both GI generators hand to the hit / miss stages
+static int fill_gi_args(sah_ctx* ctx, const sah_sun_light_constants* sun, const sah_sky_luts* sky, const sah_plane* noise, sah::GiArgs* g) {
+    if (!sun || !sky) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sun constants and sky LUTs are required (hit and miss stages)");
+    if (!plane_fmt(noise, SAH_FORMAT_R8G8B8A8_UNORM, 4) || noise->width < 128 || noise->height < 128)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "noise must be R8G8B8A8_UNORM, at least 128 x 128");
+    memset(g, 0, sizeof(*g));
+    for (int i = 0; i < 3; i++) g->sun_dir[i] = sun->direction_and_tan_size[i];
+    for (int i = 0; i < 3; i++) g->sun_color[i] = sun->color[i];
+    g->tan_size = sun->direction_and_tan_size[3];
+    g->noise = parg(noise);
+    // GI miss stage: get_sky_color(WorldRayDirection(), sun_light.direction_and_tan_size.xyz, ...) — the direction as stored (sky_unified.slang:229)
+    const float sun_dir[3] = {sun->direction_and_tan_size[0], sun->direction_and_tan_size[1], sun->direction_and_tan_size[2]};
+    if (!fill_sky_args(*sky, sun_dir, &g->sky)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "sky LUTs must be RGBA16F");
+    return SAH_OK;
+}
+
+int sah_probe_trace(sah_ctx* ctx, const sah_probe_trace_desc* d) {
+    SAH_RANGE();
+    using namespace sah;
+    if (!ctx || !d) return SAH_ERR_INVALID_ARGUMENT;
+    if (!ctx->rt.built) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_rt_build has not been called on this context");
+    if (int rc = check_cutout_inputs(ctx); rc != SAH_OK) return rc;
+    if (d->num_probes == 0) return SAH_OK;
+    if (!d->probes_to_update) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "probes_to_update is null");
+    const sah_volume& tr = d->trace_results;
+    if (!tr.ptr || tr.format != SAH_FORMAT_R16G16B16A16_SFLOAT || tr.width != 20 || tr.height != 20 || tr.depth < d->num_probes || tr.row_pitch_bytes < 160 ||
+        (uint64_t)tr.slice_pitch_bytes < (uint64_t)tr.row_pitch_bytes * 20 || ((uintptr_t)tr.ptr % 8) || (tr.row_pitch_bytes % 8) || (tr.slice_pitch_bytes % 8))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "trace_results must be R16G16B16A16_SFLOAT 20 x 20 x >= num_probes, 8-byte aligned");
+    if (!d->probe_irradiance.ptr || d->probe_irradiance.format != SAH_FORMAT_B10G11R11_UFLOAT_PACK32 || !d->probe_depth.ptr ||
+        d->probe_depth.format != SAH_FORMAT_R16G16_SFLOAT || !d->probe_validity.ptr || d->probe_validity.format != SAH_FORMAT_R8_UNORM)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "probe atlases must be B10G11R11 / R16G16F / R8_UNORM arrays");
+    ProbeTraceArgs a;
+    memset(&a, 0, sizeof(a));
+    if (int rc = fill_gi_args(ctx, d->sun, d->sky, d->noise, &a.gi); rc != SAH_OK) return rc;
+    a.cache.irradiance = varg(d->probe_irradiance);
+    a.cache.depth = varg(d->probe_depth);
+    a.cache.validity = varg(d->probe_validity);
+    for (int c = 0; c < 4; c++) {
+        for (int i = 0; i < 3; i++) a.cache.cascade_min[c][i] = d->cascades[c].min[i];
+        a.cache.spacing[c] = d->cascades[c].probe_spacing;
+    }
+    a.cache.probe_size[0] = d->probe_size[0];
+    a.cache.probe_size[1] = d->probe_size[1];
+    a.probes = d->probes_to_update;
+    a.num_probes = d->num_probes;
+    a.out = varg(tr);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_probe_trace(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
+    return SAH_OK;
+}
+
+int sah_rtgi_trace(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_sky_luts* sky, const sah_plane* depth,
+                   const sah_plane* normals, const sah_plane* noise, const sah_plane* ray_buffer, const sah_plane* ray_irradiance) {
+    SAH_RANGE();
+    using namespace sah;
+    if (!ctx || !view) return SAH_ERR_INVALID_ARGUMENT;
+    if (!ctx->rt.built) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_rt_build has not been called on this context");
+    if (int rc = check_cutout_inputs(ctx); rc != SAH_OK) return rc;
+    if (!plane_fmt(ray_buffer, SAH_FORMAT_R16G16B16A16_SFLOAT, 8) || !plane_fmt(ray_irradiance, SAH_FORMAT_R16G16B16A16_SFLOAT, 8))
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "ray_buffer / ray_irradiance must be R16G16B16A16_SFLOAT planes");
+    const uint32_t W = ray_buffer->width, H = ray_buffer->height;
+    if (ray_irradiance->width != W || ray_irradiance->height != H) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "ray_buffer and ray_irradiance differ in extent");
+    if (!plane_fmt(depth, depth ? depth->format : 0, 4) || (depth->format != SAH_FORMAT_D32_SFLOAT && depth->format != SAH_FORMAT_R32_SFLOAT) ||
+        depth->width != W || depth->height != H)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "depth must be D32_SFLOAT of the ray buffers' extent");
+    if (!plane_fmt(normals, SAH_FORMAT_R16G16B16A16_SFLOAT, 8) || normals->width != W || normals->height != H)
+        return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "normals must be R16G16B16A16_SFLOAT of the ray buffers' extent");
+    RtgiTraceArgs a;
+    memset(&a, 0, sizeof(a));
+    if (int rc = fill_gi_args(ctx, sun, sky, noise, &a.gi); rc != SAH_OK) return rc;
+    a.depth = parg(depth);
+    a.normals = parg(normals);
+    a.ray_buffer = parg(ray_buffer);
+    a.ray_irradiance = parg(ray_irradiance);
+    a.width = W;
+    a.height = H;
+    memcpy(a.inv_proj, view->inverse_projection, 64);
+    memcpy(a.inv_view, view->inverse_view, 64);
+    a.res[0] = view->render_resolution[0];
+    a.res[1] = view->render_resolution[1];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_rtgi_trace(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
 }
 

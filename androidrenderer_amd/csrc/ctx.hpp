@@ -124,6 +124,44 @@ inline int fail(sah_ctx* ctx, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, SAH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Uniform sub-expressions of sky_unified.slang:80-135 for a sun direction as get_sky_color() receives it (`sun_dir`): the Lighting pass's sky
+// fill passes -normalize(direction) (:199), the GI miss shader the raw direction (:229).  Evaluated here in fp32, operator by operator (this
+// header is compiled with -ffp-contract=off), exactly as the per-pixel code would.  Returns false when the LUTs are not RGBA16F.
+inline bool fill_sky_args(const sah_sky_luts& s, const float sun_dir[3], sah::SkyArgs* sky) {
+    if (!s.transmittance.ptr || !s.sky_view.ptr || s.transmittance.format != SAH_FORMAT_R16G16B16A16_SFLOAT || s.sky_view.format != SAH_FORMAT_R16G16B16A16_SFLOAT)
+        return false;
+    auto cross3 = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - b[1] * a[2];
+        o[1] = a[2] * b[0] - b[2] * a[0];
+        o[2] = a[0] * b[1] - b[0] * a[1];
+    };
+    sky->enabled = 1;
+    sky->transmittance = sah::PlaneArg{(const uint8_t*)s.transmittance.ptr, s.transmittance.row_pitch_bytes};
+    sky->sky_view = sah::PlaneArg{(const uint8_t*)s.sky_view.ptr, s.sky_view.row_pitch_bytes};
+    sky->t_w = s.transmittance.width;
+    sky->t_h = s.transmittance.height;
+    sky->s_w = s.sky_view.width;
+    sky->s_h = s.sky_view.height;
+    const float sky_pi = 3.14159265358f;
+    const float ground = 6.360f;
+    for (int i = 0; i < 3; i++) sky->sun_dir[i] = sun_dir[i];
+    sky->view_pos_y = 6.360f + 0.0002f;
+    sky->height = __builtin_sqrtf((0.0f * 0.0f + sky->view_pos_y * sky->view_pos_y) + 0.0f * 0.0f);
+    sky->up_y = sky->view_pos_y / sky->height;
+    {
+        float q = __builtin_sqrtf(sky->height * sky->height - ground * ground) / sky->height;
+        q = __builtin_fminf(__builtin_fmaxf(q, -1.0f), 1.0f);
+        sky->horizon_angle = (float)__builtin_acos((double)q);
+    }
+    sky->azimuth_limit = 0.5f * sky_pi - .0001f;
+    sky->min_sun_cos = (float)__builtin_cos((double)(0.53f * sky_pi / 180.0f));
+    const float up[3] = {0.0f / sky->height, sky->up_y, 0.0f / sky->height};
+    cross3(sky->sun_dir, up, sky->right);
+    cross3(up, sky->right, sky->forward);
+    sky->smooth_e0 = (float)(_Float16)0.002f;
+    return true;
+}
+
 inline uint32_t format_bpp(uint32_t f) {
     switch (f) {
         case SAH_FORMAT_R8_UNORM: return 1;

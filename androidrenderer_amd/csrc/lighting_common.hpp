@@ -426,15 +426,9 @@ SAH_DEV Fn ray_intersect_sphere(F3 ro, F3 rd, Fn rad) {
     return -b - nsqrt(discr);
 }
 
-SAH_DEV void sky_frag(const LightingArgs& a, const SkyArgs& k, uint32_t x, uint32_t y, Hn (&out)[4]) {
+// get_sky_color(view_vector_worldspace, sunDir, ...) of sky_unified.slang:137-166, sunDir and its uniform sub-expressions in `k`
+SAH_DEV F3 sky_color(const SkyArgs& k, F3 rayDir) {
     const Fn sky_pi = Fn(3.14159265358f);
-    const Fn sx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]);
-    const Fn sy = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
-    F4 vs = mul44(a.inv_proj, F4{sx, sy, Fn(1.f), Fn(1.f)});
-    vs = {vs.x / vs.w, vs.y / vs.w, vs.z / vs.w, vs.w / vs.w};
-    const F4 wv = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(0.f)});
-    F3 rayDir = -normalize(F3{wv.x, wv.y, wv.z});
-    rayDir.y = rayDir.y * Fn(-1.0f);
     const F3 sunDir = {Fn(k.sun_dir[0]), Fn(k.sun_dir[1]), Fn(k.sun_dir[2])};
     const F3 up = {Fn(0.0f) / Fn(k.height), Fn(k.up_y), Fn(0.0f) / Fn(k.height)};
     const F3 view_pos = {Fn(0.f), Fn(k.view_pos_y), Fn(0.f)};
@@ -494,6 +488,19 @@ SAH_DEV void sky_frag(const LightingArgs& a, const SkyArgs& k, uint32_t x, uint3
     lum = lum + sunLum;
     lum = lum * Fn(20.0f);
     lum = lum * Fn(1.0f);
+    return lum;
+}
+
+// main_fs of sky_unified.slang:185-206: the view vector of the pixel (SV_Position carries the +0.5: (x + 1) / W; clip xy in [0, 1]: both quirks)
+SAH_DEV void sky_frag(const LightingArgs& a, const SkyArgs& k, uint32_t x, uint32_t y, Hn (&out)[4]) {
+    const Fn sx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]);
+    const Fn sy = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
+    F4 vs = mul44(a.inv_proj, F4{sx, sy, Fn(1.f), Fn(1.f)});
+    vs = {vs.x / vs.w, vs.y / vs.w, vs.z / vs.w, vs.w / vs.w};
+    const F4 wv = mul44(a.inv_view, F4{vs.x, vs.y, vs.z, Fn(0.f)});
+    F3 rayDir = -normalize(F3{wv.x, wv.y, wv.z});
+    rayDir.y = rayDir.y * Fn(-1.0f);
+    const F3 lum = sky_color(k, rayDir);
     out[0] = Hn(lum.x.v);
     out[1] = Hn(lum.y.v);
     out[2] = Hn(lum.z.v);

@@ -12,7 +12,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lighting_common.hpp"
+#include "lighting_gi_ext.hpp"
 #include "numerics.hpp"
+#include "octahedral.hpp"
 #include "rt_args.hpp"
 #include "texture_sample.hpp"
 
@@ -302,6 +305,7 @@ SAH_DEV bool slab(const Ray& r, const float lo[3], const float hi[3]) {
 }
 struct Hit {
     float t, b1, b2;
+    bool front;  // (v1 - v0) x (v2 - v0) against the ray (sah_hip.h "Facing"): det > 0
 };
 SAH_DEV bool woop(const Ray& r, const RtTriangle& tr, Hit& h) {
     float A[3], B[3], C[3];
@@ -330,6 +334,7 @@ SAH_DEV bool woop(const Ray& r, const RtTriangle& tr, Hit& h) {
     h.t = t;
     h.b1 = V / det;
     h.b2 = W / det;
+    h.front = det > 0.0f;
     return true;
 }
 
@@ -366,7 +371,7 @@ SAH_DEV bool cutout_accepts(const RtScene& sc, const RtTriangle& tr, const Hit& 
 }
 
 // "is there an accepted candidate" (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH); CULL_NON_OPAQUE: CUTOUT primitives do not exist for this ray
-template <bool CULL_NON_OPAQUE>
+template <bool CULL_NON_OPAQUE, bool CULL_FRONT = false>
 SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Ray& r) {
     if (!r.finite || bvh.num_tris == 0) return false;
     uint32_t stack[3 * kRtMaxLevels + 4];
@@ -386,6 +391,7 @@ SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Ray& r) {
                 if (!slab(r, lo, hi)) continue;
                 Hit h;
                 if (!woop(r, tr, h)) continue;
+                if (CULL_FRONT && h.front) continue;
                 if (!(tr.flags & 1u) || cutout_accepts(sc, tr, h)) return true;
             }
         } else {
@@ -428,6 +434,224 @@ SAH_DEV F3 load_noise(const PlaneArg& p, const float* luts, uint32_t x, uint32_t
     const F3 v = {Fn(luts[256u + (w & 0xffu)]) * Fn(2.0f) - Fn(1.0f), Fn(luts[256u + ((w >> 8) & 0xffu)]) * Fn(2.0f) - Fn(1.0f),
                   Fn(luts[256u + ((w >> 16) & 0xffu)]) * Fn(2.0f) - Fn(1.0f)};
     return normalize(v);
+}
+
+// closest accepted candidate (RAY_FLAG_NONE: CUTOUT candidates run the any-hit stage); ties: smallest (primitive, triangle)
+struct Closest {
+    bool hit;
+    Hit h;
+    uint32_t tri;  // index into bvh.tris
+};
+SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, Ray r) {
+    Closest best;
+    best.hit = false;
+    best.tri = 0;
+    best.h = {0.f, 0.f, 0.f, false};
+    if (!r.finite || bvh.num_tris == 0) return best;
+    uint32_t best_prim = 0xffffffffu, best_tri = 0xffffffffu;
+    // boxes of NODES are culled against the best t so far (inclusive: ties are still visited); a triangle's own box and its test keep the ray's tmax
+    float limit = r.tmax;
+    const float tmax0 = r.tmax;
+    uint32_t stack[3 * kRtMaxLevels + 4];
+    int sp = 0;
+    stack[sp++] = ((bvh.num_levels - 1u) << 28);
+    while (sp > 0) {
+        const uint32_t e = stack[--sp];
+        const uint32_t level = e >> 28, node = e & 0x0fffffffu;
+        if (level == 0) {
+            r.tmax = tmax0;
+            for (uint32_t k = 0; k < kRtFanout; k++) {
+                const uint32_t i = node * kRtFanout + k;
+                if (i >= bvh.num_tris) break;
+                const RtTriangle tr = bvh.tris[i];
+                float lo[3], hi[3];
+                tri_box(tr, bvh.pad, lo, hi);
+                if (!slab(r, lo, hi)) continue;
+                Hit h;
+                if (!woop(r, tr, h)) continue;
+                const bool better = !best.hit || h.t < best.h.t ||
+                                    (h.t == best.h.t && (tr.primitive < best_prim || (tr.primitive == best_prim && tr.triangle < best_tri)));
+                if (!better) continue;
+                if ((tr.flags & 1u) && !cutout_accepts(sc, tr, h)) continue;
+                best.hit = true;
+                best.h = h;
+                best.tri = i;
+                best_prim = tr.primitive;
+                best_tri = tr.triangle;
+                limit = h.t;
+            }
+        } else {
+            // a hair beyond the best t: the entry into a padded box of a candidate at t <= limit is computed with its own rounding, and
+            // visiting a node too many changes nothing
+            r.tmax = limit * 1.000244140625f;
+            const uint32_t count = bvh.level_count[level - 1u];
+            const RtNode* ch = bvh.nodes + bvh.level_offset[level - 1u];
+            for (uint32_t k = 0; k < kRtFanout; k++) {
+                const uint32_t i = node * kRtFanout + k;
+                if (i >= count) break;
+                const RtNode n = ch[i];
+                const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
+                if (slab(r, lo, hi)) stack[sp++] = ((level - 1u) << 28) | i;
+            }
+        }
+    }
+    return best;
+}
+
+// unpackUnorm4x8ToHalf / packUnorm4x8 (gltf_basic_pbr.slang:257-276) of one channel
+SAH_DEV Hn unpack_channel(uint32_t packed, int c) { return Hn((float)((packed >> (8 * c)) & 0xffu)) / Hn::lit(255.0f); }
+
+struct GiPayload {
+    F3 irradiance;
+    Fn ray_distance;
+};
+
+// TraceRay(rtas, RAY_FLAG_NONE, 0xFF, RAY_TYPE_GI, ...) with remaining_bounces == 0: closest-hit stage of gltf_basic_pbr.slang:345-470 or the
+// GI miss stage of sky_unified.slang:227-230.  (dx, dy) = DispatchRaysIndex().xy
+SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const GiArgs& g, const Ray& r, uint32_t dx, uint32_t dy) {
+    GiPayload pay;
+    pay.irradiance = F3(Fn(0.f));
+    pay.ray_distance = Fn(0.f);
+    const Closest c = closest_hit(bvh, sc, r);
+    if (!c.hit) {
+        // (a ray with a non-finite component reaches no stage at all: the payload stays zero)
+        if (r.finite) pay.irradiance = sky_color(g.sky, F3{Fn(r.d[0]), Fn(r.d[1]), Fn(r.d[2])});
+        return pay;
+    }
+    const RtTriangle tr = bvh.tris[c.tri];
+    const sah_primitive& prim = sc.primitives[tr.primitive];
+    const uint32_t* idx = sc.indices + prim.first_index + 3u * tr.triangle;
+    const int64_t i0 = (int64_t)prim.vertex_offset + idx[0], i1 = (int64_t)prim.vertex_offset + idx[1], i2 = (int64_t)prim.vertex_offset + idx[2];
+    const sah_vertex_data &a = sc.vertex_data[i0], &b = sc.vertex_data[i1], &cc = sc.vertex_data[i2];
+    const Fn b1 = Fn(c.h.b1), b2 = Fn(c.h.b2), b0 = (Fn(1.0f) - b1) - b2;
+    // interpolate_vertex (:278-287): normal, texcoord in fp32; colour through half and the truncating pack
+    F3 normal_f;
+    normal_f.x = b0 * Fn(a.normal[0]) + b1 * Fn(b.normal[0]) + b2 * Fn(cc.normal[0]);
+    normal_f.y = b0 * Fn(a.normal[1]) + b1 * Fn(b.normal[1]) + b2 * Fn(cc.normal[1]);
+    normal_f.z = b0 * Fn(a.normal[2]) + b1 * Fn(b.normal[2]) + b2 * Fn(cc.normal[2]);
+    float uv[2];
+    for (int k = 0; k < 2; k++) uv[k] = (b0 * Fn(a.texcoord[k]) + b1 * Fn(b.texcoord[k]) + b2 * Fn(cc.texcoord[k])).v;
+    Hn colour[4];
+    for (int k = 0; k < 4; k++) {
+        const Fn v = b0 * Fn(tof(unpack_channel(a.color, k))) + b1 * Fn(tof(unpack_channel(b.color, k))) + b2 * Fn(tof(unpack_channel(cc.color, k)));
+        const uint32_t byte = to_uint_sat(tof(Hn(v.v) * Hn::lit(255.0f))) & 0xffu;
+        colour[k] = Hn((float)byte) / Hn::lit(255.0f);
+    }
+    // position: model * (b.x p0 + b.y p1 + b.z p2, 1)
+    const float *p0 = sc.positions + 3 * i0, *p1 = sc.positions + 3 * i1, *p2 = sc.positions + 3 * i2;
+    float mp[3];
+    for (int k = 0; k < 3; k++) mp[k] = (b0 * Fn(p0[k]) + b1 * Fn(p1[k]) + b2 * Fn(p2[k])).v;
+    float loc[3];
+    for (int k = 0; k < 3; k++) loc[k] = ((prim.model[k] * mp[0] + prim.model[4 + k] * mp[1]) + prim.model[8 + k] * mp[2]) + prim.model[12 + k] * 1.0f;
+    const sah_material& m = sc.materials[prim.material];
+    // the three material slots at level 0 (SampleLevel), or the material's constant texels
+    float base_t[4], data_t[4], emis_t[4];
+    for (int k = 0; k < 4; k++) {
+        base_t[k] = m.base_color_texel[k];
+        data_t[k] = m.data_texel[k];
+        emis_t[k] = m.emission_texel[k];
+    }
+    if (sc.material_textures) {
+        const sah_material_textures mt = sc.material_textures[prim.material];
+        if (mt.base_color != SAH_TEXTURE_NONE) sample_texture_lod(sc.luts, sc.textures[mt.base_color], uv, 0.0f, 0.0f, base_t);
+        if (mt.data != SAH_TEXTURE_NONE) sample_texture_lod(sc.luts, sc.textures[mt.data], uv, 0.0f, 0.0f, data_t);
+        if (mt.emission != SAH_TEXTURE_NONE) sample_texture_lod(sc.luts, sc.textures[mt.emission], uv, 0.0f, 0.0f, emis_t);
+    }
+    Surface<Hn> s;
+    s.base_color = {Hn(((Fn(base_t[0]) * Fn(m.base_color_tint[0])) * Fn(tof(colour[0]))).v), Hn(((Fn(base_t[1]) * Fn(m.base_color_tint[1])) * Fn(tof(colour[1]))).v),
+                    Hn(((Fn(base_t[2]) * Fn(m.base_color_tint[2])) * Fn(tof(colour[2]))).v)};
+    s.normal = {Hn(normal_f.x.v), Hn(normal_f.y.v), Hn(normal_f.z.v)};
+    s.roughness = Hn(data_t[1]) * Hn(m.roughness_factor);  // tinted_data = data_sample * half4(0, roughness_factor, metalness_factor, 0)
+    s.metalness = Hn(data_t[2]) * Hn(m.metalness_factor);
+    const H3 emission = {Hn(emis_t[0]) * Hn(m.emission_factor[0]), Hn(emis_t[1]) * Hn(m.emission_factor[1]), Hn(emis_t[2]) * Hn(m.emission_factor[2])};
+    const H3 Lh = normalize(H3{Hn(-g.sun_dir[0]), Hn(-g.sun_dir[1]), Hn(-g.sun_dir[2])});  // normalize((half3)-direction)
+    const H3 brdf_result = Fd(s, Lh, s.normal);
+    const Hn ndotl = nclamp(dot(Lh, s.normal), Hn::lit(0.f), Hn::lit(1.f));
+    Hn shadow = Hn::lit(0.f);
+    if (tof(ndotl) > 0.f) {
+        const F3 noise = load_noise(g.noise, sc.luts, dx % 128u, dy % 128u);
+        const F3 dir = normalize(to_f(Lh) + noise * Fn(g.tan_size));
+        const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
+        const Ray sr = make_ray(loc, d, 0.05f, 100000.0f);
+        if (!any_hit<true, true>(bvh, sc, sr)) shadow = Hn::lit(1.f);
+    }
+    // payload.irradiance = brdf_result * sun_light.color.rgb * ndotl * shadow (half3 * float3 -> float3, then * half, * half); += emission
+    const F3 sun = {Fn(g.sun_color[0]), Fn(g.sun_color[1]), Fn(g.sun_color[2])};
+    F3 irr = to_f(brdf_result) * sun * Fn(tof(ndotl)) * Fn(tof(shadow));
+    irr = irr + to_f(emission);
+    pay.irradiance = irr;
+    pay.ray_distance = Fn(c.h.t);
+    if (!c.h.front) {  // HIT_KIND_TRIANGLE_BACK_FACE
+        pay.ray_distance = pay.ray_distance * Fn(-1.0f);
+        pay.irradiance = F3(Fn(0.f));
+    }
+    return pay;
+}
+
+// probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes})
+__global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, const RtBvh bvh, const RtScene sc) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= 400u * a.num_probes) return;
+    const uint32_t probe = t / 400u, tx = (t % 400u) % 20u, ty = (t % 400u) / 20u;
+    const uint32_t px = a.probes[3u * probe], py = a.probes[3u * probe + 1u], pz = a.probes[3u * probe + 2u];
+    const uint32_t cascade = py / 8u;
+    float irr[3] = {0.f, 0.f, 0.f}, dist = 0.f;
+    if (cascade < 4u) {  // (cascades[cascade_index] of a 4-entry array: anything else is out of bounds in the shader; nothing is written... see below)
+        const CacheArgs& c = a.cache;
+        const Fn spacing = Fn(c.spacing[cascade]);
+        const F3 local = {Fn((float)px), Fn((float)(py % 8u)), Fn((float)pz)};
+        const F3 origin = F3{Fn(c.cascade_min[cascade][0]), Fn(c.cascade_min[cascade][1]), Fn(c.cascade_min[cascade][2])} + local * spacing;
+        const F3 dir = octahedral_direction(normalized_octahedral_coordinates(tx, ty, 20u, 20u));
+        Fn ray_distance = Fn(8192.f);
+        if (cascade < 3u) ray_distance = Fn(c.spacing[cascade + 1u]) * Fn(4.f);
+        const float o[3] = {origin.x.v, origin.y.v, origin.z.v}, d[3] = {dir.x.v, dir.y.v, dir.z.v};
+        const Ray r = make_ray(o, d, 0.05f, ray_distance.v);
+        GiPayload pay = trace_gi(bvh, sc, a.gi, r, tx, ty);
+        if (pay.ray_distance.v == 0.f) {
+            if (cascade + 1u < 4u) pay.irradiance = sample_cascade(c, origin + dir * ray_distance, dir, cascade + 1u);
+            else pay.irradiance = pay.irradiance * Fn(10.f);
+            pay.ray_distance = ray_distance;
+        } else if (pay.ray_distance.v < 0.f) {
+            pay.irradiance = F3(Fn(0.f));
+        }
+        irr[0] = pay.irradiance.x.v; irr[1] = pay.irradiance.y.v; irr[2] = pay.irradiance.z.v;
+        dist = pay.ray_distance.v;
+    }
+    const Hn e = Hn::lit(0.0031415927f);
+    const Hn out[4] = {Hn(irr[0]) * e, Hn(irr[1]) * e, Hn(irr[2]) * e, Hn(dist)};
+    uint2 w;
+    w.x = (uint32_t)__builtin_bit_cast(uint16_t, out[0].v) | ((uint32_t)__builtin_bit_cast(uint16_t, out[1].v) << 16);
+    w.y = (uint32_t)__builtin_bit_cast(uint16_t, out[2].v) | ((uint32_t)__builtin_bit_cast(uint16_t, out[3].v) << 16);
+    *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)probe * a.out.slice_pitch + (size_t)ty * a.out.row_pitch + (size_t)tx * 8) = w;
+}
+
+// rtgi.rt.slang:56-110
+__global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const RtBvh bvh, const RtScene sc) {
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u), y = blockIdx.y * 16u + (threadIdx.x >> 4);
+    if (x >= a.width || y >= a.height) return;
+    if (!((float)x < a.res[0] && (float)y < a.res[1])) return;  // any(thread_id >= render_resolution): uint against float
+    const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+    if (depth == 0.f) return;
+    const uint2 nw = *reinterpret_cast<const uint2*>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x * 8);
+    const H3 normal = {Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.x & 0xffffu))), Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.x >> 16))),
+                       Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.y & 0xffffu)))};  // not normalised (quirk)
+    float o[3];
+    world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
+    F3 dir = load_noise(a.gi.noise, sc.luts, x % 128u, y % 128u);
+    if (dot(to_f(normal), dir).v < 0.f) dir = dir * Fn(-1.0f);
+    const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
+    const Ray r = make_ray(o, d, 0.01f, 100000.0f);
+    GiPayload pay = trace_gi(bvh, sc, a.gi, r, x, y);
+    if (any_nan(pay.irradiance)) pay.irradiance = F3(Fn(0.f));
+    const Fn e = Fn(0.0031415927f);
+    auto store = [](const PlaneArg& p, uint32_t px, uint32_t py, float c0, float c1, float c2, float c3) {
+        uint2 w;
+        w.x = (uint32_t)f2h(c0) | ((uint32_t)f2h(c1) << 16);
+        w.y = (uint32_t)f2h(c2) | ((uint32_t)f2h(c3) << 16);
+        *reinterpret_cast<uint2*>(const_cast<uint8_t*>(p.ptr) + (size_t)py * p.pitch + (size_t)px * 8) = w;
+    };
+    store(a.ray_buffer, x, y, dir.x.v, dir.y.v, dir.z.v, pay.ray_distance.v);
+    store(a.ray_irradiance, x, y, (pay.irradiance.x * e).v, (pay.irradiance.y * e).v, (pay.irradiance.z * e).v, 0.f);
 }
 
 __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh, const RtScene sc) {
@@ -510,6 +734,15 @@ hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long*
     for (uint32_t l = 1; l < bvh.num_levels; l++)
         hipLaunchKernelGGL(k_rt_level, dim3((bvh.level_count[l] + 255u) / 256u), dim3(256), 0, s, nodes + bvh.level_offset[l - 1], bvh.level_count[l - 1],
                            nodes + bvh.level_offset[l], bvh.level_count[l]);
+    return hipGetLastError();
+}
+hipError_t launch_probe_trace(const ProbeTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
+    if (a.num_probes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probe_trace, dim3((400u * a.num_probes + 255u) / 256u), dim3(256), 0, s, a, bvh, sc);
+    return hipGetLastError();
+}
+hipError_t launch_rtgi_trace(const RtgiTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
+    hipLaunchKernelGGL(k_rtgi_trace, dim3((a.width + 15u) / 16u, (a.height + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
     return hipGetLastError();
 }
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {

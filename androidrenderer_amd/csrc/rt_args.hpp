@@ -79,4 +79,28 @@ struct ShadowMaskArgs {
     float tan_size, num_samples;
 };
 
+struct GiArgs {  // what the GI hit / miss stages read besides the scene (rt.hip: trace_gi)
+    float sun_dir[3];   // direction_and_tan_size.xyz as stored
+    float sun_color[3];
+    float tan_size;
+    PlaneArg noise;     // R8G8B8A8_UNORM, >= 128 x 128
+    SkyArgs sky;        // get_sky_color with the sun direction as stored (sky_unified.slang:229)
+};
+
+struct ProbeTraceArgs {
+    GiArgs gi;
+    CacheArgs cache;        // cascades + atlases the misses sample from
+    const uint32_t* probes; // device: uint3 per probe
+    uint32_t num_probes;
+    VolumeArg out;          // RGBA16F 20 x 20 x num_probes
+};
+
+struct RtgiTraceArgs {
+    GiArgs gi;
+    PlaneArg depth, normals, ray_buffer, ray_irradiance;
+    uint32_t width, height;
+    float inv_proj[16], inv_view[16];
+    float res[2];
+};
+
 }  // namespace sah

@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
     ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
                     "exchange over peer-mapped memory (sah_ipc_*: every rank copies its rows straight into every peer's buffer; handles go through torch.distributed)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 launched on a box with ONE GPU: every rank uses cuda:0, torch.distributed runs over "
+                    "gloo and the exchange is the direct one (RCCL refuses two ranks on a device) — the whole N-rank control flow of this file, "
+                    "for rehearsal; the number it prints is not a scaling measurement")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
     ap.add_argument("--ramp-ms", type=float, default=200.0, help="untimed: run the step back to back for this long before the W warm-up steps, so that the "
                     "timed region does not start in the GPU's idle power state (reported in config.clock_ramp_ms)")
@@ -179,8 +182,13 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    rehearsal = args.rehearse_on_one_gpu and world > 1
+    if rehearsal:
+        local_rank = 0
+        args.exchange = "ipc"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearsal else dev  # where the small all-reduces of this file live (gloo has no GPU tensors here)
     exchange = world > 1 or args.force_gather  # the exchange step is part of the loop
     torch_pg = world > 1 or (args.force_gather and args.torch_gather)  # torch.distributed: barrier + max over ranks (+ --torch-gather)
     saved_stdout = None
@@ -191,7 +199,9 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
+    if rehearsal:
+        dist.init_process_group(backend="gloo")
+    elif world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
     elif torch_pg:
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29511", rank=0, world_size=1, device_id=dev)
@@ -234,7 +244,7 @@ def main():
     except Exception as err:  # the communicator could not be built on this rank: every rank falls back together, and the line says so
         ctx, ok, comm_note = None, 0, str(err)
     if world > 1 and lib_gather:
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = int(flag.item())
     if not ok:
@@ -507,7 +517,7 @@ def main():
         kernel_scope = ("one pair of HIP events on the launch stream around all K steps of the timed region, / K: everything a sah_lighting call "
                         "enqueues (main kernel with its sky workgroups + fix-up) and the gaps between launches")
     if torch_pg:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -527,6 +537,8 @@ def main():
             par = "single GPU" + (" + one-rank RCCL communicator (rehearsal of the exchange)" if exchange else "")
         elif chain:
             par = f"row-shard x{world}: lighting rows + halo, all-gather of bloom mip 0, all-gather of the RGBA8 rows (reversed rank order)"
+            if rehearsal:
+                par += " — REHEARSAL: all ranks on one GPU, not a scaling measurement"
         else:
             par = f"row-shard x{world} + RCCL all-gather of the lit rows"
         out = {

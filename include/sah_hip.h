@@ -497,6 +497,15 @@ int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint
  *               (half arithmetic, truncating pack), base-colour texture at level 0 (SampleLevel: lambda = 0 + sampler bias, clamped,
  *               then the rules of sah_texture), alpha = (texel.a * tint.a) * colour.a in fp32 — and is ignored when
  *               alpha <= opacity_threshold.  Existence does not depend on the order in which candidates are found.
+ *   closest hit the accepted candidate with the smallest t; among equal t the one with the smallest (primitive index, triangle index).
+ *               Facing: a triangle is FRONT facing when (v1 - v0) x (v2 - v0) points against the ray, i.e. its vertices appear
+ *               counter-clockwise from the ray origin in the scene's right-handed world space.  That is the default of Vulkan and
+ *               D3D12 ("clockwise in a left-handed system", the same rule on the same numbers; no FLIP_FACING bit in
+ *               raytracing_scene.cpp:19-37), and it agrees with the rasteriser: what the G-buffer pass keeps as front facing is front
+ *               facing for a ray from the camera.  Evaluated as det > 0 on the fp32 determinant above (the axis permutation keeps
+ *               the winding).
+ *               RAY_FLAG_CULL_FRONT_FACING_TRIANGLES / CULL_BACK_FACING_TRIANGLES drop candidates by that sign before anything else.
+ *   a ray with a non-finite origin or direction component hits nothing.
  * The structure itself (an implicit 4-wide hierarchy over Morton-sorted triangles, built on the GPU) is an implementation detail. */
 
 /* RaytracingScene::add_primitive / commit_tlas_builds — RenderCore/render/raytracing_scene.cpp:15-170 (and the BLAS builds behind
@@ -528,6 +537,44 @@ int sah_rtao(sah_ctx* ctx, const sah_view_data* view, const sah_plane* depth, co
  * does not trace for (depth == 0, or (half)clamp(dot(L, normal), 0, 1) == 0) get 1.0.  noise: R8G8B8A8_UNORM, at least 128 x 128. */
 int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_plane* depth,
                         const sah_plane* normals, const sah_plane* noise, const sah_plane* mask_out);
+
+/* The GI rays (ray type RAY_TYPE_GI): closest hit over SOLID and alpha-tested CUTOUT geometry, shaded by the closest-hit stage of
+ * RenderCore/shaders/materials/gltf_basic_pbr.slang:345-470 — vertex attributes interpolated with the hit's barycentrics, position
+ * model * (b0 p0 + b1 p1 + b2 p2), base colour / data / emission textures at level 0, surface.normal = the interpolated OBJECT-space normal
+ * (the shader does not transform it), irradiance = Fd(surface, L, normal) * sun colour * ndotl * shadow + emission in the shader's half /
+ * float mix, shadow from one ray towards normalize(L + noise * tan_size) with RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH | CULL_NON_OPAQUE |
+ * CULL_FRONT_FACING_TRIANGLES and TMin 0.05, noise = noise[DispatchRaysIndex().xy % 128]; a back-face hit returns -t and no light;
+ * remaining_bounces is 0 in both generators, so the bounce branch is dead — or, on a miss, by the GI miss shader of
+ * shaders/sky/sky_unified.slang:227-230: get_sky_color(ray direction, sun direction AS STORED (not negated: quirk), ...). */
+
+/* IrradianceCache::dispatch_probe_updates, the "probe_tracing" pass — RenderCore/render/gi/irradiance_cache.cpp:585-640 with
+ * shaders/gi/cache/probe_tracing.rt.slang:39-106: 20 x 20 rays per listed probe along the octahedral directions of the trace texels, from
+ * cascade.min + local probe id * spacing, [0.05, 4 x the next cascade's spacing] (8192 for the last cascade).  A miss samples the NEXT
+ * cascade of the cache at the ray's end (sample_cascade, probe_sampling.slangi:6-106, on the atlases given here) or, in the last cascade,
+ * keeps 10 x the sky colour, and reports the ray's full length; a back-face hit reports -t and black.  Writes
+ * half4(irradiance * 0.0031415927h, distance) to trace_results (R16G16B16A16_SFLOAT, 20 x 20 x num_probes) — the input of sah_probe_update. */
+typedef struct sah_probe_trace_desc {
+    sah_probe_cascade cascades[4];
+    const uint32_t* probes_to_update; /* DEVICE: num_probes uint32 triples (probe x, y, layer) */
+    uint32_t num_probes;
+    const sah_sun_light_constants* sun;
+    const sah_sky_luts* sky;
+    const sah_plane* noise;           /* R8G8B8A8_UNORM, at least 128 x 128 */
+    sah_volume probe_irradiance;      /* the cache as sah_gi describes it: B10G11R11 224 x 256 x 32 */
+    sah_volume probe_depth;           /* R16G16_SFLOAT 384 x 384 x 32 */
+    sah_volume probe_validity;        /* R8_UNORM 32 x 32 x 32 */
+    uint32_t probe_size[2];           /* (5, 6) */
+    sah_volume trace_results;         /* out */
+} sah_probe_trace_desc;
+int sah_probe_trace(sah_ctx* ctx, const sah_probe_trace_desc* desc);
+
+/* RayTracedGlobalIllumination::post_render — RenderCore/render/gi/rtgi.cpp:69-139 with shaders/gi/rtgi/rtgi.rt.slang:56-110: one GI ray
+ * per pixel with depth != 0 from its world-space position along normalize(noise[pixel % 128].rgb * 2 - 1), flipped into the hemisphere of
+ * the (unnormalised) G-buffer normal, [0.01, 100000].  Writes (direction, distance) to ray_buffer and (irradiance * 0.0031415927, 0) to
+ * ray_irradiance (both R16G16B16A16_SFLOAT: the inputs of the RTGI overlay, sah_gi::ray_buffer / ray_irradiance); a NaN irradiance becomes
+ * 0; on a miss the distance stays 0.  Pixels with depth == 0 are left untouched, as the shader leaves them. */
+int sah_rtgi_trace(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_sky_luts* sky, const sah_plane* depth,
+                   const sah_plane* normals, const sah_plane* noise, const sah_plane* ray_buffer, const sah_plane* ray_irradiance);
 
 /* Multi-GPU exchange step (no reference counterpart: the reference drives one device, RenderCore/render/backend/render_backend.cpp:135-153;
  * BASELINE.json north_star: "RCCL all-gather over xGMI to reassemble the final image").

@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -845,11 +846,11 @@ private:
 };
 
 // RenderCore/render/gi/irradiance_cache.{hpp,cpp}: atlases :94-183, cascade placement :298-372, copy_probes_to_new_texture
-// :455-486, dispatch_probe_updates :585-724, overlay :203-245.  Probe ray tracing (probe_tracing.rt.slang) is outside the hot
-// path: set_trace_results() is the seam that hands its output (20 x 20 rays per probe) and the probe list to the update passes.
+// :455-486, dispatch_probe_updates :585-724 (probe_tracing rays -> sah_probe_trace, then the update passes), overlay :203-245.
+// When the scene has no acceleration structure yet, set_trace_results() is the seam for trace results produced elsewhere.
 class IrradianceCache : public IGlobalIlluminator {
 public:
-    explicit IrradianceCache(RenderBackend& backend) {
+    explicit IrradianceCache(RenderBackend& backend) : allocator(&backend.get_global_allocator()) {
         auto& alloc = backend.get_global_allocator();
         const uint32_t r11 = SAH_FORMAT_B10G11R11_UFLOAT_PACK32;
         for (int s = 0; s < 2; s++) {  // a / b sets, swapped by copy_probes_to_new_texture
@@ -877,9 +878,47 @@ public:
         probes_to_update = probes_to_update_device;
         num_probes = num_probes_in;
     }
-    void pre_render(RenderGraph& graph, const SceneView&, const RenderScene&, TextureHandle) override {
+    void pre_render(RenderGraph& graph, const SceneView&, const RenderScene& scene, TextureHandle noise_tex) override {
         copy_probes_to_new_texture(graph);
+        dispatch_probe_updates(graph, scene, noise_tex);
+    }
+    // irradiance_cache.cpp:585-650: upload the scheduler's list, 400 rays per probe into the trace results, then the update passes
+    void dispatch_probe_updates(RenderGraph& graph, const RenderScene& scene, TextureHandle noise_tex) {
+        const auto& list = scheduler.get_probes_to_update();
+        if (!list.empty() && noise_tex && scene.get_raytracing_scene().is_built() && scene.sky.transmittance_lut && scene.sky.sky_view_lut) {
+            if (list.size() > probe_list_capacity) {  // probes_to_update_buffer / trace_results_texture, sized for the scheduler's budget
+                if (probe_list_device) (void)hipFree(probe_list_device);
+                probe_list_capacity = std::max<size_t>(list.size(), 1024);
+                if (hipMalloc(&probe_list_device, probe_list_capacity * 3 * sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("Could not create probes_to_update_buffer");
+                own_trace_results = allocator->create_texture("probe_trace_results", SAH_FORMAT_R16G16B16A16_SFLOAT, 20, 20, (uint32_t)probe_list_capacity);
+            }
+            static_assert(sizeof(ProbeScheduler::ProbeIndex) == 3 * sizeof(uint32_t), "uint3 list");
+            if (hipMemcpy(probe_list_device, list.data(), list.size() * 3 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("probe list upload failed");
+            set_trace_results(own_trace_results, static_cast<const uint32_t*>(probe_list_device), (uint32_t)list.size());
+            graph.add_pass(hip_pass("probe_tracing", [this, &scene, noise_tex](sah_ctx* ctx) {
+                                sah_probe_trace_desc d{};
+                                for (int c = 0; c < 4; c++) d.cascades[c] = cascades[c];
+                                d.probes_to_update = probes_to_update;
+                                d.num_probes = num_probes;
+                                d.sun = &scene.sun.get_constants();
+                                const sah_sky_luts sky{scene.sky.transmittance_lut->plane(), scene.sky.sky_view_lut->plane()};
+                                const sah_plane noise = noise_tex->plane();
+                                d.sky = &sky;
+                                d.noise = &noise;
+                                d.probe_irradiance = set[0].rtgi->desc;
+                                d.probe_depth = set[0].depth->desc;
+                                d.probe_validity = set[0].validity->desc;
+                                d.probe_size[0] = 5;
+                                d.probe_size[1] = 6;
+                                d.trace_results = trace_results->desc;
+                                return sah_probe_trace(ctx, &d);
+                            }));
+            scheduler.clear_probes_to_update();  // :722
+        }
         dispatch_probe_updates(graph);
+    }
+    ~IrradianceCache() override {
+        if (probe_list_device) (void)hipFree(probe_list_device);
     }
     void post_render(RenderGraph&, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {}
     void copy_probes_to_new_texture(RenderGraph& graph) {
@@ -927,14 +966,19 @@ private:
     const uint32_t* probes_to_update = nullptr;
     ProbeScheduler scheduler;
     uint32_t num_probes = 0;
+    ResourceAllocator* allocator = nullptr;
+    void* probe_list_device = nullptr;
+    size_t probe_list_capacity = 0;
+    TextureHandle own_trace_results{};
 };
 
-// RenderCore/render/gi/rtgi.{hpp,cpp}: the ray-traced passes (ray generation, hit shading) stay in the renderer; their two
-// per-pixel outputs — ray direction + distance, ray irradiance — are what the reconstruction overlay (rtgi.cpp:160-188,
-// gi/rtgi/overlay.frag.slang:68-117) binds.  It owns an IrradianceCache, as the reference does (rtgi.hpp: irradiance_cache).
+// RenderCore/render/gi/rtgi.{hpp,cpp}: post_render (:69-139) traces one GI ray per pixel (sah_rtgi_trace) into the two per-pixel
+// textures — ray direction + distance, ray irradiance — that the reconstruction overlay (rtgi.cpp:160-188,
+// gi/rtgi/overlay.frag.slang:68-117) binds in the NEXT frame's Lighting pass.  It owns an IrradianceCache, as the reference does
+// (rtgi.hpp: irradiance_cache).  set_ray_textures() remains for ray textures produced elsewhere.
 class RayTracedGlobalIllumination : public IGlobalIlluminator {
 public:
-    explicit RayTracedGlobalIllumination(RenderBackend& backend) : cache(backend) {}
+    explicit RayTracedGlobalIllumination(RenderBackend& backend) : cache(backend), allocator(&backend.get_global_allocator()) {}
     void set_ray_textures(TextureHandle ray_texture_in, TextureHandle ray_irradiance_in) {
         ray_texture = ray_texture_in;
         ray_irradiance = ray_irradiance_in;
@@ -944,10 +988,25 @@ public:
         extra_ray_radius = size;
     }
     IrradianceCache& get_irradiance_cache() { return cache; }
+    TextureHandle get_ray_texture() const { return ray_texture; }
+    TextureHandle get_ray_irradiance() const { return ray_irradiance; }
     void pre_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, TextureHandle noise_tex) override {
         cache.pre_render(graph, view, scene, noise_tex);  // rtgi.cpp:60-75: the cache updates first
     }
-    void post_render(RenderGraph&, const SceneView&, const RenderScene&, const GBuffer&, TextureHandle) override {}
+    void post_render(RenderGraph& graph, const SceneView& view, const RenderScene& scene, const GBuffer& gbuffer, TextureHandle noise_tex) override {
+        if (!scene.get_raytracing_scene().is_built() || !noise_tex || !scene.sky.transmittance_lut || !scene.sky.sky_view_lut) return;
+        const uint32_t w = gbuffer.depth->desc.width, h = gbuffer.depth->desc.height;
+        if (ray_texture == nullptr || ray_texture->desc.width != w || ray_texture->desc.height != h)
+            ray_texture = allocator->create_texture("rtgi_params", SAH_FORMAT_R16G16B16A16_SFLOAT, w, h);
+        if (ray_irradiance == nullptr || ray_irradiance->desc.width != w || ray_irradiance->desc.height != h)
+            ray_irradiance = allocator->create_texture("rtgi_irradiance", SAH_FORMAT_R16G16B16A16_SFLOAT, w, h);
+        graph.add_pass(hip_pass("ray_traced_global_illumination", [this, &view, &scene, gbuffer, noise_tex](sah_ctx* ctx) {
+                            const sah_sky_luts sky{scene.sky.transmittance_lut->plane(), scene.sky.sky_view_lut->plane()};
+                            const sah_plane depth = gbuffer.depth->plane(), normals = gbuffer.normals->plane(), noise = noise_tex->plane();
+                            const sah_plane rb = ray_texture->plane(), ri = ray_irradiance->plane();
+                            return sah_rtgi_trace(ctx, &view.get_gpu_data(), &scene.sun.get_constants(), &sky, &depth, &normals, &noise, &rb, &ri);
+                        }));
+    }
     void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList& buffers) const override {
         cache.get_lighting_resource_usages(textures, buffers);
         for (TextureHandle t : {ray_texture, ray_irradiance}) textures.push_back({t, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
@@ -967,6 +1026,7 @@ public:
 
 private:
     IrradianceCache cache;
+    ResourceAllocator* allocator = nullptr;
     TextureHandle ray_texture{}, ray_irradiance{};
     uint32_t num_extra_rays = 0;
     float extra_ray_radius = 16.f;

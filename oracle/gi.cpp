@@ -354,6 +354,9 @@ bool gi_rtgi_frag(const sah_lighting_desc& d, int x, int y, float depth, const T
     return true;
 }
 
+// for the probe ray generator's misses (rt.cpp)
+F3 sample_probe_cascade(const sah_gi& gi, F3 location, F3 direction, uint32_t cascade_index) { return sample_cascade(gi, location, direction, cascade_index); }
+
 }  // namespace orc
 
 // exports for the known-answer tests (SURVEY.md §8-c fixture i)

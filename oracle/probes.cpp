@@ -134,6 +134,10 @@ bool atlases_ok(const sah_probe_atlases* a, Atlases* out) {
 }
 
 }  // namespace
+
+// direction of trace texel (tx, ty) of an n x n octahedral map, for the probe ray generator (rt.cpp)
+F3 octahedral_texel_direction(uint32_t tx, uint32_t ty, uint32_t n) { return octahedral_direction(normalized_octahedral_coordinates(tx, ty, n, n)); }
+
 }  // namespace orc
 
 using namespace orc;

@@ -1,8 +1,11 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
-// CPU restatement of the ray-tracing half of SURVEY.md §8-f4, first slice:
+// CPU restatement of the ray-tracing half of SURVEY.md §8-f4:
 //   RTAO               RenderCore/shaders/ao/rtao.comp.slang:54-102 (host: render/phase/ambient_occlusion_phase.cpp:357-397)
 //   sun shadow rays    RenderCore/shaders/lighting/directional_light.rt.slang:91-125 (host: render/directional_light.cpp:372-422)
 //   occlusion hit group / miss  RenderCore/shaders/materials/gltf_basic_pbr.slang:291-325, shaders/sky/sky_unified.slang:210-215
+//   probe rays         RenderCore/shaders/gi/cache/probe_tracing.rt.slang:39-106 (host: render/gi/irradiance_cache.cpp dispatch_probe_updates)
+//   RTGI rays          RenderCore/shaders/gi/rtgi/rtgi.rt.slang:56-110 (host: render/gi/rtgi.cpp post_render)
+//   GI hit group / miss  RenderCore/shaders/materials/gltf_basic_pbr.slang:326-520, shaders/sky/sky_unified.slang:225-230
 //   instances          RenderCore/render/raytracing_scene.cpp:15-43 (transform = model, SOLID opaque, CUTOUT non-opaque, no face culling)
 // What a ray hits is the implementation's business in Vulkan; include/sah_hip.h ("ray tracing") fixes it.  This file tests EVERY
 // triangle against every ray — no acceleration structure — which the definition makes equivalent to any box hierarchy.
@@ -12,12 +15,16 @@
 #include <vector>
 
 #include "../include/sah_hip.h"
+#include "brdf.hpp"
 #include "codec.hpp"
+#include "gi.hpp"
 #include "math.hpp"
+#include "sky.hpp"
 #include "texture.hpp"
 
 namespace orc {
-F3 worldspace_location_slang(const sah_view_data& view, int x, int y, float depth);  // lighting.cpp
+F3 sample_probe_cascade(const sah_gi& gi, F3 location, F3 direction, uint32_t cascade_index);  // gi.cpp
+F3 octahedral_texel_direction(uint32_t tx, uint32_t ty, uint32_t n);                           // probes.cpp
 
 namespace {
 
@@ -99,7 +106,7 @@ bool slab(const Ray& r, const float lo[3], const float hi[3]) {
     return tn <= tf;
 }
 
-struct Hit { float t, b1, b2; };
+struct Hit { float t, b1, b2; bool front; };
 bool woop(const Ray& r, const WorldTriangle& w, Hit& h) {
     float A[3], B[3], C[3];
     for (int c = 0; c < 3; c++) { A[c] = w.v[0][c] - r.o[c]; B[c] = w.v[1][c] - r.o[c]; C[c] = w.v[2][c] - r.o[c]; }
@@ -120,6 +127,7 @@ bool woop(const Ray& r, const WorldTriangle& w, Hit& h) {
     const float t = T / det;
     if (!(t > r.tmin && t < r.tmax)) return false;
     h.t = t; h.b1 = V / det; h.b2 = W / det;
+    h.front = det > 0.0f;  // (v1 - v0) x (v2 - v0) against the ray: the default front face of Vulkan / D3D12 (sah_hip.h "Facing")
     return true;
 }
 
@@ -153,21 +161,46 @@ bool cutout_accepts(const sah_scene_geometry& g, const WorldTriangle& w, const H
     return !(alpha.v <= m.opacity_threshold);
 }
 
-bool any_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, bool cull_non_opaque) {
+// candidate := slab(padded box of the triangle) and woop (sah_hip.h "ray tracing")
+bool candidate(const RtStructure& s, const Ray& r, const WorldTriangle& w, Hit& h) {
+    float lo[3], hi[3];
+    for (int c = 0; c < 3; c++) {
+        lo[c] = std::fmin(std::fmin(w.v[0][c], w.v[1][c]), w.v[2][c]) - s.pad;
+        hi[c] = std::fmax(std::fmax(w.v[0][c], w.v[1][c]), w.v[2][c]) + s.pad;
+    }
+    return slab(r, lo, hi) && woop(r, w, h);
+}
+
+bool any_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, bool cull_non_opaque, bool cull_front = false) {
     if (!r.finite) return false;
     for (const WorldTriangle& w : s.tris) {
         if (cull_non_opaque && w.cutout) continue;
-        float lo[3], hi[3];
-        for (int c = 0; c < 3; c++) {
-            lo[c] = std::fmin(std::fmin(w.v[0][c], w.v[1][c]), w.v[2][c]) - s.pad;
-            hi[c] = std::fmax(std::fmax(w.v[0][c], w.v[1][c]), w.v[2][c]) + s.pad;
-        }
-        if (!slab(r, lo, hi)) continue;
         Hit h;
-        if (!woop(r, w, h)) continue;
+        if (!candidate(s, r, w, h)) continue;
+        if (cull_front && h.front) continue;
         if (!w.cutout || cutout_accepts(g, w, h)) return true;
     }
     return false;
+}
+
+// RAY_FLAG_NONE: the accepted candidate of smallest t; equal t: smallest (primitive, triangle).  Returns the index into s.tris or -1
+int closest_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, Hit& best) {
+    int found = -1;
+    if (!r.finite) return found;
+    for (size_t i = 0; i < s.tris.size(); i++) {
+        const WorldTriangle& w = s.tris[i];
+        Hit h;
+        if (!candidate(s, r, w, h)) continue;
+        if (found >= 0) {
+            const WorldTriangle& b = s.tris[found];
+            const bool better = h.t < best.t || (h.t == best.t && (w.primitive < b.primitive || (w.primitive == b.primitive && w.triangle < b.triangle)));
+            if (!better) continue;
+        }
+        if (w.cutout && !cutout_accepts(g, w, h)) continue;
+        found = (int)i;
+        best = h;
+    }
+    return found;
 }
 
 bool scene_ok(const sah_scene_geometry* g) {
@@ -191,6 +224,114 @@ float load_f32(const sah_plane& p, int x, int y) {
     float f;
     std::memcpy(&f, (const uint8_t*)p.ptr + (size_t)y * p.row_pitch_bytes + (size_t)x * 4, 4);
     return f;
+}
+
+// what the GI hit and miss stages read besides the scene
+struct GiInputs {
+    const sah_scene_geometry* scene;
+    const RtStructure* s;
+    const sah_sun_light_constants* sun;
+    const sah_sky_luts* sky;
+    const sah_plane* noise;
+};
+struct GiPayload {
+    F3 irradiance = F3(F(0.0f));
+    F ray_distance = F(0.0f);
+};
+
+H unpack_channel(uint32_t packed, int c) { return H((float)((packed >> (8 * c)) & 0xffu)) / H::lit(255.0); }
+
+// TraceRay(rtas, RAY_FLAG_NONE, 0xFF, RAY_TYPE_GI, ...) with remaining_bounces = 0 (both generators): gltf_basic_pbr.slang:372-520 or
+// sky_unified.slang:227-230.  (dx, dy) = DispatchRaysIndex().xy
+GiPayload trace_gi(const GiInputs& in, const Ray& r, uint32_t dx, uint32_t dy) {
+    GiPayload pay;
+    const sah_scene_geometry& g = *in.scene;
+    Hit h = {0.0f, 0.0f, 0.0f, false};
+    const int found = closest_hit(g, *in.s, r, h);
+    if (found < 0) {
+        if (r.finite) {  // miss stage: get_sky_color(WorldRayDirection(), sun_light.direction_and_tan_size.xyz, ...) — the direction as stored
+            static const SkyConsts k;
+            const F3 sun_dir = {F(in.sun->direction_and_tan_size[0]), F(in.sun->direction_and_tan_size[1]), F(in.sun->direction_and_tan_size[2])};
+            pay.irradiance = sky_color(k, F3{F(r.d[0]), F(r.d[1]), F(r.d[2])}, sun_dir, img2d(in.sky->sky_view), img2d(in.sky->transmittance));
+        }
+        return pay;
+    }
+    const WorldTriangle& w = in.s->tris[found];
+    const sah_primitive& prim = g.primitives[w.primitive];
+    const uint32_t* idx = g.indices + prim.first_index + 3 * w.triangle;
+    const int64_t vi[3] = {(int64_t)prim.vertex_offset + idx[0], (int64_t)prim.vertex_offset + idx[1], (int64_t)prim.vertex_offset + idx[2]};
+    const sah_vertex_data &v0 = g.vertex_data[vi[0]], &v1 = g.vertex_data[vi[1]], &v2 = g.vertex_data[vi[2]];
+    const F b0 = (F(1.0f) - F(h.b1)) - F(h.b2), b1 = F(h.b1), b2 = F(h.b2);
+    // interpolate_vertex (:278-287)
+    F3 normal;
+    normal.x = (b0 * F(v0.normal[0]) + b1 * F(v1.normal[0])) + b2 * F(v2.normal[0]);
+    normal.y = (b0 * F(v0.normal[1]) + b1 * F(v1.normal[1])) + b2 * F(v2.normal[1]);
+    normal.z = (b0 * F(v0.normal[2]) + b1 * F(v1.normal[2])) + b2 * F(v2.normal[2]);
+    float uv[2];
+    for (int k = 0; k < 2; k++) uv[k] = ((b0 * F(v0.texcoord[k]) + b1 * F(v1.texcoord[k])) + b2 * F(v2.texcoord[k])).v;
+    H colour[4];
+    for (int k = 0; k < 4; k++) {
+        const F c = (b0 * F(unpack_channel(v0.color, k).v) + b1 * F(unpack_channel(v1.color, k).v)) + b2 * F(unpack_channel(v2.color, k).v);
+        const uint32_t byte = to_uint_sat((H(c.v) * H::lit(255.0)).v) & 0xffu;  // packUnorm4x8, one channel
+        colour[k] = H((float)byte) / H::lit(255.0);
+    }
+    // surface.location = model * (b.x p0 + b.y p1 + b.z p2, 1)
+    float mp[3], loc[3];
+    for (int k = 0; k < 3; k++)
+        mp[k] = ((b0 * F(g.vertex_positions[3 * vi[0] + k]) + b1 * F(g.vertex_positions[3 * vi[1] + k])) + b2 * F(g.vertex_positions[3 * vi[2] + k])).v;
+    for (int k = 0; k < 3; k++)
+        loc[k] = (((F(prim.model[k]) * F(mp[0]) + F(prim.model[4 + k]) * F(mp[1])) + F(prim.model[8 + k]) * F(mp[2])) + F(prim.model[12 + k]) * F(1.0f)).v;
+    const sah_material& m = g.materials[prim.material];
+    float base_t[4], data_t[4], emis_t[4];
+    for (int k = 0; k < 4; k++) {
+        base_t[k] = m.base_color_texel[k];
+        data_t[k] = m.data_texel[k];
+        emis_t[k] = m.emission_texel[k];
+    }
+    if (g.material_textures && g.textures && g.num_textures) {
+        const sah_material_textures& mt = g.material_textures[prim.material];
+        if (mt.base_color != SAH_TEXTURE_NONE) sample_texture_lod(g.textures[mt.base_color], uv, 0.0f, 0.0f, base_t);  // SampleLevel(v.texcoord, 0)
+        if (mt.data != SAH_TEXTURE_NONE) sample_texture_lod(g.textures[mt.data], uv, 0.0f, 0.0f, data_t);
+        if (mt.emission != SAH_TEXTURE_NONE) sample_texture_lod(g.textures[mt.emission], uv, 0.0f, 0.0f, emis_t);
+    }
+    Surface<H> surf;
+    surf.base_color = {H(((F(base_t[0]) * F(m.base_color_tint[0])) * F(colour[0].v)).v), H(((F(base_t[1]) * F(m.base_color_tint[1])) * F(colour[1].v)).v),
+                       H(((F(base_t[2]) * F(m.base_color_tint[2])) * F(colour[2].v)).v)};
+    surf.normal = to_h(normal);  // no normal map in the ray-traced path ("TODO" in the shader), not normalised either
+    surf.roughness = H(data_t[1]) * H(m.roughness_factor);
+    surf.metalness = H(data_t[2]) * H(m.metalness_factor);
+    const H3 emission = {H(emis_t[0]) * H(m.emission_factor[0]), H(emis_t[1]) * H(m.emission_factor[1]), H(emis_t[2]) * H(m.emission_factor[2])};
+    const float* sd = in.sun->direction_and_tan_size;
+    const H3 light = normalize(H3{H(-sd[0]), H(-sd[1]), H(-sd[2])});
+    const H3 brdf_result = Fd(surf, light, surf.normal);
+    const H ndotl = nclamp(dot(light, surf.normal), H::lit(0.0), H::lit(1.0));
+    H shadow = H::lit(0.0);
+    if (ndotl.v > 0.0f) {
+        const F3 noise = load_noise(*in.noise, dx % 128u, dy % 128u);
+        const F3 dir = normalize(to_f(light) + noise * F(sd[3]));
+        const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
+        // ACCEPT_FIRST_HIT_AND_END_SEARCH | CULL_NON_OPAQUE | CULL_FRONT_FACING_TRIANGLES
+        if (!any_hit(g, *in.s, make_ray(loc, d, 0.05f, 100000.0f), true, true)) shadow = H::lit(1.0);
+    }
+    const F3 sun_colour = {F(in.sun->color[0]), F(in.sun->color[1]), F(in.sun->color[2])};
+    F3 irr = to_f(brdf_result) * sun_colour * F(ndotl.v) * F(shadow.v);
+    irr = irr + to_f(emission);
+    pay.irradiance = irr;
+    pay.ray_distance = F(h.t);
+    if (!h.front) {  // HIT_KIND_TRIANGLE_BACK_FACE
+        pay.ray_distance = pay.ray_distance * F(-1.0f);
+        pay.irradiance = F3(F(0.0f));
+    }
+    return pay;
+}
+
+bool gi_inputs_ok(const sah_sun_light_constants* sun, const sah_sky_luts* sky, const sah_plane* noise) {
+    return sun && sky && plane_is(&sky->transmittance, SAH_FORMAT_R16G16B16A16_SFLOAT) && plane_is(&sky->sky_view, SAH_FORMAT_R16G16B16A16_SFLOAT) &&
+           plane_is(noise, SAH_FORMAT_R8G8B8A8_UNORM) && noise->width >= 128 && noise->height >= 128;
+}
+void store_half4(uint8_t* p, const float v[4]) {
+    const uint16_t h[4] = {f32_to_f16(v[0]), f32_to_f16(v[1]), f32_to_f16(v[2]), f32_to_f16(v[3])};
+    std::memcpy(p, h, 8);
 }
 
 }  // namespace
@@ -269,6 +410,94 @@ int orc_sun_shadow_mask(const sah_scene_geometry* scene, const sah_view_data* vi
                 mask = (shadow / F(sun->num_shadow_samples)).v;
             }
             std::memcpy((uint8_t*)mask_out->ptr + (size_t)y * mask_out->row_pitch_bytes + (size_t)x * 4, &mask, 4);
+        }
+    return SAH_OK;
+}
+
+// probe_tracing.rt.slang:39-106
+int orc_probe_trace(const sah_scene_geometry* scene, const sah_probe_trace_desc* d) {
+    using namespace orc;
+    if (!scene_ok(scene) || !d || !gi_inputs_ok(d->sun, d->sky, d->noise)) return SAH_ERR_INVALID_ARGUMENT;
+    if (d->num_probes == 0) return SAH_OK;
+    const sah_volume& tr = d->trace_results;
+    if (!d->probes_to_update || !tr.ptr || tr.format != SAH_FORMAT_R16G16B16A16_SFLOAT || tr.width != 20 || tr.height != 20 || tr.depth < d->num_probes)
+        return SAH_ERR_INVALID_ARGUMENT;
+    const RtStructure s = build(*scene);
+    const GiInputs in = {scene, &s, d->sun, d->sky, d->noise};
+    sah_gi gi;
+    std::memset(&gi, 0, sizeof(gi));
+    gi.kind = SAH_GI_CACHE;
+    gi.probe_irradiance = d->probe_irradiance;
+    gi.probe_depth = d->probe_depth;
+    gi.probe_validity = d->probe_validity;
+    for (int c = 0; c < 4; c++) gi.probe_cascades[c] = d->cascades[c];
+    gi.probe_size[0] = d->probe_size[0];
+    gi.probe_size[1] = d->probe_size[1];
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t probe = 0; probe < (int64_t)d->num_probes; probe++) {
+        const uint32_t* id = d->probes_to_update + 3 * probe;
+        const uint32_t cascade = id[1] / 8;
+        for (uint32_t ty = 0; ty < 20; ty++)
+            for (uint32_t tx = 0; tx < 20; tx++) {
+                float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (cascade < 4) {  // (the shader indexes a 4-entry array; the ABI writes zeros for anything else)
+                    const sah_probe_cascade& c = d->cascades[cascade];
+                    const F3 local = {F((float)id[0]), F((float)(id[1] % 8)), F((float)id[2])};
+                    const F3 origin = F3{F(c.min[0]), F(c.min[1]), F(c.min[2])} + local * F(c.probe_spacing);
+                    const F3 dir = octahedral_texel_direction(tx, ty, 20);
+                    F ray_distance = F(8192.0f);
+                    if (cascade < 3) ray_distance = F(d->cascades[cascade + 1].probe_spacing) * F(4.0f);
+                    const float o[3] = {origin.x.v, origin.y.v, origin.z.v}, dd[3] = {dir.x.v, dir.y.v, dir.z.v};
+                    GiPayload pay = trace_gi(in, make_ray(o, dd, 0.05f, ray_distance.v), tx, ty);
+                    if (pay.ray_distance.v == 0.0f) {
+                        if (cascade + 1 < 4) pay.irradiance = sample_probe_cascade(gi, origin + dir * ray_distance, dir, cascade + 1);
+                        else pay.irradiance = pay.irradiance * F(10.0f);
+                        pay.ray_distance = ray_distance;
+                    } else if (pay.ray_distance.v < 0.0f) {
+                        pay.irradiance = F3(F(0.0f));
+                    }
+                    const H e = H::lit(0.0031415927);
+                    out[0] = (H(pay.irradiance.x.v) * e).v;
+                    out[1] = (H(pay.irradiance.y.v) * e).v;
+                    out[2] = (H(pay.irradiance.z.v) * e).v;
+                    out[3] = H(pay.ray_distance.v).v;
+                }
+                store_half4((uint8_t*)tr.ptr + (size_t)probe * tr.slice_pitch_bytes + (size_t)ty * tr.row_pitch_bytes + (size_t)tx * 8, out);
+            }
+    }
+    return SAH_OK;
+}
+
+// rtgi.rt.slang:56-110.  Pixels the generator returns early from keep what the two targets held
+int orc_rtgi_trace(const sah_scene_geometry* scene, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_sky_luts* sky,
+                   const sah_plane* depth, const sah_plane* normals, const sah_plane* noise, const sah_plane* ray_buffer, const sah_plane* ray_irradiance) {
+    using namespace orc;
+    if (!scene_ok(scene) || !view || !gi_inputs_ok(sun, sky, noise) || !depth || !depth->ptr || !plane_is(normals, SAH_FORMAT_R16G16B16A16_SFLOAT) ||
+        !plane_is(ray_buffer, SAH_FORMAT_R16G16B16A16_SFLOAT) || !plane_is(ray_irradiance, SAH_FORMAT_R16G16B16A16_SFLOAT))
+        return SAH_ERR_INVALID_ARGUMENT;
+    const RtStructure s = build(*scene);
+    const GiInputs in = {scene, &s, sun, sky, noise};
+    const int W = (int)ray_buffer->width, Hh = (int)ray_buffer->height;
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < Hh; y++)
+        for (int x = 0; x < W; x++) {
+            if (!((float)x < view->render_resolution[0] && (float)y < view->render_resolution[1])) continue;
+            const float depth_v = load_f32(*depth, x, y);
+            if (depth_v == 0.0f) continue;
+            uint16_t nh[4];
+            std::memcpy(nh, (const uint8_t*)normals->ptr + (size_t)y * normals->row_pitch_bytes + (size_t)x * 8, 8);
+            const F3 normal = {F(f16_to_f32(nh[0])), F(f16_to_f32(nh[1])), F(f16_to_f32(nh[2]))};  // as stored: not normalised here
+            const F3 pos = worldspace_location_slang(*view, x, y, depth_v);
+            F3 dir = load_noise(*noise, (uint32_t)x % 128u, (uint32_t)y % 128u);
+            if (dot(normal, dir).v < 0.0f) dir = dir * F(-1.0f);
+            const float o[3] = {pos.x.v, pos.y.v, pos.z.v}, dd[3] = {dir.x.v, dir.y.v, dir.z.v};
+            GiPayload pay = trace_gi(in, make_ray(o, dd, 0.01f, 100000.0f), (uint32_t)x, (uint32_t)y);
+            if (any_nan(pay.irradiance)) pay.irradiance = F3(F(0.0f));
+            const F e = F(0.0031415927f);
+            const float rb[4] = {dir.x.v, dir.y.v, dir.z.v, pay.ray_distance.v};
+            const float ri[4] = {(pay.irradiance.x * e).v, (pay.irradiance.y * e).v, (pay.irradiance.z * e).v, 0.0f};
+            store_half4((uint8_t*)ray_buffer->ptr + (size_t)y * ray_buffer->row_pitch_bytes + (size_t)x * 8, rb);
+            store_half4((uint8_t*)ray_irradiance->ptr + (size_t)y * ray_irradiance->row_pitch_bytes + (size_t)x * 8, ri);
         }
     return SAH_OK;
 }

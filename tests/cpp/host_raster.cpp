@@ -122,6 +122,20 @@ int main(int argc, char** argv) {
     TextureHandle lit_scene = alloc.create_texture("lit_scene", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
     scene.sun.get_constants().num_shadow_samples = 2.0f;
     scene.sun.raytrace(graph, view, gbuffer, scene, lit_scene, stbn_3d_unitvec);
+    // the GI rays (rtgi.cpp:41-139): sky LUTs for the miss stage, the irradiance cache traces and folds the scheduler's probes
+    // (irradiance_cache.cpp:585-724), then one GI ray per pixel
+    scene.sky.create_luts(alloc);
+    scene.sky.update_sky_luts(graph, Vec3{0.3f, 0.8f, 0.2f});
+    RayTracedGlobalIllumination rtgi(backend);
+    IrradianceCache& cache = rtgi.get_irradiance_cache();
+    for (uint32_t c = 0; c < 4; c++) {
+        const float spacing = 0.5f * (float)(1u << c);
+        cache.set_cascade(c, Vec3{-16.f * spacing + 0.013f, 1.f - 4.f * spacing, -16.f * spacing + 0.021f}, spacing, Vec3{0.f, 0.f, 0.f});
+    }
+    const ProbeScheduler::ProbeIndex wanted[6] = {{16, 3, 16}, {15, 2, 17}, {10, 9, 20}, {18, 12, 14}, {16, 19, 16}, {16, 27, 15}};
+    for (const auto& id : wanted) cache.get_scheduler().request_probe_update(id);
+    rtgi.pre_render(graph, view, scene, stbn_3d_unitvec.get_layer(0));
+    rtgi.post_render(graph, view, scene, gbuffer, stbn_3d_unitvec.get_layer(0));
     graph.finish();
     for (const auto& e : graph.get_errors()) fprintf(stderr, "pass failed: %s\n", e.c_str());
     if (!graph.get_errors().empty()) return 1;
@@ -148,6 +162,20 @@ int main(int argc, char** argv) {
     for (TextureHandle t : {ao, scene.sun.shadow_mask}) {
         buf.resize((size_t)W * H * 4);
         alloc.download(t, buf.data(), W * 4);
+        fwrite(buf.data(), 1, buf.size(), out);
+    }
+    for (TextureHandle t : {scene.sky.transmittance_lut, scene.sky.sky_view_lut, rtgi.get_ray_texture(), rtgi.get_ray_irradiance()}) {
+        buf.resize((size_t)t->desc.width * t->desc.height * 8);
+        alloc.download(t, buf.data(), t->desc.width * 8);
+        fwrite(buf.data(), 1, buf.size(), out);
+    }
+    const sah_probe_atlases atl = cache.atlases(0);
+    for (const sah_volume* v : {&atl.rtgi, &atl.light_cache, &atl.depth, &atl.average, &atl.validity}) {
+        Texture t;
+        t.desc = *v;
+        const uint32_t row = v->width * format_bytes(v->format);
+        buf.resize((size_t)row * v->height * v->depth);
+        alloc.download(&t, buf.data(), row);
         fwrite(buf.data(), 1, buf.size(), out);
     }
     fclose(out);

@@ -159,6 +159,15 @@ def test_producer_passes_through_cpp_facade(tmp_path):
     lpv_got = [np.frombuffer(take(128 * 32 * 32 * 8), dtype=np.uint16).reshape(32, 32, 128, 4) for _ in range(3)]
     ao_got = np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)
     mask_got = np.frombuffer(take(W * H * 4), np.float32).reshape(H, W)
+    sky_t = np.frombuffer(take(256 * 64 * 8), np.uint16).reshape(64, 256, 4)
+    sky_v = np.frombuffer(take(200 * 200 * 8), np.uint16).reshape(200, 200, 4)
+    rb_got = np.frombuffer(take(W * H * 8), np.uint16).reshape(H, W, 4)
+    ri_got = np.frombuffer(take(W * H * 8), np.uint16).reshape(H, W, 4)
+    atl_got = {"rtgi": np.frombuffer(take(32 * 256 * 224 * 4), np.uint32).reshape(32, 256, 224),
+               "light_cache": np.frombuffer(take(32 * 416 * 416 * 4), np.uint32).reshape(32, 416, 416),
+               "depth": np.frombuffer(take(32 * 384 * 384 * 4), np.uint16).reshape(32, 384, 384, 2),
+               "average": np.frombuffer(take(32 * 32 * 32 * 4), np.uint32).reshape(32, 32, 32),
+               "validity": np.frombuffer(take(32 * 32 * 32), np.uint8).reshape(32, 32, 32)}
     assert off == len(blob)
     o = util.oracle()
     keep = []
@@ -209,6 +218,36 @@ def test_producer_passes_through_cpp_facade(tmp_path):
     assert np.array_equal(ao_got.view(np.uint32), ao_want.view(np.uint32)), "RTAO through the facade"
     assert np.array_equal(mask_got.view(np.uint32), mask_want.view(np.uint32)), "sun shadow mask through the facade"
     assert (ao_want == 0).any() and (mask_want < 1).any()
+    # the GI rays through the facade (RayTracedGlobalIllumination::pre_render -> IrradianceCache::dispatch_probe_updates, ::post_render)
+    # against the oracle, fed with the sky LUTs C++ generated
+    sky = _abi.SkyLuts(images.plane(sky_t, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(sky_v, _abi.FORMAT_R16G16B16A16_SFLOAT))
+    rb_want, ri_want = np.zeros((H, W, 4), np.uint16), np.zeros((H, W, 4), np.uint16)  # create_texture clears to zero
+    assert o.orc_rtgi_trace(C.byref(g), C.byref(view_c), C.byref(sun_rt), C.byref(sky), C.byref(pd), C.byref(pn), C.byref(pz),
+                            C.byref(images.plane(rb_want, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(ri_want, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    assert np.array_equal(rb_got, rb_want), "RTGI ray buffer through the facade"
+    assert np.array_equal(ri_got, ri_want), "RTGI ray irradiance through the facade"
+    assert (rb_want.view(np.float16)[..., 3] > 0).mean() > 0.3
+    atl_want = {k: np.zeros_like(v) for k, v in atl_got.items()}  # fresh atlases, no cascade movement: the copy pass moves zeros
+    ids = np.array([(16, 3, 16), (15, 2, 17), (10, 9, 20), (18, 12, 14), (16, 19, 16), (16, 27, 15)], np.uint32)
+    trace = np.zeros((len(ids), 20, 20, 4), np.uint16)
+    d = _abi.ProbeTraceDesc()
+    for c in range(4):
+        spacing = 0.5 * (1 << c)
+        d.cascades[c].probe_spacing = spacing
+        d.cascades[c].min[0], d.cascades[c].min[1], d.cascades[c].min[2] = -16.0 * spacing + 0.013, 1.0 - 4.0 * spacing, -16.0 * spacing + 0.021
+    d.probes_to_update, d.num_probes = ids.ctypes.data, len(ids)
+    d.sun, d.sky, d.noise = C.pointer(sun_rt), C.pointer(sky), C.pointer(pz)
+    d.probe_irradiance = images.volume(atl_want["rtgi"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
+    d.probe_depth = images.volume(atl_want["depth"], _abi.FORMAT_R16G16_SFLOAT)
+    d.probe_validity = images.volume(atl_want["validity"], _abi.FORMAT_R8_UNORM)
+    d.probe_size[0], d.probe_size[1] = 5, 6
+    d.trace_results = images.volume(trace, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_probe_trace(C.byref(g), C.byref(d)) == 0
+    tv = images.volume(trace, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert o.orc_probe_update(C.byref(util.probe_atlases_desc(atl_want)), C.byref(tv), ids.ctypes.data, len(ids)) == 0
+    for k in atl_want:
+        assert np.array_equal(atl_got[k], atl_want[k]), f"irradiance cache atlas {k} after tracing and folding six probes through the facade"
+    assert atl_want["rtgi"].any() and atl_want["validity"].any()
     # cascade fitting: same algorithm as scene.py (glm restated twice); the inverses differ in rounding, so compare loosely
     view = scene.SceneView.default(W, H)
     sun = scene.DirectionalLight(shadow_mode=_abi.SHADOW_MODE_CSM)

@@ -1,4 +1,4 @@
-"""Ray tracing (first slice): acceleration structure, RTAO, sun shadow mask.
+"""Ray tracing: acceleration structure, RTAO, sun shadow mask, and the GI rays (probe tracing, RTGI) with their hit shading.
 CPU: known answers for the hit rules of include/sah_hip.h on the oracle (which tests every triangle against every ray).
 GPU: HIP (box hierarchy) against the oracle, bit for bit, on the atrium, triangle soups with alpha-tested CUTOUT geometry, degenerate /
 non-finite / empty input, and sorts of more than one LDS chunk."""
@@ -50,16 +50,91 @@ class RtCase:
                                                  C.byref(z), C.byref(o)) == 0
         return out
 
+    # ---- GI rays: sky LUTs, the irradiance cache the probe misses sample, cascades centred on `centre` ----
+    def gi_arrays(self):
+        if not hasattr(self, "_gi"):
+            luts, at = synth.sky_luts(self.gi_seed + 200), synth.probe_atlases(self.gi_seed + 600)
+            self._gi = {"sky_t": luts["transmittance"], "sky_v": luts["sky_view"], "irr": at["irradiance"], "pdepth": at["depth"], "val": at["validity"]}
+        return self._gi
+
+    gi_seed = 3
+    cascade_centre = (0.0, 1.0, 0.0)
+    cascade_spacing = 0.5
+
+    def _sky(self, a):
+        return _abi.SkyLuts(images.plane(a["sky_t"], _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(a["sky_v"], _abi.FORMAT_R16G16B16A16_SFLOAT))
+
+    def probe_desc(self, a, probes_ptr, num_probes, noise, results):
+        """_abi.ProbeTraceDesc over host or device arrays `a` (gi_arrays() keys); returns (desc, keepalive)"""
+        d = _abi.ProbeTraceDesc()
+        for c in range(4):
+            spacing = self.cascade_spacing * (2.0 ** c)
+            ext = (32 * spacing, 8 * spacing, 32 * spacing)
+            d.cascades[c].probe_spacing = spacing
+            for i in range(3):
+                d.cascades[c].min[i] = self.cascade_centre[i] - ext[i] / 2.0 + 0.013 * (c + 1)
+        sky, nz = self._sky(a), images.plane(noise, _abi.FORMAT_R8G8B8A8_UNORM)
+        d.probes_to_update, d.num_probes = probes_ptr, num_probes
+        d.sun, d.sky, d.noise = C.pointer(self.sun.constants), C.pointer(sky), C.pointer(nz)
+        d.probe_irradiance = images.volume(a["irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
+        d.probe_depth = images.volume(a["pdepth"], _abi.FORMAT_R16G16_SFLOAT)
+        d.probe_validity = images.volume(a["val"], _abi.FORMAT_R8_UNORM)
+        d.probe_size[0], d.probe_size[1] = 5, 6
+        d.trace_results = images.volume(results, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        return d, (sky, nz)
+
+    def oracle_probe_trace(self, probes):
+        """probes: (N, 3) uint32 -> (N, 20, 20, 4) float16"""
+        probes = np.ascontiguousarray(probes, np.uint32)
+        out = np.full((max(len(probes), 1), 20, 20, 4), 0x7bff, np.uint16)
+        d, keep = self.probe_desc(self.gi_arrays(), probes.ctypes.data, len(probes), self.noise, out)
+        assert util.oracle().orc_probe_trace(C.byref(self.host_geo), C.byref(d)) == 0
+        return out[:len(probes)].view(np.float16)
+
+    def oracle_rtgi(self):
+        """-> (ray_buffer, ray_irradiance), (H, W, 4) float16 each; texels the generator skips keep the 0x7bff fill"""
+        rb, ri = (np.full((self.height, self.width, 4), 0x7bff, np.uint16) for _ in range(2))
+        a = self.gi_arrays()
+        d, n, z, _ = self.planes(self.gbuffer["depth"], self.gbuffer["normals"], self.noise, np.zeros((1, 1), np.float32))
+        sky = self._sky(a)
+        assert util.oracle().orc_rtgi_trace(C.byref(self.host_geo), C.byref(self.view.gpu_data), C.byref(self.sun.constants), C.byref(sky), C.byref(d), C.byref(n),
+                                            C.byref(z), C.byref(images.plane(rb, _abi.FORMAT_R16G16B16A16_SFLOAT)),
+                                            C.byref(images.plane(ri, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+        return rb.view(np.float16), ri.view(np.float16)
+
     # ---- HIP side (device copies made on first use) ----
     def device(self):
         if not hasattr(self, "_dev"):
             import torch
+            from androidrenderer_amd.frame import to_torch
             dev_arrays = mesh.to_device(self.arrays)
             keep = []
             self._dev = {"geo": mesh.geometry(dev_arrays, keep), "keep": keep,
                          "depth": torch.from_numpy(self.gbuffer["depth"]).cuda(), "normals": torch.from_numpy(self.gbuffer["normals"].view(np.int16)).cuda(),
                          "noise": torch.from_numpy(self.noise).cuda()}
+            self._dev["gi"] = {k: to_torch(v) for k, v in self.gi_arrays().items()}
         return self._dev
+
+    def hip_probe_trace(self, ctx, probes):
+        import torch
+        dv = self.device()
+        probes = np.ascontiguousarray(probes, np.uint32)
+        pd = torch.from_numpy(probes.view(np.int32).reshape(-1)).cuda() if len(probes) else torch.zeros(3, dtype=torch.int32, device="cuda")
+        out = torch.full((max(len(probes), 1), 20, 20, 4), 0x7bff, dtype=torch.int16, device="cuda")
+        d, keep = self.probe_desc(dv["gi"], pd.data_ptr(), len(probes), dv["noise"], out)
+        ctx.probe_trace(d)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.float16)[:len(probes)]
+
+    def hip_rtgi(self, ctx):
+        import torch
+        dv = self.device()
+        rb, ri = (torch.full((self.height, self.width, 4), 0x7bff, dtype=torch.int16, device="cuda") for _ in range(2))
+        d, n, z, _ = self.planes(dv["depth"], dv["normals"], dv["noise"], torch.zeros((1, 1), dtype=torch.float32, device="cuda"))
+        ctx.rtgi_trace(self.view.gpu_data, self.sun.constants, self._sky(dv["gi"]), d, n, z, images.plane(rb, _abi.FORMAT_R16G16B16A16_SFLOAT),
+                       images.plane(ri, _abi.FORMAT_R16G16B16A16_SFLOAT))
+        torch.cuda.synchronize()
+        return rb.cpu().numpy().view(np.float16), ri.cpu().numpy().view(np.float16)
 
     def hip_build(self, ctx):
         return ctx.rt_build(self.device()["geo"])
@@ -220,6 +295,123 @@ def test_non_finite_vertices_are_left_out():
     assert list(stats)[:2] == [1, 2]
 
 
+# ---- GI rays: known answers on the oracle ----------------------------------------------------------------------------------------
+
+def _texel_directions():
+    o = util.oracle()
+    dirs = np.zeros((20, 20, 3), np.float32)
+    c2, d3 = (C.c_float * 2)(), (C.c_float * 3)()
+    for ty in range(20):
+        for tx in range(20):
+            o.orc_octahedral_direction_of_texel(tx, ty, 20, 20, c2, d3)
+            dirs[ty, tx] = d3[:]
+    return dirs
+
+
+E_FACTOR = np.float32(0.0031415927)
+
+
+def test_probe_rays_distance_facing_and_miss():
+    case = RtCase(_floor_and_plate(), 24, 14, view=_top_down_view(24, 14))
+    case.sun.set_direction([0.1, -1.0, 0.2])
+    # cascade 0: min = centre - extent / 2 + 0.013 = (-7.987, -0.987, -7.987), spacing 0.5
+    between = (16, 3, 22)   # (0.013, 0.513, 3.013): above the floor, below the plate
+    outside = (16, 3, 10)   # (0.013, 0.513, -2.987): above the floor, no plate overhead
+    below = (16, 1, 22)     # (0.013, -0.487, 3.013): under the floor
+    far = (16, 3 + 24, 16)  # last cascade (spacing 4): (0.052, -2.948, 0.052)
+    r = case.oracle_probe_trace(np.array([between, outside, below, far], np.uint32)).astype(np.float32)
+    dirs = _texel_directions()
+    up, down = dirs[..., 1] > 0.3, dirs[..., 1] < -0.3
+    # the floor's (v1 - v0) x (v2 - v0) is +y: FRONT facing from above — distance +t, lit; from below BACK facing: -t and black
+    for k in (0, 1):
+        assert np.allclose(r[k][down][:, 3], 0.513 / -dirs[down][:, 1], rtol=3e-3)
+        assert (r[k][down][:, :3] > 0).all() and len(np.unique(r[k][down][:, 0])) == 1  # one normal, one light vector: one value
+    assert np.allclose(r[2][up][:, 3], -(0.487 / dirs[up][:, 1]), rtol=3e-3) and (r[2][up][:, :3] == 0).all()
+    # the plate (normal -y, front facing from below): hit, but the light comes from above: black
+    assert np.allclose(r[0][up][:, 3], 0.487 / dirs[up][:, 1], rtol=3e-3) and (r[0][up][:, :3] == 0).all()
+    # misses report the ray's full length — 4 x the next cascade's spacing, 8192 in the last — and carry the next cascade's irradiance or 10 x sky
+    assert (r[1][up][:, 3] == 4.0).all() and (r[2][down][:, 3] == 4.0).all() and np.isfinite(r[1][up][:, :3]).all()
+    assert (r[3][down][:, 3] == 8192.0).all() and (r[3][down][:, :3] > 0).all()
+    # a probe id outside the four cascades writes zeros (the shader would read past a 4-entry array)
+    assert (case.oracle_probe_trace(np.array([(1, 32, 1)], np.uint32)) == 0).all()
+
+
+def _floor_with_occluder(kind):
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    m.add_primitive([(-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6)], [(0, 1, 0)] * 4, (0, 2, 1, 0, 3, 2), mat)
+    quad = [(-6, 2, -6), (6, 2, -6), (6, 2, 6), (-6, 2, 6)]
+    if kind == "plate_facing_down":
+        m.add_primitive(quad, [(0, -1, 0)] * 4, (0, 1, 2, 0, 2, 3), mat)
+    elif kind == "plate_facing_up":
+        m.add_primitive(quad, [(0, 1, 0)] * 4, (0, 2, 1, 0, 3, 2), mat)
+    elif kind == "box":
+        m.add_box((-6, 2, -6), (6, 3, 6), mat)
+    return m
+
+
+def test_gi_shadow_ray_culls_front_faces():
+    """the hit stage's shadow ray carries CULL_FRONT_FACING_TRIANGLES (gltf_basic_pbr.slang:452-461): a single-sided sheet facing the
+    shaded point does not shadow it; its back, or a closed box, does"""
+    lit = {}
+    for kind in ("none", "plate_facing_down", "plate_facing_up", "box"):
+        case = RtCase(_floor_with_occluder(kind), 16, 9, view=_top_down_view(16, 9))
+        case.sun.set_direction([0.0, -1.0, 0.001])
+        case.sun.constants.direction_and_tan_size[3] = 0.0
+        r = case.oracle_probe_trace(np.array([(16, 3, 16)], np.uint32)).astype(np.float32)[0]  # (0.013, 0.513, 0.013)
+        down = _texel_directions()[..., 1] < -0.5
+        lit[kind] = np.unique(r[down][:, 0])
+        assert len(lit[kind]) == 1
+    assert lit["none"][0] > 0 and lit["plate_facing_down"][0] == lit["none"][0]
+    assert lit["plate_facing_up"][0] == 0 and lit["box"][0] == 0
+
+
+def test_rtgi_rays_emission_miss_and_untraced_pixels():
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    glow = m.add_material(mesh.material(emission=(2.0, 3.0, 4.0, 0.0)))
+    m.add_primitive([(-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6)], [(0, 1, 0)] * 4, (0, 2, 1, 0, 3, 2), mat)
+    m.add_primitive([(-6, 1, 0), (6, 1, 0), (6, 1, 6), (-6, 1, 6)], [(0, -1, 0)] * 4, (0, 1, 2, 0, 2, 3), glow)
+    case = RtCase(m, 24, 14, view=_top_down_view(24, 14))
+    case.noise[...] = (128, 255, 128, 0)
+    case.sun.set_direction([0.1, -1.0, 0.2])
+    for i in range(3):
+        case.sun.constants.color[i] = 0.0  # sun off: the irradiance of a hit is its emission
+    case.gbuffer["depth"][0, :] = 0.0      # a row of sky pixels
+    rb, ri = case.oracle_rtgi()
+    assert (rb[0].view(np.uint16) == 0x7bff).all() and (ri[0].view(np.uint16) == 0x7bff).all()  # not written
+    pos = _floor_positions(case)[1:]
+    rb, ri = rb[1:].astype(np.float32), ri[1:].astype(np.float32)
+    d = np.array([1.0 / 255.0, 1.0, 1.0 / 255.0], np.float32)
+    d /= np.linalg.norm(d)
+    assert np.allclose(rb[..., :3], d, atol=1e-3)
+    under, clear = pos[..., 2] > 0.05, pos[..., 2] < -0.05
+    assert np.allclose(rb[under][:, 3], 1.0 / d[1], rtol=2e-3)
+    want = (np.array([2.0, 3.0, 4.0], np.float32) * E_FACTOR).astype(np.float16).astype(np.float32)
+    assert np.array_equal(ri[under][:, :3], np.broadcast_to(want, ri[under][:, :3].shape)) and (ri[..., 3] == 0).all()
+    assert (rb[clear][:, 3] == 0).all() and (ri[clear][:, :3] > 0).all()  # miss: distance stays 0, sky colour
+    assert len(np.unique(ri[clear][:, 0])) == 1                            # one direction: one sky colour
+
+
+def test_closest_hit_prefers_smaller_t_then_smaller_ids():
+    # two coincident emissive sheets (different primitives) above the floor and a third one farther up: the nearest wins; of the two
+    # coincident ones, the smaller primitive index
+    m = mesh.Mesh()
+    mat = m.add_material(mesh.material())
+    m.add_primitive([(-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6)], [(0, 1, 0)] * 4, (0, 2, 1, 0, 3, 2), mat)
+    sheet = [(-6, 1, -6), (6, 1, -6), (6, 1, 6), (-6, 1, 6)]
+    for level, emission in ((2.0, (9.0, 9.0, 9.0, 0.0)), (1.0, (1.0, 0.0, 0.0, 0.0)), (1.0, (0.0, 1.0, 0.0, 0.0))):
+        m.add_primitive([(x, level, z) for (x, _, z) in sheet], [(0, -1, 0)] * 4, (0, 1, 2, 0, 2, 3), m.add_material(mesh.material(emission=emission)))
+    case = RtCase(m, 16, 9, view=_top_down_view(16, 9))
+    case.noise[...] = (128, 255, 128, 0)
+    for i in range(3):
+        case.sun.constants.color[i] = 0.0
+    rb, ri = case.oracle_rtgi()
+    ri = ri.astype(np.float32)
+    want = (np.array([1.0, 0.0, 0.0], np.float32) * E_FACTOR).astype(np.float16).astype(np.float32)
+    assert np.array_equal(ri[..., :3], np.broadcast_to(want, ri[..., :3].shape))
+
+
 # ---- GPU: HIP == oracle ---------------------------------------------------------------------------------------------------------
 
 def _check_both(ctx, case, spp=1, radius=1.5, expect_tris=None):
@@ -324,3 +516,110 @@ def test_hip_rejects_bad_arguments(hip_ctx):
         case.hip_rtao(fresh, spp=100000)
     torch.cuda.synchronize()
     fresh.close()
+
+
+# ---- GPU: the GI rays, HIP == oracle ----------------------------------------------------------------------------------------------
+
+def _probe_ids(seed, count):
+    g = synth.rng(seed)
+    ids = g.integers(0, 32, (count, 3)).astype(np.uint32)
+    ids[0] = (16, 3, 16)    # next to the cascade centre
+    ids[1] = (5, 40, 7)     # outside the four cascades: zeros
+    return ids
+
+
+def _check_gi(ctx, case, probes):
+    case.hip_build(ctx)
+    t_h, t_o = case.hip_probe_trace(ctx, probes), case.oracle_probe_trace(probes)
+    assert np.array_equal(t_h.view(np.uint16), t_o.view(np.uint16)), f"probe trace: {int((t_h.view(np.uint16) != t_o.view(np.uint16)).any(-1).sum())} texels differ"
+    (rb_h, ri_h), (rb_o, ri_o) = case.hip_rtgi(ctx), case.oracle_rtgi()
+    assert np.array_equal(rb_h.view(np.uint16), rb_o.view(np.uint16)), f"ray buffer: {int((rb_h.view(np.uint16) != rb_o.view(np.uint16)).any(-1).sum())} texels differ"
+    assert np.array_equal(ri_h.view(np.uint16), ri_o.view(np.uint16)), f"ray irradiance: {int((ri_h.view(np.uint16) != ri_o.view(np.uint16)).any(-1).sum())} texels differ"
+    return t_o, rb_o, ri_o
+
+
+@pytest.mark.gpu
+def test_hip_gi_rays_known_answer_scenes(hip_ctx):
+    for kind in ("none", "plate_facing_down", "plate_facing_up", "box"):
+        case = RtCase(_floor_with_occluder(kind), 32, 18, view=_top_down_view(32, 18))
+        _check_gi(hip_ctx, case, _probe_ids(3, 12))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subdiv,size", [(1, (96, 54)), (4, (48, 27))])
+def test_hip_gi_rays_atrium(hip_ctx, subdiv, size):
+    case = RtCase(mesh.atrium(subdiv), *size)
+    trace, rb, ri = _check_gi(hip_ctx, case, _probe_ids(5, 40))
+    d = trace.astype(np.float32)[..., 3]
+    assert (d > 0).any() and (d < 0).any()                   # probes inside boxes see back faces
+    assert (rb.astype(np.float32)[..., 3] > 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,textured", [(1, False), (2, True), (3, True)])
+def test_hip_gi_rays_triangle_soups_with_cutouts(hip_ctx, seed, textured):
+    case = RtCase(mesh.random_soup(seed, triangles=400, textured=textured), 64, 36, seed=seed)
+    case.sun.set_direction([0.3, -1.0, 0.2])
+    _check_gi(hip_ctx, case, _probe_ids(seed, 30))
+
+
+@pytest.mark.gpu
+def test_hip_gi_rays_random_planes_and_empty_scene(hip_ctx):
+    g = synth.rng(78)
+    W, H = 80, 45
+    gb = {"depth": np.where(g.uniform(size=(H, W)) < 0.1, 0.0, g.uniform(0.003, 0.2, (H, W))).astype(np.float32),
+          "normals": g.normal(size=(H, W, 4)).astype(np.float16).view(np.uint16)}
+    gb["normals"][0, :4] = 0x7c00
+    gb["normals"][1, :4] = 0
+    _check_gi(hip_ctx, RtCase(mesh.random_soup(9, triangles=600, textured=True), W, H, seed=5, gbuffer=gb), _probe_ids(9, 24))
+    empty = mesh.Mesh()
+    empty.add_material(mesh.material())
+    case = RtCase(empty, 16, 9, gbuffer={"depth": np.full((9, 16), 0.05, np.float32), "normals": np.full((9, 16, 4), 0x3c00, np.uint16)})
+    trace, rb, ri = _check_gi(hip_ctx, case, _probe_ids(2, 8))
+    assert (rb.astype(np.float32)[..., 3] == 0).all()
+    assert _check_gi(hip_ctx, case, np.zeros((0, 3), np.uint32))[0].shape[0] == 0
+
+
+@pytest.mark.gpu
+def test_hip_probe_trace_feeds_probe_update(hip_ctx):
+    """the frame's order (irradiance_cache.cpp dispatch_probe_updates): trace the probes, then fold the 20 x 20 results into the atlases"""
+    import torch
+    from androidrenderer_amd.frame import to_torch
+    case = RtCase(mesh.atrium(1), 32, 18)
+    atl, _, ids = synth.probe_maintenance_inputs(seed=31, num_probes=24)
+    trace = case.oracle_probe_trace(ids)
+    o_atl = {k: v.copy() for k, v in atl.items()}
+    tv = images.volume(trace.view(np.uint16), _abi.FORMAT_R16G16B16A16_SFLOAT)
+    assert util.oracle().orc_probe_update(C.byref(util.probe_atlases_desc(o_atl)), C.byref(tv), ids.ctypes.data, len(ids)) == 0
+    case.hip_build(hip_ctx)
+    dv = case.device()
+    pd = torch.from_numpy(ids.view(np.int32).reshape(-1)).cuda()
+    out = torch.zeros((len(ids), 20, 20, 4), dtype=torch.int16, device="cuda")
+    d, keep = case.probe_desc(dv["gi"], pd.data_ptr(), len(ids), dv["noise"], out)
+    h_atl = {k: to_torch(v) for k, v in atl.items()}
+    hip_ctx.probe_trace(d)
+    hip_ctx.probe_update(util.probe_atlases_desc(h_atl), images.volume(out, _abi.FORMAT_R16G16B16A16_SFLOAT), pd.data_ptr(), len(ids))
+    torch.cuda.synchronize()
+    for k in o_atl:
+        assert np.array_equal(h_atl[k].cpu().numpy().view(o_atl[k].dtype), o_atl[k]), k
+
+
+@pytest.mark.gpu
+def test_hip_gi_generators_reject_bad_arguments(hip_ctx):
+    from androidrenderer_amd import lib
+    import torch
+    case = RtCase(_floor_and_plate(), 16, 9, view=_top_down_view(16, 9))
+    case.hip_build(hip_ctx)
+    dv = case.device()
+    small_noise = torch.zeros((64, 64, 4), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((1, 20, 20, 4), dtype=torch.int16, device="cuda")
+    pd = torch.zeros(3, dtype=torch.int32, device="cuda")
+    d, keep = case.probe_desc(dv["gi"], pd.data_ptr(), 1, small_noise, out)
+    with pytest.raises(lib.SahError):
+        hip_ctx.probe_trace(d)
+    d, keep = case.probe_desc(dv["gi"], pd.data_ptr(), 2, dv["noise"], out)  # results hold one probe
+    with pytest.raises(lib.SahError):
+        hip_ctx.probe_trace(d)
+    d, keep = case.probe_desc(dv["gi"], 0, 1, dv["noise"], out)
+    with pytest.raises(lib.SahError):
+        hip_ctx.probe_trace(d)

@@ -5,13 +5,17 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r2"
+R = sys.argv[1] if len(sys.argv) > 1 else "r3"
 SRC, DST = "gpurun_out/refresh", "profiles"
 shutil.copy(f"{SRC}/bench.json", f"{DST}/{R}_bench_4k_deferred_gi.json")
 shutil.copy(f"{SRC}/ktrace/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_deferred_gi.csv")
 shutil.copy(f"{SRC}/pmc.txt", f"{DST}/{R}_pmc_4k_deferred_gi.txt")
 shutil.copy(f"{SRC}/passes.txt", f"{DST}/{R}_passes_4k.txt")
-shutil.copy(f"{SRC}/ta_probe.txt", f"{DST}/{R}_pmc_ta_tcp_probe.txt")
+for src, dst in (("pmc_rt_cache_tiled.txt", "pmc_rt_cache_tiled.txt"), ("pmc_tonemap.txt", "pmc_tonemap.txt"), ("cpu_baselines.txt", "cpu_baselines.txt"),
+                 ("rehearse_n2.json", "rehearse_n2_one_gpu.json"), ("strict_chain.json", "bench_4k_probe_gi_chain_strict_tonemap.json"),
+                 ("repack.json", "bench_4k_deferred_gi_repack_lpv.json")):
+    if os.path.exists(f"{SRC}/{src}"):
+        shutil.copy(f"{SRC}/{src}", f"{DST}/{R}_{dst}")
 # other workloads: replace the lines of the workloads that were re-run, keep the rest (the 8K ones come from their own run)
 path = f"{DST}/{R}_bench_other_workloads.jsonl"
 old = {}

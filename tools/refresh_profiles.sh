@@ -1,19 +1,19 @@
 #!/bin/bash
-# Regenerates the evidence under gpurun_out/ that gets copied into profiles/ (run on the GPU box from the repo root):
-#   bench line, rocprofv3 kernel-trace stats of the same command, PMC passes (traffic), per-pass table.
+# Regenerates the evidence under gpurun_out/refresh/ that tools/copy_profiles.py copies into profiles/ (run on the GPU box from the repo root):
+#   bench line with the driver's arguments, rocprofv3 kernel-trace stats of the same command, PMC passes, per-pass table, other workloads,
+#   CPU baselines of the five configs, the N = 2 rehearsal on one GPU.
 set -u
-export TMPDIR=/tmp
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/refresh
-mkdir -p $O
-python3 bench.py > $O/bench.json 2> $O/bench.err && echo "bench ok"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 > $O/ktrace.log 2>&1 && echo "ktrace ok"
+rm -rf $O; mkdir -p $O
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err && echo "bench ok"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/ktrace.log 2>&1 && echo "ktrace ok"
 bash tools/pmc_collect.sh $O/pmc > $O/pmc.txt 2>&1 && echo "pmc ok"
+PMC_ARGS="--no-cpu-baseline --steps 5 --warmup 1 --workload 4k_probe_gi_chain" PMC_KERNEL=k_lighting_tiled bash tools/pmc_collect.sh $O/pmc_tiled > $O/pmc_rt_cache_tiled.txt 2>&1 && echo "pmc tiled ok"
+PMC_SCRIPT=tools/bench_passes.py PMC_ARGS="--only tonemap --iters 5" PMC_KERNEL=k_tonemap bash tools/pmc_collect.sh $O/pmc_tm > $O/pmc_tonemap.txt 2>&1 && echo "pmc tonemap ok"
 python3 tools/bench_passes.py > $O/passes.txt 2>&1 && echo "passes ok"
-for w in 1080p_64_lights 4k_256_lights 4k_probe_gi_chain 4k_lpv_gi_chain 4k_deferred_gi_random 4k_deferred_gi_scene_shadow 4k_deferred_gi_produced 8k_deferred_gi 8k_1024_lights_gi; do python3 bench.py --workload $w --steps 50 --warmup 5 --cpu-seconds 3 > $O/bench_$w.json 2>> $O/bench.err && echo "$w ok"; done
-# the counter group pmc_collect.sh leaves out (derived TA / TCP counters): one run each, evidence kept for the cause
-for c in TA_BUSY_avr TCP_TCC_READ_REQ_sum "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
-  n=$(echo $c | tr ' ' '_')
-  timeout -k 10 120 rocprofv3 --pmc $c -d $O/ta_$n -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/ta_$n.log 2>&1; echo "TA/TCP probe '$c': rc=$?" >> $O/ta_probe.txt
-  tail -3 $O/ta_$n.log >> $O/ta_probe.txt
-done
-rocprofv3 --list-avail > $O/list_avail.txt 2>&1; grep -c "TA_\|TCP_" $O/list_avail.txt >> $O/ta_probe.txt
+for w in 1080p_64_lights 4k_256_lights 4k_probe_gi_chain 4k_lpv_gi_chain 4k_probe_gi_chain_traced 4k_deferred_gi_random 4k_deferred_gi_produced 8k_deferred_gi 8k_1024_lights_gi; do python3 bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2>> $O/bench.err && echo "$w ok"; done
+python3 bench.py --workload 4k_probe_gi_chain --strict-tonemap --steps 50 --warmup 5 --no-cpu-baseline > $O/strict_chain.json 2>> $O/bench.err && echo "strict chain ok"
+python3 bench.py --repack-lpv --steps 200 --warmup 20 --no-cpu-baseline > $O/repack.json 2>> $O/bench.err && echo "repack ok"
+python3 tools/cpu_baselines.py --seconds 5 > $O/cpu_baselines.txt 2>> $O/bench.err && echo "cpu baselines ok"
+timeout -k 10 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29651 bench.py --gpus 2 --steps 20 --warmup 5 --rehearse-on-one-gpu > $O/rehearse_n2.json 2> $O/rehearse_n2.err && echo "rehearsal ok"

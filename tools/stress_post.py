@@ -49,6 +49,7 @@ def main():
     sizes = [(320, 180), (257, 131), (64, 64), (511, 77), (96, 400), (33, 17), (8, 8), (1, 1), (3, 200), (700, 40), (1280, 720), (130, 129)]
     flavours = ["plain", "signed", "huge", "nonfinite", "tiny", "black"]
     bad = 0
+    tol_hist = np.zeros(3, np.int64)
     for case in range(args.cases):
         g = synth.rng(7000 + case)
         w, h = sizes[case % len(sizes)]
@@ -90,11 +91,23 @@ def main():
             ctx.tonemap(images.plane(sc, F16), chain, op)
         torch.cuda.synchronize()
         got = out.cpu().numpy()
+        # tolerance mode of the composite against the strict image: |code difference| histogram (finite scenes: must stay <= 1)
+        out_t = torch.zeros((oh, ow, 4), dtype=torch.uint8, device="cuda")
+        ctx.tonemap(images.plane(sc, F16), chain, images.plane(out_t, _abi.FORMAT_R8G8B8A8_SRGB), flags=_abi.TONEMAP_TOLERANCE_1CODE)
+        torch.cuda.synchronize()
+        dt = np.abs(out_t.cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+        hist = np.bincount(np.minimum(dt.reshape(-1), 2), minlength=3)
+        tol_hist += hist
+        if flavour != "nonfinite" and dt.max() > 1:
+            fails.append(f"tolerance-mode tonemap (max {int(dt.max())})")
         if not np.array_equal(got, ref):
             fails.append(f"tonemap({int((got != ref).sum())} codes, max {int(np.abs(got.astype(int) - ref.astype(int)).max())})")
         bad += bool(fails)
-        print(f"case {case:3d}: {w}x{h} -> {ow}x{oh}, {flavour}, {nm} mips: {'ok' if not fails else 'MISMATCH ' + ' '.join(fails)}", flush=True)
+        print(f"case {case:3d}: {w}x{h} -> {ow}x{oh}, {flavour}, {nm} mips: {'ok' if not fails else 'MISMATCH ' + ' '.join(fails)}; tolerance mode: "
+              f"{int(hist[1])} codes at 1, {int(hist[2])} beyond", flush=True)
     print(f"{args.cases} cases, {bad} with mismatches")
+    print(f"tolerance-mode composite (SAH_TONEMAP_TOLERANCE_1CODE) against the strict one, all cases: |code difference| histogram [0, 1, >= 2] = "
+          f"{tol_hist.tolist()} (the >= 2 entries, if any, are pixels next to inf / NaN texels of the 'nonfinite' scenes)")
     return 1 if bad else 0
 
 

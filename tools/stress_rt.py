@@ -1,0 +1,56 @@
+"""Randomised HIP-vs-oracle sweep of the ray tracer (sah_rt_build + sah_rtao + sah_sun_shadow_mask): triangle soups of varying density,
+scale and cutout share (textured or not), random planes to start the rays from (incl. sky pixels, non-finite normals), random sun
+directions, cone sizes and sample counts.  The oracle tests every triangle against every ray; HIP walks its box hierarchy.
+
+    python tools/stress_rt.py [--cases 40]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from androidrenderer_amd import lib, mesh, synth  # noqa: E402
+from tests import test_rt  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    args = ap.parse_args()
+    import torch
+    ctx = lib.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    bad = 0
+    for case in range(args.cases):
+        g = synth.rng(9000 + case)
+        tris = int(g.choice([40, 400, 1200, 3000]))
+        m = mesh.random_soup(500 + case, triangles=tris, extent=float(g.choice([3.0, 6.0, 20.0])), size=(0.02, float(g.choice([1.0, 3.0, 8.0]))),
+                             cutout_fraction=float(g.choice([0.0, 0.3, 1.0])), textured=bool(g.integers(2)))
+        W, H = (48, 27) if tris >= 1200 else (64, 36)
+        if g.random() < 0.5:
+            gb = {"depth": np.where(g.uniform(size=(H, W)) < 0.1, 0.0, g.uniform(0.003, 0.3, (H, W))).astype(np.float32),
+                  "normals": g.normal(size=(H, W, 4)).astype(np.float16).view(np.uint16)}
+            c = test_rt.RtCase(m, W, H, seed=case, gbuffer=gb)
+        else:
+            c = test_rt.RtCase(m, W, H, seed=case)
+        c.sun.set_direction(g.normal(size=3))
+        c.sun.constants.direction_and_tan_size[3] = float(g.choice([0.0, 0.0095, 0.2]))
+        c.sun.constants.num_shadow_samples = float(g.choice([1.0, 2.0, 5.0]))
+        spp, radius = int(g.choice([1, 3])), float(g.choice([0.5, 4.0, 100.0]))
+        stats = c.hip_build(ctx)
+        ao_h, ao_o = c.hip_rtao(ctx, spp, radius), c.oracle_rtao(spp, radius)
+        mk_h, mk_o = c.hip_mask(ctx), c.oracle_mask()
+        d_ao = int((ao_h.view(np.uint32) != ao_o.view(np.uint32)).sum())
+        d_mk = int((mk_h.view(np.uint32) != mk_o.view(np.uint32)).sum())
+        bad += bool(d_ao or d_mk)
+        print(f"case {case:3d}: {stats[0]:5d} triangles ({stats[1]} left out), {stats[2]} levels, {W}x{H}, spp {spp}, radius {radius}: "
+              f"ao occluded {float((ao_o == 0).mean()):.2f}, mask lit {float(np.nanmean(mk_o)):.2f}: "
+              f"{'ok' if not (d_ao or d_mk) else f'MISMATCH ao {d_ao} mask {d_mk}'}", flush=True)
+    print(f"{args.cases} cases, {bad} with mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
