@@ -138,7 +138,7 @@ class GI(C.Structure):
                 ("probe_irradiance", Volume), ("probe_depth", Volume), ("probe_validity", Volume),
                 ("probe_cascades", ProbeCascade * 4), ("probe_size", C.c_uint32 * 2), ("cache_debug_mode", C.c_uint32),
                 ("ray_buffer", Plane), ("ray_irradiance", Plane), ("noise", Plane), ("num_extra_rays", C.c_uint32),
-                ("extra_ray_radius", C.c_float), ("lpv_generation", C.c_uint32)]
+                ("extra_ray_radius", C.c_float), ("lpv_generation", C.c_uint32), ("probe_generation", C.c_uint32)]
 
 
 class SkyLuts(C.Structure):

@@ -20,6 +20,7 @@ namespace sah {
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                            const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
 hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, hipStream_t st);
+hipError_t launch_probe_irr_unpack(const VolumeArg& src, uint8_t* dst, hipStream_t st);
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                              uint32_t row_end, hipStream_t st);
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
@@ -223,6 +224,7 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->state) (void)hipFree(ctx->state);
     if (ctx->list) (void)hipFree(ctx->list);
     if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
+    if (ctx->irr32) (void)hipFree(ctx->irr32);
     if (ctx->colx_table) (void)hipFree(ctx->colx_table);
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
     if (ctx->tm_axis) (void)hipFree(ctx->tm_axis);
@@ -434,7 +436,30 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
                        gi.probe_size[0] >= 1 && gi.probe_size[0] <= 30 && gi.probe_size[1] >= 1 && gi.probe_size[1] <= 30 &&
                        // atlases exactly 32 blocks wide, as get_probe_uv assumes: texcoords then never reach the REPEAT seam
                        gi.probe_irradiance.width == 32u * (gi.probe_size[0] + 2u) && gi.probe_irradiance.height == 32u * (gi.probe_size[1] + 2u) &&
-                       gi.probe_depth.width == 32u * 12u && gi.probe_depth.height == 32u * 12u;
+                       gi.probe_depth.width == 32u * 12u && gi.probe_depth.height == 32u * 12u &&
+                       // the widened copy is addressed with 4 x the atlas's 32-bit offsets
+                       bytes(gi.probe_irradiance) < (1ull << 30) && gi.probe_irradiance.row_pitch_bytes % 4 == 0 && gi.probe_irradiance.slice_pitch_bytes % 4 == 0 &&
+                       ((uintptr_t)gi.probe_irradiance.ptr % 4) == 0;
+        if (cache.hot_ok) {
+            const size_t need = 4 * (size_t)bytes(gi.probe_irradiance);
+            if (ctx->irr32_bytes < need) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->irr32) (void)hipFree(ctx->irr32);
+                ctx->irr32 = nullptr;
+                ctx->irr32_bytes = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->irr32, need));
+                ctx->irr32_bytes = need;
+                ctx->irr32_generation = 0;
+            }
+            const bool reuse = gi.probe_generation != 0 && gi.probe_generation == ctx->irr32_generation &&
+                               memcmp(&cache.irradiance, &ctx->irr32_source, sizeof(cache.irradiance)) == 0;
+            if (!reuse) {
+                HIP_TRY(ctx, launch_probe_irr_unpack(cache.irradiance, ctx->irr32, ctx->stream));
+                ctx->irr32_generation = gi.probe_generation;
+                ctx->irr32_source = cache.irradiance;
+            }
+            cache.irr32 = ctx->irr32;
+        }
     } else if (gi_kind == SAH_GI_RTGI) {
         const sah_gi& gi = *d->gi;
         if (!plane_ok(&gi.ray_buffer, SAH_FORMAT_R16G16B16A16_SFLOAT, SAH_FORMAT_R16G16B16A16_SFLOAT, W, H) ||

@@ -351,6 +351,7 @@ int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_a
         s.validity.ptr == d.validity.ptr)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "probe copy: source and destination atlases must not alias");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->irr32_generation = 0;  // the Lighting pass's fp32 copy of an irradiance atlas is stale from here on
     HIP_TRY(ctx, sah::launch_probe_copy(s, d, cascade_movement, ctx->stream));
     return SAH_OK;
 }
@@ -370,6 +371,7 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
         (trace_results->row_pitch_bytes % 8) || (trace_results->slice_pitch_bytes % 8))
         return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "trace_results must be R16G16B16A16_SFLOAT 20 x 20 x >= num_probes, 8-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->irr32_generation = 0;
     if (!ctx->probe_slots) {  // probe cell -> position in the update list (probes.hip: ordered_stores); all zero between calls
         HIP_TRY(ctx, hipMalloc((void**)&ctx->probe_slots, 32 * 32 * 32 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->probe_slots, 0, 32 * 32 * 32 * sizeof(uint32_t), ctx->stream));

@@ -32,6 +32,10 @@ struct sah_ctx {
     sah::FrameState* state = nullptr;  // device
     uint32_t* list = nullptr;          // device: deferred-pixel list
     size_t list_bytes = 0;
+    uint8_t* irr32 = nullptr;          // device: fp32 copy of the probe irradiance atlas (lighting_tiled.hip: k_probe_irr_unpack)
+    size_t irr32_bytes = 0;
+    uint32_t irr32_generation = 0;     // sah_gi::probe_generation the copy was built for (0: not reusable)
+    sah::VolumeArg irr32_source = {};
     uint8_t* lpv_packed = nullptr;     // device: per-frame interleaved, zero-bordered copy of the three LPV volumes (lighting.hip)
     size_t lpv_packed_bytes = 0;
     uint32_t lpv_pack_serial = 0;      // number of the last k_lpv_pack run (FrameState::nonfinite_tag)

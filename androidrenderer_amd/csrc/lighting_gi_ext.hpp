@@ -275,6 +275,10 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             pidx[k][j] = f2uint((k == 1 ? pl + cascade_row : pl + Fn(0.f)).v);
             tri[k][j] = nmax(Fn(0.001f), j ? alpha : Fn(1.f) - alpha);
         }
+        // signs of the direction from a probe to the point, per axis: -dp[k][0] = ps - floor(ps) >= 0 and -dp[k][1] = ps - floor(ps) - 1 < 0.
+        // The octahedral fold below takes them as known, which needs the products with 1 / L1 not to underflow to -0: a dp[k][1] this
+        // small (a coordinate within 2^-100 cells below a cell boundary at the cascade's origin) sends the pixel to sample_cascade()
+        bad = bad || !(dp[k][1].v >= 0x1p-100f) || !(dp[k][0].v <= 0.f);
     }
     // texcoord terms per axis: idx * total + total / 2 (depth atlas: 10 + 2 texels), and the whole irradiance axis
     Fn dbase[2][2];
@@ -310,9 +314,12 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const int jx = i & 1u, jy = (i >> 1) & 1u, jz = (i >> 2) & 1u;
         float validity = 0.f;  // Texture2DArray<half>[uint3]: out-of-range loads return 0
         if (pidx[0][jx] < c.validity.width && pidx[1][jy] < c.validity.height && zin[jz]) {
-            const uint8_t b = c.validity.ptr[vlayer[jz] + pidx[1][jy] * c.validity.row_pitch + pidx[0][jx]];
-            validity = rh(lut[256u + b]);  // lut[256 + b] == (float)b / 255.0f (api.cpp)
+            // only `validity == 0` is used, and (half)(b / 255) is zero for b = 0 alone
+            validity = c.validity.ptr[vlayer[jz] + pidx[1][jy] * c.validity.row_pitch + pidx[0][jx]] ? 1.f : 0.f;
         }
+#if defined(SAH_EXP_CACHE_SKIP) && SAH_EXP_CACHE_SKIP == 3
+        validity = 1.f;
+#endif
         if (validity == 0.f) continue;
         // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
         const F3 dir_to_probe = {dp[0][jx], dp[1][jy], dp[2][jz]};
@@ -322,7 +329,25 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const Fn trilinear_weight = tri[0][jx] * tri[1][jy] * tri[2][jz];
         Fn probe_weight = Fn(1.f);
 
-        const F2 depth_oct = octahedral_coordinates_nr(-dir_to_probe, pbad);
+#if defined(SAH_EXP_CACHE_SKIP) && (SAH_EXP_CACHE_SKIP == 1 || SAH_EXP_CACHE_SKIP == 4)
+        float dt0 = dist.v * 0.5f, dt1 = dist.v;
+#else
+        // octahedral_coordinates(-dir_to_probe) with the signs above: uv = -dp.xy / L1 is >= 0 for corner 0 and < 0 for corner 1 of its
+        // axis; the fold (direction.z < 0) happens for the z corner 1 and nowhere else, and multiplying by sign_not_zero is a negation or
+        // nothing
+        F2 depth_oct;
+        {
+            const Fn l1 = nabs(dir_to_probe.x) + nabs(dir_to_probe.y) + nabs(dir_to_probe.z);
+            pbad = pbad || !(l1.v >= kDivLo && l1.v <= kDivHi);
+            const Fn inv = Fn(rcp_nr(l1.v));
+            const F2 uv = {-dir_to_probe.x * inv, -dir_to_probe.y * inv};
+            if (jz == 0) {
+                depth_oct = uv;
+            } else {
+                const Fn rx = Fn(1.f) - nabs(uv.y), ry = Fn(1.f) - nabs(uv.x);
+                depth_oct = {jx == 0 ? rx : -rx, jy == 0 ? ry : -ry};
+            }
+        }
         const float du = div_const((dbase[0][jx] + depth_oct.x * (Fn(10.f) * Fn(0.5f))).v, 384.0f, 1.0f / 384.0f);
         const float dv = div_const((dbase[1][jy] + depth_oct.y * (Fn(10.f) * Fn(0.5f))).v, 384.0f, 1.0f / 384.0f);
         const ProbeAxis dxa = probe_axis(du, c.depth.width, 4u), dya = probe_axis(dv, c.depth.height, c.depth.row_pitch);
@@ -336,6 +361,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             dt0 = fma_mix_lo(dwt[k], dw[k], dt0);
             dt1 = fma_mix_hi(dwt[k], dw[k], dt1);
         }
+#endif
         const Hn dx = Hn(dt0), dy = Hn(dt1);  // Sampler2DArray<half2>
         const Fn variance = Fn(tof(nabs(dx * dx - dy)));
         const Fn v = dist - Fn(tof(dx));
@@ -354,19 +380,23 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
 
         const ProbeAxis ixa = iax[0][jx], iya = iax[1][jy];
         const uint32_t irow0 = ilayer[jz] + iya.off + ixa.off;
-        const uint2 i0 = load_pair(c.irradiance.ptr, irow0), i1 = load_pair(c.irradiance.ptr, irow0 + c.irradiance.row_pitch);
-        const uint32_t iw[4] = {i0.x, i0.y, i1.x, i1.y};
+        // the four taps from the widened copy (R11G11B10 -> fp16 is a bit shuffle, fp16 -> fp32 exact: the products below are the
+        // fused multiply-adds v_fma_mix_f32 would do on the shuffled words).  The copy's pitches are 4 x the atlas's.
+#if defined(SAH_EXP_CACHE_SKIP) && (SAH_EXP_CACHE_SKIP == 2 || SAH_EXP_CACHE_SKIP == 4)
+        float ir = ixa.w0, ig = iya.w0, ib = (float)irow0;
+#else
+        const float4* irow = reinterpret_cast<const float4*>(c.irr32 + 4u * irow0);
+        const float4* irow_next = reinterpret_cast<const float4*>(c.irr32 + 4u * (irow0 + c.irradiance.row_pitch));
+        const float4 it[4] = {irow[0], irow[1], irow_next[0], irow_next[1]};
         const float iwt[4] = {ixa.w0 * iya.w0, ixa.w1 * iya.w0, ixa.w0 * iya.w1, ixa.w1 * iya.w1};
         float ir = 0.f, ig = 0.f, ib = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t wrd = iw[k];
-            const uint32_t rg = ((wrd << 4) & 0x7ff0u) | ((wrd << 9) & 0x7ff00000u);  // fp16(R) | fp16(G) << 16
-            const uint32_t bb = (wrd >> 17) & 0x7fe0u;                                // fp16(B)
-            ir = fma_mix_lo(iwt[k], rg, ir);
-            ig = fma_mix_hi(iwt[k], rg, ig);
-            ib = fma_mix_lo(iwt[k], bb, ib);
+            ir = __builtin_fmaf(iwt[k], it[k].x, ir);
+            ig = __builtin_fmaf(iwt[k], it[k].y, ig);
+            ib = __builtin_fmaf(iwt[k], it[k].z, ib);
         }
+#endif
         const H3 pi = {Hn(ir), Hn(ig), Hn(ib)};  // Sampler2DArray<half3>
         irradiance = irradiance + to_f(pi) * probe_weight;
         weight = weight + probe_weight;

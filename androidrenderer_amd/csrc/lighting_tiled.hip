@@ -321,6 +321,26 @@ static hipError_t launch_tiled_gi(const LightingArgs& a, const CsmArgs& csm, con
     }
 }
 
+// R11G11B10 atlas -> float4 per texel.  uf11 / uf10 share fp16's exponent width and bias, so the fp16 value of a channel is its bits
+// shifted into place (sample_cascade_fast), and fp16 -> fp32 is exact: inf and NaN stay what they are.
+__global__ void __launch_bounds__(256) k_probe_irr_unpack(const VolumeArg src, uint8_t* dst) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= src.width) return;
+    const uint32_t off = z * src.slice_pitch + y * src.row_pitch + x * 4u;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(src.ptr + off);
+    float4 t;
+    t.x = (float)__builtin_bit_cast(_Float16, (uint16_t)((w << 4) & 0x7ff0u));
+    t.y = (float)__builtin_bit_cast(_Float16, (uint16_t)((w >> 7) & 0x7ff0u));
+    t.z = (float)__builtin_bit_cast(_Float16, (uint16_t)((w >> 17) & 0x7fe0u));
+    t.w = 0.f;
+    *reinterpret_cast<float4*>(dst + 4u * (size_t)off) = t;
+}
+hipError_t launch_probe_irr_unpack(const VolumeArg& src, uint8_t* dst, hipStream_t st) {
+    if (src.width == 0 || src.height == 0 || src.depth == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probe_irr_unpack, dim3((src.width + 255u) / 256u, src.height, src.depth), dim3(256), 0, st, src, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_lighting_tiled(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                                  const SkyArgs& sky, int sun_mode, int gi, bool brute_force_lights, const FastArgs* fast, hipStream_t st) {
     switch (sun_mode) {

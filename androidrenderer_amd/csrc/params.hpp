@@ -37,6 +37,8 @@ struct CacheArgs {
     float inv_tex[2];  // RN(1 / (32 * (probe_size + 2))): the irradiance atlas extent in texels, for div_const()
     uint32_t debug_mode;
     uint32_t hot_ok;  // atlases < 4 GiB, probe grid <= 64 per axis, probe texel counts <= 30: sample_cascade_fast() applies
+    // hot_ok only: the irradiance atlas widened to float4 per texel (r, g, b, 0), same layout with every pitch x 4 (k_probe_irr_unpack)
+    const uint8_t* irr32;
 };
 
 struct RtgiArgs {

@@ -128,6 +128,7 @@ class LightingInputs:
                         gi.probe_cascades[c].min[i] = cmin[i]
                 gi.probe_size[0], gi.probe_size[1] = 5, 6  # irradiance_cache.cpp:298-299
                 gi.cache_debug_mode = self.cache_debug_mode
+                gi.probe_generation = getattr(self, "probe_generation", 0)  # 0: the library rebuilds its fp32 gather copy on every call
             elif self.gi_kind == _abi.GI_RTGI:
                 gi.ray_buffer = images.plane(arrays["ray_buffer"], _abi.FORMAT_R16G16B16A16_SFLOAT)
                 gi.ray_irradiance = images.plane(arrays["ray_irr"], _abi.FORMAT_R16G16B16A16_SFLOAT)

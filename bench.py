@@ -48,7 +48,8 @@ WORKLOADS = {
     "4k_probe_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True),                     # configs[3]
     "4k_lpv_gi_chain": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", chain=True),
     # configs[3] with nothing synthetic between the mesh and the image: the G-buffer rasterised from the atrium mesh, the AO plane and the sun's
-    # shadow mask traced every step against the structure sah_rt_build made of the same mesh (reference defaults: 1 AO ray of 8 m, 8 shadow rays)
+    # shadow mask traced every step against the structure sah_rt_build made of the same mesh (reference defaults: 1 AO ray of 8 m, 8 shadow rays),
+    # and 1024 probes of the irradiance cache traced (400 GI rays each) and folded into the atlases every step
     "4k_probe_gi_chain_traced": dict(res=(3840, 2160), gbuffer="atrium", sun="rt", gi="cache", chain=True, traced=True),
     "8k_1024_lights_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv", lights=1024, radius=3.0),         # configs[4]
 }
@@ -160,7 +161,7 @@ def main():
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
     ap.add_argument("--ramp-ms", type=float, default=200.0, help="untimed: run the step back to back for this long before the W warm-up steps, so that the "
                     "timed region does not start in the GPU's idle power state (reported in config.clock_ramp_ms)")
-    ap.add_argument("--repack-lpv", action="store_true", help="LPV workloads: lpv_generation = 0, i.e. the library rebuilds its gather copy of the LPV on every "
+    ap.add_argument("--repack-lpv", action="store_true", help="LPV / cache workloads: lpv_generation = probe_generation = 0, i.e. the library rebuilds its gather copy of the LPV on every "
                     "step (5 us + a launch), as it must when the volumes change every frame; default: the volumes of this benchmark never change, so "
                     "their change counter stays at 1 and the copy made by the first step is kept (config.lpv_gather_copy says which)")
     ap.add_argument("--strict-tonemap", action="store_true", help="chain workloads: the strict composite (codes bit-identical to the oracle) instead of "
@@ -222,6 +223,7 @@ def main():
     fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
                               synth_device=str(dev), shadow=wl.get("shadow", "noise"))
     fr.lpv_generation = 0 if args.repack_lpv else 1
+    fr.probe_generation = 0 if args.repack_lpv else 1  # (the traced workload folds probes every step: sah_probe_update drops the copy anyway)
     d_arr = fr.device_arrays(dev)
     bytes_per_pixel = fr.bytes_per_pixel()
 
@@ -310,13 +312,40 @@ def main():
         planes_rt = (images.plane(d_arr["depth"], _abi.FORMAT_D32_SFLOAT), images.plane(d_arr["normals"], _abi.FORMAT_R16G16B16A16_SFLOAT),
                      images.plane(noise_t, _abi.FORMAT_R8G8B8A8_UNORM), images.plane(d_arr["ao"], _abi.FORMAT_R32_SFLOAT),
                      images.plane(d_arr["shadow_mask"], _abi.FORMAT_R32_SFLOAT))
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        # the irradiance cache's own rays: r.GI.Cache.UpdatesPerFrame = 1024 probes x 400 GI rays, folded into the atlases the Lighting
+        # pass samples (irradiance_cache.cpp:21-23, 585-724)
+        import ctypes as C
+        n_probes = 1024
+        cells = synth.rng(33).permutation(32 * 32 * 32)[:n_probes]
+        probe_ids = torch.from_numpy(np.stack([cells % 32, (cells // 32) % 32, cells // 1024], axis=-1).astype(np.int32).reshape(-1)).to(dev)
+        trace_results = torch.zeros((n_probes, 20, 20, 4), dtype=torch.int16, device=dev)
+        light_cache = torch.zeros((32, 416, 416), dtype=torch.int32, device=dev)
+        average = torch.zeros((32, 32, 32), dtype=torch.int32, device=dev)
+        sky_luts = _abi.SkyLuts(images.plane(d_arr["sky_t"], _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(d_arr["sky_v"], _abi.FORMAT_R16G16B16A16_SFLOAT))
+        pt = _abi.ProbeTraceDesc()
+        for c, (cmin, spacing) in enumerate(fr.probe_cascades()):
+            pt.cascades[c].probe_spacing = spacing
+            for i in range(3):
+                pt.cascades[c].min[i] = cmin[i]
+        pt.probes_to_update, pt.num_probes = probe_ids.data_ptr(), n_probes
+        pt.sun, pt.sky, pt.noise = C.pointer(fr.sun.constants), C.pointer(sky_luts), C.pointer(planes_rt[2])
+        pt.probe_irradiance = images.volume(d_arr["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
+        pt.probe_depth = images.volume(d_arr["probe_depth"], _abi.FORMAT_R16G16_SFLOAT)
+        pt.probe_validity = images.volume(d_arr["probe_val"], _abi.FORMAT_R8_UNORM)
+        pt.probe_size[0], pt.probe_size[1] = 5, 6
+        pt.trace_results = images.volume(trace_results, _abi.FORMAT_R16G16B16A16_SFLOAT)
+        atlases = _abi.ProbeAtlases(pt.probe_irradiance, images.volume(light_cache, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_depth,
+                                    images.volume(average, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_validity)
+        rtgi_rb, rtgi_ri = (torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(2))
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
         torch.cuda.synchronize()
         e[0].record()
         rt_stats = ctx.rt_build(geo)
         e[1].record()
 
         def trace_planes():
+            ctx.probe_trace(pt)
+            ctx.probe_update(atlases, pt.trace_results, probe_ids.data_ptr(), n_probes)
             ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
             ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
         trace_planes()  # warm
@@ -326,11 +355,24 @@ def main():
         e[3].record()
         ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
         e[4].record()
+        ctx.probe_trace(pt)
+        e[5].record()
+        ctx.probe_update(atlases, pt.trace_results, probe_ids.data_ptr(), n_probes)
+        e[6].record()
+        # (not part of this workload's frame — the RTGI mode's generator, one GI ray per pixel — timed once for the record)
+        ctx.rtgi_trace(fr.view.gpu_data, fr.sun.constants, sky_luts, planes_rt[0], planes_rt[1], planes_rt[2],
+                       images.plane(rtgi_rb, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(rtgi_ri, _abi.FORMAT_R16G16B16A16_SFLOAT))
+        e[7].record()
         torch.cuda.synchronize()
+        tr_dist = trace_results.view(torch.float16)[..., 3].float()
         traced = {"triangles": rt_stats[0], "levels": rt_stats[2], "rt_build_ms": round(e[0].elapsed_time(e[1]), 4), "rtao_ms": round(e[2].elapsed_time(e[3]), 4),
-                  "sun_shadow_mask_ms": round(e[3].elapsed_time(e[4]), 4),
+                  "sun_shadow_mask_ms": round(e[3].elapsed_time(e[4]), 4), "probe_trace_ms": round(e[4].elapsed_time(e[5]), 4),
+                  "probe_update_ms": round(e[5].elapsed_time(e[6]), 4), "probes_per_frame": n_probes,
+                  "rtgi_trace_ms_not_in_frame": round(e[6].elapsed_time(e[7]), 4),
                   "shadow_samples": float(fr.sun.constants.num_shadow_samples), "ao_unoccluded_fraction": round(float((d_arr["ao"] == 1).float().mean()), 4),
-                  "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4)}
+                  "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4),
+                  "probe_rays_hit_front_back_miss": [round(float((tr_dist > 0).float().mean()), 4), round(float((tr_dist < 0).float().mean()), 4)],
+                  "rtgi_rays_hit_fraction": round(float((rtgi_rb.view(torch.float16)[..., 3].float() != 0).float().mean()), 4)}
 
     tm_flags = 0 if args.strict_tonemap else _abi.TONEMAP_TOLERANCE_1CODE
     pipelined = chain and gather and lib_gather and comm_stream is not None
@@ -562,6 +604,9 @@ def main():
                 "tonemap": None if not chain else ("strict" if args.strict_tonemap else "SAH_TONEMAP_TOLERANCE_1CODE (within one code of the strict composite)"),
                 "lpv_gather_copy": None if gi_kind != _abi.GI_LPV else ("rebuilt every step (lpv_generation 0)" if args.repack_lpv else
                                                                           "kept across steps (lpv_generation 1: the LPV volumes of this benchmark never change)"),
+                "probe_gather_copy": None if gi_kind != _abi.GI_CACHE else (
+                    "rebuilt every step (sah_probe_update writes the atlas every step)" if wl.get("traced") else
+                    "rebuilt every step (probe_generation 0)" if args.repack_lpv else "kept across steps (probe_generation 1: the atlases of this benchmark never change)"),
                 "gbuffer": wl["gbuffer"],
                 "parallelism": par,
                 "gather": bool(gather),

@@ -173,6 +173,12 @@ typedef struct sah_gi {
      * volume descriptors differs from the previous sah_lighting call of this context.  0 = rebuild every call.  sah_lpv_clear,
      * sah_lpv_propagate and sah_lpv_inject_vpls on this context drop the copy regardless. */
     uint32_t lpv_generation;
+    /* Irradiance cache: the same for the irradiance atlas (written by sah_probe_update / sah_probe_copy, or by the caller).  The tiled
+     * Lighting kernel gathers the bilinear taps from an fp32 copy of the R11G11B10 atlas — the widening is exact, so the arithmetic is
+     * the same — that it rebuilds on every call unless this counter is non-zero and, like the atlas descriptor, unchanged since the
+     * previous sah_lighting call of this context.  0 = rebuild every call.  sah_probe_update and sah_probe_copy on this context drop
+     * the copy regardless. */
+    uint32_t probe_generation;
 } sah_gi;
 
 /* Sky LUTs sampled by the sky fill (RenderCore/render/procedural_sky.cpp:13-42,151-172). */

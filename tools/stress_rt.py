@@ -1,4 +1,4 @@
-"""Randomised HIP-vs-oracle sweep of the ray tracer (sah_rt_build + sah_rtao + sah_sun_shadow_mask): triangle soups of varying density,
+"""Randomised HIP-vs-oracle sweep of the ray tracer (sah_rt_build + sah_rtao + sah_sun_shadow_mask + sah_probe_trace + sah_rtgi_trace): triangle soups of varying density,
 scale and cutout share (textured or not), random planes to start the rays from (incl. sky pixels, non-finite normals), random sun
 directions, cone sizes and sample counts.  The oracle tests every triangle against every ray; HIP walks its box hierarchy.
 
@@ -44,10 +44,20 @@ def main():
         mk_h, mk_o = c.hip_mask(ctx), c.oracle_mask()
         d_ao = int((ao_h.view(np.uint32) != ao_o.view(np.uint32)).sum())
         d_mk = int((mk_h.view(np.uint32) != mk_o.view(np.uint32)).sum())
-        bad += bool(d_ao or d_mk)
+        # GI rays: probes spread over the four cascades (scaled to the soup), one GI ray per pixel
+        c.cascade_spacing = float(g.choice([0.25, 0.5, 2.0]))
+        c.cascade_centre = tuple(float(v) for v in g.uniform(-1.0, 1.0, 3))
+        ids = g.integers(0, 32, (int(g.choice([6, 16])), 3)).astype(np.uint32)
+        pt_h, pt_o = c.hip_probe_trace(ctx, ids), c.oracle_probe_trace(ids)
+        (rb_h, ri_h), (rb_o, ri_o) = c.hip_rtgi(ctx), c.oracle_rtgi()
+        d_gi = int((pt_h.view(np.uint16) != pt_o.view(np.uint16)).sum()) + int((rb_h.view(np.uint16) != rb_o.view(np.uint16)).sum()) + \
+            int((ri_h.view(np.uint16) != ri_o.view(np.uint16)).sum())
+        dist = pt_o.astype(np.float32)[..., 3]
+        bad += bool(d_ao or d_mk or d_gi)
         print(f"case {case:3d}: {stats[0]:5d} triangles ({stats[1]} left out), {stats[2]} levels, {W}x{H}, spp {spp}, radius {radius}: "
               f"ao occluded {float((ao_o == 0).mean()):.2f}, mask lit {float(np.nanmean(mk_o)):.2f}: "
-              f"{'ok' if not (d_ao or d_mk) else f'MISMATCH ao {d_ao} mask {d_mk}'}", flush=True)
+              f"probe rays front {float((dist > 0).mean()):.2f} back {float((dist < 0).mean()):.2f}: "
+              f"{'ok' if not (d_ao or d_mk or d_gi) else f'MISMATCH ao {d_ao} mask {d_mk} gi {d_gi}'}", flush=True)
     print(f"{args.cases} cases, {bad} with mismatches")
     return 1 if bad else 0
 
