@@ -84,7 +84,8 @@ int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats)
             uint32_t padded = kRtSortChunk;
             while (padded < total) padded <<= 1;
             if (int rc = ensure(ctx, R_UNSORTED, (size_t)total * sizeof(RtTriangle)); rc != SAH_OK) return rc;
-            if (int rc = ensure(ctx, R_SORTED, (size_t)total * sizeof(RtTriangle)); rc != SAH_OK) return rc;
+            // (+ kRtFanout spare entries behind the triangles and the nodes: the walk loads groups of four without a predicate)
+            if (int rc = ensure(ctx, R_SORTED, (size_t)(total + kRtFanout) * sizeof(RtTriangle)); rc != SAH_OK) return rc;
             if (int rc = ensure(ctx, R_KEYS, (size_t)padded * sizeof(unsigned long long)); rc != SAH_OK) return rc;
             HIP_TRY(ctx, launch_rt_world(sc, (const uint32_t*)rt.ptr[R_TRI_BASE], total, (RtTriangle*)rt.ptr[R_UNSORTED], st, ctx->stream));
             HIP_TRY(ctx, launch_rt_sort((const RtTriangle*)rt.ptr[R_UNSORTED], st, (unsigned long long*)rt.ptr[R_KEYS], padded, ctx->stream));
@@ -94,7 +95,7 @@ int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats)
             float S;
             memcpy(&S, &host.max_abs_bits, 4);
             bvh.pad = S * 0x1p-16f;
-            uint32_t count = (bvh.num_tris + kRtFanout - 1) / kRtFanout, offset = 0, levels = 0;
+            uint32_t count = bvh.num_tris, offset = 0, levels = 0;  // level 0: one box per triangle
             while (bvh.num_tris) {
                 bvh.level_offset[levels] = offset;
                 bvh.level_count[levels] = count;
@@ -105,7 +106,7 @@ int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats)
             }
             bvh.num_levels = levels;
             if (bvh.num_tris) {
-                if (int rc = ensure(ctx, R_NODES, (size_t)offset * sizeof(RtNode)); rc != SAH_OK) return rc;
+                if (int rc = ensure(ctx, R_NODES, (size_t)(offset + kRtFanout) * sizeof(RtNode)); rc != SAH_OK) return rc;
                 bvh.tris = (const RtTriangle*)rt.ptr[R_SORTED];
                 bvh.nodes = (const RtNode*)rt.ptr[R_NODES];
                 HIP_TRY(ctx, launch_rt_nodes((const RtTriangle*)rt.ptr[R_UNSORTED], (const unsigned long long*)rt.ptr[R_KEYS], (RtTriangle*)rt.ptr[R_SORTED],

@@ -227,25 +227,17 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
     }
 }
 
-// one thread per level-0 node: gathers its (up to) four triangles into Morton order and writes the union of their padded boxes
+// one thread per triangle: moves it into Morton order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
+// meets a triangle's own box (part of the hit definition, sah_hip.h) like any other box
 __global__ __launch_bounds__(256) void k_rt_leaves(const RtTriangle* unsorted, const unsigned long long* keys, uint32_t num_tris, float pad,
-                                                   RtTriangle* sorted, RtNode* nodes, uint32_t num_nodes) {
-    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
-    if (n >= num_nodes) return;
-    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (uint32_t k = 0; k < kRtFanout; k++) {
-        const uint32_t i = n * kRtFanout + k;
-        if (i >= num_tris) break;
-        const RtTriangle r = unsorted[(uint32_t)keys[i]];
-        sorted[i] = r;
-        float l[3], h[3];
-        tri_box(r, pad, l, h);
-        for (int c = 0; c < 3; c++) {
-            lo[c] = __builtin_fminf(lo[c], l[c]);
-            hi[c] = __builtin_fmaxf(hi[c], h[c]);
-        }
-    }
-    nodes[n] = RtNode{{lo[0], lo[1], lo[2]}, hi[0], hi[1], hi[2], 0.f, 0.f};
+                                                   RtTriangle* sorted, RtNode* nodes) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= num_tris) return;
+    const RtTriangle r = unsorted[(uint32_t)(keys[i] & 0xffffffffull)];
+    sorted[i] = r;
+    float lo[3], hi[3];
+    tri_box(r, pad, lo, hi);
+    nodes[i] = RtNode{{lo[0], lo[1], lo[2]}, hi[0], hi[1], hi[2], 0.f, 0.f};
 }
 __global__ __launch_bounds__(256) void k_rt_level(const RtNode* children, uint32_t num_children, RtNode* nodes, uint32_t num_nodes) {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x;
@@ -370,40 +362,91 @@ SAH_DEV bool cutout_accepts(const RtScene& sc, const RtTriangle& tr, const Hit& 
     return !(alpha <= m.opacity_threshold);
 }
 
-// "is there an accepted candidate" (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH); CULL_NON_OPAQUE: CUTOUT primitives do not exist for this ray
+// ---- walking the hierarchy ---------------------------------------------------------------------------------------------------------
+// The hierarchy is implicit and complete (node n of level L covers nodes 4n .. 4n + 3 of level L - 1; level 0 nodes cover four triangles),
+// so a depth-first walk needs no stack in memory: the position is (level, node), and what is left to visit on the way back up is four
+// bits per level — the children of the path's node at that level that the ray's slab test passed and that have not been entered yet.
+// Per-level offsets and counts sit in LDS because the level is a per-lane value.
+struct Trav {
+    const uint32_t* off;
+    const uint32_t* cnt;
+};
+SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* 2 * kRtMaxLevels words of LDS; every thread of the workgroup calls this */) {
+#pragma unroll
+    for (uint32_t l = 0; l < kRtMaxLevels; l++)
+        if (threadIdx.x == l) {
+            smem[l] = bvh.level_offset[l];
+            smem[kRtMaxLevels + l] = bvh.level_count[l];
+        }
+    __syncthreads();
+    return {smem, smem + kRtMaxLevels};
+}
+// bit k: child 4 * node + k of (level, node) exists and the ray's slab test passes its box.  The four boxes are 128 contiguous bytes
+// (the node array ends in four spare entries, so the loads need no predicate)
+SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, uint32_t level, uint32_t node) {
+    const uint32_t first = node * kRtFanout, cnt = tv.cnt[level - 1u];
+    const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + first);
+    float4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = p[k];
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kRtFanout; k++) {
+        const float lo[3] = {q[2 * k].x, q[2 * k].y, q[2 * k].z}, hi[3] = {q[2 * k].w, q[2 * k + 1].x, q[2 * k + 1].y};
+        if (first + k < cnt && slab(r, lo, hi)) m |= 1u << k;
+    }
+    return m;
+}
+SAH_DEV RtTriangle load_triangle(const RtTriangle* tris, uint32_t i) {  // three 16-byte loads
+    const float4* p = reinterpret_cast<const float4*>(tris + i);
+    const float4 a = p[0], b = p[1], c = p[2];
+    RtTriangle t;
+    t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.primitive = __builtin_bit_cast(uint32_t, a.w);
+    t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z; t.triangle = __builtin_bit_cast(uint32_t, b.w);
+    t.v2[0] = c.x; t.v2[1] = c.y; t.v2[2] = c.z; t.flags = __builtin_bit_cast(uint32_t, c.w);
+    return t;
+}
+// next position of the walk after (level, node) left `m` of its children to visit; false when the walk is over
+template <bool DESCENDING = true>
+SAH_DEV bool trav_next(uint32_t top, uint32_t& level, uint32_t& node, unsigned long long& pending, uint32_t m) {
+    while (m == 0u) {
+        if (level == top) return false;
+        level++;
+        node >>= 2;
+        m = (uint32_t)(pending >> (4u * level)) & 15u;
+    }
+    const uint32_t k = DESCENDING ? 31u - (uint32_t)__builtin_clz(m) : (uint32_t)__builtin_ctz(m);
+    m &= ~(1u << k);
+    pending = (pending & ~(15ull << (4u * level))) | ((unsigned long long)m << (4u * level));
+    node = node * kRtFanout + k;
+    level--;
+    return true;
+}
+
+// "is there an accepted candidate" (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH); CULL_NON_OPAQUE: CUTOUT primitives do not exist for this ray.
+// Two nested loops: every lane walks boxes until it stands on a triangle whose padded box the ray passes (or is done), then the lanes
+// that have one test it together.
 template <bool CULL_NON_OPAQUE, bool CULL_FRONT = false>
-SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Ray& r) {
+SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const Ray& r) {
     if (!r.finite || bvh.num_tris == 0) return false;
-    uint32_t stack[3 * kRtMaxLevels + 4];
-    int sp = 0;
-    stack[sp++] = ((bvh.num_levels - 1u) << 28);  // the top level's single node
-    while (sp > 0) {
-        const uint32_t e = stack[--sp];
-        const uint32_t level = e >> 28, node = e & 0x0fffffffu;
-        if (level == 0) {
-            for (uint32_t k = 0; k < kRtFanout; k++) {
-                const uint32_t i = node * kRtFanout + k;
-                if (i >= bvh.num_tris) break;
-                const RtTriangle tr = bvh.tris[i];
-                if (CULL_NON_OPAQUE && (tr.flags & 1u)) continue;
-                float lo[3], hi[3];
-                tri_box(tr, bvh.pad, lo, hi);
-                if (!slab(r, lo, hi)) continue;
+    const uint32_t top = bvh.num_levels - 1u;
+    uint32_t level = top, node = 0;  // the top level's single node
+    unsigned long long pending = 0;
+    bool alive = true;
+    if (top == 0) {  // a single triangle: its box is the top node, which nothing has tested
+        const RtNode n = bvh.nodes[0];
+        const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
+        alive = slab(r, lo, hi);
+    }
+    while (alive) {
+        while (alive && level != 0) alive = trav_next(top, level, node, pending, children_hit(bvh, tv, r, level, node));
+        if (alive) {
+            const RtTriangle tr = load_triangle(bvh.tris, node);
+            if (!(CULL_NON_OPAQUE && (tr.flags & 1u))) {
                 Hit h;
-                if (!woop(r, tr, h)) continue;
-                if (CULL_FRONT && h.front) continue;
-                if (!(tr.flags & 1u) || cutout_accepts(sc, tr, h)) return true;
+                if (woop(r, tr, h) && !(CULL_FRONT && h.front) && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h))) return true;
             }
-        } else {
-            const uint32_t count = bvh.level_count[level - 1u];
-            const RtNode* ch = bvh.nodes + bvh.level_offset[level - 1u];
-            for (uint32_t k = 0; k < kRtFanout; k++) {
-                const uint32_t i = node * kRtFanout + k;
-                if (i >= count) break;
-                const RtNode n = ch[i];
-                const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
-                if (slab(r, lo, hi)) stack[sp++] = ((level - 1u) << 28) | i;
-            }
+            alive = trav_next(top, level, node, pending, 0u);
         }
     }
     return false;
@@ -442,57 +485,45 @@ struct Closest {
     Hit h;
     uint32_t tri;  // index into bvh.tris
 };
-SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, Ray r) {
+SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, Ray r) {
     Closest best;
     best.hit = false;
     best.tri = 0;
     best.h = {0.f, 0.f, 0.f, false};
     if (!r.finite || bvh.num_tris == 0) return best;
     uint32_t best_prim = 0xffffffffu, best_tri = 0xffffffffu;
-    // boxes of NODES are culled against the best t so far (inclusive: ties are still visited); a triangle's own box and its test keep the ray's tmax
-    float limit = r.tmax;
+    // boxes are culled against the best t so far (a hair beyond it: the entry into a padded box of a candidate at t <= limit is computed
+    // with its own rounding, and visiting a box too many changes nothing); the triangle test keeps the ray's own tmax
     const float tmax0 = r.tmax;
-    uint32_t stack[3 * kRtMaxLevels + 4];
-    int sp = 0;
-    stack[sp++] = ((bvh.num_levels - 1u) << 28);
-    while (sp > 0) {
-        const uint32_t e = stack[--sp];
-        const uint32_t level = e >> 28, node = e & 0x0fffffffu;
-        if (level == 0) {
-            r.tmax = tmax0;
-            for (uint32_t k = 0; k < kRtFanout; k++) {
-                const uint32_t i = node * kRtFanout + k;
-                if (i >= bvh.num_tris) break;
-                const RtTriangle tr = bvh.tris[i];
-                float lo[3], hi[3];
-                tri_box(tr, bvh.pad, lo, hi);
-                if (!slab(r, lo, hi)) continue;
-                Hit h;
-                if (!woop(r, tr, h)) continue;
+    const uint32_t top = bvh.num_levels - 1u;
+    uint32_t level = top, node = 0;
+    unsigned long long pending = 0;
+    bool alive = true;
+    if (top == 0) {
+        const RtNode n = bvh.nodes[0];
+        const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
+        alive = slab(r, lo, hi);
+    }
+    while (alive) {
+        while (alive && level != 0) alive = trav_next(top, level, node, pending, children_hit(bvh, tv, r, level, node));
+        if (alive) {
+            const RtTriangle tr = load_triangle(bvh.tris, node);
+            Ray full = r;
+            full.tmax = tmax0;
+            Hit h;
+            if (woop(full, tr, h)) {
                 const bool better = !best.hit || h.t < best.h.t ||
                                     (h.t == best.h.t && (tr.primitive < best_prim || (tr.primitive == best_prim && tr.triangle < best_tri)));
-                if (!better) continue;
-                if ((tr.flags & 1u) && !cutout_accepts(sc, tr, h)) continue;
-                best.hit = true;
-                best.h = h;
-                best.tri = i;
-                best_prim = tr.primitive;
-                best_tri = tr.triangle;
-                limit = h.t;
+                if (better && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h))) {
+                    best.hit = true;
+                    best.h = h;
+                    best.tri = node;
+                    best_prim = tr.primitive;
+                    best_tri = tr.triangle;
+                    r.tmax = h.t * 1.000244140625f;
+                }
             }
-        } else {
-            // a hair beyond the best t: the entry into a padded box of a candidate at t <= limit is computed with its own rounding, and
-            // visiting a node too many changes nothing
-            r.tmax = limit * 1.000244140625f;
-            const uint32_t count = bvh.level_count[level - 1u];
-            const RtNode* ch = bvh.nodes + bvh.level_offset[level - 1u];
-            for (uint32_t k = 0; k < kRtFanout; k++) {
-                const uint32_t i = node * kRtFanout + k;
-                if (i >= count) break;
-                const RtNode n = ch[i];
-                const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
-                if (slab(r, lo, hi)) stack[sp++] = ((level - 1u) << 28) | i;
-            }
+            alive = trav_next(top, level, node, pending, 0u);
         }
     }
     return best;
@@ -508,11 +539,11 @@ struct GiPayload {
 
 // TraceRay(rtas, RAY_FLAG_NONE, 0xFF, RAY_TYPE_GI, ...) with remaining_bounces == 0: closest-hit stage of gltf_basic_pbr.slang:345-470 or the
 // GI miss stage of sky_unified.slang:227-230.  (dx, dy) = DispatchRaysIndex().xy
-SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const GiArgs& g, const Ray& r, uint32_t dx, uint32_t dy) {
+SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const GiArgs& g, const Ray& r, uint32_t dx, uint32_t dy) {
     GiPayload pay;
     pay.irradiance = F3(Fn(0.f));
     pay.ray_distance = Fn(0.f);
-    const Closest c = closest_hit(bvh, sc, r);
+    const Closest c = closest_hit(bvh, sc, tv, r);
     if (!c.hit) {
         // (a ray with a non-finite component reaches no stage at all: the payload stays zero)
         if (r.finite) pay.irradiance = sky_color(g.sky, F3{Fn(r.d[0]), Fn(r.d[1]), Fn(r.d[2])});
@@ -573,7 +604,7 @@ SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const GiArgs& g,
         const F3 dir = normalize(to_f(Lh) + noise * Fn(g.tan_size));
         const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
         const Ray sr = make_ray(loc, d, 0.05f, 100000.0f);
-        if (!any_hit<true, true>(bvh, sc, sr)) shadow = Hn::lit(1.f);
+        if (!any_hit<true, true>(bvh, sc, tv, sr)) shadow = Hn::lit(1.f);
     }
     // payload.irradiance = brdf_result * sun_light.color.rgb * ndotl * shadow (half3 * float3 -> float3, then * half, * half); += emission
     const F3 sun = {Fn(g.sun_color[0]), Fn(g.sun_color[1]), Fn(g.sun_color[2])};
@@ -590,6 +621,8 @@ SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const GiArgs& g,
 
 // probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes})
 __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, const RtBvh bvh, const RtScene sc) {
+    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    const Trav tv = trav_init(bvh, s_levels);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= 400u * a.num_probes) return;
     const uint32_t probe = t / 400u, tx = (t % 400u) % 20u, ty = (t % 400u) / 20u;
@@ -606,7 +639,7 @@ __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, con
         if (cascade < 3u) ray_distance = Fn(c.spacing[cascade + 1u]) * Fn(4.f);
         const float o[3] = {origin.x.v, origin.y.v, origin.z.v}, d[3] = {dir.x.v, dir.y.v, dir.z.v};
         const Ray r = make_ray(o, d, 0.05f, ray_distance.v);
-        GiPayload pay = trace_gi(bvh, sc, a.gi, r, tx, ty);
+        GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, tx, ty);
         if (pay.ray_distance.v == 0.f) {
             if (cascade + 1u < 4u) pay.irradiance = sample_cascade(c, origin + dir * ray_distance, dir, cascade + 1u);
             else pay.irradiance = pay.irradiance * Fn(10.f);
@@ -627,7 +660,10 @@ __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, con
 
 // rtgi.rt.slang:56-110
 __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const RtBvh bvh, const RtScene sc) {
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u), y = blockIdx.y * 16u + (threadIdx.x >> 4);
+    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    const Trav tv = trav_init(bvh, s_levels);
+    // a wave is an 8 x 8 pixel square (rays of a wave start close together and walk the same boxes for longer), a workgroup 16 x 16
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u), y = blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
     if (x >= a.width || y >= a.height) return;
     if (!((float)x < a.res[0] && (float)y < a.res[1])) return;  // any(thread_id >= render_resolution): uint against float
     const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
@@ -641,7 +677,7 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
     if (dot(to_f(normal), dir).v < 0.f) dir = dir * Fn(-1.0f);
     const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
     const Ray r = make_ray(o, d, 0.01f, 100000.0f);
-    GiPayload pay = trace_gi(bvh, sc, a.gi, r, x, y);
+    GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, x, y);
     if (any_nan(pay.irradiance)) pay.irradiance = F3(Fn(0.f));
     const Fn e = Fn(0.0031415927f);
     auto store = [](const PlaneArg& p, uint32_t px, uint32_t py, float c0, float c1, float c2, float c3) {
@@ -655,7 +691,10 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
 }
 
 __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh, const RtScene sc) {
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u), y = blockIdx.y * 16u + (threadIdx.x >> 4);
+    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    const Trav tv = trav_init(bvh, s_levels);
+    // a wave is an 8 x 8 pixel square (rays of a wave start close together and walk the same boxes for longer), a workgroup 16 x 16
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u), y = blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
     if (x >= a.width || y >= a.height) return;
     const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
     float o[3];
@@ -665,7 +704,7 @@ __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh,
     if (dot(noise, to_f(normal)).v < 0.0f) noise = noise * Fn(-1.0f);
     const float d[3] = {noise.x.v, noise.y.v, noise.z.v};
     const Ray r = make_ray(o, d, 0.01f, a.max_distance);
-    const bool hit = any_hit<true>(bvh, sc, r);
+    const bool hit = any_hit<true>(bvh, sc, tv, r);
     // every one of the spp rays is this ray (the shader reads the same noise texel for each): ao = spp - spp or spp, exact for spp <= 4096
     const float spp = (float)a.samples;
     const float ao = (hit ? spp - spp : spp) / spp;
@@ -673,7 +712,10 @@ __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh,
 }
 
 __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a, const RtBvh bvh, const RtScene sc) {
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u), y = blockIdx.y * 16u + (threadIdx.x >> 4);
+    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    const Trav tv = trav_init(bvh, s_levels);
+    // a wave is an 8 x 8 pixel square (rays of a wave start close together and walk the same boxes for longer), a workgroup 16 x 16
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u), y = blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
     if (x >= a.width || y >= a.height) return;
     float* dst = reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)y * a.out.pitch + (size_t)x * 4);
     const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
@@ -698,7 +740,7 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
         const F3 dir = normalize(L + noise * Fn(a.tan_size));
         const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
         const Ray r = make_ray(o, d, 0.01f, 100000.0f);
-        shadow = shadow + Fn(any_hit<false>(bvh, sc, r) ? 0.0f : 1.0f);
+        shadow = shadow + Fn(any_hit<false>(bvh, sc, tv, r) ? 0.0f : 1.0f);
     }
     *dst = (shadow / Fn(a.num_samples)).v;
 }
@@ -729,8 +771,7 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
 }
 hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNode* nodes, const RtBvh& bvh, hipStream_t s) {
     if (bvh.num_tris == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rt_leaves, dim3((bvh.level_count[0] + 255u) / 256u), dim3(256), 0, s, unsorted, keys, bvh.num_tris, bvh.pad, sorted, nodes,
-                       bvh.level_count[0]);
+    hipLaunchKernelGGL(k_rt_leaves, dim3((bvh.num_tris + 255u) / 256u), dim3(256), 0, s, unsorted, keys, bvh.num_tris, bvh.pad, sorted, nodes);
     for (uint32_t l = 1; l < bvh.num_levels; l++)
         hipLaunchKernelGGL(k_rt_level, dim3((bvh.level_count[l] + 255u) / 256u), dim3(256), 0, s, nodes + bvh.level_offset[l - 1], bvh.level_count[l - 1],
                            nodes + bvh.level_offset[l], bvh.level_count[l]);

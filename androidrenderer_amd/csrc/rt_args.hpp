@@ -10,8 +10,8 @@
 namespace sah {
 
 constexpr uint32_t kRtFanout = 4;       // children per node, triangles per leaf node
-constexpr uint32_t kRtMaxLevels = 14;   // 4^14 leaves' worth: more than kRtMaxTriangles needs
-constexpr uint32_t kRtMaxTriangles = 1u << 26;  // stack entries carry (level << 28 | index)
+constexpr uint32_t kRtMaxLevels = 15;   // level 0 = one box per triangle, then 4^13 >= kRtMaxTriangles; the walk keeps 4 bits per level in 64
+constexpr uint32_t kRtMaxTriangles = 1u << 26;
 constexpr uint32_t kRtSortChunk = 2048; // keys one workgroup sorts in LDS
 
 // One world-space triangle, as the traversal reads it: three 16-byte words
@@ -47,7 +47,8 @@ struct RtScene {  // device pointers of the sah_scene_geometry given to sah_rt_b
 
 struct RtBvh {
     const RtTriangle* tris;  // Morton order
-    const RtNode* nodes;     // level 0 first: level L starts at level_offset[L] and has level_count[L] nodes; the top level has one
+    const RtNode* nodes;     // level 0 first (one padded box per triangle, same index): level L starts at level_offset[L] and has level_count[L]
+                             // nodes, node n covering nodes 4n .. 4n + 3 of level L - 1; the top level has one
     uint32_t num_tris, num_levels;
     uint32_t level_offset[kRtMaxLevels], level_count[kRtMaxLevels];
     float pad;  // S * 2^-16 (sah_hip.h "pad")

@@ -9,7 +9,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         if flt in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
