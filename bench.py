@@ -95,9 +95,13 @@ SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
 def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope, algorithmic_bytes, my_px, kernel):
     """The metric's roofline is HBM (BASELINE.json: "achieved HBM GB/s vs roofline"): achieved / peak / frac are that one, measured
     live.  `bound` names the roofline that actually binds the workload, and the other two are carried beside it:
-      valu_issue  VALU issue cycles of one launch (SQ_ACTIVE_INST_VALU x 4, summed over the SIMDs) / (1024 SIMDs x 2.4 GHz x the
-                  LIVE kernel time) — the counter is from a separate rocprofv3 --pmc pass of the same build and workload
-                  (profiles/roofline_static.json says which file), because PMC counters cannot be read from inside a run;
+      valu_issue  VALU issue cycles of one launch / (1024 SIMDs x 2.4 GHz x the LIVE kernel time).  The cycles are a MODEL: the measured
+                  SQ_INSTS_VALU of a separate rocprofv3 --pmc pass of the same build and workload (profiles/roofline_static.json says
+                  which file; PMC counters cannot be read from inside a run) x the cycles per instruction of the kernel's static VALU
+                  mix priced with the measured issue costs (tools/pmc_to_static.py, profiles/r1_valu_issue_cost.txt).  Beside it:
+                  `valu_busy_rocprof`, rocprof's VALUBusy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles) — it charges every instruction a whole
+                  quad-cycle, so it overstates kernels made of 2-cycle fp32 ops and can exceed 1 — and `lower_bound`, every
+                  instruction at the cheapest cost (2.3 cycles);
       fp32        algorithmic FLOP per pixel (counted once from the per-pixel operator list) x pixels / LIVE kernel time
                   against the 157.3 TFLOP/s vector peak.
     `traffic` is the measured HBM traffic per launch of that same static pass (FETCH_SIZE doubled per the guide's gfx950 correction +
@@ -127,12 +131,16 @@ def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope
     if st.get("hbm_traffic_bytes_per_launch"):
         out["traffic"] = int(st["hbm_traffic_bytes_per_launch"] * share)
         out["traffic_source"] = f"{st['source']} (static: separate --pmc passes of this build, not this run)"
-    if st.get("valu_active_cycles_per_launch"):
-        f = st["valu_active_cycles_per_launch"] * share / (SIMDS * MAX_CLOCK_HZ * t)
+    if st.get("valu_wave_insts_per_launch"):
+        simd_cycles = SIMDS * MAX_CLOCK_HZ * t
+        insts = st["valu_wave_insts_per_launch"] * share
+        busy = st.get("valu_active_cycles_per_launch", 0.0) * share / simd_cycles
+        lower = insts * 2.3 / simd_cycles
+        f = st["valu_model_issue_cycles_per_launch"] * share / simd_cycles if st.get("valu_model_issue_cycles_per_launch") else busy
         fracs["valu"] = f
-        out["valu_issue"] = {"frac": round(f, 4), "insts_per_px": round(st["valu_wave_insts_per_launch"] * 64 / st["pixels"], 1),
-                             "active_cycles_per_launch": int(st["valu_active_cycles_per_launch"] * share), "peak": "1024 SIMDs x 2.4 GHz",
-                             "source": f"{st['source']} (static)"}
+        out["valu_issue"] = {"frac": round(f, 4), "model_cycles_per_inst": st.get("valu_model_cycles_per_inst"), "valu_busy_rocprof": round(busy, 4),
+                             "lower_bound": round(lower, 4), "insts_per_px": round(st["valu_wave_insts_per_launch"] * 64 / st["pixels"], 1),
+                             "peak": "1024 SIMDs x 2.4 GHz", "source": f"{st['source']} (static) + static ISA mix x profiles/r1_valu_issue_cost.txt"}
     if st.get("flops_per_px"):
         tf = st["flops_per_px"] * my_px / t / 1e12
         out["fp32"] = {"achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 4),
