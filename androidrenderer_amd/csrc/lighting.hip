@@ -209,7 +209,10 @@ template <int SUN, int GI, int PPT, bool RELAXED, bool SKY>
 // slower, measured.)
 // (With the sky path in the kernel the allocator would take 137 VGPRs = 3 waves per SIMD for every wave; the bound keeps the surface
 // path's 4 — the sky path, 4 % of the frame, spills the difference.)
-__global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
+#ifndef SAH_EXP_FAST_WAVES
+#define SAH_EXP_FAST_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, (SKY && PPT == 4) ? SAH_EXP_FAST_WAVES : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
                                                                                  const FastArgs f) {
     // Sky.  ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206): those pixels need their
     // coordinates and two fp64 transcendentals each, nothing of the surface code.  With a sky bound, one workgroup in kSkyRatio + 1

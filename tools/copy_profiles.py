@@ -11,6 +11,8 @@ shutil.copy(f"{SRC}/bench.json", f"{DST}/{R}_bench_4k_deferred_gi.json")
 shutil.copy(f"{SRC}/ktrace/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_deferred_gi.csv")
 shutil.copy(f"{SRC}/pmc.txt", f"{DST}/{R}_pmc_4k_deferred_gi.txt")
 shutil.copy(f"{SRC}/passes.txt", f"{DST}/{R}_passes_4k.txt")
+if os.path.exists(f"{SRC}/roofline_static.json"):
+    shutil.copy(f"{SRC}/roofline_static.json", f"{DST}/roofline_static.json")
 for src, dst in (("pmc_rt_cache_tiled.txt", "pmc_rt_cache_tiled.txt"), ("pmc_tonemap.txt", "pmc_tonemap.txt"), ("cpu_baselines.txt", "cpu_baselines.txt"),
                  ("rehearse_n2.json", "rehearse_n2_one_gpu.json"), ("strict_chain.json", "bench_4k_probe_gi_chain_strict_tonemap.json"),
                  ("repack.json", "bench_4k_deferred_gi_repack_lpv.json")):
@@ -33,3 +35,10 @@ with open(path, "w") as out:
     for k in old:
         out.write(old[k] + "\n")
 print("copied; workloads:", list(old))
+# second half (tools/refresh_extras.sh)
+X = "gpurun_out/refresh_extras"
+for src, dst in (("pmc_rt.txt", "pmc_rt_kernels.txt"), ("ktrace_traced/kt_kernel_stats.csv", "kernel_stats_4k_probe_gi_chain_traced.csv"),
+                 ("stress_rt.txt", "stress_rt.txt"), ("stress_parity.txt", "stress_parity.txt"), ("stress_post.txt", "stress_post.txt"),
+                 ("stress_raster.txt", "stress_raster.txt")):
+    if os.path.exists(f"{X}/{src}"):
+        shutil.copy(f"{X}/{src}", f"{DST}/{R}_{dst}")

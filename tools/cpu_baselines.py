@@ -56,12 +56,16 @@ def main():
             t = time.perf_counter()
             assert o.orc_lighting(C.byref(d)) == 0
             return time.perf_counter() - t
+        # band sizing: a short band is all thread start-up (256 threads), so grow the band until one repetition takes seconds / 3 or it is the frame
         mid = H // 2
         timed(mid, mid + 8)
-        dt = max(timed(mid, mid + 16), 1e-4)
-        rows = int(max(16, min(H, 16 * (args.seconds / 3) / dt)))
-        r0 = max(0, mid - rows // 2)
-        r1 = min(H, r0 + rows)
+        rows = 64
+        while True:
+            r0 = max(0, mid - rows // 2)
+            r1 = min(H, r0 + rows)
+            if timed(r0, r1) >= args.seconds / 3 or r1 - r0 >= H:
+                break
+            rows *= 2
         ts = sorted(timed(r0, r1) for _ in range(3))
         print(f"  {name:72s} {'lighting':22s} {r1 - r0:6d} {ts[1]:8.3f} {W * (r1 - r0) / ts[1] / 1e6:10.3f}", flush=True)
         if chain:

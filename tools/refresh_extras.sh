@@ -1,0 +1,14 @@
+#!/bin/bash
+# Second half of the evidence refresh (tools/refresh_profiles.sh is the first): PMC of the ray-tracing kernels and the randomised
+# HIP-vs-oracle sweeps.  Output under gpurun_out/refresh_extras/, copied into profiles/ by tools/copy_profiles.py.
+set -u
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+O=gpurun_out/refresh_extras
+rm -rf $O; mkdir -p $O
+PMC_ARGS="--no-cpu-baseline --steps 2 --warmup 1 --ramp-ms 0 --workload 4k_probe_gi_chain_traced" PMC_KERNEL=k_rtao bash tools/pmc_collect.sh $O/pmc_rt > $O/pmc_rt.txt 2>&1 && echo "pmc rt ok"
+for k in k_sun_shadow_mask k_probe_trace k_rtgi_trace; do python3 tools/pmc_summary.py $O/pmc_rt $k >> $O/pmc_rt.txt; done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace_traced -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --workload 4k_probe_gi_chain_traced --steps 10 --warmup 3 > $O/ktrace_traced.log 2>&1 && echo "ktrace traced ok"
+timeout -k 10 400 python3 tools/stress_rt.py --cases 40 > $O/stress_rt.txt 2>&1 && echo "stress rt ok"
+timeout -k 10 400 python3 tools/stress_parity.py --seeds 12 > $O/stress_parity.txt 2>&1 && echo "stress parity ok"
+timeout -k 10 400 python3 tools/stress_post.py > $O/stress_post.txt 2>&1 && echo "stress post ok"
+timeout -k 10 400 python3 tools/stress_raster.py > $O/stress_raster.txt 2>&1 && echo "stress raster ok"

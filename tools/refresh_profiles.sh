@@ -6,10 +6,13 @@ set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/refresh
 rm -rf $O; mkdir -p $O
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err && echo "bench ok"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/ktrace.log 2>&1 && echo "ktrace ok"
 bash tools/pmc_collect.sh $O/pmc > $O/pmc.txt 2>&1 && echo "pmc ok"
 PMC_ARGS="--no-cpu-baseline --steps 5 --warmup 1 --workload 4k_probe_gi_chain" PMC_KERNEL=k_lighting_tiled bash tools/pmc_collect.sh $O/pmc_tiled > $O/pmc_rt_cache_tiled.txt 2>&1 && echo "pmc tiled ok"
+# the static half of bench.py's roofline object comes from THESE passes: fold them into profiles/roofline_static.json before any bench line is printed
+cp $O/pmc.txt profiles/r3_pmc_4k_deferred_gi.txt; cp $O/pmc_rt_cache_tiled.txt profiles/r3_pmc_rt_cache_tiled.txt
+python3 tools/pmc_to_static.py 4k_deferred_gi profiles/r3_pmc_4k_deferred_gi.txt k_lighting_fast 3840 2160 450 > $O/static.log 2>&1 && python3 tools/pmc_to_static.py 4k_probe_gi_chain profiles/r3_pmc_rt_cache_tiled.txt k_lighting_tiled 3840 2160 >> $O/static.log 2>&1 && python3 tools/pmc_to_static.py 4k_probe_gi_chain_traced profiles/r3_pmc_rt_cache_tiled.txt k_lighting_tiled 3840 2160 >> $O/static.log 2>&1 && cp profiles/roofline_static.json $O/roofline_static.json && echo "static ok"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err && echo "bench ok"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/ktrace.log 2>&1 && echo "ktrace ok"
 PMC_SCRIPT=tools/bench_passes.py PMC_ARGS="--only tonemap --iters 5" PMC_KERNEL=k_tonemap bash tools/pmc_collect.sh $O/pmc_tm > $O/pmc_tonemap.txt 2>&1 && echo "pmc tonemap ok"
 python3 tools/bench_passes.py > $O/passes.txt 2>&1 && echo "passes ok"
 for w in 1080p_64_lights 4k_256_lights 4k_probe_gi_chain 4k_lpv_gi_chain 4k_probe_gi_chain_traced 4k_deferred_gi_random 4k_deferred_gi_produced 8k_deferred_gi 8k_1024_lights_gi; do python3 bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2>> $O/bench.err && echo "$w ok"; done
