@@ -285,7 +285,7 @@ SAH_DEV Ray make_ray(const float o[3], const float d[3], float tmin, float tmax)
     r.Sz = 1.0f / dz;
     return r;
 }
-SAH_DEV bool slab(const Ray& r, const float lo[3], const float hi[3]) {
+SAH_DEV bool slab(const Ray& r, const float lo[3], const float hi[3], float* entry = nullptr) {
     float tn = r.tmin, tf = r.tmax;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -293,6 +293,7 @@ SAH_DEV bool slab(const Ray& r, const float lo[3], const float hi[3]) {
         tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1));
         tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
     }
+    if (entry) *entry = tn;
     return tn <= tf;
 }
 struct Hit {
@@ -383,18 +384,27 @@ SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* 2 * kRtMaxLevels word
 }
 // bit k: child 4 * node + k of (level, node) exists and the ray's slab test passes its box.  The four boxes are 128 contiguous bytes
 // (the node array ends in four spare entries, so the loads need no predicate)
-SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, uint32_t level, uint32_t node) {
+// `nearest` (optional): among the passing children, the one the ray enters first (the largest index among equals)
+SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, uint32_t level, uint32_t node, uint32_t* nearest = nullptr) {
     const uint32_t first = node * kRtFanout, cnt = tv.cnt[level - 1u];
     const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + first);
     float4 q[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) q[k] = p[k];
-    uint32_t m = 0;
+    uint32_t m = 0, best = 0;
+    float best_t = __builtin_inff();
 #pragma unroll
     for (uint32_t k = 0; k < kRtFanout; k++) {
         const float lo[3] = {q[2 * k].x, q[2 * k].y, q[2 * k].z}, hi[3] = {q[2 * k].w, q[2 * k + 1].x, q[2 * k + 1].y};
-        if (first + k < cnt && slab(r, lo, hi)) m |= 1u << k;
+        float tn;
+        const bool pass = first + k < cnt && slab(r, lo, hi, &tn);
+        if (pass) m |= 1u << k;
+        if (nearest && pass && tn <= best_t) {
+            best_t = tn;
+            best = k;
+        }
     }
+    if (nearest) *nearest = best;
     return m;
 }
 SAH_DEV RtTriangle load_triangle(const RtTriangle* tris, uint32_t i) {  // three 16-byte loads
@@ -407,15 +417,17 @@ SAH_DEV RtTriangle load_triangle(const RtTriangle* tris, uint32_t i) {  // three
     return t;
 }
 // next position of the walk after (level, node) left `m` of its children to visit; false when the walk is over
-template <bool DESCENDING = true>
-SAH_DEV bool trav_next(uint32_t top, uint32_t& level, uint32_t& node, unsigned long long& pending, uint32_t m) {
+// `prefer`: the child to enter first when (level, node) has just been tested (children_hit's nearest); 4 = none.  Children left for
+// later are entered in descending index order (measured: DESIGN.md §5f)
+SAH_DEV bool trav_next(uint32_t top, uint32_t& level, uint32_t& node, unsigned long long& pending, uint32_t m, uint32_t prefer = 4u) {
+    const bool fresh = m != 0u && prefer < 4u;
     while (m == 0u) {
         if (level == top) return false;
         level++;
         node >>= 2;
         m = (uint32_t)(pending >> (4u * level)) & 15u;
     }
-    const uint32_t k = DESCENDING ? 31u - (uint32_t)__builtin_clz(m) : (uint32_t)__builtin_ctz(m);
+    const uint32_t k = fresh ? prefer : 31u - (uint32_t)__builtin_clz(m);
     m &= ~(1u << k);
     pending = (pending & ~(15ull << (4u * level))) | ((unsigned long long)m << (4u * level));
     node = node * kRtFanout + k;
@@ -439,7 +451,10 @@ SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const 
         alive = slab(r, lo, hi);
     }
     while (alive) {
-        while (alive && level != 0) alive = trav_next(top, level, node, pending, children_hit(bvh, tv, r, level, node));
+        while (alive && level != 0) {
+            // (entering the nearest child first, as the closest-hit walk does, does not pay here: RTAO unchanged, shadow mask + 4 %)
+            alive = trav_next(top, level, node, pending, children_hit(bvh, tv, r, level, node));
+        }
         if (alive) {
             const RtTriangle tr = load_triangle(bvh.tris, node);
             if (!(CULL_NON_OPAQUE && (tr.flags & 1u))) {
@@ -505,7 +520,11 @@ SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv,
         alive = slab(r, lo, hi);
     }
     while (alive) {
-        while (alive && level != 0) alive = trav_next(top, level, node, pending, children_hit(bvh, tv, r, level, node));
+        while (alive && level != 0) {
+            uint32_t nearest;
+            const uint32_t m = children_hit(bvh, tv, r, level, node, &nearest);
+            alive = trav_next(top, level, node, pending, m, nearest);
+        }
         if (alive) {
             const RtTriangle tr = load_triangle(bvh.tris, node);
             Ray full = r;

@@ -253,13 +253,39 @@ struct ComputePipeline {
     std::function<int(sah_ctx*, const void* push_constants, const uint32_t num_workgroups[3])> launch;
 };
 using ComputePipelineHandle = const ComputePipeline*;
+// descriptor_set_builder.hpp:36-51: what a bound set contributes to a pass is the usage of its resources (the bindings themselves are
+// arguments of the C ABI call the pipeline's launcher makes)
+struct DescriptorSet {
+    TextureUsageList textures;
+    BufferUsageList buffers;
+    void get_resource_usage_information(TextureUsageList& texture_usages, BufferUsageList& buffer_usages) const {
+        texture_usages.insert(texture_usages.end(), textures.begin(), textures.end());
+        buffer_usages.insert(buffer_usages.end(), buffers.begin(), buffers.end());
+    }
+};
 // render_pass.hpp:48-79
 template <typename PushConstantsType = uint32_t> struct ComputeDispatch {
     std::string name;
+    std::vector<DescriptorSet> descriptor_sets;
     BufferUsageList buffers;
     PushConstantsType push_constants{};
     uint32_t num_workgroups[3] = {1, 1, 1};
     ComputePipelineHandle compute_shader = nullptr;
+};
+// render_pass.hpp:86-116: the workgroup counts come from a buffer (three uint32: VkDispatchIndirectCommand) — host-visible here, like
+// every Buffer of this backend, and read when the pass executes
+template <typename PushConstantsType = uint32_t> struct IndirectComputeDispatch {
+    std::string name;
+    std::vector<DescriptorSet> descriptor_sets;
+    BufferUsageList buffers;
+    PushConstantsType push_constants{};
+    BufferHandle dispatch = nullptr;
+    ComputePipelineHandle compute_shader = nullptr;
+};
+// render_pass.hpp:124-130
+struct BufferCopyPass {
+    std::string name;
+    BufferHandle dst = nullptr, src = nullptr;
 };
 // render_pass.hpp (RenderingAttachmentInfo / DynamicRenderingPass): load_op 1 = VK_ATTACHMENT_LOAD_OP_CLEAR
 struct RenderingAttachmentInfo {
@@ -308,6 +334,16 @@ public:
                         hipMemcpyDeviceToDevice) != hipSuccess)
             cmds.errors.push_back(pass.name + ": hipMemcpy2D failed");
     }
+    void add_copy_pass(const BufferCopyPass& pass) {  // render_graph.hpp:36-39; buffers are host-visible blocks here
+        cmds.current_pass = pass.name;
+        if (!pass.dst || !pass.src || !pass.dst->data || !pass.src->data || pass.dst->size < pass.src->size) {
+            cmds.errors.push_back(pass.name + ": buffer copy needs a destination at least as large as the source");
+            return;
+        }
+        cmds.check(sah_sync(backend.get_context()));  // work enqueued earlier may still read the destination
+        std::memcpy(const_cast<void*>(pass.dst->data), pass.src->data, pass.src->size);
+        num_passes++;
+    }
     void add_pass(ComputePass pass) {
         cmds.current_pass = pass.name;
         record_usages(pass.textures, pass.buffers);
@@ -316,12 +352,26 @@ public:
     }
     template <typename PushConstantsType = uint32_t> void add_compute_dispatch(const ComputeDispatch<PushConstantsType>& dispatch_info) {
         cmds.current_pass = dispatch_info.name;
+        record_sets(dispatch_info.descriptor_sets);
         record_usages({}, dispatch_info.buffers);
         if (!dispatch_info.compute_shader) {
             cmds.errors.push_back(dispatch_info.name + ": null compute shader");  // the reference logs a null pipeline and goes on
             return;
         }
         cmds.check(dispatch_info.compute_shader->launch(backend.get_context(), &dispatch_info.push_constants, dispatch_info.num_workgroups));
+        num_passes++;
+    }
+    template <typename PushConstantsType = uint32_t> void add_compute_dispatch(const IndirectComputeDispatch<PushConstantsType>& dispatch_info) {
+        cmds.current_pass = dispatch_info.name;
+        record_sets(dispatch_info.descriptor_sets);
+        record_usages({}, dispatch_info.buffers);
+        if (!dispatch_info.compute_shader || !dispatch_info.dispatch || !dispatch_info.dispatch->data || dispatch_info.dispatch->size < 3 * sizeof(uint32_t)) {
+            cmds.errors.push_back(dispatch_info.name + ": indirect dispatch needs a compute shader and a buffer of three workgroup counts");
+            return;
+        }
+        uint32_t num_workgroups[3];
+        std::memcpy(num_workgroups, dispatch_info.dispatch->data, sizeof(num_workgroups));
+        cmds.check(dispatch_info.compute_shader->launch(backend.get_context(), &dispatch_info.push_constants, num_workgroups));
         num_passes++;
     }
     void add_render_pass(DynamicRenderingPass pass) {
@@ -340,6 +390,9 @@ public:
     uint32_t get_num_passes() const { return num_passes; }
 
 private:
+    void record_sets(const std::vector<DescriptorSet>& sets) {
+        for (const auto& set : sets) set.get_resource_usage_information(texture_usages, buffer_usages);
+    }
     void record_usages(const TextureUsageList& textures, const BufferUsageList& buffers) {
         texture_usages.insert(texture_usages.end(), textures.begin(), textures.end());
         buffer_usages.insert(buffer_usages.end(), buffers.begin(), buffers.end());

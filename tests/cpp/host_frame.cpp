@@ -104,6 +104,23 @@ int main(int argc, char** argv) {
     clear_dispatch.num_workgroups[1] = (H + 7) / 8;
     clear_dispatch.compute_shader = &clear_ao;
     graph.add_compute_dispatch(clear_dispatch);
+    // the same shader dispatched from an indirect buffer (render_pass.hpp:86-116) with a descriptor set, and the buffer copy verb
+    TextureHandle ao_scratch2 = alloc.create_texture("ao scratch 2", SAH_FORMAT_R32_SFLOAT, W, H);
+    const ComputePipeline clear_ao2{"clear_ao2", [ao_scratch2, W, H](sah_ctx* ctx, const void*, const uint32_t* groups) {
+                                        if (groups[0] != (W + 7) / 8 || groups[1] != (H + 7) / 8 || groups[2] != 1) return (int)SAH_ERR_INVALID_ARGUMENT;
+                                        const sah_plane p = ao_scratch2->plane();
+                                        return sah_ao_clear(ctx, &p);
+                                    }};
+    const uint32_t counts_src[3] = {(W + 7) / 8, (H + 7) / 8, 1};
+    uint32_t counts_dst[3] = {0, 0, 0};
+    const Buffer counts_src_buffer{"dispatch counts (staging)", counts_src, sizeof(counts_src)}, counts_buffer{"dispatch counts", counts_dst, sizeof(counts_dst)};
+    graph.add_copy_pass(BufferCopyPass{"Upload dispatch counts", &counts_buffer, &counts_src_buffer});
+    IndirectComputeDispatch<uint32_t> indirect;
+    indirect.name = "Clear AO (indirect)";
+    indirect.descriptor_sets.push_back(DescriptorSet{{{ao_scratch2, 0x800ull /*COMPUTE_SHADER*/, 0x40ull /*SHADER_WRITE*/, 1 /*GENERAL*/}}, {}});
+    indirect.dispatch = &counts_buffer;
+    indirect.compute_shader = &clear_ao2;
+    graph.add_compute_dispatch(indirect);
     TransitionPass to_read;
     to_read.textures.push_back({ao, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly});
     graph.add_transition_pass(to_read);
@@ -130,6 +147,12 @@ int main(int argc, char** argv) {
         alloc.download(ao_scratch, ones.data(), W * 4);
         for (float v : ones)
             if (v != 1.0f) { fprintf(stderr, "Clear AO dispatch did not run\n"); return 1; }
+        alloc.download(ao_scratch2, ones.data(), W * 4);
+        for (float v : ones)
+            if (v != 1.0f) { fprintf(stderr, "indirect Clear AO dispatch did not run\n"); return 1; }
+        bool saw_set = false;
+        for (const auto& u : graph.get_texture_usages()) saw_set = saw_set || u.texture == ao_scratch2;
+        if (!saw_set) { fprintf(stderr, "descriptor set usages were not recorded\n"); return 1; }
     }
 
     FILE* out = fopen(argv[2], "wb");
