@@ -75,12 +75,13 @@ MAX_TEXTURE_MIPS = 14
 TEXTURE_NONE = 0xFFFFFFFF
 
 
-class Sampler(C.Structure):  # sah_sampler, 32 bytes
+class Sampler(C.Structure):  # sah_sampler, 40 bytes
     _fields_ = [("mag_filter", C.c_uint32), ("min_filter", C.c_uint32), ("mipmap_mode", C.c_uint32), ("address_u", C.c_uint32),
-                ("address_v", C.c_uint32), ("mip_lod_bias", C.c_float), ("min_lod", C.c_float), ("max_lod", C.c_float)]
+                ("address_v", C.c_uint32), ("mip_lod_bias", C.c_float), ("min_lod", C.c_float), ("max_lod", C.c_float),
+                ("max_anisotropy", C.c_float), ("reserved", C.c_uint32)]
 
 
-class Texture(C.Structure):  # sah_texture, 376 bytes
+class Texture(C.Structure):  # sah_texture, 384 bytes
     _fields_ = [("mips", Plane * MAX_TEXTURE_MIPS), ("num_mips", C.c_uint32), ("padding", C.c_uint32), ("sampler", Sampler)]
 
 

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k_check_textures(const RasterArgs a) {
     if (i < a.num_textures) {
         const sah_texture& T = a.textures[i];
         bad = T.num_mips < 1 || T.num_mips > SAH_MAX_TEXTURE_MIPS || T.sampler.mag_filter > 1 || T.sampler.min_filter > 1 || T.sampler.mipmap_mode > 1 ||
-              T.sampler.address_u > 2 || T.sampler.address_v > 2;
+              T.sampler.address_u > 2 || T.sampler.address_v > 2 || T.sampler.max_anisotropy > 16.0f;
         for (uint32_t l = 0; !bad && l < T.num_mips; l++) {
             const sah_plane& p = T.mips[l];
             bad = !p.ptr || p.width == 0 || p.height == 0 || p.width > 16384 || p.height > 16384 || p.format != T.mips[0].format ||

@@ -88,7 +88,31 @@ SAH_DEV void sample_texture(const float* luts, const sah_texture& T, const float
     const float rx = mxx * mxx + mxy * mxy, ry = myx * myx + myy * myy;
     const float rho2 = __builtin_fmaxf(rx, ry);
     const float lambda = rho2 > 0.0f ? 0.5f * (float)log2((double)rho2) : -__builtin_inff();
-    sample_texture_lod(luts, T, uv, lambda, shader_bias, out);
+    const float A = T.sampler.max_anisotropy;
+    if (!(A > 1.0f)) {
+        sample_texture_lod(luts, T, uv, lambda, shader_bias, out);
+        return;
+    }
+    // anisotropic footprint (sah_hip.h "anisotropy"): N taps along the major axis
+    const float rmin2 = __builtin_fminf(rx, ry);
+    float eta = 1.0f;
+    if (rho2 > 0.0f) eta = rmin2 > 0.0f ? __builtin_fminf(__builtin_sqrtf(rho2 / rmin2), A) : A;
+    const int N = (int)__builtin_ceilf(eta);
+    const float lambda_a = rho2 > 0.0f ? lambda - (float)log2((double)eta) : lambda;
+    if (N <= 1) {
+        sample_texture_lod(luts, T, uv, lambda_a, shader_bias, out);
+        return;
+    }
+    const float* d = rx > ry ? ddx : ddy;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 1; i <= N; i++) {
+        const float a = (float)i / (float)(N + 1) - 0.5f;
+        const float p[2] = {uv[0] + a * d[0], uv[1] + a * d[1]};
+        float t[4];
+        sample_texture_lod(luts, T, p, lambda_a, shader_bias, t);
+        for (int c = 0; c < 4; c++) acc[c] = acc[c] + t[c];
+    }
+    for (int c = 0; c < 4; c++) out[c] = acc[c] / (float)N;
 }
 
 }  // namespace sah

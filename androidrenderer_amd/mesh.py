@@ -23,9 +23,10 @@ IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
 
 
 def sampler(mag=_abi.FILTER_LINEAR, min=_abi.FILTER_LINEAR, mipmap=_abi.FILTER_LINEAR, address_u=_abi.ADDRESS_REPEAT, address_v=_abi.ADDRESS_REPEAT,
-            bias=0.0, min_lod=0.0, max_lod=1000.0):
-    """sah_sampler; the defaults are what gltf_model.cpp:520-586 makes of a glTF sampler with linear filters (VK_LOD_CLAMP_NONE = 1000)."""
-    return _abi.Sampler(mag, min, mipmap, address_u, address_v, bias, min_lod, max_lod)
+            bias=0.0, min_lod=0.0, max_lod=1000.0, max_anisotropy=0.0):
+    """sah_sampler; the defaults are what gltf_model.cpp:520-586 makes of a glTF sampler with linear filters (VK_LOD_CLAMP_NONE = 1000),
+    except for its anisotropy: pass max_anisotropy=8.0 for that (0 = off keeps the committed golden vectors of the isotropic path valid)."""
+    return _abi.Sampler(mag, min, mipmap, address_u, address_v, bias, min_lod, max_lod, max_anisotropy, 0)
 
 
 def mip_sizes(width, height, count=None):
@@ -237,7 +238,7 @@ def random_texture(g, width, height, levels=None, srgb=False, smp=None, alpha=(0
 def random_sampler(g):
     return sampler(mag=int(g.integers(0, 2)), min=int(g.integers(0, 2)), mipmap=int(g.integers(0, 2)), address_u=int(g.integers(0, 3)),
                    address_v=int(g.integers(0, 3)), bias=float(g.choice([0.0, 0.0, -0.75, 0.5, 1.25])), min_lod=float(g.choice([0.0, 0.0, 1.0])),
-                   max_lod=float(g.choice([1000.0, 1000.0, 2.5, 0.25])))
+                   max_lod=float(g.choice([1000.0, 1000.0, 2.5, 0.25])), max_anisotropy=float(g.choice([0.0, 8.0, 8.0, 2.5, 16.0])))
 
 
 def random_soup(seed, triangles=400, extent=6.0, size=(0.05, 3.0), cutout_fraction=0.3, instances=3, textured=False):

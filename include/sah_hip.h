@@ -352,7 +352,15 @@ typedef struct sah_material {
  *              d/dy likewise; the varying of the other pixel is the same triangle's, extrapolated when it is not covered;
  *   lod        rho2 = fmax(mx.x^2 + mx.y^2, my.x^2 + my.y^2), m = derivative * size of level 0 (every operator fp32);
  *              lambda = rho2 > 0 ? 0.5 * RN32(log2 evaluated in double) : -inf;  lambda += (sampler.mip_lod_bias + shader bias);
- *              lambda = fmin(fmax(lambda, min_lod), max_lod);  maxAnisotropy is ignored (isotropic footprint);
+ *              lambda = fmin(fmax(lambda, min_lod), max_lod);
+ *   anisotropy sampler.max_anisotropy A > 1 (gltf_model.cpp:581-584: 8 with a LINEAR mipmap mode; values <= 1 or NaN: off; at most 16),
+ *              the example formulation of the Vulkan specification ("Texel Anisotropic Filtering") with every operator in fp32:
+ *              rx = mx.x^2 + mx.y^2, ry = my.x^2 + my.y^2 (as above), rmax2 = fmax(rx, ry), rmin2 = fmin(rx, ry), major axis = x when
+ *              rx > ry, else y;  eta = 1 when rmax2 is not > 0, A when rmin2 is not > 0, else fmin(sqrt(rmax2 / rmin2), A);
+ *              N = ceil(eta);  lambda = 0.5 * RN32(log2 rmax2) - RN32(log2 eta) (then bias and clamps as above; -inf when rmax2 is
+ *              not > 0);  N == 1: the isotropic sample.  Otherwise tap i = 1..N at texcoord + (i / (N + 1) - 0.5) * (the major
+ *              axis' derivative of the texcoord), each a complete sample at that lambda (filter, level blend), summed from +0 in the
+ *              order of i and divided by (float)N.  SampleLevel (the ray-tracing stages) has no derivatives: always isotropic;
  *   filter     lambda <= 0 ? mag_filter : min_filter;
  *   level      mipmap NEAREST: lambda <= 0.5 ? 0 : min(ceil(lambda + 0.5) - 1, q), q = num_mips - 1;
  *              mipmap LINEAR:  d = clamp(lambda, 0, q), hi = floor(d), lo = min(hi + 1, q), delta = d - hi,
@@ -374,6 +382,8 @@ typedef struct sah_sampler {
     uint32_t mag_filter, min_filter, mipmap_mode;
     uint32_t address_u, address_v;
     float mip_lod_bias, min_lod, max_lod;
+    float max_anisotropy; /* VkSamplerCreateInfo::maxAnisotropy when anisotropyEnable, else 0 */
+    uint32_t reserved;
 } sah_sampler;
 
 typedef struct sah_texture {

@@ -93,12 +93,39 @@ inline void sample_texture(const sah_texture& T, const float uv[2], const float 
     const float rx = mxx * mxx + mxy * mxy, ry = myx * myx + myy * myy;
     const float rho2 = std::fmax(rx, ry);
     const float lambda = rho2 > 0.0f ? 0.5f * (float)std::log2((double)rho2) : -INFINITY;
-    sample_texture_lod(T, uv, lambda, shader_bias, out);
+    const float A = T.sampler.max_anisotropy;
+    if (!(A > 1.0f)) {
+        sample_texture_lod(T, uv, lambda, shader_bias, out);
+        return;
+    }
+    // Vulkan specification, "Texel Anisotropic Filtering" (the example formulation), as sah_hip.h fixes its arithmetic; the sampler
+    // asks for it in gltf_model.cpp:581-584
+    const float rmin2 = std::fmin(rx, ry);
+    float eta = 1.0f;
+    if (rho2 > 0.0f) eta = rmin2 > 0.0f ? std::fmin(std::sqrt(rho2 / rmin2), A) : A;
+    const int N = (int)std::ceil(eta);
+    const float lambda_a = rho2 > 0.0f ? lambda - (float)std::log2((double)eta) : lambda;
+    if (N <= 1) {
+        sample_texture_lod(T, uv, lambda_a, shader_bias, out);
+        return;
+    }
+    const float* d = rx > ry ? ddx : ddy;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 1; i <= N; i++) {
+        const float a = (float)i / (float)(N + 1) - 0.5f;
+        const float p[2] = {uv[0] + a * d[0], uv[1] + a * d[1]};
+        float t[4];
+        sample_texture_lod(T, p, lambda_a, shader_bias, t);
+        for (int c = 0; c < 4; c++) acc[c] = acc[c] + t[c];
+    }
+    for (int c = 0; c < 4; c++) out[c] = acc[c] / (float)N;
 }
 
 inline bool texture_ok(const sah_texture& T) {
     if (T.num_mips < 1 || T.num_mips > SAH_MAX_TEXTURE_MIPS) return false;
-    if (T.sampler.mag_filter > 1 || T.sampler.min_filter > 1 || T.sampler.mipmap_mode > 1 || T.sampler.address_u > 2 || T.sampler.address_v > 2) return false;
+    if (T.sampler.mag_filter > 1 || T.sampler.min_filter > 1 || T.sampler.mipmap_mode > 1 || T.sampler.address_u > 2 || T.sampler.address_v > 2 ||
+        T.sampler.max_anisotropy > 16.0f)
+        return false;
     for (uint32_t i = 0; i < T.num_mips; i++) {
         const sah_plane& p = T.mips[i];
         if (!p.ptr || p.width == 0 || p.height == 0 || p.width > 16384 || p.height > 16384 || p.format != T.mips[0].format) return false;

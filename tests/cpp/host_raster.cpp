@@ -46,15 +46,15 @@ int main(int argc, char** argv) {
     scene.geometry.indices = (const uint32_t*)to_device(read_blob(in, (size_t)hdr[4] * 4));
     scene.geometry.primitives = (const sah_primitive*)to_device(read_blob(in, (size_t)hdr[5] * sizeof(sah_primitive)));
     scene.geometry.materials = (const sah_material*)to_device(read_blob(in, (size_t)hdr[6] * sizeof(sah_material)));
-    // bindless textures (texture_descriptor_pool.hpp): per texture {format, levels, sampler (8 words)}, then per level {w, h} + texels;
+    // bindless textures (texture_descriptor_pool.hpp): per texture {format, levels, sampler (10 words)}, then per level {w, h} + texels;
     // then one sah_material_textures per material
     TextureDescriptorPool texture_pool(backend);
     for (uint32_t t = 0; t < hdr[7]; t++) {
-        uint32_t th[10];
-        if (fread(th, 4, 10, in) != 10) return 2;
+        uint32_t th[12];
+        if (fread(th, 4, 12, in) != 12) return 2;
         sah_sampler smp;
-        static_assert(sizeof(smp) == 32, "sampler words");
-        memcpy(&smp, th + 2, 32);
+        static_assert(sizeof(smp) == 40, "sampler words");
+        memcpy(&smp, th + 2, 40);
         std::vector<TextureHandle> levels;
         for (uint32_t l = 0; l < th[1]; l++) {
             uint32_t wh[2];

@@ -197,6 +197,29 @@ def test_hip_matches_golden_textured_gbuffer(hip_ctx):
         assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"
 
 
+def test_oracle_matches_golden_anisotropic_gbuffer():
+    """the same scene with anisotropic samplers (8x / 2.5x / 16x / 4x): N taps along the major axis of the footprint, per sah_hip.h"""
+    from tests.test_raster import _oracle_gbuffer
+    m, view = util.golden_raster_scene(anisotropic=True)
+    got, _ = _oracle_gbuffer(m.arrays(), view, 64, 36)
+    want = np.load(os.path.join(GOLDEN, "raster_gbuffer_aniso_64x36.npz"))
+    iso = _raster_golden()
+    for k in iso:
+        assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"
+    assert (want["color"] != iso["color"]).any() and (want["data"] != iso["data"]).any()  # the oblique wall really takes the anisotropic path
+    # (the depth plane moves too: the wall is alpha-tested with the base-colour texture's alpha)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_anisotropic_gbuffer(hip_ctx):
+    from tests.test_raster import _hip_gbuffer
+    m, view = util.golden_raster_scene(anisotropic=True)
+    got, _ = _hip_gbuffer(hip_ctx, m.arrays(), view, 64, 36)
+    want = np.load(os.path.join(GOLDEN, "raster_gbuffer_aniso_64x36.npz"))
+    for k in ("color", "normals", "data", "emission", "depth"):
+        assert np.array_equal(got[k], want[k]), f"{k}: {int((got[k] != want[k]).sum())} values differ"
+
+
 def test_oracle_matches_golden_shadow_cascades():
     """f2: two sun shadow cascades of the same scene (D16, LESS, texture-alpha cutouts) against the numpy rasteriser"""
     from tests.test_raster import _oracle_shadow

@@ -72,6 +72,53 @@ def test_level_selection_follows_the_quad_derivatives(bias, min_lod, max_lod, mi
         assert not np.array_equal(out2["data"], out["data"])
 
 
+@pytest.mark.parametrize("aniso,lam_major,lam_minor,want_level", [(0.0, 3.2, 1.2, 3), (8.0, 3.2, 1.2, 1), (2.0, 3.2, 1.2, 2), (8.0, 5.2, 0.2, 2),
+                                                                  (16.0, 5.2, 1.7, 2), (8.0, 2.2, 2.2, 2)])
+def test_anisotropic_footprint_takes_its_level_from_the_minor_axis(aniso, lam_major, lam_minor, want_level):
+    """sah_hip.h "anisotropy": eta = min(rho_max / rho_min, A), lambda = log2(rho_max) - log2(eta) — up to A times more detail than the
+    isotropic footprint; on a texture whose level i is the constant 20 (i + 1) the N taps agree, so the colour names the level"""
+    w, h = 64, 36
+    view = scene.SceneView.default(w, h)
+    mpp = _texels_per_pixel(view, w)
+    su, sv = (2.0 ** lam_major) / (64.0 * mpp), (2.0 ** lam_minor) / (64.0 * mpp)
+    m = mesh.Mesh()
+    mips, srgb = _level_texture(64)
+    t = m.add_texture(mips, srgb, mesh.sampler(mag=0, min=0, mipmap=0, max_anisotropy=aniso))
+    mat = m.add_material(mesh.material(), data=t)
+    _wall(m, mat, scale=(su, sv))
+    out, _ = _oracle_gbuffer(m.arrays(), view, w, h)
+    hit = out["depth"] > 0
+    assert hit.sum() > w * h // 2
+    got = out["data"][hit][:, 1]
+    eta = min(2.0 ** (lam_major - lam_minor), aniso) if aniso > 1 else 1.0
+    lam = lam_major - math.log2(eta)
+    level = 0 if lam <= 0.5 else math.ceil(lam + 0.5) - 1
+    assert level == want_level
+    want = round(20 * (level + 1) / 255.0 * 0.5 * 255.0)
+    assert (np.abs(got.astype(np.int64) - want) <= 0).mean() > 0.97, (np.unique(got), want)  # (a few pixels at the wall's silhouette extrapolate)
+
+
+def test_anisotropic_taps_average_along_the_major_axis():
+    """one level, NEAREST, steps in u every 8 texels (0 | 200 | 0 ...); a footprint of 3.9 texels per pixel along u and 1 along v
+    makes N = 4 taps spread over 2.3 texels around the sample point: pixels next to the step average k of 4 taps on the bright side
+    (0, 50, 100, 150, 200), where the isotropic sample knows 0 and 200 only"""
+    w, h = 64, 36
+    view = scene.SceneView.default(w, h)
+    mpp = _texels_per_pixel(view, w)
+    tex = np.zeros((64, 64, 4), np.uint8)
+    tex[:, (np.arange(64) // 8) % 2 == 1] = 200
+    seen = {}
+    for aniso in (0.0, 8.0):
+        m = mesh.Mesh()
+        t = m.add_texture([tex], False, mesh.sampler(mag=0, min=0, mipmap=0, max_anisotropy=aniso))
+        mat = m.add_material(mesh.material(rough=1.0), data=t)
+        _wall(m, mat, scale=(3.9 / (64.0 * mpp), 1.0 / (64.0 * mpp)), offset=(0.5, 0.0))
+        out, _ = _oracle_gbuffer(m.arrays(), view, w, h)
+        seen[aniso] = set(int(v) for v in np.unique(out["data"][out["depth"] > 0][:, 1]))
+    assert seen[0.0] == {0, 200}
+    assert seen[8.0] <= {0, 50, 100, 150, 200} and len(seen[8.0] & {50, 100, 150}) >= 2, seen[8.0]
+
+
 @pytest.mark.parametrize("mode", [_abi.ADDRESS_REPEAT, _abi.ADDRESS_MIRRORED_REPEAT, _abi.ADDRESS_CLAMP_TO_EDGE])
 def test_address_modes_with_the_nearest_filter(mode):
     """a 4 x 1 texture with texels 10, 20, 30, 40 over texcoords [-1, 2]: the sequence of texel values along a row names the mode"""
@@ -247,7 +294,7 @@ def test_hip_refuses_bad_texture_tables_without_touching_them(hip_ctx):
             dev["material_textures"] = torch.from_numpy(np.frombuffer(bad.tobytes(), dtype=np.uint8).copy()).cuda()
         g = mesh.geometry(dev, [])
         if what != "binding":  # patch texture 0 of the device-side table
-            table = next(t for t in g._alive if hasattr(t, "data_ptr") and t.numel() == table_bytes)
+            table = next(t for t in g._alive if hasattr(t, "data_ptr") and t.dim() == 1 and t.dtype == torch.uint8 and t.numel() == table_bytes)
             host = bytearray(table.cpu().numpy().tobytes())
             t0 = _abi.Texture.from_buffer(host)
             if what == "levels":

@@ -139,8 +139,9 @@ def golden_lighting_frame(width, height, seed, sun_mode, gi, sky=False):
     return f
 
 
-def golden_raster_scene():
-    """The scene behind tests/golden/raster_gbuffer_64x36.npz (tools/gen_golden.py): a textured, alpha-tested wall seen at an angle
+def golden_raster_scene(anisotropic=False):
+    """(anisotropic=True: the same scene with anisotropic samplers, 8x / 2.5x / 16x / 4x — tests/golden/raster_gbuffer_aniso_64x36.npz.)
+    The scene behind tests/golden/raster_gbuffer_64x36.npz (tools/gen_golden.py): a textured, alpha-tested wall seen at an angle
     (two CUTOUT triangles, every material slot bound to a texture with its own sampler), a SOLID triangle in front of it drawn twice
     at the same depth with two materials (the later draw stays) and once with the opposite winding (culled), random vertex colours,
     normals and tangents.  Returns (mesh.Mesh, scene.SceneView); nothing is clipped."""
@@ -149,11 +150,12 @@ def golden_raster_scene():
     view = scene.SceneView.default(64, 36)  # at (-7, 1, 0) looking along +x
     view.gpu_data.material_texture_mip_bias = 0.25
     m = mesh.Mesh()
-    tex = [m.add_texture(*mesh.random_texture(g, 32, 32, None, True, mesh.sampler(), alpha=(0, 256))),                  # base colour: trilinear REPEAT
-           m.add_texture(*mesh.random_texture(g, 16, 8, None, False, mesh.sampler(mag=0, min=1, mipmap=0,
+    an = (8.0, 2.5, 16.0, 4.0) if anisotropic else (0.0, 0.0, 0.0, 0.0)
+    tex = [m.add_texture(*mesh.random_texture(g, 32, 32, None, True, mesh.sampler(max_anisotropy=an[0]), alpha=(0, 256))),  # base colour: trilinear REPEAT
+           m.add_texture(*mesh.random_texture(g, 16, 8, None, False, mesh.sampler(mag=0, min=1, mipmap=0, max_anisotropy=an[1],
                                                                                      address_u=_abi.ADDRESS_MIRRORED_REPEAT, address_v=_abi.ADDRESS_CLAMP_TO_EDGE))),
-           m.add_texture(*mesh.random_texture(g, 64, 64, 3, False, mesh.sampler(mag=1, min=0, mipmap=1, bias=-0.5, max_lod=1.5))),
-           m.add_texture(*mesh.random_texture(g, 8, 8, None, True, mesh.sampler(mag=0, min=0, mipmap=0, min_lod=1.0)))]
+           m.add_texture(*mesh.random_texture(g, 64, 64, 3, False, mesh.sampler(mag=1, min=0, mipmap=1, bias=-0.5, max_lod=1.5, max_anisotropy=an[2]))),
+           m.add_texture(*mesh.random_texture(g, 8, 8, None, True, mesh.sampler(mag=0, min=0, mipmap=0, min_lod=1.0, max_anisotropy=an[3])))]
     wall = m.add_material(mesh.material(base=(0.9, 0.8, 1.0, 1.0), rough=0.7, metal=0.4, emission=(1.5, 0.5, 2.0, 0.0), opacity_threshold=0.35),
                           base_color=tex[0], normal=tex[1], data=tex[2], emission=tex[3])
     red = m.add_material(mesh.material(base=(1.0, 0.1, 0.1, 1.0), rough=0.2, metal=0.9))
