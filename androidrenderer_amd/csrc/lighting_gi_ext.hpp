@@ -276,9 +276,11 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             tri[k][j] = nmax(Fn(0.001f), j ? alpha : Fn(1.f) - alpha);
         }
         // signs of the direction from a probe to the point, per axis: -dp[k][0] = ps - floor(ps) >= 0 and -dp[k][1] = ps - floor(ps) - 1 < 0.
-        // The octahedral fold below takes them as known, which needs the products with 1 / L1 not to underflow to -0: a dp[k][1] this
-        // small (a coordinate within 2^-100 cells below a cell boundary at the cascade's origin) sends the pixel to sample_cascade()
-        bad = bad || !(dp[k][1].v >= 0x1p-100f) || !(dp[k][0].v <= 0.f);
+        // The octahedral fold below takes them as known, and the restricted-range root / reciprocal / divide of the probe loop take from
+        // here that every component of that direction is 0 or at least 2^-40 in magnitude and at most 1: the squared distance is then 0
+        // or in [2^-80, 3], the L1 norm 0 (corner 0 of all three axes only) or in [2^-40, 3].  A coordinate within 2^-40 cells of a
+        // cell boundary (or a non-finite one) sends the pixel to sample_cascade()
+        bad = bad || !(dp[k][1].v >= 0x1p-40f && dp[k][1].v <= 1.0f) || !(dp[k][0].v == 0.f || (dp[k][0].v <= -0x1p-40f && dp[k][0].v >= -1.0f));
     }
     // texcoord terms per axis: idx * total + total / 2 (depth atlas: 10 + 2 texels), and the whole irradiance axis
     Fn dbase[2][2];
@@ -324,7 +326,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
         const F3 dir_to_probe = {dp[0][jx], dp[1][jy], dp[2][jz]};
         const Fn d2 = sq[0][jx] + sq[1][jy] + sq[2][jz];
-        bool pbad = !(d2.v == 0.f || (d2.v >= 0x1p-80f && d2.v <= 0x1p+80f));
+        bool pbad = false;  // (d2 is 0 or in [2^-80, 3]: the per-axis check above)
         const Fn dist = Fn(sqrt_nr0(d2.v)) * spacing;
         const Fn trilinear_weight = tri[0][jx] * tri[1][jy] * tri[2][jz];
         Fn probe_weight = Fn(1.f);
@@ -338,7 +340,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         F2 depth_oct;
         {
             const Fn l1 = nabs(dir_to_probe.x) + nabs(dir_to_probe.y) + nabs(dir_to_probe.z);
-            pbad = pbad || !(l1.v >= kDivLo && l1.v <= kDivHi);
+            if (i == 0) pbad = !(l1.v > 0.f);  // the point ON the probe: no direction; every other corner has a component >= 2^-40
             const Fn inv = Fn(rcp_nr(l1.v));
             const F2 uv = {-dir_to_probe.x * inv, -dir_to_probe.y * inv};
             if (jz == 0) {
@@ -367,7 +369,10 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const Fn v = dist - Fn(tof(dx));
         const Fn cden = variance + (v * v);
         const bool behind = dist.v > tof(dx);
-        pbad = pbad || (behind && !((variance.v == 0.f || variance.v >= kDivLo) && variance.v <= kDivHi && cden.v >= kDivLo && cden.v <= kDivHi));
+        // div_nr's domain: variance is a half value widened (0, or in [2^-24, 65504], or not finite — and then so is cden), and
+        // cden >= variance: both are in range iff cden is (one unsigned compare on the bits: negative, NaN and inf fall outside)
+        pbad = pbad || (behind && !(__builtin_bit_cast(uint32_t, cden.v) - __builtin_bit_cast(uint32_t, kDivLo) <=
+                                    __builtin_bit_cast(uint32_t, kDivHi) - __builtin_bit_cast(uint32_t, kDivLo)));
         Fn cheb = Fn(div_nr(variance.v, cden.v));
         cheb = nmax(cheb * cheb * cheb, Fn(0.f));
         cheb = behind ? cheb : Fn(1.f);
