@@ -163,3 +163,60 @@ def test_8k_deferred_gi_fast_equals_general(hip_ctx):
     assert torch.equal(fast, general), "8K: fast and general kernels disagree"
     _shards_equal_full(hip_ctx, f, dev, fast, (540, 2703))
     _check_bands_against_oracle(f, fast, "8k_deferred_gi")
+
+
+# ---- ray tracing at 3840 x 2160 ----------------------------------------------------------------------------------------------------
+def _rt_case_4k(subdiv, hip_ctx):
+    """the atrium rasterised at 4K by the HIP rasteriser (bit-equal to the oracle's, tests/test_raster.py), as bench.py's traced workload"""
+    import torch
+    from androidrenderer_amd import mesh
+    from tests.test_rt import RtCase
+    W, H = 3840, 2160
+    m = mesh.atrium(subdiv)
+    view = scene.SceneView.default(W, H)
+    dev_arrays = mesh.to_device(m.arrays())
+    geo = mesh.geometry(dev_arrays, [])
+    gb = {"color": torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"), "normals": torch.zeros((H, W, 4), dtype=torch.int16, device="cuda"),
+          "data": torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"), "emission": torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"),
+          "depth": torch.zeros((H, W), dtype=torch.float32, device="cuda")}
+    hip_ctx.gbuffer_render(geo, view.gpu_data, images.gbuffer(gb), None)
+    torch.cuda.synchronize()
+    host = {"depth": gb["depth"].cpu().numpy(), "normals": gb["normals"].cpu().numpy().view(np.uint16)}
+    return RtCase(m, W, H, view=view, gbuffer=host)
+
+
+def test_4k_traced_planes_equal_the_brute_force_oracle(hip_ctx):
+    """every pixel of the 4K AO and shadow-mask planes (372 triangles: the oracle tests every triangle against every one of the 8.3 M +
+    8.3 M rays) — the same planes, pitches and launch geometry as bench.py's traced workload"""
+    case = _rt_case_4k(1, hip_ctx)
+    case.sun.constants.num_shadow_samples = 1.0
+    assert case.hip_build(hip_ctx)[0] == 372
+    ao_h, ao_o = case.hip_rtao(hip_ctx, 1, 8.0), case.oracle_rtao(1, 8.0)
+    assert np.array_equal(ao_h.view(np.uint32), ao_o.view(np.uint32)), int((ao_h != ao_o).sum())
+    mk_h, mk_o = case.hip_mask(hip_ctx), case.oracle_mask()
+    assert np.array_equal(mk_h.view(np.uint32), mk_o.view(np.uint32)), int((mk_h != mk_o).sum())
+    assert 0.05 < (ao_o == 0).mean() < 0.95 and 0.05 < (mk_o == 0).mean() < 0.95
+    # one GI ray per pixel: closest hit, hit shading with its own shadow ray, sky on a miss
+    (rb_h, ri_h), (rb_o, ri_o) = case.hip_rtgi(hip_ctx), case.oracle_rtgi()
+    assert np.array_equal(rb_h.view(np.uint16), rb_o.view(np.uint16)), int((rb_h.view(np.uint16) != rb_o.view(np.uint16)).any(-1).sum())
+    assert np.array_equal(ri_h.view(np.uint16), ri_o.view(np.uint16)), int((ri_h.view(np.uint16) != ri_o.view(np.uint16)).any(-1).sum())
+
+
+def test_4k_traced_planes_properties_on_the_dense_atrium(hip_ctx):
+    """23 808 triangles, where the oracle is out of reach: a larger AO radius can only occlude more, the mask is a multiple of 1 / samples,
+    a rebuilt structure gives the same planes, and the probe rays of a cascade end within their ray length"""
+    case = _rt_case_4k(8, hip_ctx)
+    stats = case.hip_build(hip_ctx)
+    assert stats[0] == 23808 and stats[1] == 0
+    near, far = case.hip_rtao(hip_ctx, 1, 1.0), case.hip_rtao(hip_ctx, 1, 8.0)
+    assert set(np.unique(near)) <= {0.0, 1.0} and (far <= near).all() and (far < near).any()
+    case.sun.constants.num_shadow_samples = 8.0
+    mask = case.hip_mask(hip_ctx)
+    assert np.array_equal(mask * 8.0, np.round(mask * 8.0)) and mask.min() == 0.0 and mask.max() == 1.0
+    case.hip_build(hip_ctx)
+    assert np.array_equal(case.hip_rtao(hip_ctx, 1, 8.0), far) and np.array_equal(case.hip_mask(hip_ctx), mask)
+    ids = np.stack([np.full(64, 16), np.arange(64) % 32, np.arange(64) // 2], axis=-1).astype(np.uint32)
+    trace = case.hip_probe_trace(hip_ctx, ids).astype(np.float32)
+    spacing = case.cascade_spacing * 2.0 ** (ids[:, 1] // 8)
+    limit = np.where(ids[:, 1] // 8 < 3, spacing * 2.0 * 4.0, 8192.0)
+    assert (np.abs(trace[..., 3]) <= limit[:, None, None] * 1.001).all() and np.isfinite(trace[..., :3]).all()
