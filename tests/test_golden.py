@@ -405,3 +405,32 @@ def test_hip_matches_golden_rt(hip_ctx):
     ao, mask = case.hip_rtao(hip_ctx, spp=2, radius=3.0), case.hip_mask(hip_ctx)
     assert np.array_equal(ao.view(np.uint32), g["ao"].view(np.uint32))
     assert np.array_equal(mask.view(np.uint32), g["mask"].view(np.uint32))
+
+
+def _check_rt_gi(rb, ri, trace):
+    g = np.load(os.path.join(GOLDEN, "rt_gi_64x36.npz"))
+    # texels the ray generator skips (sky pixels) keep the fill of the test's planes; the golden holds zeros there
+    traced = (np.load(os.path.join(GOLDEN, "rt_64x36.npz"))["depth"] != 0)[..., None]
+    for name, got, want in (("ray_buffer", rb, g["ray_buffer"]), ("ray_irradiance", ri, g["ray_irradiance"])):
+        got = np.where(traced, got.view(np.uint16), 0)
+        assert np.array_equal(got, want), f"{name}: {int((got != want).any(-1).sum())} texels differ"
+        assert (got.view(np.uint16)[~traced[..., 0]] == 0).all()
+    assert np.array_equal(trace.view(np.uint16), g["trace"]), f"probe trace: {int((trace.view(np.uint16) != g['trace']).any(-1).sum())} texels differ"
+    d = g["trace"].view(np.float16)[..., 3].astype(np.float32)
+    assert (d > 0).sum() > 2000 and (d < 0).sum() > 100 and (g["trace"][-1] == 0).all()  # hits, back faces, and the probe outside the cascades
+
+
+def test_oracle_matches_golden_rt_gi_rays():
+    """f4: one GI ray per pixel and twelve probes x 400 rays — closest hit, hit shading with its shadow ray, sky and next-cascade misses —
+    against the independent numpy restatement of tools/gen_golden.py"""
+    case, _ = _rt_fixture()
+    rb, ri = case.oracle_rtgi()
+    _check_rt_gi(rb, ri, case.oracle_probe_trace(util.golden_rt_gi_inputs()["probes"]))
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_rt_gi_rays(hip_ctx):
+    case, _ = _rt_fixture()
+    case.hip_build(hip_ctx)
+    rb, ri = case.hip_rtgi(hip_ctx)
+    _check_rt_gi(rb, ri, case.hip_probe_trace(hip_ctx, util.golden_rt_gi_inputs()["probes"]))

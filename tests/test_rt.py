@@ -67,12 +67,10 @@ class RtCase:
     def probe_desc(self, a, probes_ptr, num_probes, noise, results):
         """_abi.ProbeTraceDesc over host or device arrays `a` (gi_arrays() keys); returns (desc, keepalive)"""
         d = _abi.ProbeTraceDesc()
-        for c in range(4):
-            spacing = self.cascade_spacing * (2.0 ** c)
-            ext = (32 * spacing, 8 * spacing, 32 * spacing)
+        for c, (cmin, spacing) in enumerate(util.rt_gi_cascades(self.cascade_centre, self.cascade_spacing)):
             d.cascades[c].probe_spacing = spacing
             for i in range(3):
-                d.cascades[c].min[i] = self.cascade_centre[i] - ext[i] / 2.0 + 0.013 * (c + 1)
+                d.cascades[c].min[i] = cmin[i]
         sky, nz = self._sky(a), images.plane(noise, _abi.FORMAT_R8G8B8A8_UNORM)
         d.probes_to_update, d.num_probes = probes_ptr, num_probes
         d.sun, d.sky, d.noise = C.pointer(self.sun.constants), C.pointer(sky), C.pointer(nz)

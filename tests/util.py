@@ -195,6 +195,26 @@ def golden_rt_scene():
     return m, view, sun, noise
 
 
+def rt_gi_cascades(centre, spacing0):
+    """[(min xyz, spacing)] of the four irradiance-cache cascades around `centre` as the ray-tracing tests place them"""
+    out = []
+    for c in range(4):
+        spacing = spacing0 * (2.0 ** c)
+        ext = (32 * spacing, 8 * spacing, 32 * spacing)
+        out.append(([centre[i] - ext[i] / 2.0 + 0.013 * (c + 1) for i in range(3)], spacing))
+    return out
+
+
+def golden_rt_gi_inputs():
+    """inputs of the GI rays of tests/golden/rt_gi_64x36.npz besides golden_rt_scene(): sky LUTs, the irradiance cache the probe misses sample,
+    its cascades and the probes traced (all four cascades, inside and outside the geometry, one outside the cascades)"""
+    luts, at = synth.sky_luts(203), synth.probe_atlases(603)
+    probes = np.array([(16, 3, 16), (14, 2, 17), (10, 4, 12), (18, 5, 14), (15, 11, 16), (17, 12, 15), (16, 19, 16), (15, 20, 17), (16, 27, 16), (17, 28, 15),
+                       (3, 1, 30), (5, 40, 7)], np.uint32)
+    return {"sky_t": luts["transmittance"], "sky_v": luts["sky_view"], "irr": at["irradiance"], "pdepth": at["depth"], "val": at["validity"],
+            "cascades": rt_gi_cascades((0.0, 1.0, 0.0), 0.5), "probes": probes}
+
+
 def golden_raster_sun(view):
     """Sun whose cascades are fitted to `view` (directional_light.cpp:164-260 through scene.DirectionalLight)."""
     from androidrenderer_amd import scene

@@ -193,6 +193,56 @@ def probe_uv(pidx, oct_uv, n):
     return out
 
 
+def sample_cascade(loc, direction, cs, cmin, spacing, irr_atlas, depth_atlas, validity, psize=(5, 6)):
+    """probe_sampling.slangi:6-106.  loc, direction: 3 fp32 arrays; cs: cascade index per element (int); cmin (3 arrays), spacing: that
+    cascade's origin and probe spacing per element; atlases: irradiance (32, 256, 224, 3) fp32, depth moments (32, 384, 384, 2) fp32,
+    validity (32, 32, 32) u8; psize = irradiance texels per probe (irradiance_cache.cpp:298-299).  Returns 3 fp32 arrays."""
+    shape = np.shape(loc[0])
+    ps = [F(F(loc[k] - cmin[k]) / spacing) for k in range(3)]
+    mp = [np.floor(p) for p in ps]
+    alpha = [clamp01(F(ps[k] - mp[k])) for k in range(3)]
+    irr = [np.zeros(shape, dtype=f32) for _ in range(3)]
+    weight = np.zeros(shape, dtype=f32)
+    ioct = octahedral_coordinates(direction)
+    for i in range(8):
+        off = [f32(i & 1), f32((i >> 1) & 1), f32((i >> 2) & 1)]
+        pl = [F(mp[k] + off[k]) for k in range(3)]
+        to_probe = [F(pl[k] - ps[k]) for k in range(3)]
+        dist = F(length3(to_probe) * spacing)
+        pf = [pl[0], F(pl[1] + F(np.asarray(cs).astype(f32) * f32(8))), pl[2]]
+        with np.errstate(invalid="ignore"):
+            pidx = [np.where(p > 0, p, f32(0)).astype(np.int64) for p in pf]   # float -> uint: NaN / negative -> 0
+        inr = (pidx[0] < 32) & (pidx[1] < 32) & (pidx[2] < 32)
+        val = np.where(inr, validity[np.minimum(pidx[2], 31), np.minimum(pidx[1], 31), np.minimum(pidx[0], 31)], 0)
+        live = val != 0
+        tri = [np.maximum(f32(0.001), F(F(F(f32(1) - alpha[k]) * F(f32(1) - off[k])) + F(alpha[k] * off[k]))) for k in range(3)]
+        tw = F(F(tri[0] * tri[1]) * tri[2])
+        layer = np.minimum(pidx[2], 31)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            doct = octahedral_coordinates([F(-t) for t in to_probe])
+            duv = probe_uv(pidx, doct, (10, 10))
+            dt = h(bilinear_repeat(depth_atlas, np.nan_to_num(duv[0]), np.nan_to_num(duv[1]), layer))
+            dx, dy = dt[..., 0], dt[..., 1]
+            variance = np.abs(h(h(dx * dx) - dy))
+            v = F(dist - dx)
+            cheb = F(variance / F(variance + F(v * v)))
+            cheb = np.maximum(F(F(cheb * cheb) * cheb), f32(0))
+            cheb = np.where(dist > dx, cheb, f32(1))
+            pw = np.maximum(f32(0.05), cheb)
+            pw = np.maximum(f32(0.000001), pw)
+            k_crush = F(f32(1) / F(f32(0.2) * f32(0.2)))
+            pw = np.where(pw < f32(0.2), F(pw * F(F(pw * pw) * k_crush)), pw)
+            pw = F(pw * tw)
+            iuv = probe_uv(pidx, ioct, psize)
+            it = h(bilinear_repeat(irr_atlas, iuv[0], iuv[1], layer))
+            for c in range(3):
+                irr[c] = np.where(live, F(irr[c] + F(it[..., c] * pw)), irr[c])
+            weight = np.where(live, F(weight + pw), weight)
+    pi_h = h(f32(3.1415927))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return [np.where(weight == 0, f32(0), F(F(F(irr[c] / weight) * f32(2)) * pi_h)) for c in range(3)]
+
+
 # ---- the Lighting pass, per sub-pass --------------------------------------------------------------------------------------
 class Frame:
     def __init__(self, W, Hh, seed, sun_mode, gi, sky=False):
@@ -407,54 +457,8 @@ class Frame:
         spacing = np.array([c[1] for c in cascades], dtype=f32)[cs]
         cmin = [np.array([c[0][k] for c in cascades], dtype=f32)[cs] for k in range(3)]
 
-        irr_atlas = unpack_b10g11r11(self.f.arrays["probe_irr"])          # (32, 256, 224, 3)
-        depth_atlas = self.f.arrays["probe_depth"].astype(f32)             # (32, 384, 384, 2)
-        validity = self.f.arrays["probe_val"]                              # (32, 32, 32) u8
-        psize = (5, 6)                                                     # irradiance_cache.cpp:298-299
-
-        ps = [F(F(loc[k] - cmin[k]) / spacing) for k in range(3)]
-        mp = [np.floor(p) for p in ps]
-        alpha = [clamp01(F(ps[k] - mp[k])) for k in range(3)]
-        irr = [np.zeros(shape, dtype=f32) for _ in range(3)]
-        weight = np.zeros(shape, dtype=f32)
-        ioct = octahedral_coordinates(Nh)
-        for i in range(8):
-            off = [f32(i & 1), f32((i >> 1) & 1), f32((i >> 2) & 1)]
-            pl = [F(mp[k] + off[k]) for k in range(3)]
-            to_probe = [F(pl[k] - ps[k]) for k in range(3)]
-            dist = F(length3(to_probe) * spacing)
-            pf = [pl[0], F(pl[1] + F(cs.astype(f32) * f32(8))), pl[2]]
-            with np.errstate(invalid="ignore"):
-                pidx = [np.where(p > 0, p, f32(0)).astype(np.int64) for p in pf]   # float -> uint: NaN / negative -> 0
-            inr = (pidx[0] < 32) & (pidx[1] < 32) & (pidx[2] < 32)
-            val = np.where(inr, validity[np.minimum(pidx[2], 31), np.minimum(pidx[1], 31), np.minimum(pidx[0], 31)], 0)
-            live = val != 0
-            tri = [np.maximum(f32(0.001), F(F(F(f32(1) - alpha[k]) * F(f32(1) - off[k])) + F(alpha[k] * off[k]))) for k in range(3)]
-            tw = F(F(tri[0] * tri[1]) * tri[2])
-            layer = np.minimum(pidx[2], 31)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                doct = octahedral_coordinates([F(-t) for t in to_probe])
-                duv = probe_uv(pidx, doct, (10, 10))
-                dt = h(bilinear_repeat(depth_atlas, np.nan_to_num(duv[0]), np.nan_to_num(duv[1]), layer))
-                dx, dy = dt[..., 0], dt[..., 1]
-                variance = np.abs(h(h(dx * dx) - dy))
-                v = F(dist - dx)
-                cheb = F(variance / F(variance + F(v * v)))
-                cheb = np.maximum(F(F(cheb * cheb) * cheb), f32(0))
-                cheb = np.where(dist > dx, cheb, f32(1))
-                pw = np.maximum(f32(0.05), cheb)
-                pw = np.maximum(f32(0.000001), pw)
-                k_crush = F(f32(1) / F(f32(0.2) * f32(0.2)))
-                pw = np.where(pw < f32(0.2), F(pw * F(F(pw * pw) * k_crush)), pw)
-                pw = F(pw * tw)
-                iuv = probe_uv(pidx, ioct, psize)
-                it = h(bilinear_repeat(irr_atlas, iuv[0], iuv[1], layer))
-                for c in range(3):
-                    irr[c] = np.where(live, F(irr[c] + F(it[..., c] * pw)), irr[c])
-                weight = np.where(live, F(weight + pw), weight)
-        pi_h = h(f32(3.1415927))
-        with np.errstate(invalid="ignore", divide="ignore"):
-            irr = [np.where(weight == 0, f32(0), F(F(F(irr[c] / weight) * f32(2)) * pi_h)) for c in range(3)]
+        irr = sample_cascade(loc, Nh, cs, cmin, spacing, unpack_b10g11r11(self.f.arrays["probe_irr"]), self.f.arrays["probe_depth"].astype(f32),
+                             self.f.arrays["probe_val"])
         irr_h = [h(x) for x in irr]
         b = brdf([h(c) for c in self.base], Nh, h(self.rough), h(self.metal), Nh, V, h)
         ex = np.float64(0.314159).astype(np.float16).astype(f32)
@@ -478,8 +482,14 @@ class Frame:
         sd = np.array(self.sun.direction_and_tan_size[:3], dtype=f32)
         sn = normalize3([sd[0], sd[1], sd[2]])
         sun = [F(-x) for x in sn]
-        lut_v = self.f.arrays["sky_v"].astype(f32)
-        lut_t = self.f.arrays["sky_t"].astype(f32)
+        rgb = sky_color(ray, sun, self.f.arrays["sky_v"].astype(f32), self.f.arrays["sky_t"].astype(f32))
+        return [h(c) for c in rgb]
+
+
+def sky_color(ray, sun, lut_v, lut_t):
+    """get_sky_color (sky_unified.slang:137-166 with :54-135): ray, sun = 3 fp32 arrays / scalars each; returns 3 fp32 arrays"""
+    sx = np.asarray(ray[0], f32)
+    if True:
 
         PI = f32(3.14159265358)
         ground, atmosphere = f32(6.360), f32(6.460)
@@ -532,7 +542,7 @@ class Frame:
         out = []
         for ch in range(3):
             sl = np.where(applied, np.where(hit_t >= 0, f32(0), F(s * trans[..., ch])), s)
-            out.append(h(F(F(F(lum[..., ch] + sl) * f32(20.0)) * f32(1.0))))
+            out.append(F(F(F(lum[..., ch] + sl) * f32(20.0)) * f32(1.0)))
         return out
 
 
@@ -1551,33 +1561,38 @@ def _pick(v, k):  # v: (N, 3), k: (N,) -> (N,)
     return np.take_along_axis(v, k[:, None], axis=1)[:, 0]
 
 
-def rt_any_hit(arrays, tris, pad, o, d, tmin, tmax, cull_non_opaque):
-    """o, d: (N, 3) fp32; returns (N,) bool: is there an accepted candidate"""
-    n = o.shape[0]
-    hit = np.zeros(n, bool)
-    finite = np.isfinite(o).all(axis=1) & np.isfinite(d).all(axis=1)
-    with np.errstate(all="ignore"):
-        inv = F(f32(1) / d)
-        ad = np.abs(d)
-        kz = np.zeros(n, np.int64)
-        am = ad[:, 0].copy()
-        kz = np.where(ad[:, 1] > am, 1, kz)
-        am = np.where(ad[:, 1] > am, ad[:, 1], am)
-        kz = np.where(ad[:, 2] > am, 2, kz)
-        kx = (kz + 1) % 3
-        ky = (kx + 1) % 3
-        neg = _pick(d, kz) < 0
-        kx, ky = np.where(neg, ky, kx), np.where(neg, kx, ky)
-        dz = _pick(d, kz)
-        Sx, Sy, Sz = F(_pick(d, kx) / dz), F(_pick(d, ky) / dz), F(f32(1) / dz)
-        for t in tris:
-            if cull_non_opaque and t["cutout"]:
-                continue
+class _RtRays:
+    """per-ray set-up of the watertight test (make_ray): reciprocal direction, axis permutation, shear"""
+
+    def __init__(self, o, d, tmin, tmax):
+        n = o.shape[0]
+        self.n, self.o, self.d = n, o, d
+        self.tmin, self.tmax = np.broadcast_to(F(tmin), (n,)).astype(f32), np.broadcast_to(F(tmax), (n,)).astype(f32)
+        self.finite = np.isfinite(o).all(axis=1) & np.isfinite(d).all(axis=1)
+        with np.errstate(all="ignore"):
+            self.inv = F(f32(1) / d)
+            ad = np.abs(d)
+            kz = np.zeros(n, np.int64)
+            am = ad[:, 0].copy()
+            kz = np.where(ad[:, 1] > am, 1, kz)
+            am = np.where(ad[:, 1] > am, ad[:, 1], am)
+            kz = np.where(ad[:, 2] > am, 2, kz)
+            kx = (kz + 1) % 3
+            ky = (kx + 1) % 3
+            neg = _pick(d, kz) < 0
+            self.kx, self.ky, self.kz = np.where(neg, ky, kx), np.where(neg, kx, ky), kz
+            dz = _pick(d, kz)
+            self.Sx, self.Sy, self.Sz = F(_pick(d, self.kx) / dz), F(_pick(d, self.ky) / dz), F(f32(1) / dz)
+
+    def candidates(self, t, pad):
+        """(candidate mask, t, b1, b2, front) of triangle record `t`: slab test of its padded box, then Woop / Benthin / Wald"""
+        o, kx, ky, kz, Sx, Sy, Sz = self.o, self.kx, self.ky, self.kz, self.Sx, self.Sy, self.Sz
+        with np.errstate(all="ignore"):
             v = t["v"]
             lo, hi = F(v.min(axis=0) - pad), F(v.max(axis=0) + pad)
-            tn, tf = np.full(n, f32(tmin)), np.full(n, f32(tmax))
+            tn, tf = self.tmin.copy(), self.tmax.copy()
             for c in range(3):
-                t0, t1 = F(F(lo[c] - o[:, c]) * inv[:, c]), F(F(hi[c] - o[:, c]) * inv[:, c])
+                t0, t1 = F(F(lo[c] - o[:, c]) * self.inv[:, c]), F(F(hi[c] - o[:, c]) * self.inv[:, c])
                 tn = np.fmax(tn, np.fmin(t0, t1))
                 tf = np.fmin(tf, np.fmax(t0, t1))
             box = tn <= tf
@@ -1594,11 +1609,45 @@ def rt_any_hit(arrays, tris, pad, o, d, tmin, tmax, cull_non_opaque):
             det = F(F(U + V) + Wd)
             T = F(F(F(U * F(Sz * Akz)) + F(V * F(Sz * Bkz))) + F(Wd * F(Sz * Ckz)))
             tt = F(T / det)
-            cand = finite & box & ~mixed & (det != 0) & (tt > f32(tmin)) & (tt < f32(tmax))
-            if t["cutout"] and cand.any():
-                cand = cand & rt_cutout_accepts(arrays, t, F(V / det), F(Wd / det))
-            hit |= cand
+            cand = self.finite & box & ~mixed & (det != 0) & (tt > self.tmin) & (tt < self.tmax)
+            return cand, tt, F(V / det), F(Wd / det), det > 0
+
+
+def rt_any_hit(arrays, tris, pad, o, d, tmin, tmax, cull_non_opaque, cull_front=False):
+    """o, d: (N, 3) fp32; returns (N,) bool: is there an accepted candidate"""
+    rays = _RtRays(o, d, tmin, tmax)
+    hit = np.zeros(rays.n, bool)
+    for t in tris:
+        if cull_non_opaque and t["cutout"]:
+            continue
+        cand, tt, b1, b2, front = rays.candidates(t, pad)
+        if cull_front:
+            cand = cand & ~front
+        if t["cutout"] and cand.any():
+            cand = cand & rt_cutout_accepts(arrays, t, b1, b2)
+        hit |= cand
     return hit
+
+
+def rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax):
+    """RAY_FLAG_NONE: per ray the accepted candidate of smallest t, ties to the smallest (primitive, triangle).
+    Returns (index into tris or -1, t, b1, b2, front)."""
+    rays = _RtRays(o, d, tmin, tmax)
+    n = rays.n
+    best = np.full(n, -1, np.int64)
+    bt, bb1, bb2 = np.zeros(n, f32), np.zeros(n, f32), np.zeros(n, f32)
+    bfront = np.zeros(n, bool)
+    bprim, btri = np.full(n, 1 << 40, np.int64), np.full(n, 1 << 40, np.int64)
+    for i, t in enumerate(tris):
+        cand, tt, b1, b2, front = rays.candidates(t, pad)
+        better = cand & ((best < 0) | (tt < bt) | ((tt == bt) & ((t["primitive"] < bprim) | ((t["primitive"] == bprim) & (t["triangle"] < btri)))))
+        if t["cutout"] and better.any():
+            better = better & rt_cutout_accepts(arrays, t, b1, b2)
+        best = np.where(better, i, best)
+        bt, bb1, bb2 = np.where(better, tt, bt), np.where(better, b1, bb1), np.where(better, b2, bb2)
+        bfront = np.where(better, front, bfront)
+        bprim, btri = np.where(better, t["primitive"], bprim), np.where(better, t["triangle"], btri)
+    return best, bt, bb1, bb2, bfront
 
 
 def rt_cutout_accepts(arrays, t, b1, b2):
@@ -1690,6 +1739,154 @@ def sun_shadow_mask(arrays, view, sun, depth, normals16, noise):
     return np.where(traced, mask, f32(1)).astype(f32).reshape(Hh, W)
 
 
+def fd_general(base, n, rough, metal, l, v, rnd):
+    """Fd(surface, l, v) of brdf.slangi:58-82 / brdf.glsl:65-89 (the diffuse half of brdf() above)"""
+    r = rnd
+    one = r(f32(1.0))
+    diff = [r(r(base[i] * r(one - r(f32(0.04)))) * r(one - metal)) for i in range(3)]
+    hv = normalize3([r(v[i] + l[i]) for i in range(3)], r)
+    dn = lambda a, b: r(r(r(a[0] * b[0]) + r(a[1] * b[1])) + r(a[2] * b[2]))
+    NoV = np.abs(r(dn(n, v) + r(f32(1e-5))))
+    NoL = dn(n, l)
+    dark = NoL <= 0
+    c01 = lambda x: np.fmin(np.fmax(x, f32(0)), f32(1))
+    NoL, LoH = c01(NoL), c01(dn(l, hv))
+    f90 = r(r(f32(0.5)) + r(r(r(r(f32(2.0)) * rough) * LoH) * LoH))
+    schlick1 = lambda u: r(one + r(r(f90 - one) * pow5(c01(r(one - u)), r)))
+    fdv = r(r(schlick1(NoL) * schlick1(NoV)) * r(one / r(f32(3.1415927))))
+    return [np.where(dark, f32(0), r(diff[i] * fdv)) for i in range(3)]
+
+
+def rt_trace_gi(arrays, tris, pad, o, d, tmin, tmax, sun, sky_v, sky_t, noise, dx, dy):
+    """TraceRay(RAY_FLAG_NONE, RAY_TYPE_GI) with remaining_bounces = 0: the closest-hit stage of gltf_basic_pbr.slang:372-520 or the miss stage
+    of sky_unified.slang:227-230.  o, d: (N, 3); dx, dy: DispatchRaysIndex().xy per ray.  Returns (irradiance (N, 3) fp32, ray_distance (N,))."""
+    n = o.shape[0]
+    best, t, b1, b2, front = rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax)
+    irr, dist = np.zeros((n, 3), f32), np.zeros(n, f32)
+    finite = np.isfinite(o).all(axis=1) & np.isfinite(d).all(axis=1)
+    miss = (best < 0) & finite
+    sd = [f32(sun.direction_and_tan_size[k]) for k in range(4)]
+    if miss.any():  # get_sky_color(WorldRayDirection(), sun_light.direction_and_tan_size.xyz, ...): the direction as stored
+        with np.errstate(all="ignore"):
+            sc = sky_color([d[miss, 0], d[miss, 1], d[miss, 2]], sd[:3], sky_v.astype(f32), sky_t.astype(f32))
+        for c in range(3):
+            irr[miss, c] = sc[c]
+    light = normalize3([h(F(-sd[k])) for k in range(3)], h)
+    mt = arrays.get("material_textures")
+    for ti in np.unique(best[best >= 0]):
+        tr = tris[int(ti)]
+        sel = np.nonzero(best == ti)[0]
+        prim = arrays["primitives"][tr["primitive"]]
+        mat = arrays["materials"][int(prim["material"])]
+        vd = arrays["vertex_data"][tr["vertices"]]
+        pos = arrays["positions"][tr["vertices"]].astype(f32)
+        B1, B2 = b1[sel], b2[sel]
+        B0 = F(F(f32(1) - B1) - B2)
+        mix3 = lambda a0, a1, a2: F(F(F(B0 * f32(a0)) + F(B1 * f32(a1))) + F(B2 * f32(a2)))
+        with np.errstate(all="ignore"):
+            normal = [mix3(vd["normal"][0][k], vd["normal"][1][k], vd["normal"][2][k]) for k in range(3)]
+            uv = [mix3(vd["texcoord"][0][k], vd["texcoord"][1][k], vd["texcoord"][2][k]) for k in range(2)]
+            colour = []
+            for k in range(4):  # unpackUnorm4x8ToHalf, float * half4 sums in fp32, packUnorm4x8 (truncating), unpacked again
+                u = [h(h(f32((int(c) >> (8 * k)) & 0xff)) / h(255.0)) for c in vd["color"]]
+                cc = mix3(u[0], u[1], u[2])
+                prod = h(h(cc) * h(255.0))
+                byte = np.where(prod > 0, np.floor(prod), 0).astype(np.int64) & 0xff
+                colour.append(h(h(byte.astype(f32)) / h(255.0)))
+            mp = [mix3(pos[0][k], pos[1][k], pos[2][k]) for k in range(3)]
+            mdl = prim["model"].astype(f32)
+            loc = np.stack([F(F(F(F(mdl[k] * mp[0]) + F(mdl[4 + k] * mp[1])) + F(mdl[8 + k] * mp[2])) + F(mdl[12 + k] * f32(1))) for k in range(3)], axis=-1)
+            texel = {}
+            for slot, (key, col) in enumerate((("base_color_texel", 0), (None, None), ("data_texel", 2), ("emission_texel", 3))):
+                if key is None:
+                    continue
+                tx = np.broadcast_to(np.array(mat[key], f32), sel.shape + (4,))
+                if mt is not None and len(arrays.get("textures", [])):
+                    tex_i = int(mt[int(prim["material"])][slot])
+                    if tex_i != _abi.TEXTURE_NONE:
+                        tx = sample_bias(arrays["textures"][tex_i], uv, None, None, 0.0, explicit_lod=0.0)  # SampleLevel(v.texcoord, 0)
+                texel[key] = tx
+            base = [h(F(F(texel["base_color_texel"][..., c] * f32(mat["base_color_tint"][c])) * colour[c])) for c in range(3)]
+            nh = [h(x) for x in normal]  # no normal map in the ray-traced path, and not normalised
+            rough = h(h(texel["data_texel"][..., 1]) * h(f32(mat["roughness_factor"])))
+            metal = h(h(texel["data_texel"][..., 2]) * h(f32(mat["metalness_factor"])))
+            emission = [h(h(texel["emission_texel"][..., c]) * h(f32(mat["emission_factor"][c]))) for c in range(3)]
+            brdf_result = fd_general(base, nh, rough, metal, light, nh, h)
+            ndotl = np.fmin(np.fmax(h(h(h(light[0] * nh[0]) + h(light[1] * nh[1])) + h(light[2] * nh[2])), f32(0)), f32(1))
+            shadow = np.zeros(sel.shape, f32)
+            lit = ndotl > 0
+            if lit.any():
+                nz = rt_noise(noise, dx[sel][lit] % 128, dy[sel][lit] % 128)
+                sdir = np.stack(normalize3([F(light[k] + F(nz[:, k] * sd[3])) for k in range(3)]), axis=-1)
+                # ACCEPT_FIRST_HIT_AND_END_SEARCH | CULL_NON_OPAQUE | CULL_FRONT_FACING_TRIANGLES
+                occluded = rt_any_hit(arrays, tris, pad, loc[lit], sdir, 0.05, 100000.0, cull_non_opaque=True, cull_front=True)
+                shadow[lit] = np.where(occluded, f32(0), f32(1))
+            for c in range(3):
+                v = F(F(F(F(brdf_result[c] * f32(sun.color[c])) * ndotl) * shadow) + emission[c])
+                irr[sel, c] = np.where(front[sel], v, f32(0))  # HIT_KIND_TRIANGLE_BACK_FACE: black ...
+            dist[sel] = np.where(front[sel], t[sel], F(t[sel] * f32(-1)))  # ... and a negative distance
+    return irr, dist
+
+
+def rtgi_trace(arrays, view, sun, sky_v, sky_t, depth, normals16, noise):
+    """rtgi.rt.slang:56-110 -> (ray_buffer, ray_irradiance) as (H, W, 4) float16; texels the generator skips stay 0"""
+    Hh, W = depth.shape
+    tris, pad = rt_world_triangles(arrays)
+    ys, xs = np.meshgrid(np.arange(Hh), np.arange(W), indexing="ij")
+    go = ((xs.astype(f32) < f32(view.render_resolution[0])) & (ys.astype(f32) < f32(view.render_resolution[1])) & (depth != 0)).reshape(-1)
+    pos = rt_world_position(view, W, Hh, depth).reshape(-1, 3)
+    nrm = normals16.view(np.float16).astype(f32)[..., :3].reshape(-1, 3)  # as stored: not normalised here
+    with np.errstate(all="ignore"):
+        d = rt_noise(noise, xs % 128, ys % 128).reshape(-1, 3)
+        flip = F(F(F(nrm[:, 0] * d[:, 0]) + F(nrm[:, 1] * d[:, 1])) + F(nrm[:, 2] * d[:, 2])) < 0
+        d = np.where(flip[:, None], F(d * f32(-1)), d)
+    idx = np.nonzero(go)[0]
+    irr, dist = rt_trace_gi(arrays, tris, pad, pos[idx], d[idx], 0.01, 100000.0, sun, sky_v, sky_t, noise, xs.reshape(-1)[idx], ys.reshape(-1)[idx])
+    irr = np.where(np.isnan(irr).any(axis=1)[:, None], f32(0), irr)
+    rb, ri = np.zeros((Hh * W, 4), np.float16), np.zeros((Hh * W, 4), np.float16)
+    with np.errstate(over="ignore"):
+        rb[idx, :3], rb[idx, 3] = d[idx].astype(np.float16), dist.astype(np.float16)
+        ri[idx, :3] = F(irr * f32(0.0031415927)).astype(np.float16)
+    return rb.reshape(Hh, W, 4), ri.reshape(Hh, W, 4)
+
+
+def probe_trace(arrays, cascades, probes, sun, sky_v, sky_t, noise, irr_words, depth_atlas, validity):
+    """probe_tracing.rt.slang:39-106: cascades = [(min xyz, spacing)] x 4, probes (N, 3) -> (N, 20, 20, 4) float16"""
+    tris, pad = rt_world_triangles(arrays)
+    irr_atlas = unpack_b10g11r11(irr_words)
+    out = np.zeros((len(probes), 20, 20, 4), np.float16)
+    tys, txs = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
+    dirs = np.array([[texel_octahedral_direction(tx, ty, 20, 20) for tx in range(20)] for ty in range(20)], f32).reshape(-1, 3)
+    e = h(f32(0.0031415927))
+    for p, (px, py, pz) in enumerate(np.asarray(probes, np.int64)):
+        cascade = py // 8
+        if cascade >= 4:
+            continue
+        cmin, spacing = [f32(v) for v in cascades[cascade][0]], f32(cascades[cascade][1])
+        local = [f32(px), f32(py % 8), f32(pz)]
+        origin = np.array([F(cmin[k] + F(local[k] * spacing)) for k in range(3)], f32)
+        ray_distance = f32(8192.0) if cascade >= 3 else F(f32(cascades[cascade + 1][1]) * f32(4.0))
+        o = np.broadcast_to(origin, (400, 3)).astype(f32)
+        irr, dist = rt_trace_gi(arrays, tris, pad, o, dirs, 0.05, ray_distance, sun, sky_v, sky_t, noise, txs.reshape(-1), tys.reshape(-1))
+        miss = dist == 0
+        if miss.any():
+            if cascade + 1 < 4:
+                nmin, nsp = [f32(v) for v in cascades[cascade + 1][0]], f32(cascades[cascade + 1][1])
+                end = [F(origin[k] + F(dirs[miss, k] * ray_distance)) for k in range(3)]
+                sc = sample_cascade(end, [dirs[miss, 0], dirs[miss, 1], dirs[miss, 2]], np.full(int(miss.sum()), cascade + 1), [np.full(int(miss.sum()), v, f32) for v in nmin],
+                                    np.full(int(miss.sum()), nsp, f32), irr_atlas, depth_atlas.astype(f32), validity)
+                for c in range(3):
+                    irr[miss, c] = sc[c]
+            else:
+                irr[miss] = F(irr[miss] * f32(10.0))
+            dist = np.where(miss, ray_distance, dist)
+        irr = np.where((dist < 0)[:, None], f32(0), irr)
+        with np.errstate(over="ignore", invalid="ignore"):
+            out[p, ..., :3] = h(h(irr) * e).astype(np.float16).reshape(20, 20, 3)
+            out[p, ..., 3] = dist.astype(np.float16).reshape(20, 20)
+    return out
+
+
 def inputs_digest(arrays):
     m = hashlib.sha256()
     for k in sorted(arrays):
@@ -1710,6 +1907,27 @@ def golden_rt():
     mask = sun_shadow_mask(arrays, view.gpu_data, sun.constants, gb["depth"], gb["normals"], noise)
     np.savez_compressed(os.path.join(GOLDEN, f"rt_{W}x{Hh}.npz"), ao=ao, mask=mask, depth=gb["depth"], normals=gb["normals"])
     print("rt ok: occluded", int((ao == 0).sum()), "of", ao.size, "; shadow mask values", np.unique(mask))
+    golden_rt_gi(m, view, sun, noise, gb)
+
+
+def golden_rt_gi(m=None, view=None, sun=None, noise=None, gb=None):
+    """the GI rays on the same scene: one GI ray per pixel (rtgi.rt.slang) and twelve probes of the irradiance cache (probe_tracing.rt.slang),
+    with the sky LUTs, atlases and cascades of tests/util.py: golden_rt_gi_inputs()"""
+    from tests import util
+    W, Hh = 64, 36
+    if m is None:
+        m, view, sun, noise = util.golden_rt_scene()
+        g = np.load(os.path.join(GOLDEN, f"rt_{W}x{Hh}.npz"))
+        gb = {"depth": g["depth"], "normals": g["normals"]}
+    arrays = m.arrays()
+    gi = util.golden_rt_gi_inputs()
+    rb, ri = rtgi_trace(arrays, view.gpu_data, sun.constants, gi["sky_v"], gi["sky_t"], gb["depth"], gb["normals"], noise)
+    trace = probe_trace(arrays, gi["cascades"], gi["probes"], sun.constants, gi["sky_v"], gi["sky_t"], noise, gi["irr"], gi["pdepth"], gi["val"])
+    np.savez_compressed(os.path.join(GOLDEN, f"rt_gi_{W}x{Hh}.npz"), ray_buffer=rb.view(np.uint16), ray_irradiance=ri.view(np.uint16), trace=trace.view(np.uint16))
+    d = rb[..., 3].astype(f32)
+    td = trace[..., 3].astype(f32)
+    print("rt gi ok: rtgi hits", int((d > 0).sum()), "back", int((d < 0).sum()), "misses", int((d == 0).sum()), "; probe rays front", int((td > 0).sum()),
+          "back", int((td < 0).sum()))
 
 
 def main():
@@ -1722,6 +1940,9 @@ def main():
         iso = np.load(os.path.join(GOLDEN, "raster_gbuffer_64x36.npz"))
         print("raster_gbuffer_aniso ok: covered", int((gb["depth"] > 0).sum()), "texels that differ from the isotropic golden:",
               {k: int((gb[k] != iso[k]).any(axis=-1).sum()) if gb[k].ndim == 3 else int((gb[k] != iso[k]).sum()) for k in ("color", "normals", "data", "emission")})
+        return
+    if "--only-rt-gi" in sys.argv:
+        golden_rt_gi()
         return
     if "--only-rt" in sys.argv:
         return golden_rt()
