@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--repack-lpv", action="store_true", help="LPV / cache workloads: lpv_generation = probe_generation = 0, i.e. the library rebuilds its gather copy of the LPV on every "
                     "step (5 us + a launch), as it must when the volumes change every frame; default: the volumes of this benchmark never change, so "
                     "their change counter stays at 1 and the copy made by the first step is kept (config.lpv_gather_copy says which)")
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2], help="one-GPU chain workloads: 2 = the post chain of a frame runs on a second "
+                    "stream beside the lighting of the next one (as the N > 1 loop always does); every frame still completes inside the timed region")
     ap.add_argument("--strict-tonemap", action="store_true", help="chain workloads: the strict composite (codes bit-identical to the oracle) instead of "
                     "SAH_TONEMAP_TOLERANCE_1CODE (within one R8G8B8A8 code of it: north_star's tolerance for the final image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -384,6 +386,11 @@ def main():
 
     tm_flags = 0 if args.strict_tonemap else _abi.TONEMAP_TOLERANCE_1CODE
     pipelined = chain and gather and lib_gather and comm_stream is not None
+    # one GPU, no exchange: the same two-frames-in-flight loop when asked for (--frames-in-flight 2): the post chain of frame i on a second
+    # stream beside the lighting of frame i + 1 (the gathers of PipelinedChain are no-ops without a communicator)
+    if chain and not pipelined and world == 1 and not gather and traced is None and args.frames_in_flight == 2:
+        pipelined = True
+        comm_stream = torch.cuda.Stream(device=dev)
     if pipelined:
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
         pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev),
@@ -561,7 +568,9 @@ def main():
     if chain:
         per_step = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
         kernel_ms_mean, kernel_ms_min = sum(per_step) / len(per_step), per_step[0]
-        kernel_scope = "HIP events around each sah_lighting call of the timed region, on its stream (main kernel + fix-up)"
+        kernel_scope = "HIP events around each sah_lighting call of the timed region, on its stream (main kernel + fix-up)" + (
+            "; two frames in flight: the previous frame's post chain runs beside it on a second stream, so this is not the kernel's time alone"
+            if pipelined and not args.one_work_stream else "")
     else:
         kernel_ms_mean, kernel_ms_min = loop_ms, None
         kernel_scope = ("one pair of HIP events on the launch stream around all K steps of the timed region, / K: everything a sah_lighting call "
@@ -621,6 +630,7 @@ def main():
                 "gather_through": (("sah_allgather_rows (library, direct exchange over peer-mapped memory)" if use_ipc else "sah_allgather_rows (library, RCCL)") if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
                 "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
                 "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
+                "frames_in_flight": 2 if pipelined else 1,
                 "same_workload_on_one_gpu": single_gpu,
                 "traced": traced,
             },

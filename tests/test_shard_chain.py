@@ -195,7 +195,7 @@ def test_hip_chain_through_a_one_rank_communicator():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True), (None, True)])
 def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_streams):
     """Two frames in flight (chain.PipelinedChain: both exchanges on the side stream of a one-rank communicator), a different AO plane
     per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's.
@@ -205,7 +205,8 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
     from tests import util
     if no_split:  # the reversed exchange without ncclCommSplit (grouped point-to-point on the parent communicator)
         monkeypatch.setenv("SAH_COMM_NO_SPLIT", "1")
-    ctx = lib.Context(device=0, rank=0, world=1, comm_id=lib.comm_unique_id())
+    # (no_split None: no communicator at all — bench.py --frames-in-flight 2 on one GPU; the exchanges are no-ops)
+    ctx = lib.Context(device=0, rank=0, world=1, comm_id=None if no_split is None else lib.comm_unique_id())
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     side = torch.cuda.Stream()
     try:

@@ -15,7 +15,8 @@ if os.path.exists(f"{SRC}/roofline_static.json"):
     shutil.copy(f"{SRC}/roofline_static.json", f"{DST}/roofline_static.json")
 for src, dst in (("pmc_rt_cache_tiled.txt", "pmc_rt_cache_tiled.txt"), ("pmc_tonemap.txt", "pmc_tonemap.txt"), ("cpu_baselines.txt", "cpu_baselines.txt"),
                  ("rehearse_n2.json", "rehearse_n2_one_gpu.json"), ("strict_chain.json", "bench_4k_probe_gi_chain_strict_tonemap.json"),
-                 ("repack.json", "bench_4k_deferred_gi_repack_lpv.json")):
+                 ("repack.json", "bench_4k_deferred_gi_repack_lpv.json"), ("chain_fif2.json", "bench_4k_probe_gi_chain_two_frames_in_flight.json"),
+                 ("lpv_chain_fif2.json", "bench_4k_lpv_gi_chain_two_frames_in_flight.json")):
     if os.path.exists(f"{SRC}/{src}"):
         shutil.copy(f"{SRC}/{src}", f"{DST}/{R}_{dst}")
 # other workloads: replace the lines of the workloads that were re-run, keep the rest (the 8K ones come from their own run)

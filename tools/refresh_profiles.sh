@@ -17,6 +17,8 @@ PMC_SCRIPT=tools/bench_passes.py PMC_ARGS="--only tonemap --iters 5" PMC_KERNEL=
 python3 tools/bench_passes.py > $O/passes.txt 2>&1 && echo "passes ok"
 for w in 1080p_64_lights 4k_256_lights 4k_probe_gi_chain 4k_lpv_gi_chain 4k_probe_gi_chain_traced 4k_deferred_gi_random 4k_deferred_gi_produced 8k_deferred_gi 8k_1024_lights_gi; do python3 bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2>> $O/bench.err && echo "$w ok"; done
 python3 bench.py --workload 4k_probe_gi_chain --strict-tonemap --steps 50 --warmup 5 --no-cpu-baseline > $O/strict_chain.json 2>> $O/bench.err && echo "strict chain ok"
+python3 bench.py --workload 4k_probe_gi_chain --frames-in-flight 2 --steps 50 --warmup 5 --no-cpu-baseline > $O/chain_fif2.json 2>> $O/bench.err && echo "two frames in flight ok"
+python3 bench.py --workload 4k_lpv_gi_chain --frames-in-flight 2 --steps 50 --warmup 5 --no-cpu-baseline > $O/lpv_chain_fif2.json 2>> $O/bench.err && echo "two frames in flight (lpv) ok"
 python3 bench.py --repack-lpv --steps 200 --warmup 20 --no-cpu-baseline > $O/repack.json 2>> $O/bench.err && echo "repack ok"
 python3 tools/cpu_baselines.py --seconds 5 > $O/cpu_baselines.txt 2>> $O/bench.err && echo "cpu baselines ok"
 timeout -k 10 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29651 bench.py --gpus 2 --steps 20 --warmup 5 --rehearse-on-one-gpu > $O/rehearse_n2.json 2> $O/rehearse_n2.err && echo "rehearsal ok"
