@@ -11,6 +11,8 @@
 
 namespace sah {
 
+// (non-temporal forms of these loads / stores were measured and lose: off/none 0.0614 -> 0.0686 ms, headline 0.1728 -> 0.1795 ms —
+//  profiles/r3_lpv_pack32_experiment.txt, second table)
 template <int NW> SAH_DEV void load_words(const uint8_t* p, uint32_t (&w)[NW]) {
     if constexpr (NW == 1) {
         w[0] = *reinterpret_cast<const uint32_t*>(p);
