@@ -638,39 +638,114 @@ SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, 
     return pay;
 }
 
-// probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes})
+// Rays that leave neighbouring pixels in unrelated directions (one noise texel each: RTAO, the RTGI rays) would make the lanes of a wave
+// walk different parts of the hierarchy.  The 256 rays of a workgroup are therefore re-dealt before the walk: sorted by the octant and
+// the dominant axis of their direction (a counting sort through LDS; which lane ends up with which ray of a bin is not defined and
+// does not matter — a ray's result goes to the ray's own pixel), so that a wave holds rays that travel the same way.
+constexpr uint32_t kDealBins = 25u;  // 8 octants x 3 dominant axes, and one for the threads without a ray
+struct DealLds {
+    uint32_t count[kDealBins], base[kDealBins];
+    float ray[6][256];
+    uint16_t src[256];
+};
+// every thread of the 256-thread workgroup calls these two, in this order, with barriers of its own in between (deal_clear before
+// trav_init, whose barrier publishes the zeros)
+SAH_DEV void deal_clear(DealLds& L) {
+    if (threadIdx.x < kDealBins) L.count[threadIdx.x] = 0u;
+}
+// in: this thread's ray (has_ray false: none).  out: the ray this thread walks and the thread that made it; false: nothing to walk
+SAH_DEV bool deal_rays(DealLds& L, bool has_ray, float (&o)[3], float (&d)[3], uint32_t& src) {
+    uint32_t key = kDealBins - 1u;
+    if (has_ray) {
+        const float ax = __builtin_fabsf(d[0]), ay = __builtin_fabsf(d[1]), az = __builtin_fabsf(d[2]);
+        const uint32_t major = az > __builtin_fmaxf(ax, ay) ? 2u : (ay > ax ? 1u : 0u);
+        key = ((d[0] < 0.f ? 1u : 0u) | (d[1] < 0.f ? 2u : 0u) | (d[2] < 0.f ? 4u : 0u)) * 3u + major;
+    }
+    const uint32_t rank = atomicAdd(&L.count[key], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < kDealBins; k++) {
+            L.base[k] = sum;
+            sum += L.count[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t slot = L.base[key] + rank;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        L.ray[c][slot] = o[c];
+        L.ray[3 + c][slot] = d[c];
+    }
+    L.src[slot] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x >= L.base[kDealBins - 1u]) return false;  // the slots behind the last ray
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        o[c] = L.ray[c][threadIdx.x];
+        d[c] = L.ray[3 + c][threadIdx.x];
+    }
+    src = L.src[threadIdx.x];
+    return true;
+}
+// thread index -> pixel: a wave is an 8 x 8 pixel square, a workgroup 16 x 16
+SAH_DEV void tile_pixel(uint32_t t, uint32_t& x, uint32_t& y) {
+    x = blockIdx.x * 16u + (t & 7u) + ((t >> 3) & 8u);
+    y = blockIdx.y * 16u + ((t >> 3) & 7u) + ((t >> 4) & 8u);
+}
+
+// probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes}); a workgroup takes 256 consecutive rays
+// of the dispatch and re-deals them by direction (a probe's 400 rays cover the sphere)
 __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ DealLds s_deal;
+    deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= 400u * a.num_probes) return;
-    const uint32_t probe = t / 400u, tx = (t % 400u) % 20u, ty = (t % 400u) / 20u;
-    const uint32_t px = a.probes[3u * probe], py = a.probes[3u * probe + 1u], pz = a.probes[3u * probe + 2u];
-    const uint32_t cascade = py / 8u;
-    float irr[3] = {0.f, 0.f, 0.f}, dist = 0.f;
-    if (cascade < 4u) {  // (cascades[cascade_index] of a 4-entry array: anything else is out of bounds in the shader; nothing is written... see below)
-        const CacheArgs& c = a.cache;
-        const Fn spacing = Fn(c.spacing[cascade]);
-        const F3 local = {Fn((float)px), Fn((float)(py % 8u)), Fn((float)pz)};
-        const F3 origin = F3{Fn(c.cascade_min[cascade][0]), Fn(c.cascade_min[cascade][1]), Fn(c.cascade_min[cascade][2])} + local * spacing;
-        const F3 dir = octahedral_direction(normalized_octahedral_coordinates(tx, ty, 20u, 20u));
-        Fn ray_distance = Fn(8192.f);
-        if (cascade < 3u) ray_distance = Fn(c.spacing[cascade + 1u]) * Fn(4.f);
-        const float o[3] = {origin.x.v, origin.y.v, origin.z.v}, d[3] = {dir.x.v, dir.y.v, dir.z.v};
-        const Ray r = make_ray(o, d, 0.05f, ray_distance.v);
-        GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, tx, ty);
-        if (pay.ray_distance.v == 0.f) {
-            if (cascade + 1u < 4u) pay.irradiance = sample_cascade(c, origin + dir * ray_distance, dir, cascade + 1u);
-            else pay.irradiance = pay.irradiance * Fn(10.f);
-            pay.ray_distance = ray_distance;
-        } else if (pay.ray_distance.v < 0.f) {
-            pay.irradiance = F3(Fn(0.f));
+    const CacheArgs& c = a.cache;
+    auto probe_ray = [&](uint32_t t, uint32_t& probe, uint32_t& tx, uint32_t& ty, uint32_t& cascade, F3& origin) {
+        probe = t / 400u;
+        tx = (t % 400u) % 20u;
+        ty = (t % 400u) / 20u;
+        const uint32_t px = a.probes[3u * probe], py = a.probes[3u * probe + 1u], pz = a.probes[3u * probe + 2u];
+        cascade = py / 8u;
+        if (cascade < 4u) {
+            const F3 local = {Fn((float)px), Fn((float)(py % 8u)), Fn((float)pz)};
+            origin = F3{Fn(c.cascade_min[cascade][0]), Fn(c.cascade_min[cascade][1]), Fn(c.cascade_min[cascade][2])} + local * Fn(c.spacing[cascade]);
         }
-        irr[0] = pay.irradiance.x.v; irr[1] = pay.irradiance.y.v; irr[2] = pay.irradiance.z.v;
-        dist = pay.ray_distance.v;
+    };
+    uint32_t t = blockIdx.x * 256u + threadIdx.x, probe = 0, tx = 0, ty = 0, cascade = 4;
+    F3 origin = F3(Fn(0.f));
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    bool has_ray = false;
+    if (t < 400u * a.num_probes) {
+        probe_ray(t, probe, tx, ty, cascade, origin);
+        has_ray = cascade < 4u;
+        if (has_ray) {
+            const F3 dir = octahedral_direction(normalized_octahedral_coordinates(tx, ty, 20u, 20u));
+            d[0] = dir.x.v; d[1] = dir.y.v; d[2] = dir.z.v;
+            o[0] = origin.x.v; o[1] = origin.y.v; o[2] = origin.z.v;
+        } else {  // (cascades[cascade_index] of a 4-entry array: anything else is out of bounds in the shader; the ABI writes zeros)
+            *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)probe * a.out.slice_pitch + (size_t)ty * a.out.row_pitch + (size_t)tx * 8) = make_uint2(0u, 0u);
+        }
+    }
+    uint32_t src;
+    if (!deal_rays(s_deal, has_ray, o, d, src)) return;
+    t = blockIdx.x * 256u + src;
+    probe_ray(t, probe, tx, ty, cascade, origin);
+    const F3 dir = {Fn(d[0]), Fn(d[1]), Fn(d[2])};
+    Fn ray_distance = Fn(8192.f);
+    if (cascade < 3u) ray_distance = Fn(c.spacing[cascade + 1u]) * Fn(4.f);
+    const Ray r = make_ray(o, d, 0.05f, ray_distance.v);
+    GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, tx, ty);
+    if (pay.ray_distance.v == 0.f) {
+        if (cascade + 1u < 4u) pay.irradiance = sample_cascade(c, origin + dir * ray_distance, dir, cascade + 1u);
+        else pay.irradiance = pay.irradiance * Fn(10.f);
+        pay.ray_distance = ray_distance;
+    } else if (pay.ray_distance.v < 0.f) {
+        pay.irradiance = F3(Fn(0.f));
     }
     const Hn e = Hn::lit(0.0031415927f);
-    const Hn out[4] = {Hn(irr[0]) * e, Hn(irr[1]) * e, Hn(irr[2]) * e, Hn(dist)};
+    const Hn out[4] = {Hn(pay.irradiance.x.v) * e, Hn(pay.irradiance.y.v) * e, Hn(pay.irradiance.z.v) * e, Hn(pay.ray_distance.v)};
     uint2 w;
     w.x = (uint32_t)__builtin_bit_cast(uint16_t, out[0].v) | ((uint32_t)__builtin_bit_cast(uint16_t, out[1].v) << 16);
     w.y = (uint32_t)__builtin_bit_cast(uint16_t, out[2].v) | ((uint32_t)__builtin_bit_cast(uint16_t, out[3].v) << 16);
@@ -680,21 +755,29 @@ __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, con
 // rtgi.rt.slang:56-110
 __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ DealLds s_deal;
+    deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
-    // a wave is an 8 x 8 pixel square (rays of a wave start close together and walk the same boxes for longer), a workgroup 16 x 16
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u), y = blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
-    if (x >= a.width || y >= a.height) return;
-    if (!((float)x < a.res[0] && (float)y < a.res[1])) return;  // any(thread_id >= render_resolution): uint against float
-    const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
-    if (depth == 0.f) return;
-    const uint2 nw = *reinterpret_cast<const uint2*>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x * 8);
-    const H3 normal = {Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.x & 0xffffu))), Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.x >> 16))),
-                       Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.y & 0xffffu)))};  // not normalised (quirk)
-    float o[3];
-    world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
-    F3 dir = load_noise(a.gi.noise, sc.luts, x % 128u, y % 128u);
-    if (dot(to_f(normal), dir).v < 0.f) dir = dir * Fn(-1.0f);
-    const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
+    uint32_t x, y;
+    tile_pixel(threadIdx.x, x, y);
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    bool has_ray = x < a.width && y < a.height && (float)x < a.res[0] && (float)y < a.res[1];  // any(thread_id >= render_resolution): uint against float
+    if (has_ray) {
+        const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+        has_ray = depth != 0.f;
+        if (has_ray) {
+            const uint2 nw = *reinterpret_cast<const uint2*>(a.normals.ptr + (size_t)y * a.normals.pitch + (size_t)x * 8);
+            const H3 normal = {Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.x & 0xffffu))), Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.x >> 16))),
+                               Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(nw.y & 0xffffu)))};  // not normalised (quirk)
+            world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
+            F3 dir = load_noise(a.gi.noise, sc.luts, x % 128u, y % 128u);
+            if (dot(to_f(normal), dir).v < 0.f) dir = dir * Fn(-1.0f);
+            d[0] = dir.x.v; d[1] = dir.y.v; d[2] = dir.z.v;
+        }
+    }
+    uint32_t src;
+    if (!deal_rays(s_deal, has_ray, o, d, src)) return;
+    tile_pixel(src, x, y);  // DispatchRaysIndex of the ray this thread walks now
     const Ray r = make_ray(o, d, 0.01f, 100000.0f);
     GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, x, y);
     if (any_nan(pay.irradiance)) pay.irradiance = F3(Fn(0.f));
@@ -705,23 +788,31 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
         w.y = (uint32_t)f2h(c2) | ((uint32_t)f2h(c3) << 16);
         *reinterpret_cast<uint2*>(const_cast<uint8_t*>(p.ptr) + (size_t)py * p.pitch + (size_t)px * 8) = w;
     };
-    store(a.ray_buffer, x, y, dir.x.v, dir.y.v, dir.z.v, pay.ray_distance.v);
+    store(a.ray_buffer, x, y, d[0], d[1], d[2], pay.ray_distance.v);
     store(a.ray_irradiance, x, y, (pay.irradiance.x * e).v, (pay.irradiance.y * e).v, (pay.irradiance.z * e).v, 0.f);
 }
 
+// rtao.comp.slang:54-102
 __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ DealLds s_deal;
+    deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
-    // a wave is an 8 x 8 pixel square (rays of a wave start close together and walk the same boxes for longer), a workgroup 16 x 16
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u), y = blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
-    if (x >= a.width || y >= a.height) return;
-    const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
-    float o[3];
-    world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
-    const H3 normal = load_normal_h(a.normals, x, y);
-    F3 noise = load_noise(a.noise, sc.luts, x % a.noise_w, y % a.noise_h);
-    if (dot(noise, to_f(normal)).v < 0.0f) noise = noise * Fn(-1.0f);
-    const float d[3] = {noise.x.v, noise.y.v, noise.z.v};
+    uint32_t x, y;
+    tile_pixel(threadIdx.x, x, y);
+    const bool inside = x < a.width && y < a.height;
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (inside) {
+        const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+        world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
+        const H3 normal = load_normal_h(a.normals, x, y);
+        F3 noise = load_noise(a.noise, sc.luts, x % a.noise_w, y % a.noise_h);
+        if (dot(noise, to_f(normal)).v < 0.0f) noise = noise * Fn(-1.0f);
+        d[0] = noise.x.v; d[1] = noise.y.v; d[2] = noise.z.v;
+    }
+    uint32_t src;
+    if (!deal_rays(s_deal, inside, o, d, src)) return;
+    tile_pixel(src, x, y);
     const Ray r = make_ray(o, d, 0.01f, a.max_distance);
     const bool hit = any_hit<true>(bvh, sc, tv, r);
     // every one of the spp rays is this ray (the shader reads the same noise texel for each): ao = spp - spp or spp, exact for spp <= 4096
@@ -730,38 +821,76 @@ __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh,
     *reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)y * a.out.pitch + (size_t)x * 4) = ao;
 }
 
+// directional_light.rt.slang:91-125.  Only the pixels that face the light trace rays (half of a typical frame), each of them
+// num_shadow_samples of them, and an occluded ray ends early: one pixel per lane leaves most lanes idle most of the time.  The traced
+// pixels of a workgroup are therefore compacted into LDS and their (pixel, sample) pairs dealt to the lanes sample by sample — the
+// lanes of a wave hold neighbouring pixels with the same sample's noise offset — and a pixel's unoccluded rays are counted with an
+// LDS atomic: `shadow` is a sum of 1.0s, an exact integer whatever the order.
 __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ float s_origin[3][256];
+    __shared__ uint16_t s_pixel[256];
+    __shared__ uint32_t s_unoccluded[256], s_wave_count[4];
     const Trav tv = trav_init(bvh, s_levels);
-    // a wave is an 8 x 8 pixel square (rays of a wave start close together and walk the same boxes for longer), a workgroup 16 x 16
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u), y = blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
-    if (x >= a.width || y >= a.height) return;
-    float* dst = reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)y * a.out.pitch + (size_t)x * 4);
-    const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+    uint32_t x, y;
+    tile_pixel(threadIdx.x, x, y);
     const F3 L = {Fn(a.L[0]), Fn(a.L[1]), Fn(a.L[2])};
-    const H3 normal = load_normal_h(a.normals, x, y);
-    const Hn ndotl = Hn(nclamp(dot(L, to_f(normal)), Fn(0.f), Fn(1.f)).v);
-    if (depth == 0.0f || !(tof(ndotl) > 0.0f)) {
-        *dst = 1.0f;
-        return;
+    bool traced = false;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (x < a.width && y < a.height) {
+        const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
+        const H3 normal = load_normal_h(a.normals, x, y);
+        const Hn ndotl = Hn(nclamp(dot(L, to_f(normal)), Fn(0.f), Fn(1.f)).v);
+        traced = !(depth == 0.0f || !(tof(ndotl) > 0.0f));
+        if (traced) world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
+        else *reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)y * a.out.pitch + (size_t)x * 4) = 1.0f;
     }
-    float o[3];
-    world_position(a.inv_proj, a.inv_view, a.res, x, y, depth, o);
+    // compaction, pixel order kept: ballot + prefix inside the wave, wave totals through LDS
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long ballot = __ballot(traced);
+    if (lane == 0) s_wave_count[wave] = (uint32_t)__builtin_popcountll(ballot);
+    __syncthreads();
+    uint32_t slot = (uint32_t)__builtin_popcountll(ballot & ((1ull << lane) - 1ull)), num_traced = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t c = s_wave_count[w];
+        slot += w < wave ? c : 0u;
+        num_traced += c;
+    }
+    if (traced) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) s_origin[c][slot] = o[c];
+        s_pixel[slot] = (uint16_t)threadIdx.x;
+        s_unoccluded[slot] = 0u;
+    }
+    __syncthreads();
+    uint32_t num_samples = 0;
+    while ((float)num_samples < a.num_samples) num_samples++;  // the shader's loop condition (num_shadow_samples is a float)
     const Fn phi = Fn(1.618033988749895f);
-    Fn shadow = Fn(0.0f);
-    for (uint32_t i = 0; (float)i < a.num_samples; i++) {
+    const uint32_t items = num_traced * num_samples;
+    for (uint32_t item = threadIdx.x; item < items; item += 256u) {
+        const uint32_t i = item / num_traced, p = item - i * num_traced;  // sample-major: a wave = one sample of consecutive pixels
+        uint32_t px, py;
+        tile_pixel(s_pixel[p], px, py);
+        const float po[3] = {s_origin[0][p], s_origin[1][p], s_origin[2][p]};
         const Fn q = Fn((float)i) / phi;
         const Fn r0x = Fn(2.0f) + q, r0y = Fn(3.0f) + q;
         const Fn fx = r0x - Fn(__builtin_floorf(r0x.v)), fy = r0y - Fn(__builtin_floorf(r0y.v));
         const float offx = __builtin_rintf((fx * Fn(128.0f)).v), offy = __builtin_rintf((fy * Fn(128.0f)).v);
-        const uint32_t nx = to_uint_sat((Fn((float)x) + Fn(offx)).v) % 128u, ny = to_uint_sat((Fn((float)y) + Fn(offy)).v) % 128u;
+        const uint32_t nx = to_uint_sat((Fn((float)px) + Fn(offx)).v) % 128u, ny = to_uint_sat((Fn((float)py) + Fn(offy)).v) % 128u;
         const F3 noise = load_noise(a.noise, sc.luts, nx, ny);
         const F3 dir = normalize(L + noise * Fn(a.tan_size));
         const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
-        const Ray r = make_ray(o, d, 0.01f, 100000.0f);
-        shadow = shadow + Fn(any_hit<false>(bvh, sc, tv, r) ? 0.0f : 1.0f);
+        const Ray r = make_ray(po, d, 0.01f, 100000.0f);
+        if (!any_hit<false>(bvh, sc, tv, r)) atomicAdd(&s_unoccluded[p], 1u);
     }
-    *dst = (shadow / Fn(a.num_samples)).v;
+    __syncthreads();
+    if (threadIdx.x < num_traced) {
+        uint32_t px, py;
+        tile_pixel(s_pixel[threadIdx.x], px, py);
+        const Fn shadow = Fn((float)s_unoccluded[threadIdx.x]);
+        *reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)py * a.out.pitch + (size_t)px * 4) = (shadow / Fn(a.num_samples)).v;
+    }
 }
 
 }  // namespace
