@@ -447,10 +447,17 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
                 if (ctx->irr32) (void)hipFree(ctx->irr32);
                 ctx->irr32 = nullptr;
                 ctx->irr32_bytes = 0;
-                HIP_TRY(ctx, hipMalloc((void**)&ctx->irr32, need));
-                ctx->irr32_bytes = need;
-                ctx->irr32_generation = 0;
+                if (hipMalloc((void**)&ctx->irr32, need) == hipSuccess) {
+                    ctx->irr32_bytes = need;
+                    ctx->irr32_generation = 0;
+                } else {  // no room for the widened copy: the general gather needs none
+                    (void)hipGetLastError();
+                    ctx->irr32 = nullptr;
+                    cache.hot_ok = 0;
+                }
             }
+        }
+        if (cache.hot_ok) {
             const bool reuse = gi.probe_generation != 0 && gi.probe_generation == ctx->irr32_generation &&
                                memcmp(&cache.irradiance, &ctx->irr32_source, sizeof(cache.irradiance)) == 0;
             if (!reuse) {

@@ -40,7 +40,23 @@ bool plane_fmt(const sah_plane* p, uint32_t fmt, uint32_t bpp) {
 }
 }  // namespace
 
+// the row window of sah_rt_set_rows clipped to a plane of `height` rows ((0, 0): every row)
+static void rt_rows(const sah_ctx* ctx, uint32_t height, uint32_t* begin, uint32_t* end) {
+    const bool all = ctx->rt.row_begin == 0 && ctx->rt.row_end == 0;
+    *begin = all ? 0u : (ctx->rt.row_begin < height ? ctx->rt.row_begin : height);
+    *end = all ? height : (ctx->rt.row_end < height ? ctx->rt.row_end : height);
+}
+
 extern "C" {
+
+int sah_rt_set_rows(sah_ctx* ctx, uint32_t row_begin, uint32_t row_end) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (row_end < row_begin) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "row range [%u, %u)", row_begin, row_end);
+    ctx->rt.row_begin = row_begin;
+    ctx->rt.row_end = row_end;
+    return SAH_OK;
+}
+
 
 int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats) {
     SAH_RANGE();
@@ -167,6 +183,7 @@ int sah_rtao(sah_ctx* ctx, const sah_view_data* view, const sah_plane* depth, co
     a.samples = samples_per_pixel;
     a.max_distance = max_ray_distance;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rt_rows(ctx, H, &a.row_begin, &a.row_end);
     HIP_TRY(ctx, launch_rtao(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
 }
@@ -210,6 +227,7 @@ int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_l
     a.tan_size = sun->direction_and_tan_size[3];
     a.num_samples = sun->num_shadow_samples;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rt_rows(ctx, H, &a.row_begin, &a.row_end);
     HIP_TRY(ctx, launch_sun_shadow_mask(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
 }
@@ -295,6 +313,7 @@ int sah_rtgi_trace(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_
     a.res[0] = view->render_resolution[0];
     a.res[1] = view->render_resolution[1];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rt_rows(ctx, H, &a.row_begin, &a.row_end);
     HIP_TRY(ctx, launch_rtgi_trace(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
 }

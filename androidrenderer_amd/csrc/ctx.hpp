@@ -64,6 +64,7 @@ struct sah_ctx {
         sah::RtBvh bvh = {};
         sah::RtScene scene = {};
         bool built = false;
+        uint32_t row_begin = 0, row_end = 0;  // sah_rt_set_rows: the output rows the per-pixel ray generators write ((0, 0) = all)
     } rt;
     struct IpcState {                  // direct exchange (api_ipc.cpp): mailboxes and peer mappings
         bool open = false, connected = false;

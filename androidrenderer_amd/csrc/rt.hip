@@ -688,10 +688,10 @@ SAH_DEV bool deal_rays(DealLds& L, bool has_ray, float (&o)[3], float (&d)[3], u
     src = L.src[threadIdx.x];
     return true;
 }
-// thread index -> pixel: a wave is an 8 x 8 pixel square, a workgroup 16 x 16
-SAH_DEV void tile_pixel(uint32_t t, uint32_t& x, uint32_t& y) {
+// thread index -> pixel: a wave is an 8 x 8 pixel square, a workgroup 16 x 16; the grid's first row of tiles holds row `row_begin`
+SAH_DEV void tile_pixel(uint32_t t, uint32_t row_begin, uint32_t& x, uint32_t& y) {
     x = blockIdx.x * 16u + (t & 7u) + ((t >> 3) & 8u);
-    y = blockIdx.y * 16u + ((t >> 3) & 7u) + ((t >> 4) & 8u);
+    y = (row_begin & ~15u) + blockIdx.y * 16u + ((t >> 3) & 7u) + ((t >> 4) & 8u);
 }
 
 // probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes}); a workgroup takes 256 consecutive rays
@@ -759,9 +759,9 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
     deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
     uint32_t x, y;
-    tile_pixel(threadIdx.x, x, y);
+    tile_pixel(threadIdx.x, a.row_begin, x, y);
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-    bool has_ray = x < a.width && y < a.height && (float)x < a.res[0] && (float)y < a.res[1];  // any(thread_id >= render_resolution): uint against float
+    bool has_ray = x < a.width && y >= a.row_begin && y < a.row_end && (float)x < a.res[0] && (float)y < a.res[1];  // any(thread_id >= render_resolution): uint against float
     if (has_ray) {
         const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
         has_ray = depth != 0.f;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
     }
     uint32_t src;
     if (!deal_rays(s_deal, has_ray, o, d, src)) return;
-    tile_pixel(src, x, y);  // DispatchRaysIndex of the ray this thread walks now
+    tile_pixel(src, a.row_begin, x, y);  // DispatchRaysIndex of the ray this thread walks now
     const Ray r = make_ray(o, d, 0.01f, 100000.0f);
     GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, x, y);
     if (any_nan(pay.irradiance)) pay.irradiance = F3(Fn(0.f));
@@ -799,8 +799,8 @@ __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh,
     deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
     uint32_t x, y;
-    tile_pixel(threadIdx.x, x, y);
-    const bool inside = x < a.width && y < a.height;
+    tile_pixel(threadIdx.x, a.row_begin, x, y);
+    const bool inside = x < a.width && y >= a.row_begin && y < a.row_end;
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (inside) {
         const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh,
     }
     uint32_t src;
     if (!deal_rays(s_deal, inside, o, d, src)) return;
-    tile_pixel(src, x, y);
+    tile_pixel(src, a.row_begin, x, y);
     const Ray r = make_ray(o, d, 0.01f, a.max_distance);
     const bool hit = any_hit<true>(bvh, sc, tv, r);
     // every one of the spp rays is this ray (the shader reads the same noise texel for each): ao = spp - spp or spp, exact for spp <= 4096
@@ -833,11 +833,11 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
     __shared__ uint32_t s_unoccluded[256], s_wave_count[4];
     const Trav tv = trav_init(bvh, s_levels);
     uint32_t x, y;
-    tile_pixel(threadIdx.x, x, y);
+    tile_pixel(threadIdx.x, a.row_begin, x, y);
     const F3 L = {Fn(a.L[0]), Fn(a.L[1]), Fn(a.L[2])};
     bool traced = false;
     float o[3] = {0.f, 0.f, 0.f};
-    if (x < a.width && y < a.height) {
+    if (x < a.width && y >= a.row_begin && y < a.row_end) {
         const float depth = *reinterpret_cast<const float*>(a.depth.ptr + (size_t)y * a.depth.pitch + (size_t)x * 4);
         const H3 normal = load_normal_h(a.normals, x, y);
         const Hn ndotl = Hn(nclamp(dot(L, to_f(normal)), Fn(0.f), Fn(1.f)).v);
@@ -864,14 +864,14 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
         s_unoccluded[slot] = 0u;
     }
     __syncthreads();
-    uint32_t num_samples = 0;
-    while ((float)num_samples < a.num_samples) num_samples++;  // the shader's loop condition (num_shadow_samples is a float)
+    // the shader's loop `for (i = 0; i < num_shadow_samples; i++)` with a float bound in [0, 4096] (host check) runs ceil(bound) times
+    const uint32_t num_samples = a.num_samples > 0.f ? (uint32_t)__builtin_ceilf(a.num_samples) : 0u;
     const Fn phi = Fn(1.618033988749895f);
     const uint32_t items = num_traced * num_samples;
     for (uint32_t item = threadIdx.x; item < items; item += 256u) {
         const uint32_t i = item / num_traced, p = item - i * num_traced;  // sample-major: a wave = one sample of consecutive pixels
         uint32_t px, py;
-        tile_pixel(s_pixel[p], px, py);
+        tile_pixel(s_pixel[p], a.row_begin, px, py);
         const float po[3] = {s_origin[0][p], s_origin[1][p], s_origin[2][p]};
         const Fn q = Fn((float)i) / phi;
         const Fn r0x = Fn(2.0f) + q, r0y = Fn(3.0f) + q;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
     __syncthreads();
     if (threadIdx.x < num_traced) {
         uint32_t px, py;
-        tile_pixel(s_pixel[threadIdx.x], px, py);
+        tile_pixel(s_pixel[threadIdx.x], a.row_begin, px, py);
         const Fn shadow = Fn((float)s_unoccluded[threadIdx.x]);
         *reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)py * a.out.pitch + (size_t)px * 4) = (shadow / Fn(a.num_samples)).v;
     }
@@ -931,15 +931,18 @@ hipError_t launch_probe_trace(const ProbeTraceArgs& a, const RtBvh& bvh, const R
     return hipGetLastError();
 }
 hipError_t launch_rtgi_trace(const RtgiTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtgi_trace, dim3((a.width + 15u) / 16u, (a.height + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
+    if (a.row_end <= a.row_begin) return hipSuccess;
+    hipLaunchKernelGGL(k_rtgi_trace, dim3((a.width + 15u) / 16u, (a.row_end - (a.row_begin & ~15u) + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
     return hipGetLastError();
 }
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtao, dim3((a.width + 15u) / 16u, (a.height + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
+    if (a.row_end <= a.row_begin) return hipSuccess;
+    hipLaunchKernelGGL(k_rtao, dim3((a.width + 15u) / 16u, (a.row_end - (a.row_begin & ~15u) + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
     return hipGetLastError();
 }
 hipError_t launch_sun_shadow_mask(const ShadowMaskArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
-    hipLaunchKernelGGL(k_sun_shadow_mask, dim3((a.width + 15u) / 16u, (a.height + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
+    if (a.row_end <= a.row_begin) return hipSuccess;
+    hipLaunchKernelGGL(k_sun_shadow_mask, dim3((a.width + 15u) / 16u, (a.row_end - (a.row_begin & ~15u) + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
     return hipGetLastError();
 }
 

@@ -65,6 +65,7 @@ struct RtBuildState {
 struct RtaoArgs {
     PlaneArg depth, normals, noise, out;
     uint32_t width, height, noise_w, noise_h;
+    uint32_t row_begin, row_end;  // output rows traced (sah_rt_set_rows)
     float inv_proj[16], inv_view[16];
     float res[2];
     uint32_t samples;
@@ -74,6 +75,7 @@ struct RtaoArgs {
 struct ShadowMaskArgs {
     PlaneArg depth, normals, noise, out;
     uint32_t width, height;
+    uint32_t row_begin, row_end;
     float inv_proj[16], inv_view[16];
     float res[2];
     float L[3];  // normalize(-direction), fp32
@@ -100,6 +102,7 @@ struct RtgiTraceArgs {
     GiArgs gi;
     PlaneArg depth, normals, ray_buffer, ray_irradiance;
     uint32_t width, height;
+    uint32_t row_begin, row_end;
     float inv_proj[16], inv_view[16];
     float res[2];
 };

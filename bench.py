@@ -312,8 +312,6 @@ def main():
 
     traced = None
     if wl.get("traced"):
-        if world > 1:
-            raise SystemExit("the traced workload is a one-GPU workload (the ray generators are not part of the sharded chain yet)")
         from androidrenderer_amd import mesh
         geo_arrays = mesh.to_device(mesh.atrium(8).arrays(), dev)
         geo = mesh.geometry(geo_arrays, [])
@@ -353,11 +351,16 @@ def main():
         rt_stats = ctx.rt_build(geo)
         e[1].record()
 
+        trace_rows = [(0, 0)]  # N > 1: the rows this rank's lighting reads (set below, once the row plan exists); the structure and the probes are replicated
+
         def trace_planes():
             ctx.probe_trace(pt)
             ctx.probe_update(atlases, pt.trace_results, probe_ids.data_ptr(), n_probes)
-            ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
-            ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
+            for r0, r1 in trace_rows:
+                ctx.rt_set_rows(r0, r1)
+                ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
+                ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
+            ctx.rt_set_rows(0, 0)
         trace_planes()  # warm
         torch.cuda.synchronize()
         e[2].record()
@@ -398,8 +401,12 @@ def main():
         if use_ipc:
             pc.register_direct_exchange(allgather_handles)
         sc = pc.sets[0]
+        if traced is not None and world > 1:
+            trace_rows[:] = [r for r in (tuple(sc.plan.lit_rows), tuple(sc.plan.lit_wrap_rows)) if r[1] > r[0]]
 
         def step(i, e0=None, e1=None):
+            if traced is not None:
+                trace_planes()  # on the work stream, in front of this frame's lighting
             pc.submit((e0, e1) if e0 is not None else None)
 
         def drain():
@@ -414,6 +421,8 @@ def main():
         q, per = sc.plan.mip0_rows_per_rank, sc.plan.rows_per_rank
         mip0_bytes, out_bytes = sc.mip0_alloc.view(torch.uint8).view(-1), sc.out_alloc.view(-1)
         mip0_slot_bytes, out_slot_bytes = q * sc.mip0_alloc.shape[1] * 8, per * W * 4
+        if traced is not None and world > 1:
+            trace_rows[:] = [r for r in (tuple(sc.plan.lit_rows), tuple(sc.plan.lit_wrap_rows)) if r[1] > r[0]]
 
         def step(i, e0=None, e1=None):
             if traced is not None:

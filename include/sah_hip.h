@@ -592,6 +592,11 @@ int sah_probe_trace(sah_ctx* ctx, const sah_probe_trace_desc* desc);
 int sah_rtgi_trace(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_constants* sun, const sah_sky_luts* sky, const sah_plane* depth,
                    const sah_plane* normals, const sah_plane* noise, const sah_plane* ray_buffer, const sah_plane* ray_irradiance);
 
+/* Row window of the three per-pixel ray generators (sah_rtao, sah_sun_shadow_mask, sah_rtgi_trace), for frames sharded by rows
+ * (no reference counterpart): from now on they trace and write output rows [row_begin, row_end) only, clipped to the plane; the other
+ * rows keep their contents.  (0, 0) = every row, the state of a new context.  A pixel's result does not depend on the window. */
+int sah_rt_set_rows(sah_ctx* ctx, uint32_t row_begin, uint32_t row_end);
+
 /* Multi-GPU exchange step (no reference counterpart: the reference drives one device, RenderCore/render/backend/render_backend.cpp:135-153;
  * BASELINE.json north_star: "RCCL all-gather over xGMI to reassemble the final image").
  * In-place all-gather of row blocks of `image` over RCCL on the context's stream: rank r owns rows [rows_per_rank*r, rows_per_rank*(r+1))

@@ -621,3 +621,37 @@ def test_hip_gi_generators_reject_bad_arguments(hip_ctx):
     d, keep = case.probe_desc(dv["gi"], 0, 1, dv["noise"], out)
     with pytest.raises(lib.SahError):
         hip_ctx.probe_trace(d)
+
+
+@pytest.mark.gpu
+def test_hip_row_windows_trace_the_same_pixels(hip_ctx):
+    """sah_rt_set_rows: the per-pixel generators write the rows of the window only, and a pixel's result does not depend on the window —
+    three windows (cut inside 16-row tiles) assemble the full-frame planes; (0, 0) restores the whole frame"""
+    import torch
+    case = RtCase(mesh.atrium(1), 80, 45)
+    case.sun.constants.num_shadow_samples = 3.0
+    case.hip_build(hip_ctx)
+    try:
+        full = (case.hip_rtao(hip_ctx, 1, 4.0), case.hip_mask(hip_ctx)) + case.hip_rtgi(hip_ctx)
+        parts = [np.full_like(f, 0) for f in full]
+        for r0, r1 in ((0, 17), (17, 40), (40, 45)):
+            hip_ctx.rt_set_rows(r0, r1)
+            got = (case.hip_rtao(hip_ctx, 1, 4.0), case.hip_mask(hip_ctx)) + case.hip_rtgi(hip_ctx)
+            for k, g in enumerate(got):
+                fill = -7.0 if k < 2 else np.uint16(0x7bff).view(np.float16)  # the test planes' fill: rows outside the window keep it
+                outside = np.ones(45, bool)
+                outside[r0:r1] = False
+                assert (g[outside].view(np.uint32 if k < 2 else np.uint16) == np.array(fill, g.dtype).view(np.uint32 if k < 2 else np.uint16)).all(), (k, r0, r1)
+                parts[k][r0:r1] = g[r0:r1]
+        for k in range(4):
+            # (RTGI planes: texels the generator skips keep the fill in `full` as well)
+            a, b = parts[k].view(np.uint32 if k < 2 else np.uint16), full[k].view(np.uint32 if k < 2 else np.uint16)
+            assert np.array_equal(a, b), f"plane {k}: {int((a != b).sum())} values differ"
+        hip_ctx.rt_set_rows(30, 4000)  # clipped to the plane
+        assert np.array_equal(case.hip_rtao(hip_ctx, 1, 4.0)[30:], full[0][30:])
+        with pytest.raises(Exception):
+            hip_ctx.rt_set_rows(5, 4)
+    finally:
+        hip_ctx.rt_set_rows(0, 0)
+        torch.cuda.synchronize()
+    assert np.array_equal(case.hip_rtao(hip_ctx, 1, 4.0), full[0])
