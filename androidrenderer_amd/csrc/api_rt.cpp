@@ -12,7 +12,7 @@ namespace sah {
 hipError_t launch_rt_scan(const sah_primitive* prims, uint32_t n, uint32_t* tri_base, RtBuildState* st, hipStream_t s);
 hipError_t launch_rt_world(const RtScene& sc, const uint32_t* tri_base, uint32_t total, RtTriangle* out, RtBuildState* st, hipStream_t s);
 hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsigned long long* keys, uint32_t padded, hipStream_t s);
-hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNode* nodes, const RtBvh& bvh, hipStream_t s);
+hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNodeGroup* nodes, const RtBvh& bvh, hipStream_t s);
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 hipError_t launch_sun_shadow_mask(const ShadowMaskArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 hipError_t launch_probe_trace(const ProbeTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
@@ -113,20 +113,20 @@ int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats)
             bvh.pad = S * 0x1p-16f;
             uint32_t count = bvh.num_tris, offset = 0, levels = 0;  // level 0: one box per triangle
             while (bvh.num_tris) {
-                bvh.level_offset[levels] = offset;
+                bvh.level_offset[levels] = offset;  // in groups of four nodes
                 bvh.level_count[levels] = count;
-                offset += count;
+                offset += (count + kRtFanout - 1) / kRtFanout;
                 levels++;
                 if (count == 1) break;
                 count = (count + kRtFanout - 1) / kRtFanout;
             }
             bvh.num_levels = levels;
             if (bvh.num_tris) {
-                if (int rc = ensure(ctx, R_NODES, (size_t)(offset + kRtFanout) * sizeof(RtNode)); rc != SAH_OK) return rc;
+                if (int rc = ensure(ctx, R_NODES, (size_t)offset * sizeof(RtNodeGroup)); rc != SAH_OK) return rc;
                 bvh.tris = (const RtTriangle*)rt.ptr[R_SORTED];
-                bvh.nodes = (const RtNode*)rt.ptr[R_NODES];
+                bvh.nodes = (const RtNodeGroup*)rt.ptr[R_NODES];
                 HIP_TRY(ctx, launch_rt_nodes((const RtTriangle*)rt.ptr[R_UNSORTED], (const unsigned long long*)rt.ptr[R_KEYS], (RtTriangle*)rt.ptr[R_SORTED],
-                                             (RtNode*)rt.ptr[R_NODES], bvh, ctx->stream));
+                                             (RtNodeGroup*)rt.ptr[R_NODES], bvh, ctx->stream));
             }
         }
     }

@@ -230,27 +230,36 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
 // one thread per triangle: moves it into Morton order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
 // meets a triangle's own box (part of the hit definition, sah_hip.h) like any other box
 __global__ __launch_bounds__(256) void k_rt_leaves(const RtTriangle* unsorted, const unsigned long long* keys, uint32_t num_tris, float pad,
-                                                   RtTriangle* sorted, RtNode* nodes) {
+                                                   RtTriangle* sorted, RtNodeGroup* nodes) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= num_tris) return;
     const RtTriangle r = unsorted[(uint32_t)(keys[i] & 0xffffffffull)];
     sorted[i] = r;
     float lo[3], hi[3];
     tri_box(r, pad, lo, hi);
-    nodes[i] = RtNode{{lo[0], lo[1], lo[2]}, hi[0], hi[1], hi[2], 0.f, 0.f};
+    RtNodeGroup& g = nodes[i / kRtFanout];
+    for (int c = 0; c < 3; c++) {
+        g.lo[c][i % kRtFanout] = lo[c];
+        g.hi[c][i % kRtFanout] = hi[c];
+    }
 }
-__global__ __launch_bounds__(256) void k_rt_level(const RtNode* children, uint32_t num_children, RtNode* nodes, uint32_t num_nodes) {
+__global__ __launch_bounds__(256) void k_rt_level(const RtNodeGroup* children, uint32_t num_children, RtNodeGroup* nodes, uint32_t num_nodes) {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x;
     if (n >= num_nodes) return;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    const RtNodeGroup c = children[n];  // (the lanes of a level's last group beyond its node count hold nothing)
     for (uint32_t k = 0; k < kRtFanout; k++) {
-        const uint32_t i = n * kRtFanout + k;
-        if (i >= num_children) break;
-        const RtNode c = children[i];
-        lo[0] = __builtin_fminf(lo[0], c.lo[0]); lo[1] = __builtin_fminf(lo[1], c.lo[1]); lo[2] = __builtin_fminf(lo[2], c.lo[2]);
-        hi[0] = __builtin_fmaxf(hi[0], c.hi0); hi[1] = __builtin_fmaxf(hi[1], c.hi1); hi[2] = __builtin_fmaxf(hi[2], c.hi2);
+        if (n * kRtFanout + k >= num_children) break;
+        for (int a = 0; a < 3; a++) {
+            lo[a] = __builtin_fminf(lo[a], c.lo[a][k]);
+            hi[a] = __builtin_fmaxf(hi[a], c.hi[a][k]);
+        }
     }
-    nodes[n] = RtNode{{lo[0], lo[1], lo[2]}, hi[0], hi[1], hi[2], 0.f, 0.f};
+    RtNodeGroup& g = nodes[n / kRtFanout];
+    for (int a = 0; a < 3; a++) {
+        g.lo[a][n % kRtFanout] = lo[a];
+        g.hi[a][n % kRtFanout] = hi[a];
+    }
 }
 
 // ---- traversal --------------------------------------------------------------------------------------------------------------------
@@ -382,20 +391,22 @@ SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* 2 * kRtMaxLevels word
     __syncthreads();
     return {smem, smem + kRtMaxLevels};
 }
-// bit k: child 4 * node + k of (level, node) exists and the ray's slab test passes its box.  The four boxes are 128 contiguous bytes
-// (the node array ends in four spare entries, so the loads need no predicate)
+// bit k: child 4 * node + k of (level, node) exists and the ray's slab test passes its box.  The four boxes are one 96-byte group
 // `nearest` (optional): among the passing children, the one the ray enters first (the largest index among equals)
 SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, uint32_t level, uint32_t node, uint32_t* nearest = nullptr) {
     const uint32_t first = node * kRtFanout, cnt = tv.cnt[level - 1u];
-    const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + first);
-    float4 q[8];
+    const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + node);
+    float q[6][4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) q[k] = p[k];
+    for (int k = 0; k < 6; k++) {
+        const float4 v = p[k];
+        q[k][0] = v.x; q[k][1] = v.y; q[k][2] = v.z; q[k][3] = v.w;
+    }
     uint32_t m = 0, best = 0;
     float best_t = __builtin_inff();
 #pragma unroll
     for (uint32_t k = 0; k < kRtFanout; k++) {
-        const float lo[3] = {q[2 * k].x, q[2 * k].y, q[2 * k].z}, hi[3] = {q[2 * k].w, q[2 * k + 1].x, q[2 * k + 1].y};
+        const float lo[3] = {q[0][k], q[1][k], q[2][k]}, hi[3] = {q[3][k], q[4][k], q[5][k]};
         float tn;
         const bool pass = first + k < cnt && slab(r, lo, hi, &tn);
         if (pass) m |= 1u << k;
@@ -438,16 +449,31 @@ SAH_DEV bool trav_next(uint32_t top, uint32_t& level, uint32_t& node, unsigned l
 // "is there an accepted candidate" (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH); CULL_NON_OPAQUE: CUTOUT primitives do not exist for this ray.
 // Two nested loops: every lane walks boxes until it stands on a triangle whose padded box the ray passes (or is done), then the lanes
 // that have one test it together.
+// is triangle `i` an accepted candidate of the ray: its own padded box, the watertight test, the flags' culling, the any-hit stage
 template <bool CULL_NON_OPAQUE, bool CULL_FRONT = false>
-SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const Ray& r) {
+SAH_DEV bool accepts(const RtBvh& bvh, const RtScene& sc, const Ray& r, uint32_t i) {
+    if (!r.finite || i >= bvh.num_tris) return false;
+    const RtNodeGroup& g = bvh.nodes[i / kRtFanout];  // level 0: one box per triangle
+    const uint32_t k = i % kRtFanout;
+    const float lo[3] = {g.lo[0][k], g.lo[1][k], g.lo[2][k]}, hi[3] = {g.hi[0][k], g.hi[1][k], g.hi[2][k]};
+    if (!slab(r, lo, hi)) return false;
+    const RtTriangle tr = load_triangle(bvh.tris, i);
+    if (CULL_NON_OPAQUE && (tr.flags & 1u)) return false;
+    Hit h;
+    return woop(r, tr, h) && !(CULL_FRONT && h.front) && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h));
+}
+
+// `occluder` (optional): the triangle that ended the search
+template <bool CULL_NON_OPAQUE, bool CULL_FRONT = false>
+SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const Ray& r, uint32_t* occluder = nullptr) {
     if (!r.finite || bvh.num_tris == 0) return false;
     const uint32_t top = bvh.num_levels - 1u;
     uint32_t level = top, node = 0;  // the top level's single node
     unsigned long long pending = 0;
     bool alive = true;
     if (top == 0) {  // a single triangle: its box is the top node, which nothing has tested
-        const RtNode n = bvh.nodes[0];
-        const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
+        const RtNodeGroup& n = bvh.nodes[0];
+        const float lo[3] = {n.lo[0][0], n.lo[1][0], n.lo[2][0]}, hi[3] = {n.hi[0][0], n.hi[1][0], n.hi[2][0]};
         alive = slab(r, lo, hi);
     }
     while (alive) {
@@ -459,7 +485,10 @@ SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const 
             const RtTriangle tr = load_triangle(bvh.tris, node);
             if (!(CULL_NON_OPAQUE && (tr.flags & 1u))) {
                 Hit h;
-                if (woop(r, tr, h) && !(CULL_FRONT && h.front) && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h))) return true;
+                if (woop(r, tr, h) && !(CULL_FRONT && h.front) && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h))) {
+                    if (occluder) *occluder = node;
+                    return true;
+                }
             }
             alive = trav_next(top, level, node, pending, 0u);
         }
@@ -515,8 +544,8 @@ SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv,
     unsigned long long pending = 0;
     bool alive = true;
     if (top == 0) {
-        const RtNode n = bvh.nodes[0];
-        const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi0, n.hi1, n.hi2};
+        const RtNodeGroup& n = bvh.nodes[0];
+        const float lo[3] = {n.lo[0][0], n.lo[1][0], n.lo[2][0]}, hi[3] = {n.hi[0][0], n.hi[1][0], n.hi[2][0]};
         alive = slab(r, lo, hi);
     }
     while (alive) {
@@ -831,6 +860,10 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
     __shared__ float s_origin[3][256];
     __shared__ uint16_t s_pixel[256];
     __shared__ uint32_t s_unoccluded[256], s_wave_count[4];
+    // the triangle that last occluded a ray of the pixel: the next sample's ray leaves the same point in almost the same direction and is
+    // tried against it before anything else.  Whether a ray is occluded does not depend on which occluder is found, so neither a
+    // stale entry nor the order in which the lanes get here can change a result
+    __shared__ uint32_t s_occluder[256];
     const Trav tv = trav_init(bvh, s_levels);
     uint32_t x, y;
     tile_pixel(threadIdx.x, a.row_begin, x, y);
@@ -862,6 +895,7 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
         for (int c = 0; c < 3; c++) s_origin[c][slot] = o[c];
         s_pixel[slot] = (uint16_t)threadIdx.x;
         s_unoccluded[slot] = 0u;
+        s_occluder[slot] = 0xffffffffu;
     }
     __syncthreads();
     // the shader's loop `for (i = 0; i < num_shadow_samples; i++)` with a float bound in [0, 4096] (host check) runs ceil(bound) times
@@ -882,7 +916,14 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
         const F3 dir = normalize(L + noise * Fn(a.tan_size));
         const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
         const Ray r = make_ray(po, d, 0.01f, 100000.0f);
-        if (!any_hit<false>(bvh, sc, tv, r)) atomicAdd(&s_unoccluded[p], 1u);
+        const uint32_t last = s_occluder[p];
+        bool hit = last != 0xffffffffu && accepts<false>(bvh, sc, r, last);
+        if (!hit) {
+            uint32_t occluder;
+            hit = any_hit<false>(bvh, sc, tv, r, &occluder);
+            if (hit) s_occluder[p] = occluder;
+        }
+        if (!hit) atomicAdd(&s_unoccluded[p], 1u);
     }
     __syncthreads();
     if (threadIdx.x < num_traced) {
@@ -917,7 +958,7 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
     }
     return hipGetLastError();
 }
-hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNode* nodes, const RtBvh& bvh, hipStream_t s) {
+hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNodeGroup* nodes, const RtBvh& bvh, hipStream_t s) {
     if (bvh.num_tris == 0) return hipSuccess;
     hipLaunchKernelGGL(k_rt_leaves, dim3((bvh.num_tris + 255u) / 256u), dim3(256), 0, s, unsorted, keys, bvh.num_tris, bvh.pad, sorted, nodes);
     for (uint32_t l = 1; l < bvh.num_levels; l++)

@@ -26,11 +26,13 @@ struct RtTriangle {
 };
 static_assert(sizeof(RtTriangle) == 48, "RtTriangle layout");
 
-struct RtNode {  // padded box of a group of kRtFanout children
-    float lo[3], hi0;  // hi0 = hi[0]
-    float hi1, hi2, pad0, pad1;
+// The boxes of four sibling nodes (the children of one node of the level above), component by component: what one step of the walk
+// loads, as six 16-byte words with nothing unused in them (a 32-byte box per node had 8 bytes of padding: a quarter of the traffic
+// through the texture path, which is what the walk saturates)
+struct RtNodeGroup {
+    float lo[3][kRtFanout], hi[3][kRtFanout];
 };
-static_assert(sizeof(RtNode) == 32, "RtNode layout");
+static_assert(sizeof(RtNodeGroup) == 96, "RtNodeGroup layout");
 
 struct RtScene {  // device pointers of the sah_scene_geometry given to sah_rt_build
     const float* positions;
@@ -47,8 +49,9 @@ struct RtScene {  // device pointers of the sah_scene_geometry given to sah_rt_b
 
 struct RtBvh {
     const RtTriangle* tris;  // Morton order
-    const RtNode* nodes;     // level 0 first (one padded box per triangle, same index): level L starts at level_offset[L] and has level_count[L]
-                             // nodes, node n covering nodes 4n .. 4n + 3 of level L - 1; the top level has one
+    const RtNodeGroup* nodes;  // level 0 first (one padded box per triangle, same index): level L has level_count[L] nodes in
+                               // ceil(level_count[L] / 4) groups from group level_offset[L] on; node n is lane n % 4 of group n / 4 and
+                               // covers the four nodes of group n of level L - 1; the top level has one node
     uint32_t num_tris, num_levels;
     uint32_t level_offset[kRtMaxLevels], level_count[kRtMaxLevels];
     float pad;  // S * 2^-16 (sah_hip.h "pad")
