@@ -7,4 +7,4 @@ for g in "TA_BUSY_avr GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum" "TA_FLAT_READ_WAVEFRONTS
   timeout -k 10 150 rocprofv3 --pmc $g -d $O/g$i -o pmc --output-format csv -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 --ramp-ms 0 --workload 4k_probe_gi_chain_traced > $O/g$i.log 2>&1 || echo "group $i failed"
   i=$((i+1))
 done
-for k in k_rtao k_sun_shadow_mask k_lighting_tiled; do python3 tools/pmc_summary.py $O $k; done
+for k in k_rtao k_sun_shadow_mask k_probe_trace k_lighting_tiled; do python3 tools/pmc_summary.py $O $k; done

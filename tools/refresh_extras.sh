@@ -7,6 +7,9 @@ O=gpurun_out/refresh_extras
 rm -rf $O; mkdir -p $O
 PMC_ARGS="--no-cpu-baseline --steps 2 --warmup 1 --ramp-ms 0 --workload 4k_probe_gi_chain_traced" PMC_KERNEL=k_rtao bash tools/pmc_collect.sh $O/pmc_rt > $O/pmc_rt.txt 2>&1 && echo "pmc rt ok"
 for k in k_sun_shadow_mask k_probe_trace k_rtgi_trace; do python3 tools/pmc_summary.py $O/pmc_rt $k >> $O/pmc_rt.txt; done
+# texture-addresser load of the same kernels (derived counters: one or two per pass)
+echo "# TA counters (tools/pmc_ta.sh): TA_BUSY_avr is cycles per TA, GRBM_GUI_ACTIVE the sum over the 8 XCDs" >> $O/pmc_rt.txt
+bash tools/pmc_ta.sh >> $O/pmc_rt.txt 2>&1 && echo "pmc ta ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace_traced -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --workload 4k_probe_gi_chain_traced --steps 10 --warmup 3 > $O/ktrace_traced.log 2>&1 && echo "ktrace traced ok"
 timeout -k 10 400 python3 tools/stress_rt.py --cases 40 > $O/stress_rt.txt 2>&1 && echo "stress rt ok"
 timeout -k 10 400 python3 tools/stress_parity.py --seeds 12 > $O/stress_parity.txt 2>&1 && echo "stress parity ok"
