@@ -238,7 +238,10 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
                 if (light_ok) c = point_light_contribution_fast(s, bp, lv, d2, V, pl, redo);
                 if (__any(near && redo)) {
                     const F3 cg = point_light_contribution(s, ws, V, pl);
-                    c = redo ? cg : c;
+                    // (component by component: `c = redo ? cg : c` on the struct goes through scratch memory, 28 bytes a lane, in every iteration)
+                    c.x = redo ? cg.x : c.x;
+                    c.y = redo ? cg.y : c.y;
+                    c.z = redo ? cg.z : c.z;
                 }
                 if (near) sum = sum + c;
             }
