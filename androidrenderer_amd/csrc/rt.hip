@@ -160,7 +160,7 @@ SAH_DEV uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
     return v;
 }
 
-// sort keys: (30-bit Morton code of the box centre) << 32 | running triangle; left-out and padding slots sort to the end
+// sort keys: (30-bit Hilbert index of the box centre) << 32 | running triangle; left-out and padding slots sort to the end
 __global__ __launch_bounds__(256) void k_rt_keys(const RtTriangle* tris, const RtBuildState* st, unsigned long long* keys, uint32_t padded) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= padded) return;
@@ -175,6 +175,28 @@ __global__ __launch_bounds__(256) void k_rt_keys(const RtTriangle* tris, const R
             float f = ext > 0.f ? (centre - bmin) / ext * 1023.0f : 0.f;
             f = __builtin_fminf(__builtin_fmaxf(f, 0.f), 1023.0f);  // (NaN -> 0)
             q[c] = (uint32_t)f;
+        }
+        {  // position along the Hilbert curve through the 1024^3 grid (Skilling's transpose form, then bit-interleaved): groups of four
+           // consecutive triangles, and of four consecutive groups, are tighter than along the Z curve — RTAO 2.26 -> 1.68 ms
+            uint32_t X[3] = {q[0], q[1], q[2]};
+            const uint32_t M = 1u << 9;
+            for (uint32_t Q = M; Q > 1u; Q >>= 1) {
+                const uint32_t P = Q - 1u;
+                for (int i = 0; i < 3; i++) {
+                    if (X[i] & Q) X[0] ^= P;
+                    else {
+                        const uint32_t tt = (X[0] ^ X[i]) & P;
+                        X[0] ^= tt;
+                        X[i] ^= tt;
+                    }
+                }
+            }
+            for (int i = 1; i < 3; i++) X[i] ^= X[i - 1];
+            uint32_t tt = 0;
+            for (uint32_t Q = M; Q > 1u; Q >>= 1)
+                if (X[2] & Q) tt ^= Q - 1u;
+            for (int i = 0; i < 3; i++) X[i] ^= tt;
+            q[0] = X[0]; q[1] = X[1]; q[2] = X[2];
         }
         const uint32_t code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
         key = ((unsigned long long)code << 32) | t;
@@ -478,7 +500,8 @@ SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const 
     }
     while (alive) {
         while (alive && level != 0) {
-            // (entering the nearest child first, as the closest-hit walk does, does not pay here: RTAO unchanged, shadow mask + 4 %)
+            // (entering the nearest child first, as the closest-hit walk does, does not pay here: RTAO + 4 %, shadow mask + 17 %; ascending
+            //  index: shadow mask + 38 %)
             alive = trav_next(top, level, node, pending, children_hit(bvh, tv, r, level, node));
         }
         if (alive) {
