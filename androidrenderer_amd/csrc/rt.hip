@@ -249,7 +249,52 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
     }
 }
 
-// one thread per triangle: moves it into Morton order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
+// Local refinement of the curve order: inside every aligned window of 64 consecutive triangles (one node of level 3 and everything under
+// it) the triangles are re-partitioned top-down by median splits — the window in two along the longest axis of its centres, each half
+// again, down to the groups of four — by one wave, with four segmented 64-key bitonic sorts through shuffles.  The sets of the levels
+// above stay what the curve made them.  (A last window that is not full keeps the curve's order.)
+__global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, unsigned long long* keys, uint32_t num_tris) {
+    const uint32_t lane = threadIdx.x & 63u, window = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if ((unsigned long long)(window + 1u) * 64ull > num_tris) return;  // (uniform over the wave)
+    unsigned long long key = keys[window * 64u + lane];
+    uint32_t idx = (uint32_t)(key & 0xffffffffull);
+    float c[3];
+    {
+        const RtTriangle r = unsorted[idx];
+        for (int a = 0; a < 3; a++)
+            c[a] = __builtin_fminf(__builtin_fminf(r.v0[a], r.v1[a]), r.v2[a]) * 0.5f + __builtin_fmaxf(__builtin_fmaxf(r.v0[a], r.v1[a]), r.v2[a]) * 0.5f;
+    }
+    for (uint32_t seg = 64u; seg > 4u; seg >>= 1) {
+        // longest axis of the segment's centres (segments are aligned runs of `seg` lanes: an xor butterfly stays inside them)
+        float lo[3] = {c[0], c[1], c[2]}, hi[3] = {c[0], c[1], c[2]};
+        for (uint32_t m = 1u; m < seg; m <<= 1)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], (int)m));
+                hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], (int)m));
+            }
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const int axis = ez > __builtin_fmaxf(ex, ey) ? 2 : (ey > ex ? 1 : 0);
+        // sort the 64 lanes by (segment, coordinate on the segment's axis, present position): a bitonic network on (hi, lo) word pairs
+        uint32_t khi = lane / seg, klo = ordered(axis == 2 ? c[2] : (axis == 1 ? c[1] : c[0]));
+        uint32_t ktie = lane;
+        for (uint32_t k = 2u; k <= 64u; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                const uint32_t ohi = (uint32_t)__shfl_xor((int)khi, (int)j), olo = (uint32_t)__shfl_xor((int)klo, (int)j), otie = (uint32_t)__shfl_xor((int)ktie, (int)j);
+                const uint32_t oidx = (uint32_t)__shfl_xor((int)idx, (int)j);
+                const float oc0 = __shfl_xor(c[0], (int)j), oc1 = __shfl_xor(c[1], (int)j), oc2 = __shfl_xor(c[2], (int)j);
+                const bool other_less = ohi < khi || (ohi == khi && (olo < klo || (olo == klo && otie < ktie)));
+                const bool up = (lane & k) == 0u, lower = (lane & j) == 0u;  // the lower lane of a pair keeps the smaller key in an ascending block
+                const bool take = (lower == up) ? other_less : !other_less;
+                if (take) {
+                    khi = ohi; klo = olo; ktie = otie; idx = oidx;
+                    c[0] = oc0; c[1] = oc1; c[2] = oc2;
+                }
+            }
+    }
+    keys[window * 64u + lane] = (key & 0xffffffff00000000ull) | idx;
+}
+
+// one thread per triangle: moves it into curve order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
 // meets a triangle's own box (part of the hit definition, sah_hip.h) like any other box
 __global__ __launch_bounds__(256) void k_rt_leaves(const RtTriangle* unsorted, const unsigned long long* keys, uint32_t num_tris, float pad,
                                                    RtTriangle* sorted, RtNodeGroup* nodes) {
@@ -983,6 +1028,7 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
 }
 hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNodeGroup* nodes, const RtBvh& bvh, hipStream_t s) {
     if (bvh.num_tris == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rt_refine, dim3((bvh.num_tris / 64u + 3u) / 4u + 1u), dim3(256), 0, s, unsorted, const_cast<unsigned long long*>(keys), bvh.num_tris);
     hipLaunchKernelGGL(k_rt_leaves, dim3((bvh.num_tris + 255u) / 256u), dim3(256), 0, s, unsorted, keys, bvh.num_tris, bvh.pad, sorted, nodes);
     for (uint32_t l = 1; l < bvh.num_levels; l++)
         hipLaunchKernelGGL(k_rt_level, dim3((bvh.level_count[l] + 255u) / 256u), dim3(256), 0, s, nodes + bvh.level_offset[l - 1], bvh.level_count[l - 1],
