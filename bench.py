@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
+    ap.add_argument("--watchdog-s", type=float, default=300.0, help="N>1: end the rank when a phase makes no progress for this long (0: never)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
     ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
                     "exchange over peer-mapped memory (sah_ipc_*: every rank copies its rows straight into every peer's buffer; handles go through torch.distributed)")
@@ -210,6 +211,23 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # N > 1: a collective that never completes would leave the launcher waiting for ever.  A watchdog thread ends the rank with a message
+    # naming the phase when nothing has moved for --watchdog-s seconds (phases are marked with beat(); 0 disables it).
+    heart = {"t": time.monotonic(), "phase": "process group"}
+
+    def beat(phase):
+        heart["t"], heart["phase"] = time.monotonic(), phase
+
+    if world > 1 and args.watchdog_s > 0:
+        import threading
+
+        def watch():
+            while True:
+                time.sleep(5.0)
+                if time.monotonic() - heart["t"] > args.watchdog_s:
+                    print(f"[bench] rank {rank}: no progress for {args.watchdog_s:.0f} s in phase '{heart['phase']}' — giving up", file=sys.stderr, flush=True)
+                    os._exit(124)
+        threading.Thread(target=watch, daemon=True).start()
     if rehearsal:
         dist.init_process_group(backend="gloo")
     elif world > 1:
@@ -226,6 +244,7 @@ def main():
     n_lights = wl.get("lights", 0)
     chain = bool(wl.get("chain"))
 
+    beat("inputs")
     # ---- inputs (identical on every rank: generated from fixed seeds) ----------------------------------------------
     lights = None
     if n_lights:
@@ -237,6 +256,7 @@ def main():
     d_arr = fr.device_arrays(dev)
     bytes_per_pixel = fr.bytes_per_pixel()
 
+    beat("library context + communicator")
     # ---- the library context: its own communicator unless --torch-gather ------------------------------------------
     gather = exchange and not args.no_gather
     lib_gather = gather and not args.torch_gather
@@ -498,7 +518,9 @@ def main():
 
     # N > 1: the same workload unsharded on this rank's GPU, timed before the sharded loop — strong scaling of ONE workload can then be
     # read off this line alone (the driver's N = 1 run measures the headline lighting pass, not necessarily this workload)
+    beat("unsharded reference")
     single_gpu = None
+    ref_image = None  # chain workloads: the unsharded frame's final image, to hold the sharded loop's last frames against after the timed region
     if world > 1 or args.force_gather:
         if chain:
             ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1, tonemap_flags=tm_flags)
@@ -524,6 +546,8 @@ def main():
                       "note": "the same workload unsharded on rank 0's GPU, 30 steps, GPU time between two events"}
         del ref_step
         if chain:
+            if gather and lib_gather and traced is None:  # (traced: a rank traces only its own rows of the AO / shadow-mask planes)
+                ref_image = ref.out.clone()
             del ref
         torch.cuda.empty_cache()
 
@@ -536,10 +560,12 @@ def main():
                 k += 1
             drain()
             torch.cuda.synchronize()
+    beat("warm-up")
     for i in range(args.warmup):
         step(i)
     drain()
     torch.cuda.synchronize()
+    beat("timed region")
     if torch_pg:
         dist.barrier()
         torch.cuda.synchronize()
@@ -588,6 +614,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # after the timed region: every rank holds the last frames its loop assembled (both buffer sets of the pipelined loop) against the
+    # unsharded frame it rendered itself before the loop — the gathers moved the right rows to the right places on every rank, or not
+    beat("verification")
+    sharded_equals_unsharded = None
+    if ref_image is not None:
+        outs = [pc.image(args.steps - 1), pc.image(args.steps - 2)] if pipelined and args.steps > 1 else [pc.image(args.steps - 1) if pipelined else sc.out]
+        same = int(all(bool(torch.equal(o, ref_image)) for o in outs))
+        if torch_pg:
+            t = torch.tensor([same], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            same = int(t.item())
+        sharded_equals_unsharded = bool(same)
+        if not same:
+            print(f"[bench] rank {rank}: the sharded loop's final image differs from the unsharded frame", file=sys.stderr)
 
     if rank == 0:
         px = W * H
@@ -641,6 +681,7 @@ def main():
                 "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
                 "frames_in_flight": 2 if pipelined else 1,
                 "same_workload_on_one_gpu": single_gpu,
+                "sharded_equals_unsharded": sharded_equals_unsharded,
                 "traced": traced,
             },
             "roofline": roofline(args.workload, world, achieved, kernel_ms_mean, kernel_ms_min, kernel_scope, bytes_per_pixel * my_px, my_px,

@@ -1,7 +1,11 @@
 """One rank of tests/test_comm_gpu.py::test_two_ranks_on_one_gpu_direct_exchange: a fresh process (nothing has touched the GPU before
 this file runs).  Both ranks share GPU 0 — RCCL refuses two ranks on one device, HIP IPC does not — and run the sharded full chain with
 the direct exchange backend: once step by step, then five frames through PipelinedChain (two work streams, a side stream, two frames
-in flight).  Handles travel between the ranks over a gloo process group.  The final images go to <out_dir>/rank<r>_*.npy."""
+in flight).  Handles travel between the ranks over a gloo process group.  The final images go to <out_dir>/rank<r>_*.npy.
+
+With a sixth argument "rccl" (test_two_rank_chain_through_rccl, needs two GPUs) the same frames run one rank per GPU through the library's
+RCCL communicator instead — the parent communicator for bloom mip 0, the reversed one (ncclCommSplit, or grouped send / recv under
+SAH_COMM_NO_SPLIT=1, which the parent test sets in the environment) for the final image."""
 import os
 import sys
 
@@ -13,6 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, height, out_dir, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+    rccl = len(sys.argv) > 6 and sys.argv[6] == "rccl"
     import torch
     import torch.distributed as dist
     from androidrenderer_amd import _abi, chain, lib
@@ -25,10 +30,15 @@ def main():
         dist.all_gather_object(out, b)
         return out
 
-    torch.cuda.set_device(0)
-    ctx = lib.Context(device=0, rank=rank, world=world, comm_id=None)
+    device = rank if rccl else 0
+    torch.cuda.set_device(device)
+    comm_id = None
+    if rccl:
+        comm_id = allgather(lib.comm_unique_id() if rank == 0 else None)[0]
+    ctx = lib.Context(device=device, rank=rank, world=world, comm_id=comm_id)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    chain.connect_direct_exchange(ctx, allgather)
+    if not rccl:
+        chain.connect_direct_exchange(ctx, allgather)
     f = util.LightingFrame(160, height, seed=37, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_CACHE, flavour="atrium")
     dev = f.device_arrays()
     # 1. the chain step by step, exchanges on the work stream
@@ -36,7 +46,8 @@ def main():
     for t in (sc.lit, sc.aa, sc.mip0_alloc):
         t.fill_(0x7E01)  # an fp16 NaN: a row nobody computed or received shows
     sc.out_alloc.fill_(0x5A)
-    sc.register_direct_exchange(allgather)
+    if not rccl:
+        sc.register_direct_exchange(allgather)
     sc.step()
     ctx.sync()
     torch.cuda.synchronize()
@@ -44,7 +55,8 @@ def main():
     # 2. two frames in flight, a different shadow mask per frame
     side, second = torch.cuda.Stream(), torch.cuda.Stream()
     pc = chain.PipelinedChain(ctx, f, dev, rank, world, side, second)
-    pc.register_direct_exchange(allgather)
+    if not rccl:
+        pc.register_direct_exchange(allgather)
     g = torch.Generator(device="cpu").manual_seed(11)
     masks = [torch.rand((height, 160), generator=g).cuda() for _ in range(5)]
     images_out = {}

@@ -93,15 +93,35 @@ def test_two_ranks_on_one_gpu_direct_exchange(tmp_path, height):
     """A REAL two-rank run on the one-GPU box: two fresh child processes share GPU 0 (HIP IPC allows what RCCL refuses) and exchange bloom
     mip 0 and the final image by storing their rows straight into the peer's buffers (sah_ipc_*).  Every rank's gathered image must equal
     the unsharded chain — the HIP one for all frames, and the oracle's for the first."""
+    _run_chain_children(tmp_path, height, [])
+    _check_chain_children(tmp_path, height)
+
+
+@pytest.mark.parametrize("no_split", [False, True])
+def test_two_rank_chain_through_rccl(tmp_path, no_split):
+    """The same frames, one rank per GPU, through the library's RCCL communicator: bloom mip 0 on the parent communicator, the final image
+    on the reversed one — made by ncclCommSplit, or (SAH_COMM_NO_SPLIT=1) exchanged with grouped ncclSend / ncclRecv — step by step and
+    with two frames in flight on two work streams and a side stream.  This is the loop bench.py runs at N > 1."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round-end 8-GPU node; on the one-GPU box the direct-exchange test above runs the same frames)")
+    _run_chain_children(tmp_path, 97, ["rccl"], {"SAH_COMM_NO_SPLIT": "1"} if no_split else {})
+    _check_chain_children(tmp_path, 97)
+
+
+def _run_chain_children(tmp_path, height, extra, extra_env=None):
+    port = 29300 + (os.getpid() % 500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_child.py"), str(r), "2", str(height), str(tmp_path), str(port)] + extra,
+                              env=env) for r in range(2)]
+    rcs = [p.wait(timeout=300) for p in procs]
+    assert rcs == [0, 0], rcs
+
+
+def _check_chain_children(tmp_path, height):
     import ctypes as C
     import torch
     from androidrenderer_amd import chain
-    port = 29300 + (os.getpid() % 500)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_child.py"), str(r), "2", str(height), str(tmp_path), str(port)], env=env)
-             for r in range(2)]
-    rcs = [p.wait(timeout=300) for p in procs]
-    assert rcs == [0, 0], rcs
     # the unsharded chain in this process
     ctx = lib.Context(device=0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
