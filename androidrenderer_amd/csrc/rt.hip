@@ -249,49 +249,163 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
     }
 }
 
-// Local refinement of the curve order: inside every aligned window of 64 consecutive triangles (one node of level 3 and everything under
-// it) the triangles are re-partitioned top-down by median splits — the window in two along the longest axis of its centres, each half
-// again, down to the groups of four — by one wave, with four segmented 64-key bitonic sorts through shuffles.  The sets of the levels
-// above stay what the curve made them.  (A last window that is not full keeps the curve's order.)
+// Refinement of the curve order, guided by surface area.  The curve knows only box centres: at the seams of a mesh it puts triangles of
+// different planes into one group of four, whose box then has a volume where each plane's group would be flat.  Inside every aligned
+// window of 1024 consecutive triangles (one node of level 5 and everything under it) a workgroup therefore re-partitions the triangles
+// top-down: a segment of S slots is split into its first and second S / 2 along one of nine orders — by box centre, lower or upper corner
+// on x, y or z — whichever has the smallest area(left) x count(left) + area(right) x count(right); each half again, down to the groups of
+// four.  Every order is a bitonic sort of (22-bit quantised coordinate, item) words inside the level's segments in LDS; the halves' boxes
+// are reduced with shuffles.  Triangle sets of the levels above the window stay what the curve made them.  Slots behind the window's last
+// triangle sort last in every order, so the triangles stay a prefix of every segment (the hierarchy is complete: node n exists iff
+// n < count).  Which order wins changes no result (sah_hip.h: any hierarchy culls exactly), only how many boxes a ray meets:
+// sum of node areas / root area of the atrium's 23 808 triangles 31.3 -> 26.6 (tools/experiments/tree_cost.py).
+constexpr uint32_t kRefineWindow = 1024u;
+SAH_DEV float half_area(const float lo[3], const float hi[3]) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return (dx * dy + dy * dz) + dz * dx;
+}
 __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, unsigned long long* keys, uint32_t num_tris) {
-    const uint32_t lane = threadIdx.x & 63u, window = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if ((unsigned long long)(window + 1u) * 64ull > num_tris) return;  // (uniform over the wave)
-    unsigned long long key = keys[window * 64u + lane];
-    uint32_t idx = (uint32_t)(key & 0xffffffffull);
-    float c[3];
-    {
-        const RtTriangle r = unsorted[idx];
-        for (int a = 0; a < 3; a++)
-            c[a] = __builtin_fminf(__builtin_fminf(r.v0[a], r.v1[a]), r.v2[a]) * 0.5f + __builtin_fmaxf(__builtin_fmaxf(r.v0[a], r.v1[a]), r.v2[a]) * 0.5f;
+    __shared__ float s_box[6][kRefineWindow];  // by item = slot in the window on entry; empty items hold (+inf, -inf)
+    __shared__ uint32_t s_idx[kRefineWindow], s_srt[kRefineWindow];
+    __shared__ uint16_t s_perm[kRefineWindow], s_best_perm[kRefineWindow];
+    __shared__ float s_hbox[6][kRefineWindow / 4u];
+    __shared__ uint32_t s_hcnt[kRefineWindow / 4u];
+    __shared__ float s_best[kRefineWindow / 8u];
+    __shared__ uint32_t s_take[kRefineWindow / 8u];
+    __shared__ uint32_t s_bounds[6];
+    const uint32_t base = blockIdx.x * kRefineWindow, tid = threadIdx.x, lane = tid & 63u;
+    if (base >= num_tris) return;
+    const uint32_t n_real = min(kRefineWindow, num_tris - base);
+    if (n_real <= 4u) return;
+    if (tid < 3u) {
+        s_bounds[tid] = 0xffffffffu;
+        s_bounds[3u + tid] = 0u;
     }
-    for (uint32_t seg = 64u; seg > 4u; seg >>= 1) {
-        // longest axis of the segment's centres (segments are aligned runs of `seg` lanes: an xor butterfly stays inside them)
-        float lo[3] = {c[0], c[1], c[2]}, hi[3] = {c[0], c[1], c[2]};
-        for (uint32_t m = 1u; m < seg; m <<= 1)
-            for (int a = 0; a < 3; a++) {
-                lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], (int)m));
-                hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], (int)m));
+    __syncthreads();
+    {
+        float wlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, whi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (uint32_t j = 0; j < 4u; j++) {
+            const uint32_t pos = 4u * tid + j;
+            float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            uint32_t idx = 0;
+            if (pos < n_real) {
+                idx = (uint32_t)(keys[base + pos] & 0xffffffffull);
+                tri_box(unsorted[idx], 0.0f, lo, hi);
             }
-        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-        const int axis = ez > __builtin_fmaxf(ex, ey) ? 2 : (ey > ex ? 1 : 0);
-        // sort the 64 lanes by (segment, coordinate on the segment's axis, present position): a bitonic network on (hi, lo) word pairs
-        uint32_t khi = lane / seg, klo = ordered(axis == 2 ? c[2] : (axis == 1 ? c[1] : c[0]));
-        uint32_t ktie = lane;
-        for (uint32_t k = 2u; k <= 64u; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
-                const uint32_t ohi = (uint32_t)__shfl_xor((int)khi, (int)j), olo = (uint32_t)__shfl_xor((int)klo, (int)j), otie = (uint32_t)__shfl_xor((int)ktie, (int)j);
-                const uint32_t oidx = (uint32_t)__shfl_xor((int)idx, (int)j);
-                const float oc0 = __shfl_xor(c[0], (int)j), oc1 = __shfl_xor(c[1], (int)j), oc2 = __shfl_xor(c[2], (int)j);
-                const bool other_less = ohi < khi || (ohi == khi && (olo < klo || (olo == klo && otie < ktie)));
-                const bool up = (lane & k) == 0u, lower = (lane & j) == 0u;  // the lower lane of a pair keeps the smaller key in an ascending block
-                const bool take = (lower == up) ? other_less : !other_less;
-                if (take) {
-                    khi = ohi; klo = olo; ktie = otie; idx = oidx;
-                    c[0] = oc0; c[1] = oc1; c[2] = oc2;
+            s_idx[pos] = idx;
+            s_perm[pos] = (uint16_t)pos;
+            for (int c = 0; c < 3; c++) {
+                s_box[c][pos] = lo[c];
+                s_box[3 + c][pos] = hi[c];
+                wlo[c] = __builtin_fminf(wlo[c], lo[c]);
+                whi[c] = __builtin_fmaxf(whi[c], hi[c]);
+            }
+        }
+        for (uint32_t m = 1u; m < 64u; m <<= 1)
+            for (int c = 0; c < 3; c++) {
+                wlo[c] = __builtin_fminf(wlo[c], __shfl_xor(wlo[c], (int)m));
+                whi[c] = __builtin_fmaxf(whi[c], __shfl_xor(whi[c], (int)m));
+            }
+        if (lane == 0u)
+            for (int c = 0; c < 3; c++) {
+                atomicMin(&s_bounds[c], ordered(wlo[c]));
+                atomicMax(&s_bounds[3 + c], ordered(whi[c]));
+            }
+    }
+    __syncthreads();
+    float wmin[3], wscale[3];  // quantisation of a coordinate to 22 bits over the window's extent (monotone; ties go by item)
+    for (int c = 0; c < 3; c++) {
+        wmin[c] = unordered(s_bounds[c]);
+        const float ext = unordered(s_bounds[3 + c]) - wmin[c];
+        wscale[c] = ext > 0.f ? 4194303.0f / ext : 0.f;
+    }
+    for (uint32_t S = kRefineWindow; S >= 8u; S >>= 1) {
+        const uint32_t H = S >> 1, nseg = kRefineWindow / S, group = min(H >> 2, 64u);  // threads whose slots lie in one half (4 slots each)
+        for (uint32_t k = 0; k < 9u; k++) {
+            const uint32_t axis = k % 3u, kind = k / 3u;
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t pos = 4u * tid + j, item = s_perm[pos];
+                const float lo = s_box[axis][item], hi = s_box[3u + axis][item];
+                uint32_t q = 0x3fffffu;
+                if (lo <= hi) {
+                    const float v = kind == 0u ? lo * 0.5f + hi * 0.5f : (kind == 1u ? lo : hi);
+                    const float f = __builtin_fminf(__builtin_fmaxf((v - wmin[axis]) * wscale[axis], 0.f), 4194303.0f);  // (NaN -> 0)
+                    q = (uint32_t)f;
+                }
+                s_srt[pos] = (q << 10) | item;
+            }
+            __syncthreads();
+            for (uint32_t kk = 2u; kk <= S; kk <<= 1)
+                for (uint32_t j = kk >> 1; j > 0u; j >>= 1) {
+                    for (uint32_t t = tid; t < kRefineWindow / 2u; t += 256u) {
+                        const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
+                        const uint32_t x = s_srt[i], y = s_srt[i | j];
+                        const bool ascending = kk == S || (i & kk) == 0u;
+                        if ((x > y) == ascending) {
+                            s_srt[i] = y;
+                            s_srt[i | j] = x;
+                        }
+                    }
+                    __syncthreads();
+                }
+            // the box and the triangle count of every half: a thread's four slots lie in one half, and so do `group` neighbouring threads
+            float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t item = s_srt[4u * tid + j] & 1023u;
+                cnt += s_box[0][item] <= s_box[3][item] ? 1u : 0u;
+                for (int c = 0; c < 3; c++) {
+                    lo[c] = __builtin_fminf(lo[c], s_box[c][item]);
+                    hi[c] = __builtin_fmaxf(hi[c], s_box[3 + c][item]);
                 }
             }
+            for (uint32_t m = 1u; m < group; m <<= 1) {
+                for (int c = 0; c < 3; c++) {
+                    lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], (int)m));
+                    hi[c] = __builtin_fmaxf(hi[c], __shfl_xor(hi[c], (int)m));
+                }
+                cnt += (uint32_t)__shfl_xor((int)cnt, (int)m);
+            }
+            // one record per `group` threads: record r covers slots [4 * group * r, 4 * group * (r + 1)); a half is H / (4 * group) records
+            if ((tid & (group - 1u)) == 0u) {
+                const uint32_t r = tid / group;
+                for (int c = 0; c < 3; c++) {
+                    s_hbox[c][r] = lo[c];
+                    s_hbox[3 + c][r] = hi[c];
+                }
+                s_hcnt[r] = cnt;
+            }
+            __syncthreads();
+            if (tid < nseg) {
+                const uint32_t per_half = H / (4u * group);  // 1, or 2 for the 512-slot halves (two waves each)
+                float cost = 0.f;
+                for (uint32_t side = 0; side < 2u; side++) {
+                    float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                    uint32_t bc = 0;
+                    for (uint32_t r = (2u * tid + side) * per_half; r < (2u * tid + side + 1u) * per_half; r++) {
+                        bc += s_hcnt[r];
+                        for (int c = 0; c < 3; c++) {
+                            blo[c] = __builtin_fminf(blo[c], s_hbox[c][r]);
+                            bhi[c] = __builtin_fmaxf(bhi[c], s_hbox[3 + c][r]);
+                        }
+                    }
+                    if (bc != 0u) cost += half_area(blo, bhi) * (float)bc;
+                }
+                const bool take = k == 0u || cost < s_best[tid];
+                if (take) s_best[tid] = cost;
+                s_take[tid] = take ? 1u : 0u;
+            }
+            __syncthreads();
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t pos = 4u * tid + j;
+                if (s_take[pos / S]) s_best_perm[pos] = (uint16_t)(s_srt[pos] & 1023u);
+            }
+            __syncthreads();
+        }
+        for (uint32_t j = 0; j < 4u; j++) s_perm[4u * tid + j] = s_best_perm[4u * tid + j];
+        __syncthreads();
     }
-    keys[window * 64u + lane] = (key & 0xffffffff00000000ull) | idx;
+    for (uint32_t pos = tid; pos < n_real; pos += 256u) keys[base + pos] = (keys[base + pos] & 0xffffffff00000000ull) | s_idx[s_perm[pos]];
 }
 
 // one thread per triangle: moves it into curve order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
@@ -1028,7 +1142,7 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
 }
 hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNodeGroup* nodes, const RtBvh& bvh, hipStream_t s) {
     if (bvh.num_tris == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rt_refine, dim3((bvh.num_tris / 64u + 3u) / 4u + 1u), dim3(256), 0, s, unsorted, const_cast<unsigned long long*>(keys), bvh.num_tris);
+    hipLaunchKernelGGL(k_rt_refine, dim3((bvh.num_tris + kRefineWindow - 1u) / kRefineWindow), dim3(256), 0, s, unsorted, const_cast<unsigned long long*>(keys), bvh.num_tris);
     hipLaunchKernelGGL(k_rt_leaves, dim3((bvh.num_tris + 255u) / 256u), dim3(256), 0, s, unsorted, keys, bvh.num_tris, bvh.pad, sorted, nodes);
     for (uint32_t l = 1; l < bvh.num_levels; l++)
         hipLaunchKernelGGL(k_rt_level, dim3((bvh.level_count[l] + 255u) / 256u), dim3(256), 0, s, nodes + bvh.level_offset[l - 1], bvh.level_count[l - 1],
