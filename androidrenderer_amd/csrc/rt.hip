@@ -260,6 +260,11 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
 // n < count).  Which order wins changes no result (sah_hip.h: any hierarchy culls exactly), only how many boxes a ray meets:
 // sum of node areas / root area of the atrium's 23 808 triangles 31.3 -> 26.6 (tools/experiments/tree_cost.py).
 constexpr uint32_t kRefineWindow = 1024u;
+// which half of a full segment goes second, i.e. is entered first by the any-hit walk (descending child order): 1 = the one with the
+// larger box (a ray is likelier to meet an occluder there: shadow mask 1.65 -> 1.59 ms; the smaller one: 1.90), 0 = the sort's order
+#ifndef SAH_EXP_REFINE_SWAP
+#define SAH_EXP_REFINE_SWAP 1
+#endif
 SAH_DEV float half_area(const float lo[3], const float hi[3]) {
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     return (dx * dy + dy * dz) + dz * dx;
@@ -378,7 +383,8 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
             __syncthreads();
             if (tid < nseg) {
                 const uint32_t per_half = H / (4u * group);  // 1, or 2 for the 512-slot halves (two waves each)
-                float cost = 0.f;
+                float cost = 0.f, area[2] = {0.f, 0.f};
+                uint32_t total = 0;
                 for (uint32_t side = 0; side < 2u; side++) {
                     float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
                     uint32_t bc = 0;
@@ -389,16 +395,28 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
                             bhi[c] = __builtin_fmaxf(bhi[c], s_hbox[3 + c][r]);
                         }
                     }
-                    if (bc != 0u) cost += half_area(blo, bhi) * (float)bc;
+                    if (bc != 0u) {
+                        area[side] = half_area(blo, bhi);
+                        cost += area[side] * (float)bc;
+                    }
+                    total += bc;
                 }
                 const bool take = k == 0u || cost < s_best[tid];
                 if (take) s_best[tid] = cost;
-                s_take[tid] = take ? 1u : 0u;
+#if SAH_EXP_REFINE_SWAP == 1
+                const bool swap = total == S && area[0] > area[1];
+#elif SAH_EXP_REFINE_SWAP == 2
+                const bool swap = total == S && area[0] < area[1];
+#else
+                const bool swap = false;
+#endif
+                s_take[tid] = take ? (swap ? 2u : 1u) : 0u;
             }
             __syncthreads();
             for (uint32_t j = 0; j < 4u; j++) {
                 const uint32_t pos = 4u * tid + j;
-                if (s_take[pos / S]) s_best_perm[pos] = (uint16_t)(s_srt[pos] & 1023u);
+                const uint32_t tk = s_take[pos / S];
+                if (tk) s_best_perm[tk == 2u ? pos ^ H : pos] = (uint16_t)(s_srt[pos] & 1023u);
             }
             __syncthreads();
         }

@@ -191,3 +191,18 @@ for k in (4, 16, 64, 128, 256, 768):
     if k in (64, 256):
         t, leaf, lv = cost(multipass(order, (1,), 1024, 9, 4))
         print(f"{'   + SA refine 1024':32s} internal {t:8.3f}  levels {[round(float(x),2) for x in lv]}")
+
+print("---- fine pass, then coarse passes over the fine pass's clusters")
+fine = multipass(ho, (1,), 1024, 9, 4)
+for clusters in ((64,), (16,), (256,), (64, 16), (256, 64), (256, 64, 16), (1024, 256, 64)):
+    t, leaf, lv = cost(multipass(fine, clusters, 1024, 9, 1))
+    print(f"{'fine + coarse ' + str(clusters):36s} internal {t:8.3f}  levels {[round(float(x),2) for x in lv]}")
+
+print("---- fine, coarse, fine again")
+for clusters in ((64,), (256, 64), (16,)):
+    o2 = multipass(multipass(fine, clusters, 1024, 9, 1), (1,), 1024, 9, 4)
+    t, leaf, lv = cost(o2)
+    print(f"{'fine + coarse ' + str(clusters) + ' + fine':36s} internal {t:8.3f}  levels {[round(float(x),2) for x in lv]}")
+    o3 = multipass(multipass(o2, clusters, 1024, 9, 1), (1,), 1024, 9, 4)
+    t, leaf, lv = cost(o3)
+    print(f"{'   ... + coarse + fine':36s} internal {t:8.3f}  levels {[round(float(x),2) for x in lv]}")
