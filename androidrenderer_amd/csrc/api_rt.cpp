@@ -15,12 +15,13 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
 hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNodeGroup* nodes, const RtBvh& bvh, hipStream_t s);
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 hipError_t launch_sun_shadow_mask(const ShadowMaskArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
+hipError_t launch_noise_dirs(const PlaneArg& noise, const float* luts, float* out, hipStream_t s);
 hipError_t launch_probe_trace(const ProbeTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 hipError_t launch_rtgi_trace(const RtgiTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s);
 }  // namespace sah
 
 namespace {
-enum Slot { R_TRI_BASE, R_STATE, R_UNSORTED, R_SORTED, R_KEYS, R_NODES };
+enum Slot { R_TRI_BASE, R_STATE, R_UNSORTED, R_SORTED, R_KEYS, R_NODES, R_NOISE_DIRS };
 
 int ensure(sah_ctx* ctx, int slot, size_t bytes) {
     auto& r = ctx->rt;
@@ -228,6 +229,10 @@ int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_l
     a.num_samples = sun->num_shadow_samples;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     rt_rows(ctx, H, &a.row_begin, &a.row_end);
+    // every sample of every pixel reads one of 16 384 noise directions: normalised once per call instead of once per ray
+    if (int rc = ensure(ctx, R_NOISE_DIRS, 128u * 128u * 16u); rc != SAH_OK) return rc;
+    a.noise_dirs = static_cast<const float*>(ctx->rt.ptr[R_NOISE_DIRS]);
+    HIP_TRY(ctx, launch_noise_dirs(a.noise, ctx->rt.scene.luts, static_cast<float*>(ctx->rt.ptr[R_NOISE_DIRS]), ctx->stream));
     HIP_TRY(ctx, launch_sun_shadow_mask(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
 }

@@ -59,8 +59,8 @@ struct sah_ctx {
         uint32_t* host_counters = nullptr;  // pinned, 16 words
     } raster;
     struct RtState {                   // acceleration structure of sah_rt_build (api_rt.cpp); buffers grow on demand
-        void* ptr[6] = {};             // tri_base, build state, unsorted triangles, sorted triangles, keys, nodes
-        size_t bytes[6] = {};
+        void* ptr[7] = {};             // tri_base, build state, unsorted triangles, sorted triangles, keys, nodes, noise directions
+        size_t bytes[7] = {};
         sah::RtBvh bvh = {};
         sah::RtScene scene = {};
         bool built = false;

@@ -490,7 +490,7 @@ SAH_DEV Ray make_ray(const float o[3], const float d[3], float tmin, float tmax)
     const float dz = pick(d, kz);
     r.Sx = pick(d, kx) / dz;
     r.Sy = pick(d, ky) / dz;
-    r.Sz = 1.0f / dz;
+    r.Sz = pick(r.inv, kz);  // 1.0f / dz, already there
     return r;
 }
 SAH_DEV bool slab(const Ray& r, const float lo[3], const float hi[3], float* entry = nullptr) {
@@ -694,6 +694,49 @@ SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const 
         }
     }
     return false;
+}
+
+// ---- beams -------------------------------------------------------------------------------------------------------------------------
+// Rays that leave ONE point in nearly one direction (a pixel's sun samples) can share a walk.  A beam holds, per axis, the interval
+// [inv_lo, inv_hi] of the rays' 1 / d — all of one sign, finite — and its slab test evaluates the ray test's own operators on the
+// interval ends: x -> RN(a * x) is monotone for a fixed a, so a ray's RN((lo - o) * inv) lies between the products at the two ends, its
+// entry distance is >= the beam's and its exit distance <= the beam's: every box a ray of the beam passes, the beam passes.  The beam's
+// walk therefore reaches every triangle whose own box any of its rays passes, and there each ray is tested by itself (accepts(): the
+// full hit definition).  No result depends on the beam; it only decides which triangles are looked at.
+#ifndef SAH_EXP_MASK_SKIP
+#define SAH_EXP_MASK_SKIP 0  // timing experiments only: 1 = no beams walked, 2 = no (pixel, sample) pairs walked
+#endif
+struct Beam {
+    float o[3], inv_lo[3], inv_hi[3];
+    float tmin, tmax;
+};
+SAH_DEV bool beam_slab(const Beam& b, const float lo[3], const float hi[3]) {
+    float tn = b.tmin, tf = b.tmax;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a0 = lo[c] - b.o[c], a1 = hi[c] - b.o[c];
+        const float p0 = a0 * b.inv_lo[c], p1 = a0 * b.inv_hi[c], p2 = a1 * b.inv_lo[c], p3 = a1 * b.inv_hi[c];
+        tn = __builtin_fmaxf(tn, __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3)));
+        tf = __builtin_fminf(tf, __builtin_fmaxf(__builtin_fmaxf(p0, p1), __builtin_fmaxf(p2, p3)));
+    }
+    return tn <= tf;
+}
+SAH_DEV uint32_t children_hit_beam(const RtBvh& bvh, const Trav& tv, const Beam& b, uint32_t level, uint32_t node) {
+    const uint32_t first = node * kRtFanout, cnt = tv.cnt[level - 1u];
+    const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + node);
+    float q[6][4];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const float4 v = p[k];
+        q[k][0] = v.x; q[k][1] = v.y; q[k][2] = v.z; q[k][3] = v.w;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kRtFanout; k++) {
+        const float lo[3] = {q[0][k], q[1][k], q[2][k]}, hi[3] = {q[3][k], q[4][k], q[5][k]};
+        if (first + k < cnt && beam_slab(b, lo, hi)) m |= 1u << k;
+    }
+    return m;
 }
 
 // ---- generators -------------------------------------------------------------------------------------------------------------------
@@ -1050,20 +1093,36 @@ __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh,
     *reinterpret_cast<float*>(const_cast<uint8_t*>(a.out.ptr) + (size_t)y * a.out.pitch + (size_t)x * 4) = ao;
 }
 
+// load_noise() of the 128 x 128 texels the sun's shadow samples index, once per call
+__global__ __launch_bounds__(256) void k_noise_dirs(const PlaneArg noise, const float* luts, float* out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, x = t % 128u, y = t / 128u;
+    const F3 v = load_noise(noise, luts, x, y);
+    reinterpret_cast<float4*>(out)[t] = make_float4(v.x.v, v.y.v, v.z.v, 0.f);
+}
+
 // directional_light.rt.slang:91-125.  Only the pixels that face the light trace rays (half of a typical frame), each of them
 // num_shadow_samples of them, and an occluded ray ends early: one pixel per lane leaves most lanes idle most of the time.  The traced
-// pixels of a workgroup are therefore compacted into LDS and their (pixel, sample) pairs dealt to the lanes sample by sample — the
-// lanes of a wave hold neighbouring pixels with the same sample's noise offset — and a pixel's unoccluded rays are counted with an
-// LDS atomic: `shadow` is a sum of 1.0s, an exact integer whatever the order.
+// pixels of a workgroup are therefore compacted into LDS, and a pixel's unoccluded rays are counted with an LDS atomic: `shadow` is a
+// sum of 1.0s, an exact integer whatever the order.  Sample 0 of every traced pixel is walked first, one pixel per lane.  Then
+//   * a pixel whose sample 0 was occluded deals its other samples to the lanes as (pixel, sample) pairs, sample-major — a wave holds
+//     neighbouring pixels with the same sample's noise offset — and each is first tried against the triangle that last occluded a ray of
+//     its pixel (the occluder cache below);
+//   * a pixel whose sample 0 was not — most of them have no occluder at all, and per-ray walks would cross the whole scene once per
+//     sample — walks its other samples as ONE beam (above): what the beam meets is tested ray by ray, and the walk ends early when no
+//     ray of the pixel is left unoccluded.
 __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[2 * kRtMaxLevels];
     __shared__ float s_origin[3][256];
-    __shared__ uint16_t s_pixel[256];
-    __shared__ uint32_t s_unoccluded[256], s_wave_count[4];
+    __shared__ uint16_t s_pixel[256], s_list[2][256];
+    __shared__ uint32_t s_unoccluded[256], s_wave_count[4], s_list_n[2];
     // the triangle that last occluded a ray of the pixel: the next sample's ray leaves the same point in almost the same direction and is
     // tried against it before anything else.  Whether a ray is occluded does not depend on which occluder is found, so neither a
     // stale entry nor the order in which the lanes get here can change a result
     __shared__ uint32_t s_occluder[256];
+    constexpr uint32_t kMaskChunk = 2048u;
+    __shared__ uint16_t s_miss[kMaskChunk], s_off[64];
+    __shared__ uint32_t s_miss_n;
+    if (threadIdx.x < 2u) s_list_n[threadIdx.x] = 0u;
     const Trav tv = trav_init(bvh, s_levels);
     uint32_t x, y;
     tile_pixel(threadIdx.x, a.row_begin, x, y);
@@ -1100,30 +1159,151 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
     __syncthreads();
     // the shader's loop `for (i = 0; i < num_shadow_samples; i++)` with a float bound in [0, 4096] (host check) runs ceil(bound) times
     const uint32_t num_samples = a.num_samples > 0.f ? (uint32_t)__builtin_ceilf(a.num_samples) : 0u;
-    const Fn phi = Fn(1.618033988749895f);
-    const uint32_t items = num_traced * num_samples;
-    for (uint32_t item = threadIdx.x; item < items; item += 256u) {
-        const uint32_t i = item / num_traced, p = item - i * num_traced;  // sample-major: a wave = one sample of consecutive pixels
-        uint32_t px, py;
-        tile_pixel(s_pixel[p], a.row_begin, px, py);
-        const float po[3] = {s_origin[0][p], s_origin[1][p], s_origin[2][p]};
+    // direction of sample i of the pixel (px, py); the noise offsets of the first 64 samples are tabulated (one divide each)
+    auto sample_offset = [](uint32_t i, uint32_t& offx, uint32_t& offy) {
+        const Fn phi = Fn(1.618033988749895f);
         const Fn q = Fn((float)i) / phi;
         const Fn r0x = Fn(2.0f) + q, r0y = Fn(3.0f) + q;
         const Fn fx = r0x - Fn(__builtin_floorf(r0x.v)), fy = r0y - Fn(__builtin_floorf(r0y.v));
-        const float offx = __builtin_rintf((fx * Fn(128.0f)).v), offy = __builtin_rintf((fy * Fn(128.0f)).v);
-        const uint32_t nx = to_uint_sat((Fn((float)px) + Fn(offx)).v) % 128u, ny = to_uint_sat((Fn((float)py) + Fn(offy)).v) % 128u;
-        const F3 noise = load_noise(a.noise, sc.luts, nx, ny);
-        const F3 dir = normalize(L + noise * Fn(a.tan_size));
-        const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
-        const Ray r = make_ray(po, d, 0.01f, 100000.0f);
-        const uint32_t last = s_occluder[p];
-        bool hit = last != 0xffffffffu && accepts<false>(bvh, sc, r, last);
-        if (!hit) {
-            uint32_t occluder;
-            hit = any_hit<false>(bvh, sc, tv, r, &occluder);
-            if (hit) s_occluder[p] = occluder;
+        offx = (uint32_t)__builtin_rintf((fx * Fn(128.0f)).v);  // in [0, 128]: uint(float(px) + off) % 128 is (px + off) % 128, exactly
+        offy = (uint32_t)__builtin_rintf((fy * Fn(128.0f)).v);
+    };
+    if (threadIdx.x < 64u) {
+        uint32_t ox, oy;
+        sample_offset(threadIdx.x, ox, oy);
+        s_off[threadIdx.x] = (uint16_t)(ox | (oy << 8));
+    }
+    __syncthreads();
+    auto sample_dir = [&](uint32_t px, uint32_t py, uint32_t i, float (&d)[3]) {
+        uint32_t offx, offy;
+        if (i < 64u) {
+            const uint32_t w = s_off[i];
+            offx = w & 255u;
+            offy = w >> 8;
+        } else {
+            sample_offset(i, offx, offy);
         }
-        if (!hit) atomicAdd(&s_unoccluded[p], 1u);
+        const uint32_t nx = (px + offx) % 128u, ny = (py + offy) % 128u;
+        const float4 nv = reinterpret_cast<const float4*>(a.noise_dirs)[ny * 128u + nx];
+        const F3 noise = {Fn(nv.x), Fn(nv.y), Fn(nv.z)};
+        const F3 dir = normalize(L + noise * Fn(a.tan_size));
+        d[0] = dir.x.v; d[1] = dir.y.v; d[2] = dir.z.v;
+    };
+    const bool beams = num_samples >= 2u && num_samples <= 33u;  // samples 1 .. n - 1 of a pixel in one 32-bit mask
+    // ---- sample 0, one traced pixel per lane
+    if (threadIdx.x < num_traced && num_samples != 0u) {
+        const uint32_t p = threadIdx.x;
+        uint32_t px, py;
+        tile_pixel(s_pixel[p], a.row_begin, px, py);
+        const float po[3] = {s_origin[0][p], s_origin[1][p], s_origin[2][p]};
+        float d[3];
+        sample_dir(px, py, 0u, d);
+        const Ray r = make_ray(po, d, 0.01f, 100000.0f);
+        uint32_t occluder;
+        const bool hit = any_hit<false>(bvh, sc, tv, r, &occluder);
+        if (hit) s_occluder[p] = occluder;
+        else s_unoccluded[p] = 1u;
+        const uint32_t cls = !hit && beams ? 1u : 0u;
+        s_list[cls][atomicAdd(&s_list_n[cls], 1u)] = (uint16_t)p;
+    }
+    __syncthreads();
+    // ---- pixels whose sample 0 was unoccluded: the other samples as one beam
+    const uint32_t top = bvh.num_levels - 1u;
+#if SAH_EXP_MASK_SKIP != 1
+    for (uint32_t qi = threadIdx.x; qi < s_list_n[1]; qi += 256u) {
+        const uint32_t p = s_list[1][qi];
+        uint32_t px, py;
+        tile_pixel(s_pixel[p], a.row_begin, px, py);
+        const float po[3] = {s_origin[0][p], s_origin[1][p], s_origin[2][p]};
+        Beam b;
+        bool ok = finite3(po) && bvh.num_tris != 0u;
+        for (int c = 0; c < 3; c++) {
+            b.o[c] = po[c];
+            b.inv_lo[c] = __builtin_inff();
+            b.inv_hi[c] = -__builtin_inff();
+        }
+        b.tmin = 0.01f;
+        b.tmax = 100000.0f;
+        for (uint32_t i = 1; i < num_samples; i++) {
+            float d[3];
+            sample_dir(px, py, i, d);
+            for (int c = 0; c < 3; c++) {
+                const float inv = 1.0f / d[c];  // make_ray's
+                ok = ok && __builtin_fabsf(inv) < __builtin_inff() && inv != 0.0f && d[c] == d[c];
+                b.inv_lo[c] = __builtin_fminf(b.inv_lo[c], inv);
+                b.inv_hi[c] = __builtin_fmaxf(b.inv_hi[c], inv);
+            }
+        }
+        for (int c = 0; c < 3; c++) ok = ok && (b.inv_lo[c] > 0.0f) == (b.inv_hi[c] > 0.0f);
+        uint32_t left = (1u << (num_samples - 1u)) - 1u;  // bit i - 1: sample i has met no occluder yet
+        if (ok) {
+            uint32_t level = top, node = 0;
+            unsigned long long pending = 0;
+            bool walking = true;
+            if (top == 0u) {
+                const RtNodeGroup& g = bvh.nodes[0];
+                const float lo[3] = {g.lo[0][0], g.lo[1][0], g.lo[2][0]}, hi[3] = {g.hi[0][0], g.hi[1][0], g.hi[2][0]};
+                walking = beam_slab(b, lo, hi);
+            }
+            while (walking && left != 0u) {
+                while (walking && level != 0u) walking = trav_next(top, level, node, pending, children_hit_beam(bvh, tv, b, level, node));
+                if (walking) {
+                    for (uint32_t m = left; m != 0u; m &= m - 1u) {
+                        const uint32_t i = (uint32_t)__builtin_ctz(m) + 1u;
+                        float d[3];
+                        sample_dir(px, py, i, d);
+                        const Ray r = make_ray(po, d, 0.01f, 100000.0f);
+                        if (accepts<false>(bvh, sc, r, node)) left &= ~(1u << (i - 1u));
+                    }
+                    walking = trav_next(top, level, node, pending, 0u);
+                }
+            }
+        } else {  // (a direction with a zero or a sign change between the samples, a non-finite origin: ray by ray)
+            for (uint32_t i = 1; i < num_samples; i++) {
+                float d[3];
+                sample_dir(px, py, i, d);
+                const Ray r = make_ray(po, d, 0.01f, 100000.0f);
+                if (any_hit<false>(bvh, sc, tv, r)) left &= ~(1u << (i - 1u));
+            }
+        }
+        atomicAdd(&s_unoccluded[p], (uint32_t)__builtin_popcount(left));
+    }
+#endif
+    // ---- the others: (pixel, sample) pairs, sample-major, in chunks of 2048.  Pass 1 tries every pair against its pixel's cached
+    // occluder; the few that miss are listed in LDS and walked in pass 2, densely packed — walked where they stand, one missing lane
+    // would take its whole wave through a walk (at a 2 % miss rate three waves in four).
+#if SAH_EXP_MASK_SKIP == 2
+    const uint32_t n0 = s_list_n[0], items = 0u;
+#else
+    const uint32_t n0 = s_list_n[0], items = num_samples > 1u ? n0 * (num_samples - 1u) : 0u;
+#endif
+    auto pair_ray = [&](uint32_t item, uint32_t& p) {
+        const uint32_t i = item / n0 + 1u;
+        p = s_list[0][item % n0];
+        uint32_t px, py;
+        tile_pixel(s_pixel[p], a.row_begin, px, py);
+        const float po[3] = {s_origin[0][p], s_origin[1][p], s_origin[2][p]};
+        float d[3];
+        sample_dir(px, py, i, d);
+        return make_ray(po, d, 0.01f, 100000.0f);
+    };
+    for (uint32_t chunk = 0; chunk < items; chunk += kMaskChunk) {
+        if (threadIdx.x == 0) s_miss_n = 0u;
+        __syncthreads();
+        for (uint32_t item = chunk + threadIdx.x; item < min(items, chunk + kMaskChunk); item += 256u) {
+            uint32_t p;
+            const Ray r = pair_ray(item, p);
+            const uint32_t last = s_occluder[p];
+            if (!(last != 0xffffffffu && accepts<false>(bvh, sc, r, last))) s_miss[atomicAdd(&s_miss_n, 1u)] = (uint16_t)(item - chunk);
+        }
+        __syncthreads();
+        for (uint32_t m = threadIdx.x; m < s_miss_n; m += 256u) {
+            uint32_t p, occluder;
+            const Ray r = pair_ray(chunk + s_miss[m], p);
+            if (any_hit<false>(bvh, sc, tv, r, &occluder)) s_occluder[p] = occluder;
+            else atomicAdd(&s_unoccluded[p], 1u);
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x < num_traced) {
@@ -1180,6 +1360,10 @@ hipError_t launch_rtgi_trace(const RtgiTraceArgs& a, const RtBvh& bvh, const RtS
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
     if (a.row_end <= a.row_begin) return hipSuccess;
     hipLaunchKernelGGL(k_rtao, dim3((a.width + 15u) / 16u, (a.row_end - (a.row_begin & ~15u) + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
+    return hipGetLastError();
+}
+hipError_t launch_noise_dirs(const PlaneArg& noise, const float* luts, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_noise_dirs, dim3(64), dim3(256), 0, s, noise, luts, out);
     return hipGetLastError();
 }
 hipError_t launch_sun_shadow_mask(const ShadowMaskArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {

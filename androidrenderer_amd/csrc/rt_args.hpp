@@ -83,6 +83,7 @@ struct ShadowMaskArgs {
     float res[2];
     float L[3];  // normalize(-direction), fp32
     float tan_size, num_samples;
+    const float* noise_dirs;  // float4 per texel of the noise plane's 128 x 128 corner: normalize(texel.rgb * 2 - 1), 0 (k_noise_dirs, every call)
 };
 
 struct GiArgs {  // what the GI hit / miss stages read besides the scene (rt.hip: trace_gi)

@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (diagnostic only)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
+    ap.add_argument("--shadow-samples", type=float, default=None, help="traced workload: sun shadow rays per pixel (default: the reference's 8)")
     ap.add_argument("--watchdog-s", type=float, default=300.0, help="N>1: end the rank when a phase makes no progress for this long (0: never)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
     ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
@@ -365,6 +366,8 @@ def main():
         atlases = _abi.ProbeAtlases(pt.probe_irradiance, images.volume(light_cache, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_depth,
                                     images.volume(average, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_validity)
         rtgi_rb, rtgi_ri = (torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(2))
+        if args.shadow_samples is not None:
+            fr.sun.constants.num_shadow_samples = args.shadow_samples
         e = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
         torch.cuda.synchronize()
         e[0].record()
@@ -404,6 +407,9 @@ def main():
                   "rtgi_trace_ms_not_in_frame": round(e[6].elapsed_time(e[7]), 4),
                   "shadow_samples": float(fr.sun.constants.num_shadow_samples), "ao_unoccluded_fraction": round(float((d_arr["ao"] == 1).float().mean()), 4),
                   "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4),
+                  "mask_pixels_0_between_1": [round(float((d_arr["shadow_mask"] == 0).float().mean()), 4),
+                                              round(float(((d_arr["shadow_mask"] > 0) & (d_arr["shadow_mask"] < 1)).float().mean()), 4),
+                                              round(float((d_arr["shadow_mask"] == 1).float().mean()), 4)],
                   "probe_rays_hit_front_back_miss": [round(float((tr_dist > 0).float().mean()), 4), round(float((tr_dist < 0).float().mean()), 4)],
                   "rtgi_rays_hit_fraction": round(float((rtgi_rb.view(torch.float16)[..., 3].float() != 0).float().mean()), 4)}
 
