@@ -254,7 +254,7 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
 // window of 1024 consecutive triangles (one node of level 5 and everything under it) a workgroup therefore re-partitions the triangles
 // top-down: a segment of S slots is split into its first and second S / 2 along one of nine orders — by box centre, lower or upper corner
 // on x, y or z — whichever has the smallest area(left) x count(left) + area(right) x count(right); each half again, down to the groups of
-// four.  Every order is a bitonic sort of (22-bit quantised coordinate, item) words inside the level's segments in LDS; the halves' boxes
+// four.  Every order is a bitonic sort of (22-bit quantised coordinate, item) words inside the level's segments in LDS — the three axes of a kind side by side, a team of 256 threads each —; the halves' boxes
 // are reduced with shuffles.  Triangle sets of the levels above the window stay what the curve made them.  Slots behind the window's last
 // triangle sort last in every order, so the triangles stay a prefix of every segment (the hierarchy is complete: node n exists iff
 // n < count).  Which order wins changes no result (sah_hip.h: any hierarchy culls exactly), only how many boxes a ray meets:
@@ -269,25 +269,27 @@ SAH_DEV float half_area(const float lo[3], const float hi[3]) {
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     return (dx * dy + dy * dz) + dz * dx;
 }
-__global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, unsigned long long* keys, uint32_t num_tris) {
+__global__ __launch_bounds__(768) void k_rt_refine(const RtTriangle* unsorted, unsigned long long* keys, uint32_t num_tris) {
+    // 768 threads: three teams of 256 — team g sorts along axis g — so that the three orders of a kind advance between the same barriers
+    // (the kernel is bound by the latency of its ~650 barrier-separated sort stages per window, not by their work)
     __shared__ float s_box[6][kRefineWindow];  // by item = slot in the window on entry; empty items hold (+inf, -inf)
-    __shared__ uint32_t s_idx[kRefineWindow], s_srt[kRefineWindow];
+    __shared__ uint32_t s_idx[kRefineWindow], s_srt[3][kRefineWindow];
     __shared__ uint16_t s_perm[kRefineWindow], s_best_perm[kRefineWindow];
-    __shared__ float s_hbox[6][kRefineWindow / 4u];
-    __shared__ uint32_t s_hcnt[kRefineWindow / 4u];
-    __shared__ float s_best[kRefineWindow / 8u];
-    __shared__ uint32_t s_take[kRefineWindow / 8u];
+    __shared__ float s_hbox[3][6][kRefineWindow / 4u];
+    __shared__ uint32_t s_hcnt[3][kRefineWindow / 4u];
+    __shared__ float s_best[kRefineWindow / 8u], s_cost[3][kRefineWindow / 8u];
+    __shared__ uint32_t s_swap[3][kRefineWindow / 8u], s_take[kRefineWindow / 8u];
     __shared__ uint32_t s_bounds[6];
-    const uint32_t base = blockIdx.x * kRefineWindow, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t base = blockIdx.x * kRefineWindow, g = threadIdx.x / 256u, tid = threadIdx.x % 256u, lane = tid & 63u;
     if (base >= num_tris) return;
     const uint32_t n_real = min(kRefineWindow, num_tris - base);
     if (n_real <= 4u) return;
-    if (tid < 3u) {
-        s_bounds[tid] = 0xffffffffu;
-        s_bounds[3u + tid] = 0u;
+    if (threadIdx.x < 3u) {
+        s_bounds[threadIdx.x] = 0xffffffffu;
+        s_bounds[3u + threadIdx.x] = 0u;
     }
     __syncthreads();
-    {
+    if (g == 0u) {
         float wlo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, whi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         for (uint32_t j = 0; j < 4u; j++) {
             const uint32_t pos = 4u * tid + j;
@@ -318,37 +320,33 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
             }
     }
     __syncthreads();
-    float wmin[3], wscale[3];  // quantisation of a coordinate to 22 bits over the window's extent (monotone; ties go by item)
-    for (int c = 0; c < 3; c++) {
-        wmin[c] = unordered(s_bounds[c]);
-        const float ext = unordered(s_bounds[3 + c]) - wmin[c];
-        wscale[c] = ext > 0.f ? 4194303.0f / ext : 0.f;
-    }
+    // quantisation of this team's coordinate to 22 bits over the window's extent (monotone; ties go by item)
+    const float wmin = unordered(s_bounds[g]), wext = unordered(s_bounds[3u + g]) - wmin, wscale = wext > 0.f ? 4194303.0f / wext : 0.f;
+    uint32_t* const srt = s_srt[g];
     for (uint32_t S = kRefineWindow; S >= 8u; S >>= 1) {
         const uint32_t H = S >> 1, nseg = kRefineWindow / S, group = min(H >> 2, 64u);  // threads whose slots lie in one half (4 slots each)
-        for (uint32_t k = 0; k < 9u; k++) {
-            const uint32_t axis = k % 3u, kind = k / 3u;
+        for (uint32_t kind = 0; kind < 3u; kind++) {
             for (uint32_t j = 0; j < 4u; j++) {
                 const uint32_t pos = 4u * tid + j, item = s_perm[pos];
-                const float lo = s_box[axis][item], hi = s_box[3u + axis][item];
+                const float lo = s_box[g][item], hi = s_box[3u + g][item];
                 uint32_t q = 0x3fffffu;
                 if (lo <= hi) {
                     const float v = kind == 0u ? lo * 0.5f + hi * 0.5f : (kind == 1u ? lo : hi);
-                    const float f = __builtin_fminf(__builtin_fmaxf((v - wmin[axis]) * wscale[axis], 0.f), 4194303.0f);  // (NaN -> 0)
+                    const float f = __builtin_fminf(__builtin_fmaxf((v - wmin) * wscale, 0.f), 4194303.0f);  // (NaN -> 0)
                     q = (uint32_t)f;
                 }
-                s_srt[pos] = (q << 10) | item;
+                srt[pos] = (q << 10) | item;
             }
             __syncthreads();
             for (uint32_t kk = 2u; kk <= S; kk <<= 1)
                 for (uint32_t j = kk >> 1; j > 0u; j >>= 1) {
                     for (uint32_t t = tid; t < kRefineWindow / 2u; t += 256u) {
                         const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
-                        const uint32_t x = s_srt[i], y = s_srt[i | j];
+                        const uint32_t x = srt[i], y = srt[i | j];
                         const bool ascending = kk == S || (i & kk) == 0u;
                         if ((x > y) == ascending) {
-                            s_srt[i] = y;
-                            s_srt[i | j] = x;
+                            srt[i] = y;
+                            srt[i | j] = x;
                         }
                     }
                     __syncthreads();
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
             float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
             uint32_t cnt = 0;
             for (uint32_t j = 0; j < 4u; j++) {
-                const uint32_t item = s_srt[4u * tid + j] & 1023u;
+                const uint32_t item = srt[4u * tid + j] & 1023u;
                 cnt += s_box[0][item] <= s_box[3][item] ? 1u : 0u;
                 for (int c = 0; c < 3; c++) {
                     lo[c] = __builtin_fminf(lo[c], s_box[c][item]);
@@ -375,13 +373,13 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
             if ((tid & (group - 1u)) == 0u) {
                 const uint32_t r = tid / group;
                 for (int c = 0; c < 3; c++) {
-                    s_hbox[c][r] = lo[c];
-                    s_hbox[3 + c][r] = hi[c];
+                    s_hbox[g][c][r] = lo[c];
+                    s_hbox[g][3 + c][r] = hi[c];
                 }
-                s_hcnt[r] = cnt;
+                s_hcnt[g][r] = cnt;
             }
             __syncthreads();
-            if (tid < nseg) {
+            if (tid < nseg) {  // this team's cost of segment `tid`
                 const uint32_t per_half = H / (4u * group);  // 1, or 2 for the 512-slot halves (two waves each)
                 float cost = 0.f, area[2] = {0.f, 0.f};
                 uint32_t total = 0;
@@ -389,10 +387,10 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
                     float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
                     uint32_t bc = 0;
                     for (uint32_t r = (2u * tid + side) * per_half; r < (2u * tid + side + 1u) * per_half; r++) {
-                        bc += s_hcnt[r];
+                        bc += s_hcnt[g][r];
                         for (int c = 0; c < 3; c++) {
-                            blo[c] = __builtin_fminf(blo[c], s_hbox[c][r]);
-                            bhi[c] = __builtin_fmaxf(bhi[c], s_hbox[3 + c][r]);
+                            blo[c] = __builtin_fminf(blo[c], s_hbox[g][c][r]);
+                            bhi[c] = __builtin_fmaxf(bhi[c], s_hbox[g][3 + c][r]);
                         }
                     }
                     if (bc != 0u) {
@@ -401,29 +399,43 @@ __global__ __launch_bounds__(256) void k_rt_refine(const RtTriangle* unsorted, u
                     }
                     total += bc;
                 }
-                const bool take = k == 0u || cost < s_best[tid];
-                if (take) s_best[tid] = cost;
+                s_cost[g][tid] = cost;
 #if SAH_EXP_REFINE_SWAP == 1
-                const bool swap = total == S && area[0] > area[1];
+                s_swap[g][tid] = total == S && area[0] > area[1] ? 1u : 0u;
 #elif SAH_EXP_REFINE_SWAP == 2
-                const bool swap = total == S && area[0] < area[1];
+                s_swap[g][tid] = total == S && area[0] < area[1] ? 1u : 0u;
 #else
-                const bool swap = false;
+                s_swap[g][tid] = 0u;
 #endif
-                s_take[tid] = take ? (swap ? 2u : 1u) : 0u;
+            }
+            __syncthreads();
+            if (g == 0u && tid < nseg) {  // the cheapest of the three, against the best of the kinds before: 0 = keep, else 1 + 2 * team + swap
+                uint32_t take = 0;
+                float best = kind == 0u ? __builtin_inff() : s_best[tid];
+                for (uint32_t t = 0; t < 3u; t++) {
+                    const float c = s_cost[t][tid];
+                    if ((kind == 0u && t == 0u) || c < best) {
+                        best = c;
+                        take = 1u + 2u * t + s_swap[t][tid];
+                    }
+                }
+                s_best[tid] = best;
+                s_take[tid] = take;
             }
             __syncthreads();
             for (uint32_t j = 0; j < 4u; j++) {
                 const uint32_t pos = 4u * tid + j;
                 const uint32_t tk = s_take[pos / S];
-                if (tk) s_best_perm[tk == 2u ? pos ^ H : pos] = (uint16_t)(s_srt[pos] & 1023u);
+                if (tk != 0u && (tk - 1u) / 2u == g) s_best_perm[((tk - 1u) & 1u) ? pos ^ H : pos] = (uint16_t)(srt[pos] & 1023u);
             }
             __syncthreads();
         }
-        for (uint32_t j = 0; j < 4u; j++) s_perm[4u * tid + j] = s_best_perm[4u * tid + j];
+        if (g == 0u)
+            for (uint32_t j = 0; j < 4u; j++) s_perm[4u * tid + j] = s_best_perm[4u * tid + j];
         __syncthreads();
     }
-    for (uint32_t pos = tid; pos < n_real; pos += 256u) keys[base + pos] = (keys[base + pos] & 0xffffffff00000000ull) | s_idx[s_perm[pos]];
+    if (g == 0u)
+        for (uint32_t pos = tid; pos < n_real; pos += 256u) keys[base + pos] = (keys[base + pos] & 0xffffffff00000000ull) | s_idx[s_perm[pos]];
 }
 
 // one thread per triangle: moves it into curve order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
@@ -1340,7 +1352,7 @@ hipError_t launch_rt_sort(const RtTriangle* tris, const RtBuildState* st, unsign
 }
 hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long* keys, RtTriangle* sorted, RtNodeGroup* nodes, const RtBvh& bvh, hipStream_t s) {
     if (bvh.num_tris == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rt_refine, dim3((bvh.num_tris + kRefineWindow - 1u) / kRefineWindow), dim3(256), 0, s, unsorted, const_cast<unsigned long long*>(keys), bvh.num_tris);
+    hipLaunchKernelGGL(k_rt_refine, dim3((bvh.num_tris + kRefineWindow - 1u) / kRefineWindow), dim3(768), 0, s, unsorted, const_cast<unsigned long long*>(keys), bvh.num_tris);
     hipLaunchKernelGGL(k_rt_leaves, dim3((bvh.num_tris + 255u) / 256u), dim3(256), 0, s, unsorted, keys, bvh.num_tris, bvh.pad, sorted, nodes);
     for (uint32_t l = 1; l < bvh.num_levels; l++)
         hipLaunchKernelGGL(k_rt_level, dim3((bvh.level_count[l] + 255u) / 256u), dim3(256), 0, s, nodes + bvh.level_offset[l - 1], bvh.level_count[l - 1],
