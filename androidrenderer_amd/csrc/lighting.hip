@@ -159,23 +159,10 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
                        ((t[c].y & 0x7c000000u) == 0x7c000000u);
             }
         }
-#ifdef SAH_EXP_LPV_PACK32
-        float4* dst = reinterpret_cast<float4*>(dst_row + (size_t)px * kLpvPackTexel);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float4 w;
-            w.x = (float)__builtin_bit_cast(_Float16, (uint16_t)(t[c].x & 0xffffu));
-            w.y = (float)__builtin_bit_cast(_Float16, (uint16_t)(t[c].x >> 16));
-            w.z = (float)__builtin_bit_cast(_Float16, (uint16_t)(t[c].y & 0xffffu));
-            w.w = (float)__builtin_bit_cast(_Float16, (uint16_t)(t[c].y >> 16));
-            dst[c] = w;
-        }
-#else
         uint2* dst = reinterpret_cast<uint2*>(dst_row + (size_t)px * kLpvPackTexel);
         dst[0] = t[0];
         dst[1] = t[1];
         dst[2] = t[2];
-#endif
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicMax(&state->nonfinite_tag, serial * 2u + 1u);
 }

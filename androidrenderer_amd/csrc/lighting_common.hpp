@@ -321,30 +321,6 @@ SAH_DEV void lpv_fetch_packed(const LpvArgs& L, const uint8_t* packed, uint32_t 
     const uint32_t base = z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel;
 #endif
     const uint32_t ro[4] = {base, base + row_pitch, base + slice_pitch, base + slice_pitch + row_pitch};  // (y0,z0) (y1,z0) (y0,z1) (y1,z1)
-#ifdef SAH_EXP_LPV_PACK32
-    {
-        const float wxy[4] = {gx * gy, fx * gy, gx * fy, fx * fy};
-        float wt[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) wt[k] = wxy[k & 3] * ((k >> 2) ? fz : gz);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float4 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) t[k] = *reinterpret_cast<const float4*>(packed + ro[k >> 1] + 48u * (uint32_t)(k & 1) + 16u * (uint32_t)c);
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 8; k++) {  // tap order: x fastest, then y, then z
-                a[0] = __builtin_fmaf(wt[k], t[k].x, a[0]);
-                a[1] = __builtin_fmaf(wt[k], t[k].y, a[1]);
-                a[2] = __builtin_fmaf(wt[k], t[k].z, a[2]);
-                a[3] = __builtin_fmaf(wt[k], t[k].w, a[3]);
-            }
-            out[c] = dot4(a, n);
-        }
-        return;
-    }
-#endif
     uint32_t d[4][12];  // per row: R(x0) G(x0) B(x0) R(x1) G(x1) B(x1), two dwords (four halves) each
 #pragma unroll
     for (int r = 0; r < 4; r++) {

@@ -319,9 +319,6 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             // only `validity == 0` is used, and (half)(b / 255) is zero for b = 0 alone
             validity = c.validity.ptr[vlayer[jz] + pidx[1][jy] * c.validity.row_pitch + pidx[0][jx]] ? 1.f : 0.f;
         }
-#if defined(SAH_EXP_CACHE_SKIP) && SAH_EXP_CACHE_SKIP == 3
-        validity = 1.f;
-#endif
         if (validity == 0.f) continue;
         // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
         const F3 dir_to_probe = {dp[0][jx], dp[1][jy], dp[2][jz]};
@@ -331,9 +328,6 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const Fn trilinear_weight = tri[0][jx] * tri[1][jy] * tri[2][jz];
         Fn probe_weight = Fn(1.f);
 
-#if defined(SAH_EXP_CACHE_SKIP) && (SAH_EXP_CACHE_SKIP == 1 || SAH_EXP_CACHE_SKIP == 4)
-        float dt0 = dist.v * 0.5f, dt1 = dist.v;
-#else
         // octahedral_coordinates(-dir_to_probe) with the signs above: uv = -dp.xy / L1 is >= 0 for corner 0 and < 0 for corner 1 of its
         // axis; the fold (direction.z < 0) happens for the z corner 1 and nowhere else, and multiplying by sign_not_zero is a negation or
         // nothing
@@ -363,7 +357,6 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             dt0 = fma_mix_lo(dwt[k], dw[k], dt0);
             dt1 = fma_mix_hi(dwt[k], dw[k], dt1);
         }
-#endif
         const Hn dx = Hn(dt0), dy = Hn(dt1);  // Sampler2DArray<half2>
         const Fn variance = Fn(tof(nabs(dx * dx - dy)));
         const Fn v = dist - Fn(tof(dx));
@@ -387,9 +380,6 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const uint32_t irow0 = ilayer[jz] + iya.off + ixa.off;
         // the four taps from the widened copy (R11G11B10 -> fp16 is a bit shuffle, fp16 -> fp32 exact: the products below are the
         // fused multiply-adds v_fma_mix_f32 would do on the shuffled words).  The copy's pitches are 4 x the atlas's.
-#if defined(SAH_EXP_CACHE_SKIP) && (SAH_EXP_CACHE_SKIP == 2 || SAH_EXP_CACHE_SKIP == 4)
-        float ir = ixa.w0, ig = iya.w0, ib = (float)irow0;
-#else
         const float4* irow = reinterpret_cast<const float4*>(c.irr32 + 4u * irow0);
         const float4* irow_next = reinterpret_cast<const float4*>(c.irr32 + 4u * (irow0 + c.irradiance.row_pitch));
         const float4 it[4] = {irow[0], irow[1], irow_next[0], irow_next[1]};
@@ -401,7 +391,6 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             ig = __builtin_fmaf(iwt[k], it[k].y, ig);
             ib = __builtin_fmaf(iwt[k], it[k].z, ib);
         }
-#endif
         const H3 pi = {Hn(ir), Hn(ig), Hn(ib)};  // Sampler2DArray<half3>
         irradiance = irradiance + to_f(pi) * probe_weight;
         weight = weight + probe_weight;

@@ -113,11 +113,8 @@ struct FastArgs {
     const uint8_t* lpv_packed;
     uint32_t pk_row_pitch, pk_slice_pitch;
 };
-#ifdef SAH_EXP_LPV_PACK32  // experiment: fp32 texels {R[4], G[4], B[4]} = 48 bytes, plain v_fma_f32 taps
-constexpr uint32_t kLpvPackTexel = 48, kLpvPackBorder = 2;
-#else
+// (an fp32 copy — 48-byte texels, plain v_fma_f32 taps — was measured and loses 67 %: profiles/r3_lpv_pack32_experiment.txt)
 constexpr uint32_t kLpvPackTexel = 24, kLpvPackBorder = 2;
-#endif
 // Experiment (round 2, profiles/r2_tolerance_mode_v1.txt): a "within 1 fp16 ULP" mode of the fast kernel.  2.4x SLOWER than the strict
 // kernel (its guards send 36-50 % of the pixels through both paths), so it is not part of the ABI: the flag bit exists only in a
 // library built with SAH_EXTRA_HIPCC_FLAGS=-DSAH_EXP_TOLERANCE_1ULP, which is what tests/test_tolerance_gpu.py asks for.

@@ -260,11 +260,6 @@ SAH_DEV void tri_box(const RtTriangle& r, float pad, float lo[3], float hi[3]) {
 // n < count).  Which order wins changes no result (sah_hip.h: any hierarchy culls exactly), only how many boxes a ray meets:
 // sum of node areas / root area of the atrium's 23 808 triangles 31.3 -> 26.6 (tools/experiments/tree_cost.py).
 constexpr uint32_t kRefineWindow = 1024u;
-// which half of a full segment goes second, i.e. is entered first by the any-hit walk (descending child order): 1 = the one with the
-// larger box (a ray is likelier to meet an occluder there: shadow mask 1.65 -> 1.59 ms; the smaller one: 1.90), 0 = the sort's order
-#ifndef SAH_EXP_REFINE_SWAP
-#define SAH_EXP_REFINE_SWAP 1
-#endif
 SAH_DEV float half_area(const float lo[3], const float hi[3]) {
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     return (dx * dy + dy * dz) + dz * dx;
@@ -400,13 +395,9 @@ __global__ __launch_bounds__(768) void k_rt_refine(const RtTriangle* unsorted, u
                     total += bc;
                 }
                 s_cost[g][tid] = cost;
-#if SAH_EXP_REFINE_SWAP == 1
+                // of a full segment's halves the one with the larger box goes second, i.e. is entered first by the any-hit walk (descending
+                // child order): a ray is likelier to meet an occluder there (shadow mask 1.65 -> 1.59 ms; the smaller one second: 1.90)
                 s_swap[g][tid] = total == S && area[0] > area[1] ? 1u : 0u;
-#elif SAH_EXP_REFINE_SWAP == 2
-                s_swap[g][tid] = total == S && area[0] < area[1] ? 1u : 0u;
-#else
-                s_swap[g][tid] = 0u;
-#endif
             }
             __syncthreads();
             if (g == 0u && tid < nseg) {  // the cheapest of the three, against the best of the kinds before: 0 = keep, else 1 + 2 * team + swap
@@ -715,9 +706,6 @@ SAH_DEV bool any_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const 
 // entry distance is >= the beam's and its exit distance <= the beam's: every box a ray of the beam passes, the beam passes.  The beam's
 // walk therefore reaches every triangle whose own box any of its rays passes, and there each ray is tested by itself (accepts(): the
 // full hit definition).  No result depends on the beam; it only decides which triangles are looked at.
-#ifndef SAH_EXP_MASK_SKIP
-#define SAH_EXP_MASK_SKIP 0  // timing experiments only: 1 = no beams walked, 2 = no (pixel, sample) pairs walked
-#endif
 struct Beam {
     float o[3], inv_lo[3], inv_hi[3];
     float tmin, tmax;
@@ -1221,7 +1209,6 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
     __syncthreads();
     // ---- pixels whose sample 0 was unoccluded: the other samples as one beam
     const uint32_t top = bvh.num_levels - 1u;
-#if SAH_EXP_MASK_SKIP != 1
     for (uint32_t qi = threadIdx.x; qi < s_list_n[1]; qi += 256u) {
         const uint32_t p = s_list[1][qi];
         uint32_t px, py;
@@ -1280,15 +1267,10 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
         }
         atomicAdd(&s_unoccluded[p], (uint32_t)__builtin_popcount(left));
     }
-#endif
     // ---- the others: (pixel, sample) pairs, sample-major, in chunks of 2048.  Pass 1 tries every pair against its pixel's cached
     // occluder; the few that miss are listed in LDS and walked in pass 2, densely packed — walked where they stand, one missing lane
     // would take its whole wave through a walk (at a 2 % miss rate three waves in four).
-#if SAH_EXP_MASK_SKIP == 2
-    const uint32_t n0 = s_list_n[0], items = 0u;
-#else
     const uint32_t n0 = s_list_n[0], items = num_samples > 1u ? n0 * (num_samples - 1u) : 0u;
-#endif
     auto pair_ray = [&](uint32_t item, uint32_t& p) {
         const uint32_t i = item / n0 + 1u;
         p = s_list[0][item % n0];
