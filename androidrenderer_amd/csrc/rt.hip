@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a,
             }
         }
         for (int c = 0; c < 3; c++) ok = ok && (b.inv_lo[c] > 0.0f) == (b.inv_hi[c] > 0.0f);
-        uint32_t left = (1u << (num_samples - 1u)) - 1u;  // bit i - 1: sample i has met no occluder yet
+        uint32_t left = 0xffffffffu >> (33u - num_samples);  // bit i - 1: sample i has met no occluder yet (2 <= num_samples <= 33)
         if (ok) {
             uint32_t level = top, node = 0;
             unsigned long long pending = 0;

@@ -455,6 +455,25 @@ def test_hip_triangle_soups_with_cutouts(hip_ctx, seed, textured):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("samples,tan_size", [(1.0, 0.0095), (8.0, 0.0095), (8.0, 0.0), (7.5, 0.5), (33.0, 0.02), (34.0, 0.02), (70.0, 0.1)])
+def test_hip_shadow_mask_sample_counts_and_cones(hip_ctx, samples, tan_size):
+    """The mask kernel's paths: sample 0 alone; beams (2 .. 33 samples: the others of a pixel in one 32-bit mask) with a narrow cone, no
+    cone at all (every ray the same: inv_lo == inv_hi) and a cone so wide that directions change sign (pixels walked ray by ray); 34
+    samples and more (no beams, (pixel, sample) pairs in several chunks); samples beyond the 64 tabulated noise offsets; a fractional
+    bound (the shader's loop runs ceil(bound) times and divides by the bound).  Cutout geometry: a beam's rays run the any-hit stage
+    one by one."""
+    m = mesh.random_soup(21, triangles=500, cutout_fraction=0.4, textured=True)
+    case = RtCase(m, 48, 27, seed=3)
+    case.sun.set_direction([0.25, -1.0, 0.15])
+    case.sun.constants.num_shadow_samples = samples
+    case.sun.constants.direction_and_tan_size[3] = tan_size
+    case.hip_build(hip_ctx)
+    got, want = case.hip_mask(hip_ctx), case.oracle_mask()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (want < 1.0).any() and (want > 0.0).any()
+
+
+@pytest.mark.gpu
 def test_hip_random_planes_against_the_oracle(hip_ctx):
     """rays from arbitrary origins: random depth and normals instead of a rasterised G-buffer (grazing rays, origins inside geometry,
     sky pixels, non-finite normals)"""

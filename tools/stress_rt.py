@@ -37,7 +37,7 @@ def main():
             c = test_rt.RtCase(m, W, H, seed=case)
         c.sun.set_direction(g.normal(size=3))
         c.sun.constants.direction_and_tan_size[3] = float(g.choice([0.0, 0.0095, 0.2]))
-        c.sun.constants.num_shadow_samples = float(g.choice([1.0, 2.0, 5.0]))
+        c.sun.constants.num_shadow_samples = float(g.choice([1.0, 2.0, 5.0, 8.0, 33.0, 34.0]))
         spp, radius = int(g.choice([1, 3])), float(g.choice([0.5, 4.0, 100.0]))
         stats = c.hip_build(ctx)
         ao_h, ao_o = c.hip_rtao(ctx, spp, radius), c.oracle_rtao(spp, radius)
