@@ -890,7 +890,7 @@ SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, 
     const H3 brdf_result = Fd(s, Lh, s.normal);
     const Hn ndotl = nclamp(dot(Lh, s.normal), Hn::lit(0.f), Hn::lit(1.f));
     Hn shadow = Hn::lit(0.f);
-    if (tof(ndotl) > 0.f) {
+    if (tof(ndotl) > 0.f && c.h.front) {  // (a back-face hit is black whatever its shadow ray says: none is traced)
         const F3 noise = load_noise(g.noise, sc.luts, dx % 128u, dy % 128u);
         const F3 dir = normalize(to_f(Lh) + noise * Fn(g.tan_size));
         const float d[3] = {dir.x.v, dir.y.v, dir.z.v};

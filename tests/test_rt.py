@@ -435,10 +435,11 @@ def test_hip_known_answer_scenes(hip_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("subdiv,size", [(1, (96, 54)), (4, (64, 36))])
+@pytest.mark.parametrize("subdiv,size", [(1, (96, 54)), (4, (64, 36)), (12, (48, 27))])
 def test_hip_atrium(hip_ctx, subdiv, size):
     case = RtCase(mesh.atrium(subdiv), *size)
-    ao, mask = _check_both(hip_ctx, case, radius=1.0, expect_tris=31 * 12 * subdiv * subdiv)  # subdiv 4: 5952 triangles = three sort chunks
+    # subdiv 4: 5952 triangles = three sort chunks, six refinement windows (the last one partial); subdiv 12: 53 568 = 52 windows + 320
+    ao, mask = _check_both(hip_ctx, case, radius=1.0, expect_tris=31 * 12 * subdiv * subdiv)
     assert 0.02 < (ao == 0.0).mean() < 0.9       # something is occluded, something is not
     assert 0.02 < (mask < 1.0).mean() < 0.98
 
