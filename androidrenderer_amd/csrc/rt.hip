@@ -429,6 +429,14 @@ __global__ __launch_bounds__(768) void k_rt_refine(const RtTriangle* unsorted, u
         for (uint32_t pos = tid; pos < n_real; pos += 256u) keys[base + pos] = (keys[base + pos] & 0xffffffff00000000ull) | s_idx[s_perm[pos]];
 }
 
+// The lanes of a level's last group that stand for no node hold the box [+inf, +inf]^3, which no ray passes: RN((+inf - o) * inv) is
+// +inf on both planes of an axis where inv > 0 (entry = +inf > exit) and -inf where inv < 0 (exit = -inf < entry); inv is never 0 or
+// NaN for a ray that walks (non-finite rays do not).  The walk then needs no "does this child exist" test.
+SAH_DEV void fill_absent(RtNodeGroup& g, uint32_t first_absent) {
+    if (first_absent == 0u) return;  // the group is full
+    for (uint32_t k = first_absent; k < kRtFanout; k++)
+        for (int c = 0; c < 3; c++) g.lo[c][k] = g.hi[c][k] = __builtin_inff();
+}
 // one thread per triangle: moves it into curve order and writes its padded box — the level-0 "node" of the hierarchy, so that the walk
 // meets a triangle's own box (part of the hit definition, sah_hip.h) like any other box
 __global__ __launch_bounds__(256) void k_rt_leaves(const RtTriangle* unsorted, const unsigned long long* keys, uint32_t num_tris, float pad,
@@ -444,6 +452,7 @@ __global__ __launch_bounds__(256) void k_rt_leaves(const RtTriangle* unsorted, c
         g.lo[c][i % kRtFanout] = lo[c];
         g.hi[c][i % kRtFanout] = hi[c];
     }
+    if (i + 1u == num_tris) fill_absent(g, num_tris % kRtFanout);
 }
 __global__ __launch_bounds__(256) void k_rt_level(const RtNodeGroup* children, uint32_t num_children, RtNodeGroup* nodes, uint32_t num_nodes) {
     const uint32_t n = blockIdx.x * 256u + threadIdx.x;
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(256) void k_rt_level(const RtNodeGroup* children, u
         g.lo[a][n % kRtFanout] = lo[a];
         g.hi[a][n % kRtFanout] = hi[a];
     }
+    if (n + 1u == num_nodes) fill_absent(g, num_nodes % kRtFanout);
 }
 
 // ---- traversal --------------------------------------------------------------------------------------------------------------------
@@ -596,7 +606,6 @@ SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* 2 * kRtMaxLevels word
 // bit k: child 4 * node + k of (level, node) exists and the ray's slab test passes its box.  The four boxes are one 96-byte group
 // `nearest` (optional): among the passing children, the one the ray enters first (the largest index among equals)
 SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, uint32_t level, uint32_t node, uint32_t* nearest = nullptr) {
-    const uint32_t first = node * kRtFanout, cnt = tv.cnt[level - 1u];
     const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + node);
     float q[6][4];
 #pragma unroll
@@ -610,7 +619,7 @@ SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, ui
     for (uint32_t k = 0; k < kRtFanout; k++) {
         const float lo[3] = {q[0][k], q[1][k], q[2][k]}, hi[3] = {q[3][k], q[4][k], q[5][k]};
         float tn;
-        const bool pass = first + k < cnt && slab(r, lo, hi, &tn);
+        const bool pass = slab(r, lo, hi, &tn);  // (a child that does not exist holds a box nothing passes: fill_absent)
         if (pass) m |= 1u << k;
         if (nearest && pass && tn <= best_t) {
             best_t = tn;
@@ -722,7 +731,6 @@ SAH_DEV bool beam_slab(const Beam& b, const float lo[3], const float hi[3]) {
     return tn <= tf;
 }
 SAH_DEV uint32_t children_hit_beam(const RtBvh& bvh, const Trav& tv, const Beam& b, uint32_t level, uint32_t node) {
-    const uint32_t first = node * kRtFanout, cnt = tv.cnt[level - 1u];
     const float4* p = reinterpret_cast<const float4*>(bvh.nodes + tv.off[level - 1u] + node);
     float q[6][4];
 #pragma unroll
@@ -734,7 +742,7 @@ SAH_DEV uint32_t children_hit_beam(const RtBvh& bvh, const Trav& tv, const Beam&
 #pragma unroll
     for (uint32_t k = 0; k < kRtFanout; k++) {
         const float lo[3] = {q[0][k], q[1][k], q[2][k]}, hi[3] = {q[3][k], q[4][k], q[5][k]};
-        if (first + k < cnt && beam_slab(b, lo, hi)) m |= 1u << k;
+        if (beam_slab(b, lo, hi)) m |= 1u << k;
     }
     return m;
 }
