@@ -631,7 +631,10 @@ SAH_DEV uint32_t children_hit(const RtBvh& bvh, const Trav& tv, const Ray& r, ui
 }
 SAH_DEV RtTriangle load_triangle(const RtTriangle* tris, uint32_t i) {  // three 16-byte loads
     const float4* p = reinterpret_cast<const float4*>(tris + i);
-    const float4 a = p[0], b = p[1], c = p[2];
+    float4 a = p[0], b = p[1], c = p[2];
+    // all three in flight together: left alone the compiler fetches the flags word first and the vertices only where the flags let the
+    // triangle be tested — two memory round trips, one behind the other, per candidate
+    asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.w));
     RtTriangle t;
     t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.primitive = __builtin_bit_cast(uint32_t, a.w);
     t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z; t.triangle = __builtin_bit_cast(uint32_t, b.w);
@@ -643,11 +646,14 @@ SAH_DEV RtTriangle load_triangle(const RtTriangle* tris, uint32_t i) {  // three
 // later are entered in descending index order (measured: DESIGN.md §5f)
 SAH_DEV bool trav_next(uint32_t top, uint32_t& level, uint32_t& node, unsigned long long& pending, uint32_t m, uint32_t prefer = 4u) {
     const bool fresh = m != 0u && prefer < 4u;
-    while (m == 0u) {
-        if (level == top) return false;
-        level++;
-        node >>= 2;
-        m = (uint32_t)(pending >> (4u * level)) & 15u;
+    if (m == 0u) {  // up to the nearest level that has children left: the first non-zero nibble of `pending` above this level's (no loop:
+                    // as one, the lanes of a wave climbed one level per iteration, all waiting for the one that climbs furthest)
+        const unsigned long long above = pending >> (4u * level + 4u);
+        if (above == 0ull) return false;
+        const uint32_t up = (uint32_t)__builtin_ctzll(above) >> 2;
+        level += 1u + up;
+        node >>= 2u * (1u + up);
+        m = (uint32_t)(above >> (4u * up)) & 15u;
     }
     const uint32_t k = fresh ? prefer : 31u - (uint32_t)__builtin_clz(m);
     m &= ~(1u << k);
