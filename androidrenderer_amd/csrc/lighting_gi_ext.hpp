@@ -26,10 +26,8 @@ SAH_DEV int wrap_repeat(int i, int n) {
     return i < 0 ? i + n : i;
 }
 SAH_DEV int array_layer(float l, uint32_t layers) {  // round to nearest even, clamp to [0, layers-1]
-    const float r = __builtin_rintf(l);
-    if (!(r > 0.f)) return 0;
-    if (r > (float)(layers - 1)) return (int)layers - 1;
-    return (int)r;
+    // (min / max, not early returns: those compile to exec-mask regions around one conversion; fmaxf(NaN, 0) is 0)
+    return (int)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(l), 0.f), (float)(layers - 1));
 }
 
 // 2D-array bilinear, REPEAT (irradiance_cache.cpp:205-217), weighted-sum fma chain; NCH channels decoded by `fetch`
@@ -90,11 +88,7 @@ SAH_DEV void probe_uv(const uint32_t (&idx)[3], F2 oct, uint32_t n0, uint32_t n1
         uv[i] = u / tex_size;
     }
 }
-SAH_DEV uint32_t f2uint(float f) {  // hardware float -> uint: NaN / negatives -> 0, saturating
-    if (!(f > 0.f)) return 0u;
-    if (f >= 4294967296.f) return 0xffffffffu;
-    return (uint32_t)f;
-}
+SAH_DEV uint32_t f2uint(float f) { return cvt_u32_sat(f); }  // hardware float -> uint: NaN / negatives -> 0, saturating
 
 // probe_sampling.slangi:6-106
 SAH_DEV F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index) {
@@ -217,7 +211,8 @@ SAH_DEV uint2 load_pair(const uint8_t* base, uint32_t off) {  // 4-byte aligned,
 // octahedral_coordinates() with the reciprocal of the L1 norm from rcp_nr; `bad` when the norm is outside its domain
 SAH_DEV F2 octahedral_coordinates_nr(F3 dir, bool& bad) {
     const Fn l1 = nabs(dir.x) + nabs(dir.y) + nabs(dir.z);
-    bad = bad || !(l1.v >= kDivLo && l1.v <= kDivHi);
+    bad = bad | !((l1.v >= kDivLo) & (l1.v <= kDivHi));  // (bitwise on purpose, here and below: `||` / `&&` chains of compares compile to
+                                                          //  nested exec-mask regions of one instruction each)
     const Fn inv = Fn(rcp_nr(l1.v));
     F2 uv = {dir.x * inv, dir.y * inv};
     const Fn sx = Fn(uv.x.v >= 0.f ? 1.f : -1.f), sy = Fn(uv.y.v >= 0.f ? 1.f : -1.f);
@@ -257,8 +252,8 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
     const F3 ps = rel / spacing;
     const Fn psa[3] = {ps.x, ps.y, ps.z};
     const F2 irr_oct = octahedral_coordinates(direction);  // probe independent (IEEE form: once per pixel)
-    const bool irr_oct_ok = __builtin_fabsf(irr_oct.x.v) <= 1.0f && __builtin_fabsf(irr_oct.y.v) <= 1.0f;  // false for NaN
-    bad = bad || !irr_oct_ok;
+    const bool irr_oct_ok = (__builtin_fabsf(irr_oct.x.v) <= 1.0f) & (__builtin_fabsf(irr_oct.y.v) <= 1.0f);  // false for NaN
+    bad = bad | !irr_oct_ok;
 
     Fn dp[3][2], sq[3][2], tri[3][2];
     uint32_t pidx[3][2];
@@ -280,7 +275,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         // here that every component of that direction is 0 or at least 2^-40 in magnitude and at most 1: the squared distance is then 0
         // or in [2^-80, 3], the L1 norm 0 (corner 0 of all three axes only) or in [2^-40, 3].  A coordinate within 2^-40 cells of a
         // cell boundary (or a non-finite one) sends the pixel to sample_cascade()
-        bad = bad || !(dp[k][1].v >= 0x1p-40f && dp[k][1].v <= 1.0f) || !(dp[k][0].v == 0.f || (dp[k][0].v <= -0x1p-40f && dp[k][0].v >= -1.0f));
+        bad = bad | !((dp[k][1].v >= 0x1p-40f) & (dp[k][1].v <= 1.0f)) | !((dp[k][0].v == 0.f) | ((dp[k][0].v <= -0x1p-40f) & (dp[k][0].v >= -1.0f)));
     }
     // texcoord terms per axis: idx * total + total / 2 (depth atlas: 10 + 2 texels), and the whole irradiance axis
     Fn dbase[2][2];
@@ -299,27 +294,38 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             iax[k][j] = k == 0 ? probe_axis(uv, c.irradiance.width, 4u) : probe_axis(uv, c.irradiance.height, c.irradiance.row_pitch);
         }
     }
-    uint32_t dlayer[2], ilayer[2], vlayer[2];
-    bool zin[2];
+    uint32_t dlayer[2], ilayer[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         dlayer[j] = (uint32_t)array_layer((float)pidx[2][j], c.depth.depth) * c.depth.slice_pitch;
         ilayer[j] = (uint32_t)array_layer((float)pidx[2][j], c.irradiance.depth) * c.irradiance.slice_pitch;
-        vlayer[j] = pidx[2][j] * c.validity.slice_pitch;
-        zin[j] = pidx[2][j] < c.validity.depth;
     }
+    // the eight probes' validity bytes, fetched together before the loop (Texture2DArray<half>[uint3]: out-of-range loads return 0, so
+    // the address is clamped into the atlas and the range test applied to the result): read where they are used, each probe's byte is a
+    // memory round trip the rest of its iteration waits for — eight in a row per pixel.  Only `validity == 0` is used, and
+    // (half)(b / 255) is zero for b = 0 alone
+    uint32_t voff[3][2];
+    bool vin[3][2];
+    {
+        const uint32_t vext[3] = {c.validity.width, c.validity.height, c.validity.depth}, vpitch[3] = {1u, c.validity.row_pitch, c.validity.slice_pitch};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                vin[k][j] = pidx[k][j] < vext[k];
+                voff[k][j] = min(pidx[k][j], vext[k] - 1u) * vpitch[k];
+            }
+    }
+    uint8_t vbyte[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) vbyte[i] = c.validity.ptr[voff[2][(i >> 2) & 1u] + voff[1][(i >> 1) & 1u] + voff[0][i & 1u]];
 
     F3 irradiance = F3(Fn(0.f));
     Fn weight = Fn(0.f);
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++) {
         const int jx = i & 1u, jy = (i >> 1) & 1u, jz = (i >> 2) & 1u;
-        float validity = 0.f;  // Texture2DArray<half>[uint3]: out-of-range loads return 0
-        if (pidx[0][jx] < c.validity.width && pidx[1][jy] < c.validity.height && zin[jz]) {
-            // only `validity == 0` is used, and (half)(b / 255) is zero for b = 0 alone
-            validity = c.validity.ptr[vlayer[jz] + pidx[1][jy] * c.validity.row_pitch + pidx[0][jx]] ? 1.f : 0.f;
-        }
-        if (validity == 0.f) continue;
+        if (!((vbyte[i] != 0) & vin[0][jx] & vin[1][jy] & vin[2][jz])) continue;
         // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
         const F3 dir_to_probe = {dp[0][jx], dp[1][jy], dp[2][jz]};
         const Fn d2 = sq[0][jx] + sq[1][jy] + sq[2][jz];
@@ -364,8 +370,8 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const bool behind = dist.v > tof(dx);
         // div_nr's domain: variance is a half value widened (0, or in [2^-24, 65504], or not finite — and then so is cden), and
         // cden >= variance: both are in range iff cden is (one unsigned compare on the bits: negative, NaN and inf fall outside)
-        pbad = pbad || (behind && !(__builtin_bit_cast(uint32_t, cden.v) - __builtin_bit_cast(uint32_t, kDivLo) <=
-                                    __builtin_bit_cast(uint32_t, kDivHi) - __builtin_bit_cast(uint32_t, kDivLo)));
+        pbad = pbad | (behind & !(__builtin_bit_cast(uint32_t, cden.v) - __builtin_bit_cast(uint32_t, kDivLo) <=
+                                  __builtin_bit_cast(uint32_t, kDivHi) - __builtin_bit_cast(uint32_t, kDivLo)));
         Fn cheb = Fn(div_nr(variance.v, cden.v));
         cheb = nmax(cheb * cheb * cheb, Fn(0.f));
         cheb = behind ? cheb : Fn(1.f);
@@ -394,7 +400,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         const H3 pi = {Hn(ir), Hn(ig), Hn(ib)};  // Sampler2DArray<half3>
         irradiance = irradiance + to_f(pi) * probe_weight;
         weight = weight + probe_weight;
-        bad = bad || pbad;
+        bad = bad | pbad;
     }
     if (weight.v == 0.f) return F3(Fn(0.f));
     irradiance = irradiance / weight;
@@ -543,7 +549,7 @@ SAH_DEV F3 point_light_contribution_fast(const Surface<Fn>& s, const BrdfPixel& 
     const F3 b = brdf_fast_light(s, bp, L, V, brdf_bad);
     const F3 c = ndotl * b * F3{Fn(pl.cr), Fn(pl.cg), Fn(pl.cb)} * (Fn(pl.intensity) * att);
     const float nan_probe = (c.x + c.y + c.z).v;
-    bad = brdf_bad || !(d2.v >= 0x1p-80f && d2.v <= 0x1p+40f) || !(ww.v == 0.f || ww.v >= kDivLo) || !(nan_probe == nan_probe);
+    bad = brdf_bad | !((d2.v >= 0x1p-80f) & (d2.v <= 0x1p+40f)) | !((ww.v == 0.f) | (ww.v >= kDivLo)) | !(nan_probe == nan_probe);
     return c;
 }
 

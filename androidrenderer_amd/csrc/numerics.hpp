@@ -125,6 +125,15 @@ SAH_DEV float div_nr(float a, float b) {
 }
 #endif
 
+// float -> uint as the hardware converts (GLSL / Slang uint(float) on this path): truncation, negatives and NaN -> 0, 2^32 and above ->
+// 0xffffffff.  Written in C++ ("f > 0 ? (f >= 2^32 ? ~0 : (uint32_t)f) : 0") it compiles to two nested exec-mask regions around the one
+// instruction that does all of it.
+SAH_DEV uint32_t cvt_u32_sat(float f) {
+    uint32_t r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
 // An fp32 value is hidden from the optimiser before it is rounded to fp16.  Without this LLVM (a) narrows
 // fptrunc(fdiv(fpext, fpext)) to a half fdiv whose v_rcp_f16 expansion is not correctly rounded, and (b) fuses
 // fptrunc(fmul/fadd) into v_fma_mixlo_f16, i.e. ONE rounding of the exact result, where the contract (and the

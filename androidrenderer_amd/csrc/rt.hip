@@ -554,7 +554,7 @@ SAH_DEV bool woop(const Ray& r, const RtTriangle& tr, Hit& h) {
 
 // unpackUnorm4x8ToHalf / packUnorm4x8 of gltf_basic_pbr.slang:257-276, alpha channel only (the any-hit stage uses nothing else of v.color)
 SAH_DEV Hn unpack_alpha(uint32_t packed) { return Hn((float)(packed >> 24)) / Hn::lit(255.0f); }
-SAH_DEV uint32_t to_uint_sat(float f) { return f > 0.0f ? (f >= 4294967296.0f ? 0xffffffffu : (uint32_t)f) : 0u; }  // negative, NaN -> 0
+SAH_DEV uint32_t to_uint_sat(float f) { return cvt_u32_sat(f); }  // negative, NaN -> 0; saturating
 
 // any-hit stage of the occlusion hit group of a CUTOUT primitive (gltf_basic_pbr.slang:291-318): true = the hit is accepted
 SAH_DEV bool cutout_accepts(const RtScene& sc, const RtTriangle& tr, const Hit& h) {
