@@ -25,8 +25,15 @@ namespace {
 SAH_DEV bool finite3(const float v[3]) {
     return __builtin_fabsf(v[0]) < __builtin_inff() && __builtin_fabsf(v[1]) < __builtin_inff() && __builtin_fabsf(v[2]) < __builtin_inff();
 }
-SAH_DEV float pick(const float v[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
-// order-preserving float <-> uint (for atomicMin / atomicMax on floats of either sign)
+// v[k], k in {0, 1, 2}, as two selects on VALUES: written as a conditional expression on array elements it compiled to nested exec-mask
+// regions around single moves (eighteen per triangle test), and as selects of array elements to a dynamically indexed private array.
+SAH_DEV float pick3(float v0, float v1, float v2, int k) {
+    float r = v0;
+    r = k == 1 ? v1 : r;
+    r = k == 2 ? v2 : r;
+    return r;
+}
+SAH_DEV float pick(const float v[3], int k) { return pick3(v[0], v[1], v[2], k); }
 SAH_DEV uint32_t ordered(float f) {
     const uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
