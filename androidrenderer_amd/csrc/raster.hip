@@ -528,7 +528,9 @@ SAH_DEV bool cover(const EdgeSetup& e, int32_t px, int32_t py, double v[3]) {
     bool inside = true;
     for (int i = 0; i < 3; i++) {
         v[i] = __builtin_fma(x, e.a[i], __builtin_fma(y, e.b[i], e.c[i]));
-        inside = inside && (v[i] > 0.0 || (v[i] == 0.0 && ((e.tl >> i) & 1u)));
+        // (bitwise, here and in the block sweep: the short-circuit forms compiled to three nested exec-mask regions per pixel in the
+        //  innermost loops)
+        inside = inside & ((v[i] > 0.0) | ((v[i] == 0.0) & (((e.tl >> i) & 1u) != 0u)));
     }
     return inside;
 }
@@ -711,8 +713,8 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
         for (int32_t ox = bx0; ox <= sx1; ox += 8) {
             bool outside = false, all_in = true;
             for (int i = 0; i < 3; i++) {
-                outside = outside || base[i] + kmax[i] < 0.0;
-                all_in = all_in && base[i] + kmin[i] > 0.0;
+                outside = outside | (base[i] + kmax[i] < 0.0);
+                all_in = all_in & (base[i] + kmin[i] > 0.0);
             }
             const int32_t px = ox + lx, py = oy + ly;
             if (!outside && px <= bx1 && py <= by1) {
@@ -722,7 +724,7 @@ SAH_DEV void sweep(const RasterArgs& a, const EdgeSetup& e, uint32_t rec_index, 
                     covered = true;
                     for (int i = 0; i < 3; i++) {
                         v[i] = base[i] + lane_off[i];
-                        covered = covered && (v[i] > 0.0 || (v[i] == 0.0 && ((e.tl >> i) & 1u)));
+                        covered = covered & ((v[i] > 0.0) | ((v[i] == 0.0) & (((e.tl >> i) & 1u) != 0u)));
                     }
                 }
                 if (covered) emit_fragment<GBUFFER, TEX>(a, e, rec_index, px, py, v, tile_x, tile_y, s_depth, s_key);
