@@ -508,7 +508,7 @@ SAH_DEV EdgeSetup edge_setup(const RasterRecord& rec) {
     for (int i = 0; i < 3; i++) {
         const int va = (i + 1) % 3, vb = (i + 2) % 3;  // edge i runs from vertex i+1 to vertex i+2
         const int32_t dx = rec.X[vb] - rec.X[va], dy = rec.Y[vb] - rec.Y[va];
-        e.tl |= (dy < 0 || (dy == 0 && dx > 0)) ? 1u << i : 0u;
+        e.tl |= ((dy < 0) | ((dy == 0) & (dx > 0))) ? 1u << i : 0u;
         e.a[i] = -256.0 * (double)dy;
         e.b[i] = 256.0 * (double)dx;
         e.c[i] = (double)dx * (double)(128 - rec.Y[va]) - (double)dy * (double)(128 - rec.X[va]);
