@@ -8,14 +8,27 @@
 namespace sah {
 
 // ---- a13 -------------------------------------------------------------------------------------------------
+// Four texels of one column per thread, four rows apart, all sixteen taps in flight before the first store: with one texel per thread the
+// pass was 32 400 workgroups of a single load -> filter -> store chain each, bound by workgroup turnover (4.7 TB/s where torch's copy
+// kernel streams the same bytes at 6.9, tools/microbench/stream_ceiling.py).
+constexpr uint32_t kCopyPpt = 4;  // (8: 0.0274 ms, 4: 0.0252, 1: 0.0284)
 __global__ void __launch_bounds__(256) k_copy_scene(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                                                      uint32_t row_end) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= row_end) return;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = row_begin + blockIdx.y * (4 * kCopyPpt) + (threadIdx.x >> 6);
+    if (x >= dw) return;
     const float inv_w = 1.0f / (float)dw, inv_h = 1.0f / (float)dh;
-    const float u = ((float)x + 0.5f) * inv_w, v = ((float)y + 0.5f) * inv_h;
-    const Rgba t = bilinear<ADDR_REPEAT>(src, sw, sh, u, v);
-    store_rgba16f(dst, (int)x, (int)y, t.c[0], t.c[1], t.c[2], t.c[3]);
+    const float u = ((float)x + 0.5f) * inv_w;
+    Rgba t[kCopyPpt];
+#pragma unroll
+    for (uint32_t q = 0; q < kCopyPpt; q++) {
+        const uint32_t y = y0 + 4 * q;
+        if (y < row_end) t[q] = bilinear<ADDR_REPEAT>(src, sw, sh, u, ((float)y + 0.5f) * inv_h);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kCopyPpt; q++) {
+        const uint32_t y = y0 + 4 * q;
+        if (y < row_end) store_rgba16f(dst, (int)x, (int)y, t[q].c[0], t[q].c[1], t[q].c[2], t[q].c[3]);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_bloom_downsample(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh) {
@@ -193,7 +206,7 @@ hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float v
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                              uint32_t row_end, hipStream_t st) {
     if (row_end <= row_begin) return hipSuccess;
-    const dim3 grid((dw + 63) / 64, (row_end - row_begin + 3) / 4);
+    const dim3 grid((dw + 63) / 64, (row_end - row_begin + 4 * kCopyPpt - 1) / (4 * kCopyPpt));
     hipLaunchKernelGGL(k_copy_scene, grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);
     return hipGetLastError();
 }

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--lights", type=int, default=256)
     ap.add_argument("--light-radius", type=float, default=4.0)
-    ap.add_argument("--only", default="", help="run only the passes whose name contains this substring")
+    ap.add_argument("--only", default="", help="run only the passes whose name contains one of these comma-separated substrings")
     ap.add_argument("--json", action="store_true", help="also print the results as one JSON object")
     args = ap.parse_args()
     import torch
@@ -36,7 +36,7 @@ def main():
     results = {}
 
     def wanted(name):
-        return not args.only or args.only.lower() in name.lower()
+        return not args.only or any(part.strip().lower() in name.lower() for part in args.only.split(","))
 
     def timeit(name, fn, bytes_per_call):
         if not wanted(name):
