@@ -58,8 +58,10 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
-    const uint32_t y = a.row_begin + blockIdx.y * 16u + (threadIdx.x >> 4);
+    // a wave is an 8 x 8 pixel square of the 16 x 16 tile (not four rows of it): the light loop skips a light for the whole wave when no
+    // lane is in range, and a compact footprint is in range of fewer lights
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u);
+    const uint32_t y = a.row_begin + blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
     const bool inside = x < a.width && y < a.row_end;
 
     Px p;
