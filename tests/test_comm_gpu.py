@@ -159,3 +159,21 @@ def _check_chain_children(tmp_path, height):
     assert o.orc_tonemap(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips)),
                          C.byref(images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)), 0, 0) == 0
     assert np.array_equal(want_step, out)
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_of_two_ranks_verifies_its_frames(tmp_path):
+    """bench.py's whole N > 1 control flow (process group, row plan, two frames in flight, both exchanges, max over ranks) with two ranks on
+    the one GPU of the box (gloo + the direct exchange): the line it prints must say that the sharded loop's last frames equal the
+    unsharded frame on every rank."""
+    import json
+    port = 29800 + (os.getpid() % 150)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--rehearse-on-one-gpu"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2
+    assert d["config"]["sharded_equals_unsharded"] is True
