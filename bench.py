@@ -422,7 +422,9 @@ def main():
     if chain and not pipelined and world == 1 and not gather and traced is None and args.frames_in_flight == 2:
         pipelined = True
         comm_stream = torch.cuda.Stream(device=dev)
-    if pipelined:
+    pc = sc = None
+
+    def build_pipelined():
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
         pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev),
                                       tonemap_flags=tm_flags)
@@ -440,9 +442,10 @@ def main():
         def drain():
             pc.flush()
             ctx.comm_wait()
-        my_px = W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
-    elif chain:
-        # the whole frame, sharded (chain.py): every exchange goes through the library (torch path only with --torch-gather)
+        return pc, sc, step, drain
+
+    def build_stepwise():
+        # the whole frame, sharded (chain.py), one frame at a time: every exchange goes through the library (torch path only with --torch-gather)
         sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world, tonemap_flags=tm_flags)
         if use_ipc:
             sc.register_direct_exchange(allgather_handles)
@@ -474,7 +477,17 @@ def main():
 
         def drain():
             ctx.comm_wait()
-        my_px = W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
+        return None, sc, step, drain
+
+    def chain_px(sc):
+        return W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
+
+    if pipelined:
+        pc, sc, step, drain = build_pipelined()
+        my_px = chain_px(sc)
+    elif chain:
+        pc, sc, step, drain = build_stepwise()
+        my_px = chain_px(sc)
     else:
         # N > 1: two lit targets, so that the all-gather of frame i (side stream) overlaps the shading of frame i + 1; a target is reused
         # only after its gather has completed (stream-level wait).  Every gather finishes inside the timed region.
@@ -558,6 +571,43 @@ def main():
                 ref_image = ref.out.clone()
             del ref
         torch.cuda.empty_cache()
+
+    # N > 1, two frames in flight: before anything is timed, three frames of the loop are held against the unsharded frame on every
+    # rank.  The loop's streams and events have met more than one GPU only here: if a frame differs, every rank falls back together to
+    # the one-frame-at-a-time loop (exchanges on the work stream's own order), checks that one too, and the line says what ran.
+    preflight = None
+    if pipelined and ref_image is not None and exchange:
+        beat("pre-flight")
+        for i in range(3):
+            step(i)
+        drain()
+        torch.cuda.synchronize()
+        ok = int(bool(torch.equal(pc.image(1), ref_image)) and bool(torch.equal(pc.image(2), ref_image)))
+        if os.environ.get("SAH_BENCH_FAIL_PREFLIGHT") == "1":  # test hook: take the fall-back path
+            ok = 0
+        if torch_pg:
+            t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        preflight = {"two_frames_in_flight_ok": bool(ok), "fallback": None}
+        if not ok:
+            print(f"[bench] rank {rank}: the two-frames-in-flight loop's frames differ from the unsharded frame: falling back to one frame at a time", file=sys.stderr)
+            pc = None
+            pipelined = False
+            torch.cuda.empty_cache()
+            pc, sc, step, drain = build_stepwise()
+            my_px = chain_px(sc)
+            for i in range(2):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+            ok2 = int(bool(torch.equal(sc.out, ref_image)))
+            if torch_pg:
+                t = torch.tensor([ok2], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok2 = int(t.item())
+            preflight["fallback"] = "one frame at a time"
+            preflight["fallback_ok"] = bool(ok2)
 
     if args.ramp_ms > 0:
         t_ramp = time.perf_counter()
@@ -690,6 +740,7 @@ def main():
                 "frames_in_flight": 2 if pipelined else 1,
                 "same_workload_on_one_gpu": single_gpu,
                 "sharded_equals_unsharded": sharded_equals_unsharded,
+                "preflight": preflight,
                 "traced": traced,
             },
             "roofline": roofline(args.workload, world, achieved, kernel_ms_mean, kernel_ms_min, kernel_scope, bytes_per_pixel * my_px, my_px,
