@@ -162,18 +162,25 @@ def _check_chain_children(tmp_path, height):
 
 
 @pytest.mark.gpu
-def test_bench_rehearsal_of_two_ranks_verifies_its_frames(tmp_path):
+@pytest.mark.parametrize("fail_preflight", [False, True])
+def test_bench_rehearsal_of_two_ranks_verifies_its_frames(tmp_path, fail_preflight):
     """bench.py's whole N > 1 control flow (process group, row plan, two frames in flight, both exchanges, max over ranks) with two ranks on
     the one GPU of the box (gloo + the direct exchange): the line it prints must say that the sharded loop's last frames equal the
-    unsharded frame on every rank."""
+    unsharded frame on every rank.  With the pre-flight check made to fail (test hook) every rank must fall back to the one-frame-at-a-time
+    loop, and that loop's frames must be right too."""
     import json
     port = 29800 + (os.getpid() % 150)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **({"SAH_BENCH_FAIL_PREFLIGHT": "1"} if fail_preflight else {}))
+    port += 7 if fail_preflight else 0
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--rehearse-on-one-gpu"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2
-    assert d["config"]["sharded_equals_unsharded"] is True
+    assert d["n_gpus"] == 2 and d["config"]["sharded_equals_unsharded"] is True
+    pre = d["config"]["preflight"]
+    if fail_preflight:
+        assert d["config"]["frames_in_flight"] == 1 and pre["fallback"] == "one frame at a time" and pre["fallback_ok"] is True
+    else:
+        assert d["config"]["frames_in_flight"] == 2 and pre == {"two_frames_in_flight_ok": True, "fallback": None}
