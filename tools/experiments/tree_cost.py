@@ -206,3 +206,15 @@ for clusters in ((64,), (256, 64), (16,)):
     o3 = multipass(multipass(o2, clusters, 1024, 9, 1), (1,), 1024, 9, 4)
     t, leaf, lv = cost(o3)
     print(f"{'   ... + coarse + fine':36s} internal {t:8.3f}  levels {[round(float(x),2) for x in lv]}")
+
+print("---- Hilbert order of centres displaced along the triangle normal (separates the faces that meet at a seam)")
+e1 = T[:, 1] - T[:, 0]; e2 = T[:, 2] - T[:, 0]
+nrm = np.cross(e1, e2); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+ext = float((smax - smin).max())
+for frac in (0.0, 0.002, 0.005, 0.01, 0.02, 0.05):
+    cd = c + nrm * (frac * ext)
+    qd = np.clip(((cd - smin) / (smax - smin) * 1024).astype(np.int64), 0, 1023)
+    od = np.argsort(hilbert(qd), kind="stable")
+    t0, _, _ = cost(od)
+    t1, _, lv = cost(multipass(od, (1,), 1024, 9, 4))
+    print(f"displacement {frac:6.3f} x extent: curve {t0:7.3f}   + SA refine 1024 {t1:7.3f}  levels {[round(float(x),2) for x in lv]}")
