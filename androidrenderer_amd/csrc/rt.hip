@@ -595,20 +595,16 @@ SAH_DEV bool cutout_accepts(const RtScene& sc, const RtTriangle& tr, const Hit& 
 // The hierarchy is implicit and complete (node n of level L covers nodes 4n .. 4n + 3 of level L - 1; level 0 nodes cover four triangles),
 // so a depth-first walk needs no stack in memory: the position is (level, node), and what is left to visit on the way back up is four
 // bits per level — the children of the path's node at that level that the ray's slab test passed and that have not been entered yet.
-// Per-level offsets and counts sit in LDS because the level is a per-lane value.
+// Per-level offsets sit in LDS because the level is a per-lane value (the counts are not needed: fill_absent).
 struct Trav {
     const uint32_t* off;
-    const uint32_t* cnt;
 };
-SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* 2 * kRtMaxLevels words of LDS; every thread of the workgroup calls this */) {
+SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* kRtMaxLevels words of LDS; every thread of the workgroup calls this */) {
 #pragma unroll
     for (uint32_t l = 0; l < kRtMaxLevels; l++)
-        if (threadIdx.x == l) {
-            smem[l] = bvh.level_offset[l];
-            smem[kRtMaxLevels + l] = bvh.level_count[l];
-        }
+        if (threadIdx.x == l) smem[l] = bvh.level_offset[l];
     __syncthreads();
-    return {smem, smem + kRtMaxLevels};
+    return {smem};
 }
 // bit k: child 4 * node + k of (level, node) exists and the ray's slab test passes its box.  The four boxes are one 96-byte group
 // `nearest` (optional): among the passing children, the one the ray enters first (the largest index among equals)
@@ -990,7 +986,7 @@ SAH_DEV void tile_pixel(uint32_t t, uint32_t row_begin, uint32_t& x, uint32_t& y
 // probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes}); a workgroup takes 256 consecutive rays
 // of the dispatch and re-deals them by direction (a probe's 400 rays cover the sphere)
 __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, const RtBvh bvh, const RtScene sc) {
-    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ uint32_t s_levels[kRtMaxLevels];
     __shared__ DealLds s_deal;
     deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
@@ -1047,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, con
 
 // rtgi.rt.slang:56-110
 __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const RtBvh bvh, const RtScene sc) {
-    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ uint32_t s_levels[kRtMaxLevels];
     __shared__ DealLds s_deal;
     deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
@@ -1087,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
 
 // rtao.comp.slang:54-102
 __global__ __launch_bounds__(256) void k_rtao(const RtaoArgs a, const RtBvh bvh, const RtScene sc) {
-    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ uint32_t s_levels[kRtMaxLevels];
     __shared__ DealLds s_deal;
     deal_clear(s_deal);
     const Trav tv = trav_init(bvh, s_levels);
@@ -1132,7 +1128,7 @@ __global__ __launch_bounds__(256) void k_noise_dirs(const PlaneArg noise, const 
 //     sample — walks its other samples as ONE beam (above): what the beam meets is tested ray by ray, and the walk ends early when no
 //     ray of the pixel is left unoccluded.
 __global__ __launch_bounds__(256) void k_sun_shadow_mask(const ShadowMaskArgs a, const RtBvh bvh, const RtScene sc) {
-    __shared__ uint32_t s_levels[2 * kRtMaxLevels];
+    __shared__ uint32_t s_levels[kRtMaxLevels];
     __shared__ float s_origin[3][256];
     __shared__ uint16_t s_pixel[256], s_list[2][256];
     __shared__ uint32_t s_unoccluded[256], s_wave_count[4], s_list_n[2];
