@@ -600,9 +600,12 @@ struct Trav {
     const uint32_t* off;
 };
 SAH_DEV Trav trav_init(const RtBvh& bvh, uint32_t* smem /* kRtMaxLevels words of LDS; every thread of the workgroup calls this */) {
+    // (a chain of selects on the kernel argument's words, then one store: `if (threadIdx.x == l) smem[l] = ...` fifteen times compiled to a
+    //  decision tree of sixty exec-mask regions at the head of every workgroup)
+    uint32_t mine = 0;
 #pragma unroll
-    for (uint32_t l = 0; l < kRtMaxLevels; l++)
-        if (threadIdx.x == l) smem[l] = bvh.level_offset[l];
+    for (uint32_t l = 0; l < kRtMaxLevels; l++) mine = threadIdx.x == l ? bvh.level_offset[l] : mine;
+    if (threadIdx.x < kRtMaxLevels) smem[threadIdx.x] = mine;
     __syncthreads();
     return {smem};
 }
