@@ -739,6 +739,9 @@ def main():
                 "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
                 "frames_in_flight": 2 if pipelined else 1,
                 "same_workload_on_one_gpu": single_gpu,
+                # the N = 1 run of this file measures the headline lighting pass, a different workload from the sharded chain: the strong
+                # scaling of THIS workload is its throughput here over its throughput unsharded on one of these GPUs
+                "speedup_vs_same_workload_on_one_gpu": None if not single_gpu else round(value / single_gpu["value"], 3),
                 "sharded_equals_unsharded": sharded_equals_unsharded,
                 "preflight": preflight,
                 "traced": traced,
