@@ -48,6 +48,12 @@ class ShardedChain:
             nbytes = t.numel() * t.element_size()
             self.ctx.ipc_register(t.data_ptr(), nbytes, allgather(self.ctx.ipc_export(t.data_ptr(), nbytes)))
 
+    def unregister_direct_exchange(self):
+        """Before the chain's buffers are dropped (every rank, same order): a caching allocator may hand their addresses out again, and a
+        registration is found by address."""
+        for t in (self.mip0_alloc, self.out_alloc):
+            self.ctx.ipc_unregister(t.data_ptr())
+
     # the three local stages; `exchange_*` are the two gathers (replaceable: tests emulate several ranks on one device)
     def lighting(self):
         for desc, _keep in self.descs:
@@ -111,6 +117,10 @@ class PipelinedChain:
     def register_direct_exchange(self, allgather):
         for s in self.sets:
             s.register_direct_exchange(allgather)
+
+    def unregister_direct_exchange(self):
+        for s in self.sets:
+            s.unregister_direct_exchange()
 
     def submit(self, lighting_events=None):
         """Enqueue A(i) and the mip-0 exchange of the next frame, then B(i - 1) and the final exchange of the previous one."""

@@ -144,6 +144,8 @@ void SahRange::resolve(push_fn& push, pop_fn& pop) {
     }
 }
 
+bool sah_ipc_timed_out(const sah_ctx* ctx);  // api_ipc.cpp
+
 extern "C" {
 
 int sah_abi_version(void) { return SAH_ABI_VERSION; }
@@ -228,6 +230,8 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->colx_table) (void)hipFree(ctx->colx_table);
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
     if (ctx->tm_axis) (void)hipFree(ctx->tm_axis);
+    for (SahCacheGuard* g : {&ctx->guard_lighting, &ctx->guard_tonemap, &ctx->guard_raster, &ctx->guard_rt})
+        if (g->done) (void)hipEventDestroy(g->done);
     for (void* p : ctx->raster.ptr)
         if (p) (void)hipFree(p);
     for (void* p : ctx->rt.ptr)
@@ -240,12 +244,17 @@ void sah_destroy(sah_ctx* ctx) {
 
 int sah_set_stream(sah_ctx* ctx, void* hip_stream) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
-    // (switching streams does not order them: callers that pipeline two work streams switch per frame, androidrenderer_amd/chain.py.  The
-    // one piece of context-wide device state that a switch could expose — the probe-slot table of sah_probe_update — orders itself.)
-    if (ctx->own_stream && ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    // Switching streams does not order them as a whole: callers that pipeline two work streams switch per frame
+    // (androidrenderer_amd/chain.py).  What IS ordered is the context-wide device state a pass re-uses across calls — the LPV gather copy,
+    // the fp32 irradiance atlas, the column table and the deferred-pixel lists of sah_lighting, the axis tables of sah_tonemap_ex, the
+    // rasteriser's scratch, the ray-tracing structure (SahCacheGuard, ctx.hpp) and the probe-slot table (sah_probe_update): a pass that
+    // moves to another stream starts behind its own last use on the old one.
+    if ((hipStream_t)hip_stream == ctx->stream && !ctx->own_stream) return SAH_OK;
+    const bool drained = ctx->own_stream && ctx->stream;
+    if (drained) (void)hipStreamSynchronize(ctx->stream);
+    SahCacheGuard* guards[] = {&ctx->guard_lighting, &ctx->guard_tonemap, &ctx->guard_raster, &ctx->guard_rt};
+    for (SahCacheGuard* g : guards) HIP_TRY(ctx, sah_guard_leave(ctx, *g, drained));
+    if (drained) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return SAH_OK;
@@ -279,6 +288,9 @@ int sah_debug_deferred_pixels(sah_ctx* ctx, uint64_t* out) {
 int sah_sync(sah_ctx* ctx) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream && ctx->comm_stream != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    // a gather of the direct exchange whose wait gave up has skipped its copies: what the caller is about to read is stale or torn
+    if (sah_ipc_timed_out(ctx)) return fail(ctx, SAH_ERR_COMM, "direct exchange: a peer did not arrive within 2 s; the gathered rows are not valid");
     return SAH_OK;
 }
 
@@ -508,6 +520,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         a.num_lights = d->lights->count;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_lighting));
     FastArgs fast;
     memset(&fast, 0, sizeof(fast));
     const bool fast_kind = (gi_kind == SAH_GI_NONE || gi_kind == SAH_GI_LPV) && a.num_lights == 0;

@@ -10,13 +10,18 @@ namespace sah {
 struct IpcPeers {
     uint32_t* slot[SAH_IPC_MAX_WORLD];
 };
-hipError_t launch_ipc_signal(const IpcPeers& peers, uint32_t value, hipStream_t st);
-hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* timed_out, hipStream_t st);
+struct IpcCopies {
+    uint8_t* dst[SAH_IPC_MAX_WORLD];
+};
+hipError_t launch_ipc_signal(const IpcPeers& peers, uint32_t value, const uint32_t* abort, hipStream_t st);
+hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* abort, uint32_t* timed_out, hipStream_t st);
+hipError_t launch_ipc_copy(const IpcCopies& c, int world, const uint8_t* src, uint64_t bytes, const uint32_t* abort, hipStream_t st);
 }  // namespace sah
 
 namespace {
 constexpr uint32_t kMagic = 0x53414849u;  // "SAHI"
 constexpr uint32_t kMailboxWords = 2 * SAH_IPC_MAX_BUFFERS * SAH_IPC_MAX_WORLD;
+constexpr uint32_t kMailboxAlloc = kMailboxWords + 16;  // + the abort word (its own 64 bytes; peers never touch it)
 
 struct Handle {  // SAH_IPC_HANDLE_BYTES
     hipIpcMemHandle_t mem;  // 64 bytes: the allocation the buffer lies in
@@ -43,10 +48,11 @@ int export_range(sah_ctx* ctx, const void* ptr, uint64_t bytes, Handle* h) {
     return SAH_OK;
 }
 
-// maps the allocation behind a peer's handle (once per allocation) and returns the buffer's address in this process
+// maps the allocation behind a peer's handle (once per allocation, counted per user) and returns the buffer's address in this process
 int open_range(sah_ctx* ctx, const Handle& h, uint8_t** out) {
-    for (const auto& m : ctx->ipc.mappings)
+    for (auto& m : ctx->ipc.mappings)
         if (memcmp(m.handle, &h.mem, 64) == 0) {
+            m.users++;
             *out = (uint8_t*)m.base + h.offset;
             return SAH_OK;
         }
@@ -55,9 +61,22 @@ int open_range(sah_ctx* ctx, const Handle& h, uint8_t** out) {
     sah_ctx::IpcState::Mapping m;
     memcpy(m.handle, &h.mem, 64);
     m.base = base;
+    m.users = 1;
     ctx->ipc.mappings.push_back(m);
     *out = (uint8_t*)base + h.offset;
     return SAH_OK;
+}
+// gives back one use of the mapping that holds `ptr` (the mapping is closed with its last user)
+void close_range(sah_ctx* ctx, const Handle& h) {
+    auto& ms = ctx->ipc.mappings;
+    for (size_t i = 0; i < ms.size(); i++)
+        if (memcmp(ms[i].handle, &h.mem, 64) == 0) {
+            if (--ms[i].users == 0) {
+                (void)hipIpcCloseMemHandle(ms[i].base);
+                ms.erase(ms.begin() + (long)i);
+            }
+            return;
+        }
 }
 }  // namespace
 
@@ -70,47 +89,53 @@ extern "C" void sah_ipc_destroy(sah_ctx* ctx) {
     s.mailbox = nullptr;
     s.timed_out = nullptr;
     s.open = s.connected = false;
-    s.num_buffers = 0;
+    for (auto& b : s.buffers) b = {};
 }
+
+// a wait of an earlier gather gave up: every exchange entry point fails from then on (api.cpp: sah_sync, api_post.cpp: sah_comm_wait)
+bool sah_ipc_timed_out(const sah_ctx* ctx) { return ctx->ipc.timed_out && *ctx->ipc.timed_out != 0; }
 
 // the gather itself: called by allgather_bytes_impl (api_post.cpp) when `buffer` lies inside a registered buffer
 int sah_ipc_gather(sah_ctx* ctx, uint32_t id, uint8_t* buffer, uint64_t bytes_per_rank, bool reversed, hipStream_t st) {
     using namespace sah;
     auto& s = ctx->ipc;
     auto& b = s.buffers[id];
-    if (*s.timed_out) return fail(ctx, SAH_ERR_COMM, "direct exchange: a peer did not arrive within 2 s (an earlier gather gave up)");
+    if (sah_ipc_timed_out(ctx)) return fail(ctx, SAH_ERR_COMM, "direct exchange: a peer did not arrive within 2 s (an earlier gather gave up)");
     const uint64_t off = (uint64_t)(buffer - b.local);
     if (off + (uint64_t)ctx->world * bytes_per_rank > b.bytes) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the gather leaves the registered buffer");
     const uint32_t n = ++b.seq;
     const int slot = reversed ? ctx->world - 1 - ctx->rank : ctx->rank;
+    const uint64_t slot_off = off + (uint64_t)slot * bytes_per_rank;
     IpcPeers ready_out{}, ready_in{}, done_out{}, done_in{};
+    IpcCopies copies{};
     for (int p = 0; p < ctx->world; p++) {
         if (p == ctx->rank) continue;
         ready_out.slot[p] = s.peer_mailbox[p] + id * SAH_IPC_MAX_WORLD + ctx->rank;
         ready_in.slot[p] = s.mailbox + id * SAH_IPC_MAX_WORLD + p;
         done_out.slot[p] = s.peer_mailbox[p] + (SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + ctx->rank;
         done_in.slot[p] = s.mailbox + (SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + p;
+        copies.dst[p] = b.peer[p] + slot_off;
     }
+    uint32_t* abort = s.mailbox + kMailboxWords;
     // 1. my rows are written (stream order) and my copy of the buffer may be overwritten; 2. so may every peer's
-    HIP_TRY(ctx, launch_ipc_signal(ready_out, n, st));
-    HIP_TRY(ctx, launch_ipc_wait(ready_in, n, s.timed_out, st));
-    // 3. one hop per peer
-    const uint64_t slot_off = off + (uint64_t)slot * bytes_per_rank;
-    for (int p = 0; p < ctx->world; p++)
-        if (p != ctx->rank) HIP_TRY(ctx, hipMemcpyAsync(b.peer[p] + slot_off, b.local + slot_off, bytes_per_rank, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, launch_ipc_signal(ready_out, n, abort, st));
+    HIP_TRY(ctx, launch_ipc_wait(ready_in, n, abort, s.timed_out, st));
+    // 3. one hop per peer (skipped, like everything behind it, once a wait has given up: a peer that did not arrive may still be using
+    //    its copy of the buffer)
+    HIP_TRY(ctx, launch_ipc_copy(copies, ctx->world, b.local + slot_off, bytes_per_rank, abort, st));
     // 4. my rows have landed everywhere; 5. so have everybody's here
-    HIP_TRY(ctx, launch_ipc_signal(done_out, n, st));
-    HIP_TRY(ctx, launch_ipc_wait(done_in, n, s.timed_out, st));
+    HIP_TRY(ctx, launch_ipc_signal(done_out, n, abort, st));
+    HIP_TRY(ctx, launch_ipc_wait(done_in, n, abort, s.timed_out, st));
     return SAH_OK;
 }
 
-// index of the registered buffer that holds [ptr, ptr + bytes), or -1
+// index of the registered buffer that holds [ptr, ptr + bytes), or -1 (registrations never overlap: sah_ipc_register)
 int sah_ipc_find(const sah_ctx* ctx, const void* ptr, uint64_t bytes) {
     const auto& s = ctx->ipc;
     if (!s.connected) return -1;
-    for (uint32_t i = 0; i < s.num_buffers; i++) {
+    for (uint32_t i = 0; i < SAH_IPC_MAX_BUFFERS; i++) {
         const uint8_t* p = (const uint8_t*)ptr;
-        if (p >= s.buffers[i].local && p + bytes <= s.buffers[i].local + s.buffers[i].bytes) return (int)i;
+        if (s.buffers[i].in_use && p >= s.buffers[i].local && p + bytes <= s.buffers[i].local + s.buffers[i].bytes) return (int)i;
     }
     return -1;
 }
@@ -123,18 +148,20 @@ int sah_ipc_open(sah_ctx* ctx, void* out_handle) {
     auto& s = ctx->ipc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!s.open) {
-        // fine-grained: peers' system-scope stores become visible to the polling wave without a kernel boundary
-        if (hipExtMallocWithFlags((void**)&s.mailbox, kMailboxWords * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
+        // fine-grained: peers' system-scope stores become visible to the polling wave without a kernel boundary.  No fall-back to
+        // ordinary (coarse-grained) device memory: a polling wave might never see a peer's store there, and every gather would time out
+        if (hipExtMallocWithFlags((void**)&s.mailbox, kMailboxAlloc * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
-            HIP_TRY(ctx, hipMalloc((void**)&s.mailbox, kMailboxWords * sizeof(uint32_t)));
+            s.mailbox = nullptr;
+            return fail(ctx, SAH_ERR_UNSUPPORTED, "direct exchange: this device does not give fine-grained device memory (hipDeviceMallocFinegrained)");
         }
-        HIP_TRY(ctx, hipMemset(s.mailbox, 0, kMailboxWords * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemset(s.mailbox, 0, kMailboxAlloc * sizeof(uint32_t)));
         HIP_TRY(ctx, hipHostMalloc((void**)&s.timed_out, 64));
         *s.timed_out = 0;
         s.open = true;
     }
     Handle h;
-    if (int rc = export_range(ctx, s.mailbox, kMailboxWords * sizeof(uint32_t), &h); rc != SAH_OK) return rc;
+    if (int rc = export_range(ctx, s.mailbox, kMailboxWords * sizeof(uint32_t), &h); rc != SAH_OK) return rc;  // (the abort word stays private)
     memcpy(out_handle, &h, sizeof(h));
     return SAH_OK;
 }
@@ -173,24 +200,68 @@ int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all
     if (!ctx || !buffer || !bytes || !all_handles) return SAH_ERR_INVALID_ARGUMENT;
     auto& s = ctx->ipc;
     if (!s.connected) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "sah_ipc_connect first");
-    if (s.num_buffers == SAH_IPC_MAX_BUFFERS) return fail(ctx, SAH_ERR_UNSUPPORTED, "at most %d registered buffers", SAH_IPC_MAX_BUFFERS);
+    // A registration is looked up by address (sah_ipc_find), so no two may overlap: a buffer that was freed and whose address a caching
+    // allocator has handed out again must be unregistered first — the stale entry carries the old peer addresses and counters
+    int id = -1;
+    for (uint32_t i = 0; i < SAH_IPC_MAX_BUFFERS; i++) {
+        const auto& o = s.buffers[i];
+        if (!o.in_use) {
+            if (id < 0) id = (int)i;  // the lowest free index: the same on every rank when all register / unregister in the same order
+            continue;
+        }
+        if ((uint8_t*)buffer < o.local + o.bytes && o.local < (uint8_t*)buffer + bytes)
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "the buffer overlaps registration %u (sah_ipc_unregister it first)", i);
+    }
+    if (id < 0) return fail(ctx, SAH_ERR_UNSUPPORTED, "at most %d registered buffers", SAH_IPC_MAX_BUFFERS);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const Handle* hs = (const Handle*)all_handles;
-    auto& b = s.buffers[s.num_buffers];
+    for (int p = 0; p < ctx->world; p++)
+        if (hs[p].magic != kMagic || (int)hs[p].rank != p || hs[p].bytes != bytes)
+            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "handle %d does not describe rank %d's copy of a %llu-byte buffer", p, p, (unsigned long long)bytes);
+    auto& b = s.buffers[id];
+    const uint32_t seq = b.seq;  // counters of a mailbox slot only ever grow: a re-used index goes on counting where the last user stopped
     b = {};
+    b.seq = seq;
     b.local = (uint8_t*)buffer;
     b.bytes = bytes;
     for (int p = 0; p < ctx->world; p++) {
-        if (hs[p].magic != kMagic || (int)hs[p].rank != p || hs[p].bytes != bytes)
-            return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "handle %d does not describe rank %d's copy of a %llu-byte buffer", p, p, (unsigned long long)bytes);
         if (p == ctx->rank) {
             b.peer[p] = b.local;
             continue;
         }
-        if (int rc = open_range(ctx, hs[p], &b.peer[p]); rc != SAH_OK) return rc;
+        if (int rc = open_range(ctx, hs[p], &b.peer[p]); rc != SAH_OK) {
+            for (int q = 0; q < p; q++)
+                if (q != ctx->rank) close_range(ctx, hs[q]);
+            return rc;
+        }
+        memcpy(b.peer_handle[p], &hs[p], sizeof(Handle));
     }
-    s.num_buffers++;
+    b.in_use = true;
     return SAH_OK;
+}
+
+int sah_ipc_unregister(sah_ctx* ctx, const void* buffer) {
+    if (!ctx || !buffer) return SAH_ERR_INVALID_ARGUMENT;
+    auto& s = ctx->ipc;
+    for (uint32_t i = 0; i < SAH_IPC_MAX_BUFFERS; i++) {
+        auto& b = s.buffers[i];
+        if (!b.in_use || b.local != (const uint8_t*)buffer) continue;
+        // nothing of this context may still be copying into the peers' mappings
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int p = 0; p < ctx->world; p++) {
+            if (p == ctx->rank) continue;
+            Handle h;
+            memcpy(&h, b.peer_handle[p], sizeof(Handle));
+            close_range(ctx, h);
+        }
+        const uint32_t seq = b.seq;
+        b = {};
+        b.seq = seq;
+        return SAH_OK;
+    }
+    return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "no registration starts at %p", buffer);
 }
 
 }  // extern "C"

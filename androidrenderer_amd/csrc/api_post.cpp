@@ -100,6 +100,8 @@ bool lpv_vol_ok(const sah_volume* v) {
 int sah_ipc_find(const sah_ctx* ctx, const void* ptr, uint64_t bytes);
 int sah_ipc_gather(sah_ctx* ctx, uint32_t id, uint8_t* buffer, uint64_t bytes_per_rank, bool reversed, hipStream_t st);
 
+bool sah_ipc_timed_out(const sah_ctx* ctx);  // api_ipc.cpp
+
 extern "C" {
 
 int sah_copy_scene_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
@@ -214,7 +216,9 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
     t.row_begin = row_begin;
     t.row_end = row_end;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (flags & SAH_TONEMAP_TOLERANCE_1CODE) {
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_tonemap));
+    // (the tolerance kernel stages six mips; a longer chain takes the strict kernel, whose result is inside the tolerance by definition)
+    if ((flags & SAH_TONEMAP_TOLERANCE_1CODE) && bloom->num_mips <= 6) {
         // per-column / per-row axis set-ups: a function of the extents only, kept across calls
         uint32_t key[2 + 2 * 8 + 1] = {out->width, out->height};
         for (uint32_t m = 0; m < bloom->num_mips; m++) {
@@ -503,6 +507,9 @@ int sah_comm_wait(sah_ctx* ctx) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_done, 0));
         ctx->comm_pending = false;
     }
+    // (what is known on the host now: a wait of an EARLIER gather that gave up.  The gather just joined may still be running; sah_sync
+    // reports its outcome)
+    if (sah_ipc_timed_out(ctx)) return fail(ctx, SAH_ERR_COMM, "direct exchange: a peer did not arrive within 2 s; the gathered rows are not valid");
     return SAH_OK;
 }
 

@@ -187,6 +187,7 @@ int sah_shadow_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_s
         ((uintptr_t)shadowmap->ptr % 2) || (shadowmap->row_pitch_bytes % 2) || (shadowmap->slice_pitch_bytes % 2))
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "shadow_render: shadow map extent (1..%u), layers or pitches", kMaxExtent);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_raster));
     sah::RasterArgs a{};
     fill_scene(ctx, a, scene);
     a.num_views = num_cascades;
@@ -215,6 +216,7 @@ int sah_gbuffer_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_
         if (!plane_ok(t.p, t.fmt, t.fmt, W, H) || ((uintptr_t)t.p->ptr % t.align) || (t.p->row_pitch_bytes % t.align))
             return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "gbuffer_render: target '%s' has the wrong format, extent or alignment", t.name);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_raster));
     if (int rc = ensure_srgb_table(ctx); rc != SAH_OK) return rc;
     sah::RasterArgs a{};
     fill_scene(ctx, a, scene);
@@ -253,6 +255,7 @@ int sah_rsm_render(sah_ctx* ctx, const sah_scene_geometry* scene, const sah_sun_
             ((uintptr_t)t.v->ptr % t.bpp) || (t.v->row_pitch_bytes % t.bpp) || (t.v->slice_pitch_bytes % t.bpp))
             return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "rsm_render: target '%s' has the wrong format, extent, layers or alignment", t.name);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_raster));
     if (int rc = ensure_srgb_table(ctx); rc != SAH_OK) return rc;
     sah::RasterArgs a{};
     fill_scene(ctx, a, scene);
@@ -286,6 +289,7 @@ int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv
         rsm->depth.format != SAH_FORMAT_D16_UNORM)
         return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "lpv_extract_vpls: RSM formats are RGBA8_SRGB / RGBA8_UNORM / D16_UNORM");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_raster));
     const size_t invocations = (size_t)(res / 2) * (res / 2);
     if (int rc = ensure(ctx, S_VPL_CANDIDATES, invocations * (sizeof(sah_packed_vpl) + sizeof(uint32_t))); rc != SAH_OK) return rc;
     HIP_TRY(ctx, sah::launch_extract_vpls(varg(rsm->flux), varg(rsm->normals), varg(rsm->depth), cascades[cascade_index], cascade_index, grid_cell_size, ctx->luts,
@@ -310,6 +314,7 @@ int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint
         v[c] = varg(rgb[c]);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_raster));
     // cell index per light, then (16-byte aligned) the 12 blend sources of up to 4096 sorted lights (vpl.hip: k_inject_sorted)
     if (int rc = ensure(ctx, S_VPL_CELLS, ((size_t)capacity + 8) * sizeof(uint32_t) + (size_t)4096 * 12 * sizeof(float)); rc != SAH_OK) return rc;
     HIP_TRY(ctx, sah::launch_inject_vpls(vpl_list, vpl_count, capacity, cascades[cascade_index], cascade_index, num_cascades, v,

@@ -69,6 +69,7 @@ int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "scene arrays are null");
     if (scene->num_primitives >= (1u << 24)) return fail(ctx, SAH_ERR_UNSUPPORTED, "too many primitives");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_rt));
     RtScene sc;
     memset(&sc, 0, sizeof(sc));
     sc.positions = scene->vertex_positions;
@@ -184,6 +185,7 @@ int sah_rtao(sah_ctx* ctx, const sah_view_data* view, const sah_plane* depth, co
     a.samples = samples_per_pixel;
     a.max_distance = max_ray_distance;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_rt));
     rt_rows(ctx, H, &a.row_begin, &a.row_end);
     HIP_TRY(ctx, launch_rtao(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
@@ -228,6 +230,7 @@ int sah_sun_shadow_mask(sah_ctx* ctx, const sah_view_data* view, const sah_sun_l
     a.tan_size = sun->direction_and_tan_size[3];
     a.num_samples = sun->num_shadow_samples;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_rt));
     rt_rows(ctx, H, &a.row_begin, &a.row_end);
     // every sample of every pixel reads one of 16 384 noise directions: normalised once per call instead of once per ray
     if (int rc = ensure(ctx, R_NOISE_DIRS, 128u * 128u * 16u); rc != SAH_OK) return rc;
@@ -284,6 +287,7 @@ int sah_probe_trace(sah_ctx* ctx, const sah_probe_trace_desc* d) {
     a.num_probes = d->num_probes;
     a.out = varg(tr);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_rt));
     HIP_TRY(ctx, launch_probe_trace(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;
 }
@@ -318,6 +322,7 @@ int sah_rtgi_trace(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_
     a.res[0] = view->render_resolution[0];
     a.res[1] = view->render_resolution[1];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_rt));
     rt_rows(ctx, H, &a.row_begin, &a.row_end);
     HIP_TRY(ctx, launch_rtgi_trace(a, ctx->rt.bvh, ctx->rt.scene, ctx->stream));
     return SAH_OK;

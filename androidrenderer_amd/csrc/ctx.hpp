@@ -11,6 +11,17 @@
 #include "params.hpp"
 #include "rt_args.hpp"
 
+// Context-wide device state that entry points build once and re-use (gather copies, tables, scratch) is written and read on whatever
+// stream is current.  A caller that moves a pass to another stream (sah_set_stream) must not see a table before its build kernel has
+// finished, nor overwrite one the previous stream still reads: sah_set_stream records an event behind the old stream's work for every
+// group of such state that was last touched there, and the next entry point that touches the group on a different stream waits for it.
+// Single-stream use costs nothing; a caller that keeps each pass on its own stream (androidrenderer_amd/chain.py) never waits.
+struct SahCacheGuard {
+    hipEvent_t done = nullptr;   // behind the last use on `last`, recorded when the context left that stream
+    hipStream_t last = nullptr;
+    bool used = false, closed = false;
+};
+
 struct sah_ctx {
     int device = 0;
     int rank = 0, world = 1;
@@ -68,22 +79,25 @@ struct sah_ctx {
     } rt;
     struct IpcState {                  // direct exchange (api_ipc.cpp): mailboxes and peer mappings
         bool open = false, connected = false;
-        uint32_t* mailbox = nullptr;   // own: ready[SAH_IPC_MAX_BUFFERS][SAH_IPC_MAX_WORLD] then done[..][..], fine-grained device memory
+        uint32_t* mailbox = nullptr;   // own: ready[SAH_IPC_MAX_BUFFERS][SAH_IPC_MAX_WORLD] then done[..][..], then the abort word; fine-grained device memory
         uint32_t* peer_mailbox[SAH_IPC_MAX_WORLD] = {};
         uint32_t* timed_out = nullptr; // pinned host word the wait kernel raises
         struct Mapping {               // one opened IPC handle (an allocation of a peer)
             unsigned char handle[64];
             void* base;
+            uint32_t users;            // registered buffers (and the mailbox connection) that lie in it
         };
         std::vector<Mapping> mappings;
         struct Buffer {
+            bool in_use = false;
             uint8_t* local = nullptr;
             uint64_t bytes = 0;
             uint8_t* peer[SAH_IPC_MAX_WORLD] = {};
-            uint32_t seq = 0;          // gathers made on this buffer
+            unsigned char peer_handle[SAH_IPC_MAX_WORLD][SAH_IPC_HANDLE_BYTES] = {};  // what sah_ipc_unregister gives back
+            uint32_t seq = 0;          // gathers made through this index (mailbox counters only ever grow, whoever uses the index)
         } buffers[SAH_IPC_MAX_BUFFERS];
-        uint32_t num_buffers = 0;
     } ipc;
+    SahCacheGuard guard_lighting, guard_tonemap, guard_raster, guard_rt;  // see SahCacheGuard
     uint32_t raster_merge_cap = 2048;  // tiles whose bin list may be split (testing hook SAH_RASTER_MERGE_CAPACITY: 0 = every list whole)
     std::string last_error;
 };
@@ -121,6 +135,29 @@ inline int fail(sah_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->last_error = buf;
     return code;
+}
+
+// the entry point is about to touch the guarded state on ctx->stream
+inline hipError_t sah_guard_touch(sah_ctx* ctx, SahCacheGuard& g) {
+    hipError_t e = hipSuccess;
+    if (g.used && g.closed && g.last != ctx->stream) e = hipStreamWaitEvent(ctx->stream, g.done, 0);
+    g.used = true;
+    g.closed = false;
+    g.last = ctx->stream;
+    return e;
+}
+// the context leaves ctx->stream (sah_set_stream); `drained`: that stream has been synchronised, nothing of it is pending
+inline hipError_t sah_guard_leave(sah_ctx* ctx, SahCacheGuard& g, bool drained) {
+    if (!g.used || g.closed || g.last != ctx->stream) return hipSuccess;
+    if (drained) {
+        g.used = false;
+        return hipSuccess;
+    }
+    hipError_t e = hipSuccess;
+    if (!g.done) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(g.done, ctx->stream);
+    g.closed = e == hipSuccess;
+    return e;
 }
 
 #define HIP_TRY(ctx, expr)                                                                          \

@@ -437,8 +437,9 @@ __global__ __launch_bounds__(768) void k_rt_refine(const RtTriangle* unsorted, u
 }
 
 // The lanes of a level's last group that stand for no node hold the box [+inf, +inf]^3, which no ray passes: RN((+inf - o) * inv) is
-// +inf on both planes of an axis where inv > 0 (entry = +inf > exit) and -inf where inv < 0 (exit = -inf < entry); inv is never 0 or
-// NaN for a ray that walks (non-finite rays do not).  The walk then needs no "does this child exist" test.
+// +inf on both planes of an axis where inv > 0 (entry = +inf > exit = min(tmax, +inf): make_ray keeps tmax FINITE, and the closest-hit
+// walk only ever lowers it) and -inf where inv < 0 (exit = -inf < entry); inv is never 0 or NaN for a ray that walks (non-finite rays do
+// not).  The walk then needs no "does this child exist" test.
 SAH_DEV void fill_absent(RtNodeGroup& g, uint32_t first_absent) {
     if (first_absent == 0u) return;  // the group is full
     for (uint32_t k = first_absent; k < kRtFanout; k++)
@@ -497,7 +498,9 @@ SAH_DEV Ray make_ray(const float o[3], const float d[3], float tmin, float tmax)
         r.inv[c] = 1.0f / d[c];
     }
     r.tmin = tmin;
-    r.tmax = tmax;
+    // tmax is at most the largest finite float (sah_hip.h "ray tracing": an infinite or NaN distance means that).  fill_absent()'s boxes
+    // rely on it: with tmax = +inf a ray whose direction has no negative component would pass them and walk into nodes that do not exist
+    r.tmax = __builtin_fminf(tmax, 3.402823466e+38f);
     r.finite = finite3(o) && finite3(d);  // a ray with a non-finite origin or direction hits nothing (sah_hip.h)
     const float ax = __builtin_fabsf(d[0]), ay = __builtin_fabsf(d[1]), az = __builtin_fabsf(d[2]);
     int kz = 0;
@@ -831,7 +834,7 @@ SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv,
                     best.tri = node;
                     best_prim = tr.primitive;
                     best_tri = tr.triangle;
-                    r.tmax = h.t * 1.000244140625f;
+                    r.tmax = __builtin_fminf(h.t * 1.000244140625f, tmax0);  // (never above the ray's own, finite, tmax)
                 }
             }
             alive = trav_next(top, level, node, pending, 0u);

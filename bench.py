@@ -592,6 +592,8 @@ def main():
         preflight = {"two_frames_in_flight_ok": bool(ok), "fallback": None}
         if not ok:
             print(f"[bench] rank {rank}: the two-frames-in-flight loop's frames differ from the unsharded frame: falling back to one frame at a time", file=sys.stderr)
+            if use_ipc:  # the registrations are found by address: give them back before the allocator can hand the addresses out again
+                pc.unregister_direct_exchange()
             pc = None
             pipelined = False
             torch.cuda.empty_cache()
@@ -679,6 +681,8 @@ def main():
     if ref_image is not None:
         outs = [pc.image(args.steps - 1), pc.image(args.steps - 2)] if pipelined and args.steps > 1 else [pc.image(args.steps - 1) if pipelined else sc.out]
         same = int(all(bool(torch.equal(o, ref_image)) for o in outs))
+        if os.environ.get("SAH_BENCH_FAIL_VERIFY") == "1":  # test hook: the line must then carry no throughput and the exit code say so
+            same = 0
         if torch_pg:
             t = torch.tensor([same], dtype=torch.int32, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -686,6 +690,13 @@ def main():
         sharded_equals_unsharded = bool(same)
         if not same:
             print(f"[bench] rank {rank}: the sharded loop's final image differs from the unsharded frame", file=sys.stderr)
+    # A loop that moved wrong rows has no throughput: the line then carries value null and an error, and every rank exits non-zero (the
+    # verdicts above are all-reduced, so the ranks agree).  Likewise when the pre-flight fell back and the fall-back was wrong as well.
+    failure = None
+    if sharded_equals_unsharded is False:
+        failure = "the sharded loop's last frames differ from the unsharded frame on at least one rank"
+    elif preflight is not None and preflight.get("fallback") and not preflight.get("fallback_ok"):
+        failure = "pre-flight: the two-frames-in-flight loop AND the one-frame-at-a-time fall-back differ from the unsharded frame"
 
     if rank == 0:
         px = W * H
@@ -709,7 +720,7 @@ def main():
             par = f"row-shard x{world} + RCCL all-gather of the lit rows"
         out = {
             "metric": "lit Mpixels/sec (deferred+GI pass) at 4K",
-            "value": round(value, 1),
+            "value": None if failure else round(value, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -741,7 +752,8 @@ def main():
                 "same_workload_on_one_gpu": single_gpu,
                 # the N = 1 run of this file measures the headline lighting pass, a different workload from the sharded chain: the strong
                 # scaling of THIS workload is its throughput here over its throughput unsharded on one of these GPUs
-                "speedup_vs_same_workload_on_one_gpu": None if not single_gpu else round(value / single_gpu["value"], 3),
+                # (null in a rehearsal: there every rank — and the one-GPU reference, timed while the others wait — shares ONE GPU)
+                "speedup_vs_same_workload_on_one_gpu": None if (not single_gpu or rehearsal or failure) else round(value / single_gpu["value"], 3),
                 "sharded_equals_unsharded": sharded_equals_unsharded,
                 "preflight": preflight,
                 "traced": traced,
@@ -749,6 +761,9 @@ def main():
             "roofline": roofline(args.workload, world, achieved, kernel_ms_mean, kernel_ms_min, kernel_scope, bytes_per_pixel * my_px, my_px,
                                  "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),
         }
+        if failure:
+            out["error"] = failure
+            out["measured_but_invalid_Mpixels_per_s"] = round(value, 1)
         if n_lights:
             out["config"].update(light_stats(torch, fr, d_arr, lights, dev))
         if world == 1 and not args.no_cpu_baseline:
@@ -763,6 +778,8 @@ def main():
     if torch_pg:
         dist.barrier()
         dist.destroy_process_group()
+    if failure:
+        sys.exit(3)
 
 
 def cpu_baseline(fr, target_s):

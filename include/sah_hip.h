@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SAH_ABI_VERSION 4
+#define SAH_ABI_VERSION 5
 
 typedef enum sah_status {
     SAH_OK = 0,
@@ -236,7 +236,9 @@ const char* sah_last_error(const sah_ctx* ctx);
 int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_id);
 void sah_destroy(sah_ctx* ctx);
 int sah_comm_unique_id(void* out_128_bytes);
-/* Use an externally owned hipStream_t (e.g. the caller's frame stream) for all subsequent work. */
+/* Use an externally owned hipStream_t (e.g. the caller's frame stream) for all subsequent work.  Streams are not ordered against each
+ * other as a whole; what the library keeps between calls (gather copies, tables, scratch buffers, the ray-tracing structure) is: a pass
+ * that is moved to another stream starts behind its own last use of that state on the previous stream. */
 int sah_set_stream(sah_ctx* ctx, void* hip_stream);
 int sah_sync(sah_ctx* ctx);
 
@@ -264,7 +266,8 @@ int sah_tonemap(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* 
  * bit-identical to the oracle.  SAH_TONEMAP_TOLERANCE_1CODE: the same real-number expression evaluated in another order (the nine tent
  * taps of a mip as one column pass per tile and four row interpolations per pixel, fused multiply-adds) — every channel of every pixel
  * within ONE R8G8B8A8 code of the strict result (BASELINE.json north_star: 1 ULP of the stored format), identical on all but the few
- * pixels whose value lies within ~2^-20 relative of a code threshold; about half the time of the strict pass. */
+ * pixels whose value lies within ~2^-20 relative of a code threshold; about half the time of the strict pass.  Chains of
+ * more than six mips (SAH_MAX_BLOOM_MIPS allows eight; the reference makes six) take the strict kernel under this flag as well. */
 #define SAH_TONEMAP_TOLERANCE_1CODE (1u << 0)
 int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, const sah_plane* out_rgba8,
                    uint32_t row_begin, uint32_t row_end, uint32_t flags);
@@ -522,6 +525,9 @@ int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint
  *               the winding).
  *               RAY_FLAG_CULL_FRONT_FACING_TRIANGLES / CULL_BACK_FACING_TRIANGLES drop candidates by that sign before anything else.
  *   a ray with a non-finite origin or direction component hits nothing.
+ *   tmax        the tmax of every ray is minNum(tmax, FLT_MAX): an infinite (or NaN) distance means the largest finite float, in slab()
+ *               and in the triangle test alike (sah_rtao's max_ray_distance and 4 * probe_spacing of sah_probe_trace are the two
+ *               caller-given ones).
  * The structure itself (an implicit 4-wide hierarchy over Morton-sorted triangles, built on the GPU) is an implementation detail. */
 
 /* RaytracingScene::add_primitive / commit_tlas_builds — RenderCore/render/raytracing_scene.cpp:15-170 (and the BLAS builds behind
@@ -632,7 +638,14 @@ int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank);
  * may be overwritten" to every peer, wait for theirs, copy the own slot into every peer's buffer (hipMemcpyAsync on the exchange stream),
  * signal "done", wait for theirs — counters only ever grow, so nothing is reset between frames, and sah_comm_set_stream /
  * sah_comm_wait order it against the work stream exactly as they do the RCCL path.  A peer that does not arrive within two seconds
- * makes the waiting kernel give up and every later call on the context fail with SAH_ERR_COMM (no kernel spins forever).
+ * makes the waiting kernel give up (no kernel spins forever) and raise a device word that every later step of that gather, and of every
+ * later gather, tests first: no copy into a peer and no "done" signal leaves a rank that has given up (the copy is a kernel of this
+ * library for that reason, not hipMemcpyAsync).  sah_sync — which then also waits for the exchange stream — and sah_comm_wait return
+ * SAH_ERR_COMM from then on, as does every later gather: rows gathered by a call that has not been followed by a successful sah_sync
+ * are not known to be valid.  sah_ipc_open fails with SAH_ERR_UNSUPPORTED on a device without fine-grained device memory.
+ * Registrations are found by address and must not overlap: before a registered buffer is freed (or its address re-used) call
+ * sah_ipc_unregister(ctx, buffer) on every rank, in the same order as everything else of this protocol; it waits for the context's
+ * streams, closes the peer mappings nobody else uses and frees the slot (the lowest free slot is taken by the next registration).
  * The context may be created with comm_id == NULL and world > 1 for this path.  buffer may lie inside a larger allocation (a caching
  * allocator's block): the handle carries the offset. */
 #define SAH_IPC_HANDLE_BYTES 128
@@ -642,6 +655,7 @@ int sah_ipc_open(sah_ctx* ctx, void* out_handle);
 int sah_ipc_connect(sah_ctx* ctx, const void* all_handles);
 int sah_ipc_export(sah_ctx* ctx, const void* buffer, uint64_t bytes, void* out_handle);
 int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all_handles);
+int sah_ipc_unregister(sah_ctx* ctx, const void* buffer);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,7 @@ struct Ray {
 Ray make_ray(const float o[3], const float d[3], float tmin, float tmax) {
     Ray r;
     for (int c = 0; c < 3; c++) { r.o[c] = o[c]; r.d[c] = d[c]; r.inv[c] = 1.0f / d[c]; }
-    r.tmin = tmin; r.tmax = tmax;
+    r.tmin = tmin; r.tmax = std::fmin(tmax, 3.402823466e+38f);  // at most the largest finite float (sah_hip.h "ray tracing")
     r.finite = finite3(o) && finite3(d);
     int kz = 0;
     float am = std::fabs(d[0]);

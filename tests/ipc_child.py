@@ -52,6 +52,14 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"rank{rank}_step.npy"), sc.out.cpu().numpy())
+    if not rccl:  # the registrations go back before the pipelined chain takes their slots (sah_ipc_unregister: lowest free slot next)
+        dist.barrier()  # nobody closes a mapping a peer may still be copying through
+        sc.unregister_direct_exchange()
+        try:
+            ctx.ipc_unregister(sc.out_alloc.data_ptr())
+            raise AssertionError("unregistering twice must fail")
+        except lib.SahError:
+            pass
     # 2. two frames in flight, a different shadow mask per frame
     side, second = torch.cuda.Stream(), torch.cuda.Stream()
     pc = chain.PipelinedChain(ctx, f, dev, rank, world, side, second)

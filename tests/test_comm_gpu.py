@@ -178,9 +178,26 @@ def test_bench_rehearsal_of_two_ranks_verifies_its_frames(tmp_path, fail_preflig
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["sharded_equals_unsharded"] is True
+    assert d["n_gpus"] == 2 and d["config"]["sharded_equals_unsharded"] is True and d["value"] is not None and "error" not in d
+    assert d["config"]["speedup_vs_same_workload_on_one_gpu"] is None  # a rehearsal shares one GPU: no speed-up is claimed
     pre = d["config"]["preflight"]
     if fail_preflight:
         assert d["config"]["frames_in_flight"] == 1 and pre["fallback"] == "one frame at a time" and pre["fallback_ok"] is True
     else:
         assert d["config"]["frames_in_flight"] == 2 and pre == {"two_frames_in_flight_ok": True, "fallback": None}
+
+
+@pytest.mark.gpu
+def test_bench_reports_a_failed_verification_as_a_failure(tmp_path):
+    """A sharded loop whose last frames differ from the unsharded frame (test hook) has no throughput: value null, an `error`, exit code 3
+    on every rank."""
+    import json
+    port = 29950 + (os.getpid() % 40)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SAH_BENCH_FAIL_VERIFY="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--rehearse-on-one-gpu", "--ramp-ms", "0"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode != 0, out.stdout[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] is None and "differ" in d["error"] and d["config"]["sharded_equals_unsharded"] is False
+    assert d["config"]["speedup_vs_same_workload_on_one_gpu"] is None

@@ -211,6 +211,16 @@ def test_rtao_known_answer_plate_over_floor():
     assert np.isnan(case.oracle_rtao(spp=0, radius=5.0)).all()
 
 
+def test_rtao_infinite_and_nan_distance_mean_the_largest_finite_float():
+    """include/sah_hip.h "tmax": minNum(tmax, FLT_MAX).  (The HIP walk's boxes for absent children rely on a finite tmax.)"""
+    case = RtCase(_floor_and_plate(), 24, 14, view=_top_down_view(24, 14))
+    case.noise[...] = (128, 255, 128, 0)
+    far = case.oracle_rtao(radius=3.0e38)
+    assert (far == 0.0).any() and (far == 1.0).any()
+    assert _same_bits(case.oracle_rtao(radius=float("inf")), far)
+    assert _same_bits(case.oracle_rtao(radius=float("nan")), far)
+
+
 def test_rtao_ignores_cutout_geometry_and_hits_back_faces():
     solid = RtCase(_floor_and_plate(), 24, 14, view=_top_down_view(24, 14))
     cutout = RtCase(_floor_and_plate(plate_type=_abi.PRIMITIVE_TYPE_CUTOUT), 24, 14, view=_top_down_view(24, 14))
@@ -488,6 +498,27 @@ def test_hip_random_planes_against_the_oracle(hip_ctx):
     case = RtCase(m, W, H, seed=5, gbuffer=gb)
     case.sun.constants.num_shadow_samples = 2.0
     _check_both(hip_ctx, case, spp=1, radius=6.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("triangles", [5, 405, 1029])  # 7 n triangles with n = 1, 101, 257
+def test_hip_infinite_ray_distance(hip_ctx, triangles):
+    """tmax = +inf (and NaN) is the largest finite float.  Triangle counts that are not multiples of four leave absent children in the last
+    group of every level: with an infinite tmax a ray whose direction has no negative component used to pass their [+inf, +inf] boxes and
+    walk into nodes that do not exist.  Random normals and noise give rays of every sign pattern, all-positive directions included."""
+    g = synth.rng(1000 + triangles)
+    m = mesh.random_soup(triangles, triangles=triangles, textured=False)
+    W, H = 64, 36
+    gb = {"depth": g.uniform(0.003, 0.2, (H, W)).astype(np.float32), "normals": g.normal(size=(H, W, 4)).astype(np.float16).view(np.uint16)}
+    gb["normals"][: H // 2] = np.array([0.57, 0.57, 0.57, 0.0], np.float16).view(np.uint16)  # hemisphere of (+, +, +)
+    case = RtCase(m, W, H, seed=triangles, gbuffer=gb)
+    case.noise[: 64] = (255, 255, 255, 0)  # direction normalize((1, 1, 1)): no negative component
+    stats = case.hip_build(hip_ctx)
+    assert stats[0] % 4 != 0
+    for radius in (float("inf"), float("nan"), 3.0e38):
+        got, want = case.hip_rtao(hip_ctx, radius=radius), case.oracle_rtao(radius=radius)
+        assert _same_bits(got, want), (radius, int((got != want).sum()))
+    assert (want == 0.0).any() and (want == 1.0).any()
 
 
 @pytest.mark.gpu
