@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("SAH_HIP_CSRC") or os.path.join(HERE, "csrc")  # (experiments: a patched copy of the sources, tools/experiments/r4/variants.py)
 INCLUDE = os.path.join(HERE, "..", "include")
 OUT = os.environ.get("SAH_HIP_LIBRARY") or os.path.join(HERE, "libsah_hip.so")
 OBJDIR = os.path.join(HERE, "_build", os.path.splitext(os.path.basename(OUT))[0])  # one object directory per output (A/B builds)

@@ -229,6 +229,7 @@ void sah_destroy(sah_ctx* ctx) {
     if (ctx->irr32) (void)hipFree(ctx->irr32);
     if (ctx->colx_table) (void)hipFree(ctx->colx_table);
     if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
+    if (ctx->tm_code_table) (void)hipFree(ctx->tm_code_table);
     if (ctx->tm_axis) (void)hipFree(ctx->tm_axis);
     for (SahCacheGuard* g : {&ctx->guard_lighting, &ctx->guard_tonemap, &ctx->guard_raster, &ctx->guard_rt})
         if (g->done) (void)hipEventDestroy(g->done);

@@ -16,6 +16,8 @@ hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, cons
                              uint32_t row_end, hipStream_t st);
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                                    uint32_t row_end, hipStream_t st);
+bool launch_bloom_pair(const PlaneArg& s, uint32_t sw, uint32_t sh, const PlaneArg& a, uint32_t aw, uint32_t ah, const PlaneArg& b, uint32_t bw, uint32_t bh,
+                       hipStream_t st, hipError_t* err);
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_tonemap_axis_tables(const TonemapArgs& t, TmAxis* out, hipStream_t st);
@@ -128,6 +130,18 @@ static int bloom_range(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain*
         const sah_plane* src = m == 0 ? scene : &bloom->mips[m - 1];
         const sah_plane* dst = &bloom->mips[m];
         const uint32_t r0 = m == first_mip ? row_begin : 0u, r1 = m == first_mip ? row_end : dst->height;
+        // the small mips of the chain, two per launch (post.hip: k_bloom_pair): whole mips only, and only where the texels of the first
+        // one that neighbouring tiles compute twice cost less than the launch they save (mip 2 and beyond of a 4K chain)
+        const bool whole = r0 == 0 && r1 == dst->height;
+        if (whole && m + 1 <= last_mip && m + 1 < bloom->num_mips && (uint64_t)dst->width * dst->height <= (1u << 18)) {
+            const sah_plane* nxt = &bloom->mips[m + 1];
+            hipError_t e = hipSuccess;
+            if (sah::launch_bloom_pair(parg(src), src->width, src->height, parg(dst), dst->width, dst->height, parg(nxt), nxt->width, nxt->height, ctx->stream, &e)) {
+                HIP_TRY(ctx, e);
+                m++;
+                continue;
+            }
+        }
         HIP_TRY(ctx, sah::launch_bloom_downsample(parg(src), src->width, src->height, parg(dst), dst->width, dst->height, r0, r1, ctx->stream));
     }
     return SAH_OK;
@@ -205,8 +219,20 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_thresholds, sizeof(tab)));
         HIP_TRY(ctx, hipMemcpy(ctx->tm_thresholds, &tab, sizeof(tab), hipMemcpyHostToDevice));
+        // the same two-level search with one read per look-up: per bucket the three thresholds behind its first code, and that code
+        static float code_tab[sah::kTmMaxBuckets][4];
+        for (uint32_t b = 0; b < sah::kTmMaxBuckets; b++) {
+            const uint32_t f = tab.first[b];  // <= 252
+            code_tab[b][0] = tab.thr[f + 1];
+            code_tab[b][1] = tab.thr[f + 2];
+            code_tab[b][2] = tab.thr[f + 3];
+            memcpy(&code_tab[b][3], &f, 4);
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_code_table, sizeof(code_tab)));
+        HIP_TRY(ctx, hipMemcpy(ctx->tm_code_table, code_tab, sizeof(code_tab), hipMemcpyHostToDevice));
     }
     t.thresholds = ctx->tm_thresholds;
+    t.code_table = ctx->tm_code_table;
     t.bucket_base = ctx->tm_bucket_base;
     t.thr_lo = ctx->tm_thr_lo;
     t.thr_hi = ctx->tm_thr_hi;
@@ -218,7 +244,9 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_tonemap));
     // (the tolerance kernel stages six mips; a longer chain takes the strict kernel, whose result is inside the tolerance by definition)
-    if ((flags & SAH_TONEMAP_TOLERANCE_1CODE) && bloom->num_mips <= 6) {
+    bool tol_ok = (flags & SAH_TONEMAP_TOLERANCE_1CODE) && bloom->num_mips <= 6;
+    for (uint32_t m = 0; m < bloom->num_mips; m++) tol_ok = tol_ok && bloom->mips[m].width <= 65536u && bloom->mips[m].height <= 65536u;  // (16-bit extents in its LDS table)
+    if (tol_ok) {
         // per-column / per-row axis set-ups: a function of the extents only, kept across calls
         uint32_t key[2 + 2 * 8 + 1] = {out->width, out->height};
         for (uint32_t m = 0; m < bloom->num_mips; m++) {

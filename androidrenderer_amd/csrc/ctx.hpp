@@ -58,6 +58,7 @@ struct sah_ctx {
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds + the first-level bucket table (api_post.cpp)
+    float* tm_code_table = nullptr;    // device: the same search as one float4 per bucket (TonemapArgs::code_table)
     uint32_t tm_bucket_base = 0, tm_bucket_count = 0;
     float tm_thr_lo = 0.f, tm_thr_hi = 0.f;
     void* tm_axis = nullptr;           // device: axis set-ups of the tolerance-mode composite (tonemap_tol.hip), rebuilt when the extents change

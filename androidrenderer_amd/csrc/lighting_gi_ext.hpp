@@ -407,16 +407,45 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
     return irradiance * Fn(2.f) * Fn(rh(3.1415927f));  // PI = 3.1415927h (brdf.slangi wins the #ifndef race)
 }
 
-// `lut` != nullptr selects sample_cascade_fast(); *bad is then set when the pixel has to be re-evaluated with lut == nullptr.
-SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, Fn (&out)[4],
-                           const float* lut = nullptr, bool* bad = nullptr) {
+// What the Slang passes of one pixel — the RT-mode sun (directional_light.rt.slang:58-89), the cache overlay (overlay.frag.slang:46-66) and
+// the RTGI overlay (rtgi/overlay.frag.slang:68-80) — all begin with: the half-precision surface, the world-space location from
+// (pixel + 0.5) / resolution, and the half view vector.  The same operators on the same inputs in all three, so the tiled kernel, which runs
+// two of them per pixel, evaluates them once (the Hn constructors are opaque to the optimiser, which therefore cannot merge them itself).
+struct SlangGeom {
     Surface<Hn> s;
-    s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
-    s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
-    s.roughness = Hn(si.rough);
-    s.metalness = Hn(si.metal);
-    const F3 location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
-    const H3 V = to_h(normalize(location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+    F3 location;
+    H3 V;
+};
+SAH_DEV SlangGeom slang_geometry(const LightingArgs& a, uint32_t x, uint32_t y, const Px& p, const SurfIn& si) {
+    SlangGeom g;
+    g.s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
+    g.s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
+    g.s.roughness = Hn(si.rough);
+    g.s.metalness = Hn(si.metal);
+    g.location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
+    g.V = to_h(normalize(g.location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+    return g;
+}
+// sun_rt() (lighting_common.hpp) on the shared geometry
+SAH_DEV void sun_rt_shared(const LightingArgs& a, const Px& p, const SlangGeom& g, float (&add)[3]) {
+    const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
+    const Hn ndotl = Hn(nclamp(dot(L, to_f(g.s.normal)), Fn(0.f), Fn(1.f)).v);
+    const H3 Lh = to_h(L);
+    const H3 b = brdf_sl(g.s, Lh, g.V);  // == Fd(s, Lh, V) + Fr(s, Lh, V)
+    const H3 nb = ndotl * b;
+    F3 radiance = to_f(nb) * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])};
+    if (tof(ndotl) > 0.f) radiance = radiance * Fn(p.mask);
+    const Fn exposure = Fn(0.00031415927f);
+    add[0] = (radiance.x * exposure).v;
+    add[1] = (radiance.y * exposure).v;
+    add[2] = (radiance.z * exposure).v;
+}
+
+// `lut` != nullptr selects sample_cascade_fast(); *bad is then set when the pixel has to be re-evaluated with lut == nullptr.
+SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const SlangGeom& geom, Fn (&out)[4], const float* lut = nullptr, bool* bad = nullptr) {
+    const Surface<Hn>& s = geom.s;
+    const F3 location = geom.location;
+    const H3 V = geom.V;
     uint32_t cascade_index = 5;
     for (uint32_t i = 0; i < 4; i++) {
         if (location.x.v > c.cascade_min[i][0] && location.y.v > c.cascade_min[i][1] && location.z.v > c.cascade_min[i][2] &&
@@ -463,15 +492,10 @@ SAH_DEV void load_path(const LightingArgs& a, const RtgiArgs& r, uint32_t px, ui
     }
 }
 
-SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, uint32_t y, const Px& p, const SurfIn& si, const float* lut,
-                          Fn (&out)[4]) {
-    Surface<Hn> s;
-    s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
-    s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
-    s.roughness = Hn(si.rough);
-    s.metalness = Hn(si.metal);
-    const F3 location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
-    const H3 V = to_h(normalize(location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, uint32_t y, const SlangGeom& geom, const float* lut, Fn (&out)[4]) {
+    const Surface<Hn>& s = geom.s;
+    const F3 location = geom.location;
+    const H3 V = geom.V;
     H3 dir, irr;
     load_path(a, r, x, y, dir, irr);
     H3 radiance = rtgi_contribution(s, V, dir, irr);

@@ -258,6 +258,31 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         }
     }
 
+    // the half-precision surface, location and view vector that the Slang passes of this pixel share (lighting_gi_ext.hpp: SlangGeom)
+    constexpr bool kNeedsSlang = SUN == SAH_SHADOW_MODE_RT || GI == SAH_GI_CACHE || GI == SAH_GI_RTGI;
+    SlangGeom sg;
+    if constexpr (kNeedsSlang) {
+        // hot form: fast_geometry() (lighting_fast.hpp) with the Slang texcoords — the three view-space quotients through one refined
+        // reciprocal, the rows of the affine inverse view from the LDS table, restricted-range root and reciprocal for the view vector:
+        // the bits of worldspace_location_slang() / normalize() inside the domains its `ok` reports (depth and distance from the camera
+        // within 2^+-40), the general form for the pixels outside them
+        bool hot = false;
+        if (fast_geom && f.pos_div_nr) {
+            const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]), ty = (Fn((float)y) + Fn(0.5f)) / Fn(a.res[1]);
+            const float colx = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v, rowy = (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+            hot = surface && finite_f(p.depth);
+            const FastGeom fg = fast_geometry(a, f, colx, rowy, p.depth, si, 1.0f, s_lut, hot);  // (its fp32 normal is not used: dn = 1)
+            sg.s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};
+            sg.s.normal = normalize(H3{Hn(si.normal[0]), Hn(si.normal[1]), Hn(si.normal[2])});
+            sg.s.roughness = Hn(si.rough);
+            sg.s.metalness = Hn(si.metal);
+            sg.location = fg.ws;
+            sg.V = to_h(fg.V);
+        }
+        if (__any(surface && !hot)) {
+            if (surface && !hot) sg = slang_geometry(a, x, y, p, si);
+        }
+    }
     // (3) GI overlay
     if (surface) {
         Fn s[4];
@@ -267,11 +292,11 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
             drawn = true;
         } else if constexpr (GI == SAH_GI_CACHE) {
             bool redo = false;  // hot form first; a pixel outside its preconditions (rare) is re-evaluated with the general form
-            if (cache.hot_ok) gi_cache_frag(a, cache, x, y, p, si, s, s_lut, &redo);
-            if (redo || !cache.hot_ok) gi_cache_frag(a, cache, x, y, p, si, s);
+            if (cache.hot_ok) gi_cache_frag(a, cache, sg, s, s_lut, &redo);
+            if (redo || !cache.hot_ok) gi_cache_frag(a, cache, sg, s);
             drawn = true;
         } else if constexpr (GI == SAH_GI_RTGI) {
-            gi_rtgi_frag(a, rtgi, x, y, p, si, s_lut, s);
+            gi_rtgi_frag(a, rtgi, x, y, sg, s_lut, s);
             drawn = true;
         }
         if (drawn) {
@@ -293,7 +318,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     if constexpr (SUN == SAH_SHADOW_MODE_RT) {
         if (surface) {
             float add[3];
-            sun_rt(a, x, y, p, si, add);
+            sun_rt_shared(a, p, sg, add);
 #pragma unroll
             for (int i = 0; i < 3; i++) lit[i] = Hn(tof(lit[i]) + add[i]);
         }

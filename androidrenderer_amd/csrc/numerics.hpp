@@ -153,12 +153,28 @@ struct Hn {
 SAH_DEV Hn operator+(Hn a, Hn b) { return Hn::raw(a.v + b.v); }
 SAH_DEV Hn operator-(Hn a, Hn b) { return Hn::raw(a.v - b.v); }
 SAH_DEV Hn operator*(Hn a, Hn b) { return Hn::raw(a.v * b.v); }
-SAH_DEV Hn operator/(Hn a, Hn b) { return Hn((float)a.v / (float)b.v); }
+// fp16 divide and root: the contract is the IEEE fp32 operator on the widened operands, rounded to fp16 (the second rounding is innocuous).
+// For operands that ARE fp16 values the fp32 result only has to be accurate enough to round to the same fp16 — and the operand space is
+// small enough to check every case: tools/microbench/half_math_check.hip compares, for ALL 2^32 (a, b) pairs / all 2^16 inputs (zeros,
+// denormals, infinities, NaNs included), the fp16 bits of the sequences below with those of hipcc's IEEE expansions: 0 mismatches on
+// gfx950 (profiles/r4_half_math_check.txt).  Divide: v_rcp_f32, one Newton step on the quotient, v_div_fixup_f32 for the special cases
+// — 5 instructions, 19 issue cycles, for 11 / 34 (no v_div_scale / v_div_fmas: fp16 operands never need the scaling).  Root: v_sqrt_f32
+// alone (1 ulp in fp32) — 1 instruction for 15; a NaN result may carry another sign / payload than the expansion's.
+SAH_DEV float hdiv_f32(float a, float b) {
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float q0 = a * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+    return __builtin_amdgcn_div_fixupf(q1, b, a);
+}
+SAH_DEV Hn operator/(Hn a, Hn b) { return Hn(hdiv_f32((float)a.v, (float)b.v)); }
 SAH_DEV Hn operator-(Hn a) { return Hn::raw(-a.v); }
-SAH_DEV Hn nsqrt(Hn a) { return Hn(__builtin_sqrtf((float)a.v)); }
+SAH_DEV Hn nsqrt(Hn a) { return Hn(__builtin_amdgcn_sqrtf((float)a.v)); }
+// pow(x, 5) of an fp16 value in [0, 1] (F_Schlick's clamped argument, the only caller): the contract's fp64 product chain, rounded to fp32
+// and then to fp16, has the fp16 bits of ((x * x) * (x * x)) * x in fp32 — x * x is exact (22 bits) — for every one of the 15 361 inputs
+// (tools/microbench/half_math_check.hip, profiles/r4_half_math_check.txt): three fp32 multiplies for two conversions and four fp64 ones
 SAH_DEV Hn npow5(Hn a) {
-    double d = (double)(float)a.v;
-    return Hn((float)(d * d * d * d * d));
+    const float x = (float)a.v, x2 = x * x;
+    return Hn((x2 * x2) * x);
 }
 SAH_DEV float tof(Hn a) { return (float)a.v; }
 
@@ -226,10 +242,18 @@ template <class T> struct Surface {
 };
 
 template <class T> SAH_DEV T brdf_pi() { return T::lit(3.1415927f); }
+// 1.0 / PI of the two BRDF flavours.  The fp16 one as a constant: Hn's operators are opaque to the optimiser, which would otherwise divide
+// 1.0h by 3.140625h at run time in every D_GGX and Fd_Burley (the same value: IEEE fp32 quotient of the two fp16 numbers, rounded to fp16)
+template <class T> SAH_DEV T inv_pi();
+template <> SAH_DEV Fn inv_pi<Fn>() { return Fn(1.0f) / Fn(3.1415927f); }
+template <> SAH_DEV Hn inv_pi<Hn>() {
+    constexpr _Float16 v = (_Float16)(1.0f / (float)(_Float16)3.1415927f);
+    return Hn::raw(v);
+}
 
 template <class T> SAH_DEV T D_GGX(T NoH, T roughness) {
     T k = roughness / (T::lit(1.0f) - NoH * NoH + roughness * roughness);
-    return k * k * (T::lit(1.0f) / brdf_pi<T>());
+    return k * k * inv_pi<T>();
 }
 template <class T> SAH_DEV V3<T> F_Schlick(T u, V3<T> f0, T f90) {
     T p = npow5(nclamp(T::lit(1.0f) - u, T::lit(0.0f), T::lit(1.0f)));
@@ -246,7 +270,7 @@ template <class T> SAH_DEV V3<T> Fd_Burley(T NoV, T NoL, T LoH, T roughness) {
     V3<T> one(T::lit(1.0f));
     V3<T> lightScatter = F_Schlick(NoL, one, f90);
     V3<T> viewScatter = F_Schlick(NoV, one, f90);
-    return lightScatter * viewScatter * (T::lit(1.0f) / brdf_pi<T>());
+    return lightScatter * viewScatter * inv_pi<T>();
 }
 template <class T> SAH_DEV V3<T> Fd(const Surface<T>& s, V3<T> l, V3<T> v) {
     const T dielectric_f0 = T::lit(0.04f);

@@ -3,6 +3,8 @@
 //   RenderCore/shaders/postprocessing/bloom_downsample.comp:16-52   (host: RenderCore/render/bloomer.cpp:38-262)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "post_common.hpp"
 
 namespace sah {
@@ -60,14 +62,14 @@ constexpr int kBlW = 64, kBlPitch = 136;
 // the kernel's LDS cycles were bank conflicts); the gap moves the second sixteen lanes on by two banks.
 constexpr int kBlPitchCells = kBlPitch + (kBlPitch - 1) / 32 + 1;
 SAH_DEV int bl_cell(int tx) { return tx + (tx >> 5); }
-// one bilinear tap from the staged rectangle: columns ax.o0 and ax.o1 (byte offsets inside a row), rows ay.o0 and the one below it
-SAH_DEV C3 tap_rep(const char* tex, const AxisE& ax, const AxisE& ay) {
-    // four ds_read_b64 (kept apart by `volatile`): merged into two ds_read2_b64 they are serviced at half the bytes per clock
+// The five boxes of one destination texel from a staged rectangle: set-ups xs[0..5] = columns of u - ix, u + ix, (u - ix) -+ ix, (u + ix) -+ ix,
+// ys likewise (weights pre-scaled by the box weights, see the axis tables).  One body for every LDS-staged form of the pass, so that they
+// cannot differ in a rounding.
+template <int kPitchCells> SAH_DEV C3 tap_rep_p(const char* tex, const AxisE& ax, const AxisE& ay) {
     typedef uint32_t v2u __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const volatile v2u* LdsTexel;
-    constexpr int kRow = kBlPitchCells;  // in cells: the second row is an immediate offset
     const LdsTexel c0 = (LdsTexel)(tex + (ay.o0 + ax.o0)), c1 = (LdsTexel)(tex + (ay.o0 + ax.o1));
-    const v2u t00 = c0[0], t10 = c1[0], t01 = c0[kRow], t11 = c1[kRow];
+    const v2u t00 = c0[0], t10 = c1[0], t01 = c0[kPitchCells], t11 = c1[kPitchCells];
     const float w00 = ax.w0 * ay.w0, w10 = ax.w1 * ay.w0, w01 = ax.w0 * ay.w1, w11 = ax.w1 * ay.w1;
     C3 c;
     c.r = fma_mix_lo(w11, t11.x, fma_mix_lo(w01, t01.x, fma_mix_lo(w10, t10.x, fma_mix_lo(w00, t00.x, 0.0f))));
@@ -75,6 +77,14 @@ SAH_DEV C3 tap_rep(const char* tex, const AxisE& ax, const AxisE& ay) {
     c.b = fma_mix_lo(w11, t11.y, fma_mix_lo(w01, t01.y, fma_mix_lo(w10, t10.y, fma_mix_lo(w00, t00.y, 0.0f))));
     return c;
 }
+template <int kPitchCells> SAH_DEV C3 bloom_texel(const char* lds, const AxisE (&xs)[6], const AxisE (&ys)[6]) {
+    auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {  // (weights pre-scaled: see the table)
+        return tap_rep_p<kPitchCells>(lds, xl, yt) + tap_rep_p<kPitchCells>(lds, xr, yt) + tap_rep_p<kPitchCells>(lds, xl, yb) + tap_rep_p<kPitchCells>(lds, xr, yb);
+    };
+    return box(xs[0], xs[1], ys[0], ys[1]) + box(xs[2], xs[3], ys[2], ys[3]) + box(xs[4], xs[5], ys[2], ys[3]) + box(xs[2], xs[3], ys[4], ys[5]) +
+           box(xs[4], xs[5], ys[4], ys[5]);
+}
+
 template <int kBlPpt>
 __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint32_t sw, uint32_t sh, PlaneArg dst, uint32_t dw, uint32_t dh,
                                                                uint32_t row_begin, uint32_t row_end) {
@@ -159,12 +169,8 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
         C3 s;
         if (!bad) {
             const AxisE* rowp = s_ax + 6 * kBlW + row;
-            const AxisE yc = rowp[0], yd = rowp[kBlH], ycc = rowp[2 * kBlH], ycd = rowp[3 * kBlH], ydc = rowp[4 * kBlH], ydd = rowp[5 * kBlH];
-            auto box = [&](const AxisE& xl, const AxisE& xr, const AxisE& yt, const AxisE& yb) {  // (weights pre-scaled: see the table)
-                return tap_rep(lds, xl, yt) + tap_rep(lds, xr, yt) + tap_rep(lds, xl, yb) + tap_rep(lds, xr, yb);
-            };
-            s = box(xs[0], xs[1], yc, yd) + box(xs[2], xs[3], ycc, ycd) + box(xs[4], xs[5], ycc, ycd) + box(xs[2], xs[3], ydc, ydd) +
-                box(xs[4], xs[5], ydc, ydd);
+            const AxisE ys[6] = {rowp[0], rowp[kBlH], rowp[2 * kBlH], rowp[3 * kBlH], rowp[4 * kBlH], rowp[5 * kBlH]};
+            s = bloom_texel<kBlPitchCells>(lds, xs, ys);
         } else {  // global-memory form: the same 6 + 6 set-ups, computed per texel
             const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
             const int pitch = (int)src.pitch;
@@ -189,6 +195,215 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
         }
         store_rgba16f(dst, (int)x, (int)y, s.r, s.g, s.b, 0.0f);
     }
+}
+
+// ---- a7, two mips per launch -------------------------------------------------------------------------------------------------------
+// bloomer.cpp:50-151 makes mip i + 1 from mip i, one dispatch each; the small mips of the chain are launches of a few thousand texels
+// whose time is their own dependency chain (dispatch -> staging round trip -> filter -> store, ~5 us) plus the boundary to the next.
+// k_bloom_pair produces mips A and B = A + 1 from mip S = A - 1 in ONE launch without any exchange between workgroups: a workgroup owns
+// a TB x TB tile of B, computes every texel of A that tile's taps can touch (2 TB + 8 square, kept in LDS as fp16 exactly as it would
+// be stored) from the texels of S it staged (4 TB + 24 square), stores the part of A it owns, and filters its B tile from the LDS copy.
+// Texels of A in the overlap of neighbouring tiles are computed by several workgroups — from the same inputs by the same operators
+// (bloom_texel), so all copies are the same bits, and only the owner stores.  The host checks, with the kernel's own rectangle
+// arithmetic (pair_rect: the same fp32 operators on both sides), that every rectangle fits before it takes this path.
+struct PairRect {
+    int x0, w;  // first texel (unclamped) and number of cells along one axis
+};
+// texels of a source axis (size `src`) that the taps of destination texels [d0, d1] (axis size `dst`) can touch, as
+// k_bloom_downsample_lds computes its rectangle: cells beyond the image replicate its edge
+__host__ __device__ inline PairRect pair_rect(uint32_t d0, uint32_t d1, uint32_t dst, uint32_t src) {
+    const float p0 = ((float)d0 + 0.5f) / (float)dst * (float)src - 0.5f, p1 = ((float)d1 + 0.5f) / (float)dst * (float)src - 0.5f;
+    const int a = (int)__builtin_floorf(p0 - 3.0f), b = (int)__builtin_floorf(p1 + 3.0f) + 1;
+    return {a, b - a + 1};
+}
+__host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int TB> struct PairDims {
+    static constexpr int kAW = 2 * TB + 8;               // cells of mip A per axis
+    static constexpr int kSW = 2 * kAW + 8;              // cells of mip S per axis
+    static constexpr int kAPitch = kAW + (kAW - 1) / 32 + 1, kSPitch = kSW + (kSW - 1) / 32 + 1;  // bl_cell() gaps, as the one-mip kernel
+};
+
+struct BloomPairArgs {
+    PlaneArg s, a, b;
+    uint32_t sw, sh, aw, ah, bw, bh;
+    uint32_t tiles_x, tiles_y;
+};
+
+// NT threads: 512 for the 8 x 8 tiles, whose 24 x 24 rectangle of A is then one round of work per thread instead of three (the rounds
+// are the kernel's critical path: 12 -> ~8 us for mips 2 + 3 of a 4K chain)
+template <int TB, int NT>
+__global__ void __launch_bounds__(NT) k_bloom_pair(const BloomPairArgs g) {
+    using D = PairDims<TB>;
+    __shared__ uint2 s_src[D::kSPitch * D::kSW];
+    __shared__ uint2 s_mid[D::kAPitch * D::kAW];
+    __shared__ AxisE s_ax[6 * D::kAW], s_ay[6 * D::kAW];  // level A set-ups per cell column / row of the A rectangle
+    __shared__ AxisE s_bx[6 * TB], s_by[6 * TB];          // level B set-ups per tile column / row
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bx = blockIdx.x * TB, by = blockIdx.y * TB;
+    const uint32_t bx_last = min(bx + TB - 1, g.bw - 1), by_last = min(by + TB - 1, g.bh - 1);
+    // rectangles (uniform; every thread computes them: a handful of scalar-like operations against a barrier and an LDS round trip)
+    const PairRect ax = pair_rect(bx, bx_last, g.bw, g.aw), ay = pair_rect(by, by_last, g.bh, g.ah);
+    const int ax_lo = clampi(ax.x0, 0, (int)g.aw - 1), ax_hi = clampi(ax.x0 + ax.w - 1, 0, (int)g.aw - 1);
+    const int ay_lo = clampi(ay.x0, 0, (int)g.ah - 1), ay_hi = clampi(ay.x0 + ay.w - 1, 0, (int)g.ah - 1);
+    const PairRect sx = pair_rect((uint32_t)ax_lo, (uint32_t)ax_hi, g.aw, g.sw), sy = pair_rect((uint32_t)ay_lo, (uint32_t)ay_hi, g.ah, g.sh);
+
+    // 1. stage S (edge replication applied), all loads of a thread in flight together
+    constexpr int kSCells = D::kSW * D::kSW, kSIters = (kSCells + NT - 1) / NT;
+    {
+        uint2 staged[kSIters];
+#pragma unroll
+        for (int it = 0; it < kSIters; it++) {
+            const int i = (int)tid + it * NT;
+            const int ty = i / D::kSW, tx = i - ty * D::kSW;
+            const int gx = clampi(sx.x0 + tx, 0, (int)g.sw - 1), gy = clampi(sy.x0 + ty, 0, (int)g.sh - 1);
+            staged[it] = make_uint2(0u, 0u);
+            if (ty < sy.w && tx < sx.w) staged[it] = *reinterpret_cast<const uint2*>(g.s.ptr + (size_t)gy * g.s.pitch + (size_t)gx * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < kSIters; it++) {
+            const int i = (int)tid + it * NT;
+            const int ty = i / D::kSW, tx = i - ty * D::kSW;
+            if (i < kSCells) s_src[ty * D::kSPitch + bl_cell(tx)] = staged[it];
+        }
+    }
+    // 2. axis set-ups.  Level A: one thread per cell column / row of the A rectangle (cell j stands for texel clamp(ax.x0 + j)); level B:
+    //    one thread per tile column / row.  Six set-ups from one coordinate, exactly as k_bloom_downsample_lds tabulates them
+    auto six = [&](float c, float lo, float hi, uint32_t size, int origin, int pitch_cells, bool is_x, AxisE* out, int stride, int j) {
+        const float ca = c + lo, cb = c + hi;
+        const float coords[6] = {ca, cb, ca + lo, ca + hi, cb + lo, cb + hi};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const AxisU a = axis_unclamped(coords[k], size);
+            if (is_x) {
+                out[k * stride + j] = AxisE{bl_cell(a.i - origin) * 8, bl_cell(a.i + 1 - origin) * 8, a.w0, a.w1};
+            } else {
+                const float scale = k < 2 ? 0.125f : 0.03125f;  // box weights folded in (see k_bloom_downsample_lds)
+                out[k * stride + j] = AxisE{(a.i - origin) * pitch_cells * 8, 0, a.w0 * scale, a.w1 * scale};
+            }
+        }
+    };
+    {
+        const float six_ = 1.0f / (float)g.sw, siy = 1.0f / (float)g.sh;
+        if (tid < (uint32_t)D::kAW) {
+            const int t = clampi(ax.x0 + (int)tid, 0, (int)g.aw - 1);
+            six(((float)t + 0.5f) / (float)g.aw, six_ * -1.0f, six_ * 1.0f, g.sw, sx.x0, D::kSPitch, true, s_ax, D::kAW, (int)tid);
+        } else if (tid >= 64u && tid < 64u + (uint32_t)D::kAW) {
+            const int j = (int)tid - 64;
+            const int t = clampi(ay.x0 + j, 0, (int)g.ah - 1);
+            six(((float)t + 0.5f) / (float)g.ah, siy * -1.0f, siy * 1.0f, g.sh, sy.x0, D::kSPitch, false, s_ay, D::kAW, j);
+        } else if (tid >= 128u && tid < 128u + (uint32_t)TB) {
+            const int j = (int)tid - 128;
+            const float aix = 1.0f / (float)g.aw;
+            six(((float)min(bx + (uint32_t)j, bx_last) + 0.5f) / (float)g.bw, aix * -1.0f, aix * 1.0f, g.aw, ax.x0, D::kAPitch, true, s_bx, TB, j);
+        } else if (tid >= 192u && tid < 192u + (uint32_t)TB) {
+            const int j = (int)tid - 192;
+            const float aiy = 1.0f / (float)g.ah;
+            six(((float)min(by + (uint32_t)j, by_last) + 0.5f) / (float)g.bh, aiy * -1.0f, aiy * 1.0f, g.ah, ay.x0, D::kAPitch, false, s_by, TB, j);
+        }
+    }
+    __syncthreads();
+    // 3. mip A over its rectangle: LDS copy for step 4, global store by the owner
+    {
+        const char* lds = reinterpret_cast<const char*>(s_src);
+        // the tile owns A texels [2 bx, 2 bx + 2 TB) — the last tile of a row / column also the odd one beyond (aw = 2 bw + 1)
+        const int own_x0 = 2 * (int)bx, own_x1 = blockIdx.x + 1 == g.tiles_x ? (int)g.aw : 2 * (int)(bx + TB);
+        const int own_y0 = 2 * (int)by, own_y1 = blockIdx.y + 1 == g.tiles_y ? (int)g.ah : 2 * (int)(by + TB);
+        constexpr int kACells = D::kAW * D::kAW;
+        for (int i = (int)tid; i < kACells; i += NT) {
+            const int cy = i / D::kAW, cx = i - cy * D::kAW;
+            if (cx >= ax.w || cy >= ay.w) continue;
+            AxisE xs[6], ys[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                xs[k] = s_ax[k * D::kAW + cx];
+                ys[k] = s_ay[k * D::kAW + cy];
+            }
+            const C3 v = bloom_texel<D::kSPitch>(lds, xs, ys);
+            uint2 q;
+            q.x = (uint32_t)f2h(v.r) | ((uint32_t)f2h(v.g) << 16);
+            q.y = (uint32_t)f2h(v.b);  // alpha 0.0 (store_rgba16f(..., 0.0f))
+            s_mid[cy * D::kAPitch + bl_cell(cx)] = q;
+            const int tx = ax.x0 + cx, ty = ay.x0 + cy;  // the texel this cell stands for, when it is inside the image
+            if (tx >= own_x0 && tx < own_x1 && ty >= own_y0 && ty < own_y1)
+                *reinterpret_cast<uint2*>(const_cast<uint8_t*>(g.a.ptr) + (size_t)ty * g.a.pitch + (size_t)tx * 8) = q;
+        }
+    }
+    __syncthreads();
+    // 4. the B tile from the LDS copy of A
+    {
+        const char* lds = reinterpret_cast<const char*>(s_mid);
+        for (int i = (int)tid; i < TB * TB; i += NT) {
+            const int cy = i / TB, cx = i - cy * TB;
+            const uint32_t x = bx + (uint32_t)cx, y = by + (uint32_t)cy;
+            if (x >= g.bw || y >= g.bh) continue;
+            AxisE xs[6], ys[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                xs[k] = s_bx[k * TB + cx];
+                ys[k] = s_by[k * TB + cy];
+            }
+            const C3 v = bloom_texel<D::kAPitch>(lds, xs, ys);
+            store_rgba16f(g.b, (int)x, (int)y, v.r, v.g, v.b, 0.0f);
+        }
+    }
+}
+
+// host: every rectangle of every tile fits, and every set-up of both levels stays inside its rectangle (the kernel's own arithmetic)
+template <int TB> static bool bloom_pair_fits(uint32_t sw, uint32_t aw, uint32_t bw) {
+    using D = PairDims<TB>;
+    if (bw == 0 || aw < 2 || sw < 2 || (aw != 2 * bw && aw != 2 * bw + 1)) return false;  // ownership assumes the Vulkan mip rule
+    auto setups_inside = [](uint32_t t, uint32_t dst, uint32_t src, const PairRect& r) {
+        const float i = 1.0f / (float)src, lo = i * -1.0f, hi = i * 1.0f, c = ((float)t + 0.5f) / (float)dst;
+        const float ca = c + lo, cb = c + hi;
+        const float coords[6] = {ca, cb, ca + lo, ca + hi, cb + lo, cb + hi};
+        for (float co : coords) {
+            const float p = co * (float)src - 0.5f;
+            const float f0 = __builtin_floorf(p);
+            const int idx = (int)__builtin_fminf(__builtin_fmaxf(f0, -1.0e9f), 1.0e9f);
+            if (idx < r.x0 || idx + 1 >= r.x0 + r.w) return false;
+        }
+        return true;
+    };
+    for (uint32_t b0 = 0; b0 < bw; b0 += TB) {
+        const uint32_t b1 = std::min(b0 + TB - 1, bw - 1);
+        const PairRect a = pair_rect(b0, b1, bw, aw);
+        if (a.w <= 0 || a.w > D::kAW) return false;
+        const int lo = clampi(a.x0, 0, (int)aw - 1), hi = clampi(a.x0 + a.w - 1, 0, (int)aw - 1);
+        const PairRect sr = pair_rect((uint32_t)lo, (uint32_t)hi, aw, sw);
+        if (sr.w <= 0 || sr.w > D::kSW) return false;
+        for (uint32_t t = b0; t <= b1; t++)
+            if (!setups_inside(t, bw, aw, a)) return false;
+        for (int t = lo; t <= hi; t++)
+            if (!setups_inside((uint32_t)t, aw, sw, sr)) return false;
+        // the owner's A texels lie inside its rectangle
+        const int own0 = 2 * (int)b0, own1 = (b0 + TB >= bw ? (int)aw : 2 * (int)(b0 + TB)) - 1;
+        if (own0 < a.x0 || own1 > a.x0 + a.w - 1) return false;
+    }
+    return true;
+}
+
+// mips A and A + 1 of the chain from mip A - 1 in one launch; false: the extents do not suit it (the caller launches them one by one)
+bool launch_bloom_pair(const PlaneArg& s, uint32_t sw, uint32_t sh, const PlaneArg& a, uint32_t aw, uint32_t ah, const PlaneArg& b, uint32_t bw, uint32_t bh,
+                       hipStream_t st, hipError_t* err) {
+    *err = hipSuccess;
+    if ((uint64_t)s.pitch * sh >= (1ull << 31) || (uint64_t)a.pitch * ah >= (1ull << 31)) return false;
+    BloomPairArgs g{s, a, b, sw, sh, aw, ah, bw, bh, 0, 0};
+    // 8 x 8 tiles of B while that gives the chip at least a workgroup per CU; 4 x 4 for the last mips
+    const bool small = (uint64_t)((bw + 7) / 8) * ((bh + 7) / 8) < 256;
+    if (!small) {
+        if (!bloom_pair_fits<8>(sw, aw, bw) || !bloom_pair_fits<8>(sh, ah, bh)) return false;
+        g.tiles_x = (bw + 7) / 8;
+        g.tiles_y = (bh + 7) / 8;
+        hipLaunchKernelGGL((k_bloom_pair<8, 512>), dim3(g.tiles_x, g.tiles_y), dim3(512), 0, st, g);
+    } else {
+        if (!bloom_pair_fits<4>(sw, aw, bw) || !bloom_pair_fits<4>(sh, ah, bh)) return false;
+        g.tiles_x = (bw + 3) / 4;
+        g.tiles_y = (bh + 3) / 4;
+        hipLaunchKernelGGL((k_bloom_pair<4, 256>), dim3(g.tiles_x, g.tiles_y), dim3(256), 0, st, g);
+    }
+    *err = hipGetLastError();
+    return true;
 }
 
 // ---- a12 (AO mode Off): clear the R32F target to 1.0 — ambient_occlusion_phase.cpp:167-179 ------------------------------

@@ -16,6 +16,8 @@ struct TonemapArgs {
     uint32_t out_w, out_h;
     uint32_t row_begin, row_end;
     const float* thresholds;  // device, 256 floats then kTmMaxBuckets bytes: see api_post.cpp tonemap_code(), build_tonemap_buckets()
+    const float* code_table;  // device, kTmMaxBuckets x float4: {thresholds[first + 1], [first + 2], [first + 3], first (integer bits)} per bucket — the
+                              // same search with one 16-byte read per channel (tonemap_tol.hip reads it from global memory)
     uint32_t bucket_base;     // bit pattern >> kTmBucketShift of thresholds[1]
     float thr_lo, thr_hi;     // thresholds[1], thresholds[255]
     // tolerance mode only (tonemap_tol.hip): the axis set-ups of every output column / row, built once per (output extent, chain extents) by
@@ -24,10 +26,9 @@ struct TonemapArgs {
     uint32_t axis_stride;
 };
 
-struct TmAxis {  // texel index of the first of the two taps (unclamped) and the two weights (y: divided by 16)
-    int i;
-    float w0, w1;
-    int pad;
+struct TmAxis {  // texel index of the first of the two taps (unclamped) and the fraction f of the second (y: divided by 16): 8 bytes, the
+    int i;       // weights are 1 - f, f (y: 1/16 - f/16, f/16 — the bits of (1 - f) / 16)
+    float f;
 };
 
 constexpr uint32_t kTmBucketShift = 19, kTmMaxBuckets = 512;

@@ -19,8 +19,14 @@
 // pixel's share of pass 1 (about 2 staged rows per pixel row over the six mips).
 // Layout: a thread owns two ADJACENT pixel columns (rows r and r + 16 of the tile), so that its G reads and writes are 24 contiguous,
 // 8-byte aligned bytes — three ds_read_b64 / ds_write_b64, the full-rate LDS forms — and staged texels are 16-byte cells (one
-// ds_read_b128 per texel).  Staging and the axis tables of mip m + 1 are double-buffered and filled while mip m is filtered: two
-// barriers per mip.  LDS per workgroup: G 33.8 KB + texels 8.8 KB + tables 6 KB + code tables 1.5 KB = 3 workgroups per CU.
+// ds_read_b128 per texel) in rows of 32 cells: the two rows a ds_read_b128 lane group spans then start on the same bank, and the sixteen
+// cells the group reads fall on sixteen different bank quads (with rows of 25 cells a fifth of the kernel's LDS cycles were conflicts).
+// Round 4: the mips are filtered in STAGES — {0}, {1, 2}, {3, 4, 5} — whose rectangles, G rows and axis tables lie side by side in the same
+// LDS (22 staged rows suffice for each stage of a half-resolution chain), two barriers per stage instead of per mip: the small mips, whose
+// pass 1 is a handful of rows, no longer cost a barrier pair each.  The code look-up reads ONE 16-byte entry per channel (the three
+// thresholds of the channel's bucket and its first code) from a 7 KB table in global memory — L1-resident, on the otherwise idle texture
+// path — instead of four data-dependent LDS reads, which were where the remaining bank conflicts came from.
+// LDS per workgroup: G 32.3 KB + texels 10.8 KB + tables 9 KB = 52.3 KB, 3 workgroups per CU.
 #include <hip/hip_runtime.h>
 
 #include "post_common.hpp"
@@ -29,14 +35,17 @@ namespace sah {
 namespace {
 
 constexpr int kTile = 32;
-constexpr int kMaxRows = 22, kMaxCols = 25;  // staged rectangle: rows, texel columns (mip 0 of a half-resolution chain needs 21 x 22)
+constexpr int kMaxRows = 21;  // staged rows of one stage, all its mips together (half-resolution chains: mip 0 needs 20, mips 1 + 2 12 + 8, mips 3..5 6 + 6 + 6).
+                              // Not 22: three workgroups of 54.4 KB did NOT fit a CU's 160 KB (allocation granularity) — two per CU, 1.47 x the time
+constexpr int kPitch = 32;    // cells per staged row (a rectangle is at most 25 texel columns wide)
+constexpr int kMaxCols = 25;
 constexpr int kPlane = kMaxRows * kTile * 3;  // floats per G plane
 constexpr int kStageIters = (kMaxRows + 7) / 8;
+constexpr int kStageMips = 3;
 
-struct AxisV {  // one axis set-up: offset of the first of the two texels / rows (x: float4 cells, y: floats into a G plane) and the two weights
-    int o;
-    float w0, w1;
-    int pad;
+struct AxisS {  // one axis set-up in LDS: offset of the first of the two texels / rows (x: float4 cells, y: floats into a G plane) and the
+    int o;      // fraction f (x) or f / 16 (y); the two weights are 1 - f, f (resp. 1/16 - f/16, f/16: the same bits as (1 - f) / 16)
+    float f;
 };
 // LDS reads in the forms that run at the full 256 B/clk: ds_read_b128 for a texel cell (left to itself the compiler reads the three used
 // floats as ds_read_b96: 96 B/clk) and ds_read_b64 for the halves of a G entry (merged into ds_read2_b64 they run at 128 B/clk)
@@ -50,12 +59,9 @@ SAH_DEV float2 lds_read8(const float* p) {
     const v2f v = *(__attribute__((address_space(3))) const volatile v2f*)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
     return make_float2(v.x, v.y);
 }
-
-SAH_DEV AxisV lds_axis(const AxisV* p) {  // one ds_read_b128 per table entry (its 12 used bytes would be read as ds_read_b96)
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    const v4i v = *(__attribute__((address_space(3))) const volatile v4i*)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-    const int o = v.x, w0 = v.y, w1 = v.z;
-    return {o, __builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1), 0};
+SAH_DEV AxisS lds_axis(const AxisS* p) {
+    const float2 v = lds_read8(reinterpret_cast<const float*>(p));
+    return {__builtin_bit_cast(int, v.x), v.y};
 }
 
 struct Rect {
@@ -97,77 +103,121 @@ __global__ void __launch_bounds__(256) k_tonemap_axis_tables(TonemapArgs t, TmAx
         const float base = ((float)i + 0.5f) / (float)t.out_w;
         const float c = k == 0 ? base : base + (k == 1 ? ox : k == 2 ? oy : oz);
         const AxisU a = axis_unclamped(c, t.mip_w[m]);
-        e = {a.i, a.w0, a.w1, 0};
+        e = {a.i, a.w1};
     } else {
         const float base = 1.0f - ((float)i + 0.5f) / (float)t.out_h;
         const float c = base + (k == 0 ? 0.f : k == 1 ? oz : k == 2 ? ow : oy);
         const AxisU a = axis_unclamped(c, t.mip_h[m]);
-        e = {a.i, a.w0 * 0.0625f, a.w1 * 0.0625f, 0};
+        e = {a.i, a.w1 * 0.0625f};
     }
     out[(size_t)blockIdx.y * t.axis_stride + i] = e;
 }
 
 __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
-    // (s_src and s_xt are read by pass 1 only, which every thread has left before anybody commits the next mip: single buffers; s_yt is read
-    // by pass 2, which overlaps the next commit: double buffer)
-    __shared__ __attribute__((aligned(16))) float4 s_src[kMaxRows * kMaxCols];  // staged texels, fp32 rgb (w unused), edge replication applied
-    __shared__ __attribute__((aligned(16))) float s_g[4 * kPlane];               // [y variant][staged row][pixel column][rgb]
-    __shared__ AxisV s_xt[4][kTile], s_yt[2][4][kTile];                          // x set-ups per column, y set-ups per row (weights / 16)
-    __shared__ int s_bad[2];                                                     // the mip cannot be staged: strict evaluation from global memory
-    __shared__ Rect s_rect[6];                                                   // the six rectangles, by threads 0..5 (six divides each: not per thread and mip)
-    __shared__ float s_thr[256];
-    __shared__ uint32_t s_first[kTmMaxBuckets / 4];
-    s_thr[threadIdx.x] = t.thresholds[threadIdx.x];
-    if (threadIdx.x < kTmMaxBuckets / 4) s_first[threadIdx.x] = reinterpret_cast<const uint32_t*>(t.thresholds + 256)[threadIdx.x];
+    // (s_src and s_xt are read by pass 1 only, which every thread has left before anybody commits the next stage: single buffers; s_yt is
+    // read by pass 2, which overlaps the next commit: double buffer)
+    __shared__ __attribute__((aligned(16))) float4 s_src[kMaxRows * kPitch];  // staged texels, fp32 rgb (w unused), edge replication applied
+    __shared__ __attribute__((aligned(16))) float s_g[4 * kPlane];            // [y variant][staged row of the stage][pixel column][rgb]
+    __shared__ __attribute__((aligned(8))) AxisS s_xt[kStageMips][4][kTile], s_yt[2][kStageMips][4][kTile];
+    __shared__ int s_bad[2][kStageMips];  // the mip cannot be staged: strict evaluation from global memory
+    __shared__ Rect s_rect[6];            // the six rectangles, by threads 0..5 (six divides each: not per thread and mip)
+    // base, pitch and last texel of every mip for the staging loads, whose mip differs from lane to lane (a stage's rows lie side by side):
+    // indexing the kernel argument arrays per lane makes the compiler select among all their elements, ~70 instructions per load
+    __shared__ uint4 s_mip[6];            // {pointer lo, pointer hi, pitch, (W - 1) | (H - 1) << 16}
     const uint32_t bx = blockIdx.x * kTile, by = t.row_begin + blockIdx.y * kTile;
     const uint32_t x_last = min(bx + kTile - 1, t.out_w - 1), y_last = min(by + kTile - 1, t.row_end - 1);
     const uint32_t cp = threadIdx.x & 15u, tr = threadIdx.x >> 4;  // column pair (columns 2 cp, 2 cp + 1), tile rows tr and tr + 16
     const uint32_t nmips = min(t.num_mips, 6u);
 
-    if (threadIdx.x < nmips) s_rect[threadIdx.x] = tile_rect(t, t.mip_w[threadIdx.x], t.mip_h[threadIdx.x], bx, by, x_last, y_last);
+    if (threadIdx.x < nmips) {
+        s_rect[threadIdx.x] = tile_rect(t, t.mip_w[threadIdx.x], t.mip_h[threadIdx.x], bx, by, x_last, y_last);
+        const uint64_t ptr = reinterpret_cast<uint64_t>(t.mips[threadIdx.x].ptr);
+        s_mip[threadIdx.x] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), t.mips[threadIdx.x].pitch,
+                                        (min(t.mip_w[threadIdx.x], 65536u) - 1u) | ((min(t.mip_h[threadIdx.x], 65536u) - 1u) << 16));
+    }
     __syncthreads();
+    // stages: mips [first, first + count) filtered between one pair of barriers.  A mip whose rows do not fit beside the others of its stage
+    // (chains that are not half-resolution pyramids) is marked bad for this tile and evaluated strictly
+    auto stage_first_of = [](uint32_t s) { return s == 0 ? 0u : (s == 1 ? 1u : 3u); };
+    const uint32_t nstages = nmips == 0 ? 0u : (nmips == 1 ? 1u : (nmips <= 3 ? 2u : 3u));
+    auto stage_count = [&](uint32_t s) { return min(stage_first_of(s) + (s == 0 ? 1u : (s == 1 ? 2u : 3u)), nmips) - stage_first_of(s); };
+
     uint2 staged[kStageIters];
-    TmAxis entry = {0, 0.f, 0.f, 0};
-    Rect rc = {0, 0, 0, 0};
-    // this thread's table entry: x set-up (variant tid / 32, column tid % 32) for tid < 128, else the y one
-    const uint32_t te = threadIdx.x & (kTile - 1), tk = (threadIdx.x >> 5) & 3u, taxis = threadIdx.x >> 7;
-    const uint32_t tpos = taxis == 0 ? min(bx + te, x_last) : min(by + te, y_last);  // columns / rows past the edge re-use the last valid one
-    // requests the texels of mip m (its rectangle becomes `rc`): a thread owns texel column tid % 32 and rows tid / 32 + 8 j
-    auto stage_request = [&](uint32_t m) {
-        const uint32_t W = t.mip_w[m], H = t.mip_h[m];
-        rc = s_rect[m];
-        if (threadIdx.x == 0) s_bad[m & 1u] = rc.w == 0;
+    TmAxis entry0 = {0, 0.f}, entry1 = entry0, entry2 = entry0;
+    // rows of the stage's mips as they lie in s_src / s_g: rb_j = first row of mip j of the stage (rb3: one past the last); a mip that is bad
+    // has no rows.  (Named scalars, not arrays: a select among array elements becomes a dynamically indexed array in scratch memory.)
+    int rb0 = 0, rb1 = 0, rb2 = 0, rb3 = 0;
+    Rect rc0 = {0, 0, 0, 0}, rc1 = rc0, rc2 = rc0;
+    auto pick = [](int mj, int a, int b, int c) __attribute__((always_inline)) { return mj == 0 ? a : (mj == 1 ? b : c); };
+    auto layout = [&](uint32_t s) __attribute__((always_inline)) {
+        const uint32_t first = stage_first_of(s), cnt = stage_count(s);
+        const Rect none = {0, 0, 0, 0};
+        rc0 = cnt > 0u ? s_rect[first] : none;
+        rc1 = cnt > 1u ? s_rect[first + 1u] : none;
+        rc2 = cnt > 2u ? s_rect[first + 2u] : none;
+        rb0 = 0;
+        rb1 = rc0.h;
+        if (rb1 + rc1.h > kMaxRows) rc1 = none;  // does not fit beside the others: bad
+        rb2 = rb1 + rc1.h;
+        if (rb2 + rc2.h > kMaxRows) rc2 = none;
+        rb3 = rb2 + rc2.h;
+    };
+    // requests the texels and table entries of stage s: a thread owns texel column tid % 32 and rows tid / 32 + 8 j of the stage's rows
+    auto stage_request = [&](uint32_t s) __attribute__((always_inline)) {
+        const uint32_t first = stage_first_of(s), cnt = stage_count(s);
+        layout(s);
+        if (threadIdx.x < (uint32_t)kStageMips) s_bad[s & 1u][threadIdx.x] = threadIdx.x < cnt && pick((int)threadIdx.x, rc0.w, rc1.w, rc2.w) == 0;
         const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
-        const PlaneArg mp = t.mips[m];
-        const uint32_t sx8 = (uint32_t)min(max(rc.x0 + tx, 0), (int)W - 1) * 8u;  // clamped into the image: never predicated
 #pragma unroll
         for (int j = 0; j < kStageIters; j++) {
-            const uint32_t sy = (uint32_t)min(max(rc.y0 + ty0 + 8 * j, 0), (int)H - 1);
-            staged[j] = *reinterpret_cast<const uint2*>(mp.ptr + (sy * mp.pitch + sx8));
+            const int rr = ty0 + 8 * j;  // row of the stage
+            const int mj = (rr >= rb1 ? 1 : 0) + (rr >= rb2 ? 1 : 0);
+            const uint32_t m = min(first + (uint32_t)mj, nmips - 1u);
+            const uint4 mi = s_mip[m];
+            const int wm1 = (int)(mi.w & 0xffffu), hm1 = (int)(mi.w >> 16);
+            const int rx0 = pick(mj, rc0.x0, rc1.x0, rc2.x0), ry0 = pick(mj, rc0.y0, rc1.y0, rc2.y0), rbase = pick(mj, rb0, rb1, rb2);
+            const uint32_t sx8 = (uint32_t)min(max(rx0 + tx, 0), wm1) * 8u;  // clamped into the image: never predicated
+            const uint32_t sy = (uint32_t)min(max(ry0 + (rr - rbase), 0), hm1);
+            const uint8_t* base = reinterpret_cast<const uint8_t*>((uint64_t)mi.x | ((uint64_t)mi.y << 32));
+            staged[j] = *reinterpret_cast<const uint2*>(base + (sy * mi.z + sx8));
         }
-        entry = t.axis_tables[(size_t)((m * 2u + taxis) * 4u + tk) * t.axis_stride + tpos];
+        // table entries: e = tid + 256 q  ->  (mip q of the stage, axis, variant, column / row)
+        const uint32_t te = threadIdx.x & (kTile - 1), tk = (threadIdx.x >> 5) & 3u, taxis = threadIdx.x >> 7;
+        const uint32_t tpos = taxis == 0 ? min(bx + te, x_last) : min(by + te, y_last);  // columns / rows past the edge re-use the last valid one
+        auto load_entry = [&](uint32_t q) __attribute__((always_inline)) {
+            const uint32_t m = min(first + q, nmips - 1u);
+            return t.axis_tables[(size_t)((m * 2u + taxis) * 4u + tk) * t.axis_stride + tpos];
+        };
+        entry0 = load_entry(0u);
+        entry1 = load_entry(1u);
+        entry2 = load_entry(2u);
     };
-    // converts and stores the requested texels, and builds the axis tables of mip m (thread e: x set-up (variant e / 32, column e % 32)
-    // for e < 128, else the y one)
-    auto stage_commit = [&](uint32_t m) {
-        const uint32_t b = m & 1u;
+    // converts and stores the requested texels and builds the axis tables of stage s
+    auto stage_commit = [&](uint32_t s) __attribute__((always_inline)) {
+        const uint32_t b = s & 1u, cnt = stage_count(s);
         const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
-        if (rc.w > 0) {
 #pragma unroll
-            for (int j = 0; j < kStageIters; j++) {
-                const int ty = ty0 + 8 * j;
-                if (tx <= rc.w && ty < rc.h)
-                    s_src[ty * kMaxCols + tx] = make_float4(h2f((uint16_t)(staged[j].x & 0xffffu)), h2f((uint16_t)(staged[j].x >> 16)),
-                                                               h2f((uint16_t)(staged[j].y & 0xffffu)), 0.f);
-            }
-            if (taxis == 0) {
-                s_xt[tk][te] = {entry.i - rc.x0, entry.w0, entry.w1, 0};
-                if (!(entry.i >= rc.x0 && entry.i + 1 <= rc.x0 + rc.w)) s_bad[b] = 1;
-            } else {
-                s_yt[b][tk][te] = {(entry.i - rc.y0) * (kTile * 3), entry.w0, entry.w1, 0};
-                if (!(entry.i >= rc.y0 && entry.i + 1 < rc.y0 + rc.h)) s_bad[b] = 1;
-            }
+        for (int j = 0; j < kStageIters; j++) {
+            const int rr = ty0 + 8 * j;
+            if (rr < rb3)
+                s_src[rr * kPitch + tx] = make_float4(h2f((uint16_t)(staged[j].x & 0xffffu)), h2f((uint16_t)(staged[j].x >> 16)),
+                                                       h2f((uint16_t)(staged[j].y & 0xffffu)), 0.f);
         }
+        const uint32_t te = threadIdx.x & (kTile - 1), tk = (threadIdx.x >> 5) & 3u, taxis = threadIdx.x >> 7;
+        auto put_entry = [&](uint32_t q, const TmAxis& en, const Rect& r, int rbase) __attribute__((always_inline)) {
+            if (q < cnt && r.w > 0) {
+                if (taxis == 0) {
+                    s_xt[q][tk][te] = {en.i - r.x0, en.f};
+                    if (!(en.i >= r.x0 && en.i + 1 <= r.x0 + r.w)) s_bad[b][q] = 1;
+                } else {
+                    s_yt[b][q][tk][te] = {(en.i - r.y0 + rbase) * (kTile * 3), en.f};
+                    if (!(en.i >= r.y0 && en.i + 1 < r.y0 + r.h)) s_bad[b][q] = 1;
+                }
+            }
+        };
+        put_entry(0u, entry0, rc0, rb0);
+        put_entry(1u, entry1, rc1, rb1);
+        put_entry(2u, entry2, rc2, rb2);
     };
 
     C3 bloom[2][2];  // [row r / r + 16][column 2 cp / 2 cp + 1]
@@ -178,35 +228,76 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
     const bool live_col[2] = {x0p < t.out_w, x0p + 1u < t.out_w};
     const bool live_row[2] = {by + tr < t.row_end, by + tr + 16u < t.row_end};
 
-    if (nmips) {
+    // the scene texel of the thread's four pixels: requested before anything else, so that its latency lies under the first stage
+#ifndef SAH_TM_HOIST
+#define SAH_TM_HOIST 0
+#endif
+    C3 scene_px[2][2];
+    auto sample_scene = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1u);
+        const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t x = min(x0p + (uint32_t)c, t.out_w - 1);
+            const Rgba sc = bilinear<ADDR_CLAMP>(t.scene, t.scene_w, t.scene_h, ((float)x + 0.5f) / (float)t.out_w, v);
+            scene_px[a][c] = {sc.c[0], sc.c[1], sc.c[2]};
+        }
+    }
+    };
+    if (SAH_TM_HOIST) {
+        sample_scene();
+    } else {  // touch the lines now (one texel per pixel row), sample at the end
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1u), x = min(x0p, t.out_w - 1);
+            const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
+            const int sy = min(max((int)(v * (float)t.scene_h), 0), (int)t.scene_h - 1), sx = min(max((int)(((float)x + 0.5f) / (float)t.out_w * (float)t.scene_w), 0), (int)t.scene_w - 1);
+            uint32_t w = *reinterpret_cast<const uint32_t*>(t.scene.ptr + (size_t)sy * t.scene.pitch + (size_t)sx * 8);
+            asm volatile("" ::"v"(w));
+        }
+    }
+    if (nstages) {
         stage_request(0);
         __syncthreads();  // (s_bad[0] reset before anybody sets it)
         stage_commit(0);
     }
-    for (uint32_t m = 0; m < nmips; m++) {
-        const uint32_t b = m & 1u;
-        __syncthreads();  // texels and tables of mip m are in place; the previous mip's pass 2 is done with s_g
-        const bool bad = s_bad[b] != 0;
-        const int rows = rc.h;  // rectangle of mip m (stage_request(m) was the last one to run)
-        if (!bad) {
-            // pass 1: items (column pair, staged row): column pair = tid % 16, rows tid / 16 + 16 j
-            AxisV xa[2][4];
-#pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) xa[c][k] = lds_axis(&s_xt[k][2u * cp + (uint32_t)c]);
-            for (int r = (int)tr; r < rows; r += 16) {
-                const float4* srow = s_src + r * kMaxCols;
+    for (uint32_t s = 0; s < nstages; s++) {
+        const uint32_t b = s & 1u, first = stage_first_of(s), cnt = stage_count(s);
+        __syncthreads();  // texels and tables of stage s are in place; the previous stage's pass 2 is done with s_g
+        // (rc / rb describe stage s here: stage_request(s) was the last one to run; they change when the next stage is requested below)
+        const int total_rows = rb3, mr1 = rb1, mr2 = rb2;
+        const bool bad0 = cnt > 0u && s_bad[b][0] != 0, bad1 = cnt > 1u && s_bad[b][1] != 0, bad2 = cnt > 2u && s_bad[b][2] != 0;
+        {
+            // pass 1: items (column pair, staged row of the stage): column pair = tid % 16, rows tid / 16 + 16 j
+            for (int r = (int)tr; r < total_rows; r += 16) {
+                const int mj = (r >= mr1 ? 1 : 0) + (r >= mr2 ? 1 : 0);
+                if (mj == 0 ? bad0 : (mj == 1 ? bad1 : bad2)) continue;  // (its rows hold nothing: rc.h == 0, or the tables are not inside)
+                const float4* srow = s_src + r * kPitch;
                 float g[4][6];
+                // (the LDS reads are volatile — see lds_read16 — and therefore issue in program order: all eight set-ups first, then the
+                // texels of a column, so that an item waits for two LDS round trips, not for sixteen one behind the other)
+                AxisS xa[2][4];
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xa[c][k] = lds_axis(&s_xt[mj][k][2u * cp + (uint32_t)c]);
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
+                    float4 tp[4], tq[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        tp[k] = lds_read16(srow + xa[c][k].o);
+                        tq[k] = lds_read16(srow + xa[c][k].o + 1);
+                    }
                     float h[4][3];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const float4 p = lds_read16(srow + xa[c][k].o), q = lds_read16(srow + xa[c][k].o + 1);
-                        h[k][0] = __builtin_fmaf(xa[c][k].w1, q.x, xa[c][k].w0 * p.x);
-                        h[k][1] = __builtin_fmaf(xa[c][k].w1, q.y, xa[c][k].w0 * p.y);
-                        h[k][2] = __builtin_fmaf(xa[c][k].w1, q.z, xa[c][k].w0 * p.z);
+                        const float w1 = xa[c][k].f, w0 = 1.0f - xa[c][k].f;
+                        h[k][0] = __builtin_fmaf(w1, tq[k].x, w0 * tp[k].x);
+                        h[k][1] = __builtin_fmaf(w1, tq[k].y, w0 * tp[k].y);
+                        h[k][2] = __builtin_fmaf(w1, tq[k].z, w0 * tp[k].z);
                     }
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
@@ -227,66 +318,83 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
                 }
             }
         }
-        if (m + 1 < nmips) stage_request(m + 1);  // global loads travel during pass 2
+        if (s + 1 < nstages) stage_request(s + 1);  // global loads travel during pass 2 (rc / rb now describe stage s + 1)
         __syncthreads();
-        if (!bad) {
-            // pass 2: four row interpolations per pixel, two pixels at a time
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const uint32_t pr = min(tr + 16u * (uint32_t)a, y_last - by);  // rows past the band: the last valid one (dropped later)
-                float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < kStageMips; j++) {
+            if ((uint32_t)j >= cnt) break;
+            const uint32_t m = first + (uint32_t)j;
+            if (!(j == 0 ? bad0 : (j == 1 ? bad1 : bad2))) {
+                // pass 2: four row interpolations per pixel, two pixels at a time.  Program order of the (volatile) LDS reads: the eight set-ups,
+                // then the 24 reads of a pixel pair, then its arithmetic — three LDS round trips per mip on the thread's critical path
+                AxisS ey[2][4];
 #pragma unroll
-                for (int yv = 0; yv < 4; yv++) {
-                    const AxisV e = lds_axis(&s_yt[b][yv][pr]);
-                    const float* g0 = s_g + yv * kPlane + e.o + 6 * (int)cp;
-                    const float* g1 = g0 + kTile * 3;
-                    const float2 P0 = lds_read8(g0), P1 = lds_read8(g0 + 2), P2 = lds_read8(g0 + 4), Q0 = lds_read8(g1), Q1 = lds_read8(g1 + 2), Q2 = lds_read8(g1 + 4);
-                    s[0] = __builtin_fmaf(e.w1, Q0.x, __builtin_fmaf(e.w0, P0.x, s[0]));
-                    s[1] = __builtin_fmaf(e.w1, Q0.y, __builtin_fmaf(e.w0, P0.y, s[1]));
-                    s[2] = __builtin_fmaf(e.w1, Q1.x, __builtin_fmaf(e.w0, P1.x, s[2]));
-                    s[3] = __builtin_fmaf(e.w1, Q1.y, __builtin_fmaf(e.w0, P1.y, s[3]));
-                    s[4] = __builtin_fmaf(e.w1, Q2.x, __builtin_fmaf(e.w0, P2.x, s[4]));
-                    s[5] = __builtin_fmaf(e.w1, Q2.y, __builtin_fmaf(e.w0, P2.y, s[5]));
+                for (int a = 0; a < 2; a++) {
+                    const uint32_t pr = min(tr + 16u * (uint32_t)a, y_last - by);  // rows past the band: the last valid one (dropped later)
+#pragma unroll
+                    for (int yv = 0; yv < 4; yv++) ey[a][yv] = lds_axis(&s_yt[b][j][yv][pr]);
                 }
-                bloom[a][0] = bloom[a][0] + C3{s[0], s[1], s[2]};
-                bloom[a][1] = bloom[a][1] + C3{s[3], s[4], s[5]};
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    float2 P[4][3], Q[4][3];
+#pragma unroll
+                    for (int yv = 0; yv < 4; yv++) {
+                        const float* g0 = s_g + yv * kPlane + ey[a][yv].o + 6 * (int)cp;
+                        const float* g1 = g0 + kTile * 3;
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            P[yv][q] = lds_read8(g0 + 2 * q);
+                            Q[yv][q] = lds_read8(g1 + 2 * q);
+                        }
+                    }
+                    float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int yv = 0; yv < 4; yv++) {
+                        const float w1 = ey[a][yv].f, w0 = 0.0625f - ey[a][yv].f;
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            sacc[2 * q] = __builtin_fmaf(w1, Q[yv][q].x, __builtin_fmaf(w0, P[yv][q].x, sacc[2 * q]));
+                            sacc[2 * q + 1] = __builtin_fmaf(w1, Q[yv][q].y, __builtin_fmaf(w0, P[yv][q].y, sacc[2 * q + 1]));
+                        }
+                    }
+                    bloom[a][0] = bloom[a][0] + C3{sacc[0], sacc[1], sacc[2]};
+                    bloom[a][1] = bloom[a][1] + C3{sacc[3], sacc[4], sacc[5]};
+                }
+            } else {  // (uniform over the workgroup) a rectangle that does not fit: the strict evaluation from global memory
+                const PlaneArg mp = t.mips[m];
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1), x = min(x0p + (uint32_t)c, t.out_w - 1);
+                        bloom[a][c] = bloom[a][c] + tent_blur(mp, t.mip_w[m], t.mip_h[m], ((float)x + 0.5f) / (float)t.out_w, 1.0f - ((float)y + 0.5f) / (float)t.out_h);
+                    }
             }
-        } else {  // (uniform over the workgroup) a rectangle that does not fit: the strict evaluation from global memory
-            const PlaneArg mp = t.mips[m];
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1), x = min(x0p + (uint32_t)c, t.out_w - 1);
-                    bloom[a][c] = bloom[a][c] + tent_blur(mp, t.mip_w[m], t.mip_h[m], ((float)x + 0.5f) / (float)t.out_w, 1.0f - ((float)y + 0.5f) / (float)t.out_h);
-                }
         }
-        if (m + 1 < nmips) stage_commit(m + 1);
+        if (s + 1 < nstages) stage_commit(s + 1);
     }
+    const float4* code_tab = reinterpret_cast<const float4*>(t.code_table);
 #pragma unroll
     for (int a = 0; a < 2; a++) {
         if (!live_row[a]) continue;
         const uint32_t y = by + tr + 16u * (uint32_t)a;
-        const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
         uint32_t px[2] = {0u, 0u};
+        if (!SAH_TM_HOIST && a == 0) sample_scene();
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const uint32_t x = min(x0p + (uint32_t)c, t.out_w - 1);
-            const float u = ((float)x + 0.5f) / (float)t.out_w;
-            const Rgba sc = bilinear<ADDR_CLAMP>(t.scene, t.scene_w, t.scene_h, u, v);
-            const C3 col = {__builtin_fmaf(bloom[a][c].r, 0.014159f, sc.c[0]), __builtin_fmaf(bloom[a][c].g, 0.014159f, sc.c[1]),
-                            __builtin_fmaf(bloom[a][c].b, 0.014159f, sc.c[2])};
+            const C3 sc = scene_px[a][c];
+            const C3 col = {__builtin_fmaf(bloom[a][c].r, 0.014159f, sc.r), __builtin_fmaf(bloom[a][c].g, 0.014159f, sc.g),
+                            __builtin_fmaf(bloom[a][c].b, 0.014159f, sc.b)};
             const float luma = __builtin_fmaf(col.b, 0.0722f, __builtin_fmaf(col.g, 0.7152f, col.r * 0.2126f));
             const float factor = luma / (luma + 1.f);
             const float rgb[3] = {col.r * factor, col.g * factor, col.b * factor};
-            uint32_t code[3];  // the code search of tonemap.hip: exact for whatever value reaches it
+            uint32_t code[3];  // the code search of tonemap.hip, one table entry per channel: exact for whatever value reaches it
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const float xc = __builtin_fminf(__builtin_fmaxf(rgb[ch], t.thr_lo), t.thr_hi);
                 const uint32_t bk = (__builtin_bit_cast(uint32_t, xc) >> kTmBucketShift) - t.bucket_base;
-                const uint32_t first = reinterpret_cast<const uint8_t*>(s_first)[bk];
-                const float* th = s_thr + first;
-                code[ch] = first + (rgb[ch] >= th[1] ? 1u : 0u) + (rgb[ch] >= th[2] ? 1u : 0u) + (rgb[ch] >= th[3] ? 1u : 0u);
+                const float4 e = code_tab[bk];  // thresholds first + 1 .. first + 3, first
+                code[ch] = __builtin_bit_cast(uint32_t, e.w) + (rgb[ch] >= e.x ? 1u : 0u) + (rgb[ch] >= e.y ? 1u : 0u) + (rgb[ch] >= e.z ? 1u : 0u);
             }
             px[c] = code[0] | (code[1] << 8) | (code[2] << 16) | (255u << 24);
         }
