@@ -27,7 +27,6 @@ SHADOW_MODE_OFF, SHADOW_MODE_CSM, SHADOW_MODE_RT = 0, 1, 2
 GI_NONE, GI_LPV, GI_CACHE, GI_RTGI = 0, 1, 2, 3
 LIGHTING_QUIRK_SUN_BLEND = 1 << 0
 LIGHTING_BRUTE_FORCE_LIGHTS = 1 << 1
-EXP_LIGHTING_TOLERANCE_1ULP = 1 << 2  # experiment builds only (-DSAH_EXP_TOLERANCE_1ULP); not in include/sah_hip.h
 LIGHTING_DEFAULT_FLAGS = LIGHTING_QUIRK_SUN_BLEND
 MAX_BLOOM_MIPS = 8
 TONEMAP_TOLERANCE_1CODE = 1 << 0

@@ -61,6 +61,9 @@ class ShardedChain:
 
     def reduce(self):
         p = self.plan
+        if p.aa_rows[1] > p.aa_rows[0] and p.mip0_rows[1] > p.mip0_rows[0]:  # one pass over lit: antialiased rows + mip 0 rows
+            self.ctx.copy_scene_bloom_mip0(self.lit_p, self.aa_p, self.mc, p.aa_rows, p.mip0_rows)
+            return
         if p.aa_rows[1] > p.aa_rows[0]:
             self.ctx.copy_scene(self.lit_p, self.aa_p, *p.aa_rows)
         if p.mip0_rows[1] > p.mip0_rows[0]:

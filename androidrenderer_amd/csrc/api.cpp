@@ -605,9 +605,6 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             const uint64_t gpr = W / (uint32_t)ppt, threads = (gpr * (r1 - r0) + 255) / 256 * 256;
             fast.row_magic = (gpr >= 2 && threads * gpr < (1ull << 32)) ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u;
         }
-#ifdef SAH_EXP_TOLERANCE_1ULP
-        fast.tolerance = (d->flags & sah::kExpLightingTolerance1Ulp) ? 1u : 0u;
-#endif
         fast.state = ctx->state;
     }
     HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, (use_fast || tiled_fast_geom) ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,

@@ -16,6 +16,8 @@ hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, cons
                              uint32_t row_end, hipStream_t st);
 hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                                    uint32_t row_end, hipStream_t st);
+bool launch_copy_bloom_mip0(const PlaneArg& lit, uint32_t lw, uint32_t lh, const PlaneArg& aa, uint32_t aw, uint32_t ah, const PlaneArg& mip0, uint32_t mw, uint32_t mh,
+                            uint32_t mip_row_begin, uint32_t mip_row_end, uint32_t aa_row_begin, uint32_t aa_row_end, hipStream_t st, hipError_t* err);
 bool launch_bloom_pair(const PlaneArg& s, uint32_t sw, uint32_t sh, const PlaneArg& a, uint32_t aw, uint32_t ah, const PlaneArg& b, uint32_t bw, uint32_t bh,
                        hipStream_t st, hipError_t* err);
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
@@ -144,6 +146,45 @@ static int bloom_range(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain*
         }
         HIP_TRY(ctx, sah::launch_bloom_downsample(parg(src), src->width, src->height, parg(dst), dst->width, dst->height, r0, r1, ctx->stream));
     }
+    return SAH_OK;
+}
+
+// "Copy scene" + the first bloom dispatch in one pass over lit_scene (post.hip: k_copy_bloom_mip0).  Rows of `antialiased` that the fused
+// launch cannot own (farther than 3 rows from the rows of mip 0's sources) are copied by plain launches; extents that do not suit it take
+// the two passes one after the other.
+int sah_copy_scene_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* out, const sah_mipchain* bloom, uint32_t aa_row_begin, uint32_t aa_row_end,
+                                   uint32_t mip_row_begin, uint32_t mip_row_end) {
+    SAH_RANGE();
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!rgba16f_ok(lit) || !rgba16f_ok(out)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "copy_scene needs RGBA16F planes");
+    if (!bloom || bloom->num_mips == 0 || bloom->num_mips > SAH_MAX_BLOOM_MIPS || !rgba16f_ok(&bloom->mips[0]))
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d RGBA16F mips", SAH_MAX_BLOOM_MIPS);
+    const sah_plane* m0 = &bloom->mips[0];
+    if (aa_row_begin == 0 && aa_row_end == 0) aa_row_end = out->height;
+    if (mip_row_begin == 0 && mip_row_end == 0) mip_row_end = m0->height;
+    if (aa_row_end > out->height || aa_row_begin > aa_row_end || mip_row_end > m0->height || mip_row_begin > mip_row_end)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad row range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (mip_row_end > mip_row_begin && aa_row_end > aa_row_begin) {
+        // what the fused launch can own: from 3 rows above the first source row of the mip rows to 3 rows below the last
+        const uint32_t lo = (uint32_t)std::max<int64_t>(std::max<int64_t>((int64_t)2 * mip_row_begin - 3, (int64_t)aa_row_begin), 0);
+        const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)2 * mip_row_end + 2, aa_row_end);
+        if (hi > lo) {
+            hipError_t e = hipSuccess;
+            if (sah::launch_copy_bloom_mip0(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, parg(m0), m0->width, m0->height, mip_row_begin,
+                                            mip_row_end, lo, hi, ctx->stream, &e)) {
+                HIP_TRY(ctx, e);
+                if (lo > aa_row_begin) HIP_TRY(ctx, sah::launch_copy_scene(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, aa_row_begin, lo, ctx->stream));
+                if (aa_row_end > hi) HIP_TRY(ctx, sah::launch_copy_scene(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, hi, aa_row_end, ctx->stream));
+                return SAH_OK;
+            }
+        }
+    }
+    // the two passes
+    if (aa_row_end > aa_row_begin)
+        HIP_TRY(ctx, sah::launch_copy_scene(parg(lit), lit->width, lit->height, parg(out), out->width, out->height, aa_row_begin, aa_row_end, ctx->stream));
+    if (mip_row_end > mip_row_begin)
+        HIP_TRY(ctx, sah::launch_bloom_downsample(parg(out), out->width, out->height, parg(m0), m0->width, m0->height, mip_row_begin, mip_row_end, ctx->stream));
     return SAH_OK;
 }
 

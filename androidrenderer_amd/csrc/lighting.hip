@@ -185,21 +185,15 @@ __global__ void __launch_bounds__(256) k_colx_table(const LightingArgs a, const 
     out[stride + x] = colx_slang_of(a, f, x);
 }
 
-#ifndef SAH_SKY_RATIO
-#define SAH_SKY_RATIO 4
-#endif
-constexpr uint32_t kSkyRatio = SAH_SKY_RATIO;  // surface workgroups per sky workgroup
+constexpr uint32_t kSkyRatio = 4;  // surface workgroups per sky workgroup (1, 2, 8, 16 measured worse: DESIGN.md §5 "Deferred pixels ... and the sky")
 
 // ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
-template <int SUN, int GI, int PPT, bool RELAXED, bool SKY>
+template <int SUN, int GI, int PPT, bool SKY>
 // (106 VGPRs at 4 px/thread = 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 36-44 bytes per lane and is 12-20 %
 // slower, measured.)
 // (With the sky path in the kernel the allocator would take 137 VGPRs = 3 waves per SIMD for every wave; the bound keeps the surface
 // path's 4 — the sky path, 4 % of the frame, spills the difference.)
-#ifndef SAH_EXP_FAST_WAVES
-#define SAH_EXP_FAST_WAVES 4
-#endif
-__global__ void __launch_bounds__(256, (SKY && PPT == 4) ? SAH_EXP_FAST_WAVES : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
+__global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
                                                                                  const FastArgs f) {
     // Sky.  ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206): those pixels need their
     // coordinates and two fp64 transcendentals each, nothing of the surface code.  With a sky bound, one workgroup in kSkyRatio + 1
@@ -309,7 +303,7 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? SAH_EXP_FAST_WAVES : 
             if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) colx_glsl = colx_glsl_of(a, f, x);
             if (SUN == SAH_SHADOW_MODE_RT) colx_slang = colx_slang_of(a, f, x);
         }
-        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI, RELAXED>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
+        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
         out[2 * i] = r.lit.x;
         out[2 * i + 1] = r.lit.y;
         if (r.deferred) deferred_mask |= 1u << i;
@@ -371,21 +365,14 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     }
     const uint32_t blocks = (uint32_t)((groups + 255) / 256);
     const dim3 block(256);
-    // tolerance experiment (params.hpp: kExpLightingTolerance1Ulp): only where the relaxed body differs (fp32 BRDF of the CSM sun, LPV overlay products) and for the 4-pixel layout
-    [[maybe_unused]] constexpr bool kHasRelaxed = SUN != SAH_SHADOW_MODE_RT && (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV);
-    auto launch = [&](auto ppt_c, auto relaxed_c) {
+    auto launch = [&](auto ppt_c) {
         constexpr int P = decltype(ppt_c)::value;
-        constexpr bool R = decltype(relaxed_c)::value;
-        if (sky.enabled) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, R, true>), dim3((kSkyRatio + 1u) * ((blocks + kSkyRatio - 1u) / kSkyRatio)), block, 0, st, a, csm, lpv, sky, f);
-        else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, R, false>), dim3(blocks), block, 0, st, a, csm, lpv, sky, f);
+        if (sky.enabled) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, true>), dim3((kSkyRatio + 1u) * ((blocks + kSkyRatio - 1u) / kSkyRatio)), block, 0, st, a, csm, lpv, sky, f);
+        else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, false>), dim3(blocks), block, 0, st, a, csm, lpv, sky, f);
     };
-#ifdef SAH_EXP_TOLERANCE_1ULP
-    if (ppt == 4 && kHasRelaxed && f.tolerance) launch(std::integral_constant<int, 4>{}, std::integral_constant<bool, kHasRelaxed>{});
-    else
-#endif
-    if (ppt == 4) launch(std::integral_constant<int, 4>{}, std::false_type{});
-    else if (ppt == 2) launch(std::integral_constant<int, 2>{}, std::false_type{});
-    else launch(std::integral_constant<int, 1>{}, std::false_type{});
+    if (ppt == 4) launch(std::integral_constant<int, 4>{});
+    else if (ppt == 2) launch(std::integral_constant<int, 2>{});
+    else launch(std::integral_constant<int, 1>{});
     const dim3 fgrid((f.num_segments + kFixupSegs - 1) / kFixupSegs);
     if (ppt == 4) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 4>), fgrid, block, 0, st, a, csm, lpv, sky, f);
     else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 2>), fgrid, block, 0, st, a, csm, lpv, sky, f);

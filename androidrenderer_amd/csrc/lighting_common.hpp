@@ -315,11 +315,7 @@ SAH_DEV void lpv_fetch_packed(const LpvArgs& L, const uint8_t* packed, uint32_t 
     const int b = (int)kLpvPackBorder;
     const uint32_t x0 = (uint32_t)(min(max(clamp_to_int(fx0), -b), W) + b), y0 = (uint32_t)(min(max(clamp_to_int(fy0), -b), H) + b),
                    z0 = (uint32_t)(min(max(clamp_to_int(fz0), -b), D) + b);
-#ifdef SAH_EXP_UNIFORM_LPV  // experiment: same VALU work, every lane reads texel 0 (isolates the cost of divergent gathers)
-    const uint32_t base = (z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel) & 0u;
-#else
     const uint32_t base = z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel;
-#endif
     const uint32_t ro[4] = {base, base + row_pitch, base + slice_pitch, base + slice_pitch + row_pitch};  // (y0,z0) (y1,z0) (y0,z1) (y1,z1)
     uint32_t d[4][12];  // per row: R(x0) G(x0) B(x0) R(x1) G(x1) B(x1), two dwords (four halves) each
 #pragma unroll

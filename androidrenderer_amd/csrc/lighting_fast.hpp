@@ -16,11 +16,6 @@ SAH_DEV bool finite_f(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 // LDS table of the fast kernel: [0,512) format LUTs, then the per-cascade rows that are indexed per lane
 enum : uint32_t { TAB_CSM = 512, TAB_LPV = 512 + 48, TAB_VIEW = 512 + 48 + 32, TAB_SIZE = 512 + 48 + 32 + 12 };
 
-#ifndef SAH_TOL_G2
-#define SAH_TOL_G2 1.0f
-#endif
-constexpr float kTolG2 = SAH_TOL_G2;
-
 struct FastPixelOut {
     uint2 lit;
     bool deferred;
@@ -83,7 +78,6 @@ SAH_DEV FastGeom fast_geometry(const LightingArgs& a, const FastArgs& f, float c
 // a1: the CSM-mode sun term of one pixel, sc = direct * exposure per channel (0 when unlit or shadowed).  direct = ((ndotl * brdf) *
 // colour) * shadow is exactly 0 (or NaN, which the shader's guard turns into 0) whenever ndotl == 0 or shadow == 0, so both the PCF
 // lookup and the BRDF are skipped when no lane of the wave needs them (wave-uniform votes: no divergent branches).
-template <bool RELAXED>
 SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float* tab, const F3& N, const F3& ws, const Fn vsz, const F3& V, const F3& L,
                           const Surface<Fn>& s, const SurfIn& si, bool sky_px, bool& ok, Fn (&sc)[3]) {
     const Fn ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
@@ -118,11 +112,7 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
         const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * 2u, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * 2u;
         const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
         const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
-#ifdef SAH_EXP_UNIFORM_PCF  // experiment: divergent addresses folded into the first 64 KiB of the map (always cache resident)
-        const uint32_t pcf_off[4] = {(lo + ra + xa) & 0xfffeu, (lo + ra + xb) & 0xfffeu, (lo + rb + xa) & 0xfffeu, (lo + rb + xb) & 0xfffeu};
-#else
         const uint32_t pcf_off[4] = {lo + ra + xa, lo + ra + xb, lo + rb + xa, lo + rb + xb};
-#endif
         // PCF taps (compare LESS, then filter); the fast path is D16_UNORM only (anything else: general kernel)
         float dtap[4];
         uint16_t raw[4];
@@ -144,20 +134,6 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
         shadow = cascade > 3u ? 0.0f : shadow;
         shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
         if (__any(ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f)) {
-            if constexpr (RELAXED) {
-                const float base[3] = {si.color[0], si.color[1], si.color[2]};
-                float b[3], dden, dh, dvis;
-                brdf_relaxed(base, si.metal, si.rough, N, L, V, ndotl_sun.v, b, dden, dh, dvis);
-                const bool lit_px = ndotl_sun.v > 0.f && shadow != 0.0f;  // else direct is exactly 0 (or NaN -> 0) in the shader
-                const float t = (ndotl_sun.v * shadow) * 0.00031415927f;
-                // G2: the error of 1 - NoH^2 (about 2^-22 absolute) reaches brdf() as 2^-21 / dden times the specular share
-                // D Vis F / brdf <= D Vis / min(brdf): kept small by D Vis <= dden min(brdf) / kTolG2.  NaN operands fail the test.
-                const float bmin = __builtin_fminf(__builtin_fminf(b[0], b[1]), b[2]);
-                ok = ok && !(lit_px && !(dden * bmin >= kTolG2 * dvis && dh >= 0.25f));
-                sc[0] = Fn(lit_px ? (b[0] * (a.sun_color[0] * t)) : 0.0f);
-                sc[1] = Fn(lit_px ? (b[1] * (a.sun_color[1] * t)) : 0.0f);
-                sc[2] = Fn(lit_px ? (b[2] * (a.sun_color[2] * t)) : 0.0f);
-            } else {
             bool brdf_out_of_domain;
             const F3 b = brdf_fast(s, L, V, brdf_out_of_domain);
             const F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
@@ -170,22 +146,11 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
             sc[0] = direct.x * exposure;
             sc[1] = direct.y * exposure;
             sc[2] = direct.z * exposure;
-            }
         }
     }
 }
 
-// RELAXED = the tolerance experiment (params.hpp: kExpLightingTolerance1Ulp; instantiated only with -DSAH_EXP_TOLERANCE_1ULP): the BRDF evaluation and the overlay's final products run as fused / hardware
-// arithmetic (numerics.hpp: brdf_relaxed); everything that decides something or is ill-conditioned stays the strict sequence below.
-// Guards (all lead to `deferred`, i.e. to the strict restatement in the fix-up kernel):
-//   G1  sun term: an fp32 value within kTieMargin ulps of an fp16 rounding tie, in fp16's denormal range, or >= 65000 — the blend
-//       result lit1 = RN16(s^2) (or RN16(0 + s)) is then the strict one bit for bit, whatever the (bounded) error of s;
-//   G2  D_GGX: 0.5 * D * Vis > dden * min(brdf) — the error of 1 - NoH^2 (absolute, about 2^-22) is then too large a share of the result;
-//       |v + l|^2 < 0.25 — the half vector is the difference of two nearly opposite unit vectors;
-//   G3  overlay: |lit1 + gi| < |gi| / 4 (cancellation amplifies gi's relative error), result in fp16's denormal range or >= 65000, NaN;
-//       and, for pixels with emission, a near-tie of lit1 + gi (lit2 is then exact, so is RN16(lit2 + emission)).
-// Without G3's last clause lit2 = RN16(lit1 + gi~) is within 1 fp16 ulp of the strict value (|gi~ - gi| << ulp), and emission 0 leaves it as is.
-template <int SUN, int GI, bool RELAXED = false>
+template <int SUN, int GI>
 SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const FastArgs& f, float colx_glsl,
                                          float rowy_glsl, float colx_slang, float rowy_slang, const Px& p, const float* tab,
                                          bool lpv_has_nonfinite) {
@@ -269,7 +234,7 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     // The votes are wave-uniform: the body stays free of divergent branches.
     if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
         Fn sc[3];
-        fast_csm_sun<RELAXED>(a, csm, tab, N, ws, vsz, V, L, s, si, sky_px, ok, sc);
+        fast_csm_sun(a, csm, tab, N, ws, vsz, V, L, s, si, sky_px, ok, sc);
         const bool quirk = (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) != 0;
         // quirk: dst is the cleared target, s*s + 0*0 == s*s, alpha 1*0 + 0*0 == 0; otherwise plain additive
         float x1[3];
@@ -278,15 +243,6 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
 #pragma unroll
         for (int i = 0; i < 3; i++) lit[i] = Hn(x1[i]);
         lit[3] = quirk ? Hn::lit(0.0f) : Hn::lit(1.0f);
-        if constexpr (RELAXED) {
-            // G1 on the three values about to be rounded (non-negative; exact zeros pass): near a tie, 0 < x < 2^-14 (fp16 denormal
-            // grid), x >= 65000 (inf / NaN included: their bit patterns are larger).  Integer tests on the bit patterns, min3 / max3.
-            const uint32_t b0 = __float_as_uint(x1[0]), b1 = __float_as_uint(x1[1]), b2 = __float_as_uint(x1[2]);
-            const uint32_t near = min(min(tie_key(x1[0]), tie_key(x1[1])), tie_key(x1[2]));
-            const uint32_t small = min(min(b0 - 1u, b1 - 1u), b2 - 1u);  // 0 wraps to 0xffffffff
-            const uint32_t big = max(max(b0, b1), b2);
-            ok = ok && near >= kTieLimit && small >= 0x38800000u - 1u && big < 0x477de800u;
-        }
     }
 
     // ---------------- a3: LPV overlay ----------------
@@ -295,29 +251,6 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         lpv_fetch_packed(lpv, f.lpv_packed, f.pk_row_pitch, f.pk_slice_pitch, lpv_u, lpv_v, lpv_w, nc, indirect);
         // Fd(surface, N, N) == diffuse_color * (1/pi) exactly when N is a finite normalised vector, and the specular term
         // is (finite) * (finite * 0) == +-0 when roughness > 0 and the volumes are finite (DESIGN.md "Fast path proofs").
-        if constexpr (RELAXED) {
-            // the same products, re-associated (relative error of a few 2^-24; `indirect` itself is the strict sum)
-            const float kk = ((1.0f - si.metal) * (0.96f * 0.31830987f)) * (p.ao * lpv.exposure);
-            float x2[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const float gi = indirect[i].v * (si.color[i] * kk);
-                x2[i] = tof(lit[i]) + gi;
-                // G3: cancellation (lit1 >= 0, so only a negative overlay can cancel) would amplify gi's relative error
-                ok = ok && !(__builtin_fabsf(x2[i]) < 0.25f * __builtin_fabsf(gi));
-            }
-            // fp16 denormal range (absolute grid), overflow, NaN (a NaN / inf AO texel): strict restatement
-            const uint32_t u0 = __float_as_uint(x2[0]) << 1, u1 = __float_as_uint(x2[1]) << 1, u2 = __float_as_uint(x2[2]) << 1;
-            const uint32_t small = min(min(u0 - 2u, u1 - 2u), u2 - 2u), big = max(max(u0, u1), u2);
-            ok = ok && small >= (0x38800000u << 1) - 2u && big < (0x477de800u << 1);
-            if (__any((p.emission & 0x00ffffffu) != 0u)) {  // emissive pixels: lit2 must be the strict value before emission is added
-                const uint32_t near = min(min(tie_key(x2[0]), tie_key(x2[1])), tie_key(x2[2]));
-                ok = ok && !((p.emission & 0x00ffffffu) != 0u && near < kTieLimit);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++) lit[i] = Hn(x2[i]);
-            lit[3] = Hn(tof(lit[3]) + 1.0f);
-        } else {
         const Fn dielectric_f0 = Fn(0.04f);
         const F3 diffuse_color = s.base_color * (Fn(1.0f) - dielectric_f0) * (Fn(1.0f) - s.metalness);
         const Fn inv_pi = (Fn(1.0f) * Fn(1.0f)) * (Fn(1.0f) / Fn(3.1415927f));
@@ -332,7 +265,6 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         lit[1] = Hn(tof(lit[1]) + (total.y * exposure).v);
         lit[2] = Hn(tof(lit[2]) + (total.z * exposure).v);
         lit[3] = Hn(tof(lit[3]) + 1.0f);
-        }
     }
 
     // ---------------- a2: emissive (also the only pass that touches depth == 0 pixels when there is no sky) --------------

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         if (fast_geom) {
             const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
             Fn sc3[3];
-            fast_csm_sun<false>(a, csm, s_lut, g.N, g.ws, g.vsz, g.V, L, s, si, !surface, sun_ok, sc3);
+            fast_csm_sun(a, csm, s_lut, g.N, g.ws, g.vsz, g.V, L, s, si, !surface, sun_ok, sc3);
             sc[0] = sc3[0]; sc[1] = sc3[1]; sc[2] = sc3[2];
         }
         if (__any(surface && !sun_ok)) {

@@ -47,16 +47,6 @@ struct Fn {
 SAH_DEV Fn operator+(Fn a, Fn b) { return Fn(a.v + b.v); }
 SAH_DEV Fn operator-(Fn a, Fn b) { return Fn(a.v - b.v); }
 SAH_DEV Fn operator*(Fn a, Fn b) { return Fn(a.v * b.v); }
-#ifdef SAH_EXP_APPROX_MATH  // experiment (profiles/r2_approx_math_bound.txt, tools/experiments/approx_bound.py): every divide / sqrt / pow5 at hardware precision (1 ulp v_rcp / v_rsq
-                           // / v_sqrt, fp32 powers) — NOT the contract; an upper bound on what any tolerance mode could gain
-SAH_DEV Fn operator/(Fn a, Fn b) { return Fn(a.v * __builtin_amdgcn_rcpf(b.v)); }
-SAH_DEV Fn operator-(Fn a) { return Fn(-a.v); }
-SAH_DEV Fn nsqrt(Fn a) { return Fn(__builtin_amdgcn_sqrtf(a.v)); }
-SAH_DEV Fn npow5(Fn a) {
-    const float d2 = a.v * a.v;
-    return Fn(d2 * d2 * a.v);
-}
-#else
 SAH_DEV Fn operator/(Fn a, Fn b) { return Fn(a.v / b.v); }
 SAH_DEV Fn operator-(Fn a) { return Fn(-a.v); }
 SAH_DEV Fn nsqrt(Fn a) { return Fn(__builtin_sqrtf(a.v)); }
@@ -64,7 +54,6 @@ SAH_DEV Fn npow5(Fn a) {
     double d = (double)a.v;
     return Fn((float)(d * d * d * d * d));
 }
-#endif
 SAH_DEV float tof(Fn a) { return a.v; }
 
 // ---- correctly rounded sqrt / reciprocal / divide for operands of KNOWN range ----------------------------------------------
@@ -79,12 +68,6 @@ SAH_DEV float tof(Fn a) { return a.v; }
 constexpr float kNrLo = 0x1p-100f, kNrHi = 0x1p+100f;  // domain of sqrt_nr / rcp_nr (magnitudes)
 constexpr float kDivLo = 0x1p-40f, kDivHi = 0x1p+40f;  // domain of div_nr (|a|, |b|; a may also be +0)
 
-#ifdef SAH_EXP_APPROX_MATH
-SAH_DEV float sqrt_nr(float x) { return __builtin_amdgcn_sqrtf(x); }
-SAH_DEV float sqrt_nr0(float x) { return __builtin_amdgcn_sqrtf(x); }
-SAH_DEV float rcp_nr(float x) { return __builtin_amdgcn_rcpf(x); }
-SAH_DEV float div_nr(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-#else
 // x in [2^-100, 2^100] -> RN(sqrt(x))
 SAH_DEV float sqrt_nr(float x) {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -123,7 +106,6 @@ SAH_DEV float div_nr(float a, float b) {
     const float r1 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(r1, y1, q1);
 }
-#endif
 
 // float -> uint as the hardware converts (GLSL / Slang uint(float) on this path): truncation, negatives and NaN -> 0, 2^32 and above ->
 // 0xffffffff.  Written in C++ ("f > 0 ? (f >= 2^32 ? ~0 : (uint32_t)f) : 0") it compiles to two nested exec-mask regions around the one
@@ -429,58 +411,5 @@ SAH_DEV F3 brdf_fast_light(const Surface<Fn>& s, const BrdfPixel& p, F3 l, F3 v,
     out_of_domain = !dark && !(lo_sqrt >= 0x1p-80f && lo_div >= kDivLo);
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
-
-// ---- tolerance experiment (-DSAH_EXP_TOLERANCE_1ULP, params.hpp): the fp32 brdf() of brdf.glsl:29-121 for the fast kernel -------------------------
-// Inputs are the strict (exact) unit vectors; the evaluation uses explicit FMAs, v_rsq / v_rcp / v_sqrt (1 ulp) and x^5 as three
-// multiplies.  Every term is a product or a sum of non-negative quantities except 1 - NoH^2 + a^2, whose error is bounded by the caller's
-// guard on `dden` (the D_GGX denominator): a relative error of about 2^-22 / dden in D.  Returns fd + fr for a lit pixel (NoL > 0);
-// the caller selects 0 for N.L <= 0 as the shader's early-outs do.
-SAH_DEV void brdf_relaxed(const float (&base)[3], float metal, float a, F3 n, F3 l, F3 v, float NoL, float (&out)[3], float& dden, float& dh_out,
-                          float& dvis) {
-    const float om = 1.0f - metal;
-    const float c04 = 0.04f * om, k96 = 0.96f * om;
-    // h = normalize(v + l): the sum is the strict one, its length through v_rsq
-    const float vlx = v.x.v + l.x.v, vly = v.y.v + l.y.v, vlz = v.z.v + l.z.v;
-    const float dh = __builtin_fmaf(vlx, vlx, __builtin_fmaf(vly, vly, vlz * vlz));
-    const float ih = __builtin_amdgcn_rsqf(dh);
-    const float NoV = __builtin_fabsf((n.x * v.x + n.y * v.y + n.z * v.z + Fn(1e-5f)).v);  // strict: it feeds 1 - NoV near grazing angles
-    auto sat = [](float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); };
-    const float NoH = sat(__builtin_fmaf(n.x.v, vlx, __builtin_fmaf(n.y.v, vly, n.z.v * vlz)) * ih);
-    const float VoH = sat(__builtin_fmaf(v.x.v, vlx, __builtin_fmaf(v.y.v, vly, v.z.v * vlz)) * ih);
-    const float LoH = sat(__builtin_fmaf(l.x.v, vlx, __builtin_fmaf(l.y.v, vly, l.z.v * vlz)) * ih);
-    // Fd_Burley
-    const float f90m1 = __builtin_fmaf((a + a) * LoH, LoH, -0.5f);
-    const float ul = 1.0f - NoL, ul2 = ul * ul;
-    const float uv = sat(1.0f - NoV), uv2 = uv * uv;
-    const float ls = __builtin_fmaf(f90m1, ul2 * ul2 * ul, 1.0f), vs = __builtin_fmaf(f90m1, uv2 * uv2 * uv, 1.0f);
-    const float fd = ls * vs * 0.31830987f;
-    // D_GGX
-    const float a2 = a * a;
-    dden = __builtin_fmaf(-NoH, NoH, 1.0f) + a2;
-    const float k = a * __builtin_amdgcn_rcpf(dden);
-    // F_Schlick(VoH, f0, 1)
-    const float w = 1.0f - VoH, w2 = w * w, w5 = w2 * w2 * w;
-    // V_SmithGGXCorrelated
-    const float argL = __builtin_fmaf(__builtin_fmaf(-NoL, a2, NoL), NoL, a2), argV = __builtin_fmaf(__builtin_fmaf(-NoV, a2, NoV), NoV, a2);
-    const float vden = __builtin_fmaf(NoL, __builtin_amdgcn_sqrtf(argV), NoV * __builtin_amdgcn_sqrtf(argL));
-    const float dv = (k * k) * (0.31830987f * 0.5f) * __builtin_amdgcn_rcpf(vden);  // D * Vis
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float f0 = __builtin_fmaf(base[i], metal, c04);
-        const float F = __builtin_fmaf(1.0f - f0, w5, f0);
-        out[i] = __builtin_fmaf(dv, F, (base[i] * k96) * fd);
-    }
-    dh_out = dh;
-    dvis = dv;
-}
-
-// Near-tie test of an fp32 value against the fp16 rounding grid: true when the 13 bits that RN16 drops are within `kTieMargin` fp32
-// ulps of the tie point, i.e. when a relative perturbation of up to kTieMargin * 2^-23 could change the fp16 result.
-#ifndef SAH_TOL_MARGIN
-#define SAH_TOL_MARGIN 48
-#endif
-constexpr uint32_t kTieMargin = SAH_TOL_MARGIN;  // fp32 ulps either side (a relative error budget of 2^-17.4); 2 * 48 / 8192 = 1.2 % of values trip it
-SAH_DEV uint32_t tie_key(float x) { return (__float_as_uint(x) + (kTieMargin - 0x1000u)) << 19; }  // v_add_lshl_u32
-constexpr uint32_t kTieLimit = (2u * kTieMargin) << 19;
 
 }  // namespace sah

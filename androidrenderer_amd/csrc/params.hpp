@@ -99,7 +99,6 @@ struct FastArgs {
     uint32_t repack;       // 1: this call rebuilds the gather copy first
     const float* colx_tab; // per-column view-space x numerators (k_colx_table): [0, width) the GLSL flavour, [colx_stride, ..) the Slang one; or null
     uint32_t colx_stride;
-    uint32_t tolerance;  // experiment builds only (-DSAH_EXP_TOLERANCE_1ULP): run the relaxed body where it exists; always 0 otherwise
     FrameState* state;
     // Deferred pixels, without atomics: the wave that shades thread groups [64 s, 64 s + 64) owns segment s — kSegSize(PPT) byte codes
     // (lane * PPT + pixel) at seg_list + s * seg_stride — general pixels from the front, sky pixels (depth == 0) from the back — and
@@ -115,10 +114,6 @@ struct FastArgs {
 };
 // (an fp32 copy — 48-byte texels, plain v_fma_f32 taps — was measured and loses 67 %: profiles/r3_lpv_pack32_experiment.txt)
 constexpr uint32_t kLpvPackTexel = 24, kLpvPackBorder = 2;
-// Experiment (round 2, profiles/r2_tolerance_mode_v1.txt): a "within 1 fp16 ULP" mode of the fast kernel.  2.4x SLOWER than the strict
-// kernel (its guards send 36-50 % of the pixels through both paths), so it is not part of the ABI: the flag bit exists only in a
-// library built with SAH_EXTRA_HIPCC_FLAGS=-DSAH_EXP_TOLERANCE_1ULP, which is what tests/test_tolerance_gpu.py asks for.
-constexpr uint32_t kExpLightingTolerance1Ulp = 1u << 2;
 
 struct LightingArgs {
     PlaneArg color, normals, data, emission, depth, ao, shadow_mask, lit;

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_bloom_downsample(PlaneArg src, uint32_t
 // 6 distinct x and 6 distinct y coordinates (u -+ ix, and those -+ ix again); same taps, same order, same operators as
 // k_bloom_downsample: bit-identical.  A tile whose rectangle does not fit (extreme aspect ratios) takes the global-memory form.
 // `row_begin/row_end`: destination rows to produce (row-sharded pyramids).
-// (PPT = SAH_BLOOM_PPT for the large mips; small mips take PPT = 1 — 64x4 tiles — so that their few texels spread over more
+// (PPT = 2 for the large mips; small mips take PPT = 1 — 64x4 tiles — so that their few texels spread over more
 // workgroups with shorter dependency chains: 10.5 -> 5 us per launch for the 240x135 mip and below)
 constexpr int kBlW = 64, kBlPitch = 136;
 // LDS row layout: texel tx of a staged row sits in cell tx + tx / 32 (one empty cell after every 32).  Adjacent destination columns
@@ -195,6 +195,208 @@ __global__ void __launch_bounds__(256) k_bloom_downsample_lds(PlaneArg src, uint
         }
         store_rgba16f(dst, (int)x, (int)y, s.r, s.g, s.b, 0.0f);
     }
+}
+
+// ---- a13 + a7 mip 0 in one pass --------------------------------------------------------------------------------------------------
+// "Copy scene" writes `antialiased` and the first bloom dispatch reads it straight back (scene_renderer.cpp:502-527, bloomer.cpp:50-72): two
+// launches and 8 B/px of traffic that exist only because they are two draws.  Here the workgroup that produces a 64 x 8 tile of mip 0 computes
+// the antialiased texels its taps can touch (136 x 24, edge replication applied — the rectangle k_bloom_downsample_lds would load) from
+// `lit` with the copy pass's own sampler arithmetic (bilinear<ADDR_REPEAT>: same operators, tabulated per column / row), keeps them in LDS as
+// the fp16 bits it would have loaded, stores the ones it OWNS to `antialiased`, and filters its tile from LDS with bloom_texel().  Texels in
+// the overlap of neighbouring tiles are computed by each of them, from the same inputs with the same operators: the same bits, and only the
+// owner stores.  Ownership: antialiased rows [2 by, 2 by + 16) x columns [2 bx, 2 bx + 128) of the tile at (bx, by); the first / last tile
+// row of the launch also owns the rows from aa_row_begin / up to aa_row_end (the rows its neighbours' taps and the composite need from
+// beyond the mip rows of a row-sharded frame — they lie inside its rectangle: the host checks), the last tile column the odd column.
+struct CopyAxis {  // one axis of the copy's bilinear tap: byte offsets of the two (wrapped) texels and the two weights
+    uint32_t o0, o1;
+    float w0, w1;
+};
+struct CopyBloomArgs {
+    PlaneArg lit, aa, mip0;
+    uint32_t lw, lh, aw, ah, mw, mh;
+    uint32_t mip_row_begin, mip_row_end, aa_row_begin, aa_row_end;
+};
+template <int kBlPpt>
+__global__ void __launch_bounds__(256) k_copy_bloom_mip0(const CopyBloomArgs g) {
+    constexpr int kBlH = 4 * kBlPpt, kBlRows = 2 * kBlH + 8, kBlTexels = kBlPitch * kBlRows;
+    __shared__ uint2 s_tex[kBlPitchCells * kBlRows];
+    __shared__ AxisE s_ax[6 * kBlW + 6 * kBlH];
+    __shared__ CopyAxis s_cx[kBlPitch], s_cy[kBlRows];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bx = blockIdx.x * kBlW, by = g.mip_row_begin + blockIdx.y * kBlH;
+    const uint32_t x_last = min(bx + kBlW - 1, g.mw - 1), y_last = min(by + kBlH - 1, g.mip_row_end - 1);
+    const uint32_t sw = g.aw, sh = g.ah, dw = g.mw, dh = g.mh;  // the bloom pass's source (antialiased) and destination (mip 0)
+    const float ix = 1.0f / (float)sw, iy = 1.0f / (float)sh;
+    const float ox = ix * -1.0f, oy = iy * -1.0f, oz = ix * 1.0f, ow = iy * 1.0f;
+    // the rectangle of k_bloom_downsample_lds (uniform, every thread)
+    const float pu0 = ((float)bx + 0.5f) / (float)dw * (float)sw - 0.5f, pu1 = ((float)x_last + 0.5f) / (float)dw * (float)sw - 0.5f;
+    const float pv0 = ((float)by + 0.5f) / (float)dh * (float)sh - 0.5f, pv1 = ((float)y_last + 0.5f) / (float)dh * (float)sh - 0.5f;
+    const int rx0 = (int)__builtin_floorf(pu0 - 3.0f), rx1 = (int)__builtin_floorf(pu1 + 3.0f) + 1;
+    const int ry0 = (int)__builtin_floorf(pv0 - 3.0f), ry1 = (int)__builtin_floorf(pv1 + 3.0f) + 1;
+    const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;  // (<= kBlPitch x kBlRows: host check)
+    // 1. the copy's axis set-ups for the rectangle's columns / rows (cell j stands for antialiased texel clamp(r0 + j)) and the bloom
+    //    pass's six set-ups per tile column / row
+    if (tid < (uint32_t)(kBlPitch + kBlRows)) {
+        const bool is_x = tid < (uint32_t)kBlPitch;
+        const int j = is_x ? (int)tid : (int)tid - kBlPitch;
+        const int t = is_x ? min(max(rx0 + j, 0), (int)sw - 1) : min(max(ry0 + j, 0), (int)sh - 1);
+        // copy_with_sampler.frag.slang: uv = SV_Position.xy * inverse_resolution, linear sampler with REPEAT addressing (k_copy_scene)
+        const float inv = 1.0f / (float)(is_x ? sw : sh);
+        const float c = ((float)t + 0.5f) * inv;
+        const uint32_t n = is_x ? g.lw : g.lh;
+        const float p = c * (float)n - 0.5f;
+        const float f0 = __builtin_floorf(p);
+        const float f = p - f0;
+        const int i0 = (int)__builtin_fminf(__builtin_fmaxf(f0, -1.0e9f), 1.0e9f);
+        const uint32_t a = (uint32_t)wrap<ADDR_REPEAT>(i0, (int)n), b = (uint32_t)wrap<ADDR_REPEAT>(i0 + 1, (int)n);
+        const uint32_t stride = is_x ? 8u : g.lit.pitch;
+        (is_x ? s_cx : s_cy)[j] = CopyAxis{a * stride, b * stride, 1.0f - f, f};
+    }
+    {
+        const uint32_t u = tid;  // bloom tables by the first kBlW + kBlH threads, exactly as k_bloom_downsample_lds
+        if (u < (uint32_t)(kBlW + kBlH)) {
+            const bool is_x = u < (uint32_t)kBlW;
+            const uint32_t j = is_x ? u : u - kBlW;
+            const float c = is_x ? ((float)min(bx + j, x_last) + 0.5f) / (float)dw : ((float)min(by + j, y_last) + 0.5f) / (float)dh;
+            const float lo = is_x ? ox : oy, hi = is_x ? oz : ow;
+            const float ca = c + lo, cb = c + hi;
+            const float coords[6] = {ca, cb, ca + lo, ca + hi, cb + lo, cb + hi};
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const AxisU a = axis_unclamped(coords[k], is_x ? sw : sh);
+                if (is_x) {
+                    s_ax[k * kBlW + j] = AxisE{bl_cell(a.i - rx0) * 8, bl_cell(a.i + 1 - rx0) * 8, a.w0, a.w1};
+                } else {
+                    const float scale = k < 2 ? 0.125f : 0.03125f;
+                    s_ax[6 * kBlW + k * kBlH + j] = AxisE{(a.i - ry0) * kBlPitchCells * 8, 0, a.w0 * scale, a.w1 * scale};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 2. the antialiased texels of the rectangle: seven cells per round and thread, their taps in flight together
+    {
+        const int own_x0 = 2 * (int)bx, own_x1 = blockIdx.x + 1 == gridDim.x ? (int)sw : 2 * (int)(bx + kBlW);
+        const int own_y0 = blockIdx.y == 0 ? (int)g.aa_row_begin : max(2 * (int)by, (int)g.aa_row_begin);
+        const int own_y1 = blockIdx.y + 1 == gridDim.y ? (int)g.aa_row_end : min(2 * (int)(by + kBlH), (int)g.aa_row_end);
+        constexpr int kCells = 7, kRounds = (kBlTexels + 256 * kCells - 1) / (256 * kCells);  // 13 cells per thread in two rounds of 7 x 4 taps in flight (4: 57.9 us at 4K)
+        const uint8_t* lit = g.lit.ptr;
+        for (int round = 0; round < kRounds; round++) {
+            uint2 t[kCells][4];
+            CopyAxis cx[kCells], cy[kCells];
+            int cell_x[kCells], cell_y[kCells];
+#pragma unroll
+            for (int q = 0; q < kCells; q++) {
+                const int i = (int)tid + (round * kCells + q) * 256;
+                const int ty = min(i / kBlPitch, kBlRows - 1), tx = i - (i / kBlPitch) * kBlPitch;  // (cells past the rectangle: a valid address, dropped below)
+                cell_x[q] = i < kBlTexels && tx < rw && ty < rh ? tx : -1;
+                cell_y[q] = ty;
+                cx[q] = s_cx[tx];
+                cy[q] = s_cy[ty];
+                t[q][0] = *reinterpret_cast<const uint2*>(lit + (cy[q].o0 + cx[q].o0));
+                t[q][1] = *reinterpret_cast<const uint2*>(lit + (cy[q].o0 + cx[q].o1));
+                t[q][2] = *reinterpret_cast<const uint2*>(lit + (cy[q].o1 + cx[q].o0));
+                t[q][3] = *reinterpret_cast<const uint2*>(lit + (cy[q].o1 + cx[q].o1));
+            }
+#pragma unroll
+            for (int q = 0; q < kCells; q++) {
+                if (cell_x[q] < 0) continue;
+                // bilinear<ADDR_REPEAT>: weights formed as there, fma chain in tap order from +0, four channels
+                const float w[4] = {cx[q].w0 * cy[q].w0, cx[q].w1 * cy[q].w0, cx[q].w0 * cy[q].w1, cx[q].w1 * cy[q].w1};
+                float ch[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t word = c < 2 ? t[q][k].x : t[q][k].y;
+                        a = __builtin_fmaf(w[k], h2f((uint16_t)((c & 1) ? word >> 16 : word & 0xffffu)), a);
+                    }
+                    ch[c] = a;
+                }
+                uint2 v;
+                v.x = (uint32_t)f2h(ch[0]) | ((uint32_t)f2h(ch[1]) << 16);
+                v.y = (uint32_t)f2h(ch[2]) | ((uint32_t)f2h(ch[3]) << 16);
+                s_tex[cell_y[q] * kBlPitchCells + bl_cell(cell_x[q])] = v;
+                const int ax = rx0 + cell_x[q], ay = ry0 + cell_y[q];  // the texel the cell stands for, when inside the image
+                if (ax >= own_x0 && ax < own_x1 && ay >= own_y0 && ay < own_y1)
+                    *reinterpret_cast<uint2*>(const_cast<uint8_t*>(g.aa.ptr) + (size_t)ay * g.aa.pitch + (size_t)ax * 8) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it
+    const uint32_t col = tid & 63u, x = bx + col;
+    if (x >= dw) return;
+    const char* lds = reinterpret_cast<const char*>(s_tex);
+    AxisE xs[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) xs[k] = s_ax[k * kBlW + col];
+#pragma unroll
+    for (uint32_t q = 0; q < (uint32_t)kBlPpt; q++) {
+        const uint32_t row = (tid >> 6) + 4u * q, y = by + row;
+        if (y >= g.mip_row_end) break;
+        const AxisE* rowp = s_ax + 6 * kBlW + row;
+        const AxisE ys[6] = {rowp[0], rowp[kBlH], rowp[2 * kBlH], rowp[3 * kBlH], rowp[4 * kBlH], rowp[5 * kBlH]};
+        const C3 s = bloom_texel<kBlPitchCells>(lds, xs, ys);
+        store_rgba16f(g.mip0, (int)x, (int)y, s.r, s.g, s.b, 0.0f);
+    }
+}
+
+// host: every tile's rectangle fits and holds its set-ups (the kernel's arithmetic), the rows asked for beyond the mip rows lie inside the
+// first / last tile row's rectangle, and the extents are those of a half-resolution mip (ownership)
+template <int kBlPpt> static bool copy_bloom_fits(const CopyBloomArgs& g) {
+    constexpr int kBlH = 4 * kBlPpt, kBlRows = 2 * kBlH + 8;
+    if (g.mw == 0 || g.mh == 0 || (g.aw != 2 * g.mw && g.aw != 2 * g.mw + 1) || (g.ah != 2 * g.mh && g.ah != 2 * g.mh + 1)) return false;
+    if (g.lw > 32768 || g.lh > 32768 || (uint64_t)g.lit.pitch * g.lh >= (1ull << 31)) return false;  // 32-bit byte offsets in the copy's tables
+    auto axis_ok = [](uint32_t d0, uint32_t d1, uint32_t dst, uint32_t src, int cap, int* r0, int* r1) {
+        const float p0 = ((float)d0 + 0.5f) / (float)dst * (float)src - 0.5f, p1 = ((float)d1 + 0.5f) / (float)dst * (float)src - 0.5f;
+        const int a = (int)__builtin_floorf(p0 - 3.0f), b = (int)__builtin_floorf(p1 + 3.0f) + 1;
+        *r0 = a;
+        *r1 = b;
+        if (b - a + 1 > cap) return false;
+        const float i = 1.0f / (float)src, lo = i * -1.0f, hi = i * 1.0f;
+        for (uint32_t t = d0; t <= d1; t++) {
+            const float c = ((float)t + 0.5f) / (float)dst, ca = c + lo, cb = c + hi;
+            const float coords[6] = {ca, cb, ca + lo, ca + hi, cb + lo, cb + hi};
+            for (float co : coords) {
+                const float p = co * (float)src - 0.5f;
+                const int idx = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(p), -1.0e9f), 1.0e9f);
+                if (idx < a || idx + 1 > b) return false;
+            }
+        }
+        return true;
+    };
+    int r0, r1;
+    for (uint32_t b0 = 0; b0 < g.mw; b0 += kBlW) {
+        const uint32_t b1 = std::min(b0 + kBlW - 1, g.mw - 1);
+        if (!axis_ok(b0, b1, g.mw, g.aw, kBlPitch, &r0, &r1)) return false;
+        const int own1 = (b0 + kBlW >= g.mw ? (int)g.aw : 2 * (int)(b0 + kBlW)) - 1;
+        if (2 * (int)b0 < r0 || own1 > r1) return false;
+    }
+    for (uint32_t b0 = g.mip_row_begin; b0 < g.mip_row_end; b0 += kBlH) {
+        const uint32_t b1 = std::min(b0 + kBlH - 1, g.mip_row_end - 1);
+        if (!axis_ok(b0, b1, g.mh, g.ah, kBlRows, &r0, &r1)) return false;
+        const int own0 = b0 == g.mip_row_begin ? (int)g.aa_row_begin : 2 * (int)b0;
+        const int own1 = (b0 + kBlH >= g.mip_row_end ? (int)g.aa_row_end : 2 * (int)(b0 + kBlH)) - 1;
+        if (own0 < r0 || own1 > r1) return false;
+    }
+    return true;
+}
+
+// antialiased rows [aa_row_begin, aa_row_end) and mip 0 rows [mip_row_begin, mip_row_end) in one launch; false: not in this form (the caller
+// runs the two passes)
+bool launch_copy_bloom_mip0(const PlaneArg& lit, uint32_t lw, uint32_t lh, const PlaneArg& aa, uint32_t aw, uint32_t ah, const PlaneArg& mip0, uint32_t mw, uint32_t mh,
+                            uint32_t mip_row_begin, uint32_t mip_row_end, uint32_t aa_row_begin, uint32_t aa_row_end, hipStream_t st, hipError_t* err) {
+    *err = hipSuccess;
+    if (mip_row_end <= mip_row_begin || (uint64_t)aa.pitch * ah >= (1ull << 31)) return false;
+    const CopyBloomArgs g{lit, aa, mip0, lw, lh, aw, ah, mw, mh, mip_row_begin, mip_row_end, aa_row_begin, aa_row_end};
+    constexpr int kPpt = 2;
+    if (!copy_bloom_fits<kPpt>(g)) return false;
+    const uint32_t rows = mip_row_end - mip_row_begin;
+    hipLaunchKernelGGL(k_copy_bloom_mip0<kPpt>, dim3((mw + kBlW - 1) / kBlW, (rows + 4 * kPpt - 1) / (4 * kPpt)), dim3(256), 0, st, g);
+    *err = hipGetLastError();
+    return true;
 }
 
 // ---- a7, two mips per launch -------------------------------------------------------------------------------------------------------
@@ -430,11 +632,8 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
     if (row_end <= row_begin) return hipSuccess;
     if ((uint64_t)src.pitch * sh < (1ull << 31)) {
         const uint32_t cols = (dw + kBlW - 1) / kBlW, rows = row_end - row_begin;
-#ifndef SAH_BLOOM_PPT
-#define SAH_BLOOM_PPT 2  // texels per thread in the large mips; 2 and 4 measured alike (0.094 / 0.096 ms for the 4K chain)
-#endif
-        constexpr int kBig = SAH_BLOOM_PPT;
-        if ((uint64_t)cols * ((rows + 15) / 16) >= 1024) {  // enough 64x16 tiles for four per CU
+        constexpr int kBig = 2;  // texels per thread in the large mips; 2 and 4 measured alike (0.094 / 0.096 ms for the 4K chain)
+        if ((uint64_t)cols * ((rows + 15) / 16) >= 500) {  // enough 64x16 tiles for two per CU (mip 1 of a 4K chain, 510 of them: 15.5 -> 12.7 us)
             hipLaunchKernelGGL(k_bloom_downsample_lds<kBig>, dim3(cols, (rows + 4 * kBig - 1) / (4 * kBig)), dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);
         } else {
             hipLaunchKernelGGL(k_bloom_downsample_lds<1>, dim3(cols, (rows + 3) / 4), dim3(256), 0, st, src, sw, sh, dst, dw, dh, row_begin, row_end);

@@ -862,9 +862,6 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
     // workgroup, one after the other: lanes form an 8x8 pixel block, the four waves take alternate block rows of the bounding box.
     __shared__ BigRecord s_big[kBigSlots];
     __shared__ uint32_t s_nbig;
-#ifdef SAH_EXP_RASTER_SKIP_LIST  // timing experiment: tile init + write-out only
-    const uint32_t begin = 0, count = 0, parts = 1, slot_of_tile = ~0u;
-#else
     // (a bin list that does not fit the buffer is not read: the host repeats the pass with a larger one)
     const uint32_t whole = (uint64_t)a.tile_offset[tile] + a.tile_count[tile] <= a.pairs_capacity ? a.tile_count[tile] : 0u;
     const uint32_t slot_of_tile = a.heavy_slot[tile] < a.merge_capacity ? a.heavy_slot[tile] : ~0u;  // ~0: the list is not split
@@ -872,7 +869,6 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
     if (part >= parts) return;
     const uint32_t first = slot_of_tile != ~0u ? part * kSplit : 0u;
     const uint32_t begin = a.tile_offset[tile] + first, count = slot_of_tile != ~0u ? min(kSplit, whole - min(whole, first)) : whole;
-#endif
     for (uint32_t base = 0; base < count; base += kTileThreads) {
         if (tid == 0) s_nbig = 0;
         __syncthreads();
@@ -891,10 +887,6 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
             area = (uint32_t)((x1 - x0 + 1) * (y1 - y0 + 1));
             mine = edge_setup(rec);  // every lane sets up its own record: 64 set-ups for the price of one
             medium_rec = area > kSmallArea && area <= kMediumArea;
-#ifdef SAH_EXP_RASTER_SKIP_SMALL  // timing experiment: lane-walked records dropped
-            if (area <= kSmallArea) {
-            } else
-#endif
             if (area <= kSmallArea) {
                 for (int32_t py = y0; py <= y1; py++)
                     for (int32_t px = x0; px <= x1; px++) test_pixel<GBUFFER, TEX>(a, mine, rec_index, px, py, tile_x, tile_y, s_depth, s_key);
@@ -911,11 +903,7 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
         }
         // medium records: one at a time by the wave that read them, lanes as an 8x8 block sweeping the clipped bounding box; the
         // owner lane's set-up moves to scalar registers with v_readlane (no memory round trip per record)
-#ifdef SAH_EXP_RASTER_SKIP_MEDIUM  // timing experiment: wave-swept records dropped
-        uint64_t medium = 0;
-#else
         uint64_t medium = __ballot(medium_rec);
-#endif
         while (medium) {
             const int src = __builtin_ctzll(medium);
             medium &= medium - 1;
@@ -926,11 +914,7 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
             sweep<GBUFFER, TEX>(a, e, ri, bx0, bx1, bx1, by1, by0, 8, lane, tile_x, tile_y, s_depth, s_key);
         }
         __syncthreads();
-#ifdef SAH_EXP_RASTER_SKIP_BIG  // timing experiment: no workgroup-cooperative records
-        const uint32_t nbig = 0;
-#else
         const uint32_t nbig = min(s_nbig, kBigSlots);
-#endif
         for (uint32_t k = 0; k < nbig; k++) {
             const EdgeSetup e = s_big[k].e;  // same address in every lane: an LDS broadcast
             const uint32_t ri = s_big[k].rec_index;
@@ -997,15 +981,11 @@ __global__ __launch_bounds__(kTileThreads, (GBUFFER && !TEX) ? 3 : 1) void k_ras
             const int32_t px = tile_x + (int32_t)(i % kTile), py = tile_y + (int32_t)(i / kTile);
             if ((uint32_t)px >= a.width || (uint32_t)py >= a.height) continue;
             const unsigned long long key = s_key[i];
-#ifdef SAH_EXP_RASTER_SKIP_RESOLVE  // timing experiment: no fragment stage
-            if (true) {
-#else
             if (key == 0ull && a.rsm) {  // clear values, light_propagation_volume.cpp:586-606
                 *(uint32_t*)(a.rsm_flux.ptr + (size_t)view * a.rsm_flux.slice_pitch + (size_t)py * a.rsm_flux.row_pitch + (size_t)px * 4) = 0u;
                 *(uint32_t*)(a.rsm_normals.ptr + (size_t)view * a.rsm_normals.slice_pitch + (size_t)py * a.rsm_normals.row_pitch + (size_t)px * 4) = 0x00ff8080u;
                 *(uint16_t*)(a.rsm_depth.ptr + (size_t)view * a.rsm_depth.slice_pitch + (size_t)py * a.rsm_depth.row_pitch + (size_t)px * 2) = 0xffffu;
             } else if (key == 0ull) {  // clear values, gbuffer_phase.cpp:66-87
-#endif
                 *(uint32_t*)(a.out_color.ptr + (size_t)py * a.out_color.pitch + (size_t)px * 4) = 0u;
                 *(uint2*)(a.out_normals.ptr + (size_t)py * a.out_normals.pitch + (size_t)px * 8) = make_uint2(0x38003800u, 0x00003c00u);
                 *(uint32_t*)(a.out_data.ptr + (size_t)py * a.out_data.pitch + (size_t)px * 4) = 0u;

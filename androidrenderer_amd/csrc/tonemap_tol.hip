@@ -34,14 +34,23 @@
 namespace sah {
 namespace {
 
-constexpr int kTile = 32;
-constexpr int kMaxRows = 21;  // staged rows of one stage, all its mips together (half-resolution chains: mip 0 needs 20, mips 1 + 2 12 + 8, mips 3..5 6 + 6 + 6).
-                              // Not 22: three workgroups of 54.4 KB did NOT fit a CU's 160 KB (allocation granularity) — two per CU, 1.47 x the time
+constexpr int kTile = 32;     // tile width in pixels
 constexpr int kPitch = 32;    // cells per staged row (a rectangle is at most 25 texel columns wide)
 constexpr int kMaxCols = 25;
-constexpr int kPlane = kMaxRows * kTile * 3;  // floats per G plane
-constexpr int kStageIters = (kMaxRows + 7) / 8;
 constexpr int kStageMips = 3;
+// Tile height and how the mips are grouped into stages.  32 rows: {0}, {1, 2}, {3, 4, 5} — 21 staged rows hold each stage of a
+// half-resolution chain (mip 0 needs 20, mips 1 + 2 12 + 8, mips 3..5 6 + 6 + 6); 52.3 KB of LDS, three workgroups per CU (22 rows: 54.4 KB,
+// which did NOT fit three times into a CU's 160 KB — two per CU, 1.47 x the time).  16 rows, for row bands whose 32-row tiles would not
+// fill the chip twice (a rank's rows of a sharded frame): {0}, {1, 2}, {3, 4}, {5} in 14 rows, 34 KB, four workgroups per CU.
+template <int TH> struct TmShape;
+template <> struct TmShape<32> {
+    static constexpr int kMaxRows = 21, kWaves = 3;
+    static SAH_DEV uint32_t first(uint32_t s) { return s == 0 ? 0u : (s == 1 ? 1u : (s == 2 ? 3u : 6u)); }
+};
+template <> struct TmShape<16> {
+    static constexpr int kMaxRows = 14, kWaves = 4;
+    static SAH_DEV uint32_t first(uint32_t s) { return s == 0 ? 0u : (s == 1 ? 1u : (s == 2 ? 3u : (s == 3 ? 5u : 6u))); }
+};
 
 struct AxisS {  // one axis set-up in LDS: offset of the first of the two texels / rows (x: float4 cells, y: floats into a G plane) and the
     int o;      // fraction f (x) or f / 16 (y); the two weights are 1 - f, f (resp. 1/16 - f/16, f/16: the same bits as (1 - f) / 16)
@@ -70,7 +79,7 @@ struct Rect {
 
 // texel rectangle of mip (W x H) the tile can touch (as tonemap.hip): tile bounds in mip texels, widened by the tap offsets (x: -max(1,
 // W/H) .. +1 texels, y: -+max(1, H/W)) and half a texel for the roundings of the set-ups; a tap also reads the texel to the right / below
-SAH_DEV Rect tile_rect(const TonemapArgs& t, uint32_t W, uint32_t H, uint32_t bx, uint32_t by, uint32_t x_last, uint32_t y_last) {
+SAH_DEV Rect tile_rect(const TonemapArgs& t, uint32_t W, uint32_t H, uint32_t bx, uint32_t by, uint32_t x_last, uint32_t y_last, int max_rows) {
     const float Wf = (float)W, Hf = (float)H;
     const float left = __builtin_fmaxf(1.0f, Wf / Hf) + 0.5f, right = 1.5f, updown = __builtin_fmaxf(1.0f, Hf / Wf) + 0.5f;
     const float pu0 = ((float)bx + 0.5f) / (float)t.out_w * Wf - 0.5f, pu1 = ((float)x_last + 0.5f) / (float)t.out_w * Wf - 0.5f;
@@ -81,7 +90,7 @@ SAH_DEV Rect tile_rect(const TonemapArgs& t, uint32_t W, uint32_t H, uint32_t bx
     const int x1 = (int)__builtin_floorf(pu1 + right), y1 = (int)__builtin_floorf(pv1 + updown) + 1;
     r.w = x1 - r.x0 + 1;
     r.h = y1 - r.y0 + 1;
-    if (!(r.w > 0 && r.h > 0 && r.w + 1 <= kMaxCols && r.h <= kMaxRows)) r.w = r.h = 0;
+    if (!(r.w > 0 && r.h > 0 && r.w + 1 <= kMaxCols && r.h <= max_rows)) r.w = r.h = 0;
     return r;
 }
 
@@ -113,24 +122,28 @@ __global__ void __launch_bounds__(256) k_tonemap_axis_tables(TonemapArgs t, TmAx
     out[(size_t)blockIdx.y * t.axis_stride + i] = e;
 }
 
-__global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
+template <int kTileH>
+__global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(TonemapArgs t) {
+    using Shape = TmShape<kTileH>;
+    constexpr int kMaxRows = Shape::kMaxRows, kPlane = kMaxRows * kTile * 3, kStageIters = (kMaxRows + 7) / 8;
+    constexpr int kA = kTileH / 16;  // pixel rows per thread: tile rows tr + 16 a
     // (s_src and s_xt are read by pass 1 only, which every thread has left before anybody commits the next stage: single buffers; s_yt is
     // read by pass 2, which overlaps the next commit: double buffer)
     __shared__ __attribute__((aligned(16))) float4 s_src[kMaxRows * kPitch];  // staged texels, fp32 rgb (w unused), edge replication applied
     __shared__ __attribute__((aligned(16))) float s_g[4 * kPlane];            // [y variant][staged row of the stage][pixel column][rgb]
-    __shared__ __attribute__((aligned(8))) AxisS s_xt[kStageMips][4][kTile], s_yt[2][kStageMips][4][kTile];
+    __shared__ __attribute__((aligned(8))) AxisS s_xt[kStageMips][4][kTile], s_yt[2][kStageMips][4][kTileH];
     __shared__ int s_bad[2][kStageMips];  // the mip cannot be staged: strict evaluation from global memory
     __shared__ Rect s_rect[6];            // the six rectangles, by threads 0..5 (six divides each: not per thread and mip)
     // base, pitch and last texel of every mip for the staging loads, whose mip differs from lane to lane (a stage's rows lie side by side):
     // indexing the kernel argument arrays per lane makes the compiler select among all their elements, ~70 instructions per load
     __shared__ uint4 s_mip[6];            // {pointer lo, pointer hi, pitch, (W - 1) | (H - 1) << 16}
-    const uint32_t bx = blockIdx.x * kTile, by = t.row_begin + blockIdx.y * kTile;
-    const uint32_t x_last = min(bx + kTile - 1, t.out_w - 1), y_last = min(by + kTile - 1, t.row_end - 1);
+    const uint32_t bx = blockIdx.x * kTile, by = t.row_begin + blockIdx.y * kTileH;
+    const uint32_t x_last = min(bx + kTile - 1, t.out_w - 1), y_last = min(by + kTileH - 1, t.row_end - 1);
     const uint32_t cp = threadIdx.x & 15u, tr = threadIdx.x >> 4;  // column pair (columns 2 cp, 2 cp + 1), tile rows tr and tr + 16
     const uint32_t nmips = min(t.num_mips, 6u);
 
     if (threadIdx.x < nmips) {
-        s_rect[threadIdx.x] = tile_rect(t, t.mip_w[threadIdx.x], t.mip_h[threadIdx.x], bx, by, x_last, y_last);
+        s_rect[threadIdx.x] = tile_rect(t, t.mip_w[threadIdx.x], t.mip_h[threadIdx.x], bx, by, x_last, y_last, kMaxRows);
         const uint64_t ptr = reinterpret_cast<uint64_t>(t.mips[threadIdx.x].ptr);
         s_mip[threadIdx.x] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), t.mips[threadIdx.x].pitch,
                                         (min(t.mip_w[threadIdx.x], 65536u) - 1u) | ((min(t.mip_h[threadIdx.x], 65536u) - 1u) << 16));
@@ -138,10 +151,14 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
     __syncthreads();
     // stages: mips [first, first + count) filtered between one pair of barriers.  A mip whose rows do not fit beside the others of its stage
     // (chains that are not half-resolution pyramids) is marked bad for this tile and evaluated strictly
-    auto stage_first_of = [](uint32_t s) { return s == 0 ? 0u : (s == 1 ? 1u : 3u); };
-    const uint32_t nstages = nmips == 0 ? 0u : (nmips == 1 ? 1u : (nmips <= 3 ? 2u : 3u));
-    auto stage_count = [&](uint32_t s) { return min(stage_first_of(s) + (s == 0 ? 1u : (s == 1 ? 2u : 3u)), nmips) - stage_first_of(s); };
+    auto stage_first_of = [](uint32_t s) __attribute__((always_inline)) { return Shape::first(s); };
+    uint32_t nstages = 0;
+    while (Shape::first(nstages) < nmips) nstages++;
+    auto stage_count = [&](uint32_t s) __attribute__((always_inline)) { return min(Shape::first(s + 1u), nmips) - Shape::first(s); };
 
+    // the thread's table entry of a mip: (axis, variant, column / row) = (tid / 128, tid / 32 % 4, tid % 32)
+    const uint32_t entry_off = (((threadIdx.x >> 7) * 4u + ((threadIdx.x >> 5) & 3u)) * t.axis_stride) +
+                               ((threadIdx.x >> 7) == 0 ? min(bx + (threadIdx.x & 31u), x_last) : min(by + (threadIdx.x & 31u), y_last));  // past the edge: the last valid one
     uint2 staged[kStageIters];
     TmAxis entry0 = {0, 0.f}, entry1 = entry0, entry2 = entry0;
     // rows of the stage's mips as they lie in s_src / s_g: rb_j = first row of mip j of the stage (rb3: one past the last); a mip that is bad
@@ -152,9 +169,14 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
     auto layout = [&](uint32_t s) __attribute__((always_inline)) {
         const uint32_t first = stage_first_of(s), cnt = stage_count(s);
         const Rect none = {0, 0, 0, 0};
-        rc0 = cnt > 0u ? s_rect[first] : none;
-        rc1 = cnt > 1u ? s_rect[first + 1u] : none;
-        rc2 = cnt > 2u ? s_rect[first + 2u] : none;
+        // (wave-uniform values, made scalar: read from LDS they would sit in vector registers and every select, add and compare on them —
+        // most of what a stage's set-up does — would be a vector instruction)
+        auto uniform_rect = [](const Rect& r) __attribute__((always_inline)) {
+            return Rect{__builtin_amdgcn_readfirstlane(r.x0), __builtin_amdgcn_readfirstlane(r.y0), __builtin_amdgcn_readfirstlane(r.w), __builtin_amdgcn_readfirstlane(r.h)};
+        };
+        rc0 = cnt > 0u ? uniform_rect(s_rect[first]) : none;
+        rc1 = cnt > 1u ? uniform_rect(s_rect[first + 1u]) : none;
+        rc2 = cnt > 2u ? uniform_rect(s_rect[first + 2u]) : none;
         rb0 = 0;
         rb1 = rc0.h;
         if (rb1 + rc1.h > kMaxRows) rc1 = none;  // does not fit beside the others: bad
@@ -181,12 +203,10 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
             const uint8_t* base = reinterpret_cast<const uint8_t*>((uint64_t)mi.x | ((uint64_t)mi.y << 32));
             staged[j] = *reinterpret_cast<const uint2*>(base + (sy * mi.z + sx8));
         }
-        // table entries: e = tid + 256 q  ->  (mip q of the stage, axis, variant, column / row)
-        const uint32_t te = threadIdx.x & (kTile - 1), tk = (threadIdx.x >> 5) & 3u, taxis = threadIdx.x >> 7;
-        const uint32_t tpos = taxis == 0 ? min(bx + te, x_last) : min(by + te, y_last);  // columns / rows past the edge re-use the last valid one
+        // table entries: the thread's (axis, variant, column / row) of the three mips of the stage
         auto load_entry = [&](uint32_t q) __attribute__((always_inline)) {
             const uint32_t m = min(first + q, nmips - 1u);
-            return t.axis_tables[(size_t)((m * 2u + taxis) * 4u + tk) * t.axis_stride + tpos];
+            return t.axis_tables[(size_t)(m * 8u) * t.axis_stride + entry_off];
         };
         entry0 = load_entry(0u);
         entry1 = load_entry(1u);
@@ -209,7 +229,7 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
                 if (taxis == 0) {
                     s_xt[q][tk][te] = {en.i - r.x0, en.f};
                     if (!(en.i >= r.x0 && en.i + 1 <= r.x0 + r.w)) s_bad[b][q] = 1;
-                } else {
+                } else if (te < (uint32_t)kTileH) {
                     s_yt[b][q][tk][te] = {(en.i - r.y0 + rbase) * (kTile * 3), en.f};
                     if (!(en.i >= r.y0 && en.i + 1 < r.y0 + r.h)) s_bad[b][q] = 1;
                 }
@@ -220,22 +240,22 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
         put_entry(2u, entry2, rc2, rb2);
     };
 
-    C3 bloom[2][2];  // [row r / r + 16][column 2 cp / 2 cp + 1]
+    C3 bloom[kA][2];  // [row r / r + 16][column 2 cp / 2 cp + 1]
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < kA; a++)
         for (int c = 0; c < 2; c++) bloom[a][c] = {0.f, 0.f, 0.f};
     const uint32_t x0p = bx + 2u * cp;
     const bool live_col[2] = {x0p < t.out_w, x0p + 1u < t.out_w};
-    const bool live_row[2] = {by + tr < t.row_end, by + tr + 16u < t.row_end};
+    bool live_row[kA];
+#pragma unroll
+    for (int a = 0; a < kA; a++) live_row[a] = by + tr + 16u * (uint32_t)a < t.row_end;
 
-    // the scene texel of the thread's four pixels: requested before anything else, so that its latency lies under the first stage
-#ifndef SAH_TM_HOIST
-#define SAH_TM_HOIST 0
-#endif
-    C3 scene_px[2][2];
+    // the scene texels of the thread's pixels are sampled at the END (hoisted to the start, their twelve registers spilled across the whole
+    // stage loop: 0.202 against 0.193 ms); one texel per pixel row is touched here so that the lines are in L2 by then
+    C3 scene_px[kA][2];
     auto sample_scene = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
+    for (int a = 0; a < kA; a++) {
         const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1u);
         const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
 #pragma unroll
@@ -246,11 +266,9 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
         }
     }
     };
-    if (SAH_TM_HOIST) {
-        sample_scene();
-    } else {  // touch the lines now (one texel per pixel row), sample at the end
+    {
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
+        for (int a = 0; a < kA; a++) {
             const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1u), x = min(x0p, t.out_w - 1);
             const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
             const int sy = min(max((int)(v * (float)t.scene_h), 0), (int)t.scene_h - 1), sx = min(max((int)(((float)x + 0.5f) / (float)t.out_w * (float)t.scene_w), 0), (int)t.scene_w - 1);
@@ -268,7 +286,8 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
         __syncthreads();  // texels and tables of stage s are in place; the previous stage's pass 2 is done with s_g
         // (rc / rb describe stage s here: stage_request(s) was the last one to run; they change when the next stage is requested below)
         const int total_rows = rb3, mr1 = rb1, mr2 = rb2;
-        const bool bad0 = cnt > 0u && s_bad[b][0] != 0, bad1 = cnt > 1u && s_bad[b][1] != 0, bad2 = cnt > 2u && s_bad[b][2] != 0;
+        const bool bad0 = cnt > 0u && __builtin_amdgcn_readfirstlane(s_bad[b][0]) != 0, bad1 = cnt > 1u && __builtin_amdgcn_readfirstlane(s_bad[b][1]) != 0,
+                   bad2 = cnt > 2u && __builtin_amdgcn_readfirstlane(s_bad[b][2]) != 0;
         {
             // pass 1: items (column pair, staged row of the stage): column pair = tid % 16, rows tid / 16 + 16 j
             for (int r = (int)tr; r < total_rows; r += 16) {
@@ -327,15 +346,15 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
             if (!(j == 0 ? bad0 : (j == 1 ? bad1 : bad2))) {
                 // pass 2: four row interpolations per pixel, two pixels at a time.  Program order of the (volatile) LDS reads: the eight set-ups,
                 // then the 24 reads of a pixel pair, then its arithmetic — three LDS round trips per mip on the thread's critical path
-                AxisS ey[2][4];
+                AxisS ey[kA][4];
 #pragma unroll
-                for (int a = 0; a < 2; a++) {
+                for (int a = 0; a < kA; a++) {
                     const uint32_t pr = min(tr + 16u * (uint32_t)a, y_last - by);  // rows past the band: the last valid one (dropped later)
 #pragma unroll
                     for (int yv = 0; yv < 4; yv++) ey[a][yv] = lds_axis(&s_yt[b][j][yv][pr]);
                 }
 #pragma unroll
-                for (int a = 0; a < 2; a++) {
+                for (int a = 0; a < kA; a++) {
                     float2 P[4][3], Q[4][3];
 #pragma unroll
                     for (int yv = 0; yv < 4; yv++) {
@@ -363,7 +382,7 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
             } else {  // (uniform over the workgroup) a rectangle that does not fit: the strict evaluation from global memory
                 const PlaneArg mp = t.mips[m];
 #pragma unroll
-                for (int a = 0; a < 2; a++)
+                for (int a = 0; a < kA; a++)
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
                         const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1), x = min(x0p + (uint32_t)c, t.out_w - 1);
@@ -375,11 +394,11 @@ __global__ void __launch_bounds__(256, 3) k_tonemap_tol(TonemapArgs t) {
     }
     const float4* code_tab = reinterpret_cast<const float4*>(t.code_table);
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
+    for (int a = 0; a < kA; a++) {
         if (!live_row[a]) continue;
         const uint32_t y = by + tr + 16u * (uint32_t)a;
         uint32_t px[2] = {0u, 0u};
-        if (!SAH_TM_HOIST && a == 0) sample_scene();
+        if (a == 0) sample_scene();
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const C3 sc = scene_px[a][c];
@@ -418,8 +437,11 @@ hipError_t launch_tonemap_axis_tables(const TonemapArgs& t, TmAxis* out, hipStre
 hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st) {
     const uint32_t rows = t.row_end - t.row_begin;
     if (rows == 0) return hipSuccess;
-    const dim3 grid((t.out_w + kTile - 1) / kTile, (rows + kTile - 1) / kTile);
-    hipLaunchKernelGGL(k_tonemap_tol, grid, dim3(256), 0, st, t);
+    const uint32_t cols = (t.out_w + kTile - 1) / kTile;
+    // 32-row tiles unless they would not fill the chip's 768 workgroup slots twice (a rank's band of a row-sharded frame: its last,
+    // partly filled round would be half the pass): then 16-row tiles, four per CU
+    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL(k_tonemap_tol<32>, dim3(cols, (rows + 31) / 32), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL(k_tonemap_tol<16>, dim3(cols, (rows + 15) / 16), dim3(256), 0, st, t);
     return hipGetLastError();
 }
 

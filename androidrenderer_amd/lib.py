@@ -21,7 +21,7 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
            "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister"]
@@ -52,6 +52,7 @@ def load():
     lib.sah_copy_scene.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     lib.sah_copy_scene_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_bloom.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
+    lib.sah_copy_scene_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)] + [C.c_uint32] * 4
     lib.sah_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32]
     lib.sah_bloom_from_mip0.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
     lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
@@ -136,6 +137,10 @@ class Context:
 
     def copy_scene(self, lit, out, row_begin=0, row_end=0):
         self._check(self.lib.sah_copy_scene_rows(self.handle, C.byref(lit), C.byref(out), row_begin, row_end))
+
+    def copy_scene_bloom_mip0(self, lit, out, chain, aa_rows=(0, 0), mip_rows=(0, 0)):
+        """Copy scene + bloom mip 0 in one pass over lit (rows of `antialiased`, rows of mip 0; (0, 0) = all)."""
+        self._check(self.lib.sah_copy_scene_bloom_mip0_rows(self.handle, C.byref(lit), C.byref(out), C.byref(chain), aa_rows[0], aa_rows[1], mip_rows[0], mip_rows[1]))
 
     def bloom(self, scene, chain):
         self._check(self.lib.sah_bloom(self.handle, C.byref(scene), C.byref(chain)))

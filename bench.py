@@ -115,7 +115,7 @@ def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope
     share = my_px / st["pixels"] if st.get("pixels") else 1.0
     hbm_frac = achieved_gbs / HBM_PEAK_GBS
     out = {
-        "bound": "hbm",
+        "bound": None,  # named below, and only when this workload has a static record to compare the HBM fraction with
         "achieved": round(achieved_gbs, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -147,7 +147,11 @@ def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope
         tf = st["flops_per_px"] * my_px / t / 1e12
         out["fp32"] = {"achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 4),
                        "flops_per_px": st["flops_per_px"], "source": "DESIGN.md §7c operator count (static)"}
-    out["bound"] = max(fracs, key=fracs.get)
+    # the binding roofline is the larger of the fractions — when there is more than the HBM one to compare: a workload without a static
+    # record (profiles/roofline_static.json) says null rather than claim "hbm" by default
+    out["bound"] = max(fracs, key=fracs.get) if len(fracs) > 1 else None
+    if out["bound"] is None:
+        out["bound_note"] = "no static counter record for this workload in profiles/roofline_static.json: only the HBM fraction is known"
     return out
 
 
@@ -180,6 +184,10 @@ def main():
                     "stream beside the lighting of the next one (as the N > 1 loop always does); every frame still completes inside the timed region")
     ap.add_argument("--strict-tonemap", action="store_true", help="chain workloads: the strict composite (codes bit-identical to the oracle) instead of "
                     "SAH_TONEMAP_TOLERANCE_1CODE (within one R8G8B8A8 code of it: north_star's tolerance for the final image)")
+    ap.add_argument("--synth-device", choices=["cuda", "cpu"], default="cuda", help="where the synthetic inputs are generated (same values either way).  cpu: no torch "
+                    "kernel is launched before the timed passes — for rocprofv3 --pmc runs of the 8K workloads, whose input synthesis on the GPU dies inside the "
+                    "profiler's dispatch interception (profiles/README.md, round 4)")
+    ap.add_argument("--no-light-stats", action="store_true", help="light workloads: skip the lights-per-tile / per-pixel statistics (torch kernels on full-frame tensors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
     args = ap.parse_args()
@@ -253,7 +261,7 @@ def main():
     if n_lights:
         lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, wl["radius"], seed=8)
     fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
-                              synth_device=str(dev), shadow=wl.get("shadow", "noise"))
+                              synth_device=str(dev) if args.synth_device == "cuda" else "cpu", shadow=wl.get("shadow", "noise"))
     fr.lpv_generation = 0 if args.repack_lpv else 1
     fr.probe_generation = 0 if args.repack_lpv else 1  # (the traced workload folds probes every step: sah_probe_update drops the copy anyway)
     d_arr = fr.device_arrays(dev)
@@ -764,7 +772,7 @@ def main():
         if failure:
             out["error"] = failure
             out["measured_but_invalid_Mpixels_per_s"] = round(value, 1)
-        if n_lights:
+        if n_lights and not args.no_light_stats:
             out["config"].update(light_stats(torch, fr, d_arr, lights, dev))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)

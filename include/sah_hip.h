@@ -249,6 +249,12 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* desc);
 int sah_copy_scene(sah_ctx* ctx, const sah_plane* lit, const sah_plane* antialiased);
 /* Rows [row_begin, row_end) of the same copy (0, 0 = all); output row j reads lit rows j - 1 .. j + 1. */
 int sah_copy_scene_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* antialiased, uint32_t row_begin, uint32_t row_end);
+/* "Copy scene" and the first dispatch of Bloomer::fill_bloom_tex (scene_renderer.cpp:502-527 then bloomer.cpp:50-72) as ONE pass over lit:
+ * rows [aa_row_begin, aa_row_end) of `antialiased` and rows [mip_row_begin, mip_row_end) of bloom->mips[0], each exactly what
+ * sah_copy_scene_rows followed by sah_bloom_mip0_rows writes ((0, 0) = all rows).  The mip rows' sources — antialiased rows
+ * 2 * mip_row_begin - 3 .. 2 * mip_row_end + 2 — need NOT be among the rows asked for: they are computed from lit either way. */
+int sah_copy_scene_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* lit, const sah_plane* antialiased, const sah_mipchain* bloom, uint32_t aa_row_begin,
+                                   uint32_t aa_row_end, uint32_t mip_row_begin, uint32_t mip_row_end);
 
 /* Bloomer::fill_bloom_tex — RenderCore/render/bloomer.hpp:15, bloomer.cpp:38-262 */
 int sah_bloom(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom);

@@ -3,6 +3,8 @@ this file runs).  Both ranks share GPU 0 — RCCL refuses two ranks on one devic
 the direct exchange backend: once step by step, then five frames through PipelinedChain (two work streams, a side stream, two frames
 in flight).  Handles travel between the ranks over a gloo process group.  The final images go to <out_dir>/rank<r>_*.npy.
 
+With a sixth argument "ipc2" (test_two_rank_chain_direct_exchange_across_devices, needs two GPUs) the direct exchange runs one rank per
+GPU: the stores then cross a link, and the peer's consumer kernels read them from another device's memory system.
 With a sixth argument "rccl" (test_two_rank_chain_through_rccl, needs two GPUs) the same frames run one rank per GPU through the library's
 RCCL communicator instead — the parent communicator for bloom mip 0, the reversed one (ncclCommSplit, or grouped send / recv under
 SAH_COMM_NO_SPLIT=1, which the parent test sets in the environment) for the final image."""
@@ -18,6 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, height, out_dir, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
     rccl = len(sys.argv) > 6 and sys.argv[6] == "rccl"
+    two_devices = rccl or (len(sys.argv) > 6 and sys.argv[6] == "ipc2")  # "ipc2": the direct exchange, one rank per GPU (two GPUs)
     import torch
     import torch.distributed as dist
     from androidrenderer_amd import _abi, chain, lib
@@ -30,7 +33,7 @@ def main():
         dist.all_gather_object(out, b)
         return out
 
-    device = rank if rccl else 0
+    device = rank if two_devices else 0
     torch.cuda.set_device(device)
     comm_id = None
     if rccl:

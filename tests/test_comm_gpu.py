@@ -109,6 +109,17 @@ def test_two_rank_chain_through_rccl(tmp_path, no_split):
     _check_chain_children(tmp_path, 97)
 
 
+def test_two_rank_chain_direct_exchange_across_devices(tmp_path):
+    """The direct (IPC) exchange with one rank per GPU — what the one-GPU test cannot show: that a peer DEVICE's stores into this rank's
+    buffers are visible to its next kernels after the counter handshake (same-device peers share an L2).  The first box with two GPUs
+    decides it; RCCL stays bench.py's default until then."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round-end 8-GPU node)")
+    _run_chain_children(tmp_path, 97, ["ipc2"])
+    _check_chain_children(tmp_path, 97)
+
+
 def _run_chain_children(tmp_path, height, extra, extra_env=None):
     port = 29300 + (os.getpid() % 500)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))

@@ -123,6 +123,67 @@ def test_lpv_propagate_and_clear(hip_ctx, steps):
     assert all(int(t.abs().max()) == 0 for t in a_t) and int(b_t[0].abs().max()) == 0
 
 
+@pytest.mark.parametrize("size", [(256, 144), (250, 130), (333, 187), (64, 36), (9, 5), (2048, 96), (97, 512), (1920, 1080)])
+def test_copy_scene_and_bloom_mip0_in_one_pass(hip_ctx, size):
+    """sah_copy_scene_bloom_mip0_rows == sah_copy_scene_rows followed by sah_bloom_mip0_rows == the oracle, bit for bit: whole frames (odd
+    extents: the last tile column / row owns the odd texels; extents the fused form does not take fall back to the two passes), non-finite
+    and negative texels included."""
+    import torch
+    w, h = size
+    o = util.oracle()
+    scene = synth.hdr_scene(w, h, seed=31)
+    f = scene.reshape(h, w, 4)
+    rng = np.random.default_rng(5)
+    ys, xs = rng.integers(0, h, 60), rng.integers(0, w, 60)
+    f[ys[:20], xs[:20], :3] *= np.float16(-1.0)
+    f[ys[20:40], xs[20:40], 0] = np.float16(np.inf)
+    f[ys[40:], xs[40:], 1] = np.float16(np.nan)
+    lit = scene.view(np.uint16)
+    aa_ref = np.zeros((h, w, 4), np.uint16)
+    mips_ref = _mips_np(w, h, 1)
+    assert o.orc_copy_scene(C.byref(images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(aa_ref, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    assert o.orc_bloom(C.byref(images.plane(aa_ref, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips_ref))) == 0
+    lit_t = util.to_torch(lit)
+    aa_t = torch.full((h, w, 4), 0x3C00, dtype=torch.int16, device="cuda")
+    mip_t = [torch.full(mips_ref[0].shape, 0x3C00, dtype=torch.int16, device="cuda")]
+    hip_ctx.copy_scene_bloom_mip0(images.plane(lit_t, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(aa_t, _abi.FORMAT_R16G16B16A16_SFLOAT), images.mipchain(mip_t))
+    torch.cuda.synchronize()
+    assert np.array_equal(util.from_torch(aa_t, np.uint16), aa_ref)
+    assert np.array_equal(util.from_torch(mip_t[0], np.uint16), mips_ref[0])
+
+
+def test_copy_scene_and_bloom_mip0_in_one_pass_row_ranges(hip_ctx):
+    """Row-sharded form: antialiased rows and mip 0 rows given separately — rows beyond the mip rows' sources are copied by plain launches,
+    rows not asked for keep their contents, and any partition gives the unsharded result."""
+    import torch
+    w, h = 300, 170
+    o = util.oracle()
+    lit = synth.hdr_scene(w, h, seed=33).view(np.uint16)
+    aa_ref = np.zeros((h, w, 4), np.uint16)
+    mips_ref = _mips_np(w, h, 1)
+    assert o.orc_copy_scene(C.byref(images.plane(lit, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(aa_ref, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    assert o.orc_bloom(C.byref(images.plane(aa_ref, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.mipchain(mips_ref))) == 0
+    lit_t = util.to_torch(lit)
+    lp = images.plane(lit_t, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    sentinel = 0x7E01
+    for parts in ([((0, 170), (0, 85))], [((0, 24), (0, 11)), ((20, 25), (11, 12)), ((21, 121), (12, 60)), ((119, 170), (60, 85))],
+                  [((60, 110), (40, 45))], [((75, 100), (40, 45))], [((0, 170), (80, 85))], [((5, 6), (0, 85))]):
+        aa_t = torch.full((h, w, 4), sentinel, dtype=torch.int16, device="cuda")
+        mip_t = [torch.full(mips_ref[0].shape, sentinel, dtype=torch.int16, device="cuda")]
+        ap, mc = images.plane(aa_t, _abi.FORMAT_R16G16B16A16_SFLOAT), images.mipchain(mip_t)
+        aa_rows, mip_rows = np.zeros(h, bool), np.zeros(mips_ref[0].shape[0], bool)
+        for (a0, a1), (m0, m1) in parts:
+            hip_ctx.copy_scene_bloom_mip0(lp, ap, mc, (a0, a1), (m0, m1))
+            aa_rows[a0:a1] = True
+            mip_rows[m0:m1] = True
+        torch.cuda.synchronize()
+        aa, mip = util.from_torch(aa_t, np.uint16), util.from_torch(mip_t[0], np.uint16)
+        assert np.array_equal(aa[aa_rows], aa_ref[aa_rows]), parts
+        assert (aa[~aa_rows] == sentinel).all(), parts
+        assert np.array_equal(mip[mip_rows], mips_ref[0][mip_rows]), parts
+        assert (mip[~mip_rows] == sentinel).all(), parts
+
+
 def test_bloom_in_two_steps_equals_bloom(hip_ctx):
     """sah_bloom_mip0_rows over any partition of mip 0's rows + sah_bloom_from_mip0 == sah_bloom (the row-sharded pyramid)."""
     import torch

@@ -1,5 +1,6 @@
 """One rank's compute of the sharded chain at N ranks, emulated on one GPU without exchanges: one stream against two streams
-(A(i+1) = lighting + copy + mip-0 rows beside B(i) = mips 1-5 + tonemap rows).  usage: chain_two_streams.py [world] [rank]"""
+(A(i+1) = lighting + copy + mip-0 rows beside B(i) = mips 1-5 + tonemap rows).  usage: chain_two_streams.py [world] [rank] [--strict-tonemap]
+(the tonemap runs in tolerance mode, as bench.py's chain workloads do, unless --strict-tonemap is given)"""
 import os
 import sys
 import time
@@ -9,8 +10,10 @@ import torch
 
 from androidrenderer_amd import _abi, chain, frame, lib
 
-world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+strict = "--strict-tonemap" in sys.argv
+argv = [a for a in sys.argv if not a.startswith("--")]
+world = int(argv[1]) if len(argv) > 1 else 8
+rank = int(argv[2]) if len(argv) > 2 else 3
 W, H = 3840, 2160
 fr = frame.LightingInputs(W, H, seed=2, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_CACHE, flavour="atrium", shadowmap_res=4096, synth_device="cuda")
 dev = fr.device_arrays("cuda")
@@ -18,7 +21,7 @@ ctx = lib.Context(0)
 s1 = torch.cuda.current_stream()
 s2 = torch.cuda.Stream()
 ctx.set_stream(s1.cuda_stream)
-sets = [chain.ShardedChain(ctx, fr, dev, rank, world) for _ in range(2)]
+sets = [chain.ShardedChain(ctx, fr, dev, rank, world, tonemap_flags=0 if strict else _abi.TONEMAP_TOLERANCE_1CODE) for _ in range(2)]
 N = 300
 
 

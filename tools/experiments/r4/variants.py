@@ -96,6 +96,19 @@ VARIANTS["fast_lpv_first_no_vote1"] = (["lighting.hip"], VARIANTS["fast_lpv_firs
 
 VARIANTS["tm_hoist"] = (["tonemap_tol.hip"], [("tonemap_tol.hip", "#define SAH_TM_HOIST 0", "#define SAH_TM_HOIST 1")])
 
+# ---- a9 light loop: what the builder-owned spec choices cost (results differ from the spec: timing only) ----
+VARIANTS["lights_pow5_f32"] = (["lighting_tiled.hip"], [
+    ("numerics.hpp", "    const Fn light_scatter = one + (f90 - one) * npow5(nclamp(one - NoL, zero, one));",
+     "    const Fn ls_u = nclamp(one - NoL, zero, one), ls_u2 = ls_u * ls_u;\n    const Fn light_scatter = one + (f90 - one) * (ls_u2 * ls_u2 * ls_u);"),
+    ("numerics.hpp", "    const F3 Fv = F_Schlick(VoH, p.f0, one);\n    // V_SmithGGXCorrelated\n    const Fn argL = (-NoL * p.a2 + NoL) * NoL + p.a2;",
+     "    const Fn fv_u = nclamp(one - VoH, zero, one), fv_u2 = fv_u * fv_u, fv_p = fv_u2 * fv_u2 * fv_u;\n"
+     "    const F3 Fv = {p.f0.x + (one - p.f0.x) * fv_p, p.f0.y + (one - p.f0.y) * fv_p, p.f0.z + (one - p.f0.z) * fv_p};\n"
+     "    // V_SmithGGXCorrelated\n    const Fn argL = (-NoL * p.a2 + NoL) * NoL + p.a2;")])
+VARIANTS["lights_inv_r"] = (["lighting_tiled.hip"], [("lighting_gi_ext.hpp", "    const Fn xr = Fn(div_nr(dist.v, pl.radius));", "    const Fn xr = dist * Fn(__builtin_amdgcn_rcpf(pl.radius));")])
+VARIANTS["lights_both"] = (["lighting_tiled.hip"], VARIANTS["lights_pow5_f32"][1] + VARIANTS["lights_inv_r"][1])
+
+VARIANTS["bloom_big_tiles_mip1"] = (["post.hip"], [("post.hip", "if ((uint64_t)cols * ((rows + 15) / 16) >= 1024) {", "if ((uint64_t)cols * ((rows + 15) / 16) >= 500) {")])
+
 # compound variants
 VARIANTS["tiled_skeleton"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_cheb"][1] + VARIANTS["tiled_no_depth_dir"][1] + VARIANTS["tiled_no_depth_lookup"][1] +
                               VARIANTS["tiled_no_irr_taps"][1])
