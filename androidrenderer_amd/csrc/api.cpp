@@ -19,7 +19,7 @@
 namespace sah {
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                            const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st);
-hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, hipStream_t st);
+hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, uint32_t row_stride, hipStream_t st);
 hipError_t launch_probe_irr_unpack(const VolumeArg& src, uint8_t* dst, hipStream_t st);
 hipError_t launch_copy_scene(const PlaneArg& src, uint32_t sw, uint32_t sh, const PlaneArg& dst, uint32_t dw, uint32_t dh, uint32_t row_begin,
                              uint32_t row_end, hipStream_t st);
@@ -578,34 +578,37 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             }
             fast.pack_serial = ctx->lpv_pack_serial;
         }
-        // per-column numerators of the view-space x (4 IEEE divides per thread otherwise): a function of the width, the render resolution
-        // and two entries of the inverse projection — rebuilt when one of them changes
-        if (ppt == 4 && (sun_mode != SAH_SHADOW_MODE_OFF || gi_kind == SAH_GI_LPV)) {
-            const float key[3] = {a.res[0], fast.p0, fast.p12};
-            const uint32_t stride = (W + 63u) & ~63u;
-            if (ctx->colx_capacity < 2 * stride) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->colx_table) (void)hipFree(ctx->colx_table);
-                ctx->colx_table = nullptr;
-                ctx->colx_capacity = 0;
-                HIP_TRY(ctx, hipMalloc((void**)&ctx->colx_table, (size_t)2 * stride * sizeof(float)));
-                ctx->colx_capacity = 2 * stride;
-                ctx->colx_width = 0;
-            }
-            if (ctx->colx_width != W || memcmp(key, ctx->colx_key, sizeof(key)) != 0) {
-                HIP_TRY(ctx, launch_colx_table(a, fast, ctx->colx_table, stride, ctx->stream));
-                ctx->colx_width = W;
-                memcpy(ctx->colx_key, key, sizeof(key));
-            }
-            fast.colx_tab = ctx->colx_table;
-            fast.colx_stride = stride;
-        }
         fast.sky_enabled = sky.enabled;
         {  // thread index -> (row, group in row) by a multiply-high: exact while gid * groups_per_row < 2^32 (magic = floor(2^32 / d) + 1)
             const uint64_t gpr = W / (uint32_t)ppt, threads = (gpr * (r1 - r0) + 255) / 256 * 256;
             fast.row_magic = (gpr >= 2 && threads * gpr < (1ull << 32)) ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u;
         }
         fast.state = ctx->state;
+    }
+    // per-column numerators of the view-space x and per-row ones of y (IEEE divides per thread / per pixel otherwise; the tiled kernel reads
+    // them too): a function of the extent, the render resolution
+    // and two entries of the inverse projection — rebuilt when one of them changes
+    if ((use_fast && ppt == 4 && (sun_mode != SAH_SHADOW_MODE_OFF || gi_kind == SAH_GI_LPV)) || tiled_fast_geom) {
+        const float key[7] = {a.res[0], fast.p0, fast.p12, a.res[1], fast.p5, fast.p13, (float)H};
+        const uint32_t stride = (W + 63u) & ~63u, row_stride = (H + 63u) & ~63u;
+        const uint32_t need = 2 * stride + 2 * row_stride;
+        if (ctx->colx_capacity < need) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->colx_table) (void)hipFree(ctx->colx_table);
+            ctx->colx_table = nullptr;
+            ctx->colx_capacity = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->colx_table, (size_t)need * sizeof(float)));
+            ctx->colx_capacity = need;
+            ctx->colx_width = 0;
+        }
+        if (ctx->colx_width != W || memcmp(key, ctx->colx_key, sizeof(key)) != 0) {
+            HIP_TRY(ctx, launch_colx_table(a, fast, ctx->colx_table, stride, row_stride, ctx->stream));
+            ctx->colx_width = W;
+            memcpy(ctx->colx_key, key, sizeof(key));
+        }
+        fast.colx_tab = ctx->colx_table;
+        fast.colx_stride = stride;
+        fast.rowy_stride = row_stride;
     }
     HIP_TRY(ctx, launch_lighting(a, csm, lpv, cache, rtgi, sky, (use_fast || tiled_fast_geom) ? &fast : nullptr, (int)sun_mode, (int)gi_kind, ppt,
                                  (d->flags & SAH_LIGHTING_BRUTE_FORCE_LIGHTS) != 0, ctx->stream));

@@ -54,7 +54,7 @@ struct sah_ctx {
     sah::VolumeArg lpv_pack_source[3] = {};
     float* colx_table = nullptr;       // device: per-column view-space x numerators of the fast kernel, two flavours (lighting.hip: k_colx_table)
     uint32_t colx_capacity = 0, colx_width = 0;
-    float colx_key[3] = {};            // render_resolution.x, p0, p12 the table was built for
+    float colx_key[7] = {};            // render_resolution, p0, p12, p5, p13, height the tables were built for
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds + the first-level bucket table (api_post.cpp)

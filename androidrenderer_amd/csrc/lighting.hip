@@ -178,11 +178,26 @@ SAH_DEV float colx_slang_of(const LightingArgs& a, const FastArgs& f, uint32_t x
     return (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
 }
 // the same values for every column, once per (width, render resolution, p0, p12): the kernel then loads PPT of them instead of dividing
-__global__ void __launch_bounds__(256) k_colx_table(const LightingArgs a, const FastArgs f, float* out, uint32_t stride) {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    if (x >= a.width) return;
-    out[x] = colx_glsl_of(a, f, x);
-    out[stride + x] = colx_slang_of(a, f, x);
+// ... and the per-row numerators of the view-space y (vs.y = p5 * ndc.y + p13), rows [0, height): at out + 2 * stride (GLSL) and
+// out + 2 * stride + row_stride (Slang) — two IEEE divides per THREAD otherwise, which at four pixels per thread is 8 instructions per pixel
+SAH_DEV float rowy_glsl_of(const LightingArgs& a, const FastArgs& f, uint32_t y) {
+    const Fn ty = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
+    return (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+}
+SAH_DEV float rowy_slang_of(const LightingArgs& a, const FastArgs& f, uint32_t y) {
+    const Fn ty = (Fn((float)y) + Fn(0.5f)) / Fn(a.res[1]);
+    return (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+}
+__global__ void __launch_bounds__(256) k_colx_table(const LightingArgs a, const FastArgs f, float* out, uint32_t stride, uint32_t row_stride) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < a.width) {
+        out[i] = colx_glsl_of(a, f, i);
+        out[stride + i] = colx_slang_of(a, f, i);
+    }
+    if (i < a.height) {
+        out[2u * stride + i] = rowy_glsl_of(a, f, i);
+        out[2u * stride + row_stride + i] = rowy_slang_of(a, f, i);
+    }
 }
 
 constexpr uint32_t kSkyRatio = 4;  // surface workgroups per sky workgroup (1, 2, 8, 16 measured worse: DESIGN.md §5 "Deferred pixels ... and the sky")
@@ -274,11 +289,16 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
     }
     __syncthreads();
 
-    // per-row / per-column terms of the view-space position (two texcoord conventions, see lighting_common.hpp)
-    const Fn ty_g = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
-    const float rowy_glsl = (Fn(f.p5) * (ty_g * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
-    const Fn ty_s = (Fn((float)y) + Fn(0.5f)) / Fn(a.res[1]);
-    const float rowy_slang = (Fn(f.p5) * (ty_s * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+    // per-row / per-column terms of the view-space position (two texcoord conventions, see lighting_common.hpp): from the table where
+    // the host has built one (uniform branch), else computed
+    float rowy_glsl = 0.f, rowy_slang = 0.f;
+    if (f.colx_tab) {
+        if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) rowy_glsl = f.colx_tab[2u * f.colx_stride + y];
+        if (SUN == SAH_SHADOW_MODE_RT) rowy_slang = f.colx_tab[2u * f.colx_stride + f.rowy_stride + y];
+    } else {
+        if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) rowy_glsl = rowy_glsl_of(a, f, y);
+        if (SUN == SAH_SHADOW_MODE_RT) rowy_slang = rowy_slang_of(a, f, y);
+    }
 
     uint32_t out[2 * PPT];
     uint32_t deferred_mask = 0, sky_mask = 0;
@@ -325,15 +345,18 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
     // the thread; the order inside a segment is irrelevant.  (Sky pixels are not listed: the sky workgroups find them by their depth.)
     const uint32_t seg = gid >> 6, lane = threadIdx.x & 63u;
     uint32_t front = 0;
-    uint8_t* seg_codes = f.seg_list + (size_t)seg * f.seg_stride;
+    const uint32_t listed = SKY ? deferred_mask & ~sky_mask : deferred_mask;
+    if (__any(listed != 0u)) {  // (a wave of a coherent frame lists nothing: one vote instead of PPT ballots)
+        uint8_t* seg_codes = f.seg_list + (size_t)seg * f.seg_stride;
 #pragma unroll
-    for (int i = 0; i < PPT; i++) {
-        const bool mine = ((deferred_mask >> i) & 1u) && !(SKY && ((sky_mask >> i) & 1u));
-        const uint64_t m = __ballot(mine);
-        if (m) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (mine) seg_codes[front + before] = (uint8_t)(lane * PPT + (uint32_t)i);
-            front += (uint32_t)__builtin_popcountll(m);
+        for (int i = 0; i < PPT; i++) {
+            const bool mine = (listed >> i) & 1u;
+            const uint64_t m = __ballot(mine);
+            if (m) {
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (mine) seg_codes[front + before] = (uint8_t)(lane * PPT + (uint32_t)i);
+                front += (uint32_t)__builtin_popcountll(m);
+            }
         }
     }
     if (lane == 0 && seg < f.num_segments) f.seg_count[seg] = (uint16_t)front;
@@ -392,8 +415,8 @@ static hipError_t launch_gi(const LightingArgs& a, const CsmArgs& csm, const Lpv
     }
 }
 
-hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, hipStream_t st) {
-    hipLaunchKernelGGL(k_colx_table, dim3((a.width + 255u) / 256u), dim3(256), 0, st, a, f, out, stride);
+hipError_t launch_colx_table(const LightingArgs& a, const FastArgs& f, float* out, uint32_t stride, uint32_t row_stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_colx_table, dim3((max(a.width, a.height) + 255u) / 256u), dim3(256), 0, st, a, f, out, stride, row_stride);
     return hipGetLastError();
 }
 

@@ -95,8 +95,18 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         if (fast_geom) {
             const float dn = (si.normal[0] * si.normal[0] + si.normal[1] * si.normal[1]) + si.normal[2] * si.normal[2];
             geom_ok = surface && finite_f(p.depth) && dn > 0.f && finite_f(dn);
-            const Fn tx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]), ty = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
-            const float colx_glsl = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v, rowy_glsl = (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+            // (the per-column / per-row numerators come from the context's tables — api.cpp builds them for this kernel too; clamped
+            //  indices: the threads of a partial tile read a valid entry)
+            const uint32_t xt = min(x, a.width - 1u), yt = min(y, a.height - 1u);
+            float colx_glsl, rowy_glsl;
+            if (f.colx_tab) {
+                colx_glsl = f.colx_tab[xt];
+                rowy_glsl = f.colx_tab[2u * f.colx_stride + yt];
+            } else {
+                const Fn tx = (Fn((float)x + 0.5f) + Fn(0.5f)) / Fn(a.res[0]), ty = (Fn((float)y + 0.5f) + Fn(0.5f)) / Fn(a.res[1]);
+                colx_glsl = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+                rowy_glsl = (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+            }
             g = fast_geometry(a, f, colx_glsl, rowy_glsl, p.depth, si, dn, s_lut, geom_ok);
         }
         s.base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
@@ -268,8 +278,16 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         // within 2^+-40), the general form for the pixels outside them
         bool hot = false;
         if (fast_geom && f.pos_div_nr) {
-            const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]), ty = (Fn((float)y) + Fn(0.5f)) / Fn(a.res[1]);
-            const float colx = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v, rowy = (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+            const uint32_t xt = min(x, a.width - 1u), yt = min(y, a.height - 1u);
+            float colx, rowy;
+            if (f.colx_tab) {
+                colx = f.colx_tab[f.colx_stride + xt];
+                rowy = f.colx_tab[2u * f.colx_stride + f.rowy_stride + yt];
+            } else {
+                const Fn tx = (Fn((float)x) + Fn(0.5f)) / Fn(a.res[0]), ty = (Fn((float)y) + Fn(0.5f)) / Fn(a.res[1]);
+                colx = (Fn(f.p0) * (tx * Fn(2.0f) - Fn(1.0f)) + Fn(f.p12)).v;
+                rowy = (Fn(f.p5) * (ty * Fn(2.0f) - Fn(1.0f)) + Fn(f.p13)).v;
+            }
             hot = surface && finite_f(p.depth);
             const FastGeom fg = fast_geometry(a, f, colx, rowy, p.depth, si, 1.0f, s_lut, hot);  // (its fp32 normal is not used: dn = 1)
             sg.s.base_color = {Hn(si.color[0]), Hn(si.color[1]), Hn(si.color[2])};

@@ -99,6 +99,7 @@ struct FastArgs {
     uint32_t repack;       // 1: this call rebuilds the gather copy first
     const float* colx_tab; // per-column view-space x numerators (k_colx_table): [0, width) the GLSL flavour, [colx_stride, ..) the Slang one; or null
     uint32_t colx_stride;
+    uint32_t rowy_stride;  // per-row numerators of the view-space y behind the two column tables: [2 * colx_stride, ..) GLSL, [2 * colx_stride + rowy_stride, ..) Slang
     FrameState* state;
     // Deferred pixels, without atomics: the wave that shades thread groups [64 s, 64 s + 64) owns segment s — kSegSize(PPT) byte codes
     // (lane * PPT + pixel) at seg_list + s * seg_stride — general pixels from the front, sky pixels (depth == 0) from the back — and
