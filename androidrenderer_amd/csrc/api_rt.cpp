@@ -59,6 +59,13 @@ int sah_rt_set_rows(sah_ctx* ctx, uint32_t row_begin, uint32_t row_end) {
 }
 
 
+int sah_rt_set_bounces(sah_ctx* ctx, uint32_t num_bounces) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (num_bounces > (uint32_t)sah::kRtMaxBounces) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "at most %d bounces (asked for %u)", sah::kRtMaxBounces, num_bounces);
+    ctx->rt.num_bounces = num_bounces;
+    return SAH_OK;
+}
+
 int sah_rt_build(sah_ctx* ctx, const sah_scene_geometry* scene, uint32_t* stats) {
     SAH_RANGE();
     using namespace sah;
@@ -250,6 +257,7 @@ static int fill_gi_args(sah_ctx* ctx, const sah_sun_light_constants* sun, const 
     for (int i = 0; i < 3; i++) g->sun_color[i] = sun->color[i];
     g->tan_size = sun->direction_and_tan_size[3];
     g->noise = parg(noise);
+    g->num_bounces = ctx->rt.num_bounces;
     // GI miss stage: get_sky_color(WorldRayDirection(), sun_light.direction_and_tan_size.xyz, ...) — the direction as stored (sky_unified.slang:229)
     const float sun_dir[3] = {sun->direction_and_tan_size[0], sun->direction_and_tan_size[1], sun->direction_and_tan_size[2]};
     if (!fill_sky_args(*sky, sun_dir, &g->sky)) return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "sky LUTs must be RGBA16F");

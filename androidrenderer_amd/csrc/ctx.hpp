@@ -77,6 +77,7 @@ struct sah_ctx {
         sah::RtScene scene = {};
         bool built = false;
         uint32_t row_begin = 0, row_end = 0;  // sah_rt_set_rows: the output rows the per-pixel ray generators write ((0, 0) = all)
+        uint32_t num_bounces = 0;             // sah_rt_set_bounces: remaining_bounces of the GI generators' rays
     } rt;
     struct IpcState {                  // direct exchange (api_ipc.cpp): mailboxes and peer mappings
         bool open = false, connected = false;

@@ -22,6 +22,10 @@
 namespace sah {
 namespace {
 
+SAH_DEV bool finite3r(float a, float b, float c) {
+    const float inf = __builtin_inff();
+    return __builtin_fabsf(a) < inf && __builtin_fabsf(b) < inf && __builtin_fabsf(c) < inf;
+}
 SAH_DEV bool finite3(const float v[3]) {
     return __builtin_fabsf(v[0]) < __builtin_inff() && __builtin_fabsf(v[1]) < __builtin_inff() && __builtin_fabsf(v[2]) < __builtin_inff();
 }
@@ -795,6 +799,8 @@ struct Closest {
     Hit h;
     uint32_t tri;  // index into bvh.tris
 };
+// (CULL_NON_OPAQUE / CULL_BACK: the flags of the bounce rays of the GI hit stage, gltf_basic_pbr.slang:498-506)
+template <bool CULL_NON_OPAQUE = false, bool CULL_BACK = false>
 SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv, Ray r) {
     Closest best;
     best.hit = false;
@@ -828,7 +834,8 @@ SAH_DEV Closest closest_hit(const RtBvh& bvh, const RtScene& sc, const Trav& tv,
             if (woop(full, tr, h)) {
                 const bool better = !best.hit || h.t < best.h.t ||
                                     (h.t == best.h.t && (tr.primitive < best_prim || (tr.primitive == best_prim && tr.triangle < best_tri)));
-                if (better && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h))) {
+                const bool culled = (CULL_NON_OPAQUE && (tr.flags & 1u)) || (CULL_BACK && !h.front);
+                if (better && !culled && (!(tr.flags & 1u) || cutout_accepts(sc, tr, h))) {
                     best.hit = true;
                     best.h = h;
                     best.tri = node;
@@ -853,11 +860,15 @@ struct GiPayload {
 
 // TraceRay(rtas, RAY_FLAG_NONE, 0xFF, RAY_TYPE_GI, ...) with remaining_bounces == 0: closest-hit stage of gltf_basic_pbr.slang:345-470 or the
 // GI miss stage of sky_unified.slang:227-230.  (dx, dy) = DispatchRaysIndex().xy
-SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const GiArgs& g, const Ray& r, uint32_t dx, uint32_t dy) {
+// MAXB: how deep the bounce branch of the hit stage (gltf_basic_pbr.slang:481-517) is instantiated; `remaining` = payload.remaining_bounces
+// (<= MAXB).  The reference's generators trace with 0 (they never forward their num_bounces push constant: the branch is dead there); a
+// context may ask for up to 2 (sah_rt_set_bounces).  BOUNCE: this ray IS a bounce ray (RAY_FLAG_CULL_NON_OPAQUE | CULL_BACK_FACING_TRIANGLES).
+template <int MAXB = 0, bool BOUNCE = false>
+SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, const GiArgs& g, const Ray& r, uint32_t dx, uint32_t dy, uint32_t remaining = 0u) {
     GiPayload pay;
     pay.irradiance = F3(Fn(0.f));
     pay.ray_distance = Fn(0.f);
-    const Closest c = closest_hit(bvh, sc, tv, r);
+    const Closest c = closest_hit<BOUNCE, BOUNCE>(bvh, sc, tv, r);
     if (!c.hit) {
         // (a ray with a non-finite component reaches no stage at all: the payload stays zero)
         if (r.finite) pay.irradiance = sky_color(g.sky, F3{Fn(r.d[0]), Fn(r.d[1]), Fn(r.d[2])});
@@ -926,6 +937,21 @@ SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, 
     irr = irr + to_f(emission);
     pay.irradiance = irr;
     pay.ray_distance = Fn(c.h.t);
+    if constexpr (MAXB > 0) {
+        // (a back-face hit is zeroed below whatever the bounce brings: its bounce ray is not traced)
+        if (remaining > 0u && c.h.front) {
+            F3 dir = load_noise(g.noise, sc.luts, dx % 128u, dy % 128u);  // the launch index's noise texel, at every depth
+            if (dot(to_f(s.normal), dir).v < 0.f) dir = dir * Fn(-1.0f);
+            const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
+            const GiPayload next = trace_gi<MAXB - 1, true>(bvh, sc, tv, g, make_ray(loc, d, 0.05f, 100000.0f), dx, dy, remaining - 1u);
+            const H3 dh = {Hn(dir.x.v), Hn(dir.y.v), Hn(dir.z.v)};
+            const H3 bounce_brdf = Fd(s, dh, s.normal);  // brdf(surface, bounce_ray.Direction, surface.normal)
+            const Hn bounce_ndotl = Hn(nclamp(dot(dir, to_f(s.normal)), Fn(0.f), Fn(1.f)).v);
+            const F3 radiance = to_f(bounce_brdf * bounce_ndotl) * next.irradiance;  // half * half3, then * float3
+            const bool finite = finite3r(radiance.x.v, radiance.y.v, radiance.z.v);  // !any(isnan) && !any(isinf)
+            if (finite) pay.irradiance = pay.irradiance + radiance;
+        }
+    }
     if (!c.h.front) {  // HIT_KIND_TRIANGLE_BACK_FACE
         pay.ray_distance = pay.ray_distance * Fn(-1.0f);
         pay.irradiance = F3(Fn(0.f));
@@ -991,6 +1017,7 @@ SAH_DEV void tile_pixel(uint32_t t, uint32_t row_begin, uint32_t& x, uint32_t& y
 
 // probe_tracing.rt.slang:39-106: thread (tx, ty, probe) of dispatch_rays({20, 20, num_probes}); a workgroup takes 256 consecutive rays
 // of the dispatch and re-deals them by direction (a probe's 400 rays cover the sphere)
+template <int MAXB>
 __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[kRtMaxLevels];
     __shared__ DealLds s_deal;
@@ -1031,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, con
     Fn ray_distance = Fn(8192.f);
     if (cascade < 3u) ray_distance = Fn(c.spacing[cascade + 1u]) * Fn(4.f);
     const Ray r = make_ray(o, d, 0.05f, ray_distance.v);
-    GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, tx, ty);
+    GiPayload pay = trace_gi<MAXB>(bvh, sc, tv, a.gi, r, tx, ty, MAXB ? a.gi.num_bounces : 0u);
     if (pay.ray_distance.v == 0.f) {
         if (cascade + 1u < 4u) pay.irradiance = sample_cascade(c, origin + dir * ray_distance, dir, cascade + 1u);
         else pay.irradiance = pay.irradiance * Fn(10.f);
@@ -1048,6 +1075,7 @@ __global__ __launch_bounds__(256) void k_probe_trace(const ProbeTraceArgs a, con
 }
 
 // rtgi.rt.slang:56-110
+template <int MAXB>
 __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const RtBvh bvh, const RtScene sc) {
     __shared__ uint32_t s_levels[kRtMaxLevels];
     __shared__ DealLds s_deal;
@@ -1074,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_rtgi_trace(const RtgiTraceArgs a, const
     if (!deal_rays(s_deal, has_ray, o, d, src)) return;
     tile_pixel(src, a.row_begin, x, y);  // DispatchRaysIndex of the ray this thread walks now
     const Ray r = make_ray(o, d, 0.01f, 100000.0f);
-    GiPayload pay = trace_gi(bvh, sc, tv, a.gi, r, x, y);
+    GiPayload pay = trace_gi<MAXB>(bvh, sc, tv, a.gi, r, x, y, MAXB ? a.gi.num_bounces : 0u);
     if (any_nan(pay.irradiance)) pay.irradiance = F3(Fn(0.f));
     const Fn e = Fn(0.0031415927f);
     auto store = [](const PlaneArg& p, uint32_t px, uint32_t py, float c0, float c1, float c2, float c3) {
@@ -1366,12 +1394,16 @@ hipError_t launch_rt_nodes(const RtTriangle* unsorted, const unsigned long long*
 }
 hipError_t launch_probe_trace(const ProbeTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
     if (a.num_probes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_probe_trace, dim3((400u * a.num_probes + 255u) / 256u), dim3(256), 0, s, a, bvh, sc);
+    // (the bounce branch is a second instantiation: the reference's configuration, no bounces, runs the kernel without it)
+    if (a.gi.num_bounces == 0u) hipLaunchKernelGGL(k_probe_trace<0>, dim3((400u * a.num_probes + 255u) / 256u), dim3(256), 0, s, a, bvh, sc);
+    else hipLaunchKernelGGL(k_probe_trace<kRtMaxBounces>, dim3((400u * a.num_probes + 255u) / 256u), dim3(256), 0, s, a, bvh, sc);
     return hipGetLastError();
 }
 hipError_t launch_rtgi_trace(const RtgiTraceArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {
     if (a.row_end <= a.row_begin) return hipSuccess;
-    hipLaunchKernelGGL(k_rtgi_trace, dim3((a.width + 15u) / 16u, (a.row_end - (a.row_begin & ~15u) + 15u) / 16u), dim3(256), 0, s, a, bvh, sc);
+    const dim3 grid((a.width + 15u) / 16u, (a.row_end - (a.row_begin & ~15u) + 15u) / 16u);
+    if (a.gi.num_bounces == 0u) hipLaunchKernelGGL(k_rtgi_trace<0>, grid, dim3(256), 0, s, a, bvh, sc);
+    else hipLaunchKernelGGL(k_rtgi_trace<kRtMaxBounces>, grid, dim3(256), 0, s, a, bvh, sc);
     return hipGetLastError();
 }
 hipError_t launch_rtao(const RtaoArgs& a, const RtBvh& bvh, const RtScene& sc, hipStream_t s) {

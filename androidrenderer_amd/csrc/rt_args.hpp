@@ -92,7 +92,9 @@ struct GiArgs {  // what the GI hit / miss stages read besides the scene (rt.hip
     float tan_size;
     PlaneArg noise;     // R8G8B8A8_UNORM, >= 128 x 128
     SkyArgs sky;        // get_sky_color with the sun direction as stored (sky_unified.slang:229)
+    uint32_t num_bounces;  // payload.remaining_bounces of the generators' rays (sah_rt_set_bounces; the reference: 0)
 };
+constexpr int kRtMaxBounces = 2;
 
 struct ProbeTraceArgs {
     GiArgs gi;

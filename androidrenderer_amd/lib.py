@@ -23,7 +23,7 @@ _lib = None
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
-           "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
+           "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_rt_set_bounces", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
            "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister"]
 
 
@@ -83,6 +83,7 @@ def load():
     lib.sah_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane),
                                         C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     lib.sah_rt_set_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.sah_rt_set_bounces.argtypes = [C.c_void_p, C.c_uint32]
     lib.sah_probe_trace.argtypes = [C.c_void_p, C.POINTER(_abi.ProbeTraceDesc)]
     lib.sah_rtgi_trace.argtypes = [C.c_void_p, C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.SkyLuts)] + [C.POINTER(_abi.Plane)] * 5
     lib.sah_ipc_open.argtypes = [C.c_void_p, C.c_void_p]
@@ -219,6 +220,10 @@ class Context:
     def rt_set_rows(self, row_begin=0, row_end=0):
         """output rows [row_begin, row_end) for rtao / sun_shadow_mask / rtgi_trace from now on; (0, 0) = all"""
         self._check(self.lib.sah_rt_set_rows(self.handle, row_begin, row_end))
+
+    def rt_set_bounces(self, num_bounces=0):
+        """remaining_bounces of the rays probe_trace / rtgi_trace generate from now on (0..2; 0 = what the reference's generators set)"""
+        self._check(self.lib.sah_rt_set_bounces(self.handle, num_bounces))
 
     def probe_trace(self, desc):
         """desc: _abi.ProbeTraceDesc (device addresses); 400 GI rays per probe into desc.trace_results."""

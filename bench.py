@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one lit target, the all-gather of frame i finishes before frame i+1 is shaded")
     ap.add_argument("--force-gather", action="store_true", help="N=1: run the exchange path anyway, through a one-rank RCCL communicator (rehearsal of the N>1 loop)")
     ap.add_argument("--shadow-samples", type=float, default=None, help="traced workload: sun shadow rays per pixel (default: the reference's 8)")
+    ap.add_argument("--atrium-subdiv", type=int, default=8, help="traced workload: tessellation of the atrium the rays are traced against (8: 23.8 K triangles, the "
+                    "default; 24: 214 K)")
+    ap.add_argument("--rt-bounces", type=int, default=0, help="traced workload: sah_rt_set_bounces for the GI generators (the reference: 0)")
     ap.add_argument("--watchdog-s", type=float, default=300.0, help="N>1: end the rank when a phase makes no progress for this long (0: never)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
     ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
@@ -344,9 +347,10 @@ def main():
     traced = None
     if wl.get("traced"):
         from androidrenderer_amd import mesh
-        geo_arrays = mesh.to_device(mesh.atrium(8).arrays(), dev)
+        geo_arrays = mesh.to_device(mesh.atrium(args.atrium_subdiv).arrays(), dev)
         geo = mesh.geometry(geo_arrays, [])
         ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
+        ctx.rt_set_bounces(args.rt_bounces)
         noise_t = torch.from_numpy(synth.rng(31).integers(0, 256, (128, 128, 4), dtype=np.uint8)).to(dev)
         planes_rt = (images.plane(d_arr["depth"], _abi.FORMAT_D32_SFLOAT), images.plane(d_arr["normals"], _abi.FORMAT_R16G16B16A16_SFLOAT),
                      images.plane(noise_t, _abi.FORMAT_R8G8B8A8_UNORM), images.plane(d_arr["ao"], _abi.FORMAT_R32_SFLOAT),
@@ -411,7 +415,7 @@ def main():
         e[7].record()
         torch.cuda.synchronize()
         tr_dist = trace_results.view(torch.float16)[..., 3].float()
-        traced = {"triangles": rt_stats[0], "levels": rt_stats[2], "rt_build_ms": round(e[0].elapsed_time(e[1]), 4), "rtao_ms": round(e[2].elapsed_time(e[3]), 4),
+        traced = {"triangles": rt_stats[0], "levels": rt_stats[2], "gi_bounces": args.rt_bounces, "rt_build_ms": round(e[0].elapsed_time(e[1]), 4), "rtao_ms": round(e[2].elapsed_time(e[3]), 4),
                   "sun_shadow_mask_ms": round(e[3].elapsed_time(e[4]), 4), "probe_trace_ms": round(e[4].elapsed_time(e[5]), 4),
                   "probe_update_ms": round(e[5].elapsed_time(e[6]), 4), "probes_per_frame": n_probes,
                   "rtgi_trace_ms_not_in_frame": round(e[6].elapsed_time(e[7]), 4),

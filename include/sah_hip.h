@@ -609,6 +609,15 @@ int sah_rtgi_trace(sah_ctx* ctx, const sah_view_data* view, const sah_sun_light_
  * rows keep their contents.  (0, 0) = every row, the state of a new context.  A pixel's result does not depend on the window. */
 int sah_rt_set_rows(sah_ctx* ctx, uint32_t row_begin, uint32_t row_end);
 
+/* payload.remaining_bounces of the rays the two GI generators (sah_probe_trace, sah_rtgi_trace) trace from now on — the bounce branch of the
+ * GI hit stage, RenderCore/shaders/materials/gltf_basic_pbr.slang:481-517: a front-face hit with bounces left traces one more GI ray from the
+ * hit point along the launch index's noise direction (flipped into the hit normal's hemisphere; [0.05, 100000]; non-opaque and back-facing
+ * triangles culled) with one bounce fewer, and adds ndotl * brdf * its irradiance when that is finite.  0..2; a new context holds 0, which is
+ * what the reference's generators set (rtgi.rt.slang:88, probe_tracing.rt.slang:66 — they upload r.GI.NumBounces as a push constant,
+ * rtgi.cpp:131, and never read it): with 0 the results are the reference's, with 1 or 2 they are what its hit stage computes once a generator
+ * forwards the constant. */
+int sah_rt_set_bounces(sah_ctx* ctx, uint32_t num_bounces);
+
 /* Multi-GPU exchange step (no reference counterpart: the reference drives one device, RenderCore/render/backend/render_backend.cpp:135-153;
  * BASELINE.json north_star: "RCCL all-gather over xGMI to reassemble the final image").
  * In-place all-gather of row blocks of `image` over RCCL on the context's stream: rank r owns rows [rows_per_rank*r, rows_per_rank*(r+1))

@@ -183,14 +183,17 @@ bool any_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, bo
     return false;
 }
 
-// RAY_FLAG_NONE: the accepted candidate of smallest t; equal t: smallest (primitive, triangle).  Returns the index into s.tris or -1
-int closest_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, Hit& best) {
+// The accepted candidate of smallest t; equal t: smallest (primitive, triangle).  Returns the index into s.tris or -1.  RAY_FLAG_NONE for the
+// generators' rays; `bounce`: RAY_FLAG_CULL_NON_OPAQUE | RAY_FLAG_CULL_BACK_FACING_TRIANGLES (gltf_basic_pbr.slang:498-506)
+int closest_hit(const sah_scene_geometry& g, const RtStructure& s, const Ray& r, Hit& best, bool bounce = false) {
     int found = -1;
     if (!r.finite) return found;
     for (size_t i = 0; i < s.tris.size(); i++) {
         const WorldTriangle& w = s.tris[i];
+        if (bounce && w.cutout) continue;
         Hit h;
         if (!candidate(s, r, w, h)) continue;
+        if (bounce && !h.front) continue;
         if (found >= 0) {
             const WorldTriangle& b = s.tris[found];
             const bool better = h.t < best.t || (h.t == best.t && (w.primitive < b.primitive || (w.primitive == b.primitive && w.triangle < b.triangle)));
@@ -241,13 +244,16 @@ struct GiPayload {
 
 H unpack_channel(uint32_t packed, int c) { return H((float)((packed >> (8 * c)) & 0xffu)) / H::lit(255.0); }
 
-// TraceRay(rtas, RAY_FLAG_NONE, 0xFF, RAY_TYPE_GI, ...) with remaining_bounces = 0 (both generators): gltf_basic_pbr.slang:372-520 or
-// sky_unified.slang:227-230.  (dx, dy) = DispatchRaysIndex().xy
-GiPayload trace_gi(const GiInputs& in, const Ray& r, uint32_t dx, uint32_t dy) {
+// payload.remaining_bounces of the generators' rays: 0 in the reference (rtgi.rt.slang:88, probe_tracing.rt.slang:66), orc_rt_set_bounces
+uint32_t g_num_bounces = 0;
+
+// TraceRay(rtas, RAY_FLAG_NONE, 0xFF, RAY_TYPE_GI, ...): gltf_basic_pbr.slang:372-520 or sky_unified.slang:227-230.
+// (dx, dy) = DispatchRaysIndex().xy; `bounce`: the ray is the bounce ray of a hit stage (other flags, :498-506)
+GiPayload trace_gi(const GiInputs& in, const Ray& r, uint32_t dx, uint32_t dy, uint32_t remaining_bounces, bool bounce = false) {
     GiPayload pay;
     const sah_scene_geometry& g = *in.scene;
     Hit h = {0.0f, 0.0f, 0.0f, false};
-    const int found = closest_hit(g, *in.s, r, h);
+    const int found = closest_hit(g, *in.s, r, h, bounce);
     if (found < 0) {
         if (r.finite) {  // miss stage: get_sky_color(WorldRayDirection(), sun_light.direction_and_tan_size.xyz, ...) — the direction as stored
             static const SkyConsts k;
@@ -318,6 +324,17 @@ GiPayload trace_gi(const GiInputs& in, const Ray& r, uint32_t dx, uint32_t dy) {
     irr = irr + to_f(emission);
     pay.irradiance = irr;
     pay.ray_distance = F(h.t);
+    if (remaining_bounces > 0) {  // :481-517
+        F3 ray_direction = load_noise(*in.noise, dx % 128u, dy % 128u);
+        if (dot(to_f(surf.normal), ray_direction).v < 0.0f) ray_direction = ray_direction * F(-1.0f);
+        const float d[3] = {ray_direction.x.v, ray_direction.y.v, ray_direction.z.v};
+        const GiPayload new_payload = trace_gi(in, make_ray(loc, d, 0.05f, 100000.0f), dx, dy, remaining_bounces - 1, true);
+        const H3 bounce_brdf_result = Fd(surf, to_h(ray_direction), surf.normal);
+        const H bounce_ndotl = H(nclamp(dot(ray_direction, to_f(surf.normal)), F(0.0f), F(1.0f)).v);
+        const F3 bounce_radiance = to_f(bounce_brdf_result * bounce_ndotl) * new_payload.irradiance;
+        const float br[3] = {bounce_radiance.x.v, bounce_radiance.y.v, bounce_radiance.z.v};
+        if (std::isfinite(br[0]) && std::isfinite(br[1]) && std::isfinite(br[2])) pay.irradiance = pay.irradiance + bounce_radiance;
+    }
     if (!h.front) {  // HIT_KIND_TRIANGLE_BACK_FACE
         pay.ray_distance = pay.ray_distance * F(-1.0f);
         pay.irradiance = F3(F(0.0f));
@@ -415,6 +432,13 @@ int orc_sun_shadow_mask(const sah_scene_geometry* scene, const sah_view_data* vi
 }
 
 // probe_tracing.rt.slang:39-106
+// remaining_bounces of the rays orc_probe_trace / orc_rtgi_trace generate from now on (process-wide; the reference's generators: 0)
+int orc_rt_set_bounces(uint32_t num_bounces) {
+    if (num_bounces > 8) return 1;
+    orc::g_num_bounces = num_bounces;
+    return 0;
+}
+
 int orc_probe_trace(const sah_scene_geometry* scene, const sah_probe_trace_desc* d) {
     using namespace orc;
     if (!scene_ok(scene) || !d || !gi_inputs_ok(d->sun, d->sky, d->noise)) return SAH_ERR_INVALID_ARGUMENT;
@@ -448,7 +472,7 @@ int orc_probe_trace(const sah_scene_geometry* scene, const sah_probe_trace_desc*
                     F ray_distance = F(8192.0f);
                     if (cascade < 3) ray_distance = F(d->cascades[cascade + 1].probe_spacing) * F(4.0f);
                     const float o[3] = {origin.x.v, origin.y.v, origin.z.v}, dd[3] = {dir.x.v, dir.y.v, dir.z.v};
-                    GiPayload pay = trace_gi(in, make_ray(o, dd, 0.05f, ray_distance.v), tx, ty);
+                    GiPayload pay = trace_gi(in, make_ray(o, dd, 0.05f, ray_distance.v), tx, ty, g_num_bounces);
                     if (pay.ray_distance.v == 0.0f) {
                         if (cascade + 1 < 4) pay.irradiance = sample_probe_cascade(gi, origin + dir * ray_distance, dir, cascade + 1);
                         else pay.irradiance = pay.irradiance * F(10.0f);
@@ -491,7 +515,7 @@ int orc_rtgi_trace(const sah_scene_geometry* scene, const sah_view_data* view, c
             F3 dir = load_noise(*noise, (uint32_t)x % 128u, (uint32_t)y % 128u);
             if (dot(normal, dir).v < 0.0f) dir = dir * F(-1.0f);
             const float o[3] = {pos.x.v, pos.y.v, pos.z.v}, dd[3] = {dir.x.v, dir.y.v, dir.z.v};
-            GiPayload pay = trace_gi(in, make_ray(o, dd, 0.01f, 100000.0f), (uint32_t)x, (uint32_t)y);
+            GiPayload pay = trace_gi(in, make_ray(o, dd, 0.01f, 100000.0f), (uint32_t)x, (uint32_t)y, g_num_bounces);
             if (any_nan(pay.irradiance)) pay.irradiance = F3(F(0.0f));
             const F e = F(0.0031415927f);
             const float rb[4] = {dir.x.v, dir.y.v, dir.z.v, pay.ray_distance.v};

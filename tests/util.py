@@ -75,6 +75,7 @@ def oracle():
     o.orc_sun_shadow_mask.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.Plane),
                                       C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     o.orc_probe_trace.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ProbeTraceDesc)]
+    o.orc_rt_set_bounces.argtypes = [C.c_uint32]
     o.orc_rtgi_trace.argtypes = [C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.SunLightConstants), C.POINTER(_abi.SkyLuts)] + \
         [C.POINTER(_abi.Plane)] * 5
     _oracle = o
