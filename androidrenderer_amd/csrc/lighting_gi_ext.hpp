@@ -446,13 +446,19 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
     const Surface<Hn>& s = geom.s;
     const F3 location = geom.location;
     const H3 V = geom.V;
-    uint32_t cascade_index = 5;
-    for (uint32_t i = 0; i < 4; i++) {
-        if (location.x.v > c.cascade_min[i][0] && location.y.v > c.cascade_min[i][1] && location.z.v > c.cascade_min[i][2] &&
-            location.x.v < c.cascade_max[i][0] && location.y.v < c.cascade_max[i][1] && location.z.v < c.cascade_max[i][2]) {
-            cascade_index = i;
-            break;
-        }
+    // the first cascade whose box holds the point (5: none).  Cascade 0 is tested first: where it holds every lane of the wave (near-field
+    // pixels) the other three boxes cannot change the answer and are not tested (six compares each)
+    auto inside = [&](uint32_t i) {
+        return location.x.v > c.cascade_min[i][0] && location.y.v > c.cascade_min[i][1] && location.z.v > c.cascade_min[i][2] &&
+               location.x.v < c.cascade_max[i][0] && location.y.v < c.cascade_max[i][1] && location.z.v < c.cascade_max[i][2];
+    };
+    uint32_t cascade_index = 0;
+    const bool in0 = inside(0u);
+    if (!__all(in0)) {
+        cascade_index = 5;
+#pragma unroll
+        for (int i = 3; i >= 1; i--) cascade_index = inside((uint32_t)i) ? (uint32_t)i : cascade_index;
+        cascade_index = in0 ? 0u : cascade_index;
     }
     if (cascade_index > 3) {  // returns (half4)0 and is still blended (overlay.frag.slang:79-81)
         out[0] = out[1] = out[2] = out[3] = Fn(0.f);
@@ -463,9 +469,9 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
     const H3 b = brdf_sl(s, s.normal, V);  // == Fd(s, N, V) + Fr(s, N, V)
     const Hn exposure = Hn::lit(0.314159f);
     H3 col = b * irradiance * exposure;
-    if (c.debug_mode == 1) {
-        const float dbg[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}};
-        col = {Hn(dbg[cascade_index][0]), Hn(dbg[cascade_index][1]), Hn(dbg[cascade_index][2])};
+    if (c.debug_mode == 1) {  // red, green, blue, yellow by cascade (three selects: a table indexed per lane costs a compare chain per entry)
+        const bool r = cascade_index == 0u || cascade_index == 3u, g = cascade_index == 1u || cascade_index == 3u, bl = cascade_index == 2u;
+        col = {r ? Hn::lit(1.f) : Hn::lit(0.f), g ? Hn::lit(1.f) : Hn::lit(0.f), bl ? Hn::lit(1.f) : Hn::lit(0.f)};
     }
     if (any_nan(col)) col = H3(Hn::lit(0.f));
     out[0] = Fn(tof(col.x));

@@ -794,6 +794,25 @@ def main():
         sys.exit(3)
 
 
+def usable_cpus():
+    """the CPUs this process may actually run on: its affinity mask, capped by the cgroup's CPU quota (a one-GPU box shares a 256-thread
+    host: os.cpu_count() says 256 where 16 are granted, and 256 OpenMP threads on 16 CPUs time the scheduler, not the oracle)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(fr, target_s):
     """Times the CPU oracle (a port of the reference shaders, OpenMP over rows) on a bounded band of rows of the same frame
     (lighting pass only): built here with -O3 -march=native (oracle/Makefile target `native`), one warm-up, then the
@@ -827,7 +846,11 @@ def cpu_baseline(fr, target_s):
     lit = np.zeros((H, W, 4), dtype=np.uint16)
     fr.row_begin = fr.row_end = 0
     d, keep = fr.describe(fr.arrays, lit)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(cores)  # the oracle's OpenMP runtime: as many threads as there are CPUs to run them
+    except Exception:
+        cores = os.cpu_count() or 1  # (the runtime's own default then applies)
     mid = H // 2
 
     def timed(r0, r1):

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--lights", type=int, default=256)
     ap.add_argument("--light-radius", type=float, default=4.0)
+    ap.add_argument("--ramp-ms", type=float, default=150.0, help="untimed: each pass runs back to back for this long before its timed launches (the same clock "
+                    "ramp bench.py gives its step: profiles/r3_clock_ramp.txt)")
     ap.add_argument("--only", default="", help="run only the passes whose name contains one of these comma-separated substrings")
     ap.add_argument("--json", action="store_true", help="also print the results as one JSON object")
     args = ap.parse_args()
@@ -41,9 +43,14 @@ def main():
     def timeit(name, fn, bytes_per_call):
         if not wanted(name):
             return
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
+        import time
+        t_end = time.perf_counter() + args.ramp_ms * 1e-3
+        while True:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            if time.perf_counter() >= t_end:
+                break
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
@@ -90,6 +97,7 @@ def main():
     mips = [torch.zeros((mh, mw, 4), dtype=torch.int16, device="cuda") for (mw, mh) in images.bloom_mip_sizes(W, H, 6)]
     chain = images.mipchain(mips)
     timeit("bloom chain (6 mips)", lambda: ctx.bloom(sp, chain), int((8 + 2.667 + 2.667) * px))
+    timeit("copy scene + bloom mip 0 (one pass)", lambda: ctx.copy_scene_bloom_mip0(sp, ap_, chain, (0, H), (0, mips[0].shape[0])), int((8 + 8 + 2) * px))
     out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
     op = images.plane(out, _abi.FORMAT_R8G8B8A8_SRGB)
     timeit("tonemap composite", lambda: ctx.tonemap(sp, chain, op), int((8 + 4 + 2.667) * px))

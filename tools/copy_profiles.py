@@ -5,11 +5,13 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r3"
+R = sys.argv[1] if len(sys.argv) > 1 else "r4"
 SRC, DST = "gpurun_out/refresh", "profiles"
 shutil.copy(f"{SRC}/bench.json", f"{DST}/{R}_bench_4k_deferred_gi.json")
 shutil.copy(f"{SRC}/ktrace/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_deferred_gi.csv")
 shutil.copy(f"{SRC}/pmc.txt", f"{DST}/{R}_pmc_4k_deferred_gi.txt")
+if os.path.exists(f"{SRC}/ktrace_chain/kt_kernel_stats.csv"):
+    shutil.copy(f"{SRC}/ktrace_chain/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_probe_gi_chain.csv")
 shutil.copy(f"{SRC}/passes.txt", f"{DST}/{R}_passes_4k.txt")
 if os.path.exists(f"{SRC}/roofline_static.json"):
     shutil.copy(f"{SRC}/roofline_static.json", f"{DST}/roofline_static.json")

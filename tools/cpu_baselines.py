@@ -38,7 +38,9 @@ def main():
     o.orc_bloom.argtypes = [C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
     o.orc_tonemap.argtypes = [C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     flags = open(os.path.join(ROOT, "oracle", "liboracle_native.flags")).read().strip()
-    cores = os.cpu_count()
+    import bench
+    cores = bench.usable_cpus()  # affinity capped by the cgroup quota: the threads that can actually run
+    C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
     print(f"# CPU oracle ({flags}), {cores} OpenMP threads; per config: a band of rows sized for ~{args.seconds:.0f} s, median of 3 repetitions")
     print(f"# {'config':72s} {'pass':22s} {'rows':>6s} {'s':>8s} {'Mpx/s':>10s}")
     sun = {"csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}

@@ -110,6 +110,16 @@ VARIANTS["lights_both"] = (["lighting_tiled.hip"], VARIANTS["lights_pow5_f32"][1
 VARIANTS["bloom_big_tiles_mip1"] = (["post.hip"], [("post.hip", "if ((uint64_t)cols * ((rows + 15) / 16) >= 1024) {", "if ((uint64_t)cols * ((rows + 15) / 16) >= 500) {")])
 
 # compound variants
+# ---- k_copy_bloom_mip0 (copy scene + bloom mip 0 in one pass): what do the copy's four taps per cell, the antialiased stores and the
+# filter cost? -------------------------------------------------------------------------------------------------------------------------
+VARIANTS["cbm_one_tap"] = (["post.hip"], [("post.hip", "                t[q][1] = *reinterpret_cast<const uint2*>(lit + (cy[q].o0 + cx[q].o1));\n"
+                                           "                t[q][2] = *reinterpret_cast<const uint2*>(lit + (cy[q].o1 + cx[q].o0));\n"
+                                           "                t[q][3] = *reinterpret_cast<const uint2*>(lit + (cy[q].o1 + cx[q].o1));\n",
+                                           "                t[q][1] = t[q][2] = t[q][3] = t[q][0];\n")])
+VARIANTS["cbm_no_aa_store"] = (["post.hip"], [("post.hip", "                if (ax >= own_x0 && ax < own_x1 && ay >= own_y0 && ay < own_y1)\n", "                if (ax == -77)\n")])
+VARIANTS["cbm_no_filter"] = (["post.hip"], [("post.hip", "    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it\n    const uint32_t col = tid & 63u, x = bx + col;\n    if (x >= dw) return;",
+                                             "    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it\n    const uint32_t col = tid & 63u, x = bx + col;\n    if (x >= dw || g.mw != 77u) return;")])
+VARIANTS["cbm_one_tap_no_filter"] = (["post.hip"], VARIANTS["cbm_one_tap"][1] + VARIANTS["cbm_no_filter"][1])
 VARIANTS["tiled_skeleton"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_cheb"][1] + VARIANTS["tiled_no_depth_dir"][1] + VARIANTS["tiled_no_depth_lookup"][1] +
                               VARIANTS["tiled_no_irr_taps"][1])
 VARIANTS["tiled_no_lookups"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_depth_lookup"][1] + VARIANTS["tiled_no_irr_taps"][1])
