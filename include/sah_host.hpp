@@ -1040,6 +1040,10 @@ public:
         num_extra_rays = num_samples;
         extra_ray_radius = size;
     }
+    // r.GI.NumBounces (rtgi.cpp:10).  The reference pushes it to the generator (rtgi.cpp:131), which never reads it and sets
+    // payload.remaining_bounces = 0 (rtgi.rt.slang:88): 0 here is the reference's image, 1 or 2 what its hit stage (gltf_basic_pbr.slang:481-517)
+    // computes once the generator forwards the constant
+    void set_forwarded_bounces(uint32_t n) { forwarded_bounces = n; }
     IrradianceCache& get_irradiance_cache() { return cache; }
     TextureHandle get_ray_texture() const { return ray_texture; }
     TextureHandle get_ray_irradiance() const { return ray_irradiance; }
@@ -1057,7 +1061,10 @@ public:
                             const sah_sky_luts sky{scene.sky.transmittance_lut->plane(), scene.sky.sky_view_lut->plane()};
                             const sah_plane depth = gbuffer.depth->plane(), normals = gbuffer.normals->plane(), noise = noise_tex->plane();
                             const sah_plane rb = ray_texture->plane(), ri = ray_irradiance->plane();
-                            return sah_rtgi_trace(ctx, &view.get_gpu_data(), &scene.sun.get_constants(), &sky, &depth, &normals, &noise, &rb, &ri);
+                            if (int rc = sah_rt_set_bounces(ctx, forwarded_bounces); rc != SAH_OK) return rc;
+                            const int rc = sah_rtgi_trace(ctx, &view.get_gpu_data(), &scene.sun.get_constants(), &sky, &depth, &normals, &noise, &rb, &ri);
+                            sah_rt_set_bounces(ctx, 0);  // (the context's setting also governs the irradiance cache's probe rays)
+                            return rc;
                         }));
     }
     void get_lighting_resource_usages(TextureUsageList& textures, BufferUsageList& buffers) const override {
@@ -1081,6 +1088,7 @@ private:
     IrradianceCache cache;
     ResourceAllocator* allocator = nullptr;
     TextureHandle ray_texture{}, ray_irradiance{};
+    uint32_t forwarded_bounces = 0;
     uint32_t num_extra_rays = 0;
     float extra_ray_radius = 16.f;
 };
@@ -1187,6 +1195,17 @@ public:
         graph.add_pass(hip_pass("Bloom", [this, scene_color](sah_ctx* ctx) {
                             const sah_plane s = scene_color->plane();
                             return sah_bloom(ctx, &s, &chain);
+                        }));
+    }
+    // "Copy scene" (scene_renderer.cpp:502-527) directly followed by the bloom pass (bloomer.cpp:50-72), as the frame records them: the copy
+    // and the first bloom dispatch in one pass over lit_scene, then the rest of the chain.  Same bits as evaluate_antialiasing_none() +
+    // fill_bloom_tex(); extents the fused form does not take fall back to the two passes inside the library.
+    void copy_scene_and_fill_bloom_tex(RenderGraph& graph, TextureHandle lit_scene, TextureHandle antialiased_scene) {
+        if (mips.empty()) create_bloom_tex(antialiased_scene);
+        graph.add_pass(hip_pass("Copy scene + Bloom", [this, lit_scene, antialiased_scene](sah_ctx* ctx) {
+                            const sah_plane l = lit_scene->plane(), a = antialiased_scene->plane();
+                            if (int rc = sah_copy_scene_bloom_mip0_rows(ctx, &l, &a, &chain, 0, 0, 0, 0); rc != SAH_OK) return rc;
+                            return sah_bloom_from_mip0(ctx, &a, &chain);
                         }));
     }
     TextureHandle get_bloom_tex() const { return bloom_tex.get(); }  // bloomer.hpp:17

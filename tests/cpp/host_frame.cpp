@@ -129,6 +129,11 @@ int main(int argc, char** argv) {
     gi->draw_debug_overlays(graph, view, gbuffer, lit_scene);
     evaluate_antialiasing_none(graph, lit_scene, antialiased);
     bloomer.fill_bloom_tex(graph, antialiased);
+    // the same two passes as one ("Copy scene + Bloom": the copy and the first bloom dispatch in one pass over lit_scene), into a second
+    // set of images that must come out bit for bit the same
+    TextureHandle antialiased_fused = alloc.create_texture("antialiased_scene (fused)", SAH_FORMAT_R16G16B16A16_SFLOAT, W, H);
+    Bloomer bloomer_fused(backend);
+    bloomer_fused.copy_scene_and_fill_bloom_tex(graph, lit_scene, antialiased_fused);
     DynamicRenderingPass ui_pass;  // scene_renderer.cpp:426-449
     ui_pass.name = "UI";
     ui_pass.textures = {{antialiased, kStageFragmentShader, kAccessShaderRead, kLayoutShaderReadOnly},
@@ -153,6 +158,23 @@ int main(int argc, char** argv) {
         bool saw_set = false;
         for (const auto& u : graph.get_texture_usages()) saw_set = saw_set || u.texture == ao_scratch2;
         if (!saw_set) { fprintf(stderr, "descriptor set usages were not recorded\n"); return 1; }
+    }
+
+    {
+        std::vector<unsigned char> a((size_t)W * H * 8), b((size_t)W * H * 8);
+        alloc.download(antialiased, a.data(), W * 8);
+        alloc.download(antialiased_fused, b.data(), W * 8);
+        if (a != b) { fprintf(stderr, "Copy scene + Bloom: antialiased_scene differs from the two passes'\n"); return 1; }
+        for (uint32_t m = 0; m < bloomer.get_bloom_tex()->mips.num_mips; m++) {
+            const sah_plane pa = bloomer.get_bloom_tex()->mips.mips[m], pb = bloomer_fused.get_bloom_tex()->mips.mips[m];
+            std::vector<unsigned char> ma((size_t)pa.width * pa.height * 8), mb(ma.size());
+            if (hipMemcpy2D(ma.data(), (size_t)pa.width * 8, pa.ptr, pa.row_pitch_bytes, (size_t)pa.width * 8, pa.height, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy2D(mb.data(), (size_t)pb.width * 8, pb.ptr, pb.row_pitch_bytes, (size_t)pb.width * 8, pb.height, hipMemcpyDeviceToHost) != hipSuccess) {
+                fprintf(stderr, "bloom mip read-back failed\n");
+                return 1;
+            }
+            if (ma != mb) { fprintf(stderr, "Copy scene + Bloom: bloom mip %u differs from the two passes'\n", m); return 1; }
+        }
     }
 
     FILE* out = fopen(argv[2], "wb");
