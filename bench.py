@@ -84,6 +84,10 @@ def light_stats(torch, fr, d_arr, lights_np, dev):
         d = torch.clamp(torch.maximum(lo - c, c - hi), min=0.0)
         per_tile += ((d * d).sum(-1) <= (r * 1.0001 + 1e-6) ** 2).float()
         per_px += (((ws - c) ** 2).sum(-1) <= (r * 1.001) ** 2).float()
+        if i % 32 == 31:
+            # about twenty launches per light, queued far ahead of an 8K frame's kernels: with 16,384 dispatches outstanding — the queue's
+            # packet count — rocprofv3 --pmc faults inside librocprofiler-sdk's queue interception (profiles/README.md "8K under --pmc")
+            torch.cuda.synchronize()
     return {"lights_per_tile_mean": round(float(per_tile.mean()), 2), "lights_per_tile_max": int(per_tile.max()),
             "lights_shaded_per_pixel_mean": round(float(per_px[surf].mean()) if bool(surf.any()) else 0.0, 3)}
 
