@@ -437,6 +437,14 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             }
             cache.spacing[c] = gi.probe_cascades[c].probe_spacing;
         }
+        cache.spacing_pow2 = 1;
+        for (int c = 0; c < 4; c++) {
+            int e = 0;
+            const float sp = cache.spacing[c], m = frexpf(sp, &e);
+            // 2^-60 .. 2^60: neither the reciprocal nor a quotient of a finite coordinate's difference can leave the normal range unevenly
+            cache.spacing_pow2 = cache.spacing_pow2 && m == 0.5f && e > -60 && e < 60;
+            cache.inv_spacing[c] = 1.0f / sp;
+        }
         cache.probe_size[0] = gi.probe_size[0];
         cache.probe_size[1] = gi.probe_size[1];
         for (int i = 0; i < 2; i++) cache.inv_tex[i] = 1.0f / (((float)gi.probe_size[i] + 2.0f) * 32.0f);

@@ -302,6 +302,13 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
 
     uint32_t out[2 * PPT];
     uint32_t deferred_mask = 0, sky_mask = 0;
+    bool emissive_wave;  // (one vote for the thread's PPT pixels)
+    {
+        uint32_t any_e = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) any_e |= we[i];
+        emissive_wave = __any(active && (any_e & 0xffffffu) != 0u);
+    }
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
         if (!active) break;
@@ -323,7 +330,7 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
             if (SUN == SAH_SHADOW_MODE_CSM || GI == SAH_GI_LPV) colx_glsl = colx_glsl_of(a, f, x);
             if (SUN == SAH_SHADOW_MODE_RT) colx_slang = colx_slang_of(a, f, x);
         }
-        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad);
+        const FastPixelOut r = shade_pixel_fast_sl<SUN, GI>(a, csm, lpv, f, colx_glsl, rowy_glsl, colx_slang, rowy_slang, p, s_lut, lpv_bad, emissive_wave);
         out[2 * i] = r.lit.x;
         out[2 * i + 1] = r.lit.y;
         if (r.deferred) deferred_mask |= 1u << i;

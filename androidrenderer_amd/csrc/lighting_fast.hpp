@@ -153,7 +153,7 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
 template <int SUN, int GI>
 SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const FastArgs& f, float colx_glsl,
                                          float rowy_glsl, float colx_slang, float rowy_slang, const Px& p, const float* tab,
-                                         bool lpv_has_nonfinite) {
+                                         bool lpv_has_nonfinite, bool emissive_wave) {
     const float* lut = tab;
     const float D = p.depth;
     const bool sky_px = D == 0.f;
@@ -264,18 +264,28 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         lit[0] = Hn(tof(lit[0]) + (total.x * exposure).v);
         lit[1] = Hn(tof(lit[1]) + (total.y * exposure).v);
         lit[2] = Hn(tof(lit[2]) + (total.z * exposure).v);
-        lit[3] = Hn(tof(lit[3]) + 1.0f);
+        lit[3] = lit[3] + Hn::lit(1.0f);  // (1 is an fp16 value: RN16(RN32(a + 1)) of an fp16 a is the fp16 sum, 24 >= 2 * 11 + 2)
     }
 
     // ---------------- a2: emissive (also the only pass that touches depth == 0 pixels when there is no sky) --------------
-    const Fn e = Fn(3.1415927f);
-    const float er = (Fn(lut[p.emission & 0xffu]) * e).v;
-    const float eg = (Fn(lut[(p.emission >> 8) & 0xffu]) * e).v;
-    const float eb = (Fn(lut[(p.emission >> 16) & 0xffu]) * e).v;
-    lit[0] = Hn(tof(lit[0]) + er);
-    lit[1] = Hn(tof(lit[1]) + eg);
-    lit[2] = Hn(tof(lit[2]) + eb);
-    lit[3] = Hn(tof(lit[3]) + 1.0f);
+    // `emissive_wave` (wave-uniform): some pixel of the wave has a non-zero emission texel.  Without one every colour gets +0 added (table
+    // entry 0 is +0).  RN16(RN32(lit + 0)) is lit for every fp16 lit but -0, which becomes +0 (a tiny negative LPV term rounds to -0 in the
+    // blend before) — exactly what one fp16 add of +0 does (fp16 -> fp32 is exact, a NaN keeps its bits): the look-ups, products and fp32
+    // blends become three v_add_f16
+    float er = 0.f, eg = 0.f, eb = 0.f;
+    if (emissive_wave) {
+        const Fn e = Fn(3.1415927f);
+        er = (Fn(lut[p.emission & 0xffu]) * e).v;
+        eg = (Fn(lut[(p.emission >> 8) & 0xffu]) * e).v;
+        eb = (Fn(lut[(p.emission >> 16) & 0xffu]) * e).v;
+        lit[0] = Hn(tof(lit[0]) + er);
+        lit[1] = Hn(tof(lit[1]) + eg);
+        lit[2] = Hn(tof(lit[2]) + eb);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) lit[i] = lit[i] + Hn::lit(0.f);
+    }
+    lit[3] = lit[3] + Hn::lit(1.0f);
 
     // ---------------- a1b: sun, RT mode (Slang half flavour) ----------------
     if constexpr (SUN == SAH_SHADOW_MODE_RT) {

@@ -249,7 +249,9 @@ SAH_DEV ProbeAxis probe_axis(float u, uint32_t size, uint32_t stride) {
 SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index, const float* lut, bool& bad) {
     const Fn spacing = Fn(c.spacing[cascade_index]);
     const F3 rel = location - F3{Fn(c.cascade_min[cascade_index][0]), Fn(c.cascade_min[cascade_index][1]), Fn(c.cascade_min[cascade_index][2])};
-    const F3 ps = rel / spacing;
+    // (a power-of-two spacing — the reference's 0.5 m doubled per cascade — divides exactly: the product with its reciprocal is the same
+    // real number rounded the same way; uniform branch)
+    const F3 ps = c.spacing_pow2 ? rel * Fn(c.inv_spacing[cascade_index]) : rel / spacing;
     const Fn psa[3] = {ps.x, ps.y, ps.z};
     const F2 irr_oct = octahedral_coordinates(direction);  // probe independent (IEEE form: once per pixel)
     const bool irr_oct_ok = (__builtin_fabsf(irr_oct.x.v) <= 1.0f) & (__builtin_fabsf(irr_oct.y.v) <= 1.0f);  // false for NaN
@@ -403,7 +405,25 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         bad = bad | pbad;
     }
     if (weight.v == 0.f) return F3(Fn(0.f));
-    irradiance = irradiance / weight;
+    // the three quotients through one refined reciprocal (div_nr with its y1 steps shared): the sums are +0 or at least 2^-40 and the weight
+    // at least 2^-40 wherever the probes carry light and one of them counts; a pixel outside that domain is re-evaluated by sample_cascade()
+    {
+        const float w = weight.v;
+        // (on the bit patterns, unsigned: the sums are >= +0, so "0 or >= 2^-40" is bits - 1 >= bits(2^-40) - 1 with 0 - 1 wrapping to the
+        // top, and anything negative, infinite or NaN lies above bits(2^40))
+        const uint32_t bx = __builtin_bit_cast(uint32_t, irradiance.x.v), by = __builtin_bit_cast(uint32_t, irradiance.y.v),
+                       bz = __builtin_bit_cast(uint32_t, irradiance.z.v), bw = __builtin_bit_cast(uint32_t, w);
+        const uint32_t mn = min(min(bx - 1u, by - 1u), min(bz - 1u, bw - 1u)), mx = max(max(bx, by), max(bz, bw));
+        bad = bad | !((mn >= __builtin_bit_cast(uint32_t, kDivLo) - 1u) & (mx <= __builtin_bit_cast(uint32_t, kDivHi)));
+        const float y0 = __builtin_amdgcn_rcpf(w);
+        const float y1 = __builtin_fmaf(__builtin_fmaf(-w, y0, 1.0f), y0, y0);
+        auto quot = [&](float a) {
+            const float q0 = a * y1;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-w, q0, a), y1, q0);
+            return Fn(__builtin_fmaf(__builtin_fmaf(-w, q1, a), y1, q1));
+        };
+        irradiance = {quot(irradiance.x.v), quot(irradiance.y.v), quot(irradiance.z.v)};
+    }
     return irradiance * Fn(2.f) * Fn(rh(3.1415927f));  // PI = 3.1415927h (brdf.slangi wins the #ifndef race)
 }
 
@@ -442,7 +462,8 @@ SAH_DEV void sun_rt_shared(const LightingArgs& a, const Px& p, const SlangGeom& 
 }
 
 // `lut` != nullptr selects sample_cascade_fast(); *bad is then set when the pixel has to be re-evaluated with lut == nullptr.
-SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const SlangGeom& geom, Fn (&out)[4], const float* lut = nullptr, bool* bad = nullptr) {
+// (the Slang overlays return half4: `out` is what the fragment hands to the blender)
+SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const SlangGeom& geom, Hn (&out)[4], const float* lut = nullptr, bool* bad = nullptr) {
     const Surface<Hn>& s = geom.s;
     const F3 location = geom.location;
     const H3 V = geom.V;
@@ -461,7 +482,7 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
         cascade_index = in0 ? 0u : cascade_index;
     }
     if (cascade_index > 3) {  // returns (half4)0 and is still blended (overlay.frag.slang:79-81)
-        out[0] = out[1] = out[2] = out[3] = Fn(0.f);
+        out[0] = out[1] = out[2] = out[3] = Hn::lit(0.f);
         return;
     }
     const H3 irradiance = to_h(lut ? sample_cascade_fast(c, location, to_f(s.normal), cascade_index, lut, *bad)
@@ -474,10 +495,10 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
         col = {r ? Hn::lit(1.f) : Hn::lit(0.f), g ? Hn::lit(1.f) : Hn::lit(0.f), bl ? Hn::lit(1.f) : Hn::lit(0.f)};
     }
     if (any_nan(col)) col = H3(Hn::lit(0.f));
-    out[0] = Fn(tof(col.x));
-    out[1] = Fn(tof(col.y));
-    out[2] = Fn(tof(col.z));
-    out[3] = Fn(1.f);
+    out[0] = col.x;
+    out[1] = col.y;
+    out[2] = col.z;
+    out[3] = Hn::lit(1.f);
 }
 
 // ---- a5 ------------------------------------------------------------------------------------------------------------------
@@ -498,7 +519,7 @@ SAH_DEV void load_path(const LightingArgs& a, const RtgiArgs& r, uint32_t px, ui
     }
 }
 
-SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, uint32_t y, const SlangGeom& geom, const float* lut, Fn (&out)[4]) {
+SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, uint32_t y, const SlangGeom& geom, const float* lut, Hn (&out)[4]) {
     const Surface<Hn>& s = geom.s;
     const F3 location = geom.location;
     const H3 V = geom.V;
@@ -534,10 +555,10 @@ SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, 
     }
     if (any_nan(radiance)) radiance = H3(Hn::lit(0.f));
     const Hn n = Hn((float)num_samples);
-    out[0] = Fn(tof(radiance.x / n));
-    out[1] = Fn(tof(radiance.y / n));
-    out[2] = Fn(tof(radiance.z / n));
-    out[3] = Fn(1.f);
+    out[0] = radiance.x / n;
+    out[1] = radiance.y / n;
+    out[2] = radiance.z / n;
+    out[3] = Hn::lit(1.f);
 }
 
 // ---- a9 (extension): one point light, spec in DESIGN.md §5b and include/sah_hip.h ---------------------------------------

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
             lit[0] = Hn(tof(lit[0]) + (sum.x * exposure).v);
             lit[1] = Hn(tof(lit[1]) + (sum.y * exposure).v);
             lit[2] = Hn(tof(lit[2]) + (sum.z * exposure).v);
-            lit[3] = Hn(tof(lit[3]) + 1.0f);
+            lit[3] = lit[3] + Hn::lit(1.0f);  // (1 is an fp16 value: the blend is an fp16 add, as for the Slang overlays below)
         }
     }
 
@@ -303,32 +303,41 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     }
     // (3) GI overlay
     if (surface) {
-        Fn s[4];
-        bool drawn = false;
         if constexpr (GI == SAH_GI_LPV) {
+            Fn s[4];
             gi_lpv_frag(a, lpv, x, y, p, si, s);
-            drawn = true;
-        } else if constexpr (GI == SAH_GI_CACHE) {
-            bool redo = false;  // hot form first; a pixel outside its preconditions (rare) is re-evaluated with the general form
-            if (cache.hot_ok) gi_cache_frag(a, cache, sg, s, s_lut, &redo);
-            if (redo || !cache.hot_ok) gi_cache_frag(a, cache, sg, s);
-            drawn = true;
-        } else if constexpr (GI == SAH_GI_RTGI) {
-            gi_rtgi_frag(a, rtgi, x, y, sg, s_lut, s);
-            drawn = true;
-        }
-        if (drawn) {
 #pragma unroll
             for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
+        } else if constexpr (GI == SAH_GI_CACHE || GI == SAH_GI_RTGI) {
+            Hn s[4];
+            if constexpr (GI == SAH_GI_CACHE) {
+                bool redo = false;  // hot form first; a pixel outside its preconditions (rare) is re-evaluated with the general form
+                if (cache.hot_ok) gi_cache_frag(a, cache, sg, s, s_lut, &redo);
+                if (redo || !cache.hot_ok) gi_cache_frag(a, cache, sg, s);
+            } else {
+                gi_rtgi_frag(a, rtgi, x, y, sg, s_lut, s);
+            }
+            // the blend RN16(RN32(lit + s)) of two fp16 values is their fp16 sum: rounding a sum of 11-bit operands to 24 bits first is
+            // innocuous (24 >= 2 * 11 + 2), so one v_add_f16 per channel stands for two conversions, the fp32 add and the conversion back
+#pragma unroll
+            for (int i = 0; i < 4; i++) lit[i] = lit[i] + s[i];
         }
     }
-    // (4) emissive
+    // (4) emissive.  A wave without an emissive texel adds +0 to every colour (table entry 0 is +0: api.cpp's format tables decode byte 0 to
+    // 0).  RN16(RN32(lit + 0)) is lit for every fp16 lit but -0, which becomes +0 (a tiny negative GI term rounds to -0 in the blend before) —
+    // exactly what one fp16 add of +0 does (fp16 -> fp32 is exact, a NaN keeps its bits), so the look-ups, products and fp32 blends become
+    // three v_add_f16
     {
-        const Fn e = Fn(3.1415927f);
-        lit[0] = Hn(tof(lit[0]) + (Fn(s_lut[p.emission & 0xffu]) * e).v);
-        lit[1] = Hn(tof(lit[1]) + (Fn(s_lut[(p.emission >> 8) & 0xffu]) * e).v);
-        lit[2] = Hn(tof(lit[2]) + (Fn(s_lut[(p.emission >> 16) & 0xffu]) * e).v);
-        lit[3] = Hn(tof(lit[3]) + 1.0f);
+        if (__any((p.emission & 0xffffffu) != 0u)) {
+            const Fn e = Fn(3.1415927f);
+            lit[0] = Hn(tof(lit[0]) + (Fn(s_lut[p.emission & 0xffu]) * e).v);
+            lit[1] = Hn(tof(lit[1]) + (Fn(s_lut[(p.emission >> 8) & 0xffu]) * e).v);
+            lit[2] = Hn(tof(lit[2]) + (Fn(s_lut[(p.emission >> 16) & 0xffu]) * e).v);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) lit[i] = lit[i] + Hn::lit(0.f);
+        }
+        lit[3] = lit[3] + Hn::lit(1.0f);
     }
     // (5) sky
     if (sky.enabled && inside && !surface) sky_frag(a, sky, x, y, lit);

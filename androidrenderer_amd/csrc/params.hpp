@@ -33,6 +33,8 @@ struct CacheArgs {
     float cascade_min[4][3];
     float cascade_max[4][3];  // min + (32,8,32) * spacing
     float spacing[4];
+    float inv_spacing[4];   // 1 / spacing
+    uint32_t spacing_pow2;  // every spacing is a normal power of two: x / spacing == x * inv_spacing, bit for bit (an exact scaling either way)
     uint32_t probe_size[2];
     float inv_tex[2];  // RN(1 / (32 * (probe_size + 2))): the irradiance atlas extent in texels, for div_const()
     uint32_t debug_mode;

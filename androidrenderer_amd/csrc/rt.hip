@@ -945,7 +945,7 @@ SAH_DEV GiPayload trace_gi(const RtBvh& bvh, const RtScene& sc, const Trav& tv, 
             const float d[3] = {dir.x.v, dir.y.v, dir.z.v};
             const GiPayload next = trace_gi<MAXB - 1, true>(bvh, sc, tv, g, make_ray(loc, d, 0.05f, 100000.0f), dx, dy, remaining - 1u);
             const H3 dh = {Hn(dir.x.v), Hn(dir.y.v), Hn(dir.z.v)};
-            const H3 bounce_brdf = Fd(s, dh, s.normal);  // brdf(surface, bounce_ray.Direction, surface.normal)
+            const H3 bounce_brdf = brdf_sl(s, dh, s.normal);  // brdf(surface, bounce_ray.Direction, surface.normal) = Fd + Fr (the sun term above is Fd alone)
             const Hn bounce_ndotl = Hn(nclamp(dot(dir, to_f(s.normal)), Fn(0.f), Fn(1.f)).v);
             const F3 radiance = to_f(bounce_brdf * bounce_ndotl) * next.irradiance;  // half * half3, then * float3
             const bool finite = finite3r(radiance.x.v, radiance.y.v, radiance.z.v);  // !any(isnan) && !any(isinf)

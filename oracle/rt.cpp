@@ -329,7 +329,7 @@ GiPayload trace_gi(const GiInputs& in, const Ray& r, uint32_t dx, uint32_t dy, u
         if (dot(to_f(surf.normal), ray_direction).v < 0.0f) ray_direction = ray_direction * F(-1.0f);
         const float d[3] = {ray_direction.x.v, ray_direction.y.v, ray_direction.z.v};
         const GiPayload new_payload = trace_gi(in, make_ray(loc, d, 0.05f, 100000.0f), dx, dy, remaining_bounces - 1, true);
-        const H3 bounce_brdf_result = Fd(surf, to_h(ray_direction), surf.normal);
+        const H3 bounce_brdf_result = brdf(surf, to_h(ray_direction), surf.normal);  // brdf() = Fd() + Fr() here, Fd() alone for the sun above (:438)
         const H bounce_ndotl = H(nclamp(dot(ray_direction, to_f(surf.normal)), F(0.0f), F(1.0f)).v);
         const F3 bounce_radiance = to_f(bounce_brdf_result * bounce_ndotl) * new_payload.irradiance;
         const float br[3] = {bounce_radiance.x.v, bounce_radiance.y.v, bounce_radiance.z.v};

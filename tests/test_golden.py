@@ -428,6 +428,36 @@ def test_oracle_matches_golden_rt_gi_rays():
     _check_rt_gi(rb, ri, case.oracle_probe_trace(util.golden_rt_gi_inputs()["probes"]))
 
 
+def _check_rt_gi_bounces(run_rtgi, set_bounces):
+    g = np.load(os.path.join(GOLDEN, "rt_gi_bounces_64x36.npz"))
+    base = np.load(os.path.join(GOLDEN, "rt_gi_64x36.npz"))
+    traced = (np.load(os.path.join(GOLDEN, "rt_64x36.npz"))["depth"] != 0)[..., None]
+    try:
+        for nb in (1, 2):
+            set_bounces(nb)
+            rb, ri = run_rtgi()
+            assert np.array_equal(np.where(traced, rb.view(np.uint16), 0), base["ray_buffer"])  # directions, first-hit distances: as without
+            got, want = np.where(traced, ri.view(np.uint16), 0), g[f"ray_irradiance_{nb}"]
+            assert np.array_equal(got, want), f"{nb} bounce(s): {int((got != want).any(-1).sum())} texels differ"
+            assert (want.view(np.float16).astype(np.float32) > base["ray_irradiance"].view(np.float16).astype(np.float32)).any()
+    finally:
+        set_bounces(0)
+
+
+def test_oracle_matches_golden_rt_gi_bounces():
+    """the bounce branch of the GI hit stage (gltf_basic_pbr.slang:481-517; brdf() = Fd + Fr there, Fd alone for the sun) against the numpy
+    restatement, 1 and 2 bounces"""
+    case, _ = _rt_fixture()
+    _check_rt_gi_bounces(case.oracle_rtgi, lambda n: util.oracle().orc_rt_set_bounces(n))
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_rt_gi_bounces(hip_ctx):
+    case, _ = _rt_fixture()
+    case.hip_build(hip_ctx)
+    _check_rt_gi_bounces(lambda: case.hip_rtgi(hip_ctx), hip_ctx.rt_set_bounces)
+
+
 @pytest.mark.gpu
 def test_hip_matches_golden_rt_gi_rays(hip_ctx):
     case, _ = _rt_fixture()

@@ -1629,9 +1629,9 @@ def rt_any_hit(arrays, tris, pad, o, d, tmin, tmax, cull_non_opaque, cull_front=
     return hit
 
 
-def rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax):
-    """RAY_FLAG_NONE: per ray the accepted candidate of smallest t, ties to the smallest (primitive, triangle).
-    Returns (index into tris or -1, t, b1, b2, front)."""
+def rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax, bounce=False):
+    """RAY_FLAG_NONE (bounce: RAY_FLAG_CULL_NON_OPAQUE | RAY_FLAG_CULL_BACK_FACING_TRIANGLES, gltf_basic_pbr.slang:498-506): per ray the accepted
+    candidate of smallest t, ties to the smallest (primitive, triangle).  Returns (index into tris or -1, t, b1, b2, front)."""
     rays = _RtRays(o, d, tmin, tmax)
     n = rays.n
     best = np.full(n, -1, np.int64)
@@ -1639,7 +1639,11 @@ def rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax):
     bfront = np.zeros(n, bool)
     bprim, btri = np.full(n, 1 << 40, np.int64), np.full(n, 1 << 40, np.int64)
     for i, t in enumerate(tris):
+        if bounce and t["cutout"]:
+            continue
         cand, tt, b1, b2, front = rays.candidates(t, pad)
+        if bounce:
+            cand = cand & front
         better = cand & ((best < 0) | (tt < bt) | ((tt == bt) & ((t["primitive"] < bprim) | ((t["primitive"] == bprim) & (t["triangle"] < btri)))))
         if t["cutout"] and better.any():
             better = better & rt_cutout_accepts(arrays, t, b1, b2)
@@ -1757,11 +1761,12 @@ def fd_general(base, n, rough, metal, l, v, rnd):
     return [np.where(dark, f32(0), r(diff[i] * fdv)) for i in range(3)]
 
 
-def rt_trace_gi(arrays, tris, pad, o, d, tmin, tmax, sun, sky_v, sky_t, noise, dx, dy):
-    """TraceRay(RAY_FLAG_NONE, RAY_TYPE_GI) with remaining_bounces = 0: the closest-hit stage of gltf_basic_pbr.slang:372-520 or the miss stage
-    of sky_unified.slang:227-230.  o, d: (N, 3); dx, dy: DispatchRaysIndex().xy per ray.  Returns (irradiance (N, 3) fp32, ray_distance (N,))."""
+def rt_trace_gi(arrays, tris, pad, o, d, tmin, tmax, sun, sky_v, sky_t, noise, dx, dy, remaining=0, bounce=False):
+    """TraceRay(RAY_TYPE_GI) with payload.remaining_bounces = `remaining` (the reference's generators: 0): the closest-hit stage of
+    gltf_basic_pbr.slang:372-520 or the miss stage of sky_unified.slang:227-230.  `bounce`: the ray is a hit stage's bounce ray (its flags).
+    o, d: (N, 3); dx, dy: DispatchRaysIndex().xy per ray.  Returns (irradiance (N, 3) fp32, ray_distance (N,))."""
     n = o.shape[0]
-    best, t, b1, b2, front = rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax)
+    best, t, b1, b2, front = rt_closest_hit(arrays, tris, pad, o, d, tmin, tmax, bounce)
     irr, dist = np.zeros((n, 3), f32), np.zeros(n, f32)
     finite = np.isfinite(o).all(axis=1) & np.isfinite(d).all(axis=1)
     miss = (best < 0) & finite
@@ -1821,14 +1826,26 @@ def rt_trace_gi(arrays, tris, pad, o, d, tmin, tmax, sun, sky_v, sky_t, noise, d
                 # ACCEPT_FIRST_HIT_AND_END_SEARCH | CULL_NON_OPAQUE | CULL_FRONT_FACING_TRIANGLES
                 occluded = rt_any_hit(arrays, tris, pad, loc[lit], sdir, 0.05, 100000.0, cull_non_opaque=True, cull_front=True)
                 shadow[lit] = np.where(occluded, f32(0), f32(1))
+            val = [F(F(F(F(brdf_result[c] * f32(sun.color[c])) * ndotl) * shadow) + emission[c]) for c in range(3)]
+            if remaining > 0:  # :481-517 (a back-face hit is zeroed below whatever the bounce brings)
+                nz = rt_noise(noise, dx[sel] % 128, dy[sel] % 128)
+                nf = [nh[k].astype(f32) for k in range(3)]
+                flip = F(F(F(nf[0] * nz[:, 0]) + F(nf[1] * nz[:, 1])) + F(nf[2] * nz[:, 2])) < 0
+                bd = np.where(flip[:, None], F(nz * f32(-1)), nz)
+                nirr, _ = rt_trace_gi(arrays, tris, pad, loc, bd, 0.05, 100000.0, sun, sky_v, sky_t, noise, dx[sel], dy[sel], remaining - 1, True)
+                bl = [h(bd[:, k]) for k in range(3)]
+                bb = brdf(base, nh, rough, metal, bl, nh, h)  # brdf(surface, bounce_ray.Direction, surface.normal) = Fd + Fr
+                bndotl = h(np.fmin(np.fmax(F(F(F(bd[:, 0] * nf[0]) + F(bd[:, 1] * nf[1])) + F(bd[:, 2] * nf[2])), f32(0)), f32(1)))
+                rad = np.stack([F(h(bndotl * bb[c]).astype(f32) * nirr[:, c]) for c in range(3)], axis=-1)
+                fin = np.isfinite(rad).all(axis=1)
+                val = [np.where(fin, F(val[c] + rad[:, c]), val[c]) for c in range(3)]
             for c in range(3):
-                v = F(F(F(F(brdf_result[c] * f32(sun.color[c])) * ndotl) * shadow) + emission[c])
-                irr[sel, c] = np.where(front[sel], v, f32(0))  # HIT_KIND_TRIANGLE_BACK_FACE: black ...
+                irr[sel, c] = np.where(front[sel], val[c], f32(0))  # HIT_KIND_TRIANGLE_BACK_FACE: black ...
             dist[sel] = np.where(front[sel], t[sel], F(t[sel] * f32(-1)))  # ... and a negative distance
     return irr, dist
 
 
-def rtgi_trace(arrays, view, sun, sky_v, sky_t, depth, normals16, noise):
+def rtgi_trace(arrays, view, sun, sky_v, sky_t, depth, normals16, noise, bounces=0):
     """rtgi.rt.slang:56-110 -> (ray_buffer, ray_irradiance) as (H, W, 4) float16; texels the generator skips stay 0"""
     Hh, W = depth.shape
     tris, pad = rt_world_triangles(arrays)
@@ -1841,7 +1858,7 @@ def rtgi_trace(arrays, view, sun, sky_v, sky_t, depth, normals16, noise):
         flip = F(F(F(nrm[:, 0] * d[:, 0]) + F(nrm[:, 1] * d[:, 1])) + F(nrm[:, 2] * d[:, 2])) < 0
         d = np.where(flip[:, None], F(d * f32(-1)), d)
     idx = np.nonzero(go)[0]
-    irr, dist = rt_trace_gi(arrays, tris, pad, pos[idx], d[idx], 0.01, 100000.0, sun, sky_v, sky_t, noise, xs.reshape(-1)[idx], ys.reshape(-1)[idx])
+    irr, dist = rt_trace_gi(arrays, tris, pad, pos[idx], d[idx], 0.01, 100000.0, sun, sky_v, sky_t, noise, xs.reshape(-1)[idx], ys.reshape(-1)[idx], bounces)
     irr = np.where(np.isnan(irr).any(axis=1)[:, None], f32(0), irr)
     rb, ri = np.zeros((Hh * W, 4), np.float16), np.zeros((Hh * W, 4), np.float16)
     with np.errstate(over="ignore"):
@@ -1924,6 +1941,15 @@ def golden_rt_gi(m=None, view=None, sun=None, noise=None, gb=None):
     rb, ri = rtgi_trace(arrays, view.gpu_data, sun.constants, gi["sky_v"], gi["sky_t"], gb["depth"], gb["normals"], noise)
     trace = probe_trace(arrays, gi["cascades"], gi["probes"], sun.constants, gi["sky_v"], gi["sky_t"], noise, gi["irr"], gi["pdepth"], gi["val"])
     np.savez_compressed(os.path.join(GOLDEN, f"rt_gi_{W}x{Hh}.npz"), ray_buffer=rb.view(np.uint16), ray_irradiance=ri.view(np.uint16), trace=trace.view(np.uint16))
+    # the same GI rays with the hit stage's bounce branch on (remaining_bounces = 1, 2: sah_rt_set_bounces)
+    b = {}
+    for nb in (1, 2):
+        rb_b, ri_b = rtgi_trace(arrays, view.gpu_data, sun.constants, gi["sky_v"], gi["sky_t"], gb["depth"], gb["normals"], noise, bounces=nb)
+        assert np.array_equal(rb_b.view(np.uint16), rb.view(np.uint16))  # directions and first-hit distances do not depend on the bounces
+        b[f"ray_irradiance_{nb}"] = ri_b.view(np.uint16)
+        print(f"rt gi, {nb} bounce(s): texels brighter than with {nb - 1}:", int((ri_b.astype(f32) > (ri if nb == 1 else prev).astype(f32)).any(-1).sum()))
+        prev = ri_b
+    np.savez_compressed(os.path.join(GOLDEN, f"rt_gi_bounces_{W}x{Hh}.npz"), **b)
     d = rb[..., 3].astype(f32)
     td = trace[..., 3].astype(f32)
     print("rt gi ok: rtgi hits", int((d > 0).sum()), "back", int((d < 0).sum()), "misses", int((d == 0).sum()), "; probe rays front", int((td > 0).sum()),
