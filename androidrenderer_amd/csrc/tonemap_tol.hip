@@ -405,7 +405,10 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
             const C3 col = {__builtin_fmaf(bloom[a][c].r, 0.014159f, sc.r), __builtin_fmaf(bloom[a][c].g, 0.014159f, sc.g),
                             __builtin_fmaf(bloom[a][c].b, 0.014159f, sc.b)};
             const float luma = __builtin_fmaf(col.b, 0.0722f, __builtin_fmaf(col.g, 0.7152f, col.r * 0.2126f));
-            const float factor = luma / (luma + 1.f);
+            // (tolerance mode: the quotient through v_rcp_f32 and one Newton step on it, within an ulp of the IEEE divide's — the same order
+            // of error as the re-associated sums above, 11 instructions fewer)
+            const float den = luma + 1.f, y0 = __builtin_amdgcn_rcpf(den), q0 = luma * y0;
+            const float factor = __builtin_fmaf(__builtin_fmaf(-den, q0, luma), y0, q0);
             const float rgb[3] = {col.r * factor, col.g * factor, col.b * factor};
             uint32_t code[3];  // the code search of tonemap.hip, one table entry per channel: exact for whatever value reaches it
 #pragma unroll
