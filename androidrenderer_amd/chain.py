@@ -1,6 +1,6 @@
-"""One frame of the sharded full chain on one rank: lighting (own rows + halo) -> copy scene -> bloom mip 0 rows -> exchange of
-mip 0 -> bloom mips 1.. -> tonemap of the rank's final rows -> exchange of the RGBA8 image (androidrenderer_amd/shard.py has the
-row arithmetic).  Plumbing shared by bench.py and tests/: buffers are torch tensors, every pass goes through the C ABI."""
+"""One frame of the sharded full chain on one rank: lighting (own rows + halo) -> copy scene + bloom mip 0 rows (one pass) -> its bloom
+mip 1 rows -> exchange of mip 1 -> bloom mips 2.. -> tonemap of the rank's final rows -> exchange of the RGBA8 image
+(androidrenderer_amd/shard.py has the row arithmetic).  Plumbing shared by bench.py and tests/: buffers are torch tensors, every pass goes through the C ABI."""
 from . import _abi, images, shard
 
 
@@ -22,15 +22,16 @@ class ShardedChain:
         self.lit = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
         self.aa = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
         sizes = images.bloom_mip_sizes(W, H, num_mips)
-        # mip 0 and the final image are gathered in place: equal slots, so their allocations are padded to slots * world rows
-        self.mip0_alloc = torch.zeros((p.mip0_rows_per_rank * world, sizes[0][0], 4), dtype=torch.int16, device=dev)
-        self.mips = [self.mip0_alloc[:sizes[0][1]]] + [torch.zeros((mh, mw, 4), dtype=torch.int16, device=dev) for (mw, mh) in sizes[1:]]
+        # mip 1 and the final image are gathered in place: equal slots, so their allocations are padded to slots * world rows
+        self.mip1_alloc = torch.zeros((p.mip1_rows_per_rank * world, sizes[1][0], 4), dtype=torch.int16, device=dev)
+        self.mips = [torch.zeros((sizes[0][1], sizes[0][0], 4), dtype=torch.int16, device=dev), self.mip1_alloc[:sizes[1][1]]] + \
+                    [torch.zeros((mh, mw, 4), dtype=torch.int16, device=dev) for (mw, mh) in sizes[2:]]
         self.out_alloc = torch.zeros((p.rows_per_rank * world, W, 4), dtype=torch.uint8, device=dev)
         self.out = self.out_alloc[:H]
         self.lit_p = images.plane(self.lit, _abi.FORMAT_R16G16B16A16_SFLOAT)
         self.aa_p = images.plane(self.aa, _abi.FORMAT_R16G16B16A16_SFLOAT)
         self.mc = images.mipchain(self.mips)
-        self.mip0_p = images.plane(self.mips[0], _abi.FORMAT_R16G16B16A16_SFLOAT)
+        self.mip1_p = images.plane(self.mips[1], _abi.FORMAT_R16G16B16A16_SFLOAT)
         self.out_p = images.plane(self.out, _abi.FORMAT_R8G8B8A8_SRGB)
         self.descs = []
         for rows in ((p.lit_rows, p.lit_wrap_rows) if world > 1 else ((0, 0),)):
@@ -42,16 +43,16 @@ class ShardedChain:
         self.world = world
 
     def register_direct_exchange(self, allgather):
-        """Makes the two gathered buffers of this chain (bloom mip 0, final image) visible to the peers: their exchanges then go straight
+        """Makes the two gathered buffers of this chain (bloom mip 1, final image) visible to the peers: their exchanges then go straight
         into every peer's copy (sah_ipc_register) instead of through RCCL.  Every rank must register its chains in the same order."""
-        for t in (self.mip0_alloc, self.out_alloc):
+        for t in (self.mip1_alloc, self.out_alloc):
             nbytes = t.numel() * t.element_size()
             self.ctx.ipc_register(t.data_ptr(), nbytes, allgather(self.ctx.ipc_export(t.data_ptr(), nbytes)))
 
     def unregister_direct_exchange(self):
         """Before the chain's buffers are dropped (every rank, same order): a caching allocator may hand their addresses out again, and a
         registration is found by address."""
-        for t in (self.mip0_alloc, self.out_alloc):
+        for t in (self.mip1_alloc, self.out_alloc):
             self.ctx.ipc_unregister(t.data_ptr())
 
     # the three local stages; `exchange_*` are the two gathers (replaceable: tests emulate several ranks on one device)
@@ -63,18 +64,20 @@ class ShardedChain:
         p = self.plan
         if p.aa_rows[1] > p.aa_rows[0] and p.mip0_rows[1] > p.mip0_rows[0]:  # one pass over lit: antialiased rows + mip 0 rows
             self.ctx.copy_scene_bloom_mip0(self.lit_p, self.aa_p, self.mc, p.aa_rows, p.mip0_rows)
-            return
-        if p.aa_rows[1] > p.aa_rows[0]:
-            self.ctx.copy_scene(self.lit_p, self.aa_p, *p.aa_rows)
-        if p.mip0_rows[1] > p.mip0_rows[0]:
-            self.ctx.bloom_mip0_rows(self.aa_p, self.mc, *p.mip0_rows)
+        else:
+            if p.aa_rows[1] > p.aa_rows[0]:
+                self.ctx.copy_scene(self.lit_p, self.aa_p, *p.aa_rows)
+            if p.mip0_rows[1] > p.mip0_rows[0]:
+                self.ctx.bloom_mip_rows(self.aa_p, self.mc, 0, *p.mip0_rows)
+        if p.mip1_rows[1] > p.mip1_rows[0]:
+            self.ctx.bloom_mip_rows(self.aa_p, self.mc, 1, *p.mip1_rows)
 
-    def exchange_mip0(self):
-        self.ctx.allgather_rows(self.mip0_p, self.plan.mip0_rows_per_rank, self.plan.mip0_rows_per_rank * self.world)
+    def exchange_mip(self):
+        self.ctx.allgather_rows(self.mip1_p, self.plan.mip1_rows_per_rank, self.plan.mip1_rows_per_rank * self.world)
         self.ctx.comm_wait()
 
     def composite(self):
-        self.ctx.bloom_from_mip0(self.aa_p, self.mc)
+        self.ctx.bloom_from_mip(self.aa_p, self.mc, 1)
         if self.plan.out_rows[1] > self.plan.out_rows[0]:
             self.ctx.tonemap(self.aa_p, self.mc, self.out_p, *self.plan.out_rows, flags=self.tonemap_flags)
 
@@ -86,7 +89,7 @@ class ShardedChain:
         self.lighting()
         self.reduce()
         if gather:
-            self.exchange_mip0()
+            self.exchange_mip()
         self.composite()
         if gather:
             self.exchange_final()
@@ -94,8 +97,8 @@ class ShardedChain:
 
 class PipelinedChain:
     """Two frames in flight on one rank, so that both exchanges run beside compute (bench.py, N > 1).  Frame i is split at its first
-    exchange: A(i) = lighting + copy + bloom mip 0 rows, then the mip-0 gather is queued on the communicator's side stream; B(i) = bloom
-    mips 1.. + tonemap, then the gather of the final rows.  Enqueue order: A(0) | A(1) B(0) | A(2) B(1) | ... : the mip-0 gather
+    exchange: A(i) = lighting + copy + bloom mip 0 and mip 1 rows, then the mip-1 gather is queued on the communicator's side stream; B(i) =
+    bloom mips 2.. + tonemap, then the gather of the final rows.  Enqueue order: A(0) | A(1) B(0) | A(2) B(1) | ... : the mip-1 gather
     of frame i travels while A(i + 1) computes, the final gather of frame i while A(i + 2) and B(i + 1) do.  With `second_stream` the
     B halves run on that stream, beside the A half of the next frame: B is mostly the replicated small mips of the bloom pyramid —
     launches of a few hundred texels that leave the chip idle — and at 8 ranks a quarter of a rank's frame (one rank's compute of
@@ -109,7 +112,7 @@ class PipelinedChain:
         self.work2 = second_stream
         self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world, tonemap_flags=tonemap_flags) for _ in range(2)]
         self.plan = self.sets[0].plan
-        self.mip0_done = [None, None]   # event behind the mip-0 gather of the frame that last used the set
+        self.mip_done = [None, None]    # event behind the mip-1 gather of the frame that last used the set
         self.final_done = [None, None]  # ... behind its final-image gather
         self.b_done = [None, None]      # ... behind its B half (second stream only)
         self.submitted = 0
@@ -126,11 +129,11 @@ class PipelinedChain:
             s.unregister_direct_exchange()
 
     def submit(self, lighting_events=None):
-        """Enqueue A(i) and the mip-0 exchange of the next frame, then B(i - 1) and the final exchange of the previous one."""
+        """Enqueue A(i) and the mip-1 exchange of the next frame, then B(i - 1) and the final exchange of the previous one."""
         i = self.submitted
         s = self.sets[i % 2]
-        # A(i) overwrites the set's lit / antialiased / own mip-0 rows: their last readers were B(i - 2) — same stream and earlier, or
-        # waited for here — and the mip-0 gather of frame i - 2 (B(i - 2) waited for it before it ran)
+        # A(i) overwrites the set's lit / antialiased / mip-0 / own mip-1 rows: their last readers were B(i - 2) — same stream and earlier,
+        # or waited for here — and the mip-1 gather of frame i - 2 (B(i - 2) waited for it before it ran)
         if self.work2 is not None and self.b_done[i % 2] is not None:
             self.work.wait_event(self.b_done[i % 2])
         if lighting_events is not None:
@@ -139,8 +142,8 @@ class PipelinedChain:
         if lighting_events is not None:
             lighting_events[1].record(self.work)
         s.reduce()
-        self.ctx.allgather_rows(s.mip0_p, s.plan.mip0_rows_per_rank, s.plan.mip0_rows_per_rank * s.world)  # side stream, behind A(i)
-        self.mip0_done[i % 2] = self.comm_stream.record_event()
+        self.ctx.allgather_rows(s.mip1_p, s.plan.mip1_rows_per_rank, s.plan.mip1_rows_per_rank * s.world)  # side stream, behind A(i)
+        self.mip_done[i % 2] = self.comm_stream.record_event()
         self.submitted += 1
         while self.finished < self.submitted - 1:  # B of the frame before this one (already done if flush() ran in between)
             self._finish(self.finished)
@@ -150,7 +153,7 @@ class PipelinedChain:
         st = self.work2 if self.work2 is not None else self.work
         if self.work2 is not None:
             self.ctx.set_stream(st.cuda_stream)      # the library enqueues B(j), and orders its gather, on the second stream
-        st.wait_event(self.mip0_done[j % 2])         # mips 1.. read every rank's rows of mip 0 (and the gather ran behind A(j))
+        st.wait_event(self.mip_done[j % 2])          # mips 2.. read every rank's rows of mip 1 (and the gather ran behind A(j))
         if self.final_done[j % 2] is not None:       # the final gather of frame j - 2 still reads / writes this set's image
             st.wait_event(self.final_done[j % 2])
         s.composite()

@@ -211,6 +211,24 @@ int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain
     return bloom_range(ctx, scene, bloom, 1, bloom->num_mips - 1, 0, bloom->mips[1].height);
 }
 
+int sah_bloom_mip_rows(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, uint32_t mip, uint32_t row_begin, uint32_t row_end) {
+    SAH_RANGE();
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!bloom || bloom->num_mips == 0 || bloom->num_mips > SAH_MAX_BLOOM_MIPS || mip >= bloom->num_mips)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips and a mip index below their number", SAH_MAX_BLOOM_MIPS);
+    if (row_end > bloom->mips[mip].height || row_begin > row_end) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bad row range");
+    return bloom_range(ctx, scene, bloom, mip, mip, row_begin, row_end);
+}
+
+int sah_bloom_from_mip(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, uint32_t mip) {
+    SAH_RANGE();
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    if (!bloom || bloom->num_mips == 0 || bloom->num_mips > SAH_MAX_BLOOM_MIPS || mip >= bloom->num_mips)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "bloom needs 1..%d mips and a mip index below their number", SAH_MAX_BLOOM_MIPS);
+    if (mip + 1 >= bloom->num_mips) return SAH_OK;
+    return bloom_range(ctx, scene, bloom, mip + 1, bloom->num_mips - 1, 0, bloom->mips[mip + 1].height);
+}
+
 int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
     return sah_tonemap_ex(ctx, scene, bloom, out, row_begin, row_end, 0u);
 }

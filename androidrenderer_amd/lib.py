@@ -21,7 +21,7 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_bloom_mip_rows", "sah_bloom_from_mip", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_rt_set_bounces", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
            "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister"]
@@ -55,6 +55,8 @@ def load():
     lib.sah_copy_scene_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)] + [C.c_uint32] * 4
     lib.sah_bloom_mip0_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32]
     lib.sah_bloom_from_mip0.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
+    lib.sah_bloom_mip_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.sah_bloom_from_mip.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32]
     lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_tonemap_ex.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32, C.c_uint32]
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
@@ -148,6 +150,14 @@ class Context:
 
     def bloom_mip0_rows(self, scene, chain, row_begin, row_end):
         self._check(self.lib.sah_bloom_mip0_rows(self.handle, C.byref(scene), C.byref(chain), row_begin, row_end))
+
+    def bloom_mip_rows(self, scene, chain, mip, row_begin, row_end):
+        """rows of mip `mip` from its source (the scene for mip 0, mip - 1 otherwise)"""
+        self._check(self.lib.sah_bloom_mip_rows(self.handle, C.byref(scene), C.byref(chain), mip, row_begin, row_end))
+
+    def bloom_from_mip(self, scene, chain, mip):
+        """mips mip + 1 .. from mip `mip`"""
+        self._check(self.lib.sah_bloom_from_mip(self.handle, C.byref(scene), C.byref(chain), mip))
 
     def bloom_from_mip0(self, scene, chain):
         self._check(self.lib.sah_bloom_from_mip0(self.handle, C.byref(scene), C.byref(chain)))

@@ -10,8 +10,8 @@ LIBRARY's exchange entry point (sah_allgather_rows: RCCL all-gather, on a side s
 the shading of frame i + 1; `--torch-gather` uses torch.distributed instead, `--no-overlap` / `--no-gather` are diagnostics);
 total work is fixed => "scaling": "strong".
 The `*_chain` workloads are the whole frame: lighting, copy scene, bloom pyramid, tonemap composite.  At N > 1 they run the sharded
-chain of androidrenderer_amd/chain.py: every rank shades its rows (+ halo), reduces them to its rows of bloom mip 0, all ranks
-exchange the half-resolution mip 0, build the small mips redundantly, composite their rows of the final image and exchange the
+chain of androidrenderer_amd/chain.py: every rank shades its rows (+ halo), reduces them to its rows of bloom mips 0 and 1, all ranks
+exchange the quarter-resolution mip 1, build the smaller mips redundantly, composite their rows of the final image and exchange the
 RGBA8 rows — in reversed rank order, because the composite samples the scene upside down.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` (dominant kernel vs HBM peak,
@@ -465,9 +465,9 @@ def main():
         sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world, tonemap_flags=tm_flags)
         if use_ipc:
             sc.register_direct_exchange(allgather_handles)
-        q, per = sc.plan.mip0_rows_per_rank, sc.plan.rows_per_rank
-        mip0_bytes, out_bytes = sc.mip0_alloc.view(torch.uint8).view(-1), sc.out_alloc.view(-1)
-        mip0_slot_bytes, out_slot_bytes = q * sc.mip0_alloc.shape[1] * 8, per * W * 4
+        q, per = sc.plan.mip1_rows_per_rank, sc.plan.rows_per_rank
+        mip_bytes, out_bytes = sc.mip1_alloc.view(torch.uint8).view(-1), sc.out_alloc.view(-1)
+        mip_slot_bytes, out_slot_bytes = q * sc.mip1_alloc.shape[1] * 8, per * W * 4
         if traced is not None and world > 1:
             trace_rows[:] = [r for r in (tuple(sc.plan.lit_rows), tuple(sc.plan.lit_wrap_rows)) if r[1] > r[0]]
 
@@ -481,9 +481,9 @@ def main():
                 e1.record()
             sc.reduce()
             if gather and lib_gather:
-                sc.exchange_mip0()
+                sc.exchange_mip()
             elif gather:
-                dist.all_gather_into_tensor(mip0_bytes, mip0_bytes[rank * mip0_slot_bytes:(rank + 1) * mip0_slot_bytes])
+                dist.all_gather_into_tensor(mip_bytes, mip_bytes[rank * mip_slot_bytes:(rank + 1) * mip_slot_bytes])
             sc.composite()
             if gather and lib_gather:
                 sc.exchange_final()
@@ -729,7 +729,7 @@ def main():
         if world == 1:
             par = "single GPU" + (" + one-rank RCCL communicator (rehearsal of the exchange)" if exchange else "")
         elif chain:
-            par = f"row-shard x{world}: lighting rows + halo, all-gather of bloom mip 0, all-gather of the RGBA8 rows (reversed rank order)"
+            par = f"row-shard x{world}: lighting rows + halo, all-gather of bloom mip 1, all-gather of the RGBA8 rows (reversed rank order)"
             if rehearsal:
                 par += " — REHEARSAL: all ranks on one GPU, not a scaling measurement"
         else:

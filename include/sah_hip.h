@@ -263,6 +263,13 @@ int sah_bloom(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bl
  * rank's mip 0 rows have been exchanged (sah_allgather_rows on mips[0]), mips 1.. from mip 0.  Together they write what sah_bloom writes. */
 int sah_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, uint32_t row_begin, uint32_t row_end);
 int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom);
+/* The same split one level down, or at any level: rows [row_begin, row_end) of mip `mip` from its source (the scene for mip 0, mip - 1
+ * otherwise: row j reads source rows 2j - 2 .. 2j + 3, which must be valid), and mips mip + 1 .. from mip `mip`.  A frame sharded by rows
+ * that exchanges mip 1 instead of mip 0 moves a quarter of the bytes: every rank then computes the mip 0 rows its own mip 1 rows and its own
+ * rows of the composite read (androidrenderer_amd/shard.py) — sah_bloom_mip_rows(.., 0, ..) or the fused copy above —,
+ * sah_bloom_mip_rows(.., 1, ..), the exchange of mips[1], sah_bloom_from_mip(.., 1). */
+int sah_bloom_mip_rows(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, uint32_t mip, uint32_t row_begin, uint32_t row_end);
+int sah_bloom_from_mip(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, uint32_t mip);
 
 /* UiPhase::draw_scene_image — RenderCore/render/phase/ui_phase.cpp:98-113; out = R8G8B8A8 (sRGB-encoded).
  * Rows [row_begin,row_end) of the output are written (0,0 = all). */

@@ -46,7 +46,7 @@ def main():
     dev = f.device_arrays()
     # 1. the chain step by step, exchanges on the work stream
     sc = chain.ShardedChain(ctx, f, dev, rank, world)
-    for t in (sc.lit, sc.aa, sc.mip0_alloc):
+    for t in (sc.lit, sc.aa, sc.mips[0], sc.mip1_alloc):
         t.fill_(0x7E01)  # an fp16 NaN: a row nobody computed or received shows
     sc.out_alloc.fill_(0x5A)
     if not rccl:

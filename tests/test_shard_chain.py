@@ -22,19 +22,33 @@ def test_plans_cover_the_frame_and_their_dependencies():
             plans = [shard.chain_plan(H, N, r) for r in range(N)]
             outs = sorted(p.out_rows for p in plans)
             assert sum(b - a for a, b in outs) == H and all(x[1] == y[0] or y[1] == y[0] for x, y in zip(outs, outs[1:]))
-            assert sum(p.mip0_rows[1] - p.mip0_rows[0] for p in plans) == max(1, H // 2)
+            h0 = max(1, H // 2)
+            h1 = max(1, h0 // 2)
+            assert sum(p.mip1_rows[1] - p.mip1_rows[0] for p in plans) == h1  # mip 1 is partitioned (and gathered) ...
+            assert all(p.mip0_height == h0 and p.mip1_height == h1 for p in plans)
             for p in plans:
                 assert p.out_rows == shard._clip(p.out_slot * p.rows_per_rank, (p.out_slot + 1) * p.rows_per_rank, H)
-                for y in range(*p.out_rows):  # composite: scene row H - 1 - y and its neighbours (clamped at the edges)
+                for y in range(*p.out_rows):  # composite: scene row H - 1 - y and its neighbours (clamped at the edges) ...
                     assert p.aa_rows[0] <= max(H - 2 - y, 0) and min(H - y, H - 1) < p.aa_rows[1]
+                    # ... and the mip 0 rows its tent taps can touch: v = 1 - (y + 0.5) / H, one texel either side, each a bilinear pair
+                    pos = (1.0 - (y + 0.5) / H) * h0 - 0.5
+                    lo, hi = int(np.floor(pos - 1.0 - 1e-3)), int(np.floor(pos + 1.0 + 1e-3)) + 1
+                    assert p.mip0_rows[0] <= min(max(lo, 0), h0 - 1) and min(max(hi, 0), h0 - 1) < p.mip0_rows[1]
+                def sources(j, hs, hd):  # rows within two texels of the tap centre, with the bilinear partner
+                    c = (j + 0.5) * hs / hd - 0.5
+                    return min(max(int(np.floor(c - 2.0 - 1e-3)), 0), hs - 1), min(max(int(np.floor(c + 2.0 + 1e-3)) + 1, 0), hs - 1)
+                for j in range(*p.mip1_rows):  # ... mip 0 is not: every rank computes the rows its mip 1 rows read
+                    lo, hi = sources(j, h0, h1)
+                    assert p.mip0_rows[0] <= lo and hi < p.mip0_rows[1]
                 for j in range(*p.mip0_rows):
-                    assert p.aa_rows[0] <= max(2 * j - 2, 0) and min(2 * j + 3, H - 1) < p.aa_rows[1]
+                    lo, hi = sources(j, H, h0)
+                    assert p.aa_rows[0] <= lo and hi < p.aa_rows[1]
                 have = set(range(*p.lit_rows)) | set(range(*p.lit_wrap_rows))
                 for j in range(*p.aa_rows):  # the copy's sampler repeats: row -1 is row H - 1, row H is row 0
                     assert {(j - 1) % H, j, (j + 1) % H} <= have
 
 
-def _oracle_chain_rank(f, plan, gather_mip0, gather_final):
+def _oracle_chain_rank(f, plan, gather_mip, gather_final):
     """One rank with the oracle as compute: whole-plane oracle passes, then everything outside the rows the plan assigns to this
     rank is poisoned before the next stage may read it."""
     from tests import util
@@ -51,14 +65,18 @@ def _oracle_chain_rank(f, plan, gather_mip0, gather_final):
     aa[:plan.aa_rows[0]] = POISON16
     aa[plan.aa_rows[1]:] = POISON16
     sizes = images.bloom_mip_sizes(W, H, 6)
-    q = plan.mip0_rows_per_rank
-    mip0_alloc = np.full((q * plan.world, sizes[0][0], 4), POISON16, np.uint16)
     mip0 = np.zeros((sizes[0][1], sizes[0][0], 4), np.uint16)
     assert o.orc_bloom_downsample(C.byref(images.plane(aa, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(mip0, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
-    mip0_alloc[plan.mip0_rows[0]:plan.mip0_rows[1]] = mip0[plan.mip0_rows[0]:plan.mip0_rows[1]]
-    gather_mip0(mip0_alloc, q)
-    mips = [np.ascontiguousarray(mip0_alloc[:sizes[0][1]])] + [np.zeros((mh, mw, 4), np.uint16) for (mw, mh) in sizes[1:]]
-    for m in range(1, 6):
+    mip0[:plan.mip0_rows[0]] = POISON16  # mip 0 is not exchanged: the rank has the rows it computed for itself and nothing else
+    mip0[plan.mip0_rows[1]:] = POISON16
+    q = plan.mip1_rows_per_rank
+    mip1_alloc = np.full((q * plan.world, sizes[1][0], 4), POISON16, np.uint16)
+    mip1 = np.zeros((sizes[1][1], sizes[1][0], 4), np.uint16)
+    assert o.orc_bloom_downsample(C.byref(images.plane(mip0, _abi.FORMAT_R16G16B16A16_SFLOAT)), C.byref(images.plane(mip1, _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
+    mip1_alloc[plan.mip1_rows[0]:plan.mip1_rows[1]] = mip1[plan.mip1_rows[0]:plan.mip1_rows[1]]
+    gather_mip(mip1_alloc, q)
+    mips = [mip0, np.ascontiguousarray(mip1_alloc[:sizes[1][1]])] + [np.zeros((mh, mw, 4), np.uint16) for (mw, mh) in sizes[2:]]
+    for m in range(2, 6):
         assert o.orc_bloom_downsample(C.byref(images.plane(mips[m - 1], _abi.FORMAT_R16G16B16A16_SFLOAT)),
                                       C.byref(images.plane(mips[m], _abi.FORMAT_R16G16B16A16_SFLOAT))) == 0
     out_alloc = np.full((plan.rows_per_rank * plan.world, W, 4), 0x5A, np.uint8)
@@ -117,6 +135,31 @@ def test_sharded_chain_over_gloo_equals_unsharded(tmp_path, height):
         assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), ref), f"rank {r}: final image differs from the unsharded chain"
 
 
+@pytest.mark.parametrize("height,world", [(150, 3), (37, 3), (149, 4), (75, 8)])
+def test_oracle_sharded_chain_with_emulated_ranks(height, world):
+    """every rank in turn with the oracle as compute and poisoned rows outside its plan (no processes: the mip-1 slots of a first pass are
+    handed to the second) — odd heights, where a mip is not exactly half of its source and the downsample's rows drift"""
+    f, ref = _frame(height), _unsharded_oracle(height)
+    slots = {}
+
+    def run(rank, collect):
+        plan = shard.chain_plan(height, world, rank)
+
+        def gather_mip(alloc, q):
+            if collect:
+                slots[rank] = alloc[rank * q:(rank + 1) * q].copy()
+            else:
+                for r, v in slots.items():
+                    alloc[r * q:(r + 1) * q] = v
+        return plan, _oracle_chain_rank(f, plan, gather_mip, lambda alloc, per: None)
+    for r in range(world):
+        run(r, True)
+    for r in range(world):
+        plan, out = run(r, False)
+        rows = slice(*plan.out_rows)
+        assert np.array_equal(out[rows], ref[rows]), f"rank {r} of {world}: its rows of the final image differ from the unsharded chain"
+
+
 # ---- GPU -----------------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
@@ -135,15 +178,15 @@ def test_hip_sharded_chain_with_emulated_ranks(hip_ctx, world):
     want = ref.out.cpu().numpy()
     ranks = [chain.ShardedChain(hip_ctx, f, dev, r, world) for r in range(world)]
     for c in ranks:
-        for t in (c.lit, c.aa, c.mip0_alloc):
+        for t in (c.lit, c.aa, c.mips[0], c.mip1_alloc):
             t.fill_(POISON16)
         c.out_alloc.fill_(0x5A)
         c.lighting()
         c.reduce()
-    for c in ranks:  # exchange 1: rank r's slot r of mip 0 goes to everybody
-        q = c.plan.mip0_rows_per_rank
+    for c in ranks:  # exchange 1: rank r's slot r of mip 1 goes to everybody
+        q = c.plan.mip1_rows_per_rank
         for src in ranks:
-            c.mip0_alloc[src.plan.rank * q:(src.plan.rank + 1) * q] = src.mip0_alloc[src.plan.rank * q:(src.plan.rank + 1) * q]
+            c.mip1_alloc[src.plan.rank * q:(src.plan.rank + 1) * q] = src.mip1_alloc[src.plan.rank * q:(src.plan.rank + 1) * q]
     for c in ranks:
         c.composite()
     for c in ranks:  # exchange 2: rank r's slot world - 1 - r of the final image

@@ -1,5 +1,5 @@
 """One rank's compute of the sharded chain at N ranks, emulated on one GPU without exchanges: one stream against two streams
-(A(i+1) = lighting + copy + mip-0 rows beside B(i) = mips 1-5 + tonemap rows).  usage: chain_two_streams.py [world] [rank] [--strict-tonemap]
+(A(i+1) = lighting + copy + mip-0 and mip-1 rows beside B(i) = mips 2-5 + tonemap rows).  usage: chain_two_streams.py [world] [rank] [--strict-tonemap]
 (the tonemap runs in tolerance mode, as bench.py's chain workloads do, unless --strict-tonemap is given)"""
 import os
 import sys
