@@ -125,6 +125,35 @@ VARIANTS["tiled_skeleton"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_cheb"][
 VARIANTS["tiled_no_lookups"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_depth_lookup"][1] + VARIANTS["tiled_no_irr_taps"][1])
 
 
+# ---- compiler scheduling options on the two lighting translation units (same source, same bits: timing only) ----------------------------
+FLAG_VARIANTS = {
+    "sched_max_ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "sched_max_clause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "sched_iter_ilp": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+    "sched_iter_minreg": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
+    "sched_bias0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
+    "sched_bias100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
+    "sched_no_post": ["-mllvm", "-enable-post-misched=0"],
+    "sched_relaxed_occ": ["-mllvm", "-amdgpu-schedule-relaxed-occupancy=true"],
+}
+for _n in FLAG_VARIANTS:
+    VARIANTS[_n] = (FAST, [])
+# the tiled translation unit alone
+for _n, _f in (("tiled_no_post", ["-mllvm", "-enable-post-misched=0"]),
+               ("tiled_no_post_clause", ["-mllvm", "-enable-post-misched=0", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
+               ("tiled_no_post_ilp", ["-mllvm", "-enable-post-misched=0", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+               ("tiled_clause", ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"])):
+    FLAG_VARIANTS[_n] = _f
+    VARIANTS[_n] = (["lighting_tiled.hip"], [])
+
+
+# ... and of every other translation unit with kernels in it, one at a time
+for _src in ("post.hip", "tonemap_tol.hip", "tonemap.hip", "rt.hip", "raster.hip", "lpv.hip", "probes.hip"):
+    _n = "np_" + _src.split(".")[0]
+    FLAG_VARIANTS[_n] = ["-mllvm", "-enable-post-misched=0"]
+    VARIANTS[_n] = ([_src], [])
+
+
 def build_variant(name):
     sources, patches = VARIANTS[name]
     src_root = os.path.join(OUT, "src", name)
@@ -146,7 +175,8 @@ def build_variant(name):
     for s in base_build.SOURCES:
         if s in sources:
             obj = os.path.join(objdir, s + ".o")
-            subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + base_build.FLAGS + ["-Wno-unused-variable", "-Wno-unused-but-set-variable", "-c", os.path.join(csrc, s), "-o", obj])
+            subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + base_build.FLAGS + (FLAG_VARIANTS[name] if name in FLAG_VARIANTS else base_build.SOURCE_FLAGS.get(s, [])) +
+                                  ["-Wno-unused-variable", "-Wno-unused-but-set-variable", "-c", os.path.join(csrc, s), "-o", obj])
         else:
             obj = os.path.join(base_build.OBJDIR, s + ".o")  # the product build's object
             if not os.path.exists(obj):
