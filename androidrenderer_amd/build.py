@@ -29,7 +29,11 @@ FLAGS += os.environ.get("SAH_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
 # loop) whose order the pre-RA scheduler already fixed around the loads; the post-RA pass re-orders them for a latency model that does not hold
 # at four waves per SIMD and costs 1.8 % on the cache-GI kernel (0.3626 -> 0.3559 ms), 1.0-1.2 % on the light workloads
 # (tools/experiments/r4/r4_sched.sh: eight scheduling options measured; on lighting.hip every one of them loses).  Same instructions, other order.
-SOURCE_FLAGS = {"lighting_tiled.hip": ["-mllvm", "-enable-post-misched=0"]}
+# tonemap*.hip with LLVM's wave-priority pass (s_setprio raised until a wave's loads are out): the composite's waves stage texels from
+# global memory before each filter stage, and the ones still issuing loads then go ahead of the ones that are filtering — tolerance
+# composite 0.1824 -> 0.1793 ms, strict 0.2536 -> 0.2503 (r4_sched3.sh, two alternating runs each); nothing for the ray tracer or the bloom.
+SOURCE_FLAGS = {"lighting_tiled.hip": ["-mllvm", "-enable-post-misched=0"],
+                "tonemap_tol.hip": ["-mllvm", "-amdgpu-set-wave-priority"], "tonemap.hip": ["-mllvm", "-amdgpu-set-wave-priority"]}
 
 
 def _headers_digest():

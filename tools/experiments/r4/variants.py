@@ -147,6 +147,20 @@ for _n, _f in (("tiled_no_post", ["-mllvm", "-enable-post-misched=0"]),
     VARIANTS[_n] = (["lighting_tiled.hip"], [])
 
 
+for _n, _f, _src in (("prio_fast", ["-mllvm", "-amdgpu-set-wave-priority"], ["lighting.hip"]),
+                     ("prio_tiled", ["-mllvm", "-enable-post-misched=0", "-mllvm", "-amdgpu-set-wave-priority"], ["lighting_tiled.hip"]),
+                     ("prio_both", ["-mllvm", "-amdgpu-set-wave-priority"], ["lighting.hip"]),
+                     ("o2_fast", ["-O2"], ["lighting.hip"]),
+                     ("nocluster_fast", ["-mllvm", "-misched-cluster=0"], ["lighting.hip"]),
+                     ("revlocal_fast", ["-mllvm", "-greedy-reverse-local-assignment"], ["lighting.hip"]),
+                     ("clause4_fast", ["-mllvm", "-amdgpu-max-memory-clause=4"], ["lighting.hip"]),
+                     ("prio_post", ["-mllvm", "-amdgpu-set-wave-priority"], ["post.hip", "tonemap_tol.hip"]),
+                     ("prio_tm", ["-mllvm", "-amdgpu-set-wave-priority"], ["tonemap_tol.hip"]),
+                     ("prio_np_tm", ["-mllvm", "-amdgpu-set-wave-priority", "-mllvm", "-enable-post-misched=0"], ["tonemap_tol.hip"]),
+                     ("prio_tm_strict", ["-mllvm", "-amdgpu-set-wave-priority"], ["tonemap.hip"]),
+                     ("prio_rt", ["-mllvm", "-amdgpu-set-wave-priority"], ["rt.hip"])):
+    FLAG_VARIANTS[_n] = _f
+    VARIANTS[_n] = (_src, [])
 # ... and of every other translation unit with kernels in it, one at a time
 for _src in ("post.hip", "tonemap_tol.hip", "tonemap.hip", "rt.hip", "raster.hip", "lpv.hip", "probes.hip"):
     _n = "np_" + _src.split(".")[0]
