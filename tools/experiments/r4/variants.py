@@ -158,7 +158,13 @@ for _n, _f, _src in (("prio_fast", ["-mllvm", "-amdgpu-set-wave-priority"], ["li
                      ("prio_tm", ["-mllvm", "-amdgpu-set-wave-priority"], ["tonemap_tol.hip"]),
                      ("prio_np_tm", ["-mllvm", "-amdgpu-set-wave-priority", "-mllvm", "-enable-post-misched=0"], ["tonemap_tol.hip"]),
                      ("prio_tm_strict", ["-mllvm", "-amdgpu-set-wave-priority"], ["tonemap.hip"]),
-                     ("prio_rt", ["-mllvm", "-amdgpu-set-wave-priority"], ["rt.hip"])):
+                     ("prio_rt", ["-mllvm", "-amdgpu-set-wave-priority"], ["rt.hip"]),
+                     ("tm_prio_ilp", ["-mllvm", "-amdgpu-set-wave-priority", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["tonemap_tol.hip"]),
+                     ("tm_prio_clause", ["-mllvm", "-amdgpu-set-wave-priority", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"], ["tonemap_tol.hip"]),
+                     ("tm_prio_bias100", ["-mllvm", "-amdgpu-set-wave-priority", "-mllvm", "-amdgpu-schedule-metric-bias=100"], ["tonemap_tol.hip"]),
+                     ("tm_prio_revlocal", ["-mllvm", "-amdgpu-set-wave-priority", "-mllvm", "-greedy-reverse-local-assignment"], ["tonemap_tol.hip"]),
+                     ("post_ilp", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["post.hip"]),
+                     ("post_clause", ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"], ["post.hip"])):
     FLAG_VARIANTS[_n] = _f
     VARIANTS[_n] = (_src, [])
 # ... and of every other translation unit with kernels in it, one at a time
