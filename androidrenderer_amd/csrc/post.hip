@@ -2,6 +2,7 @@
 //   RenderCore/shaders/util/copy_with_sampler.frag.slang:9-12
 //   RenderCore/shaders/postprocessing/bloom_downsample.comp:16-52   (host: RenderCore/render/bloomer.cpp:38-262)
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -392,7 +393,19 @@ bool launch_copy_bloom_mip0(const PlaneArg& lit, uint32_t lw, uint32_t lh, const
     if (mip_row_end <= mip_row_begin || (uint64_t)aa.pitch * ah >= (1ull << 31)) return false;
     const CopyBloomArgs g{lit, aa, mip0, lw, lh, aw, ah, mw, mh, mip_row_begin, mip_row_end, aa_row_begin, aa_row_end};
     constexpr int kPpt = 2;
-    if (!copy_bloom_fits<kPpt>(g)) return false;
+    // the fit check walks every tile column and row of the launch (about 18,000 set-ups at 4K): its answer depends on the extents, the lit
+    // pitch and the row ranges only, and a frame loop asks the same question every frame — the last answer is kept per calling thread
+    struct FitKey {
+        uint32_t v[11];
+        bool ok;
+    };
+    static thread_local FitKey last = {{0}, false};
+    const uint32_t key[11] = {lw, lh, aw, ah, mw, mh, mip_row_begin, mip_row_end, aa_row_begin, aa_row_end, lit.pitch};
+    if (memcmp(last.v, key, sizeof(key)) != 0) {
+        memcpy(last.v, key, sizeof(key));
+        last.ok = copy_bloom_fits<kPpt>(g);
+    }
+    if (!last.ok) return false;
     const uint32_t rows = mip_row_end - mip_row_begin;
     hipLaunchKernelGGL(k_copy_bloom_mip0<kPpt>, dim3((mw + kBlW - 1) / kBlW, (rows + 4 * kPpt - 1) / (4 * kPpt)), dim3(256), 0, st, g);
     *err = hipGetLastError();
