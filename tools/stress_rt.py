@@ -12,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from androidrenderer_amd import lib, mesh, synth  # noqa: E402
-from tests import test_rt  # noqa: E402
+from tests import test_rt, util  # noqa: E402
 
 
 def main():
@@ -48,13 +48,20 @@ def main():
         c.cascade_spacing = float(g.choice([0.25, 0.5, 2.0]))
         c.cascade_centre = tuple(float(v) for v in g.uniform(-1.0, 1.0, 3))
         ids = g.integers(0, 32, (int(g.choice([6, 16])), 3)).astype(np.uint32)
-        pt_h, pt_o = c.hip_probe_trace(ctx, ids), c.oracle_probe_trace(ids)
-        (rb_h, ri_h), (rb_o, ri_o) = c.hip_rtgi(ctx), c.oracle_rtgi()
+        bounces = int(g.choice([0, 0, 1, 2]))  # the GI hit stage's bounce branch (sah_rt_set_bounces; the reference's generators: 0)
+        util.oracle().orc_rt_set_bounces(bounces)
+        ctx.rt_set_bounces(bounces)
+        try:
+            pt_h, pt_o = c.hip_probe_trace(ctx, ids), c.oracle_probe_trace(ids)
+            (rb_h, ri_h), (rb_o, ri_o) = c.hip_rtgi(ctx), c.oracle_rtgi()
+        finally:
+            util.oracle().orc_rt_set_bounces(0)
+            ctx.rt_set_bounces(0)
         d_gi = int((pt_h.view(np.uint16) != pt_o.view(np.uint16)).sum()) + int((rb_h.view(np.uint16) != rb_o.view(np.uint16)).sum()) + \
             int((ri_h.view(np.uint16) != ri_o.view(np.uint16)).sum())
         dist = pt_o.astype(np.float32)[..., 3]
         bad += bool(d_ao or d_mk or d_gi)
-        print(f"case {case:3d}: {stats[0]:5d} triangles ({stats[1]} left out), {stats[2]} levels, {W}x{H}, spp {spp}, radius {radius}: "
+        print(f"case {case:3d}: {stats[0]:5d} triangles ({stats[1]} left out), {stats[2]} levels, {W}x{H}, spp {spp}, radius {radius}, {bounces} bounce(s): "
               f"ao occluded {float((ao_o == 0).mean()):.2f}, mask lit {float(np.nanmean(mk_o)):.2f}: "
               f"probe rays front {float((dist > 0).mean()):.2f} back {float((dist < 0).mean()):.2f}: "
               f"{'ok' if not (d_ao or d_mk or d_gi) else f'MISMATCH ao {d_ao} mask {d_mk} gi {d_gi}'}", flush=True)
