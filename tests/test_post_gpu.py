@@ -202,6 +202,31 @@ def test_bloom_in_two_steps_equals_bloom(hip_ctx):
         assert np.array_equal(util.from_torch(a, np.uint16), b)
 
 
+@pytest.mark.parametrize("mip", [0, 1, 2, 5])
+def test_bloom_split_at_any_mip_equals_bloom(hip_ctx, mip):
+    """sah_bloom_mip_rows over a partition of every mip up to `mip` + sah_bloom_from_mip(mip) == sah_bloom — the pyramid cut at the mip a
+    sharded frame exchanges (mip 1 since round 4); odd extents, where a mip is not exactly half of its source"""
+    import torch
+    w, h = 301, 171
+    scene = synth.hdr_scene(w, h, seed=25)
+    want, _ = _run_post_hip(hip_ctx, scene, w, h)
+    sc = util.to_torch(scene.view(np.uint16))
+    mips = [torch.full(m.shape, 0x3C00, dtype=torch.int16, device="cuda") for m in _mips_np(w, h)]
+    chain = images.mipchain(mips)
+    sp = images.plane(sc, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    for m in range(mip + 1):
+        rows = mips[m].shape[0]
+        cuts = sorted({0, rows // 3, rows // 3 + 1, (2 * rows) // 3, rows})
+        for r0, r1 in zip(cuts, cuts[1:]):
+            hip_ctx.bloom_mip_rows(sp, chain, m, r0, r1)
+    hip_ctx.bloom_from_mip(sp, chain, mip)
+    torch.cuda.synchronize()
+    for a, b in zip(mips, want):
+        assert np.array_equal(util.from_torch(a, np.uint16), b)
+    with pytest.raises(Exception):
+        hip_ctx.bloom_mip_rows(sp, chain, 6, 0, 1)  # no such mip
+
+
 @pytest.mark.parametrize("case", ["no_mips", "one_mip", "three_mips", "output_2x", "output_smaller", "wide_21_9"])
 def test_tonemap_unusual_chains(hip_ctx, case):
     """Fewer than six bloom mips (the kernel's staging loads are unconditional: absent mips alias the scene), an output that is not
