@@ -120,6 +120,7 @@ VARIANTS["cbm_no_aa_store"] = (["post.hip"], [("post.hip", "                if (
 VARIANTS["cbm_no_filter"] = (["post.hip"], [("post.hip", "    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it\n    const uint32_t col = tid & 63u, x = bx + col;\n    if (x >= dw) return;",
                                              "    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it\n    const uint32_t col = tid & 63u, x = bx + col;\n    if (x >= dw || g.mw != 77u) return;")])
 VARIANTS["cbm_one_tap_no_filter"] = (["post.hip"], VARIANTS["cbm_one_tap"][1] + VARIANTS["cbm_no_filter"][1])
+VARIANTS["tm_always16"] = (["tonemap_tol.hip"], [("tonemap_tol.hip", "    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL", "    if (false) hipLaunchKernelGGL")])
 VARIANTS["tiled_skeleton"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_cheb"][1] + VARIANTS["tiled_no_depth_dir"][1] + VARIANTS["tiled_no_depth_lookup"][1] +
                               VARIANTS["tiled_no_irr_taps"][1])
 VARIANTS["tiled_no_lookups"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_depth_lookup"][1] + VARIANTS["tiled_no_irr_taps"][1])
