@@ -60,8 +60,11 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // a wave is an 8 x 8 pixel square of the 16 x 16 tile (not four rows of it): the light loop skips a light for the whole wave when no
     // lane is in range, and a compact footprint is in range of fewer lights
-    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u);
-    const uint32_t y = a.row_begin + blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);
+    // Without a light list nothing ties the workgroup to a tile: it is then 32 x 8 pixels, a wave two rows of 32 — plane loads of 128 / 256
+    // contiguous bytes per row instead of eight 32-byte pieces (cache GI in the frame 0.3557 -> 0.3538 ms, the RTGI overlay 0.1290 -> 0.1232;
+    // 64 x 1 and 16 x 4 waves measured within 0.5 % of it: tools/experiments/r4/README.md)
+    const uint32_t x = LIGHTS ? blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u) : blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = a.row_begin + (LIGHTS ? blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u) : blockIdx.y * 8u + (threadIdx.x >> 5));
     const bool inside = x < a.width && y < a.row_end;
 
     Px p;
@@ -362,7 +365,7 @@ static hipError_t launch_tiled_lights(const LightingArgs& a, const CsmArgs& csm,
     if (rows == 0 || a.width == 0) return hipSuccess;
     const dim3 grid((a.width + 15) / 16, (rows + 15) / 16), block(256);
     if (a.num_lights) hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, true>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, brute ? 1u : 0u, f, fast_geom);
-    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), grid, block, 0, st, a, csm, lpv, cache, rtgi, sky, 0u, f, fast_geom);
+    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), dim3((a.width + 31) / 32, (rows + 7) / 8), block, 0, st, a, csm, lpv, cache, rtgi, sky, 0u, f, fast_geom);
     return hipGetLastError();
 }
 

@@ -120,6 +120,16 @@ VARIANTS["cbm_no_aa_store"] = (["post.hip"], [("post.hip", "                if (
 VARIANTS["cbm_no_filter"] = (["post.hip"], [("post.hip", "    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it\n    const uint32_t col = tid & 63u, x = bx + col;\n    if (x >= dw) return;",
                                              "    // 3. the mip 0 tile, as k_bloom_downsample_lds filters it\n    const uint32_t col = tid & 63u, x = bx + col;\n    if (x >= dw || g.mw != 77u) return;")])
 VARIANTS["cbm_one_tap_no_filter"] = (["post.hip"], VARIANTS["cbm_one_tap"][1] + VARIANTS["cbm_no_filter"][1])
+# the tiled kernel WITHOUT a light list as 64 x 1 pixel strips per wave (64 x 4 per workgroup) instead of 8 x 8 squares in a 16 x 16 tile
+for _n, _xy, _grid in (("tiled_strips_64x1", ("blockIdx.x * 64u + (threadIdx.x & 63u)", "blockIdx.y * 4u + (threadIdx.x >> 6)"), "dim3((a.width + 63) / 64, (rows + 3) / 4)"),
+                       ("tiled_strips_32x2", ("blockIdx.x * 32u + (threadIdx.x & 31u)", "blockIdx.y * 8u + (threadIdx.x >> 5)"), "dim3((a.width + 31) / 32, (rows + 7) / 8)"),
+                       ("tiled_strips_16x4", ("blockIdx.x * 16u + (threadIdx.x & 15u)", "blockIdx.y * 16u + (threadIdx.x >> 4)"), "dim3((a.width + 15) / 16, (rows + 15) / 16)")):
+    VARIANTS[_n] = (["lighting_tiled.hip"], [
+        ("lighting_tiled.hip", "    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u);\n"
+         "    const uint32_t y = a.row_begin + blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u);",
+         "    const uint32_t x = LIGHTS ? blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u) : " + _xy[0] + ";\n"
+         "    const uint32_t y = a.row_begin + (LIGHTS ? blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u) : " + _xy[1] + ");"),
+        ("lighting_tiled.hip", "    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), grid, block,", "    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), " + _grid + ", block,")])
 VARIANTS["tm_always16"] = (["tonemap_tol.hip"], [("tonemap_tol.hip", "    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL", "    if (false) hipLaunchKernelGGL")])
 VARIANTS["tiled_skeleton"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_cheb"][1] + VARIANTS["tiled_no_depth_dir"][1] + VARIANTS["tiled_no_depth_lookup"][1] +
                               VARIANTS["tiled_no_irr_taps"][1])
