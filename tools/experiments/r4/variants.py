@@ -130,6 +130,12 @@ for _n, _xy, _grid in (("tiled_strips_64x1", ("blockIdx.x * 64u + (threadIdx.x &
          "    const uint32_t x = LIGHTS ? blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u) : " + _xy[0] + ";\n"
          "    const uint32_t y = a.row_begin + (LIGHTS ? blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u) : " + _xy[1] + ");"),
         ("lighting_tiled.hip", "    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), grid, block,", "    else hipLaunchKernelGGL((k_lighting_tiled<SUN, GI, false>), " + _grid + ", block,")])
+# the tiled kernel WITH a light list: waves of 16 x 4 pixels of the 16 x 16 tile instead of 8 x 8 squares
+VARIANTS["tiled_lights_16x4"] = (["lighting_tiled.hip"], [
+    ("lighting_tiled.hip", "    const uint32_t x = LIGHTS ? blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u) : blockIdx.x * 32u + (threadIdx.x & 31u);",
+     "    const uint32_t x = LIGHTS ? blockIdx.x * 16u + (threadIdx.x & 15u) : blockIdx.x * 32u + (threadIdx.x & 31u);"),
+    ("lighting_tiled.hip", "    const uint32_t y = a.row_begin + (LIGHTS ? blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u) : blockIdx.y * 8u + (threadIdx.x >> 5));",
+     "    const uint32_t y = a.row_begin + (LIGHTS ? blockIdx.y * 16u + (threadIdx.x >> 4) : blockIdx.y * 8u + (threadIdx.x >> 5));")])
 VARIANTS["tm_always16"] = (["tonemap_tol.hip"], [("tonemap_tol.hip", "    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL", "    if (false) hipLaunchKernelGGL")])
 VARIANTS["tiled_skeleton"] = (["lighting_tiled.hip"], VARIANTS["tiled_no_cheb"][1] + VARIANTS["tiled_no_depth_dir"][1] + VARIANTS["tiled_no_depth_lookup"][1] +
                               VARIANTS["tiled_no_irr_taps"][1])
