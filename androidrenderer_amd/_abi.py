@@ -30,6 +30,7 @@ LIGHTING_BRUTE_FORCE_LIGHTS = 1 << 1
 LIGHTING_DEFAULT_FLAGS = LIGHTING_QUIRK_SUN_BLEND
 MAX_BLOOM_MIPS = 8
 TONEMAP_TOLERANCE_1CODE = 1 << 0
+GENERATION_TRACKED = 0xFFFFFFFF  # sah_gi::lpv_generation / probe_generation: the context keeps its gather copies current itself
 
 
 class Plane(C.Structure):
@@ -159,6 +160,18 @@ class LightingDesc(C.Structure):
                 ("shadow_mask", C.POINTER(Plane)), ("lights", C.POINTER(LightList)), ("gi", C.POINTER(GI)),
                 ("sky", C.POINTER(SkyLuts)), ("flags", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32)]
 
+
+class ChainPlan(C.Structure):  # sah_chain_plan
+    _fields_ = [("aa_rows", C.c_uint32 * 2), ("mip0_rows", C.c_uint32 * 2), ("mip1_rows", C.c_uint32 * 2), ("out_rows", C.c_uint32 * 2),
+                ("mip1_rows_per_rank", C.c_uint32), ("mip1_allocated_rows", C.c_uint32), ("rows_per_rank", C.c_uint32),
+                ("out_allocated_rows", C.c_uint32)]
+
+
+class ChainFrame(C.Structure):  # sah_chain_frame
+    _fields_ = [("lighting", C.POINTER(LightingDesc) * 2), ("lit", Plane), ("antialiased", Plane), ("bloom", MipChain), ("out", Plane)]
+
+
+CHAIN_NO_EXCHANGE = 1 << 0
 
 assert C.sizeof(ViewData) == 432
 assert C.sizeof(SunLightConstants) == 640

@@ -18,7 +18,7 @@ CSRC = os.environ.get("SAH_HIP_CSRC") or os.path.join(HERE, "csrc")  # (experime
 INCLUDE = os.path.join(HERE, "..", "include")
 OUT = os.environ.get("SAH_HIP_LIBRARY") or os.path.join(HERE, "libsah_hip.so")
 OBJDIR = os.path.join(HERE, "_build", os.path.splitext(os.path.basename(OUT))[0])  # one object directory per output (A/B builds)
-SOURCES = ["api.cpp", "api_post.cpp", "api_raster.cpp", "api_rt.cpp", "rt.hip", "api_ipc.cpp", "ipc.hip", "lighting.hip", "lighting_tiled.hip", "post.hip", "tonemap.hip", "tonemap_tol.hip", "lpv.hip",
+SOURCES = ["api.cpp", "api_post.cpp", "api_raster.cpp", "api_rt.cpp", "rt.hip", "api_ipc.cpp", "api_chain.cpp", "ipc.hip", "lighting.hip", "lighting_tiled.hip", "post.hip", "tonemap.hip", "tonemap_tol.hip", "lpv.hip",
            "probes.hip", "sky_luts.hip", "raster.hip", "vpl.hip"]
 # -fno-slp-vectorize: on MI355X v_pk_{mul,add,fma}_f32 issue in 4 cycles against 2 for the scalar forms (profiles/r1_valu_issue_cost.txt),
 # so the SLP vectoriser's packed pairs gain nothing and cost the register shuffles that feed them.

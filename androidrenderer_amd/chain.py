@@ -112,6 +112,7 @@ class PipelinedChain:
         self.work2 = second_stream
         self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world, tonemap_flags=tonemap_flags) for _ in range(2)]
         self.plan = self.sets[0].plan
+        self.a_done = [None, None]      # event behind the A half of the frame that last used the set (second stream only)
         self.mip_done = [None, None]    # event behind the mip-1 gather of the frame that last used the set
         self.final_done = [None, None]  # ... behind its final-image gather
         self.b_done = [None, None]      # ... behind its B half (second stream only)
@@ -142,6 +143,8 @@ class PipelinedChain:
         if lighting_events is not None:
             lighting_events[1].record(self.work)
         s.reduce()
+        if self.work2 is not None:  # (without a communicator the gather below enqueues nothing: B(i) is then ordered behind A(i) by this alone)
+            self.a_done[i % 2] = self.work.record_event()
         self.ctx.allgather_rows(s.mip1_p, s.plan.mip1_rows_per_rank, s.plan.mip1_rows_per_rank * s.world)  # side stream, behind A(i)
         self.mip_done[i % 2] = self.comm_stream.record_event()
         self.submitted += 1
@@ -153,6 +156,8 @@ class PipelinedChain:
         st = self.work2 if self.work2 is not None else self.work
         if self.work2 is not None:
             self.ctx.set_stream(st.cuda_stream)      # the library enqueues B(j), and orders its gather, on the second stream
+        if self.work2 is not None:
+            st.wait_event(self.a_done[j % 2])
         st.wait_event(self.mip_done[j % 2])          # mips 2.. read every rank's rows of mip 1 (and the gather ran behind A(j))
         if self.final_done[j % 2] is not None:       # the final gather of frame j - 2 still reads / writes this set's image
             st.wait_event(self.final_done[j % 2])
@@ -174,3 +179,68 @@ class PipelinedChain:
 
     def image(self, frame_index):
         return self.sets[frame_index % 2].out
+
+
+class NativePipelinedChain:
+    """PipelinedChain with the loop inside the library (sah_chain_create / _submit / _flush, csrc/api_chain.cpp): the same enqueue order,
+    waits and exchanges, one ABI call per frame instead of ten plus the stream and event traffic — the host side of a rank's frame drops
+    from 72 us to the cost of the launches themselves (tools/experiments/chain_two_streams.py).  PipelinedChain stays as the statement of the
+    order the tests hold this one against (tests/test_shard_chain.py).  `exchange=False`: both gathers left out (SAH_CHAIN_NO_EXCHANGE: a
+    rank's compute of an N-rank plan on a context of another world size)."""
+
+    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream=None, second_stream=None, tonemap_flags=0, exchange=True):
+        import torch
+        self.ctx, self.torch = ctx, torch
+        self.work = torch.cuda.current_stream()
+        self.work2 = second_stream
+        self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world, tonemap_flags=tonemap_flags) for _ in range(2)]
+        self.plan = p = self.sets[0].plan
+        self.submitted = 0
+        ctx.set_stream(self.work.cuda_stream)
+        if comm_stream is not None:
+            ctx.comm_set_stream(comm_stream.cuda_stream)
+        cp = _abi.ChainPlan()
+        cp.aa_rows[:], cp.mip0_rows[:], cp.mip1_rows[:], cp.out_rows[:] = p.aa_rows, p.mip0_rows, p.mip1_rows, p.out_rows
+        cp.mip1_rows_per_rank, cp.mip1_allocated_rows = p.mip1_rows_per_rank, self.sets[0].mip1_alloc.shape[0]
+        cp.rows_per_rank, cp.out_allocated_rows = p.rows_per_rank, self.sets[0].out_alloc.shape[0]
+        frames = (_abi.ChainFrame * 2)()
+        import ctypes as C
+        for k, s in enumerate(self.sets):
+            for j, (desc, _keep) in enumerate(s.descs[:2]):
+                frames[k].lighting[j] = C.pointer(desc)
+            frames[k].lit, frames[k].antialiased, frames[k].bloom, frames[k].out = s.lit_p, s.aa_p, s.mc, s.out_p
+        self.handle = ctx.chain_create(cp, frames, tonemap_flags, 0 if exchange else _abi.CHAIN_NO_EXCHANGE, self.work.cuda_stream,
+                                       second_stream.cuda_stream if second_stream is not None else None)
+
+    def register_direct_exchange(self, allgather):
+        for s in self.sets:
+            s.register_direct_exchange(allgather)
+
+    def unregister_direct_exchange(self):
+        for s in self.sets:
+            s.unregister_direct_exchange()
+
+    def submit(self, lighting_events=None):
+        if lighting_events is not None:
+            e0, e1 = lighting_events
+            self.ctx.chain_submit(self.handle, e0.cuda_event, e1.cuda_event)
+        else:
+            self.ctx.chain_submit(self.handle)
+        self.submitted += 1
+
+    def flush(self):
+        self.ctx.chain_flush(self.handle)
+
+    def image(self, frame_index):
+        return self.sets[frame_index % 2].out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.chain_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

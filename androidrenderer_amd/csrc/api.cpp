@@ -213,6 +213,22 @@ int sah_create(sah_ctx** out, int device, int rank, int world, const void* comm_
     return SAH_OK;
 }
 
+// Test hook (tests/test_abi_fuzz.py): a context on a machine WITHOUT a HIP device.  Every entry point validates its arguments as it always
+// does and then fails at its first HIP call with SAH_ERR_HIP — which is what the argument fuzz wants to see for every combination of extents,
+// pitches, formats, row ranges and null sub-pointers: a status code, never a fault.  Refused where a device exists (a launch with the fuzz's
+// made-up addresses must not reach a GPU).
+int sah_debug_create_detached(sah_ctx** out) {
+    if (!out) return SAH_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 0) return SAH_ERR_UNSUPPORTED;
+    (void)hipGetLastError();
+    sah_ctx* ctx = new sah_ctx();
+    ctx->device = -1;
+    *out = ctx;
+    return SAH_OK;
+}
+
 void sah_destroy(sah_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -283,6 +299,15 @@ int sah_debug_deferred_pixels(sah_ctx* ctx, uint64_t* out) {
     uint64_t n = 0;
     for (uint16_t c : counts) n += c;  // (the general list only: sky pixels are not counted)
     *out = n;
+    return SAH_OK;
+}
+
+// Debug / test hook: how many times sah_lighting has rebuilt its gather copy of the LPV volumes (k_lpv_pack) and its fp32 copy of the
+// irradiance atlas (k_probe_irr_unpack) in full since the context was made — the change counters of sah_gi exist to keep these at rest.
+int sah_debug_copy_rebuilds(sah_ctx* ctx, uint32_t out[2]) {
+    if (!ctx || !out) return SAH_ERR_INVALID_ARGUMENT;
+    out[0] = ctx->dbg_lpv_packs;
+    out[1] = ctx->dbg_irr_unpacks;
     return SAH_OK;
 }
 
@@ -480,9 +505,10 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         }
         if (cache.hot_ok) {
             const bool reuse = gi.probe_generation != 0 && gi.probe_generation == ctx->irr32_generation &&
-                               memcmp(&cache.irradiance, &ctx->irr32_source, sizeof(cache.irradiance)) == 0;
+                               same_volume(cache.irradiance, ctx->irr32_source);
             if (!reuse) {
                 HIP_TRY(ctx, launch_probe_irr_unpack(cache.irradiance, ctx->irr32, ctx->stream));
+                ctx->dbg_irr_unpacks++;
                 ctx->irr32_generation = gi.probe_generation;
                 ctx->irr32_source = cache.irradiance;
             }
@@ -557,32 +583,25 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         fast.seg_count = (uint16_t*)((uint8_t*)ctx->list + codes_bytes);
         fast.num_segments = nseg;
         fast.seg_stride = seg_stride;
-        if (gi_kind == SAH_GI_LPV) {  // gather copy of the LPV volumes, rebuilt by k_lpv_pack on every call
-            const uint64_t row = (uint64_t)(lpv.red.width + 2 * kLpvPackBorder) * kLpvPackTexel;
-            const uint64_t slice = row * (lpv.red.height + 2 * kLpvPackBorder);
-            const uint64_t total = slice * (lpv.red.depth + 2 * kLpvPackBorder) + 64;  // + slack: the last x-pair is read as 48 bytes
-            if (total >= (1ull << 32)) return fail(ctx, SAH_ERR_UNSUPPORTED, "LPV volumes too large for the packed gather copy");
-            if (ctx->lpv_packed_bytes < total) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
-                ctx->lpv_packed = nullptr;
-                ctx->lpv_packed_bytes = 0;
-                HIP_TRY(ctx, hipMalloc((void**)&ctx->lpv_packed, total));
-                ctx->lpv_packed_bytes = total;
-                ctx->lpv_pack_generation = 0;
-            }
+        if (gi_kind == SAH_GI_LPV) {  // gather copy of the LPV volumes: rebuilt by k_lpv_pack unless the change counter says it stands
+            // (SAH_GENERATION_TRACKED: the last step of sah_lpv_propagate has written it — api_post.cpp)
+            const SahLpvPackLayout pk = sah_lpv_pack_layout(lpv.red.width, lpv.red.height, lpv.red.depth);
+            if (pk.total >= (1ull << 32)) return fail(ctx, SAH_ERR_UNSUPPORTED, "LPV volumes too large for the packed gather copy");
+            HIP_TRY(ctx, sah_lpv_pack_reserve(ctx, pk.total));
             fast.lpv_packed = ctx->lpv_packed;
-            fast.pk_row_pitch = (uint32_t)row;
-            fast.pk_slice_pitch = (uint32_t)slice;
+            fast.pk_row_pitch = pk.row_pitch;
+            fast.pk_slice_pitch = pk.slice_pitch;
             // the copy of the previous call is kept when the caller's change counter says the volumes are the ones it was made from
             const sah::VolumeArg src[3] = {lpv.red, lpv.green, lpv.blue};
             const uint32_t gen = d->gi->lpv_generation;
-            const bool reuse = gen != 0 && gen == ctx->lpv_pack_generation && memcmp(src, ctx->lpv_pack_source, sizeof(src)) == 0;
+            const bool reuse = gen != 0 && gen == ctx->lpv_pack_generation && same_volume(src[0], ctx->lpv_pack_source[0]) &&
+                               same_volume(src[1], ctx->lpv_pack_source[1]) && same_volume(src[2], ctx->lpv_pack_source[2]);
             fast.repack = reuse ? 0u : 1u;
             if (!reuse) {
+                ctx->dbg_lpv_packs++;
                 ctx->lpv_pack_serial++;
                 ctx->lpv_pack_generation = gen;
-                memcpy(ctx->lpv_pack_source, src, sizeof(src));
+                for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = src[i];
             }
             fast.pack_serial = ctx->lpv_pack_serial;
         }

@@ -1,0 +1,230 @@
+// sah_chain_*: one rank's share of the row-sharded frame, two frames in flight, as a loop inside the library (include/sah_hip.h).
+// The order of enqueues, waits and exchanges is the one androidrenderer_amd/chain.py: PipelinedChain defines (and tests/test_shard_chain.py
+// checks against the unsharded chain); what moves here is the host side of it: eight to ten entry points, three stream switches and six
+// event operations per frame cost 72 us when each crossed ctypes, against 0.12 ms of GPU work per rank at eight ranks.
+// No reference counterpart: the reference has one queue and one device (RenderCore/render/backend/render_backend.cpp:135-153).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "../../include/sah_hip.h"
+#include "ctx.hpp"
+
+namespace {
+
+// a sah_lighting_desc with everything it points to on the host, owned
+struct OwnedLighting {
+    bool used = false;
+    sah_lighting_desc d = {};
+    sah_gbuffer gbuffer = {};
+    sah_plane ao = {}, lit = {}, shadow_mask = {};
+    sah_view_data view = {};
+    sah_sun_light_constants sun = {};
+    sah_volume shadowmap = {};
+    sah_light_list lights = {};
+    sah_gi gi = {};
+    sah_lpv_cascade_matrices cascades[4] = {};
+    sah_sky_luts sky = {};
+
+    bool take(const sah_lighting_desc* src) {
+        if (!src) return true;
+        if (!src->gbuffer || !src->lit || !src->view || !src->sun) return false;
+        used = true;
+        d = *src;
+        gbuffer = *src->gbuffer;
+        d.gbuffer = &gbuffer;
+        lit = *src->lit;
+        d.lit = &lit;
+        view = *src->view;
+        d.view = &view;
+        sun = *src->sun;
+        d.sun = &sun;
+        if (src->ao) { ao = *src->ao; d.ao = &ao; }
+        if (src->shadow_mask) { shadow_mask = *src->shadow_mask; d.shadow_mask = &shadow_mask; }
+        if (src->shadowmap) { shadowmap = *src->shadowmap; d.shadowmap = &shadowmap; }
+        if (src->lights) { lights = *src->lights; d.lights = &lights; }
+        if (src->sky) { sky = *src->sky; d.sky = &sky; }
+        if (src->gi) {
+            gi = *src->gi;
+            if (gi.lpv_cascades) {
+                if (gi.lpv_num_cascades > 4) return false;
+                for (uint32_t i = 0; i < gi.lpv_num_cascades; i++) cascades[i] = src->gi->lpv_cascades[i];
+                gi.lpv_cascades = cascades;
+            }
+            d.gi = &gi;
+        }
+        return true;
+    }
+};
+
+struct FrameSet {
+    OwnedLighting lighting[2];
+    sah_plane lit = {}, antialiased = {}, mip1 = {}, out = {};
+    sah_mipchain bloom = {};
+    // behind the A half / the mip-1 gather / the final gather / the B half of the frame that last used the set
+    hipEvent_t a_done = nullptr, mip_done = nullptr, final_done = nullptr, b_done = nullptr;
+    bool mip_valid = false, final_valid = false, b_valid = false;
+};
+
+}  // namespace
+
+struct sah_chain {
+    sah_ctx* ctx = nullptr;
+    sah_chain_plan plan = {};
+    FrameSet sets[2];
+    uint32_t tonemap_flags = 0;
+    bool exchange = true;
+    hipStream_t work = nullptr, post = nullptr;
+    uint64_t submitted = 0, finished = 0;
+};
+
+#define CHAIN_TRY(expr)                  \
+    do {                                 \
+        const int rc_ = (expr);          \
+        if (rc_ != SAH_OK) return rc_;   \
+    } while (0)
+
+static bool rows_nonempty(const uint32_t r[2]) { return r[1] > r[0]; }
+
+// the stream the exchanges are enqueued on (allgather_bytes_impl, api_post.cpp): the side stream if there is one
+static hipStream_t exchange_stream(const sah_ctx* ctx) { return (ctx->comm_stream && ctx->comm_stream != ctx->stream) ? ctx->comm_stream : ctx->stream; }
+
+// B(j): mips 2.. + the composite of the rank's rows + the exchange of the final image
+static int chain_finish(sah_chain* c, uint64_t j) {
+    sah_ctx* ctx = c->ctx;
+    FrameSet& s = c->sets[j & 1];
+    hipStream_t st = c->post ? c->post : c->work;
+    if (c->post) CHAIN_TRY(sah_set_stream(ctx, (void*)st));  // the library enqueues B(j), and orders its gather, on the post stream
+    // mips 2.. read every rank's rows of mip 1 (the gather ran behind A(j) — and where there is nothing to gather, one rank without a
+    // communicator, nothing ran at all: hence a_done); the final gather of frame j - 2 still reads this set's image
+    if (c->post) HIP_TRY(ctx, hipStreamWaitEvent(st, s.a_done, 0));
+    if (s.mip_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.mip_done, 0));
+    if (s.final_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.final_done, 0));
+    CHAIN_TRY(sah_bloom_from_mip(ctx, &s.antialiased, &s.bloom, 1));
+    if (rows_nonempty(c->plan.out_rows)) CHAIN_TRY(sah_tonemap_ex(ctx, &s.antialiased, &s.bloom, &s.out, c->plan.out_rows[0], c->plan.out_rows[1], c->tonemap_flags));
+    if (c->exchange) {
+        CHAIN_TRY(sah_allgather_rows_reversed(ctx, &s.out, c->plan.rows_per_rank, c->plan.out_allocated_rows));
+        HIP_TRY(ctx, hipEventRecord(s.final_done, exchange_stream(ctx)));
+        s.final_valid = true;
+    }
+    if (c->post) {
+        HIP_TRY(ctx, hipEventRecord(s.b_done, st));
+        s.b_valid = true;
+        CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
+    }
+    c->finished++;
+    return SAH_OK;
+}
+
+extern "C" {
+
+int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_frame frames[2], uint32_t tonemap_flags, uint32_t chain_flags,
+                     void* work_stream, void* post_stream, sah_chain** out) {
+    SAH_RANGE();
+    if (!ctx || !plan || !frames || !out) return SAH_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    const uint32_t* ranges[] = {plan->aa_rows, plan->mip0_rows, plan->mip1_rows, plan->out_rows};
+    for (const uint32_t* r : ranges)
+        if (r[1] < r[0]) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "chain plan: a row range ends before it begins");
+    sah_chain* c = new (std::nothrow) sah_chain;
+    if (!c) return fail(ctx, SAH_ERR_HIP, "out of host memory");
+    c->ctx = ctx;
+    c->plan = *plan;
+    c->tonemap_flags = tonemap_flags;
+    c->exchange = !(chain_flags & SAH_CHAIN_NO_EXCHANGE);
+    c->work = (hipStream_t)work_stream;
+    c->post = (post_stream && post_stream != work_stream) ? (hipStream_t)post_stream : nullptr;
+    auto bail = [&](int code, const char* msg) {
+        sah_chain_destroy(c);
+        return fail(ctx, code, "%s", msg);
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) return bail(SAH_ERR_HIP, "hipSetDevice failed");
+    for (int k = 0; k < 2; k++) {
+        const sah_chain_frame& f = frames[k];
+        FrameSet& s = c->sets[k];
+        if (!f.lighting[0] || !s.lighting[0].take(f.lighting[0]) || !s.lighting[1].take(f.lighting[1]))
+            return bail(SAH_ERR_INVALID_ARGUMENT, "chain frame: lighting[0] (with gbuffer, lit, view, sun) is required; at most 4 LPV cascades");
+        if (!f.lit.ptr || !f.antialiased.ptr || !f.out.ptr || f.bloom.num_mips < 2 || f.bloom.num_mips > SAH_MAX_BLOOM_MIPS)
+            return bail(SAH_ERR_INVALID_ARGUMENT, "chain frame: lit, antialiased, out and a bloom chain of at least two mips are required");
+        s.lit = f.lit;
+        s.antialiased = f.antialiased;
+        s.bloom = f.bloom;
+        s.mip1 = f.bloom.mips[1];
+        s.out = f.out;
+        if (c->exchange && ((uint64_t)plan->mip1_rows_per_rank * ctx->world > plan->mip1_allocated_rows || (uint64_t)plan->rows_per_rank * ctx->world > plan->out_allocated_rows))
+            return bail(SAH_ERR_INVALID_ARGUMENT, "chain plan: an allocation holds fewer rows than its gather's equal slots (slot rows * world)");
+        for (hipEvent_t* e : {&s.a_done, &s.mip_done, &s.final_done, &s.b_done})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(SAH_ERR_HIP, "hipEventCreateWithFlags failed");
+    }
+    const int rc = sah_set_stream(ctx, (void*)c->work);
+    if (rc != SAH_OK) {
+        sah_chain_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SAH_OK;
+}
+
+int sah_chain_submit(sah_chain* c, void* lighting_begin, void* lighting_end) {
+    SAH_RANGE();
+    if (!c) return SAH_ERR_INVALID_ARGUMENT;
+    sah_ctx* ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const sah_chain_plan& p = c->plan;
+    FrameSet& s = c->sets[c->submitted & 1];
+    CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
+    // A(i) overwrites the set's lit / antialiased / mip-0 / own mip-1 rows: their last readers were B(i - 2) — same stream and earlier, or
+    // waited for here — and the mip-1 gather of frame i - 2 (B(i - 2) waited for it before it ran)
+    if (c->post && s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.b_done, 0));
+    if (lighting_begin) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_begin, c->work));
+    for (OwnedLighting& l : s.lighting)
+        if (l.used) CHAIN_TRY(sah_lighting(ctx, &l.d));
+    if (lighting_end) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_end, c->work));
+    if (rows_nonempty(p.aa_rows) && rows_nonempty(p.mip0_rows)) {  // one pass over lit: antialiased rows + mip 0 rows
+        CHAIN_TRY(sah_copy_scene_bloom_mip0_rows(ctx, &s.lit, &s.antialiased, &s.bloom, p.aa_rows[0], p.aa_rows[1], p.mip0_rows[0], p.mip0_rows[1]));
+    } else {
+        if (rows_nonempty(p.aa_rows)) CHAIN_TRY(sah_copy_scene_rows(ctx, &s.lit, &s.antialiased, p.aa_rows[0], p.aa_rows[1]));
+        if (rows_nonempty(p.mip0_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 0, p.mip0_rows[0], p.mip0_rows[1]));
+    }
+    if (rows_nonempty(p.mip1_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 1, p.mip1_rows[0], p.mip1_rows[1]));
+    if (c->post) HIP_TRY(ctx, hipEventRecord(s.a_done, c->work));
+    if (c->exchange) {
+        CHAIN_TRY(sah_allgather_rows(ctx, &s.mip1, p.mip1_rows_per_rank, p.mip1_allocated_rows));  // side stream, behind A(i)
+        HIP_TRY(ctx, hipEventRecord(s.mip_done, exchange_stream(ctx)));
+        s.mip_valid = true;
+    }
+    c->submitted++;
+    while (c->finished + 1 < c->submitted) CHAIN_TRY(chain_finish(c, c->finished));  // B of the frame before this one (done already if a flush came in between)
+    return SAH_OK;
+}
+
+int sah_chain_flush(sah_chain* c) {
+    SAH_RANGE();
+    if (!c) return SAH_ERR_INVALID_ARGUMENT;
+    sah_ctx* ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    while (c->finished < c->submitted) CHAIN_TRY(chain_finish(c, c->finished));
+    for (FrameSet& s : c->sets) {
+        if (s.final_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.final_done, 0));
+        if (s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.b_done, 0));
+    }
+    return SAH_OK;
+}
+
+int sah_chain_counts(const sah_chain* c, uint64_t* submitted, uint64_t* finished) {
+    if (!c) return SAH_ERR_INVALID_ARGUMENT;
+    if (submitted) *submitted = c->submitted;
+    if (finished) *finished = c->finished;
+    return SAH_OK;
+}
+
+void sah_chain_destroy(sah_chain* c) {
+    if (!c) return;
+    for (FrameSet& s : c->sets)
+        for (hipEvent_t e : {s.a_done, s.mip_done, s.final_done, s.b_done})
+            if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+}  // extern "C"

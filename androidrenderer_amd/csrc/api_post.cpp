@@ -24,11 +24,12 @@ hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_tonemap_axis_tables(const TonemapArgs& t, TmAxis* out, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
-hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, const LpvPackEmit* emit, hipStream_t st);
 hipError_t launch_lpv_build_tables(hipStream_t st);
 hipError_t launch_sky_luts(const PlaneArg& transmittance, const PlaneArg& multiscattering, const PlaneArg& sky_view, const float light_vector[3], hipStream_t st);
 hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st);
 hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
+hipError_t launch_probe_irr_unpack_probes(const VolumeArg& src, uint8_t* dst, const uint32_t* probes, uint32_t num_probes, hipStream_t st);  // lighting_tiled.hip
 hipError_t launch_probe_update(const ProbeAtlasArgs& atl, const VolumeArg& trace, const uint32_t* probes, uint32_t num_probes, uint32_t* slots,
                                hipStream_t st);
 }  // namespace sah
@@ -265,21 +266,17 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
         t.mip_w[m] = scene->width;
         t.mip_h[m] = scene->height;
     }
-    if (!ctx->tm_thresholds) {  // built once per context (~15k libm pow calls)
+    if (!ctx->tm_thresholds || !ctx->tm_code_table) {  // built once per context (~15k libm pow calls)
         struct {
             float thr[256];
             uint8_t first[sah::kTmMaxBuckets];
         } tab;
+        uint32_t bucket_base = 0, bucket_count = 0;
         build_tonemap_thresholds(tab.thr);
-        if (!build_tonemap_buckets(tab.thr, tab.first, &ctx->tm_bucket_base, &ctx->tm_bucket_count))
+        if (!build_tonemap_buckets(tab.thr, tab.first, &bucket_base, &bucket_count))
             return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "tonemap code table: a bucket spans more than three codes (internal)");
-        ctx->tm_thr_lo = tab.thr[1];
-        ctx->tm_thr_hi = tab.thr[255];
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_thresholds, sizeof(tab)));
-        HIP_TRY(ctx, hipMemcpy(ctx->tm_thresholds, &tab, sizeof(tab), hipMemcpyHostToDevice));
         // the same two-level search with one read per look-up: per bucket the three thresholds behind its first code, and that code
-        static float code_tab[sah::kTmMaxBuckets][4];
+        float code_tab[sah::kTmMaxBuckets][4];
         for (uint32_t b = 0; b < sah::kTmMaxBuckets; b++) {
             const uint32_t f = tab.first[b];  // <= 252
             code_tab[b][0] = tab.thr[f + 1];
@@ -287,8 +284,27 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
             code_tab[b][2] = tab.thr[f + 3];
             memcpy(&code_tab[b][3], &f, 4);
         }
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->tm_code_table, sizeof(code_tab)));
-        HIP_TRY(ctx, hipMemcpy(ctx->tm_code_table, code_tab, sizeof(code_tab), hipMemcpyHostToDevice));
+        // both tables are uploaded into locals and published together: a context whose second upload failed must not be left with the
+        // first table set and the second one null (the next call would skip this block and launch with a null code table)
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        float *d_thr = nullptr, *d_code = nullptr;
+        hipError_t e = hipMalloc((void**)&d_thr, sizeof(tab));
+        if (e == hipSuccess) e = hipMemcpy(d_thr, &tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_code, sizeof(code_tab));
+        if (e == hipSuccess) e = hipMemcpy(d_code, code_tab, sizeof(code_tab), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (d_thr) (void)hipFree(d_thr);
+            if (d_code) (void)hipFree(d_code);
+            return fail(ctx, SAH_ERR_HIP, "tonemap code tables: %s", hipGetErrorString(e));
+        }
+        if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
+        if (ctx->tm_code_table) (void)hipFree(ctx->tm_code_table);
+        ctx->tm_thresholds = d_thr;
+        ctx->tm_code_table = d_code;
+        ctx->tm_bucket_base = bucket_base;
+        ctx->tm_bucket_count = bucket_count;
+        ctx->tm_thr_lo = tab.thr[1];
+        ctx->tm_thr_hi = tab.thr[255];
     }
     t.thresholds = ctx->tm_thresholds;
     t.code_table = ctx->tm_code_table;
@@ -376,9 +392,29 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
     // light_propagation_volume.cpp:1016-1034: `steps` dispatches ping-ponging A -> B -> A ...  (Two steps per launch — 8^3 bricks with
     // their halo in LDS, bit-identical — were measured: 28 us per pair against 2 x 9.3 us, 1.5x the arithmetic in longer dependency
     // chains; not kept.)
+    // The LAST step also writes the Lighting pass's gather copy of the volumes it stores (sah_gi::lpv_generation, SAH_GENERATION_TRACKED) when
+    // the propagated cells are the whole volume — (32 * cascades) x 32 x 32, the reference's extent: a larger volume has texels no step
+    // writes.  The copy's buffer belongs to the state sah_lighting builds and reads, possibly on another stream: same guard.
+    sah::LpvPackEmit emit = {};
+    bool emits = steps > 0;
+    const sah::VolumeArg* last = (steps & 1) ? b : a;  // where the last step stores
+    for (int i = 0; i < 3; i++) emits = emits && last[i].width == 32 * num_cascades && last[i].height == 32 && last[i].depth == 32;
+    if (emits) {
+        const SahLpvPackLayout pk = sah_lpv_pack_layout(last[0].width, last[0].height, last[0].depth);
+        HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_lighting));
+        HIP_TRY(ctx, sah_lpv_pack_reserve(ctx, pk.total));
+        if (!ctx->state) emits = false;  // (made by sah_create; a context without it has no fast Lighting path either)
+        emit = {ctx->lpv_packed, pk.row_pitch, pk.slice_pitch, ctx->state, ctx->lpv_pack_serial + 1};
+    }
     for (uint32_t s = 0; s < steps; s++) {
-        if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, ctx->stream));
-        else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, ctx->stream));
+        const sah::LpvPackEmit* e = (emits && s + 1 == steps) ? &emit : nullptr;
+        if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, e, ctx->stream));
+        else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, e, ctx->stream));
+    }
+    if (emits) {
+        ctx->lpv_pack_serial++;
+        ctx->lpv_pack_generation = SAH_GENERATION_TRACKED;
+        for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = last[i];
     }
     return SAH_OK;
 }
@@ -462,7 +498,10 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
         (trace_results->row_pitch_bytes % 8) || (trace_results->slice_pitch_bytes % 8))
         return fail(ctx, SAH_ERR_UNSUPPORTED_FORMAT, "trace_results must be R16G16B16A16_SFLOAT 20 x 20 x >= num_probes, 8-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->irr32_generation = 0;
+    // the Lighting pass's fp32 copy of this irradiance atlas: kept current probe by probe when the context tracks it
+    // (SAH_GENERATION_TRACKED, made from this very atlas), stale otherwise
+    const bool patch_irr32 = ctx->irr32 && ctx->irr32_generation == SAH_GENERATION_TRACKED && same_volume(a.rtgi, ctx->irr32_source);
+    if (!patch_irr32) ctx->irr32_generation = 0;
     if (!ctx->probe_slots) {  // probe cell -> position in the update list (probes.hip: ordered_stores); all zero between calls
         HIP_TRY(ctx, hipMalloc((void**)&ctx->probe_slots, 32 * 32 * 32 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->probe_slots, 0, 32 * 32 * 32 * sizeof(uint32_t), ctx->stream));
@@ -471,8 +510,25 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
     if (!ctx->probe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->probe_done, hipEventDisableTiming));
     if (ctx->probe_stream && ctx->probe_stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->probe_done, 0));
     HIP_TRY(ctx, sah::launch_probe_update(a, varg(*trace_results), probes_to_update, num_probes, ctx->probe_slots, ctx->stream));
+    if (patch_irr32) {
+        HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_lighting));
+        HIP_TRY(ctx, sah::launch_probe_irr_unpack_probes(a.rtgi, ctx->irr32, probes_to_update, num_probes, ctx->stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->probe_done, ctx->stream));
     ctx->probe_stream = ctx->stream;
+    return SAH_OK;
+}
+
+int sah_probe_notify_updated(sah_ctx* ctx, const sah_volume* probe_irradiance, const uint32_t* probes, uint32_t num_probes) {
+    SAH_RANGE();
+    if (!ctx || !probe_irradiance) return SAH_ERR_INVALID_ARGUMENT;
+    if (num_probes == 0) return SAH_OK;
+    if (!probes) return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "probes is null");
+    const sah::VolumeArg irr = varg(*probe_irradiance);
+    if (!ctx->irr32 || ctx->irr32_generation != SAH_GENERATION_TRACKED || !same_volume(irr, ctx->irr32_source)) return SAH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_lighting));
+    HIP_TRY(ctx, sah::launch_probe_irr_unpack_probes(irr, ctx->irr32, probes, num_probes, ctx->stream));
     return SAH_OK;
 }
 

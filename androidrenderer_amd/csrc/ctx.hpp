@@ -55,6 +55,7 @@ struct sah_ctx {
     float* colx_table = nullptr;       // device: per-column view-space x numerators of the fast kernel, two flavours (lighting.hip: k_colx_table)
     uint32_t colx_capacity = 0, colx_width = 0;
     float colx_key[7] = {};            // render_resolution, p0, p12, p5, p13, height the tables were built for
+    uint32_t dbg_lpv_packs = 0, dbg_irr_unpacks = 0;  // full rebuilds of the two gather copies by sah_lighting (debug hook sah_debug_copy_rebuilds)
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;
     float* tm_thresholds = nullptr;    // device: 256 tonemap code thresholds + the first-level bucket table (api_post.cpp)
@@ -168,6 +169,32 @@ inline hipError_t sah_guard_leave(sah_ctx* ctx, SahCacheGuard& g, bool drained) 
         if (e_ != hipSuccess) return fail(ctx, SAH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// The gather copy of the LPV volumes (params.hpp: FastArgs::lpv_packed): its geometry for a volume extent, and the context's grow-only buffer.
+// A NEW buffer is zeroed on ctx->stream: k_lpv_pack writes the border texels itself, the emitting propagation step (lpv.hip) relies on them
+// being zero already.
+struct SahLpvPackLayout {
+    uint32_t row_pitch, slice_pitch;
+    uint64_t total;
+};
+inline SahLpvPackLayout sah_lpv_pack_layout(uint32_t w, uint32_t h, uint32_t d) {
+    const uint64_t row = (uint64_t)(w + 2 * sah::kLpvPackBorder) * sah::kLpvPackTexel;
+    const uint64_t slice = row * (h + 2 * sah::kLpvPackBorder);
+    return {(uint32_t)row, (uint32_t)slice, slice * (d + 2 * sah::kLpvPackBorder) + 64};  // + slack: the last x-pair is read as 48 bytes
+}
+inline hipError_t sah_lpv_pack_reserve(sah_ctx* ctx, uint64_t total) {
+    if (ctx->lpv_packed_bytes >= total) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return e;
+    if (ctx->lpv_packed) (void)hipFree(ctx->lpv_packed);
+    ctx->lpv_packed = nullptr;
+    ctx->lpv_packed_bytes = 0;
+    ctx->lpv_pack_generation = 0;
+    e = hipMalloc((void**)&ctx->lpv_packed, total);
+    if (e != hipSuccess) return e;
+    ctx->lpv_packed_bytes = total;
+    return hipMemsetAsync(ctx->lpv_packed, 0, total, ctx->stream);
+}
+
 // Uniform sub-expressions of sky_unified.slang:80-135 for a sun direction as get_sky_color() receives it (`sun_dir`): the Lighting pass's sky
 // fill passes -normalize(direction) (:199), the GI miss shader the raw direction (:229).  Evaluated here in fp32, operator by operator (this
 // header is compiled with -ffp-contract=off), exactly as the per-pixel code would.  Returns false when the LUTs are not RGBA16F.
@@ -222,6 +249,12 @@ inline bool plane_ok(const sah_plane* p, uint32_t fmt_a, uint32_t fmt_b, uint32_
     if (p->format != fmt_a && p->format != fmt_b) return false;
     if (p->width != w || p->height != h) return false;
     return (uint64_t)p->row_pitch_bytes >= (uint64_t)w * format_bpp(p->format);
+}
+
+// (field by field: VolumeArg has four bytes of padding behind its last member, which aggregate initialisation leaves unspecified — two
+// descriptors of the same volume built on different paths need not be memcmp-equal)
+inline bool same_volume(const sah::VolumeArg& a, const sah::VolumeArg& b) {
+    return a.ptr == b.ptr && a.width == b.width && a.height == b.height && a.depth == b.depth && a.row_pitch == b.row_pitch && a.slice_pitch == b.slice_pitch;
 }
 
 inline sah::PlaneArg parg(const sah_plane* p) { return sah::PlaneArg{p ? (const uint8_t*)p->ptr : nullptr, p ? p->row_pitch_bytes : 0}; }

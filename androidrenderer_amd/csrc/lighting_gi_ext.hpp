@@ -435,6 +435,7 @@ struct SlangGeom {
     Surface<Hn> s;
     F3 location;
     H3 V;
+    BrdfView<Hn> bv;  // brdf_sl_view(s, V): the half BRDF's view-only terms, shared by every brdf of the pixel (set by the kernel once s and V stand)
 };
 SAH_DEV SlangGeom slang_geometry(const LightingArgs& a, uint32_t x, uint32_t y, const Px& p, const SurfIn& si) {
     SlangGeom g;
@@ -444,6 +445,7 @@ SAH_DEV SlangGeom slang_geometry(const LightingArgs& a, uint32_t x, uint32_t y, 
     g.s.metalness = Hn(si.metal);
     g.location = worldspace_location_slang(a, (float)x, (float)y, p.depth);
     g.V = to_h(normalize(g.location - F3{Fn(a.view_pos[0]), Fn(a.view_pos[1]), Fn(a.view_pos[2])}));
+    g.bv = brdf_sl_view(g.s, g.V);
     return g;
 }
 // sun_rt() (lighting_common.hpp) on the shared geometry
@@ -451,7 +453,7 @@ SAH_DEV void sun_rt_shared(const LightingArgs& a, const Px& p, const SlangGeom& 
     const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
     const Hn ndotl = Hn(nclamp(dot(L, to_f(g.s.normal)), Fn(0.f), Fn(1.f)).v);
     const H3 Lh = to_h(L);
-    const H3 b = brdf_sl(g.s, Lh, g.V);  // == Fd(s, Lh, V) + Fr(s, Lh, V)
+    const H3 b = brdf_sl_light(g.s, g.bv, Lh, g.V);  // == Fd(s, Lh, V) + Fr(s, Lh, V)
     const H3 nb = ndotl * b;
     F3 radiance = to_f(nb) * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])};
     if (tof(ndotl) > 0.f) radiance = radiance * Fn(p.mask);
@@ -487,7 +489,7 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
     }
     const H3 irradiance = to_h(lut ? sample_cascade_fast(c, location, to_f(s.normal), cascade_index, lut, *bad)
                                    : sample_cascade(c, location, to_f(s.normal), cascade_index));
-    const H3 b = brdf_sl(s, s.normal, V);  // == Fd(s, N, V) + Fr(s, N, V)
+    const H3 b = brdf_sl_light(s, geom.bv, s.normal, V);  // == Fd(s, N, V) + Fr(s, N, V)
     const Hn exposure = Hn::lit(0.314159f);
     H3 col = b * irradiance * exposure;
     if (c.debug_mode == 1) {  // red, green, blue, yellow by cascade (three selects: a table indexed per lane costs a compare chain per entry)
@@ -502,8 +504,8 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
 }
 
 // ---- a5 ------------------------------------------------------------------------------------------------------------------
-SAH_DEV H3 rtgi_contribution(const Surface<Hn>& s, H3 V, H3 dir, H3 irr) {
-    const H3 b = brdf_sl(s, dir, V);  // == Fd(s, dir, V) + Fr(s, dir, V)
+SAH_DEV H3 rtgi_contribution(const Surface<Hn>& s, const BrdfView<Hn>& bv, H3 V, H3 dir, H3 irr) {
+    const H3 b = brdf_sl_light(s, bv, dir, V);  // == Fd(s, dir, V) + Fr(s, dir, V)
     const Hn ndotl = Hn(nclamp(Fn(tof(dot(dir, s.normal))), Fn(0.f), Fn(1.f)).v);
     return b * irr * ndotl;
 }
@@ -525,7 +527,7 @@ SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, 
     const H3 V = geom.V;
     H3 dir, irr;
     load_path(a, r, x, y, dir, irr);
-    H3 radiance = rtgi_contribution(s, V, dir, irr);
+    H3 radiance = rtgi_contribution(s, geom.bv, V, dir, irr);
     uint32_t num_samples = 1;
     for (uint32_t ray = 0; ray < r.num_extra_rays; ray++) {
         const Fn phi = Fn(1.618033988749895f);  // r1(n): overlay.frag.slang:30-36
@@ -550,7 +552,7 @@ SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, 
         if (length(location - other).v > 2.f) continue;  // NaN compares false: not skipped, as in the shader
         H3 d2, i2;
         load_path(a, r, opx, opy, d2, i2);
-        radiance = radiance + rtgi_contribution(s, V, d2, i2);
+        radiance = radiance + rtgi_contribution(s, geom.bv, V, d2, i2);
         num_samples++;
     }
     if (any_nan(radiance)) radiance = H3(Hn::lit(0.f));

@@ -299,6 +299,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
             sg.s.metalness = Hn(si.metal);
             sg.location = fg.ws;
             sg.V = to_h(fg.V);
+            sg.bv = brdf_sl_view(sg.s, sg.V);
         }
         if (__any(surface && !hot)) {
             if (surface && !hot) sg = slang_geometry(a, x, y, p, si);
@@ -394,6 +395,31 @@ __global__ void __launch_bounds__(256) k_probe_irr_unpack(const VolumeArg src, u
     t.z = (float)__builtin_bit_cast(_Float16, (uint16_t)((w >> 17) & 0x7fe0u));
     t.w = 0.f;
     *reinterpret_cast<float4*>(dst + 4u * (size_t)off) = t;
+}
+// The same for the blocks of a list of probes: what sah_probe_update runs behind its dispatches when the context keeps the copy current
+// (SAH_GENERATION_TRACKED).  An update stores to the cells -2 .. R of a probe's (R + 2)-wide block (probes.hip: ordered_stores — the odd
+// block sizes reach into the neighbours'), so cells [-2, block) per axis are widened again: 90 texels per probe of the 7 x 8 atlas.
+__global__ void __launch_bounds__(128) k_probe_irr_unpack_probes(const VolumeArg src, uint8_t* dst, const uint32_t* probes, uint32_t bw, uint32_t bh) {
+    const uint32_t px = probes[3u * blockIdx.x], py = probes[3u * blockIdx.x + 1u], pz = probes[3u * blockIdx.x + 2u];
+    if (px >= 32768u || py >= 32768u || pz >= src.depth) return;  // (not a probe of this atlas: sah_probe_update stored nothing for it either)
+    const uint32_t w = bw + 2u, h = bh + 2u;
+    for (uint32_t t = threadIdx.x; t < w * h; t += 128u) {
+        const int x = (int)(px * bw) - 2 + (int)(t % w), y = (int)(py * bh) - 2 + (int)(t / w);
+        if (x < 0 || y < 0 || x >= (int)src.width || y >= (int)src.height) continue;
+        const uint32_t off = pz * src.slice_pitch + (uint32_t)y * src.row_pitch + (uint32_t)x * 4u;
+        const uint32_t wd = *reinterpret_cast<const uint32_t*>(src.ptr + off);
+        float4 v;
+        v.x = (float)__builtin_bit_cast(_Float16, (uint16_t)((wd << 4) & 0x7ff0u));
+        v.y = (float)__builtin_bit_cast(_Float16, (uint16_t)((wd >> 7) & 0x7ff0u));
+        v.z = (float)__builtin_bit_cast(_Float16, (uint16_t)((wd >> 17) & 0x7fe0u));
+        v.w = 0.f;
+        *reinterpret_cast<float4*>(dst + 4u * (size_t)off) = v;
+    }
+}
+hipError_t launch_probe_irr_unpack_probes(const VolumeArg& src, uint8_t* dst, const uint32_t* probes, uint32_t num_probes, hipStream_t st) {
+    if (num_probes == 0 || src.width < 32 || src.height < 32) return hipSuccess;
+    hipLaunchKernelGGL(k_probe_irr_unpack_probes, dim3(num_probes), dim3(128), 0, st, src, dst, probes, src.width / 32u, src.height / 32u);
+    return hipGetLastError();
 }
 hipError_t launch_probe_irr_unpack(const VolumeArg& src, uint8_t* dst, hipStream_t st) {
     if (src.width == 0 || src.height == 0 || src.depth == 0) return hipSuccess;

@@ -73,6 +73,14 @@ SAH_DEV void store_h4(const VolumeArg& v, int x, int y, int z, H4 c) {
 struct PropArgs {
     VolumeArg src[3], dst[3];
     uint32_t num_cascades;
+    // the emitting step (the last one of a sah_lpv_propagate call, when the context keeps the Lighting pass's gather copy current:
+    // SAH_GENERATION_TRACKED): every texel is also stored into the interleaved copy — colour c of texel (x, y, z) at
+    // (z + 2) * pk_slice_pitch + (y + 2) * pk_row_pitch + (x + 2) * 24 + 8 c, inside a border of zeros that is already there
+    // (params.hpp: FastArgs::lpv_packed) — and an inf / NaN texel raises the copy's tag as k_lpv_pack does
+    uint8_t* packed;
+    uint32_t pk_row_pitch, pk_slice_pitch;
+    FrameState* state;
+    uint32_t serial;
 };
 
 // tables of the 30 direction pairs: built once per context into device memory (k_build_prop_tables) and read by the propagate kernels
@@ -120,7 +128,7 @@ SAH_DEV H4 propagate_from(const PropTables& T, const H4 (&coef)[6]) {
 // one propagation step of one cell: lpv_propagate.comp.slang:76-156
 // (one colour volume per call: the three channels are independent and run as separate workgroups, blockIdx.y, which triples the
 // number of waves in flight — with one thread per cell doing all three the step was bound by its own dependency chains)
-SAH_DEV void propagate_cell(const PropTables& T, const VolumeArg& src, const VolumeArg& dst, uint32_t idx) {
+SAH_DEV H4 propagate_cell(const PropTables& T, const VolumeArg& src, const VolumeArg& dst, uint32_t idx) {
     const int cx = idx & 31, cy = (idx >> 5) & 31, cz = (idx >> 10) & 31, cascade = idx >> 15;
     const int xoff = cascade * 32;
     // All 18 neighbour texels are fetched before any arithmetic (one latency phase instead of six: with two waves per SIMD the
@@ -134,15 +142,28 @@ SAH_DEV void propagate_cell(const PropTables& T, const VolumeArg& src, const Vol
         const bool skipped = nx < -1 || ny < -1 || nz < -1 || nx > 31 || ny > 31 || nz > 31;
         coef[n] = load_h4(src, skipped ? -1 : nx + xoff, ny, nz);
     }
-    store_h4(dst, cx + xoff, cy, cz, propagate_from(T, coef));
+    const H4 out = propagate_from(T, coef);
+    store_h4(dst, cx + xoff, cy, cz, out);
+    return out;
 }
 
+template <bool EMIT>
 __global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
     const PropTables& T = c_prop_tables;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= a.num_cascades * 32768u) return;
     const uint32_t c = blockIdx.y;  // colour volume
-    propagate_cell(T, a.src[c], a.dst[c], idx);
+    const H4 out = propagate_cell(T, a.src[c], a.dst[c], idx);
+    if constexpr (EMIT) {
+        const uint32_t x = (idx & 31u) + (idx >> 15) * 32u, y = (idx >> 5) & 31u, z = (idx >> 10) & 31u;
+        uint2 q;
+        q.x = (uint32_t)__builtin_bit_cast(uint16_t, out.x.v) | ((uint32_t)__builtin_bit_cast(uint16_t, out.y.v) << 16);
+        q.y = (uint32_t)__builtin_bit_cast(uint16_t, out.z.v) | ((uint32_t)__builtin_bit_cast(uint16_t, out.w.v) << 16);
+        *reinterpret_cast<uint2*>(a.packed + (size_t)(z + kLpvPackBorder) * a.pk_slice_pitch + (size_t)(y + kLpvPackBorder) * a.pk_row_pitch +
+                                  (size_t)(x + kLpvPackBorder) * kLpvPackTexel + 8u * c) = q;
+        const bool bad = ((q.x & 0x7c00u) == 0x7c00u) | ((q.x & 0x7c000000u) == 0x7c000000u) | ((q.y & 0x7c00u) == 0x7c00u) | ((q.y & 0x7c000000u) == 0x7c000000u);
+        if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicMax(&a.state->nonfinite_tag, a.serial * 2u + 1u);
+    }
 }
 
 struct ClearArgs {
@@ -179,11 +200,21 @@ hipError_t launch_lpv_build_tables(hipStream_t st) {  // on the current device
     return hipGetLastError();
 }
 
-hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st) {
-    PropArgs a;
+// `emit` (or null): where the step also writes the Lighting pass's gather copy of `dst` (PropArgs)
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, const LpvPackEmit* emit, hipStream_t st) {
+    PropArgs a = {};
     for (int i = 0; i < 3; i++) { a.src[i] = src[i]; a.dst[i] = dst[i]; }
     a.num_cascades = num_cascades;
-    hipLaunchKernelGGL(k_lpv_propagate, dim3(num_cascades * 128, 3), dim3(256), 0, st, a);
+    if (emit) {
+        a.packed = emit->packed;
+        a.pk_row_pitch = emit->row_pitch;
+        a.pk_slice_pitch = emit->slice_pitch;
+        a.state = emit->state;
+        a.serial = emit->serial;
+        hipLaunchKernelGGL(k_lpv_propagate<true>, dim3(num_cascades * 128, 3), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_lpv_propagate<false>, dim3(num_cascades * 128, 3), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

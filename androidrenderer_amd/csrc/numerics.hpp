@@ -309,6 +309,53 @@ template <class T> SAH_DEV V3<T> brdf_sl(const Surface<T>& s, V3<T> l, V3<T> v) 
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
 
+// brdf_sl() split for pixels that evaluate it more than once with the same surface and view vector (the tiled kernel's Slang passes: the
+// RT-mode sun with L = the sun, the cache overlay with L = N, the RTGI overlay with one L per sample): what depends on the surface and V
+// only — f0, the diffuse colour, |N.V + 1e-5|, a^2, the view half of the Smith term, pow5(clamp(1 - NoV)) — is evaluated once.  The
+// per-light part applies the same operators to the same operands in the same order as brdf_sl(), so the same bits (the three channels
+// of Fd_Burley's two Schlick terms are one value: f0 = 1 in all of them).
+template <class T> struct BrdfView {
+    V3<T> f0, diffuse_color;
+    T NoV, a2, sqrtV, powV;  // |N.V + 1e-5|, a^2, sqrt((-NoV * a2 + NoV) * NoV + a2), pow5(clamp(1 - NoV, 0, 1))
+};
+template <class T> SAH_DEV BrdfView<T> brdf_sl_view(const Surface<T>& s, V3<T> v) {
+    const T one = T::lit(1.0f), zero = T::lit(0.0f);
+    const T dielectric_f0 = T::lit(0.04f);
+    BrdfView<T> p;
+    p.f0 = mix(V3<T>(dielectric_f0), s.base_color, s.metalness);
+    p.diffuse_color = s.base_color * (one - dielectric_f0) * (one - s.metalness);
+    p.NoV = nabs(dot(s.normal, v) + T::lit(1e-5f));
+    p.a2 = s.roughness * s.roughness;
+    p.sqrtV = nsqrt((-p.NoV * p.a2 + p.NoV) * p.NoV + p.a2);
+    p.powV = npow5(nclamp(one - p.NoV, zero, one));
+    return p;
+}
+template <class T> SAH_DEV V3<T> brdf_sl_light(const Surface<T>& s, const BrdfView<T>& p, V3<T> l, V3<T> v) {
+    const T one = T::lit(1.0f), zero = T::lit(0.0f);
+    const V3<T> h = normalize(v + l);
+    T NoL = dot(s.normal, l);
+    const T NoH = nclamp(dot(s.normal, h), zero, one);
+    const T VoH = nclamp(dot(v, h), zero, one);
+    const bool dark = tof(NoL) <= 0.f;
+    NoL = nclamp(NoL, zero, one);
+    const T LoH = nclamp(dot(l, h), zero, one);
+    // Fd_Burley(NoV, NoL, LoH, roughness)
+    const T f90 = T::lit(0.5f) + T::lit(2.0f) * s.roughness * LoH * LoH;
+    const T light_scatter = one + (f90 - one) * npow5(nclamp(one - NoL, zero, one));
+    const T view_scatter = one + (f90 - one) * p.powV;
+    const T burley = light_scatter * view_scatter * inv_pi<T>();
+    const V3<T> fd = p.diffuse_color * V3<T>(burley);
+    const T D = D_GGX(NoH, s.roughness);
+    const V3<T> Fv = F_Schlick(VoH, p.f0, one);
+    // V_SmithGGXCorrelated(NoV, NoL, roughness)
+    const T GGXL = p.NoV * nsqrt((-NoL * p.a2 + NoL) * NoL + p.a2);
+    const T GGXV = NoL * p.sqrtV;
+    const T Vis = T::lit(0.5f) / (GGXV + GGXL);
+    const V3<T> fr = (D * Vis) * Fv;
+    const V3<T> sum = fd + fr;
+    return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
+}
+
 // fp32 brdf() = Fd() + Fr() for the hot paths: the shared sub-expressions written once, the `NoL <= 0 -> 0` early-outs as one
 // select (both halves return 0 together and 0 + 0 == +0), and every sqrt / divide replaced by its restricted-range twin
 // (sqrt_nr, rcp_nr, div_nr: same bits inside the domain).  `out_of_domain` is set when an operand leaves the domain for a pixel

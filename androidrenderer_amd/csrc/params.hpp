@@ -117,6 +117,12 @@ struct FastArgs {
 };
 // (an fp32 copy — 48-byte texels, plain v_fma_f32 taps — was measured and loses 67 %: profiles/r3_lpv_pack32_experiment.txt)
 constexpr uint32_t kLpvPackTexel = 24, kLpvPackBorder = 2;
+struct LpvPackEmit {  // the gather copy as the emitting propagation step writes it (lpv.hip)
+    uint8_t* packed;
+    uint32_t row_pitch, slice_pitch;
+    FrameState* state;
+    uint32_t serial;
+};
 
 struct LightingArgs {
     PlaneArg color, normals, data, emission, depth, ao, shadow_mask, lit;

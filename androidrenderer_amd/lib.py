@@ -21,10 +21,11 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_bloom_mip_rows", "sah_bloom_from_mip", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_bloom_mip_rows", "sah_bloom_from_mip", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate", "sah_probe_notify_updated",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_rt_set_bounces", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
-           "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister"]
+           "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister",
+           "sah_chain_create", "sah_chain_submit", "sah_chain_flush", "sah_chain_counts", "sah_chain_destroy"]
 
 
 def load():
@@ -48,6 +49,7 @@ def load():
     lib.sah_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.sah_sync.argtypes = [C.c_void_p]
     lib.sah_debug_deferred_pixels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.sah_debug_copy_rebuilds.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     lib.sah_lighting.argtypes = [C.c_void_p, C.POINTER(_abi.LightingDesc)]
     lib.sah_copy_scene.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane)]
     lib.sah_copy_scene_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
@@ -70,6 +72,7 @@ def load():
     lib.sah_sky_update_luts.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(_abi.Plane), C.POINTER(C.c_float)]
     lib.sah_probe_copy.argtypes =[C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.ProbeAtlases), C.POINTER(C.c_float * 3)]
     lib.sah_probe_update.argtypes = [C.c_void_p, C.POINTER(_abi.ProbeAtlases), C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
+    lib.sah_probe_notify_updated.argtypes = [C.c_void_p, C.POINTER(_abi.Volume), C.c_void_p, C.c_uint32]
     lib.sah_shadow_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.SunLightConstants), C.c_uint32,
                                       C.POINTER(_abi.Volume), C.c_void_p]
     lib.sah_gbuffer_render.argtypes = [C.c_void_p, C.POINTER(_abi.SceneGeometry), C.POINTER(_abi.ViewData), C.POINTER(_abi.GBuffer), C.c_void_p]
@@ -93,6 +96,13 @@ def load():
     lib.sah_ipc_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.sah_ipc_register.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.sah_ipc_unregister.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sah_chain_create.argtypes = [C.c_void_p, C.POINTER(_abi.ChainPlan), C.POINTER(_abi.ChainFrame), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_void_p)]
+    lib.sah_chain_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sah_chain_flush.argtypes = [C.c_void_p]
+    lib.sah_chain_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.sah_chain_destroy.argtypes = [C.c_void_p]
+    lib.sah_chain_destroy.restype = None
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
@@ -131,6 +141,12 @@ class Context:
         n = C.c_uint64()
         self._check(self.lib.sah_debug_deferred_pixels(self.handle, C.byref(n)))
         return int(n.value)
+
+    def copy_rebuilds(self):
+        """Test hook: (full rebuilds of the LPV gather copy, of the fp32 irradiance copy) by lighting() since the context was made."""
+        out = (C.c_uint32 * 2)()
+        self._check(self.lib.sah_debug_copy_rebuilds(self.handle, out))
+        return int(out[0]), int(out[1])
 
     def sync(self):
         self._check(self.lib.sah_sync(self.handle))
@@ -191,6 +207,10 @@ class Context:
     def probe_update(self, atlases, trace_results, probes_to_update_ptr, num_probes):
         """probes_to_update_ptr: device address of num_probes packed uint32 triples."""
         self._check(self.lib.sah_probe_update(self.handle, C.byref(atlases), C.byref(trace_results), C.c_void_p(probes_to_update_ptr), num_probes))
+
+    def probe_notify_updated(self, probe_irradiance, probes_ptr, num_probes):
+        """The caller rewrote these probes' blocks of the irradiance atlas itself: a tracked fp32 copy of it is patched (see sah_hip.h)."""
+        self._check(self.lib.sah_probe_notify_updated(self.handle, C.byref(probe_irradiance), C.c_void_p(probes_ptr), num_probes))
 
     def shadow_render(self, scene, sun, num_cascades, shadowmap, stats_ptr=None):
         """scene: _abi.SceneGeometry of device addresses; stats_ptr: device address of 8 uint32 or None."""
@@ -282,6 +302,22 @@ class Context:
 
     def allgather_bytes(self, device_ptr, bytes_per_rank):
         self._check(self.lib.sah_allgather_bytes(self.handle, C.c_void_p(device_ptr), bytes_per_rank))
+
+    # ---- the sharded frame as a loop of the library (sah_chain_*): handles are plain integers, androidrenderer_amd/chain.py wraps them
+    def chain_create(self, plan, frames, tonemap_flags, chain_flags, work_stream, post_stream):
+        h = C.c_void_p()
+        self._check(self.lib.sah_chain_create(self.handle, C.byref(plan), frames, tonemap_flags, chain_flags, C.c_void_p(work_stream),
+                                              C.c_void_p(post_stream) if post_stream else None, C.byref(h)))
+        return h
+
+    def chain_submit(self, chain, begin_event=None, end_event=None):
+        self._check(self.lib.sah_chain_submit(chain, C.c_void_p(begin_event) if begin_event else None, C.c_void_p(end_event) if end_event else None))
+
+    def chain_flush(self, chain):
+        self._check(self.lib.sah_chain_flush(chain))
+
+    def chain_destroy(self, chain):
+        self.lib.sah_chain_destroy(chain)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define SAH_ABI_VERSION 5
+#define SAH_ABI_VERSION 6
+
+/* sah_gi::lpv_generation / probe_generation: the library keeps its gather copies current itself (see there) */
+#define SAH_GENERATION_TRACKED 0xffffffffu
 
 typedef enum sah_status {
     SAH_OK = 0,
@@ -171,13 +174,18 @@ typedef struct sah_gi {
      * light_propagation_volume.cpp:970-1063).  The fast Lighting kernel gathers from an interleaved copy of the volumes that it otherwise
      * rebuilds on every call (5 us + a launch); with a non-zero counter the copy is rebuilt only when the counter or one of the three
      * volume descriptors differs from the previous sah_lighting call of this context.  0 = rebuild every call.  sah_lpv_clear,
-     * sah_lpv_propagate and sah_lpv_inject_vpls on this context drop the copy regardless. */
+     * sah_lpv_propagate and sah_lpv_inject_vpls on this context drop the copy regardless.
+     * SAH_GENERATION_TRACKED: "these volumes are written through this context only".  The LAST step of sah_lpv_propagate then writes the
+     * interleaved copy beside the volumes it stores anyway (same texels, no extra pass), and the Lighting pass that follows gathers from
+     * it without a rebuild: a frame that propagates and then shades — the reference's order — never runs the 5 us copy pass. */
     uint32_t lpv_generation;
     /* Irradiance cache: the same for the irradiance atlas (written by sah_probe_update / sah_probe_copy, or by the caller).  The tiled
      * Lighting kernel gathers the bilinear taps from an fp32 copy of the R11G11B10 atlas — the widening is exact, so the arithmetic is
      * the same — that it rebuilds on every call unless this counter is non-zero and, like the atlas descriptor, unchanged since the
      * previous sah_lighting call of this context.  0 = rebuild every call.  sah_probe_update and sah_probe_copy on this context drop
-     * the copy regardless. */
+     * the copy regardless — except under SAH_GENERATION_TRACKED ("this atlas is written through this context only"): sah_probe_update then
+     * re-widens just the blocks of the probes it updated (<= 1024 of 32768 per frame in the reference: irradiance_cache.cpp:21-23), and
+     * only sah_probe_copy into the atlas, which rewrites all of it, drops the copy. */
     uint32_t probe_generation;
 } sah_gi;
 
@@ -334,6 +342,13 @@ int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_a
  * probes_to_update: DEVICE pointer to num_probes tightly packed uint32 triples (probe x, y, layer), all distinct. */
 int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_volume* trace_results, const uint32_t* probes_to_update,
                      uint32_t num_probes);
+
+/* For a caller that updates probes of the irradiance atlas by its own means (the reference's own update shaders, say:
+ * IrradianceCache::dispatch_probe_updates, irradiance_cache.cpp:644-723) while the context tracks its fp32 copy of that atlas
+ * (sah_gi::probe_generation = SAH_GENERATION_TRACKED): "the blocks of these probes have changed" — the context widens those blocks again
+ * (what sah_probe_update does by itself), on its stream, behind the caller's writes.  A no-op when the context holds no tracked copy of
+ * `probe_irradiance`.  probes: DEVICE pointer to num_probes uint32 triples (probe x, y, layer), as for sah_probe_update. */
+int sah_probe_notify_updated(sah_ctx* ctx, const sah_volume* probe_irradiance, const uint32_t* probes, uint32_t num_probes);
 
 /* ---- producers either side of the lighting pass ----------------------------------------------------------
  * The two rasterisation passes whose outputs a1 gathers from: the sun shadow cascades (depth only, multiview) and the G-buffer.
@@ -678,6 +693,47 @@ int sah_ipc_connect(sah_ctx* ctx, const void* all_handles);
 int sah_ipc_export(sah_ctx* ctx, const void* buffer, uint64_t bytes, void* out_handle);
 int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all_handles);
 int sah_ipc_unregister(sah_ctx* ctx, const void* buffer);
+
+/* ---- the row-sharded frame as a loop of this library (no reference counterpart: north_star's "shard by screen-tile rows, all-gather the
+ * final image"; the reference records one frame at a time on one queue, render_backend.cpp:135-153) ---------------------------------------
+ * One rank's share of the whole chain — Lighting of its rows (LightingPhase::render), "Copy scene" + bloom mip 0 over its band
+ * (scene_renderer.cpp:502-527, bloomer.cpp:50-72), its rows of bloom mip 1, [exchange of mip 1], mips 2.. (bloomer.cpp:74-262), the
+ * composite of its rows (ui_phase.cpp:98-113), [exchange of the R8G8B8A8 rows, reversed rank order] — with two frames in flight, so that
+ * both exchanges travel beside compute: frame i is cut at its first exchange into A(i) (up to mip 1) and B(i) (the rest);
+ * sah_chain_submit enqueues A(i), the mip-1 gather, then B(i - 1) and its final gather.  Everything a frame writes exists twice
+ * (`frames[2]`, used alternately).  With a post stream B(i - 1) runs there, beside A(i) on the work stream; the exchanges run on the
+ * context's side stream if one is set (sah_comm_set_stream), through RCCL or the direct exchange as sah_allgather_rows would.
+ * The row arithmetic is the caller's (androidrenderer_amd/shard.py: chain_plan; include/sah_host.hpp); this object only keeps the order
+ * and the events, which is what cost the host 72 us per frame when every call crossed a language boundary.
+ * All descriptors are copied (pointers into HOST memory need not outlive sah_chain_create); device memory must outlive the chain. */
+typedef struct sah_chain sah_chain;
+typedef struct sah_chain_plan {
+    uint32_t aa_rows[2];   /* rows of `antialiased` this rank needs: [begin, end) */
+    uint32_t mip0_rows[2]; /* rows of bloom mip 0 it computes for itself */
+    uint32_t mip1_rows[2]; /* rows of bloom mip 1 it contributes to the first exchange (may be empty) */
+    uint32_t out_rows[2];  /* rows of the final image it composites (slot world - 1 - rank; may be empty) */
+    uint32_t mip1_rows_per_rank, mip1_allocated_rows; /* gather slot of mip 1 and the rows its allocation holds (>= slot * world) */
+    uint32_t rows_per_rank, out_allocated_rows;       /* the same for the final image */
+} sah_chain_plan;
+typedef struct sah_chain_frame {
+    const sah_lighting_desc* lighting[2]; /* the rank's lit rows; the row on the opposite edge that "Copy scene"'s REPEAT sampler taps, or NULL */
+    sah_plane lit, antialiased;
+    sah_mipchain bloom;
+    sah_plane out; /* R8G8B8A8 */
+} sah_chain_frame;
+/* work_stream: the stream of the A halves (the context is left on it after every call); post_stream: the stream of the B halves, or NULL
+ * for the work stream.  tonemap_flags as for sah_tonemap_ex.  chain_flags: SAH_CHAIN_NO_EXCHANGE = both gathers are left out (one rank's
+ * compute of an N-rank plan on a context of another world size: rehearsals and measurements of a rank's share on one GPU). */
+#define SAH_CHAIN_NO_EXCHANGE (1u << 0)
+int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_frame frames[2], uint32_t tonemap_flags, uint32_t chain_flags,
+                     void* work_stream, void* post_stream, sah_chain** out);
+/* lighting_begin / lighting_end: optional hipEvent_t recorded on the work stream around the frame's sah_lighting calls (NULL: none) */
+int sah_chain_submit(sah_chain* chain, void* lighting_begin, void* lighting_end);
+/* Completes every submitted frame; the work stream then waits for the last gathers and B halves. */
+int sah_chain_flush(sah_chain* chain);
+/* frames submitted / frames whose B half has been enqueued */
+int sah_chain_counts(const sah_chain* chain, uint64_t* submitted, uint64_t* finished);
+void sah_chain_destroy(sah_chain* chain);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_status_strings():
     l = lib.load()
-    assert l.sah_abi_version() == 5  # 5: sah_ipc_unregister, sah_sync / sah_comm_wait report a direct exchange that gave up
+    assert l.sah_abi_version() == 6  # 6: SAH_GENERATION_TRACKED (the context keeps its gather copies current), sah_chain_*
     assert l.sah_status_string(0) == b"ok"
     assert l.sah_status_string(_abi.SAH_ERR_NO_DEVICE) == b"no HIP device"
 

@@ -238,11 +238,13 @@ def test_hip_chain_through_a_one_rank_communicator():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True), (None, True)])
-def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_streams):
+@pytest.mark.parametrize("native", [False, True], ids=["python-loop", "library-loop"])
+@pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True), (None, True), (None, False)])
+def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_streams, native):
     """Two frames in flight (chain.PipelinedChain: both exchanges on the side stream of a one-rank communicator), a different AO plane
     per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's.
-    `two_streams`: the B halves (mips 1.., tonemap, final exchange) on a second work stream beside the next frame's lighting."""
+    `two_streams`: the B halves (mips 1.., tonemap, final exchange) on a second work stream beside the next frame's lighting.
+    `native`: the same loop inside the library (sah_chain_create / _submit / _flush through chain.NativePipelinedChain)."""
     import torch
     from androidrenderer_amd import chain, lib
     from tests import util
@@ -265,7 +267,7 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
             torch.cuda.synchronize()
             want.append(plain.out.cpu().numpy().copy())
         assert not np.array_equal(want[0], want[1])
-        pc = chain.PipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None)
+        pc = (chain.NativePipelinedChain if native else chain.PipelinedChain)(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None)
         got = {}
         for i, a in enumerate(ao):
             dev["ao"].copy_(a)             # on the work stream: ordered with the frames around it
@@ -282,7 +284,9 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
         got[5] = pc.image(5).cpu().numpy().copy()
         for i, img in sorted(got.items()):
             assert np.array_equal(img, want[i]), f"frame {i}"
-        assert pc.finished == pc.submitted == 7
+        assert pc.submitted == 7 and (native or pc.finished == 7)
+        if native:
+            pc.close()
     finally:
         torch.cuda.synchronize()
         ctx.close()

@@ -11,7 +11,7 @@ from androidrenderer_amd.frame import from_torch, to_torch  # noqa: F401  (re-ex
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_SO = os.environ.get("SAH_ORACLE_SO") or os.path.join(ORACLE_DIR, "liboracle.so")  # (override: the sanitizer build, tools/sanitize.sh)
 
 _oracle = None
 

@@ -1,33 +1,52 @@
 """One rank's compute of the sharded chain at N ranks, emulated on one GPU without exchanges: one stream against two streams
-(A(i+1) = lighting + copy + mip-0 and mip-1 rows beside B(i) = mips 2-5 + tonemap rows).  usage: chain_two_streams.py [world] [rank] [--strict-tonemap]
-(the tonemap runs in tolerance mode, as bench.py's chain workloads do, unless --strict-tonemap is given)"""
+(A(i+1) = lighting + copy + mip-0 and mip-1 rows beside B(i) = mips 2-5 + tonemap rows), enqueued call by call from Python against the
+library's own loop (sah_chain_submit, round 5).
+usage: chain_two_streams.py [world] [rank] [--strict-tonemap] [--rebuild-copies] [--no-probe-updates]
+  the tonemap runs in tolerance mode, as bench.py's chain workloads do, unless --strict-tonemap is given;
+  the context tracks its fp32 copy of the irradiance atlas (sah_gi::probe_generation = SAH_GENERATION_TRACKED) and every frame re-widens
+  the blocks of 1024 probes — the reference's r.GI.Cache.UpdatesPerFrame — through sah_probe_notify_updated, unless --no-probe-updates;
+  --rebuild-copies: probe_generation 0, the whole atlas widened every frame (what rounds 3-4 measured)."""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
 import torch
 
-from androidrenderer_amd import _abi, chain, frame, lib
+from androidrenderer_amd import _abi, chain, frame, images, lib, synth
 
 strict = "--strict-tonemap" in sys.argv
+rebuild = "--rebuild-copies" in sys.argv
+probe_updates = "--no-probe-updates" not in sys.argv and not rebuild
 argv = [a for a in sys.argv if not a.startswith("--")]
 world = int(argv[1]) if len(argv) > 1 else 8
 rank = int(argv[2]) if len(argv) > 2 else 3
 W, H = 3840, 2160
 fr = frame.LightingInputs(W, H, seed=2, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI_CACHE, flavour="atrium", shadowmap_res=4096, synth_device="cuda")
+fr.probe_generation = 0 if rebuild else _abi.GENERATION_TRACKED
 dev = fr.device_arrays("cuda")
 ctx = lib.Context(0)
 s1 = torch.cuda.current_stream()
 s2 = torch.cuda.Stream()
 ctx.set_stream(s1.cuda_stream)
-sets = [chain.ShardedChain(ctx, fr, dev, rank, world, tonemap_flags=0 if strict else _abi.TONEMAP_TOLERANCE_1CODE) for _ in range(2)]
+tm = 0 if strict else _abi.TONEMAP_TOLERANCE_1CODE
+sets = [chain.ShardedChain(ctx, fr, dev, rank, world, tonemap_flags=tm) for _ in range(2)]
+cells = synth.rng(33).permutation(32 * 32 * 32)[:1024]
+probe_ids = torch.from_numpy(np.stack([cells % 32, (cells // 32) % 32, cells // 1024], axis=-1).astype(np.int32).reshape(-1)).cuda()
+irr_vol = images.volume(dev["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
 N = 300
+
+
+def maintain():
+    if probe_updates:
+        ctx.probe_notify_updated(irr_vol, probe_ids.data_ptr(), 1024)
 
 
 def one_stream():
     for i in range(N):
         s = sets[i % 2]
+        maintain()
         s.lighting()
         s.reduce()
         s.composite()
@@ -42,6 +61,7 @@ def two_streams():
             ctx.set_stream(s1.cuda_stream)
             if b_done[i % 2] is not None:
                 s1.wait_event(b_done[i % 2])
+            maintain()
             s.lighting()
             s.reduce()
             a_done[i % 2] = s1.record_event()
@@ -55,7 +75,19 @@ def two_streams():
     ctx.set_stream(s1.cuda_stream)
 
 
-for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("one stream", one_stream), ("two streams", two_streams)):
+def library_loop(second):
+    pc = chain.NativePipelinedChain(ctx, fr, dev, rank, world, None, second, tonemap_flags=tm, exchange=False)
+
+    def run():
+        for _ in range(N):
+            maintain()
+            pc.submit()
+        pc.flush()
+    return run
+
+
+lib_one, lib_two = library_loop(None), library_loop(s2)
+for name, fn in (("python, one stream", one_stream), ("python, two streams", two_streams), ("library loop, one stream", lib_one), ("library loop, two streams", lib_two)) * 2:
     fn()
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -63,4 +95,4 @@ for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("one
     host = (time.perf_counter() - t) / N
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / N
-    print(f"world {world} rank {rank}: {name:12s} {dt * 1e3:.4f} ms per frame (host enqueue {host * 1e3:.4f} ms)")
+    print(f"world {world} rank {rank}: {name:26s} {dt * 1e3:.4f} ms per frame (host enqueue {host * 1e3:.4f} ms)", flush=True)

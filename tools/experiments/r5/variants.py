@@ -1,0 +1,140 @@
+"""Round-5 experiment builds (the mechanism is round 4's: tools/experiments/r4/variants.py — a variant is the product source with patches
+applied to a COPY, built into build_ab/<name>.so, loaded through SAH_HIP_LIBRARY; nothing here touches csrc/).
+
+    python tools/experiments/r5/variants.py            # every round-5 variant
+    python tools/experiments/r5/variants.py NAME ...
+
+fast_stats   VERDICT r4 item 3 (a): k_lighting_fast<CSM, LPV, 4> with counters — per pixel `ndotl > 0`, `ndotl > 0 and shadow != 0`; per
+             thread "its four pixels share the LPV cascade / the base cell of the trilinear footprint"; per wave how many PCF / BRDF
+             evaluations the present wave votes run against how many a dense (compacted) evaluation would.  Same images as the product
+             build (the counters only read); read back with sah_debug_fast_stats (tools/experiments/r5/lit_fractions.py).
+"""
+import concurrent.futures
+import importlib.util
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location("r4_variants", os.path.join(HERE, "..", "r4", "variants.py"))
+base = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(base)
+
+VARIANTS = {}
+
+_STATS_KERNEL = r"""
+    {   // ---- round-5 counters (experiment build only) ----
+        const uint32_t lane_ = threadIdx.x & 63u;
+        uint32_t n_surface = 0, n_lit = 0, n_unshadowed = 0, slot_pcf = 0, slot_brdf = 0;
+        bool all_surface = active;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const bool surf = active && dbg_surface[i];
+            all_surface = all_surface && surf;
+            const uint64_t ms = __ballot(surf), ml = __ballot(surf && (dbg_flags[i] & 1u)), mu = __ballot(surf && (dbg_flags[i] & 2u));
+            n_surface += (uint32_t)__builtin_popcountll(ms);
+            n_lit += (uint32_t)__builtin_popcountll(ml);
+            n_unshadowed += (uint32_t)__builtin_popcountll(mu);
+            slot_pcf += ml ? 1u : 0u;
+            slot_brdf += mu ? 1u : 0u;
+        }
+        bool same_cascade = all_surface, same_cell = all_surface;
+#pragma unroll
+        for (int i = 1; i < PPT; i++) {
+            same_cascade = same_cascade && dbg_sel[i] == dbg_sel[0];
+            same_cell = same_cell && dbg_sel[i] == dbg_sel[0] && dbg_cell[i] == dbg_cell[0];
+        }
+        const uint64_t m_threads = __ballot(all_surface), m_casc = __ballot(same_cascade), m_cell = __ballot(same_cell), m_act = __ballot(active);
+        if (lane_ == 0 && m_act) {
+            atomicAdd(&g_fast_stats[0], (unsigned long long)__builtin_popcountll(m_act) * PPT);  // pixels
+            atomicAdd(&g_fast_stats[1], (unsigned long long)n_surface);                          // surface pixels
+            atomicAdd(&g_fast_stats[2], (unsigned long long)n_lit);                              // ... with ndotl > 0
+            atomicAdd(&g_fast_stats[3], (unsigned long long)n_unshadowed);                       // ... and shadow != 0
+            atomicAdd(&g_fast_stats[4], 1ull);                                                   // waves
+            atomicAdd(&g_fast_stats[5], (unsigned long long)slot_pcf);                           // PCF evaluations (wave x pixel slot) as voted today
+            atomicAdd(&g_fast_stats[6], (unsigned long long)slot_brdf);                          // BRDF evaluations as voted today
+            atomicAdd(&g_fast_stats[7], (unsigned long long)((n_lit + 63u) / 64u));              // PCF evaluations if the wave's lit pixels were dense
+            atomicAdd(&g_fast_stats[8], (unsigned long long)((n_unshadowed + 63u) / 64u));       // BRDF evaluations if dense
+            atomicAdd(&g_fast_stats[9], (unsigned long long)__builtin_popcountll(m_threads));    // threads whose four pixels are all surface
+            atomicAdd(&g_fast_stats[10], (unsigned long long)__builtin_popcountll(m_casc));      // ... and share the LPV cascade
+            atomicAdd(&g_fast_stats[11], (unsigned long long)__builtin_popcountll(m_cell));      // ... and the base cell of the footprint
+            atomicAdd(&g_fast_stats[12], (unsigned long long)__builtin_popcountll(m_act));       // threads
+        }
+    }
+"""
+
+VARIANTS["fast_stats"] = (["lighting.hip"], [
+    ("lighting_fast.hpp", "struct FastPixelOut {\n    uint2 lit;\n    bool deferred;\n};",
+     "struct FastPixelOut {\n    uint2 lit;\n    bool deferred;\n    uint32_t dbg_flags, dbg_cell, dbg_sel;\n};"),
+    ("lighting_fast.hpp", "const Surface<Fn>& s, const SurfIn& si, bool sky_px, bool& ok, Fn (&sc)[3]) {",
+     "const Surface<Fn>& s, const SurfIn& si, bool sky_px, bool& ok, Fn (&sc)[3], uint32_t* dbg = nullptr) {\n    if (dbg) *dbg = 0u;"),
+    ("lighting_fast.hpp", "        shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;\n",
+     "        shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;\n"
+     "        if (dbg) *dbg = ((ok && !sky_px && ndotl_sun.v > 0.f) ? 1u : 0u) | ((ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f) ? 2u : 0u);\n"),
+    ("lighting_common.hpp", "                              const Fn (&n)[4], Fn (&out)[3]) {\n    const int W = (int)L.red.width",
+     "                              const Fn (&n)[4], Fn (&out)[3], uint32_t* dbg_base = nullptr) {\n    const int W = (int)L.red.width"),
+    ("lighting_common.hpp", "    const uint32_t base = z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel;\n",
+     "    const uint32_t base = z0 * slice_pitch + y0 * row_pitch + x0 * kLpvPackTexel;\n    if (dbg_base) *dbg_base = base;\n"),
+    ("lighting_fast.hpp", "    Fn nc[4];\n    float lpv_u = 0.f, lpv_v = 0.f, lpv_w = 0.f;\n", "    Fn nc[4];\n    float lpv_u = 0.f, lpv_v = 0.f, lpv_w = 0.f;\n    uint32_t dbg_flags = 0, dbg_cell = 0, dbg_sel = 0;\n"),
+    ("lighting_fast.hpp", "        cpx = cpx + Fn((float)selected);\n", "        cpx = cpx + Fn((float)selected);\n        dbg_sel = selected;\n"),
+    ("lighting_fast.hpp", "        fast_csm_sun(a, csm, tab, N, ws, vsz, V, L, s, si, sky_px, ok, sc);", "        fast_csm_sun(a, csm, tab, N, ws, vsz, V, L, s, si, sky_px, ok, sc, &dbg_flags);"),
+    ("lighting_fast.hpp", "        lpv_fetch_packed(lpv, f.lpv_packed, f.pk_row_pitch, f.pk_slice_pitch, lpv_u, lpv_v, lpv_w, nc, indirect);",
+     "        lpv_fetch_packed(lpv, f.lpv_packed, f.pk_row_pitch, f.pk_slice_pitch, lpv_u, lpv_v, lpv_w, nc, indirect, &dbg_cell);"),
+    ("lighting_fast.hpp", "    o.deferred = sky_px ? (f.sky_enabled != 0u) : !ok;\n",
+     "    o.deferred = sky_px ? (f.sky_enabled != 0u) : !ok;\n    o.dbg_flags = dbg_flags;\n    o.dbg_cell = dbg_cell;\n    o.dbg_sel = dbg_sel;\n"),
+    ("lighting.hip", "constexpr uint32_t kSkyRatio = 4;", "__device__ unsigned long long g_fast_stats[16];\nconstexpr uint32_t kSkyRatio = 4;"),
+    ("lighting.hip", "    uint32_t out[2 * PPT];\n    uint32_t deferred_mask = 0, sky_mask = 0;\n",
+     "    uint32_t out[2 * PPT];\n    uint32_t deferred_mask = 0, sky_mask = 0;\n    uint32_t dbg_flags[PPT] = {}, dbg_cell[PPT] = {}, dbg_sel[PPT] = {};\n    bool dbg_surface[PPT] = {};\n"),
+    ("lighting.hip", "        if (p.depth == 0.f) sky_mask |= 1u << i;\n    }\n",
+     "        if (p.depth == 0.f) sky_mask |= 1u << i;\n        dbg_flags[i] = r.dbg_flags;\n        dbg_cell[i] = r.dbg_cell;\n        dbg_sel[i] = r.dbg_sel;\n"
+     "        dbg_surface[i] = p.depth != 0.f && !r.deferred;\n    }\n" + _STATS_KERNEL),
+    ("lighting.hip", "}  // namespace sah\n",
+     "}  // namespace sah\n"
+     "extern \"C\" __attribute__((visibility(\"default\"))) int sah_debug_fast_stats(unsigned long long* out, int reset) {\n"
+     "    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sah::g_fast_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;\n"
+     "    if (reset) {\n        unsigned long long z[16] = {};\n        if (hipMemcpyToSymbol(HIP_SYMBOL(sah::g_fast_stats), z, sizeof(z)) != hipSuccess) return -1;\n    }\n"
+     "    return 0;\n}\n"),
+])
+
+# ---- XCD-aware workgroup order (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement": blocks are dealt round-robin over the 8 XCDs, each
+# with its own 4 MiB L2).  In launch order, neighbouring tiles of a row land on eight different L2s and every XCD gathers from the whole
+# of the side tables (48 MB of probe atlases, the 4.1 MB LPV copy, the shadow cascades); remapped, XCD k shades the k-th contiguous eighth
+# of the launch's tiles.  Same images (a permutation of which workgroup shades which tile).
+_XCD_REMAP = (
+    "    // XCD-aware order: physical block L (XCD L % 8 under round-robin dealing) shades logical tile start(L % 8) + L / 8\n"
+    "    {\n        const uint32_t T_ = TOTAL_, L_ = LINEAR_, q_ = T_ / 8u, r_ = T_ % 8u, k_ = L_ % 8u;\n"
+    "        LOGICAL_ = k_ * q_ + min(k_, r_) + L_ / 8u;\n    }\n")
+VARIANTS["tiled_xcd"] = (["lighting_tiled.hip"], [
+    ("lighting_tiled.hip",
+     "    const uint32_t x = LIGHTS ? blockIdx.x * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u) : blockIdx.x * 32u + (threadIdx.x & 31u);\n"
+     "    const uint32_t y = a.row_begin + (LIGHTS ? blockIdx.y * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u) : blockIdx.y * 8u + (threadIdx.x >> 5));\n".replace("\\n", "\n"),
+     "    uint32_t logical_ = 0;\n" + _XCD_REMAP.replace("TOTAL_", "gridDim.x * gridDim.y").replace("LINEAR_", "blockIdx.y * gridDim.x + blockIdx.x").replace("LOGICAL_", "logical_") +
+     "    const uint32_t bx_ = LIGHTS ? blockIdx.x : logical_ % gridDim.x, by_ = LIGHTS ? blockIdx.y : logical_ / gridDim.x;\n"
+     "    const uint32_t x = LIGHTS ? bx_ * 16u + (threadIdx.x & 7u) + ((threadIdx.x >> 3) & 8u) : bx_ * 32u + (threadIdx.x & 31u);\n"
+     "    const uint32_t y = a.row_begin + (LIGHTS ? by_ * 16u + ((threadIdx.x >> 3) & 7u) + ((threadIdx.x >> 4) & 8u) : by_ * 8u + (threadIdx.x >> 5));\n"),
+])
+VARIANTS["fast_xcd"] = (["lighting.hip"], [
+    ("lighting.hip", "    uint32_t block_id = blockIdx.x;\n    if (SKY) {\n        if (blockIdx.x % (kSkyRatio + 1u) == kSkyRatio) {",
+     "    uint32_t vb_ = 0;\n" + _XCD_REMAP.replace("TOTAL_", "gridDim.x").replace("LINEAR_", "blockIdx.x").replace("LOGICAL_", "vb_") +
+     "    uint32_t block_id = vb_;\n    if (SKY) {\n        if (vb_ % (kSkyRatio + 1u) == kSkyRatio) {"),
+    ("lighting.hip", "((blockIdx.x / (kSkyRatio + 1u)) * kSkyRatio + k)", "((vb_ / (kSkyRatio + 1u)) * kSkyRatio + k)"),
+    ("lighting.hip", "        block_id = blockIdx.x - blockIdx.x / (kSkyRatio + 1u);", "        block_id = vb_ - vb_ / (kSkyRatio + 1u);"),
+])
+VARIANTS["both_xcd"] = (["lighting.hip", "lighting_tiled.hip"], VARIANTS["fast_xcd"][1] + VARIANTS["tiled_xcd"][1])
+# the tolerance composite on a row band: 32-row tiles whatever the band's height (the product picks 16-row tiles when 32-row ones would not
+# fill the chip's 768 slots twice)
+VARIANTS["tm_band32"] = (["tonemap_tol.hip"], [("tonemap_tol.hip", "    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL", "    if (true) hipLaunchKernelGGL")])
+for _k, _v in list(VARIANTS.items()):  # (the patch texts above are written with escaped newlines for readability)
+    VARIANTS[_k] = (_v[0], [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n")) for f, o, n in _v[1]])
+
+
+def build_variant(name):
+    base.VARIANTS[name] = VARIANTS[name]
+    return base.build_variant(name)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or sorted(VARIANTS)
+    base.base_build.build()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        for n in ex.map(build_variant, names):
+            print("built", n, flush=True)
