@@ -14,13 +14,15 @@ struct IpcCopies {
     uint8_t* dst[SAH_IPC_MAX_WORLD];
 };
 hipError_t launch_ipc_signal(const IpcPeers& peers, uint32_t value, const uint32_t* abort, hipStream_t st);
-hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* abort, uint32_t* timed_out, hipStream_t st);
-hipError_t launch_ipc_copy(const IpcCopies& c, int world, const uint8_t* src, uint64_t bytes, const uint32_t* abort, hipStream_t st);
+hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* abort, uint32_t* timed_out, const IpcPeers& notes, hipStream_t st);
+hipError_t launch_ipc_copy(const IpcCopies& c, int world, const uint8_t* src, uint64_t bytes, const uint32_t* abort, const uint32_t* gave_up, hipStream_t st);
 }  // namespace sah
 
 namespace {
 constexpr uint32_t kMagic = 0x53414849u;  // "SAHI"
-constexpr uint32_t kMailboxWords = 2 * SAH_IPC_MAX_BUFFERS * SAH_IPC_MAX_WORLD;
+// ready[buffer][rank], done[buffer][rank], then one "rank p has given up" note per peer (k_ipc_wait writes its own into every peer's mailbox)
+constexpr uint32_t kNotesBase = 2 * SAH_IPC_MAX_BUFFERS * SAH_IPC_MAX_WORLD;
+constexpr uint32_t kMailboxWords = kNotesBase + SAH_IPC_MAX_WORLD;
 constexpr uint32_t kMailboxAlloc = kMailboxWords + 16;  // + the abort word (its own 64 bytes; peers never touch it)
 
 struct Handle {  // SAH_IPC_HANDLE_BYTES
@@ -106,7 +108,7 @@ int sah_ipc_gather(sah_ctx* ctx, uint32_t id, uint8_t* buffer, uint64_t bytes_pe
     const uint32_t n = ++b.seq;
     const int slot = reversed ? ctx->world - 1 - ctx->rank : ctx->rank;
     const uint64_t slot_off = off + (uint64_t)slot * bytes_per_rank;
-    IpcPeers ready_out{}, ready_in{}, done_out{}, done_in{};
+    IpcPeers ready_out{}, ready_in{}, done_out{}, done_in{}, notes{};
     IpcCopies copies{};
     for (int p = 0; p < ctx->world; p++) {
         if (p == ctx->rank) continue;
@@ -115,17 +117,18 @@ int sah_ipc_gather(sah_ctx* ctx, uint32_t id, uint8_t* buffer, uint64_t bytes_pe
         done_out.slot[p] = s.peer_mailbox[p] + (SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + ctx->rank;
         done_in.slot[p] = s.mailbox + (SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + p;
         copies.dst[p] = b.peer[p] + slot_off;
+        notes.slot[p] = s.peer_mailbox[p] + kNotesBase + ctx->rank;
     }
     uint32_t* abort = s.mailbox + kMailboxWords;
     // 1. my rows are written (stream order) and my copy of the buffer may be overwritten; 2. so may every peer's
     HIP_TRY(ctx, launch_ipc_signal(ready_out, n, abort, st));
-    HIP_TRY(ctx, launch_ipc_wait(ready_in, n, abort, s.timed_out, st));
+    HIP_TRY(ctx, launch_ipc_wait(ready_in, n, abort, s.timed_out, notes, st));
     // 3. one hop per peer (skipped, like everything behind it, once a wait has given up: a peer that did not arrive may still be using
     //    its copy of the buffer)
-    HIP_TRY(ctx, launch_ipc_copy(copies, ctx->world, b.local + slot_off, bytes_per_rank, abort, st));
+    HIP_TRY(ctx, launch_ipc_copy(copies, ctx->world, b.local + slot_off, bytes_per_rank, abort, s.mailbox + kNotesBase, st));
     // 4. my rows have landed everywhere; 5. so have everybody's here
     HIP_TRY(ctx, launch_ipc_signal(done_out, n, abort, st));
-    HIP_TRY(ctx, launch_ipc_wait(done_in, n, abort, s.timed_out, st));
+    HIP_TRY(ctx, launch_ipc_wait(done_in, n, abort, s.timed_out, notes, st));
     return SAH_OK;
 }
 
@@ -237,6 +240,34 @@ int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all
         memcpy(b.peer_handle[p], &hs[p], sizeof(Handle));
     }
     b.in_use = true;
+    return SAH_OK;
+}
+
+// After a gather has given up (SAH_ERR_COMM): the collective way back.  Every rank drains its streams (sah_sync, whatever it returns),
+// all ranks meet (the caller's barrier), every rank calls this, all ranks meet again, and the exchange works as before.  A gather that
+// one rank made and another skipped leaves their sequence numbers apart: each buffer's number is raised to the highest one anybody has
+// signalled — every rank sees the same maximum, because every counter a peer ever stored has landed by the time of the first barrier.
+int sah_ipc_reset(sah_ctx* ctx) {
+    if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
+    auto& s = ctx->ipc;
+    if (!s.open) return SAH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    std::vector<uint32_t> host(kMailboxWords);
+    HIP_TRY(ctx, hipMemcpy(host.data(), s.mailbox, kMailboxWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t id = 0; id < SAH_IPC_MAX_BUFFERS; id++) {
+        uint32_t m = s.buffers[id].seq;
+        for (int p = 0; p < ctx->world; p++) {
+            if (p == ctx->rank) continue;
+            for (uint32_t v : {host[id * SAH_IPC_MAX_WORLD + p], host[(SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + p]})
+                if ((int32_t)(v - m) > 0) m = v;
+        }
+        s.buffers[id].seq = m;
+    }
+    HIP_TRY(ctx, hipMemset(s.mailbox + kNotesBase, 0, (kMailboxAlloc - kNotesBase) * sizeof(uint32_t)));  // the peers' notes and the abort word
+    *s.timed_out = 0;
+    ctx->comm_pending = false;
     return SAH_OK;
 }
 

@@ -27,7 +27,10 @@ __global__ void __launch_bounds__(64) k_ipc_signal(const IpcPeers peers, uint32_
 
 // every polled counter >= value, or 2 s (wall_clock64 ticks at 100 MHz) have passed: then *abort (device) and *timed_out (pinned host
 // memory) are raised
-__global__ void __launch_bounds__(64) k_ipc_wait(const IpcPeers own, uint32_t value, uint32_t* abort, uint32_t* timed_out) {
+// `notes`: this rank's "gave up" word in every peer's mailbox, raised together with them: a peer that arrives late still finds its own
+// ready-wait satisfied (this rank's counter is there) and would copy its rows into a buffer this rank may be about to give back — its copy
+// kernel reads the note first (k_ipc_copy).
+__global__ void __launch_bounds__(64) k_ipc_wait(const IpcPeers own, uint32_t value, uint32_t* abort, uint32_t* timed_out, const IpcPeers notes) {
     if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const uint32_t p = threadIdx.x;
     const bool mine = p < SAH_IPC_MAX_WORLD && own.slot[p];
@@ -41,6 +44,7 @@ __global__ void __launch_bounds__(64) k_ipc_wait(const IpcPeers own, uint32_t va
                 __hip_atomic_store(abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            if (p < SAH_IPC_MAX_WORLD && notes.slot[p]) __hip_atomic_store(notes.slot[p], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         __builtin_amdgcn_s_sleep(32);
@@ -49,10 +53,12 @@ __global__ void __launch_bounds__(64) k_ipc_wait(const IpcPeers own, uint32_t va
 
 // The own slot into every peer's copy of the buffer: blockIdx.y = peer, 16 bytes per lane and step.  (A kernel instead of one
 // hipMemcpyAsync per peer so that the abort word can stop it: copies the host has already enqueued cannot be taken back.)
-__global__ void __launch_bounds__(256) k_ipc_copy(const IpcCopies c, const uint8_t* src, uint64_t bytes, const uint32_t* abort) {
+// `gave_up`: the peers' notes in the own mailbox (k_ipc_wait): nothing is copied into a peer that has given up.
+__global__ void __launch_bounds__(256) k_ipc_copy(const IpcCopies c, const uint8_t* src, uint64_t bytes, const uint32_t* abort, const uint32_t* gave_up) {
     if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     uint8_t* dst = c.dst[blockIdx.y];
     if (!dst) return;
+    if (__hip_atomic_load(gave_up + blockIdx.y, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0u;
     const uint64_t whole = aligned ? (bytes & ~(uint64_t)15) : 0u;
     // four 16-byte loads in flight per lane and step (the stores over the link are posted; the loads are what a step waits for)
@@ -74,16 +80,16 @@ hipError_t launch_ipc_signal(const IpcPeers& peers, uint32_t value, const uint32
     hipLaunchKernelGGL(k_ipc_signal, dim3(1), dim3(64), 0, st, peers, value, abort);
     return hipGetLastError();
 }
-hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* abort, uint32_t* timed_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, st, own, value, abort, timed_out);
+hipError_t launch_ipc_wait(const IpcPeers& own, uint32_t value, uint32_t* abort, uint32_t* timed_out, const IpcPeers& notes, hipStream_t st) {
+    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, st, own, value, abort, timed_out, notes);
     return hipGetLastError();
 }
-hipError_t launch_ipc_copy(const IpcCopies& c, int world, const uint8_t* src, uint64_t bytes, const uint32_t* abort, hipStream_t st) {
+hipError_t launch_ipc_copy(const IpcCopies& c, int world, const uint8_t* src, uint64_t bytes, const uint32_t* abort, const uint32_t* gave_up, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
     // a few workgroups per peer keep a link busy without taking the chip from the frame that is being shaded beside the exchange
     const uint64_t chunks = (bytes + 4u * 256u * 16u - 1) / (4u * 256u * 16u);
     const uint32_t gx = (uint32_t)(chunks < 32u ? chunks : 32u);  // per peer; grid-stride beyond
-    hipLaunchKernelGGL(k_ipc_copy, dim3(gx, (uint32_t)world), dim3(256), 0, st, c, src, bytes, abort);
+    hipLaunchKernelGGL(k_ipc_copy, dim3(gx, (uint32_t)world), dim3(256), 0, st, c, src, bytes, abort, gave_up);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create
            "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_bloom_mip_rows", "sah_bloom_from_mip", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate", "sah_probe_notify_updated",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_rt_set_bounces", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
-           "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister",
+           "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister", "sah_ipc_reset",
            "sah_chain_create", "sah_chain_submit", "sah_chain_flush", "sah_chain_counts", "sah_chain_destroy"]
 
 
@@ -96,6 +96,7 @@ def load():
     lib.sah_ipc_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.sah_ipc_register.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.sah_ipc_unregister.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sah_ipc_reset.argtypes = [C.c_void_p]
     lib.sah_chain_create.argtypes = [C.c_void_p, C.POINTER(_abi.ChainPlan), C.POINTER(_abi.ChainFrame), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.POINTER(C.c_void_p)]
     lib.sah_chain_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -299,6 +300,10 @@ class Context:
     def ipc_unregister(self, device_ptr):
         """Before a registered buffer is freed (every rank, same order): waits for the context's streams and frees the registration."""
         self._check(self.lib.sah_ipc_unregister(self.handle, C.c_void_p(device_ptr)))
+
+    def ipc_reset(self):
+        """After SahError COMM from the direct exchange, collectively: sync (ignore its error), barrier, ipc_reset, barrier (see sah_hip.h)."""
+        self._check(self.lib.sah_ipc_reset(self.handle))
 
     def allgather_bytes(self, device_ptr, bytes_per_rank):
         self._check(self.lib.sah_allgather_bytes(self.handle, C.c_void_p(device_ptr), bytes_per_rank))

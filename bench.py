@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# BASELINE.json configs[1..4] plus diagnostics.  The headline (`metric`) is 4k_deferred_gi.
+# BASELINE.json configs[0..4] plus diagnostics.  The headline (`metric`) is 4k_deferred_gi.
 WORKLOADS = {
     "4k_deferred_gi": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv"),
     "4k_deferred_gi_scene_shadow": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", shadow="scene"),  # CSM ray-cast from the atrium
@@ -40,6 +40,9 @@ WORKLOADS = {
     "4k_deferred_gi_produced": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="lpv", produced=True),
     "4k_deferred_gi_random": dict(res=(3840, 2160), gbuffer="random", sun="csm", gi="lpv"),
     "4k_deferred_only": dict(res=(3840, 2160), gbuffer="atrium", sun="csm", gi="none"),
+    # configs[0]: 1280x720, a single directional light, deferred shading only — the reference's default sun (RT mode, directional_light.rt.slang) with
+    # every shadow ray unoccluded (mask = 1), no GI overlay
+    "720p_deferred_only": dict(res=(1280, 720), gbuffer="atrium", sun="rt", gi="none", mask="ones"),                      # configs[0]
     "1080p_deferred_gi": dict(res=(1920, 1080), gbuffer="atrium", sun="csm", gi="lpv"),
     "8k_deferred_gi": dict(res=(7680, 4320), gbuffer="atrium", sun="csm", gi="lpv"),
     # light radii per SURVEY.md §8-d: 64 lights r = 6 m, 256 lights r = 4 m, 1024 lights r = 3 m
@@ -102,10 +105,10 @@ def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope
       valu_issue  VALU issue cycles of one launch / (1024 SIMDs x 2.4 GHz x the LIVE kernel time).  The cycles are a MODEL: the measured
                   SQ_INSTS_VALU of a separate rocprofv3 --pmc pass of the same build and workload (profiles/roofline_static.json says
                   which file; PMC counters cannot be read from inside a run) x the cycles per instruction of the kernel's static VALU
-                  mix priced with the measured issue costs (tools/pmc_to_static.py, profiles/r1_valu_issue_cost.txt).  Beside it:
-                  `valu_busy_rocprof`, rocprof's VALUBusy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles) — it charges every instruction a whole
-                  quad-cycle, so it overstates kernels made of 2-cycle fp32 ops and can exceed 1 — and `lower_bound`, every
-                  instruction at the cheapest cost (2.3 cycles);
+                  mix priced with the measured issue costs (tools/pmc_to_static.py, profiles/r1_valu_issue_cost.txt).  Beside it
+                  `lower_bound`, every instruction at the cheapest cost (2.3 cycles).  (rocprof's VALUBusy — SQ_ACTIVE_INST_VALU x 4 / SIMD
+                  cycles — charged every instruction a whole quad-cycle and read 1.16-1.36 for the tiled kernels: a mis-scaled counter
+                  is not a fraction, and the line no longer carries it.)
       fp32        algorithmic FLOP per pixel (counted once from the per-pixel operator list) x pixels / LIVE kernel time
                   against the 157.3 TFLOP/s vector peak.
     `traffic` is the measured HBM traffic per launch of that same static pass (FETCH_SIZE doubled per the guide's gfx950 correction +
@@ -138,13 +141,12 @@ def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope
     if st.get("valu_wave_insts_per_launch"):
         simd_cycles = SIMDS * MAX_CLOCK_HZ * t
         insts = st["valu_wave_insts_per_launch"] * share
-        busy = st.get("valu_active_cycles_per_launch", 0.0) * share / simd_cycles
         lower = insts * 2.3 / simd_cycles
-        f = st["valu_model_issue_cycles_per_launch"] * share / simd_cycles if st.get("valu_model_issue_cycles_per_launch") else busy
+        f = st["valu_model_issue_cycles_per_launch"] * share / simd_cycles if st.get("valu_model_issue_cycles_per_launch") else lower
         fracs["valu"] = f
         # the static mix prices every instruction once, the kernel runs its loops' instructions many times: a model that comes out above
         # 1 says "at the issue roofline, and the executed mix is cheaper than the static one" — reported as 1 with the raw value beside it
-        out["valu_issue"] = {"frac": round(min(f, 1.0), 4), **({"model_uncapped": round(f, 4)} if f > 1.0 else {}), "model_cycles_per_inst": st.get("valu_model_cycles_per_inst"), "valu_busy_rocprof": round(busy, 4),
+        out["valu_issue"] = {"frac": round(min(f, 1.0), 4), **({"model_uncapped": round(f, 4)} if f > 1.0 else {}), "model_cycles_per_inst": st.get("valu_model_cycles_per_inst"),
                              "lower_bound": round(lower, 4), "insts_per_px": round(st["valu_wave_insts_per_launch"] * 64 / st["pixels"], 1),
                              "peak": "1024 SIMDs x 2.4 GHz", "source": f"{st['source']} (static) + static ISA mix x profiles/r1_valu_issue_cost.txt"}
     if st.get("flops_per_px"):
@@ -159,7 +161,11 @@ def roofline(workload, world, achieved_gbs, kernel_ms_mean, kernel_ms_min, scope
     return out
 
 
-def main():
+class Run:
+    """The state the stages of one benchmark run share (plain attributes; each stage below says what it adds)."""
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -176,6 +182,8 @@ def main():
     ap.add_argument("--rt-bounces", type=int, default=0, help="traced workload: sah_rt_set_bounces for the GI generators (the reference: 0)")
     ap.add_argument("--watchdog-s", type=float, default=300.0, help="N>1: end the rank when a phase makes no progress for this long (0: never)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
+    ap.add_argument("--python-loop", action="store_true", help="two frames in flight: enqueue every pass from Python (chain.PipelinedChain) instead of through the library's own "
+                    "frame loop (sah_chain_submit, chain.NativePipelinedChain: the default)")
     ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
                     "exchange over peer-mapped memory (sah_ipc_*: every rank copies its rows straight into every peer's buffer; handles go through torch.distributed)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 launched on a box with ONE GPU: every rank uses cuda:0, torch.distributed runs over "
@@ -184,49 +192,65 @@ def main():
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of the library's sah_allgather_rows")
     ap.add_argument("--ramp-ms", type=float, default=200.0, help="untimed: run the step back to back for this long before the W warm-up steps, so that the "
                     "timed region does not start in the GPU's idle power state (reported in config.clock_ramp_ms)")
-    ap.add_argument("--repack-lpv", action="store_true", help="LPV / cache workloads: lpv_generation = probe_generation = 0, i.e. the library rebuilds its gather copy of the LPV on every "
-                    "step (5 us + a launch), as it must when the volumes change every frame; default: the volumes of this benchmark never change, so "
-                    "their change counter stays at 1 and the copy made by the first step is kept (config.lpv_gather_copy says which)")
+    ap.add_argument("--lpv-copy", choices=["propagate", "rebuild", "kept"], default="propagate",
+                    help="LPV workloads: where the library's interleaved gather copy of the three volumes comes from.  propagate (default): the frame's LPV "
+                         "maintenance is the library's own — sah_lpv_propagate runs once before the loop on the synthetic volumes (one step; the benchmark's "
+                         "volumes do not change afterwards, the reference's frame would run it every frame: light_propagation_volume.cpp:970-1063), its last "
+                         "step stores the gather copy beside the volumes (SAH_GENERATION_TRACKED), and no Lighting pass rebuilds it; the same pass with the "
+                         "copy rebuilt inside every step is timed beside it (config.lpv_gather_copy_rebuilt_every_step).  rebuild: lpv_generation 0, k_lpv_pack "
+                         "runs inside every timed step — a frame whose volumes somebody else's pass rewrites.  kept: lpv_generation 1 on the synthetic volumes "
+                         "(rounds 1-4's default)")
+    ap.add_argument("--repack-lpv", action="store_true", help="(rounds 3-4; now the default) same as --lpv-copy rebuild --probe-copy rebuild")
+    ap.add_argument("--probe-copy", choices=["patched", "rebuild", "kept"], default="patched",
+                    help="irradiance-cache workloads: the library's fp32 copy of the irradiance atlas.  patched (default): the context tracks the atlas "
+                         "(SAH_GENERATION_TRACKED) and every step re-widens the blocks of 1024 probes — the reference's r.GI.Cache.UpdatesPerFrame — through "
+                         "sah_probe_notify_updated (the traced workload's own sah_probe_update does it by itself); rebuild: probe_generation 0, the whole atlas "
+                         "every step; kept: probe_generation 1")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2], help="one-GPU chain workloads: 2 = the post chain of a frame runs on a second "
                     "stream beside the lighting of the next one (as the N > 1 loop always does); every frame still completes inside the timed region")
     ap.add_argument("--strict-tonemap", action="store_true", help="chain workloads: the strict composite (codes bit-identical to the oracle) instead of "
                     "SAH_TONEMAP_TOLERANCE_1CODE (within one R8G8B8A8 code of it: north_star's tolerance for the final image)")
     ap.add_argument("--synth-device", choices=["cuda", "cpu"], default="cuda", help="where the synthetic inputs are generated (same values either way).  cpu: no torch "
-                    "kernel is launched before the timed passes — for rocprofv3 --pmc runs of the 8K workloads, whose input synthesis on the GPU dies inside the "
-                    "profiler's dispatch interception (profiles/README.md, round 4)")
+                    "kernel is launched before the timed passes (diagnostic: profiles/README.md \"8K under --pmc\" — the fault it was added for turned out to be "
+                    "the light statistics' 16,384 outstanding dispatches, not the input synthesis)")
     ap.add_argument("--no-light-stats", action="store_true", help="light workloads: skip the lights-per-tile / per-pixel statistics (torch kernels on full-frame tensors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.repack_lpv:
+        args.lpv_copy, args.probe_copy = "rebuild", "rebuild"
+    return args
 
+
+def setup_distributed(args):
+    """torch, the process group, this rank's device and the stdout discipline.  Adds: torch, dist, world, rank, local_rank, dev, red_dev, rehearsal,
+    exchange, torch_pg, saved_stdout, beat."""
     import torch
     import torch.distributed as dist
-
-    from androidrenderer_amd import _abi, chain as chain_mod, frame, images, lib, scene, shard, synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    R = Run()
+    R.args, R.torch, R.dist = args, torch, dist
+    R.world = int(os.environ.get("WORLD_SIZE", "1"))
+    R.rank = int(os.environ.get("RANK", "0"))
+    R.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if R.world != args.gpus and R.world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    rehearsal = args.rehearse_on_one_gpu and world > 1
-    if rehearsal:
-        local_rank = 0
+    R.rehearsal = args.rehearse_on_one_gpu and R.world > 1
+    if R.rehearsal:
+        R.local_rank = 0
         args.exchange = "ipc"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    red_dev = torch.device("cpu") if rehearsal else dev  # where the small all-reduces of this file live (gloo has no GPU tensors here)
-    exchange = world > 1 or args.force_gather  # the exchange step is part of the loop
-    torch_pg = world > 1 or (args.force_gather and args.torch_gather)  # torch.distributed: barrier + max over ranks (+ --torch-gather)
-    saved_stdout = None
-    if exchange:
+    torch.cuda.set_device(R.local_rank)
+    R.dev = torch.device("cuda", R.local_rank)
+    R.red_dev = torch.device("cpu") if R.rehearsal else R.dev  # where the small all-reduces of this file live (gloo has no GPU tensors here)
+    R.exchange = R.world > 1 or args.force_gather  # the exchange step is part of the loop
+    R.torch_pg = R.world > 1 or (args.force_gather and args.torch_gather)  # torch.distributed: barrier + max over ranks (+ --torch-gather)
+    R.saved_stdout = None
+    if R.exchange:
         # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line by pointing
         # fd 1 at stderr until the result is printed
         sys.stdout.flush()
-        saved_stdout = os.dup(1)
+        R.saved_stdout = os.dup(1)
         os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # N > 1: a collective that never completes would leave the launcher waiting for ever.  A watchdog thread ends the rank with a message
@@ -235,245 +259,313 @@ def main():
 
     def beat(phase):
         heart["t"], heart["phase"] = time.monotonic(), phase
-
-    if world > 1 and args.watchdog_s > 0:
+    R.beat = beat
+    if R.world > 1 and args.watchdog_s > 0:
         import threading
 
         def watch():
             while True:
                 time.sleep(5.0)
                 if time.monotonic() - heart["t"] > args.watchdog_s:
-                    print(f"[bench] rank {rank}: no progress for {args.watchdog_s:.0f} s in phase '{heart['phase']}' — giving up", file=sys.stderr, flush=True)
+                    print(f"[bench] rank {R.rank}: no progress for {args.watchdog_s:.0f} s in phase '{heart['phase']}' — giving up", file=sys.stderr, flush=True)
                     os._exit(124)
         threading.Thread(target=watch, daemon=True).start()
-    if rehearsal:
+    if R.rehearsal:
         dist.init_process_group(backend="gloo")
-    elif world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-    elif torch_pg:
-        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29511", rank=0, world_size=1, device_id=dev)
+    elif R.world > 1:
+        dist.init_process_group(backend="nccl", device_id=R.dev)
+    elif R.torch_pg:
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29511", rank=0, world_size=1, device_id=R.dev)
+    return R
 
+
+def all_ranks_min(R, value):
+    """an int every rank agrees on: the minimum over the ranks (1 = everybody fine)"""
+    if not R.torch_pg:
+        return int(value)
+    t = R.torch.tensor([int(value)], dtype=R.torch.int32, device=R.red_dev)
+    R.dist.all_reduce(t, op=R.dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def make_inputs(R):
+    """The workload's synthetic frame, identical on every rank (fixed seeds).  Adds: wl, W, H, sun_mode, gi_kind, n_lights, chain, lights, fr, d_arr,
+    bytes_per_pixel, probe_ids."""
+    from androidrenderer_amd import _abi, frame, scene, synth
+    args = R.args
     if args.workload is None:
-        args.workload = "4k_probe_gi_chain" if world > 1 else "4k_deferred_gi"
-    wl = WORKLOADS[args.workload]
-    W, H = wl["res"]
-    sun_mode = {"off": _abi.SHADOW_MODE_OFF, "csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}[wl["sun"]]
-    gi_kind = {"none": _abi.GI_NONE, "lpv": _abi.GI_LPV, "cache": _abi.GI_CACHE, "rtgi": _abi.GI_RTGI}[wl["gi"]]
-    n_lights = wl.get("lights", 0)
-    chain = bool(wl.get("chain"))
+        args.workload = "4k_probe_gi_chain" if R.world > 1 else "4k_deferred_gi"
+    R.wl = wl = WORKLOADS[args.workload]
+    R.W, R.H = wl["res"]
+    R.sun_mode = {"off": _abi.SHADOW_MODE_OFF, "csm": _abi.SHADOW_MODE_CSM, "rt": _abi.SHADOW_MODE_RT}[wl["sun"]]
+    R.gi_kind = {"none": _abi.GI_NONE, "lpv": _abi.GI_LPV, "cache": _abi.GI_CACHE, "rtgi": _abi.GI_RTGI}[wl["gi"]]
+    R.n_lights = wl.get("lights", 0)
+    R.chain = bool(wl.get("chain"))
+    R.beat("inputs")
+    R.lights = synth.point_lights(scene.SceneView.default(R.W, R.H), R.n_lights, wl["radius"], seed=8) if R.n_lights else None
+    fr = frame.LightingInputs(R.W, R.H, seed=2, sun_mode=R.sun_mode, gi=R.gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=R.lights,
+                              synth_device=str(R.dev) if args.synth_device == "cuda" else "cpu", shadow=wl.get("shadow", "noise"))
+    if wl.get("mask") == "ones":  # "deferred shading only": every shadow ray of the RT-mode sun unoccluded
+        fr.arrays["shadow_mask"] = np.ones((R.H, R.W), dtype=np.float32)
+    fr.lpv_generation = {"propagate": _abi.GENERATION_TRACKED, "rebuild": 0, "kept": 1}[args.lpv_copy]  # (propagate: see propagate_lpv below)
+    # (the traced workload folds probes every step: sah_probe_update keeps a tracked copy current by itself)
+    fr.probe_generation = {"patched": _abi.GENERATION_TRACKED, "rebuild": 0, "kept": 1}[args.probe_copy]
+    R.fr = fr
+    R.d_arr = fr.device_arrays(R.dev)
+    R.bytes_per_pixel = fr.bytes_per_pixel()
+    R.probe_ids = None
+    if R.gi_kind == _abi.GI_CACHE and args.probe_copy == "patched" and not wl.get("traced"):
+        cells = synth.rng(33).permutation(32 * 32 * 32)[:1024]
+        R.probe_ids = R.torch.from_numpy(np.stack([cells % 32, (cells // 32) % 32, cells // 1024], axis=-1).astype(np.int32).reshape(-1)).to(R.dev)
 
-    beat("inputs")
-    # ---- inputs (identical on every rank: generated from fixed seeds) ----------------------------------------------
-    lights = None
-    if n_lights:
-        lights = synth.point_lights(scene.SceneView.default(W, H), n_lights, wl["radius"], seed=8)
-    fr = frame.LightingInputs(W, H, seed=2, sun_mode=sun_mode, gi=gi_kind, flavour=wl["gbuffer"], shadowmap_res=4096, lights=lights,
-                              synth_device=str(dev) if args.synth_device == "cuda" else "cpu", shadow=wl.get("shadow", "noise"))
-    fr.lpv_generation = 0 if args.repack_lpv else 1
-    fr.probe_generation = 0 if args.repack_lpv else 1  # (the traced workload folds probes every step: sah_probe_update drops the copy anyway)
-    d_arr = fr.device_arrays(dev)
-    bytes_per_pixel = fr.bytes_per_pixel()
 
-    beat("library context + communicator")
-    # ---- the library context: its own communicator unless --torch-gather ------------------------------------------
-    gather = exchange and not args.no_gather
-    lib_gather = gather and not args.torch_gather
+def make_context(R):
+    """The library context with its own communicator (unless --torch-gather), the direct exchange's connection and the side stream.
+    Adds: ctx, gather, lib_gather, use_ipc, comm_note, comm_stream, allgather_handles, rows_per, r0, r1."""
+    from androidrenderer_amd import chain as chain_mod, lib, shard
+    args, torch, dist = R.args, R.torch, R.dist
+    R.beat("library context + communicator")
+    R.gather = R.exchange and not args.no_gather
+    R.lib_gather = R.gather and not args.torch_gather
     comm_id = None
-    use_ipc = lib_gather and args.exchange == "ipc" and world > 1
-    if lib_gather and not use_ipc:
-        if world > 1:  # rank 0's ncclUniqueId to everybody
-            box = [lib.comm_unique_id() if rank == 0 else None]
+    R.use_ipc = R.lib_gather and args.exchange == "ipc" and R.world > 1
+    if R.lib_gather and not R.use_ipc:
+        if R.world > 1:  # rank 0's ncclUniqueId to everybody
+            box = [lib.comm_unique_id() if R.rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm_id = box[0]
         else:
             comm_id = lib.comm_unique_id()
-    comm_note = None
+    R.comm_note = None
     try:
-        ctx = lib.Context(device=local_rank, rank=rank, world=world, comm_id=comm_id)
+        R.ctx = lib.Context(device=R.local_rank, rank=R.rank, world=R.world, comm_id=comm_id)
         ok = 1
     except Exception as err:  # the communicator could not be built on this rank: every rank falls back together, and the line says so
-        ctx, ok, comm_note = None, 0, str(err)
-    if world > 1 and lib_gather:
-        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
+        R.ctx, ok, R.comm_note = None, 0, str(err)
+    if R.world > 1 and R.lib_gather:
+        ok = all_ranks_min(R, ok)
     if not ok:
-        if not lib_gather:
-            raise SystemExit(f"sah_create failed: {comm_note}")
-        print(f"[bench] rank {rank}: library communicator unavailable ({comm_note}); all ranks use torch.distributed for the exchange", file=sys.stderr)
-        lib_gather = False
-        del ctx
-        ctx = lib.Context(device=local_rank, rank=rank, world=world, comm_id=None)
-        comm_note = comm_note or "another rank failed to build the library communicator"
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        if not R.lib_gather:
+            raise SystemExit(f"sah_create failed: {R.comm_note}")
+        print(f"[bench] rank {R.rank}: library communicator unavailable ({R.comm_note}); all ranks use torch.distributed for the exchange", file=sys.stderr)
+        R.lib_gather = False
+        R.ctx = lib.Context(device=R.local_rank, rank=R.rank, world=R.world, comm_id=None)
+        R.comm_note = R.comm_note or "another rank failed to build the library communicator"
+    R.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def allgather_handles(b):  # the channel the direct exchange's IPC handles travel over
-        out_h = [None] * world
+        out_h = [None] * R.world
         dist.all_gather_object(out_h, b)
         return out_h
-    if use_ipc:
-        chain_mod.connect_direct_exchange(ctx, allgather_handles)
-    comm_stream = None
-    if lib_gather and not args.no_overlap:
-        comm_stream = torch.cuda.Stream(device=dev)
-        if not chain:
-            ctx.comm_set_stream(comm_stream.cuda_stream)
-
+    R.allgather_handles = allgather_handles
+    if R.use_ipc:
+        chain_mod.connect_direct_exchange(R.ctx, allgather_handles)
+    R.comm_stream = None
+    if R.lib_gather and not args.no_overlap:
+        R.comm_stream = torch.cuda.Stream(device=R.dev)
+        if not R.chain:
+            R.ctx.comm_set_stream(R.comm_stream.cuda_stream)
     # row shard of this rank: ceil(H / world) rows per gather slot, clipped to the image (androidrenderer_amd/shard.py)
-    rows_per = -(-H // world)
-    r0, r1 = shard.lighting_rows(H, world, rank)
-    if world > 1:
-        fr.row_begin, fr.row_end = r0, r1
-    if wl.get("produced"):  # overwrite the synthetic planes with what the library's own producer passes make of the atrium mesh
-        from androidrenderer_amd import mesh
-        geo_arrays = mesh.to_device(mesh.atrium(8).arrays(), dev)
-        geo = mesh.geometry(geo_arrays, [])
-        ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
-        ctx.shadow_render(geo, fr.sun.constants, 4, images.volume(d_arr["shadowmap"], _abi.FORMAT_D16_UNORM))
-        rsm_t = {"flux": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device=dev), "normals": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device=dev),
-                 "depth": torch.zeros((4, 128, 128), dtype=torch.int16, device=dev)}
-        rsm = _abi.RsmTargets(images.volume(rsm_t["flux"], _abi.FORMAT_R8G8B8A8_SRGB), images.volume(rsm_t["normals"], _abi.FORMAT_R8G8B8A8_UNORM),
-                              images.volume(rsm_t["depth"], _abi.FORMAT_D16_UNORM))
-        ctx.rsm_render(geo, fr.sun.constants, fr.lpv.matrices, 4, rsm)
-        vols = [d_arr[k] for k in ("lpv_r", "lpv_g", "lpv_b")]
-        for v in vols:
-            v.zero_()
-        vd = [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols]
-        vpls = torch.zeros((4096, 4), dtype=torch.int32, device=dev)
-        count = torch.zeros(1, dtype=torch.int32, device=dev)
-        for c in range(4):
-            ctx.lpv_extract_vpls(rsm, fr.lpv.matrices, c, 0.25, vpls.data_ptr(), count.data_ptr())
-            ctx.lpv_inject_vpls(vpls.data_ptr(), count.data_ptr(), 4096, fr.lpv.matrices, c, 4, vd)
-        scratch = [torch.zeros_like(v) for v in vols]
-        ctx.lpv_propagate(vd, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in scratch], 4, 32)
-        torch.cuda.synchronize()
+    R.rows_per = -(-R.H // R.world)
+    R.r0, R.r1 = shard.lighting_rows(R.H, R.world, R.rank)
+    if R.world > 1:
+        R.fr.row_begin, R.fr.row_end = R.r0, R.r1
 
-    traced = None
-    if wl.get("traced"):
-        from androidrenderer_amd import mesh
-        geo_arrays = mesh.to_device(mesh.atrium(args.atrium_subdiv).arrays(), dev)
-        geo = mesh.geometry(geo_arrays, [])
-        ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
-        ctx.rt_set_bounces(args.rt_bounces)
-        noise_t = torch.from_numpy(synth.rng(31).integers(0, 256, (128, 128, 4), dtype=np.uint8)).to(dev)
-        planes_rt = (images.plane(d_arr["depth"], _abi.FORMAT_D32_SFLOAT), images.plane(d_arr["normals"], _abi.FORMAT_R16G16B16A16_SFLOAT),
-                     images.plane(noise_t, _abi.FORMAT_R8G8B8A8_UNORM), images.plane(d_arr["ao"], _abi.FORMAT_R32_SFLOAT),
-                     images.plane(d_arr["shadow_mask"], _abi.FORMAT_R32_SFLOAT))
-        # the irradiance cache's own rays: r.GI.Cache.UpdatesPerFrame = 1024 probes x 400 GI rays, folded into the atlases the Lighting
-        # pass samples (irradiance_cache.cpp:21-23, 585-724)
-        import ctypes as C
-        n_probes = 1024
-        cells = synth.rng(33).permutation(32 * 32 * 32)[:n_probes]
-        probe_ids = torch.from_numpy(np.stack([cells % 32, (cells // 32) % 32, cells // 1024], axis=-1).astype(np.int32).reshape(-1)).to(dev)
-        trace_results = torch.zeros((n_probes, 20, 20, 4), dtype=torch.int16, device=dev)
-        light_cache = torch.zeros((32, 416, 416), dtype=torch.int32, device=dev)
-        average = torch.zeros((32, 32, 32), dtype=torch.int32, device=dev)
-        sky_luts = _abi.SkyLuts(images.plane(d_arr["sky_t"], _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(d_arr["sky_v"], _abi.FORMAT_R16G16B16A16_SFLOAT))
-        pt = _abi.ProbeTraceDesc()
-        for c, (cmin, spacing) in enumerate(fr.probe_cascades()):
-            pt.cascades[c].probe_spacing = spacing
-            for i in range(3):
-                pt.cascades[c].min[i] = cmin[i]
-        pt.probes_to_update, pt.num_probes = probe_ids.data_ptr(), n_probes
-        pt.sun, pt.sky, pt.noise = C.pointer(fr.sun.constants), C.pointer(sky_luts), C.pointer(planes_rt[2])
-        pt.probe_irradiance = images.volume(d_arr["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
-        pt.probe_depth = images.volume(d_arr["probe_depth"], _abi.FORMAT_R16G16_SFLOAT)
-        pt.probe_validity = images.volume(d_arr["probe_val"], _abi.FORMAT_R8_UNORM)
-        pt.probe_size[0], pt.probe_size[1] = 5, 6
-        pt.trace_results = images.volume(trace_results, _abi.FORMAT_R16G16B16A16_SFLOAT)
-        atlases = _abi.ProbeAtlases(pt.probe_irradiance, images.volume(light_cache, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_depth,
-                                    images.volume(average, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_validity)
-        rtgi_rb, rtgi_ri = (torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(2))
-        if args.shadow_samples is not None:
-            fr.sun.constants.num_shadow_samples = args.shadow_samples
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
-        torch.cuda.synchronize()
-        e[0].record()
-        rt_stats = ctx.rt_build(geo)
-        e[1].record()
 
-        trace_rows = [(0, 0)]  # N > 1: the rows this rank's lighting reads (set below, once the row plan exists); the structure and the probes are replicated
+def propagate_lpv(R):
+    """--lpv-copy propagate: the workload's LPV volumes become what ONE step of the library's sah_lpv_propagate makes of the synthetic ones — the
+    step that, in a frame, ends the LPV maintenance and stores the Lighting pass's gather copy beside the volumes.  Host copies follow, so that the
+    CPU baseline shades the same inputs."""
+    from androidrenderer_amd import _abi, frame, images
+    torch, ctx, fr, d_arr = R.torch, R.ctx, R.fr, R.d_arr
+    keys = ("lpv_r", "lpv_g", "lpv_b")
+    b_t = [torch.zeros_like(d_arr[k]) for k in keys]
+    ctx.lpv_propagate([images.volume(d_arr[k], _abi.FORMAT_R16G16B16A16_SFLOAT) for k in keys], [images.volume(t, _abi.FORMAT_R16G16B16A16_SFLOAT) for t in b_t], 4, 1)
+    torch.cuda.synchronize()
+    for k, t in zip(keys, b_t):
+        d_arr[k] = t
+        fr.arrays[k] = frame.from_torch(t, np.uint16).view(np.float16).reshape(fr.arrays[k].shape)
 
-        def trace_planes():
-            ctx.probe_trace(pt)
-            ctx.probe_update(atlases, pt.trace_results, probe_ids.data_ptr(), n_probes)
-            for r0, r1 in trace_rows:
-                ctx.rt_set_rows(r0, r1)
-                ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
-                ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
-            ctx.rt_set_rows(0, 0)
-        trace_planes()  # warm
-        torch.cuda.synchronize()
-        e[2].record()
-        ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
-        e[3].record()
-        ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
-        e[4].record()
+
+def produce_inputs(R):
+    """`produced` workloads: overwrite the synthetic planes with what the library's own producer passes make of the atrium mesh (rasterised
+    G-buffer and shadow cascades, LPV from RSM -> VPLs -> propagation)."""
+    from androidrenderer_amd import _abi, images, mesh
+    torch, ctx, fr, d_arr, dev = R.torch, R.ctx, R.fr, R.d_arr, R.dev
+    geo = mesh.geometry(mesh.to_device(mesh.atrium(8).arrays(), dev), [])
+    ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
+    ctx.shadow_render(geo, fr.sun.constants, 4, images.volume(d_arr["shadowmap"], _abi.FORMAT_D16_UNORM))
+    rsm_t = {"flux": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device=dev), "normals": torch.zeros((4, 128, 128, 4), dtype=torch.uint8, device=dev),
+             "depth": torch.zeros((4, 128, 128), dtype=torch.int16, device=dev)}
+    rsm = _abi.RsmTargets(images.volume(rsm_t["flux"], _abi.FORMAT_R8G8B8A8_SRGB), images.volume(rsm_t["normals"], _abi.FORMAT_R8G8B8A8_UNORM),
+                          images.volume(rsm_t["depth"], _abi.FORMAT_D16_UNORM))
+    ctx.rsm_render(geo, fr.sun.constants, fr.lpv.matrices, 4, rsm)
+    vols = [d_arr[k] for k in ("lpv_r", "lpv_g", "lpv_b")]
+    for v in vols:
+        v.zero_()
+    vd = [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in vols]
+    vpls = torch.zeros((4096, 4), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    for c in range(4):
+        ctx.lpv_extract_vpls(rsm, fr.lpv.matrices, c, 0.25, vpls.data_ptr(), count.data_ptr())
+        ctx.lpv_inject_vpls(vpls.data_ptr(), count.data_ptr(), 4096, fr.lpv.matrices, c, 4, vd)
+    scratch = [torch.zeros_like(v) for v in vols]
+    ctx.lpv_propagate(vd, [images.volume(v, _abi.FORMAT_R16G16B16A16_SFLOAT) for v in scratch], 4, 32)
+    torch.cuda.synchronize()
+    R.keep_produced = (geo, rsm_t, scratch)
+
+
+def setup_traced(R):
+    """`traced` workload: the G-buffer rasterised from the atrium mesh, the AO plane and the sun's shadow mask traced every step against the
+    structure sah_rt_build made of the same mesh, 1024 probes of the irradiance cache traced and folded into the atlases every step
+    (irradiance_cache.cpp:21-23, 585-724).  Adds: traced (the report's dict), trace_planes(), trace_rows."""
+    from androidrenderer_amd import _abi, images, mesh, synth
+    args, torch, ctx, fr, d_arr, dev, W, H = R.args, R.torch, R.ctx, R.fr, R.d_arr, R.dev, R.W, R.H
+    geo = mesh.geometry(mesh.to_device(mesh.atrium(args.atrium_subdiv).arrays(), dev), [])
+    ctx.gbuffer_render(geo, fr.view.gpu_data, images.gbuffer(d_arr))
+    ctx.rt_set_bounces(args.rt_bounces)
+    noise_t = torch.from_numpy(synth.rng(31).integers(0, 256, (128, 128, 4), dtype=np.uint8)).to(dev)
+    planes_rt = (images.plane(d_arr["depth"], _abi.FORMAT_D32_SFLOAT), images.plane(d_arr["normals"], _abi.FORMAT_R16G16B16A16_SFLOAT),
+                 images.plane(noise_t, _abi.FORMAT_R8G8B8A8_UNORM), images.plane(d_arr["ao"], _abi.FORMAT_R32_SFLOAT),
+                 images.plane(d_arr["shadow_mask"], _abi.FORMAT_R32_SFLOAT))
+    n_probes = 1024
+    cells = synth.rng(33).permutation(32 * 32 * 32)[:n_probes]
+    probe_ids = torch.from_numpy(np.stack([cells % 32, (cells // 32) % 32, cells // 1024], axis=-1).astype(np.int32).reshape(-1)).to(dev)
+    trace_results = torch.zeros((n_probes, 20, 20, 4), dtype=torch.int16, device=dev)
+    light_cache = torch.zeros((32, 416, 416), dtype=torch.int32, device=dev)
+    average = torch.zeros((32, 32, 32), dtype=torch.int32, device=dev)
+    sky_luts = _abi.SkyLuts(images.plane(d_arr["sky_t"], _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(d_arr["sky_v"], _abi.FORMAT_R16G16B16A16_SFLOAT))
+    pt = _abi.ProbeTraceDesc()
+    for c, (cmin, spacing) in enumerate(fr.probe_cascades()):
+        pt.cascades[c].probe_spacing = spacing
+        for i in range(3):
+            pt.cascades[c].min[i] = cmin[i]
+    pt.probes_to_update, pt.num_probes = probe_ids.data_ptr(), n_probes
+    pt.sun, pt.sky, pt.noise = C.pointer(fr.sun.constants), C.pointer(sky_luts), C.pointer(planes_rt[2])
+    pt.probe_irradiance = images.volume(d_arr["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
+    pt.probe_depth = images.volume(d_arr["probe_depth"], _abi.FORMAT_R16G16_SFLOAT)
+    pt.probe_validity = images.volume(d_arr["probe_val"], _abi.FORMAT_R8_UNORM)
+    pt.probe_size[0], pt.probe_size[1] = 5, 6
+    pt.trace_results = images.volume(trace_results, _abi.FORMAT_R16G16B16A16_SFLOAT)
+    atlases = _abi.ProbeAtlases(pt.probe_irradiance, images.volume(light_cache, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_depth,
+                                images.volume(average, _abi.FORMAT_B10G11R11_UFLOAT_PACK32), pt.probe_validity)
+    rtgi_rb, rtgi_ri = (torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(2))
+    if args.shadow_samples is not None:
+        fr.sun.constants.num_shadow_samples = args.shadow_samples
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
+    torch.cuda.synchronize()
+    e[0].record()
+    rt_stats = ctx.rt_build(geo)
+    e[1].record()
+    R.trace_rows = [(0, 0)]  # N > 1: the rows this rank's lighting reads (set once the row plan exists); the structure and the probes are replicated
+
+    def trace_planes():
         ctx.probe_trace(pt)
-        e[5].record()
         ctx.probe_update(atlases, pt.trace_results, probe_ids.data_ptr(), n_probes)
-        e[6].record()
-        # (not part of this workload's frame — the RTGI mode's generator, one GI ray per pixel — timed once for the record)
-        ctx.rtgi_trace(fr.view.gpu_data, fr.sun.constants, sky_luts, planes_rt[0], planes_rt[1], planes_rt[2],
-                       images.plane(rtgi_rb, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(rtgi_ri, _abi.FORMAT_R16G16B16A16_SFLOAT))
-        e[7].record()
-        torch.cuda.synchronize()
-        tr_dist = trace_results.view(torch.float16)[..., 3].float()
-        traced = {"triangles": rt_stats[0], "levels": rt_stats[2], "gi_bounces": args.rt_bounces, "rt_build_ms": round(e[0].elapsed_time(e[1]), 4), "rtao_ms": round(e[2].elapsed_time(e[3]), 4),
-                  "sun_shadow_mask_ms": round(e[3].elapsed_time(e[4]), 4), "probe_trace_ms": round(e[4].elapsed_time(e[5]), 4),
-                  "probe_update_ms": round(e[5].elapsed_time(e[6]), 4), "probes_per_frame": n_probes,
-                  "rtgi_trace_ms_not_in_frame": round(e[6].elapsed_time(e[7]), 4),
-                  "shadow_samples": float(fr.sun.constants.num_shadow_samples), "ao_unoccluded_fraction": round(float((d_arr["ao"] == 1).float().mean()), 4),
-                  "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4),
-                  "mask_pixels_0_between_1": [round(float((d_arr["shadow_mask"] == 0).float().mean()), 4),
-                                              round(float(((d_arr["shadow_mask"] > 0) & (d_arr["shadow_mask"] < 1)).float().mean()), 4),
-                                              round(float((d_arr["shadow_mask"] == 1).float().mean()), 4)],
-                  "probe_rays_hit_front_back_miss": [round(float((tr_dist > 0).float().mean()), 4), round(float((tr_dist < 0).float().mean()), 4)],
-                  "rtgi_rays_hit_fraction": round(float((rtgi_rb.view(torch.float16)[..., 3].float() != 0).float().mean()), 4)}
+        for r0, r1 in R.trace_rows:
+            ctx.rt_set_rows(r0, r1)
+            ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
+            ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
+        ctx.rt_set_rows(0, 0)
+    R.trace_planes = trace_planes
+    trace_planes()  # warm
+    torch.cuda.synchronize()
+    e[2].record()
+    ctx.rtao(fr.view.gpu_data, planes_rt[0], planes_rt[1], planes_rt[2], 1, 8.0, planes_rt[3])
+    e[3].record()
+    ctx.sun_shadow_mask(fr.view.gpu_data, fr.sun.constants, planes_rt[0], planes_rt[1], planes_rt[2], planes_rt[4])
+    e[4].record()
+    ctx.probe_trace(pt)
+    e[5].record()
+    ctx.probe_update(atlases, pt.trace_results, probe_ids.data_ptr(), n_probes)
+    e[6].record()
+    # (not part of this workload's frame — the RTGI mode's generator, one GI ray per pixel — timed once for the record)
+    ctx.rtgi_trace(fr.view.gpu_data, fr.sun.constants, sky_luts, planes_rt[0], planes_rt[1], planes_rt[2],
+                   images.plane(rtgi_rb, _abi.FORMAT_R16G16B16A16_SFLOAT), images.plane(rtgi_ri, _abi.FORMAT_R16G16B16A16_SFLOAT))
+    e[7].record()
+    torch.cuda.synchronize()
+    tr_dist = trace_results.view(torch.float16)[..., 3].float()
+    R.keep_traced = (geo, noise_t, trace_results, light_cache, average, sky_luts, pt, atlases, planes_rt, probe_ids)
+    R.traced = {"triangles": rt_stats[0], "levels": rt_stats[2], "gi_bounces": args.rt_bounces, "rt_build_ms": round(e[0].elapsed_time(e[1]), 4), "rtao_ms": round(e[2].elapsed_time(e[3]), 4),
+                "sun_shadow_mask_ms": round(e[3].elapsed_time(e[4]), 4), "probe_trace_ms": round(e[4].elapsed_time(e[5]), 4),
+                "probe_update_ms": round(e[5].elapsed_time(e[6]), 4), "probes_per_frame": n_probes,
+                "rtgi_trace_ms_not_in_frame": round(e[6].elapsed_time(e[7]), 4),
+                "shadow_samples": float(fr.sun.constants.num_shadow_samples), "ao_unoccluded_fraction": round(float((d_arr["ao"] == 1).float().mean()), 4),
+                "mask_lit_fraction": round(float(d_arr["shadow_mask"].mean()), 4),
+                "mask_pixels_0_between_1": [round(float((d_arr["shadow_mask"] == 0).float().mean()), 4),
+                                            round(float(((d_arr["shadow_mask"] > 0) & (d_arr["shadow_mask"] < 1)).float().mean()), 4),
+                                            round(float((d_arr["shadow_mask"] == 1).float().mean()), 4)],
+                "probe_rays_hit_front_back_miss": [round(float((tr_dist > 0).float().mean()), 4), round(float((tr_dist < 0).float().mean()), 4)],
+                "rtgi_rays_hit_fraction": round(float((rtgi_rb.view(torch.float16)[..., 3].float() != 0).float().mean()), 4)}
 
-    tm_flags = 0 if args.strict_tonemap else _abi.TONEMAP_TOLERANCE_1CODE
-    pipelined = chain and gather and lib_gather and comm_stream is not None
+
+def frame_maintenance(R):
+    """What a frame does to the GI side tables before its Lighting pass, on the work stream: the traced workload traces and folds its probes;
+    the other irradiance-cache workloads tell the context which 1024 probes "the frame's update shaders" rewrote (--probe-copy patched)."""
+    if R.traced is not None:
+        R.trace_planes()
+    elif R.probe_ids is not None:
+        R.ctx.probe_notify_updated(R.irr_volume, R.probe_ids.data_ptr(), 1024)
+
+
+def build_loop(R, force_stepwise=False):
+    """The step of the timed loop.  Three shapes: the whole frame sharded with two frames in flight (chain workloads with a library
+    exchange, or one GPU with --frames-in-flight 2), the whole frame one at a time, the Lighting pass alone (with its all-gather of
+    the lit rows at N > 1).  Adds: step(i, e0, e1), drain(), my_px, pc, sc, pipelined."""
+    from androidrenderer_amd import _abi, chain as chain_mod, images
+    args, torch, dist, ctx, fr, d_arr, dev, W, H, world, rank = R.args, R.torch, R.dist, R.ctx, R.fr, R.d_arr, R.dev, R.W, R.H, R.world, R.rank
+    R.tm_flags = tm_flags = 0 if args.strict_tonemap else _abi.TONEMAP_TOLERANCE_1CODE
+    if R.gi_kind == _abi.GI_CACHE:
+        R.irr_volume = images.volume(d_arr["probe_irr"], _abi.FORMAT_B10G11R11_UFLOAT_PACK32)
+    pipelined = R.chain and R.gather and R.lib_gather and R.comm_stream is not None and not force_stepwise
     # one GPU, no exchange: the same two-frames-in-flight loop when asked for (--frames-in-flight 2): the post chain of frame i on a second
-    # stream beside the lighting of frame i + 1 (the gathers of PipelinedChain are no-ops without a communicator)
-    if chain and not pipelined and world == 1 and not gather and traced is None and args.frames_in_flight == 2:
+    # stream beside the lighting of frame i + 1 (the gathers are no-ops without a communicator)
+    if R.chain and not pipelined and world == 1 and not R.gather and R.traced is None and args.frames_in_flight == 2 and not force_stepwise:
         pipelined = True
-        comm_stream = torch.cuda.Stream(device=dev)
-    pc = sc = None
+        if R.comm_stream is None:
+            R.comm_stream = torch.cuda.Stream(device=dev)
+    R.pipelined = pipelined
+    R.pc = R.sc = None
 
-    def build_pipelined():
-        # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute (chain.py: PipelinedChain)
-        pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev),
-                                      tonemap_flags=tm_flags)
-        if use_ipc:
-            pc.register_direct_exchange(allgather_handles)
-        sc = pc.sets[0]
-        if traced is not None and world > 1:
-            trace_rows[:] = [r for r in (tuple(sc.plan.lit_rows), tuple(sc.plan.lit_wrap_rows)) if r[1] > r[0]]
+    def chain_px(sc):
+        return W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
+
+    def set_trace_rows(sc):
+        if R.traced is not None and world > 1:
+            R.trace_rows[:] = [r for r in (tuple(sc.plan.lit_rows), tuple(sc.plan.lit_wrap_rows)) if r[1] > r[0]]
+
+    if pipelined:
+        # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute.  The loop itself lives in
+        # the library (sah_chain_submit: chain.NativePipelinedChain); --python-loop enqueues the same order pass by pass (chain.PipelinedChain)
+        cls = chain_mod.PipelinedChain if args.python_loop else chain_mod.NativePipelinedChain
+        pc = cls(ctx, fr, d_arr, rank, world, R.comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev), tonemap_flags=tm_flags)
+        if R.use_ipc:
+            pc.register_direct_exchange(R.allgather_handles)
+        R.pc, R.sc = pc, pc.sets[0]
+        set_trace_rows(R.sc)
 
         def step(i, e0=None, e1=None):
-            if traced is not None:
-                trace_planes()  # on the work stream, in front of this frame's lighting
+            frame_maintenance(R)  # on the work stream, in front of this frame's lighting
             pc.submit((e0, e1) if e0 is not None else None)
 
         def drain():
             pc.flush()
             ctx.comm_wait()
-        return pc, sc, step, drain
-
-    def build_stepwise():
+        R.my_px = chain_px(R.sc)
+    elif R.chain:
         # the whole frame, sharded (chain.py), one frame at a time: every exchange goes through the library (torch path only with --torch-gather)
         sc = chain_mod.ShardedChain(ctx, fr, d_arr, rank, world, tonemap_flags=tm_flags)
-        if use_ipc:
-            sc.register_direct_exchange(allgather_handles)
+        if R.use_ipc:
+            sc.register_direct_exchange(R.allgather_handles)
         q, per = sc.plan.mip1_rows_per_rank, sc.plan.rows_per_rank
         mip_bytes, out_bytes = sc.mip1_alloc.view(torch.uint8).view(-1), sc.out_alloc.view(-1)
         mip_slot_bytes, out_slot_bytes = q * sc.mip1_alloc.shape[1] * 8, per * W * 4
-        if traced is not None and world > 1:
-            trace_rows[:] = [r for r in (tuple(sc.plan.lit_rows), tuple(sc.plan.lit_wrap_rows)) if r[1] > r[0]]
+        R.sc = sc
+        set_trace_rows(sc)
+        gather, lib_gather = R.gather, R.lib_gather
 
         def step(i, e0=None, e1=None):
-            if traced is not None:
-                trace_planes()
+            frame_maintenance(R)
             if e0 is not None:
                 e0.record()
             sc.lighting()
@@ -493,20 +585,11 @@ def main():
 
         def drain():
             ctx.comm_wait()
-        return None, sc, step, drain
-
-    def chain_px(sc):
-        return W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
-
-    if pipelined:
-        pc, sc, step, drain = build_pipelined()
-        my_px = chain_px(sc)
-    elif chain:
-        pc, sc, step, drain = build_stepwise()
-        my_px = chain_px(sc)
+        R.my_px = chain_px(sc)
     else:
         # N > 1: two lit targets, so that the all-gather of frame i (side stream) overlaps the shading of frame i + 1; a target is reused
         # only after its gather has completed (stream-level wait).  Every gather finishes inside the timed region.
+        gather, lib_gather, comm_stream, rows_per, r0, r1 = R.gather, R.lib_gather, R.comm_stream, R.rows_per, R.r0, R.r1
         nbuf = 2 if (gather and not args.no_overlap) else 1
         shard_bytes = rows_per * W * 8
         bufs = []
@@ -514,11 +597,12 @@ def main():
             lf = torch.zeros((rows_per * world, W, 4), dtype=torch.int16, device=dev)  # equal slots for the all-gather
             desc_b, keep_b = fr.describe(d_arr, lf[:H])
             lb = lf.view(torch.uint8).view(-1)  # RCCL has no int16: the rows travel as bytes
-            if use_ipc:
-                ctx.ipc_register(lf.data_ptr(), lf.numel() * 2, allgather_handles(ctx.ipc_export(lf.data_ptr(), lf.numel() * 2)))
+            if R.use_ipc:
+                ctx.ipc_register(lf.data_ptr(), lf.numel() * 2, R.allgather_handles(ctx.ipc_export(lf.data_ptr(), lf.numel() * 2)))
             bufs.append({"lit": lf[:H], "desc": desc_b, "keep": keep_b, "bytes": lb, "slot": lb[rank * shard_bytes:(rank + 1) * shard_bytes],
                          "plane": images.plane(lf[:H], _abi.FORMAT_R16G16B16A16_SFLOAT)})
         pending = [None] * nbuf
+        R.bufs = bufs
 
         def step(i, e0=None, e1=None):
             b = bufs[i % nbuf]
@@ -551,82 +635,89 @@ def main():
                     if not lib_gather:
                         pending[k].wait()
                     pending[k] = None
-        my_px = W * (r1 - r0) if world > 1 else W * H
+        R.my_px = W * (r1 - r0) if world > 1 else W * H
+    R.step, R.drain = step, drain
 
-    # N > 1: the same workload unsharded on this rank's GPU, timed before the sharded loop — strong scaling of ONE workload can then be
-    # read off this line alone (the driver's N = 1 run measures the headline lighting pass, not necessarily this workload)
-    beat("unsharded reference")
-    single_gpu = None
-    ref_image = None  # chain workloads: the unsharded frame's final image, to hold the sharded loop's last frames against after the timed region
-    if world > 1 or args.force_gather:
-        if chain:
-            ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1, tonemap_flags=tm_flags)
-            ref_step = lambda: ref.step(gather=False)
-        else:
-            ref_lit = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
-            saved_rows = (fr.row_begin, fr.row_end)
-            fr.row_begin = fr.row_end = 0
-            ref_desc, ref_keep = fr.describe(d_arr, ref_lit)
-            fr.row_begin, fr.row_end = saved_rows
-            ref_step = lambda: ctx.lighting(ref_desc)
-        for _ in range(5):
-            ref_step()
-        torch.cuda.synchronize()
-        r_e0, r_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        r_e0.record()
-        for _ in range(30):
-            ref_step()
-        r_e1.record()
-        torch.cuda.synchronize()
-        ref_ms = r_e0.elapsed_time(r_e1) / 30
-        single_gpu = {"ms_per_step": round(ref_ms, 5), "value": round(W * H / (ref_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
-                      "note": "the same workload unsharded on rank 0's GPU, 30 steps, GPU time between two events"}
-        del ref_step
-        if chain:
-            if gather and lib_gather and traced is None:  # (traced: a rank traces only its own rows of the AO / shadow-mask planes)
-                ref_image = ref.out.clone()
-            del ref
-        torch.cuda.empty_cache()
 
-    # N > 1, two frames in flight: before anything is timed, three frames of the loop are held against the unsharded frame on every
-    # rank.  The loop's streams and events have met more than one GPU only here: if a frame differs, every rank falls back together to
-    # the one-frame-at-a-time loop (exchanges on the work stream's own order), checks that one too, and the line says what ran.
-    preflight = None
-    if pipelined and ref_image is not None and exchange:
-        beat("pre-flight")
-        for i in range(3):
-            step(i)
-        drain()
-        torch.cuda.synchronize()
-        ok = int(bool(torch.equal(pc.image(1), ref_image)) and bool(torch.equal(pc.image(2), ref_image)))
-        if os.environ.get("SAH_BENCH_FAIL_PREFLIGHT") == "1":  # test hook: take the fall-back path
-            ok = 0
-        if torch_pg:
-            t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
-        preflight = {"two_frames_in_flight_ok": bool(ok), "fallback": None}
-        if not ok:
-            print(f"[bench] rank {rank}: the two-frames-in-flight loop's frames differ from the unsharded frame: falling back to one frame at a time", file=sys.stderr)
-            if use_ipc:  # the registrations are found by address: give them back before the allocator can hand the addresses out again
-                pc.unregister_direct_exchange()
-            pc = None
-            pipelined = False
-            torch.cuda.empty_cache()
-            pc, sc, step, drain = build_stepwise()
-            my_px = chain_px(sc)
-            for i in range(2):
-                step(i)
-            drain()
-            torch.cuda.synchronize()
-            ok2 = int(bool(torch.equal(sc.out, ref_image)))
-            if torch_pg:
-                t = torch.tensor([ok2], dtype=torch.int32, device=red_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                ok2 = int(t.item())
-            preflight["fallback"] = "one frame at a time"
-            preflight["fallback_ok"] = bool(ok2)
+def time_unsharded(R):
+    """N > 1 (or --force-gather): the same workload unsharded on this rank's GPU, timed before the sharded loop — the strong scaling of ONE
+    workload can then be read off this line alone (the driver's N = 1 run measures the headline lighting pass, not necessarily this
+    workload) — and, for chain workloads, the unsharded frame's final image to hold the sharded loop's frames against.  Adds: single_gpu, ref_image."""
+    from androidrenderer_amd import chain as chain_mod
+    torch, ctx, fr, d_arr, W, H = R.torch, R.ctx, R.fr, R.d_arr, R.W, R.H
+    R.beat("unsharded reference")
+    R.single_gpu = R.ref_image = None
+    if not (R.world > 1 or R.args.force_gather):
+        return
+    if R.chain:
+        ref = chain_mod.ShardedChain(ctx, fr, d_arr, 0, 1, tonemap_flags=R.tm_flags)
+        ref_step = lambda: ref.step(gather=False)
+    else:
+        ref_lit = torch.zeros((H, W, 4), dtype=torch.int16, device=R.dev)
+        saved_rows = (fr.row_begin, fr.row_end)
+        fr.row_begin = fr.row_end = 0
+        ref_desc, ref_keep = fr.describe(d_arr, ref_lit)
+        fr.row_begin, fr.row_end = saved_rows
+        ref_step = lambda: ctx.lighting(ref_desc)
+    for _ in range(5):
+        ref_step()
+    torch.cuda.synchronize()
+    r_e0, r_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    r_e0.record()
+    for _ in range(30):
+        ref_step()
+    r_e1.record()
+    torch.cuda.synchronize()
+    ref_ms = r_e0.elapsed_time(r_e1) / 30
+    R.single_gpu = {"ms_per_step": round(ref_ms, 5), "value": round(W * H / (ref_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                    "note": "the same workload unsharded on rank 0's GPU, 30 steps, GPU time between two events"}
+    if R.chain and R.gather and R.lib_gather and R.traced is None:  # (traced: a rank traces only its own rows of the AO / shadow-mask planes)
+        R.ref_image = ref.out.clone()
+    del ref_step
+    torch.cuda.empty_cache()
 
+
+def preflight(R):
+    """N > 1, two frames in flight: before anything is timed, three frames of the loop are held against the unsharded frame on every rank.
+    The loop's streams and events have met more than one GPU only here: if a frame differs, every rank falls back together to the
+    one-frame-at-a-time loop (exchanges in the work stream's own order), checks that one too, and the line says what ran.  Adds: preflight."""
+    torch = R.torch
+    R.preflight = None
+    if not (R.pipelined and R.ref_image is not None and R.exchange):
+        return
+    R.beat("pre-flight")
+    for i in range(3):
+        R.step(i)
+    R.drain()
+    torch.cuda.synchronize()
+    ok = int(bool(torch.equal(R.pc.image(1), R.ref_image)) and bool(torch.equal(R.pc.image(2), R.ref_image)))
+    if os.environ.get("SAH_BENCH_FAIL_PREFLIGHT") == "1":  # test hook: take the fall-back path
+        ok = 0
+    ok = all_ranks_min(R, ok)
+    R.preflight = {"two_frames_in_flight_ok": bool(ok), "fallback": None}
+    if ok:
+        return
+    print(f"[bench] rank {R.rank}: the two-frames-in-flight loop's frames differ from the unsharded frame: falling back to one frame at a time", file=sys.stderr)
+    if R.use_ipc:  # the registrations are found by address: give them back before the allocator can hand the addresses out again
+        R.pc.unregister_direct_exchange()
+    if hasattr(R.pc, "close"):
+        R.pc.close()
+    R.pc = None
+    torch.cuda.empty_cache()
+    build_loop(R, force_stepwise=True)
+    for i in range(2):
+        R.step(i)
+    R.drain()
+    torch.cuda.synchronize()
+    ok2 = all_ranks_min(R, int(bool(torch.equal(R.sc.out, R.ref_image))))
+    R.preflight["fallback"] = "one frame at a time"
+    R.preflight["fallback_ok"] = bool(ok2)
+
+
+def run_timed(R):
+    """Clock ramp, W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides.  Adds: elapsed (max over ranks),
+    kernel_ms_mean, kernel_ms_min, kernel_scope."""
+    args, torch, dist, step, drain = R.args, R.torch, R.dist, R.step, R.drain
     if args.ramp_ms > 0:
         t_ramp = time.perf_counter()
         k = 0
@@ -636,13 +727,13 @@ def main():
                 k += 1
             drain()
             torch.cuda.synchronize()
-    beat("warm-up")
+    R.beat("warm-up")
     for i in range(args.warmup):
         step(i)
     drain()
     torch.cuda.synchronize()
-    beat("timed region")
-    if torch_pg:
+    R.beat("timed region")
+    if R.torch_pg:
         dist.barrier()
         torch.cuda.synchronize()
     # GPU time of the timed region: ONE pair of HIP events on the launch stream around all K steps (round 2 recorded a pair per step:
@@ -653,148 +744,220 @@ def main():
     g1.record()
     torch.cuda.synchronize()
     # chain workloads: the roofline is the Lighting kernel's, one pass of several in a step, so those keep a pair per step around the
-    # sah_lighting call (2 x ~10 us on a ~0.9 ms step); created and recorded before t0 as well
+    # sah_lighting call (2 x ~10 us on a ~0.6 ms step); created and recorded before t0 as well
     ev = []
-    if chain:
+    if R.chain:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         for a_, b_ in ev:
             a_.record()
             b_.record()
         torch.cuda.synchronize()
+    rebuilds0 = R.ctx.copy_rebuilds()
     t0 = time.perf_counter()
     g0.record()
     for i in range(args.steps):
-        if chain:
+        if R.chain:
             step(i, ev[i][0], ev[i][1])
         else:
             step(i)
     drain()
     g1.record()
     torch.cuda.synchronize()
-    if torch_pg:
+    if R.torch_pg:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    R.rebuilds_in_timed_region = {"lpv": R.ctx.copy_rebuilds()[0] - rebuilds0[0], "irradiance_atlas": R.ctx.copy_rebuilds()[1] - rebuilds0[1]}
     loop_ms = g0.elapsed_time(g1) / args.steps
-    if chain:
+    if R.chain:
         per_step = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
-        kernel_ms_mean, kernel_ms_min = sum(per_step) / len(per_step), per_step[0]
-        kernel_scope = "HIP events around each sah_lighting call of the timed region, on its stream (main kernel + fix-up)" + (
+        R.kernel_ms_mean, R.kernel_ms_min = sum(per_step) / len(per_step), per_step[0]
+        R.kernel_scope = "HIP events around each sah_lighting call of the timed region, on its stream (main kernel + fix-up)" + (
             "; two frames in flight: the previous frame's post chain runs beside it on a second stream, so this is not the kernel's time alone"
-            if pipelined and not args.one_work_stream else "")
+            if R.pipelined and not args.one_work_stream else "")
     else:
-        kernel_ms_mean, kernel_ms_min = loop_ms, None
-        kernel_scope = ("one pair of HIP events on the launch stream around all K steps of the timed region, / K: everything a sah_lighting call "
-                        "enqueues (main kernel with its sky workgroups + fix-up) and the gaps between launches")
-    if torch_pg:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        R.kernel_ms_mean, R.kernel_ms_min = loop_ms, None
+        R.kernel_scope = ("one pair of HIP events on the launch stream around all K steps of the timed region, / K: everything a sah_lighting call "
+                          "enqueues (gather-copy rebuild if any, main kernel with its sky workgroups, fix-up) and the gaps between launches")
+    if R.torch_pg:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=R.red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # after the timed region: every rank holds the last frames its loop assembled (both buffer sets of the pipelined loop) against the
-    # unsharded frame it rendered itself before the loop — the gathers moved the right rows to the right places on every rank, or not
-    beat("verification")
-    sharded_equals_unsharded = None
-    if ref_image is not None:
-        outs = [pc.image(args.steps - 1), pc.image(args.steps - 2)] if pipelined and args.steps > 1 else [pc.image(args.steps - 1) if pipelined else sc.out]
-        same = int(all(bool(torch.equal(o, ref_image)) for o in outs))
+    R.elapsed = elapsed
+
+
+def verify(R):
+    """After the timed region: every rank holds the last frames its loop assembled (both buffer sets of the pipelined loop) against the
+    unsharded frame it rendered itself before the loop — the gathers moved the right rows to the right places on every rank, or not.
+    A loop that moved wrong rows has no throughput: the line then carries value null and an error, and every rank exits non-zero (the
+    verdicts are all-reduced, so the ranks agree).  Adds: sharded_equals_unsharded, failure."""
+    torch, args = R.torch, R.args
+    R.beat("verification")
+    R.sharded_equals_unsharded = None
+    if R.ref_image is not None:
+        outs = [R.pc.image(args.steps - 1), R.pc.image(args.steps - 2)] if R.pipelined and args.steps > 1 else [R.pc.image(args.steps - 1) if R.pipelined else R.sc.out]
+        same = int(all(bool(torch.equal(o, R.ref_image)) for o in outs))
         if os.environ.get("SAH_BENCH_FAIL_VERIFY") == "1":  # test hook: the line must then carry no throughput and the exit code say so
             same = 0
-        if torch_pg:
-            t = torch.tensor([same], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            same = int(t.item())
-        sharded_equals_unsharded = bool(same)
+        same = all_ranks_min(R, same)
+        R.sharded_equals_unsharded = bool(same)
         if not same:
-            print(f"[bench] rank {rank}: the sharded loop's final image differs from the unsharded frame", file=sys.stderr)
-    # A loop that moved wrong rows has no throughput: the line then carries value null and an error, and every rank exits non-zero (the
-    # verdicts above are all-reduced, so the ranks agree).  Likewise when the pre-flight fell back and the fall-back was wrong as well.
-    failure = None
-    if sharded_equals_unsharded is False:
-        failure = "the sharded loop's last frames differ from the unsharded frame on at least one rank"
-    elif preflight is not None and preflight.get("fallback") and not preflight.get("fallback_ok"):
-        failure = "pre-flight: the two-frames-in-flight loop AND the one-frame-at-a-time fall-back differ from the unsharded frame"
+            print(f"[bench] rank {R.rank}: the sharded loop's final image differs from the unsharded frame", file=sys.stderr)
+    R.failure = None
+    if R.sharded_equals_unsharded is False:
+        R.failure = "the sharded loop's last frames differ from the unsharded frame on at least one rank"
+    elif R.preflight is not None and R.preflight.get("fallback") and not R.preflight.get("fallback_ok"):
+        R.failure = "pre-flight: the two-frames-in-flight loop AND the one-frame-at-a-time fall-back differ from the unsharded frame"
 
-    if rank == 0:
-        px = W * H
-        value = px * args.steps / elapsed / 1e6
-        achieved = bytes_per_pixel * my_px / (kernel_ms_mean * 1e-3) / 1e9
-        sun_txt = {"csm": "sun CSM 4x4096^2 D16 PCF", "rt": "sun RT (shadow-mask plane, half-precision BRDF)", "off": "sun off"}[wl["sun"]]
-        gi_txt = {"none": "no GI", "lpv": "LPV GI gather + AO", "cache": "irradiance-cache probe gather", "rtgi": "RTGI reconstruction"}[wl["gi"]]
-        parts = [sun_txt, gi_txt, "emissive", "sky"]
-        if n_lights:
-            parts.insert(1, f"{n_lights} point lights (r={wl['radius']} m) with LDS tile culling")
-        what = "fused deferred lighting (" + " + ".join(parts) + ")"
-        if chain:
-            what += " + copy scene + bloom pyramid + tonemap composite"
-        if world == 1:
-            par = "single GPU" + (" + one-rank RCCL communicator (rehearsal of the exchange)" if exchange else "")
-        elif chain:
-            par = f"row-shard x{world}: lighting rows + halo, all-gather of bloom mip 1, all-gather of the RGBA8 rows (reversed rank order)"
-            if rehearsal:
-                par += " — REHEARSAL: all ranks on one GPU, not a scaling measurement"
-        else:
-            par = f"row-shard x{world} + RCCL all-gather of the lit rows"
-        out = {
-            "metric": "lit Mpixels/sec (deferred+GI pass) at 4K",
-            "value": None if failure else round(value, 1),
-            "unit": "Mpixels/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {W}x{H} {what}, {wl['gbuffer']} G-buffer"
-                            + (" (G-buffer, shadow cascades and LPV made on the GPU by the producer passes)" if wl.get("produced") else ""),
-                "resolution": [W, H],
-                "clock_ramp_ms": args.ramp_ms,
-                "tonemap": None if not chain else ("strict" if args.strict_tonemap else "SAH_TONEMAP_TOLERANCE_1CODE (within one code of the strict composite)"),
-                "lpv_gather_copy": None if gi_kind != _abi.GI_LPV else ("rebuilt every step (lpv_generation 0)" if args.repack_lpv else
-                                                                          "kept across steps (lpv_generation 1: the LPV volumes of this benchmark never change)"),
-                "probe_gather_copy": None if gi_kind != _abi.GI_CACHE else (
-                    "rebuilt every step (sah_probe_update writes the atlas every step)" if wl.get("traced") else
-                    "rebuilt every step (probe_generation 0)" if args.repack_lpv else "kept across steps (probe_generation 1: the atlases of this benchmark never change)"),
-                "gbuffer": wl["gbuffer"],
-                "parallelism": par,
-                "gather": bool(gather),
-                "gather_through": (("sah_allgather_rows (library, direct exchange over peer-mapped memory)" if use_ipc else "sah_allgather_rows (library, RCCL)") if lib_gather else "torch.distributed" + (f" (fallback: {comm_note})" if comm_note else "")) if gather else None,
-                "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (pipelined or not chain)),
-                "post_chain_beside_next_frames_lighting": bool(pipelined and not args.one_work_stream),
-                "frames_in_flight": 2 if pipelined else 1,
-                "same_workload_on_one_gpu": single_gpu,
-                # the N = 1 run of this file measures the headline lighting pass, a different workload from the sharded chain: the strong
-                # scaling of THIS workload is its throughput here over its throughput unsharded on one of these GPUs
-                # (null in a rehearsal: there every rank — and the one-GPU reference, timed while the others wait — shares ONE GPU)
-                "speedup_vs_same_workload_on_one_gpu": None if (not single_gpu or rehearsal or failure) else round(value / single_gpu["value"], 3),
-                "sharded_equals_unsharded": sharded_equals_unsharded,
-                "preflight": preflight,
-                "traced": traced,
-            },
-            "roofline": roofline(args.workload, world, achieved, kernel_ms_mean, kernel_ms_min, kernel_scope, bytes_per_pixel * my_px, my_px,
-                                 "sah::k_lighting_tiled" if (n_lights or gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),
-        }
-        if failure:
-            out["error"] = failure
-            out["measured_but_invalid_Mpixels_per_s"] = round(value, 1)
-        if n_lights and not args.no_light_stats:
-            out["config"].update(light_stats(torch, fr, d_arr, lights, dev))
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)
-        if saved_stdout is not None:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
-        if saved_stdout is not None:
-            os.dup2(2, 1)  # teardown chatter goes to stderr as well
-    ctx.close()
-    if torch_pg:
-        dist.barrier()
-        dist.destroy_process_group()
-    if failure:
+
+def time_with_rebuild(R):
+    """One GPU, LPV lighting workloads under --lpv-copy propagate: the same pass with lpv_generation 0 — k_lpv_pack inside every step, what the
+    frame pays when its volumes are rewritten by a pass that is not the library's.  Outside the timed region; returns the report's dict or None."""
+    from androidrenderer_amd import _abi
+    torch, ctx, fr, d_arr = R.torch, R.ctx, R.fr, R.d_arr
+    if not (R.world == 1 and R.gi_kind == _abi.GI_LPV and not R.chain and not R.exchange and R.args.lpv_copy == "propagate"):
+        return None
+    saved = fr.lpv_generation
+    fr.lpv_generation = 0
+    lit = torch.zeros((R.H, R.W, 4), dtype=torch.int16, device=R.dev)
+    desc, keep = fr.describe(d_arr, lit)
+    fr.lpv_generation = saved
+    n = max(20, R.args.steps)
+    for _ in range(10):
+        ctx.lighting(desc)
+    torch.cuda.synchronize()
+    before = ctx.copy_rebuilds()[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ctx.lighting(desc)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return {"ms_per_step": round(ms, 5), "value": round(R.W * R.H / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "steps": n,
+            "gather_copy_rebuilds_during_it": ctx.copy_rebuilds()[0] - before,
+            "note": "the same pass with lpv_generation 0 (k_lpv_pack + the pass in every step), GPU time between two events, after the timed region"}
+
+
+def report(R):
+    """Rank 0 prints the ONE JSON line."""
+    from androidrenderer_amd import _abi
+    args, wl, W, H, world = R.args, R.wl, R.W, R.H, R.world
+    px = W * H
+    value = px * args.steps / R.elapsed / 1e6
+    achieved = R.bytes_per_pixel * R.my_px / (R.kernel_ms_mean * 1e-3) / 1e9
+    sun_txt = {"csm": "sun CSM 4x4096^2 D16 PCF", "rt": "sun RT (shadow-mask plane, half-precision BRDF)", "off": "sun off"}[wl["sun"]]
+    if wl.get("mask") == "ones":
+        sun_txt = "sun RT, every shadow ray unoccluded (mask = 1): a single directional light, half-precision BRDF"
+    gi_txt = {"none": "no GI", "lpv": "LPV GI gather + AO", "cache": "irradiance-cache probe gather", "rtgi": "RTGI reconstruction"}[wl["gi"]]
+    parts = [sun_txt, gi_txt, "emissive", "sky"]
+    if R.n_lights:
+        parts.insert(1, f"{R.n_lights} point lights (r={wl['radius']} m) with LDS tile culling")
+    what = "fused deferred lighting (" + " + ".join(parts) + ")"
+    if R.chain:
+        what += " + copy scene + bloom pyramid + tonemap composite"
+    if world == 1:
+        par = "single GPU" + (" + one-rank RCCL communicator (rehearsal of the exchange)" if R.exchange else "")
+    elif R.chain:
+        par = f"row-shard x{world}: lighting rows + halo, all-gather of bloom mip 1, all-gather of the RGBA8 rows (reversed rank order)"
+        if R.rehearsal:
+            par += " — REHEARSAL: all ranks on one GPU, not a scaling measurement"
+    else:
+        par = f"row-shard x{world} + RCCL all-gather of the lit rows"
+    gather, lib_gather = R.gather, R.lib_gather
+    out = {
+        "metric": "lit Mpixels/sec (deferred+GI pass) at 4K",
+        "value": None if R.failure else round(value, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(R.elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {W}x{H} {what}, {wl['gbuffer']} G-buffer"
+                        + (" (G-buffer, shadow cascades and LPV made on the GPU by the producer passes)" if wl.get("produced") else ""),
+            "resolution": [W, H],
+            "clock_ramp_ms": args.ramp_ms,
+            "tonemap": None if not R.chain else ("strict" if args.strict_tonemap else "SAH_TONEMAP_TOLERANCE_1CODE (within one code of the strict composite)"),
+            "lpv_gather_copy": None if R.gi_kind != _abi.GI_LPV else (
+                "written by the last step of sah_lpv_propagate beside the volumes (SAH_GENERATION_TRACKED; the propagation ran once before the loop — the "
+                "benchmark's volumes do not change — where a frame runs it every frame): no Lighting pass rebuilds it" if args.lpv_copy == "propagate" else
+                "rebuilt inside every step (lpv_generation 0: k_lpv_pack + the pass — a frame whose volumes somebody else's propagation rewrites)"
+                if args.lpv_copy == "rebuild" else "kept across steps (lpv_generation 1: the LPV volumes of this benchmark never change)"),
+            "gather_copy_rebuilds_in_timed_region": R.rebuilds_in_timed_region,
+            "probe_gather_copy": None if R.gi_kind != _abi.GI_CACHE else (
+                "tracked by the context (SAH_GENERATION_TRACKED): sah_probe_update re-widens the blocks of the 1024 probes it folds every step" if (wl.get("traced") and args.probe_copy == "patched") else
+                "tracked by the context (SAH_GENERATION_TRACKED): every step re-widens the blocks of 1024 probes (sah_probe_notify_updated: r.GI.Cache.UpdatesPerFrame)" if args.probe_copy == "patched" else
+                "rebuilt every step (probe_generation 0)" if args.probe_copy == "rebuild" else "kept across steps (probe_generation 1: the atlases of this benchmark never change)"),
+            "gbuffer": wl["gbuffer"],
+            "parallelism": par,
+            "gather": bool(gather),
+            "gather_through": (("sah_allgather_rows (library, direct exchange over peer-mapped memory)" if R.use_ipc else "sah_allgather_rows (library, RCCL)") if lib_gather else "torch.distributed" + (f" (fallback: {R.comm_note})" if R.comm_note else "")) if gather else None,
+            "gather_overlapped_with_next_frame": bool(gather and not args.no_overlap and (R.pipelined or not R.chain)),
+            "post_chain_beside_next_frames_lighting": bool(R.pipelined and not args.one_work_stream),
+            "frames_in_flight": 2 if R.pipelined else 1,
+            "frame_loop": None if not R.pipelined else ("Python, pass by pass (chain.PipelinedChain)" if args.python_loop else "the library's (sah_chain_submit)"),
+            "same_workload_on_one_gpu": R.single_gpu,
+            # the N = 1 run of this file measures the headline lighting pass, a different workload from the sharded chain: the strong
+            # scaling of THIS workload is its throughput here over its throughput unsharded on one of these GPUs
+            # (null in a rehearsal: there every rank — and the one-GPU reference, timed while the others wait — shares ONE GPU)
+            "speedup_vs_same_workload_on_one_gpu": None if (not R.single_gpu or R.rehearsal or R.failure) else round(value / R.single_gpu["value"], 3),
+            "sharded_equals_unsharded": R.sharded_equals_unsharded,
+            "preflight": R.preflight,
+            "traced": R.traced,
+        },
+        "roofline": roofline(args.workload, world, achieved, R.kernel_ms_mean, R.kernel_ms_min, R.kernel_scope, R.bytes_per_pixel * R.my_px, R.my_px,
+                             "sah::k_lighting_tiled" if (R.n_lights or R.gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),
+    }
+    if R.with_rebuild is not None:
+        out["config"]["lpv_gather_copy_rebuilt_every_step"] = R.with_rebuild
+    if R.failure:
+        out["error"] = R.failure
+        out["measured_but_invalid_Mpixels_per_s"] = round(value, 1)
+    if R.n_lights and not args.no_light_stats:
+        out["config"].update(light_stats(R.torch, R.fr, R.d_arr, R.lights, R.dev))
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(R.fr, args.cpu_seconds)
+    if R.saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(R.saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+    if R.saved_stdout is not None:
+        os.dup2(2, 1)  # teardown chatter goes to stderr as well
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    R = setup_distributed(args)
+    make_inputs(R)
+    make_context(R)
+    if R.wl.get("produced"):
+        produce_inputs(R)  # (its propagation's last step has stored the gather copy as well)
+    elif R.gi_kind == 1 and args.lpv_copy == "propagate":  # _abi.GI_LPV
+        propagate_lpv(R)
+    R.traced = None
+    if R.wl.get("traced"):
+        setup_traced(R)
+    build_loop(R)
+    time_unsharded(R)
+    preflight(R)
+    run_timed(R)
+    verify(R)
+    R.with_rebuild = time_with_rebuild(R) if R.rank == 0 and not R.failure else None
+    if R.rank == 0:
+        report(R)
+    if R.pc is not None and hasattr(R.pc, "close"):
+        R.pc.close()
+    R.ctx.close()
+    if R.torch_pg:
+        R.dist.barrier()
+        R.dist.destroy_process_group()
+    if R.failure:
         sys.exit(3)
 
 

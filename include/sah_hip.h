@@ -693,6 +693,16 @@ int sah_ipc_connect(sah_ctx* ctx, const void* all_handles);
 int sah_ipc_export(sah_ctx* ctx, const void* buffer, uint64_t bytes, void* out_handle);
 int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all_handles);
 int sah_ipc_unregister(sah_ctx* ctx, const void* buffer);
+/* After SAH_ERR_COMM (a gather of the direct exchange gave up: a peer stalled for more than two seconds, a rank skipped a gather).
+ * The state is sticky on purpose — rows gathered behind a give-up are not valid, and a rank that has given up neither copies into its
+ * peers nor is copied into by them (its "gave up" note reaches every peer's mailbox with the give-up; a peer that arrives late reads it
+ * before it copies).  What the caller must NOT do on the error is free or unregister a gathered buffer at once: a peer that saw no
+ * error yet may be in the middle of its copy into it.  The order out of the state, on EVERY rank:
+ *     sah_sync (drain; it reports the error once more)  ->  barrier over the caller's own channel  ->  sah_ipc_reset  ->  barrier
+ * after which gathers work again (a gather one rank made and another skipped has left their sequence numbers apart: sah_ipc_reset
+ * raises every buffer's number to the highest one any rank has signalled, which every rank reads identically after the first barrier)
+ * and buffers may be unregistered and freed as usual.  A no-op on a context that has not opened the exchange. */
+int sah_ipc_reset(sah_ctx* ctx);
 
 /* ---- the row-sharded frame as a loop of this library (no reference counterpart: north_star's "shard by screen-tile rows, all-gather the
  * final image"; the reference records one frame at a time on one queue, render_backend.cpp:135-153) ---------------------------------------

@@ -220,3 +220,62 @@ def test_4k_traced_planes_properties_on_the_dense_atrium(hip_ctx):
     spacing = case.cascade_spacing * 2.0 ** (ids[:, 1] // 8)
     limit = np.where(ids[:, 1] // 8 < 3, spacing * 2.0 * 4.0, 8192.0)
     assert (np.abs(trace[..., 3]) <= limit[:, None, None] * 1.001).all() and np.isfinite(trace[..., :3]).all()
+
+
+def _lights_frame_checks(ctx, f, dev, name, band, shard_cuts):
+    """culled == brute force on `band` (tile aligned), shards with edges inside a tile row == the same rows of the full frame, the oracle on three
+    8-row bands of the full frame (the shape of test_8k_1024_lights_gi)"""
+    import torch
+    full = _run(ctx, f, dev)
+    torch.cuda.synchronize()
+    b0, b1 = band
+    brute = torch.zeros_like(full)
+    f.flags |= _abi.LIGHTING_BRUTE_FORCE_LIGHTS
+    _run(ctx, f, dev, brute, (b0, b1))
+    f.flags &= ~_abi.LIGHTING_BRUTE_FORCE_LIGHTS
+    torch.cuda.synchronize()
+    assert torch.equal(brute[b0:b1], full[b0:b1]), f"{name}: tile culling changed the image"
+    _shards_equal_full(ctx, f, dev, full, shard_cuts)
+    _check_bands_against_oracle(f, full, name)
+    return full
+
+
+def test_720p_deferred_only(hip_ctx):
+    """configs[0]: 1280x720, a single directional light, deferred shading only — the reference's default sun (r.Shadow.SunShadowMode =
+    RayTracing, directional_light.rt.slang:58-139) with every shadow ray unoccluded (mask == 1), no GI overlay.  Fast == general,
+    shards == full (cuts off the 4-pixel-group and 16-row grids), oracle on three bands."""
+    import torch
+    W, H = 1280, 720
+    f = _make(W, H, "atrium", _abi.SHADOW_MODE_RT, _abi.GI_NONE)
+    f.arrays["shadow_mask"] = np.ones((H, W), dtype=np.float32)
+    dev = f.device_arrays()
+    fast = _run(hip_ctx, f, dev)
+    hip_ctx.debug_set(force_general=True)
+    general = _run(hip_ctx, f, dev)
+    hip_ctx.debug_set(force_general=False)
+    torch.cuda.synchronize()
+    assert torch.equal(fast, general), "720p: fast kernel differs from the general kernel"
+    _shards_equal_full(hip_ctx, f, dev, fast, [90, 91, 359, 700])
+    _check_bands_against_oracle(f, fast, "720p_deferred_only")
+    # the same frame without a mask plane at all (NULL = 1, include/sah_hip.h) is the same image
+    del f.arrays["shadow_mask"], dev["shadow_mask"]
+    assert torch.equal(_run(hip_ctx, f, dev), fast), "720p: shadow_mask == NULL differs from a plane of ones"
+
+
+def test_1080p_64_lights_on_the_random_gbuffer(hip_ctx):
+    """configs[1]: synthetic RANDOM G-buffer 1920x1080 (every texel independent: every gather misses, every wave vote fails), 1 directional
+    light (CSM, 4 x 4096^2 D16) + 64 point lights (r = 6 m)."""
+    W, H = 1920, 1080
+    lights = synth.point_lights(scene.SceneView.default(W, H), 64, 6.0, seed=8)
+    f = _make(W, H, "random", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, lights=lights)
+    dev = f.device_arrays()
+    _lights_frame_checks(hip_ctx, f, dev, "1080p_64_lights", (512, 768), [100, 101, 539, 1077])
+
+
+def test_4k_256_lights(hip_ctx):
+    """configs[2]: 3840x2160 atrium, sun CSM + 256 point lights (r = 4 m) with LDS tile light culling."""
+    W, H = 3840, 2160
+    lights = synth.point_lights(scene.SceneView.default(W, H), 256, 4.0, seed=8)
+    f = _make(W, H, "atrium", _abi.SHADOW_MODE_CSM, _abi.GI_NONE, lights=lights)
+    dev = f.device_arrays()
+    _lights_frame_checks(hip_ctx, f, dev, "4k_256_lights", (1024, 1280), [270, 271, 1079, 2150])
