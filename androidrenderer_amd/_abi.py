@@ -172,6 +172,7 @@ class ChainFrame(C.Structure):  # sah_chain_frame
 
 
 CHAIN_NO_EXCHANGE = 1 << 0
+CHAIN_CAPTURE = 1 << 1
 
 assert C.sizeof(ViewData) == 432
 assert C.sizeof(SunLightConstants) == 640

@@ -186,9 +186,10 @@ class NativePipelinedChain:
     waits and exchanges, one ABI call per frame instead of ten plus the stream and event traffic — the host side of a rank's frame drops
     from 72 us to the cost of the launches themselves (tools/experiments/chain_two_streams.py).  PipelinedChain stays as the statement of the
     order the tests hold this one against (tests/test_shard_chain.py).  `exchange=False`: both gathers left out (SAH_CHAIN_NO_EXCHANGE: a
-    rank's compute of an N-rank plan on a context of another world size)."""
+    rank's compute of an N-rank plan on a context of another world size).  `capture=True`: the two halves of a frame are replayed as HIP graphs
+    (SAH_CHAIN_CAPTURE, include/sah_hip.h), one graph launch per half instead of three to five kernel launches."""
 
-    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream=None, second_stream=None, tonemap_flags=0, exchange=True):
+    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream=None, second_stream=None, tonemap_flags=0, exchange=True, capture=False):
         import torch
         self.ctx, self.torch = ctx, torch
         self.work = torch.cuda.current_stream()
@@ -209,7 +210,7 @@ class NativePipelinedChain:
             for j, (desc, _keep) in enumerate(s.descs[:2]):
                 frames[k].lighting[j] = C.pointer(desc)
             frames[k].lit, frames[k].antialiased, frames[k].bloom, frames[k].out = s.lit_p, s.aa_p, s.mc, s.out_p
-        self.handle = ctx.chain_create(cp, frames, tonemap_flags, 0 if exchange else _abi.CHAIN_NO_EXCHANGE, self.work.cuda_stream,
+        self.handle = ctx.chain_create(cp, frames, tonemap_flags, (0 if exchange else _abi.CHAIN_NO_EXCHANGE) | (_abi.CHAIN_CAPTURE if capture else 0), self.work.cuda_stream,
                                        second_stream.cuda_stream if second_stream is not None else None)
 
     def register_direct_exchange(self, allgather):
@@ -233,6 +234,9 @@ class NativePipelinedChain:
 
     def image(self, frame_index):
         return self.sets[frame_index % 2].out
+
+    def graphs(self):
+        return self.ctx.chain_graphs(self.handle)
 
     def close(self):
         if getattr(self, "handle", None):

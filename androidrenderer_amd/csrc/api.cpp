@@ -496,6 +496,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
                 if (hipMalloc((void**)&ctx->irr32, need) == hipSuccess) {
                     ctx->irr32_bytes = need;
                     ctx->irr32_generation = 0;
+                    ctx->cache_epoch++;
                 } else {  // no room for the widened copy: the general gather needs none
                     (void)hipGetLastError();
                     ctx->irr32 = nullptr;
@@ -507,6 +508,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             const bool reuse = gi.probe_generation != 0 && gi.probe_generation == ctx->irr32_generation &&
                                same_volume(cache.irradiance, ctx->irr32_source);
             if (!reuse) {
+                if (gi.probe_generation != 0) ctx->cache_epoch++;  // (with 0 every call rebuilds: the same launches every time)
                 HIP_TRY(ctx, launch_probe_irr_unpack(cache.irradiance, ctx->irr32, ctx->stream));
                 ctx->dbg_irr_unpacks++;
                 ctx->irr32_generation = gi.probe_generation;
@@ -578,6 +580,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             ctx->list_bytes = 0;
             HIP_TRY(ctx, hipMalloc((void**)&ctx->list, need));
             ctx->list_bytes = need;
+            ctx->cache_epoch++;
         }
         fast.seg_list = (uint8_t*)ctx->list;
         fast.seg_count = (uint16_t*)((uint8_t*)ctx->list + codes_bytes);
@@ -598,12 +601,11 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
                                same_volume(src[1], ctx->lpv_pack_source[1]) && same_volume(src[2], ctx->lpv_pack_source[2]);
             fast.repack = reuse ? 0u : 1u;
             if (!reuse) {
+                if (gen != 0) ctx->cache_epoch++;  // (with 0 every call rebuilds: the same launches every time)
                 ctx->dbg_lpv_packs++;
-                ctx->lpv_pack_serial++;
                 ctx->lpv_pack_generation = gen;
                 for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = src[i];
             }
-            fast.pack_serial = ctx->lpv_pack_serial;
         }
         fast.sky_enabled = sky.enabled;
         {  // thread index -> (row, group in row) by a multiply-high: exact while gid * groups_per_row < 2^32 (magic = floor(2^32 / d) + 1)
@@ -626,10 +628,12 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             ctx->colx_capacity = 0;
             HIP_TRY(ctx, hipMalloc((void**)&ctx->colx_table, (size_t)need * sizeof(float)));
             ctx->colx_capacity = need;
+            ctx->cache_epoch++;
             ctx->colx_width = 0;
         }
         if (ctx->colx_width != W || memcmp(key, ctx->colx_key, sizeof(key)) != 0) {
             HIP_TRY(ctx, launch_colx_table(a, fast, ctx->colx_table, stride, row_stride, ctx->stream));
+            ctx->cache_epoch++;
             ctx->colx_width = W;
             memcpy(ctx->colx_key, key, sizeof(key));
         }

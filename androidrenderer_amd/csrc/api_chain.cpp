@@ -7,6 +7,7 @@
 
 #include <cstring>
 #include <new>
+#include <string>
 
 #include "../../include/sah_hip.h"
 #include "ctx.hpp"
@@ -58,7 +59,19 @@ struct OwnedLighting {
     }
 };
 
+// One half of a frame (everything between two exchanges) as a captured HIP graph.  A half is enqueued call by call the first time its buffer
+// set is used — the context's grow-only buffers, tables and gather copies come into being then —, captured the second time, and replayed
+// from then on for as long as sah_ctx::cache_epoch stands (ctx.hpp: while it does, the same calls enqueue the same kernels with the same
+// arguments).  Anything that moves the epoch — another user of the context, a dropped gather copy, other extents — sends the half back to
+// direct calls and a fresh capture.  One replay costs the host what one launch costs it; a half is three to five launches.
+struct HalfGraph {
+    hipGraphExec_t exec = nullptr;
+    uint64_t epoch = 0;
+    uint32_t direct_runs = 0;
+};
+
 struct FrameSet {
+    HalfGraph graph_a, graph_b;
     OwnedLighting lighting[2];
     sah_plane lit = {}, antialiased = {}, mip1 = {}, out = {};
     sah_mipchain bloom = {};
@@ -75,6 +88,9 @@ struct sah_chain {
     FrameSet sets[2];
     uint32_t tonemap_flags = 0;
     bool exchange = true;
+    bool capture = false, capture_failed = false;  // SAH_CHAIN_CAPTURE; a capture that did not work out: direct calls from then on
+    uint64_t replays = 0, captures = 0;
+    std::string capture_note;  // why the capture failed (sah_debug_chain_graphs leaves it in the context's last error)
     hipStream_t work = nullptr, post = nullptr;
     uint64_t submitted = 0, finished = 0;
 };
@@ -86,6 +102,58 @@ struct sah_chain {
     } while (0)
 
 static bool rows_nonempty(const uint32_t r[2]) { return r[1] > r[0]; }
+
+// `body`: the direct calls of one half, enqueued on `st` (the context's current stream).  See HalfGraph.
+template <class Body> static int run_half(sah_chain* c, HalfGraph& g, hipStream_t st, bool may_replay, Body body) {
+    sah_ctx* ctx = c->ctx;
+    if (!c->capture || c->capture_failed || !may_replay || st == nullptr) return body();  // (the null stream cannot be captured)
+    if (g.exec && g.epoch == ctx->cache_epoch) {
+        HIP_TRY(ctx, hipGraphLaunch(g.exec, st));
+        c->replays++;
+        return SAH_OK;
+    }
+    if (g.exec) {  // stale: something the launches depend on has changed since the capture
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        g.direct_runs = 0;
+    }
+    if (g.direct_runs == 0) {
+        g.direct_runs++;
+        return body();
+    }
+    const uint64_t epoch_before = ctx->cache_epoch;
+    if (const hipError_t eb = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed); eb != hipSuccess) {
+        (void)hipGetLastError();
+        c->capture_failed = true;
+        c->capture_note = std::string("hipStreamBeginCapture: ") + hipGetErrorString(eb);
+        return body();
+    }
+    const int rc = body();
+    const std::string body_error = rc != SAH_OK ? ctx->last_error : std::string();
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    hipGraphExec_t exec = nullptr;
+    hipError_t ei = hipSuccess;
+    if (rc != SAH_OK || e != hipSuccess || !graph || (ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) {
+        // (a call that cannot be captured — an allocation, a synchronous copy: nothing of the half has run; run it now, directly, and stay direct)
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        c->capture_failed = true;
+        c->capture_note = rc != SAH_OK ? "a captured call failed: " + body_error
+                                       : (e != hipSuccess ? std::string("hipStreamEndCapture: ") + hipGetErrorString(e) : std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        return body();
+    }
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(ctx, hipGraphLaunch(exec, st));
+    c->captures++;
+    if (ctx->cache_epoch != epoch_before) {  // the captured calls (re)built something: a replay would rebuild it every time.  Used once; captured again next time
+        (void)hipGraphExecDestroy(exec);
+        return SAH_OK;
+    }
+    g.exec = exec;
+    g.epoch = ctx->cache_epoch;
+    return SAH_OK;
+}
 
 // the stream the exchanges are enqueued on (allgather_bytes_impl, api_post.cpp): the side stream if there is one
 static hipStream_t exchange_stream(const sah_ctx* ctx) { return (ctx->comm_stream && ctx->comm_stream != ctx->stream) ? ctx->comm_stream : ctx->stream; }
@@ -101,8 +169,11 @@ static int chain_finish(sah_chain* c, uint64_t j) {
     if (c->post) HIP_TRY(ctx, hipStreamWaitEvent(st, s.a_done, 0));
     if (s.mip_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.mip_done, 0));
     if (s.final_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.final_done, 0));
-    CHAIN_TRY(sah_bloom_from_mip(ctx, &s.antialiased, &s.bloom, 1));
-    if (rows_nonempty(c->plan.out_rows)) CHAIN_TRY(sah_tonemap_ex(ctx, &s.antialiased, &s.bloom, &s.out, c->plan.out_rows[0], c->plan.out_rows[1], c->tonemap_flags));
+    CHAIN_TRY(run_half(c, s.graph_b, st, true, [&]() -> int {
+        CHAIN_TRY(sah_bloom_from_mip(ctx, &s.antialiased, &s.bloom, 1));
+        if (rows_nonempty(c->plan.out_rows)) CHAIN_TRY(sah_tonemap_ex(ctx, &s.antialiased, &s.bloom, &s.out, c->plan.out_rows[0], c->plan.out_rows[1], c->tonemap_flags));
+        return SAH_OK;
+    }));
     if (c->exchange) {
         CHAIN_TRY(sah_allgather_rows_reversed(ctx, &s.out, c->plan.rows_per_rank, c->plan.out_allocated_rows));
         HIP_TRY(ctx, hipEventRecord(s.final_done, exchange_stream(ctx)));
@@ -133,6 +204,7 @@ int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_f
     c->plan = *plan;
     c->tonemap_flags = tonemap_flags;
     c->exchange = !(chain_flags & SAH_CHAIN_NO_EXCHANGE);
+    c->capture = (chain_flags & SAH_CHAIN_CAPTURE) != 0;
     c->work = (hipStream_t)work_stream;
     c->post = (post_stream && post_stream != work_stream) ? (hipStream_t)post_stream : nullptr;
     auto bail = [&](int code, const char* msg) {
@@ -177,17 +249,21 @@ int sah_chain_submit(sah_chain* c, void* lighting_begin, void* lighting_end) {
     // A(i) overwrites the set's lit / antialiased / mip-0 / own mip-1 rows: their last readers were B(i - 2) — same stream and earlier, or
     // waited for here — and the mip-1 gather of frame i - 2 (B(i - 2) waited for it before it ran)
     if (c->post && s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.b_done, 0));
-    if (lighting_begin) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_begin, c->work));
-    for (OwnedLighting& l : s.lighting)
-        if (l.used) CHAIN_TRY(sah_lighting(ctx, &l.d));
-    if (lighting_end) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_end, c->work));
-    if (rows_nonempty(p.aa_rows) && rows_nonempty(p.mip0_rows)) {  // one pass over lit: antialiased rows + mip 0 rows
-        CHAIN_TRY(sah_copy_scene_bloom_mip0_rows(ctx, &s.lit, &s.antialiased, &s.bloom, p.aa_rows[0], p.aa_rows[1], p.mip0_rows[0], p.mip0_rows[1]));
-    } else {
-        if (rows_nonempty(p.aa_rows)) CHAIN_TRY(sah_copy_scene_rows(ctx, &s.lit, &s.antialiased, p.aa_rows[0], p.aa_rows[1]));
-        if (rows_nonempty(p.mip0_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 0, p.mip0_rows[0], p.mip0_rows[1]));
-    }
-    if (rows_nonempty(p.mip1_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 1, p.mip1_rows[0], p.mip1_rows[1]));
+    // (a caller that wants the Lighting pass timed gets the half call by call: its events are not part of a captured graph)
+    CHAIN_TRY(run_half(c, s.graph_a, c->work, !lighting_begin && !lighting_end, [&]() -> int {
+        if (lighting_begin) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_begin, c->work));
+        for (OwnedLighting& l : s.lighting)
+            if (l.used) CHAIN_TRY(sah_lighting(ctx, &l.d));
+        if (lighting_end) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_end, c->work));
+        if (rows_nonempty(p.aa_rows) && rows_nonempty(p.mip0_rows)) {  // one pass over lit: antialiased rows + mip 0 rows
+            CHAIN_TRY(sah_copy_scene_bloom_mip0_rows(ctx, &s.lit, &s.antialiased, &s.bloom, p.aa_rows[0], p.aa_rows[1], p.mip0_rows[0], p.mip0_rows[1]));
+        } else {
+            if (rows_nonempty(p.aa_rows)) CHAIN_TRY(sah_copy_scene_rows(ctx, &s.lit, &s.antialiased, p.aa_rows[0], p.aa_rows[1]));
+            if (rows_nonempty(p.mip0_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 0, p.mip0_rows[0], p.mip0_rows[1]));
+        }
+        if (rows_nonempty(p.mip1_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 1, p.mip1_rows[0], p.mip1_rows[1]));
+        return SAH_OK;
+    }));
     if (c->post) HIP_TRY(ctx, hipEventRecord(s.a_done, c->work));
     if (c->exchange) {
         CHAIN_TRY(sah_allgather_rows(ctx, &s.mip1, p.mip1_rows_per_rank, p.mip1_allocated_rows));  // side stream, behind A(i)
@@ -219,11 +295,24 @@ int sah_chain_counts(const sah_chain* c, uint64_t* submitted, uint64_t* finished
     return SAH_OK;
 }
 
+// test / analysis hook: out[0] = graph replays, out[1] = captures so far, out[2] = 1 when a capture failed and the chain went back to direct calls
+int sah_debug_chain_graphs(const sah_chain* c, uint64_t out[3]) {
+    if (!c || !out) return SAH_ERR_INVALID_ARGUMENT;
+    out[0] = c->replays;
+    out[1] = c->captures;
+    out[2] = c->capture_failed ? 1u : 0u;
+    if (c->capture_failed) c->ctx->last_error = "graph capture: " + c->capture_note;
+    return SAH_OK;
+}
+
 void sah_chain_destroy(sah_chain* c) {
     if (!c) return;
-    for (FrameSet& s : c->sets)
+    for (FrameSet& s : c->sets) {
         for (hipEvent_t e : {s.a_done, s.mip_done, s.final_done, s.b_done})
             if (e) (void)hipEventDestroy(e);
+        for (HalfGraph* g : {&s.graph_a, &s.graph_b})
+            if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    }
     delete c;
 }
 

@@ -230,6 +230,21 @@ int sah_bloom_from_mip(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain*
     return bloom_range(ctx, scene, bloom, mip + 1, bloom->num_mips - 1, 0, bloom->mips[mip + 1].height);
 }
 
+int sah_bloom_source_rows(uint32_t src_height, uint32_t dst_height, uint32_t row_begin, uint32_t row_end, uint32_t out[2]) {
+    if (!out || src_height == 0 || dst_height == 0 || row_begin > row_end || row_end > dst_height) return SAH_ERR_INVALID_ARGUMENT;
+    out[0] = out[1] = 0;
+    if (row_begin == row_end) return SAH_OK;
+    // exact integer floors of c -+ 2 with c = ((2 j + 1) * hs - hd) / (2 hd); with hs = 2 hd every tap coordinate is an integer + 0.5 and no
+    // rounding can move its floor, otherwise one row of slack either side (androidrenderer_amd/shard.py: _downsample_sources)
+    const int64_t hs = src_height, hd = dst_height, slack = (hs == 2 * hd) ? 0 : 1;
+    auto floordiv = [](int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    const int64_t lo = floordiv((2 * (int64_t)row_begin + 1) * hs - hd - 4 * hd, 2 * hd) - slack;
+    const int64_t hi = floordiv((2 * ((int64_t)row_end - 1) + 1) * hs - hd + 4 * hd, 2 * hd) + 1 + slack + 1;
+    out[0] = (uint32_t)std::min<int64_t>(std::max<int64_t>(lo, 0), hs);
+    out[1] = (uint32_t)std::min<int64_t>(std::max<int64_t>(hi, 0), hs);
+    return SAH_OK;
+}
+
 int sah_tonemap(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* bloom, const sah_plane* out, uint32_t row_begin, uint32_t row_end) {
     return sah_tonemap_ex(ctx, scene, bloom, out, row_begin, row_end, 0u);
 }
@@ -300,6 +315,7 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
         if (ctx->tm_thresholds) (void)hipFree(ctx->tm_thresholds);
         if (ctx->tm_code_table) (void)hipFree(ctx->tm_code_table);
         ctx->tm_thresholds = d_thr;
+        ctx->cache_epoch++;
         ctx->tm_code_table = d_code;
         ctx->tm_bucket_base = bucket_base;
         ctx->tm_bucket_count = bucket_count;
@@ -343,6 +359,7 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
         t.axis_tables = (const sah::TmAxis*)ctx->tm_axis;
         if (rebuild) {
             HIP_TRY(ctx, sah::launch_tonemap_axis_tables(t, (sah::TmAxis*)ctx->tm_axis, ctx->stream));
+            ctx->cache_epoch++;
             memcpy(ctx->tm_axis_key, key, sizeof(key));
         }
         HIP_TRY(ctx, sah::launch_tonemap_tol(t, ctx->stream));
@@ -355,7 +372,7 @@ int sah_tonemap_ex(sah_ctx* ctx, const sah_plane* scene, const sah_mipchain* blo
 int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, const sah_volume* blue, const sah_volume* geometry,
                   uint32_t num_cascades) {
     SAH_RANGE();
-    if (ctx) ctx->lpv_pack_generation = 0;  // the volumes change: the Lighting pass's gather copy of them is stale
+    if (ctx) sah_drop_lpv_copy(ctx);
     if (!ctx || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
     const sah_volume* in[4] = {red, green, blue, geometry};
     sah::VolumeArg v[4];
@@ -373,7 +390,6 @@ int sah_lpv_clear(sah_ctx* ctx, const sah_volume* red, const sah_volume* green, 
 
 int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume b_rgb[3], uint32_t num_cascades, uint32_t steps) {
     SAH_RANGE();
-    if (ctx) ctx->lpv_pack_generation = 0;  // the volumes change: the Lighting pass's gather copy of them is stale
     if (!ctx || !a_rgb || !b_rgb || num_cascades == 0 || num_cascades > 4) return SAH_ERR_INVALID_ARGUMENT;
     sah::VolumeArg a[3], b[3];
     for (int i = 0; i < 3; i++) {
@@ -384,6 +400,11 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         a[i] = varg(a_rgb[i]);
         b[i] = varg(b_rgb[i]);
     }
+    // (arguments are in order: from here on the volumes change, and the Lighting pass's gather copy of them is stale — the epoch follows at the end)
+    const uint32_t prev_gen = ctx->lpv_pack_generation;
+    sah::VolumeArg prev_src[3];
+    for (int i = 0; i < 3; i++) prev_src[i] = ctx->lpv_pack_source[i];
+    ctx->lpv_pack_generation = 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->lpv_tables_built) {  // the 30 direction pairs' SH / lobe vectors, into this device's constant memory, once per context
         HIP_TRY(ctx, sah::launch_lpv_build_tables(ctx->stream));
@@ -404,7 +425,7 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_lighting));
         HIP_TRY(ctx, sah_lpv_pack_reserve(ctx, pk.total));
         if (!ctx->state) emits = false;  // (made by sah_create; a context without it has no fast Lighting path either)
-        emit = {ctx->lpv_packed, pk.row_pitch, pk.slice_pitch, ctx->state, ctx->lpv_pack_serial + 1};
+        emit = {ctx->lpv_packed, pk.row_pitch, pk.slice_pitch, ctx->state};
     }
     for (uint32_t s = 0; s < steps; s++) {
         const sah::LpvPackEmit* e = (emits && s + 1 == steps) ? &emit : nullptr;
@@ -412,10 +433,14 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, e, ctx->stream));
     }
     if (emits) {
-        ctx->lpv_pack_serial++;
         ctx->lpv_pack_generation = SAH_GENERATION_TRACKED;
         for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = last[i];
     }
+    // a frame loop that propagates into the same volumes every frame leaves the state as it found it (copy tracked, made from `last`):
+    // the Lighting pass that follows enqueues what it enqueued the frame before.  Anything else is a change.
+    bool same = emits && prev_gen == SAH_GENERATION_TRACKED;
+    for (int i = 0; i < 3 && same; i++) same = same_volume(prev_src[i], last[i]);
+    if (!same && (prev_gen != 0 || emits)) ctx->cache_epoch++;
     return SAH_OK;
 }
 
@@ -478,7 +503,7 @@ int sah_probe_copy(sah_ctx* ctx, const sah_probe_atlases* src, const sah_probe_a
         s.validity.ptr == d.validity.ptr)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "probe copy: source and destination atlases must not alias");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->irr32_generation = 0;  // the Lighting pass's fp32 copy of an irradiance atlas is stale from here on
+    sah_drop_irr32_copy(ctx);  // the Lighting pass's fp32 copy of an irradiance atlas is stale from here on
     HIP_TRY(ctx, sah::launch_probe_copy(s, d, cascade_movement, ctx->stream));
     return SAH_OK;
 }
@@ -501,7 +526,7 @@ int sah_probe_update(sah_ctx* ctx, const sah_probe_atlases* atlases, const sah_v
     // the Lighting pass's fp32 copy of this irradiance atlas: kept current probe by probe when the context tracks it
     // (SAH_GENERATION_TRACKED, made from this very atlas), stale otherwise
     const bool patch_irr32 = ctx->irr32 && ctx->irr32_generation == SAH_GENERATION_TRACKED && same_volume(a.rtgi, ctx->irr32_source);
-    if (!patch_irr32) ctx->irr32_generation = 0;
+    if (!patch_irr32) sah_drop_irr32_copy(ctx);
     if (!ctx->probe_slots) {  // probe cell -> position in the update list (probes.hip: ordered_stores); all zero between calls
         HIP_TRY(ctx, hipMalloc((void**)&ctx->probe_slots, 32 * 32 * 32 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->probe_slots, 0, 32 * 32 * 32 * sizeof(uint32_t), ctx->stream));

@@ -300,7 +300,7 @@ int sah_lpv_extract_vpls(sah_ctx* ctx, const sah_rsm_targets* rsm, const sah_lpv
 int sah_lpv_inject_vpls(sah_ctx* ctx, const sah_packed_vpl* vpl_list, const uint32_t* vpl_count, uint32_t capacity, const sah_lpv_cascade_matrices* cascades,
                         uint32_t cascade_index, uint32_t num_cascades, const sah_volume rgb[3]) {
     SAH_RANGE();
-    if (ctx) ctx->lpv_pack_generation = 0;  // the volumes change: the Lighting pass's gather copy of them is stale
+    if (ctx) sah_drop_lpv_copy(ctx);
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     if (!vpl_list || !vpl_count || !cascades || !rgb || num_cascades == 0 || num_cascades > 4 || cascade_index >= num_cascades)
         return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "lpv_inject_vpls: null argument or cascade index");

@@ -49,12 +49,15 @@ struct sah_ctx {
     sah::VolumeArg irr32_source = {};
     uint8_t* lpv_packed = nullptr;     // device: per-frame interleaved, zero-bordered copy of the three LPV volumes (lighting.hip)
     size_t lpv_packed_bytes = 0;
-    uint32_t lpv_pack_serial = 0;      // number of the last k_lpv_pack run (FrameState::nonfinite_tag)
     uint32_t lpv_pack_generation = 0;  // sah_gi::lpv_generation the gather copy was built for (0: not reusable)
     sah::VolumeArg lpv_pack_source[3] = {};
     float* colx_table = nullptr;       // device: per-column view-space x numerators of the fast kernel, two flavours (lighting.hip: k_colx_table)
     uint32_t colx_capacity = 0, colx_width = 0;
     float colx_key[7] = {};            // render_resolution, p0, p12, p5, p13, height the tables were built for
+    // Raised whenever something changes that a launch of sah_lighting / sah_tonemap_ex DEPENDS on beyond its arguments: a context buffer is
+    // reallocated, a table is rebuilt for other extents, a gather copy that calls were re-using is dropped or has to be rebuilt.  While it
+    // stands, the same call enqueues the same kernels with the same kernel arguments — what sah_chain's captured graphs rely on (api_chain.cpp).
+    uint64_t cache_epoch = 0;
     uint32_t dbg_lpv_packs = 0, dbg_irr_unpacks = 0;  // full rebuilds of the two gather copies by sah_lighting (debug hook sah_debug_copy_rebuilds)
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;
@@ -169,6 +172,15 @@ inline hipError_t sah_guard_leave(sah_ctx* ctx, SahCacheGuard& g, bool drained) 
         if (e_ != hipSuccess) return fail(ctx, SAH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+inline void sah_drop_lpv_copy(sah_ctx* ctx) {  // the volumes change: the Lighting pass's gather copy of them is stale
+    if (ctx->lpv_pack_generation != 0) ctx->cache_epoch++;
+    ctx->lpv_pack_generation = 0;
+}
+inline void sah_drop_irr32_copy(sah_ctx* ctx) {  // the same for the fp32 copy of an irradiance atlas
+    if (ctx->irr32_generation != 0) ctx->cache_epoch++;
+    ctx->irr32_generation = 0;
+}
+
 // The gather copy of the LPV volumes (params.hpp: FastArgs::lpv_packed): its geometry for a volume extent, and the context's grow-only buffer.
 // A NEW buffer is zeroed on ctx->stream: k_lpv_pack writes the border texels itself, the emitting propagation step (lpv.hip) relies on them
 // being zero already.
@@ -189,6 +201,7 @@ inline hipError_t sah_lpv_pack_reserve(sah_ctx* ctx, uint64_t total) {
     ctx->lpv_packed = nullptr;
     ctx->lpv_packed_bytes = 0;
     ctx->lpv_pack_generation = 0;
+    ctx->cache_epoch++;
     e = hipMalloc((void**)&ctx->lpv_packed, total);
     if (e != hipSuccess) return e;
     ctx->lpv_packed_bytes = total;

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
 // 4-5 cache lines, instead of 24 dwordx2 loads over three allocations, and CLAMP_TO_BORDER needs no per-tap masking: border
 // texels are real zeros.
 __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const VolumeArg g, const VolumeArg b, uint8_t* packed, uint32_t pk_row_pitch,
-                                                  uint32_t pk_slice_pitch, FrameState* state, uint32_t serial) {
+                                                  uint32_t pk_slice_pitch, FrameState* state) {
     const uint32_t prow = blockIdx.x;  // one block per padded (z, y) row
     const uint32_t ph = r.height + 2 * kLpvPackBorder;
     const uint32_t pz = prow / ph, py = prow - pz * ph;
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
         dst[1] = t[1];
         dst[2] = t[2];
     }
-    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicMax(&state->nonfinite_tag, serial * 2u + 1u);
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicMax(&state->nonfinite, 1u);
 }
 
 // per-column numerator of the view-space x (inverse_projection separable: vs.x = p0 * ndc.x + p12), with the two texcoord conventions:
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
     const uint32_t ry = active ? (f.row_magic ? __umulhi(gid, f.row_magic) : gid / groups_per_row) : 0u;
     const uint32_t y = a.row_begin + ry;
     const uint32_t x0 = active ? (gid - ry * groups_per_row) * PPT : 0u;
-    const bool lpv_bad = (GI == SAH_GI_LPV) ? (f.state->nonfinite_tag == f.pack_serial * 2u + 1u) : false;
+    const bool lpv_bad = (GI == SAH_GI_LPV) ? (f.state->nonfinite != 0u) : false;
 
     uint32_t wc[PPT], wd[PPT], we[PPT], wz[PPT], wn[2 * PPT], wao[PPT], wm[PPT];
     float colx_g[PPT], colx_s[PPT];
@@ -390,8 +390,10 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     if (groups == 0) return hipSuccess;
     if (GI == SAH_GI_LPV && f.repack) {
         const uint32_t prows = (lpv.red.height + 2 * kLpvPackBorder) * (lpv.red.depth + 2 * kLpvPackBorder);
+        const hipError_t me = hipMemsetAsync(&f.state->nonfinite, 0, sizeof(uint32_t), st);  // the new copy's verdict starts at "finite"
+        if (me != hipSuccess) return me;
         hipLaunchKernelGGL(k_lpv_pack, dim3(prows), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, const_cast<uint8_t*>(f.lpv_packed), f.pk_row_pitch,
-                           f.pk_slice_pitch, f.state, f.pack_serial);
+                           f.pk_slice_pitch, f.state);
     }
     const uint32_t blocks = (uint32_t)((groups + 255) / 256);
     const dim3 block(256);

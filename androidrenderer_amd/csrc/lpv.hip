@@ -76,11 +76,10 @@ struct PropArgs {
     // the emitting step (the last one of a sah_lpv_propagate call, when the context keeps the Lighting pass's gather copy current:
     // SAH_GENERATION_TRACKED): every texel is also stored into the interleaved copy — colour c of texel (x, y, z) at
     // (z + 2) * pk_slice_pitch + (y + 2) * pk_row_pitch + (x + 2) * 24 + 8 c, inside a border of zeros that is already there
-    // (params.hpp: FastArgs::lpv_packed) — and an inf / NaN texel raises the copy's tag as k_lpv_pack does
+    // (params.hpp: FastArgs::lpv_packed) — and an inf / NaN texel raises the copy's flag as k_lpv_pack does
     uint8_t* packed;
     uint32_t pk_row_pitch, pk_slice_pitch;
     FrameState* state;
-    uint32_t serial;
 };
 
 // tables of the 30 direction pairs: built once per context into device memory (k_build_prop_tables) and read by the propagate kernels
@@ -162,7 +161,7 @@ __global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
         *reinterpret_cast<uint2*>(a.packed + (size_t)(z + kLpvPackBorder) * a.pk_slice_pitch + (size_t)(y + kLpvPackBorder) * a.pk_row_pitch +
                                   (size_t)(x + kLpvPackBorder) * kLpvPackTexel + 8u * c) = q;
         const bool bad = ((q.x & 0x7c00u) == 0x7c00u) | ((q.x & 0x7c000000u) == 0x7c000000u) | ((q.y & 0x7c00u) == 0x7c00u) | ((q.y & 0x7c000000u) == 0x7c000000u);
-        if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicMax(&a.state->nonfinite_tag, a.serial * 2u + 1u);
+        if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicMax(&a.state->nonfinite, 1u);
     }
 }
 
@@ -210,7 +209,8 @@ hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], 
         a.pk_row_pitch = emit->row_pitch;
         a.pk_slice_pitch = emit->slice_pitch;
         a.state = emit->state;
-        a.serial = emit->serial;
+        const hipError_t me = hipMemsetAsync(&emit->state->nonfinite, 0, sizeof(uint32_t), st);  // the copy's verdict starts at "finite"
+        if (me != hipSuccess) return me;
         hipLaunchKernelGGL(k_lpv_propagate<true>, dim3(num_cascades * 128, 3), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(k_lpv_propagate<false>, dim3(num_cascades * 128, 3), dim3(256), 0, st, a);

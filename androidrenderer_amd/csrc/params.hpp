@@ -80,10 +80,11 @@ struct SkyArgs {
 // is needed between calls: the fix-up kernel of call k zeroes the slots call k+1 will use).
 struct FrameState {
     uint32_t unused[3];
-    // serial * 2 + 1 of the last k_lpv_pack run that met an inf / NaN texel (atomicMax; packs are numbered from 1 per context): the gather
-    // copy of pack number n holds a non-finite texel iff this word equals n * 2 + 1 — nothing to clear between packs, and a copy that is
-    // kept over several Lighting calls (sah_gi::lpv_generation) keeps its verdict
-    uint32_t nonfinite_tag;
+    // 1 when the gather copy of the LPV volumes holds an inf / NaN texel: cleared (a 4-byte memset in front of the kernel) and raised by whatever
+    // writes the copy — k_lpv_pack, or the emitting step of the propagation — and read by the Lighting kernels; a copy that is kept over several
+    // Lighting calls keeps its verdict.  (Rounds 2-4 compared a tag with the copy's serial number, a KERNEL ARGUMENT: a captured launch replays
+    // its arguments, so the verdict now lives in memory only.)
+    uint32_t nonfinite;
 };
 
 // What the fast kernel may assume, established by the host (api.cpp: detect_fast_path):
@@ -97,7 +98,6 @@ struct FastArgs {
     uint32_t pos_div_nr;  // view-space position quotients may use the shared-reciprocal divide (lighting_fast.hpp)
     uint32_t sky_enabled;
     uint32_t row_magic;  // floor(2^32 / groups per row) + 1 when mulhi(gid, row_magic) == gid / groups_per_row for every thread of the call, else 0
-    uint32_t pack_serial;  // number of the k_lpv_pack run that made (or makes, in this call) the gather copy
     uint32_t repack;       // 1: this call rebuilds the gather copy first
     const float* colx_tab; // per-column view-space x numerators (k_colx_table): [0, width) the GLSL flavour, [colx_stride, ..) the Slang one; or null
     uint32_t colx_stride;
@@ -121,7 +121,6 @@ struct LpvPackEmit {  // the gather copy as the emitting propagation step writes
     uint8_t* packed;
     uint32_t row_pitch, slice_pitch;
     FrameState* state;
-    uint32_t serial;
 };
 
 struct LightingArgs {

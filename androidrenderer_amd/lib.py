@@ -21,7 +21,7 @@ _lib = None
 
 # every symbol include/sah_hip.h declares
 EXPORTS = ["sah_abi_version", "sah_status_string", "sah_last_error", "sah_create", "sah_destroy", "sah_comm_unique_id", "sah_set_stream",
-           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_bloom_mip_rows", "sah_bloom_from_mip", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate", "sah_probe_notify_updated",
+           "sah_sync", "sah_lighting", "sah_copy_scene", "sah_copy_scene_rows", "sah_copy_scene_bloom_mip0_rows", "sah_bloom", "sah_bloom_mip0_rows", "sah_bloom_from_mip0", "sah_bloom_mip_rows", "sah_bloom_from_mip", "sah_bloom_source_rows", "sah_tonemap", "sah_tonemap_ex", "sah_lpv_clear", "sah_lpv_propagate", "sah_probe_notify_updated",
            "sah_sky_update_luts", "sah_ao_clear", "sah_probe_copy", "sah_probe_update", "sah_shadow_render", "sah_gbuffer_render", "sah_rsm_render", "sah_lpv_extract_vpls",
            "sah_lpv_inject_vpls", "sah_rt_build", "sah_rtao", "sah_sun_shadow_mask", "sah_probe_trace", "sah_rtgi_trace", "sah_rt_set_rows", "sah_rt_set_bounces", "sah_allgather_rows", "sah_allgather_rows_reversed", "sah_allgather_bytes", "sah_comm_set_stream", "sah_comm_wait",
            "sah_ipc_open", "sah_ipc_connect", "sah_ipc_export", "sah_ipc_register", "sah_ipc_unregister", "sah_ipc_reset",
@@ -59,6 +59,7 @@ def load():
     lib.sah_bloom_from_mip0.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain)]
     lib.sah_bloom_mip_rows.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32, C.c_uint32, C.c_uint32]
     lib.sah_bloom_from_mip.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.c_uint32]
+    lib.sah_bloom_source_rows.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
     lib.sah_tonemap.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32]
     lib.sah_tonemap_ex.argtypes = [C.c_void_p, C.POINTER(_abi.Plane), C.POINTER(_abi.MipChain), C.POINTER(_abi.Plane), C.c_uint32, C.c_uint32, C.c_uint32]
     lib.sah_lpv_clear.argtypes = [C.c_void_p] + [C.POINTER(_abi.Volume)] * 4 + [C.c_uint32]
@@ -103,6 +104,7 @@ def load():
     lib.sah_chain_flush.argtypes = [C.c_void_p]
     lib.sah_chain_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.sah_chain_destroy.argtypes = [C.c_void_p]
+    lib.sah_debug_chain_graphs.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.sah_chain_destroy.restype = None
     lib.sah_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _lib = lib
@@ -320,6 +322,14 @@ class Context:
 
     def chain_flush(self, chain):
         self._check(self.lib.sah_chain_flush(chain))
+
+    def chain_graphs(self, chain):
+        """(graph replays, captures, 1 if a capture failed and the chain fell back to direct calls)"""
+        out = (C.c_uint64 * 3)()
+        self._check(self.lib.sah_debug_chain_graphs(chain, out))
+        if out[2]:
+            print("[sah] " + self.lib.sah_last_error(self.handle).decode())
+        return int(out[0]), int(out[1]), int(out[2])
 
     def chain_destroy(self, chain):
         self.lib.sah_chain_destroy(chain)

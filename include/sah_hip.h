@@ -267,17 +267,25 @@ int sah_copy_scene_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* lit, const sah
 /* Bloomer::fill_bloom_tex — RenderCore/render/bloomer.hpp:15, bloomer.cpp:38-262 */
 int sah_bloom(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom);
 /* The same pyramid in two steps, for frames sharded by rows (the pyramid is the one pass that is not row-local): rows
- * [row_begin, row_end) of mip 0 from the scene — mip 0 row j reads scene rows 2j - 2 .. 2j + 3, which must be valid — and, once every
- * rank's mip 0 rows have been exchanged (sah_allgather_rows on mips[0]), mips 1.. from mip 0.  Together they write what sah_bloom writes. */
+ * [row_begin, row_end) of mip 0 from the scene — the source rows they read must be valid: sah_bloom_source_rows below — and, once every
+ * rank's mip 0 rows have been exchanged (sah_allgather_rows on mips[0]), mips 1.. from mip 0.  Together they write what sah_bloom writes.
+ * An EMPTY range (row_begin == row_end, (0, 0) included) writes nothing: unlike the other *_rows entry points these two have no
+ * "(0, 0) = all rows" convention — a rank of a sharded frame may own no row of a small mip, and must be able to say so. */
 int sah_bloom_mip0_rows(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, uint32_t row_begin, uint32_t row_end);
 int sah_bloom_from_mip0(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom);
 /* The same split one level down, or at any level: rows [row_begin, row_end) of mip `mip` from its source (the scene for mip 0, mip - 1
- * otherwise: row j reads source rows 2j - 2 .. 2j + 3, which must be valid), and mips mip + 1 .. from mip `mip`.  A frame sharded by rows
+ * otherwise; the source rows they read must be valid: sah_bloom_source_rows), and mips mip + 1 .. from mip `mip`.  A frame sharded by rows
  * that exchanges mip 1 instead of mip 0 moves a quarter of the bytes: every rank then computes the mip 0 rows its own mip 1 rows and its own
  * rows of the composite read (androidrenderer_amd/shard.py) — sah_bloom_mip_rows(.., 0, ..) or the fused copy above —,
  * sah_bloom_mip_rows(.., 1, ..), the exchange of mips[1], sah_bloom_from_mip(.., 1). */
 int sah_bloom_mip_rows(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, uint32_t mip, uint32_t row_begin, uint32_t row_end);
 int sah_bloom_from_mip(sah_ctx* ctx, const sah_plane* scene_color, const sah_mipchain* bloom, uint32_t mip);
+/* Which source rows the downsample reads for destination rows [row_begin, row_end) (bloom_downsample.comp:16-52: 20 bilinear taps within two
+ * source texels of c = (j + 0.5) * src_height / dst_height - 0.5).  That is 2j - 2 .. 2j + 3 ONLY when the source is exactly twice as high;
+ * otherwise — a 75-row mip under a 37-row one — the window drifts by up to a row over the mip's height, and one more row either side is
+ * allowed for the shader's fp32 coordinate.  out[0], out[1] = [first, one past last) source row, clipped to [0, src_height).  A caller that
+ * shards an odd-height frame by the "2j - 2 .. 2j + 3" rule feeds rows nobody validated; this is the rule androidrenderer_amd/shard.py uses. */
+int sah_bloom_source_rows(uint32_t src_height, uint32_t dst_height, uint32_t row_begin, uint32_t row_end, uint32_t out[2]);
 
 /* UiPhase::draw_scene_image — RenderCore/render/phase/ui_phase.cpp:98-113; out = R8G8B8A8 (sRGB-encoded).
  * Rows [row_begin,row_end) of the output are written (0,0 = all). */
@@ -735,6 +743,14 @@ typedef struct sah_chain_frame {
  * for the work stream.  tonemap_flags as for sah_tonemap_ex.  chain_flags: SAH_CHAIN_NO_EXCHANGE = both gathers are left out (one rank's
  * compute of an N-rank plan on a context of another world size: rehearsals and measurements of a rank's share on one GPU). */
 #define SAH_CHAIN_NO_EXCHANGE (1u << 0)
+/* SAH_CHAIN_CAPTURE: the two halves of a frame (the launches between two exchanges) are captured into HIP graphs the second time a buffer set
+ * is used and replayed afterwards — one graph launch instead of three to five kernel launches per half.  A replay enqueues exactly what
+ * the captured calls enqueued, so it is only used while nothing those calls depend on has changed (context buffers and tables, the gather
+ * copies' state: the context counts such changes) — any other use of the context in between sends the chain back to direct calls and a new
+ * capture — and not for a submit that asks for the Lighting pass's events.  Frame descriptors are fixed at sah_chain_create either way; what
+ * the planes and side tables CONTAIN may change from frame to frame (SAH_GENERATION_TRACKED or 0 for copies the library keeps: a non-zero
+ * caller-kept change counter in a fixed descriptor could not change). */
+#define SAH_CHAIN_CAPTURE (1u << 1)
 int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_frame frames[2], uint32_t tonemap_flags, uint32_t chain_flags,
                      void* work_stream, void* post_stream, sah_chain** out);
 /* lighting_begin / lighting_end: optional hipEvent_t recorded on the work stream around the frame's sah_lighting calls (NULL: none) */

@@ -264,6 +264,8 @@ def main():
         "sah_ipc_export": lambda: L.sah_ipc_export(ctx(), f.addr(), int(f.g.integers(0, 2 ** 40)), handles(1)),
         "sah_ipc_register": lambda: L.sah_ipc_register(ctx(), f.addr(), int(f.g.integers(0, 2 ** 40)), handles()),
         "sah_ipc_unregister": lambda: L.sah_ipc_unregister(ctx(), f.addr()),
+        "sah_ipc_reset": lambda: L.sah_ipc_reset(ctx()),
+        "sah_bloom_source_rows": lambda: L.sah_bloom_source_rows(f.u32((0, 1, 37, 75, 1080)), f.u32((0, 1, 18, 37, 540)), f.u32(), f.u32(), None if f.g.random() < 0.1 else (C.c_uint32 * 2)()),
         "sah_chain_create": chain_create,
         "sah_chain_submit": lambda: L.sah_chain_submit(None, None, None),
         "sah_chain_flush": lambda: L.sah_chain_flush(None),

@@ -113,3 +113,22 @@ def test_point_lights_on_the_surface(hip_ctx):
         lights[k, 7] = 4000.0
     f = util.LightingFrame(64, 48, seed=50, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_NONE, flavour="atrium", lights=lights)
     _vs_oracle(f, hip_ctx, "lights placed on surface points", max_ulp=0)
+
+
+@pytest.mark.parametrize("gi,extra", [(_abi.GI_CACHE, 0), (_abi.GI_RTGI, 2)])
+@pytest.mark.parametrize("sun_mode", [_abi.SHADOW_MODE_RT, _abi.SHADOW_MODE_CSM])
+def test_tiled_kernel_adversarial_surface_inputs(hip_ctx, sun_mode, gi, extra):
+    """Zero, NaN, infinite and denormal normals / depths and roughness 0 through the TILED kernel's Slang passes (the half root is
+    v_sqrt_f32 alone, whose NaN may carry another sign or payload than the IEEE expansion the oracle uses — DESIGN.md §3 leaves NaN bit
+    patterns unspecified; what must hold is that a NaN is a NaN in the same channels of the same pixels, and every finite value is the
+    oracle's: util.f16_ulp_diff counts NaN against NaN as equal and NaN against a number as 65535)."""
+    from tests.test_lighting_gpu import _poison
+    g = synth.random_gbuffer(160, 96, seed=91)
+    _poison(g, np.random.default_rng(7))
+    f = util.LightingFrame(160, 96, gbuffer=g, seed=92, sun_mode=sun_mode, gi=gi, num_extra_rays=extra)
+    if "shadow_mask" in f.arrays:
+        f.arrays["shadow_mask"][4, 6] = np.nan
+        f.arrays["shadow_mask"][9, 11] = np.inf
+    got = _vs_oracle(f, hip_ctx, f"tiled adversarial sun={sun_mode} gi={gi}", max_ulp=0)
+    nan = (got & 0x7FFF) > 0x7C00
+    print(f"NaN channels in the image: {int(nan.sum())}")

@@ -238,13 +238,14 @@ def test_hip_chain_through_a_one_rank_communicator():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native", [False, True], ids=["python-loop", "library-loop"])
+@pytest.mark.parametrize("native", [False, True, "graphs"], ids=["python-loop", "library-loop", "library-loop-graphs"])
 @pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True), (None, True), (None, False)])
 def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_streams, native):
     """Two frames in flight (chain.PipelinedChain: both exchanges on the side stream of a one-rank communicator), a different AO plane
     per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's.
     `two_streams`: the B halves (mips 1.., tonemap, final exchange) on a second work stream beside the next frame's lighting.
-    `native`: the same loop inside the library (sah_chain_create / _submit / _flush through chain.NativePipelinedChain)."""
+    `native`: the same loop inside the library (sah_chain_create / _submit / _flush through chain.NativePipelinedChain); "graphs": with its
+    halves captured into HIP graphs and replayed (SAH_CHAIN_CAPTURE) — the AO plane still changes every frame, the descriptors do not."""
     import torch
     from androidrenderer_amd import chain, lib
     from tests import util
@@ -252,6 +253,9 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
         monkeypatch.setenv("SAH_COMM_NO_SPLIT", "1")
     # (no_split None: no communicator at all — bench.py --frames-in-flight 2 on one GPU; the exchanges are no-ops)
     ctx = lib.Context(device=0, rank=0, world=1, comm_id=None if no_split is None else lib.comm_unique_id())
+    previous_stream = torch.cuda.current_stream()
+    if native == "graphs":
+        torch.cuda.set_stream(torch.cuda.Stream())  # a work stream of its own: the null stream cannot be captured
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     side = torch.cuda.Stream()
     try:
@@ -267,7 +271,10 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
             torch.cuda.synchronize()
             want.append(plain.out.cpu().numpy().copy())
         assert not np.array_equal(want[0], want[1])
-        pc = (chain.NativePipelinedChain if native else chain.PipelinedChain)(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None)
+        if native:
+            pc = chain.NativePipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None, capture=native == "graphs")
+        else:
+            pc = chain.PipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None)
         got = {}
         for i, a in enumerate(ao):
             dev["ao"].copy_(a)             # on the work stream: ordered with the frames around it
@@ -285,8 +292,31 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
         for i, img in sorted(got.items()):
             assert np.array_equal(img, want[i]), f"frame {i}"
         assert pc.submitted == 7 and (native or pc.finished == 7)
+        if native == "graphs":  # seven frames over two buffer sets: each half direct once, captured once, replayed afterwards
+            replays, captures, failed = pc.graphs()
+            assert not failed and captures >= 4 and replays >= 4, (replays, captures, failed)
         if native:
             pc.close()
     finally:
         torch.cuda.synchronize()
+        torch.cuda.set_stream(previous_stream)
         ctx.close()
+
+
+def test_library_source_row_rule_is_the_plans():
+    """sah_bloom_source_rows (include/sah_hip.h): the C ABI's statement of which source rows a band of a bloom mip reads — the rule a C caller
+    needs to shard an odd-height frame — is the one the Python plan uses (shard._downsample_sources), for every band of several pyramids."""
+    import ctypes as C
+    from androidrenderer_amd import lib, shard
+    L = lib.load()
+    out = (C.c_uint32 * 2)()
+    for hs, hd in ((2160, 1080), (1080, 540), (75, 37), (37, 18), (149, 74), (9, 4), (3, 1), (2, 1), (1, 1)):
+        for j0 in range(0, hd, max(1, hd // 7)):
+            for j1 in (j0 + 1, min(hd, j0 + 5), hd):
+                if j1 <= j0:
+                    continue
+                assert L.sah_bloom_source_rows(hs, hd, j0, j1, out) == 0
+                lo, hi = shard._downsample_sources(j0, j1, hs, hd)
+                assert (out[0], out[1]) == shard._clip(lo, hi, hs), (hs, hd, j0, j1)
+    assert L.sah_bloom_source_rows(10, 5, 3, 3, out) == 0 and (out[0], out[1]) == (0, 0)  # an empty band reads nothing
+    assert L.sah_bloom_source_rows(10, 5, 4, 3, out) != 0 and L.sah_bloom_source_rows(10, 5, 0, 6, out) != 0 and L.sah_bloom_source_rows(0, 5, 0, 1, out) != 0

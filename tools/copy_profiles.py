@@ -5,7 +5,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r4"
+R = sys.argv[1] if len(sys.argv) > 1 else "r5"
 SRC, DST = "gpurun_out/refresh", "profiles"
 shutil.copy(f"{SRC}/bench.json", f"{DST}/{R}_bench_4k_deferred_gi.json")
 shutil.copy(f"{SRC}/ktrace/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_deferred_gi.csv")
@@ -17,7 +17,7 @@ if os.path.exists(f"{SRC}/roofline_static.json"):
     shutil.copy(f"{SRC}/roofline_static.json", f"{DST}/roofline_static.json")
 for src, dst in (("pmc_rt_cache_tiled.txt", "pmc_rt_cache_tiled.txt"), ("pmc_tonemap.txt", "pmc_tonemap.txt"), ("cpu_baselines.txt", "cpu_baselines.txt"),
                  ("rehearse_n2.json", "rehearse_n2_one_gpu.json"), ("strict_chain.json", "bench_4k_probe_gi_chain_strict_tonemap.json"),
-                 ("repack.json", "bench_4k_deferred_gi_repack_lpv.json"), ("chain_fif2.json", "bench_4k_probe_gi_chain_two_frames_in_flight.json"),
+                 ("repack.json", "bench_4k_deferred_gi_lpv_copy_rebuilt_every_step.json"), ("kept.json", "bench_4k_deferred_gi_lpv_copy_kept.json"), ("bench200.json", "bench_4k_deferred_gi_200_steps.json"), ("chain_fif2.json", "bench_4k_probe_gi_chain_two_frames_in_flight.json"),
                  ("lpv_chain_fif2.json", "bench_4k_lpv_gi_chain_two_frames_in_flight.json")):
     if os.path.exists(f"{SRC}/{src}"):
         shutil.copy(f"{SRC}/{src}", f"{DST}/{R}_{dst}")

@@ -27,6 +27,7 @@ fr = frame.LightingInputs(W, H, seed=2, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI
 fr.probe_generation = 0 if rebuild else _abi.GENERATION_TRACKED
 dev = fr.device_arrays("cuda")
 ctx = lib.Context(0)
+torch.cuda.set_stream(torch.cuda.Stream())  # a work stream of its own: the null stream cannot be captured into a graph
 s1 = torch.cuda.current_stream()
 s2 = torch.cuda.Stream()
 ctx.set_stream(s1.cuda_stream)
@@ -75,8 +76,8 @@ def two_streams():
     ctx.set_stream(s1.cuda_stream)
 
 
-def library_loop(second):
-    pc = chain.NativePipelinedChain(ctx, fr, dev, rank, world, None, second, tonemap_flags=tm, exchange=False)
+def library_loop(second, capture=False):
+    pc = chain.NativePipelinedChain(ctx, fr, dev, rank, world, None, second, tonemap_flags=tm, exchange=False, capture=capture)
 
     def run():
         for _ in range(N):
@@ -86,8 +87,9 @@ def library_loop(second):
     return run
 
 
-lib_one, lib_two = library_loop(None), library_loop(s2)
-for name, fn in (("python, one stream", one_stream), ("python, two streams", two_streams), ("library loop, one stream", lib_one), ("library loop, two streams", lib_two)) * 2:
+lib_one, lib_two, graph_one, graph_two = library_loop(None), library_loop(s2), library_loop(None, True), library_loop(s2, True)
+for name, fn in (("python, one stream", one_stream), ("python, two streams", two_streams), ("library loop, one stream", lib_one), ("library loop, two streams", lib_two),
+                 ("library loop + graphs, one", graph_one), ("library loop + graphs, two", graph_two)) * 2:
     fn()
     torch.cuda.synchronize()
     t = time.perf_counter()

@@ -5,7 +5,9 @@ profiles/roofline_static.json, the per-workload record bench.py's `roofline` obj
 
 Per launch of the named kernel: VALU wave-instructions (SQ_INSTS_VALU), rocprof's VALUBusy numerator (SQ_ACTIVE_INST_VALU counts
 quad-cycles: x 4), HBM traffic (FETCH_SIZE is in KiB-like units of 1000 B on this stack and reports half of a wide streaming read on
-gfx950 — MI355X_MICROARCH.md "HBM": doubled here — plus WRITE_SIZE).
+gfx950 — MI355X_MICROARCH.md "HBM": doubled here — plus WRITE_SIZE).  The guide states the factor for wide coalesced reads; round 5 calibrated it for
+the narrow accesses of this path as well (tools/microbench/fetch_calib.hip, profiles/r5_pmc_gather_calibration.txt): every L2 miss fetches one
+128-byte line whatever the access width — 2-byte gathers and PCF footprints included — and FETCH_SIZE tallies it as 64 bytes, so x 2 holds there too.
 
 SQ_ACTIVE_INST_VALU charges every instruction a whole quad-cycle (its mean is 4.09 cycles per instruction on every kernel here), while
 MI355X issues fp32 mul / add / fma / mov in ~2.3 cycles (profiles/r1_valu_issue_cost.txt), so VALUBusy OVERSTATES the issue time of a
