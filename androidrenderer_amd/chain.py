@@ -189,11 +189,12 @@ class NativePipelinedChain:
     rank's compute of an N-rank plan on a context of another world size).  `capture=True`: the two halves of a frame are replayed as HIP graphs
     (SAH_CHAIN_CAPTURE, include/sah_hip.h), one graph launch per half instead of three to five kernel launches."""
 
-    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream=None, second_stream=None, tonemap_flags=0, exchange=True, capture=False):
+    def __init__(self, ctx, frame, device_arrays, rank, world, comm_stream=None, second_stream=None, tonemap_flags=0, exchange=True, capture=False, reduce_stream=None):
         import torch
         self.ctx, self.torch = ctx, torch
         self.work = torch.cuda.current_stream()
         self.work2 = second_stream
+        self.reduce_stream = reduce_stream  # (kept alive: the library holds the raw handles)
         self.sets = [ShardedChain(ctx, frame, device_arrays, rank, world, tonemap_flags=tonemap_flags) for _ in range(2)]
         self.plan = p = self.sets[0].plan
         self.submitted = 0
@@ -211,7 +212,7 @@ class NativePipelinedChain:
                 frames[k].lighting[j] = C.pointer(desc)
             frames[k].lit, frames[k].antialiased, frames[k].bloom, frames[k].out = s.lit_p, s.aa_p, s.mc, s.out_p
         self.handle = ctx.chain_create(cp, frames, tonemap_flags, (0 if exchange else _abi.CHAIN_NO_EXCHANGE) | (_abi.CHAIN_CAPTURE if capture else 0), self.work.cuda_stream,
-                                       second_stream.cuda_stream if second_stream is not None else None)
+                                       reduce_stream.cuda_stream if reduce_stream is not None else None, second_stream.cuda_stream if second_stream is not None else None)
 
     def register_direct_exchange(self, allgather):
         for s in self.sets:

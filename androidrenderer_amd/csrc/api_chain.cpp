@@ -71,13 +71,13 @@ struct HalfGraph {
 };
 
 struct FrameSet {
-    HalfGraph graph_a, graph_b;
+    HalfGraph graph_l, graph_r, graph_b;
     OwnedLighting lighting[2];
     sah_plane lit = {}, antialiased = {}, mip1 = {}, out = {};
     sah_mipchain bloom = {};
-    // behind the A half / the mip-1 gather / the final gather / the B half of the frame that last used the set
-    hipEvent_t a_done = nullptr, mip_done = nullptr, final_done = nullptr, b_done = nullptr;
-    bool mip_valid = false, final_valid = false, b_valid = false;
+    // behind the lighting / the reduction (copy, mip 0 and mip 1 rows) / the mip-1 gather / the final gather / the B part of the frame that last used the set
+    hipEvent_t l_done = nullptr, r_done = nullptr, mip_done = nullptr, final_done = nullptr, b_done = nullptr;
+    bool r_valid = false, mip_valid = false, final_valid = false, b_valid = false;
 };
 
 }  // namespace
@@ -91,7 +91,7 @@ struct sah_chain {
     bool capture = false, capture_failed = false;  // SAH_CHAIN_CAPTURE; a capture that did not work out: direct calls from then on
     uint64_t replays = 0, captures = 0;
     std::string capture_note;  // why the capture failed (sah_debug_chain_graphs leaves it in the context's last error)
-    hipStream_t work = nullptr, post = nullptr;
+    hipStream_t work = nullptr, reduce = nullptr, post = nullptr;  // reduce == work / post == reduce: that part shares the stream of the one before it
     uint64_t submitted = 0, finished = 0;
 };
 
@@ -158,15 +158,27 @@ template <class Body> static int run_half(sah_chain* c, HalfGraph& g, hipStream_
 // the stream the exchanges are enqueued on (allgather_bytes_impl, api_post.cpp): the side stream if there is one
 static hipStream_t exchange_stream(const sah_ctx* ctx) { return (ctx->comm_stream && ctx->comm_stream != ctx->stream) ? ctx->comm_stream : ctx->stream; }
 
-// B(j): mips 2.. + the composite of the rank's rows + the exchange of the final image
+// A frame in three parts, each on its stream (streams may coincide):
+//   L(i)  lighting of the rank's rows                                      work stream
+//   R(i)  copy scene + bloom mip 0 over its band, its rows of mip 1        reduce stream      -> exchange of mip 1
+//   B(i)  mips 2.., the composite of its rows                              post stream        -> exchange of the final image
+// Everything a frame writes exists twice (sets[i & 1]); what a part overwrites was last read by a part of frame i - 2:
+//   L(i) writes lit                 <- read by R(i - 2)
+//   R(i) writes antialiased, mips   <- read by B(i - 2) (which had waited for the mip-1 gather of frame i - 2)
+//   B(i) writes mips 2.., out       <- out read by the final gather of frame i - 2
+// On ONE stream that is stream order; between streams it is the events below.  sah_chain_submit enqueues L(i), R(i), the mip-1 gather,
+// then B(i - 1) and its gather: the gathers travel beside the parts enqueued behind them.  Three streams matter on a rank of eight: the
+// lighting of frame i + 1 starts when that of frame i ends instead of behind its copy and mip rows (0.125 -> 0.106 ms per frame for one
+// rank's share of the 4K chain, tools/experiments/chain_two_streams.py).
+
+// B(j)
 static int chain_finish(sah_chain* c, uint64_t j) {
     sah_ctx* ctx = c->ctx;
     FrameSet& s = c->sets[j & 1];
-    hipStream_t st = c->post ? c->post : c->work;
-    if (c->post) CHAIN_TRY(sah_set_stream(ctx, (void*)st));  // the library enqueues B(j), and orders its gather, on the post stream
-    // mips 2.. read every rank's rows of mip 1 (the gather ran behind A(j) — and where there is nothing to gather, one rank without a
-    // communicator, nothing ran at all: hence a_done); the final gather of frame j - 2 still reads this set's image
-    if (c->post) HIP_TRY(ctx, hipStreamWaitEvent(st, s.a_done, 0));
+    hipStream_t st = c->post;
+    CHAIN_TRY(sah_set_stream(ctx, (void*)st));  // the library enqueues B(j), and orders its gather, on the post stream
+    if (c->post != c->reduce) HIP_TRY(ctx, hipStreamWaitEvent(st, s.r_done, 0));
+    // mips 2.. read every rank's rows of mip 1 (the gather ran behind R(j)); the final gather of frame j - 2 still reads this set's image
     if (s.mip_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.mip_done, 0));
     if (s.final_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.final_done, 0));
     CHAIN_TRY(run_half(c, s.graph_b, st, true, [&]() -> int {
@@ -179,10 +191,9 @@ static int chain_finish(sah_chain* c, uint64_t j) {
         HIP_TRY(ctx, hipEventRecord(s.final_done, exchange_stream(ctx)));
         s.final_valid = true;
     }
-    if (c->post) {
+    if (c->post != c->reduce) {
         HIP_TRY(ctx, hipEventRecord(s.b_done, st));
         s.b_valid = true;
-        CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
     }
     c->finished++;
     return SAH_OK;
@@ -191,7 +202,7 @@ static int chain_finish(sah_chain* c, uint64_t j) {
 extern "C" {
 
 int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_frame frames[2], uint32_t tonemap_flags, uint32_t chain_flags,
-                     void* work_stream, void* post_stream, sah_chain** out) {
+                     void* work_stream, void* reduce_stream, void* post_stream, sah_chain** out) {
     SAH_RANGE();
     if (!ctx || !plan || !frames || !out) return SAH_ERR_INVALID_ARGUMENT;
     *out = nullptr;
@@ -206,12 +217,14 @@ int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_f
     c->exchange = !(chain_flags & SAH_CHAIN_NO_EXCHANGE);
     c->capture = (chain_flags & SAH_CHAIN_CAPTURE) != 0;
     c->work = (hipStream_t)work_stream;
-    c->post = (post_stream && post_stream != work_stream) ? (hipStream_t)post_stream : nullptr;
+    c->reduce = reduce_stream ? (hipStream_t)reduce_stream : c->work;
+    c->post = post_stream ? (hipStream_t)post_stream : c->reduce;
     auto bail = [&](int code, const char* msg) {
         sah_chain_destroy(c);
         return fail(ctx, code, "%s", msg);
     };
     if (hipSetDevice(ctx->device) != hipSuccess) return bail(SAH_ERR_HIP, "hipSetDevice failed");
+    if (c->post == c->work && c->reduce != c->work) return bail(SAH_ERR_INVALID_ARGUMENT, "chain streams: the post stream is the reduce stream or a stream of its own");
     for (int k = 0; k < 2; k++) {
         const sah_chain_frame& f = frames[k];
         FrameSet& s = c->sets[k];
@@ -226,7 +239,7 @@ int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_f
         s.out = f.out;
         if (c->exchange && ((uint64_t)plan->mip1_rows_per_rank * ctx->world > plan->mip1_allocated_rows || (uint64_t)plan->rows_per_rank * ctx->world > plan->out_allocated_rows))
             return bail(SAH_ERR_INVALID_ARGUMENT, "chain plan: an allocation holds fewer rows than its gather's equal slots (slot rows * world)");
-        for (hipEvent_t* e : {&s.a_done, &s.mip_done, &s.final_done, &s.b_done})
+        for (hipEvent_t* e : {&s.l_done, &s.r_done, &s.mip_done, &s.final_done, &s.b_done})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(SAH_ERR_HIP, "hipEventCreateWithFlags failed");
     }
     const int rc = sah_set_stream(ctx, (void*)c->work);
@@ -245,16 +258,25 @@ int sah_chain_submit(sah_chain* c, void* lighting_begin, void* lighting_end) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const sah_chain_plan& p = c->plan;
     FrameSet& s = c->sets[c->submitted & 1];
+    // ---- L(i)
     CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
-    // A(i) overwrites the set's lit / antialiased / mip-0 / own mip-1 rows: their last readers were B(i - 2) — same stream and earlier, or
-    // waited for here — and the mip-1 gather of frame i - 2 (B(i - 2) waited for it before it ran)
-    if (c->post && s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.b_done, 0));
-    // (a caller that wants the Lighting pass timed gets the half call by call: its events are not part of a captured graph)
-    CHAIN_TRY(run_half(c, s.graph_a, c->work, !lighting_begin && !lighting_end, [&]() -> int {
+    if (c->reduce != c->work && s.r_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.r_done, 0));  // lit of this set: last read by R(i - 2)
+    // (a caller that wants the Lighting pass timed gets it call by call: its events are not part of a captured graph)
+    CHAIN_TRY(run_half(c, s.graph_l, c->work, !lighting_begin && !lighting_end, [&]() -> int {
         if (lighting_begin) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_begin, c->work));
         for (OwnedLighting& l : s.lighting)
             if (l.used) CHAIN_TRY(sah_lighting(ctx, &l.d));
         if (lighting_end) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_end, c->work));
+        return SAH_OK;
+    }));
+    // ---- R(i)
+    if (c->reduce != c->work) {
+        HIP_TRY(ctx, hipEventRecord(s.l_done, c->work));
+        CHAIN_TRY(sah_set_stream(ctx, (void*)c->reduce));
+        HIP_TRY(ctx, hipStreamWaitEvent(c->reduce, s.l_done, 0));
+    }
+    if (c->post != c->reduce && s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->reduce, s.b_done, 0));  // antialiased / mips of this set: last read by B(i - 2)
+    CHAIN_TRY(run_half(c, s.graph_r, c->reduce, true, [&]() -> int {
         if (rows_nonempty(p.aa_rows) && rows_nonempty(p.mip0_rows)) {  // one pass over lit: antialiased rows + mip 0 rows
             CHAIN_TRY(sah_copy_scene_bloom_mip0_rows(ctx, &s.lit, &s.antialiased, &s.bloom, p.aa_rows[0], p.aa_rows[1], p.mip0_rows[0], p.mip0_rows[1]));
         } else {
@@ -264,14 +286,19 @@ int sah_chain_submit(sah_chain* c, void* lighting_begin, void* lighting_end) {
         if (rows_nonempty(p.mip1_rows)) CHAIN_TRY(sah_bloom_mip_rows(ctx, &s.antialiased, &s.bloom, 1, p.mip1_rows[0], p.mip1_rows[1]));
         return SAH_OK;
     }));
-    if (c->post) HIP_TRY(ctx, hipEventRecord(s.a_done, c->work));
+    if (c->reduce != c->work || c->post != c->reduce) {  // (one rank without a communicator gathers nothing: B(i) is then ordered behind R(i) by this alone)
+        HIP_TRY(ctx, hipEventRecord(s.r_done, c->reduce));
+        s.r_valid = true;
+    }
     if (c->exchange) {
-        CHAIN_TRY(sah_allgather_rows(ctx, &s.mip1, p.mip1_rows_per_rank, p.mip1_allocated_rows));  // side stream, behind A(i)
+        CHAIN_TRY(sah_allgather_rows(ctx, &s.mip1, p.mip1_rows_per_rank, p.mip1_allocated_rows));  // side stream, behind R(i)
         HIP_TRY(ctx, hipEventRecord(s.mip_done, exchange_stream(ctx)));
         s.mip_valid = true;
     }
     c->submitted++;
-    while (c->finished + 1 < c->submitted) CHAIN_TRY(chain_finish(c, c->finished));  // B of the frame before this one (done already if a flush came in between)
+    // ---- B(i - 1) (done already if a flush came in between)
+    while (c->finished + 1 < c->submitted) CHAIN_TRY(chain_finish(c, c->finished));
+    CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
     return SAH_OK;
 }
 
@@ -281,7 +308,9 @@ int sah_chain_flush(sah_chain* c) {
     sah_ctx* ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     while (c->finished < c->submitted) CHAIN_TRY(chain_finish(c, c->finished));
+    CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
     for (FrameSet& s : c->sets) {
+        if (s.r_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.r_done, 0));
         if (s.final_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.final_done, 0));
         if (s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.b_done, 0));
     }
@@ -308,9 +337,9 @@ int sah_debug_chain_graphs(const sah_chain* c, uint64_t out[3]) {
 void sah_chain_destroy(sah_chain* c) {
     if (!c) return;
     for (FrameSet& s : c->sets) {
-        for (hipEvent_t e : {s.a_done, s.mip_done, s.final_done, s.b_done})
+        for (hipEvent_t e : {s.l_done, s.r_done, s.mip_done, s.final_done, s.b_done})
             if (e) (void)hipEventDestroy(e);
-        for (HalfGraph* g : {&s.graph_a, &s.graph_b})
+        for (HalfGraph* g : {&s.graph_l, &s.graph_r, &s.graph_b})
             if (g->exec) (void)hipGraphExecDestroy(g->exec);
     }
     delete c;

@@ -98,7 +98,7 @@ def load():
     lib.sah_ipc_register.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.sah_ipc_unregister.argtypes = [C.c_void_p, C.c_void_p]
     lib.sah_ipc_reset.argtypes = [C.c_void_p]
-    lib.sah_chain_create.argtypes = [C.c_void_p, C.POINTER(_abi.ChainPlan), C.POINTER(_abi.ChainFrame), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+    lib.sah_chain_create.argtypes = [C.c_void_p, C.POINTER(_abi.ChainPlan), C.POINTER(_abi.ChainFrame), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.POINTER(C.c_void_p)]
     lib.sah_chain_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sah_chain_flush.argtypes = [C.c_void_p]
@@ -311,10 +311,10 @@ class Context:
         self._check(self.lib.sah_allgather_bytes(self.handle, C.c_void_p(device_ptr), bytes_per_rank))
 
     # ---- the sharded frame as a loop of the library (sah_chain_*): handles are plain integers, androidrenderer_amd/chain.py wraps them
-    def chain_create(self, plan, frames, tonemap_flags, chain_flags, work_stream, post_stream):
+    def chain_create(self, plan, frames, tonemap_flags, chain_flags, work_stream, reduce_stream, post_stream):
         h = C.c_void_p()
         self._check(self.lib.sah_chain_create(self.handle, C.byref(plan), frames, tonemap_flags, chain_flags, C.c_void_p(work_stream),
-                                              C.c_void_p(post_stream) if post_stream else None, C.byref(h)))
+                                              C.c_void_p(reduce_stream) if reduce_stream else None, C.c_void_p(post_stream) if post_stream else None, C.byref(h)))
         return h
 
     def chain_submit(self, chain, begin_event=None, end_event=None):

@@ -182,6 +182,8 @@ def parse_args(argv=None):
     ap.add_argument("--rt-bounces", type=int, default=0, help="traced workload: sah_rt_set_bounces for the GI generators (the reference: 0)")
     ap.add_argument("--watchdog-s", type=float, default=300.0, help="N>1: end the rank when a phase makes no progress for this long (0: never)")
     ap.add_argument("--one-work-stream", action="store_true", help="N>1 chain: mips 1.. + tonemap of frame i on the lighting stream instead of beside the lighting of frame i+1")
+    ap.add_argument("--two-work-streams", action="store_true", help="N>1 chain: lighting and copy + mip rows share the work stream, mips 2.. + tonemap run on a second one "
+                    "(rounds 3-4's shape; default since round 5: three streams — the lighting of frame i+1 does not wait for the copy and mip rows of frame i)")
     ap.add_argument("--python-loop", action="store_true", help="two frames in flight: enqueue every pass from Python (chain.PipelinedChain) instead of through the library's own "
                     "frame loop (sah_chain_submit, chain.NativePipelinedChain: the default)")
     ap.add_argument("--exchange", choices=["rccl", "ipc"], default="rccl", help="N>1: how the library's gathers travel — ncclAllGather (default) or the direct "
@@ -526,6 +528,7 @@ def build_loop(R, force_stepwise=False):
             R.comm_stream = torch.cuda.Stream(device=dev)
     R.pipelined = pipelined
     R.pc = R.sc = None
+    R.work_streams = 1
 
     def chain_px(sc):
         return W * (sc.plan.lit_rows[1] - sc.plan.lit_rows[0] + sc.plan.lit_wrap_rows[1] - sc.plan.lit_wrap_rows[0]) if world > 1 else W * H
@@ -537,8 +540,13 @@ def build_loop(R, force_stepwise=False):
     if pipelined:
         # the whole frame, sharded, two frames in flight: both exchanges run on the side stream beside compute.  The loop itself lives in
         # the library (sah_chain_submit: chain.NativePipelinedChain); --python-loop enqueues the same order pass by pass (chain.PipelinedChain)
-        cls = chain_mod.PipelinedChain if args.python_loop else chain_mod.NativePipelinedChain
-        pc = cls(ctx, fr, d_arr, rank, world, R.comm_stream, None if args.one_work_stream else torch.cuda.Stream(device=dev), tonemap_flags=tm_flags)
+        post_stream = None if args.one_work_stream else torch.cuda.Stream(device=dev)
+        if args.python_loop:
+            pc = chain_mod.PipelinedChain(ctx, fr, d_arr, rank, world, R.comm_stream, post_stream, tonemap_flags=tm_flags)
+        else:  # lighting | copy + mip rows | mips 2.. + composite, each on a stream of its own (sah_hip.h "the row-sharded frame as a loop of this library")
+            reduce_stream = None if (args.one_work_stream or args.two_work_streams) else torch.cuda.Stream(device=dev)
+            pc = chain_mod.NativePipelinedChain(ctx, fr, d_arr, rank, world, R.comm_stream, post_stream, tonemap_flags=tm_flags, reduce_stream=reduce_stream)
+        R.work_streams = 1 if args.one_work_stream else (2 if (args.python_loop or args.two_work_streams) else 3)
         if R.use_ipc:
             pc.register_direct_exchange(R.allgather_handles)
         R.pc, R.sc = pc, pc.sets[0]
@@ -810,6 +818,28 @@ def verify(R):
         R.failure = "pre-flight: the two-frames-in-flight loop AND the one-frame-at-a-time fall-back differ from the unsharded frame"
 
 
+def time_longer_run(R):
+    """The driver times 20 steps of a 0.17 ms pass: 3.4 ms, over before a power sample sees it.  On one GPU the line therefore carries, beside the
+    driver's K steps, the same loop over at least 200 steps (GPU time between two events, after the timed region): what the K-step number is good
+    for can be read off the two."""
+    torch = R.torch
+    if not (R.world == 1 and not R.exchange and R.args.steps < 200):
+        return None
+    n = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    R.drain()
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(n):
+        R.step(i)
+    R.drain()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return {"steps": n, "ms_per_step": round(ms, 5), "value": round(R.W * R.H / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+            "note": "the same loop over 200 steps, GPU time between two events, after the timed region"}
+
+
 def time_with_rebuild(R):
     """One GPU, LPV lighting workloads under --lpv-copy propagate: the same pass with lpv_generation 0 — k_lpv_pack inside every step, what the
     frame pays when its volumes are rewritten by a pass that is not the library's.  Outside the timed region; returns the report's dict or None."""
@@ -902,6 +932,7 @@ def report(R):
             "post_chain_beside_next_frames_lighting": bool(R.pipelined and not args.one_work_stream),
             "frames_in_flight": 2 if R.pipelined else 1,
             "frame_loop": None if not R.pipelined else ("Python, pass by pass (chain.PipelinedChain)" if args.python_loop else "the library's (sah_chain_submit)"),
+            "work_streams": None if not R.pipelined else R.work_streams,
             "same_workload_on_one_gpu": R.single_gpu,
             # the N = 1 run of this file measures the headline lighting pass, a different workload from the sharded chain: the strong
             # scaling of THIS workload is its throughput here over its throughput unsharded on one of these GPUs
@@ -916,6 +947,8 @@ def report(R):
     }
     if R.with_rebuild is not None:
         out["config"]["lpv_gather_copy_rebuilt_every_step"] = R.with_rebuild
+    if R.longer_run is not None:
+        out["config"]["same_loop_over_200_steps"] = R.longer_run
     if R.failure:
         out["error"] = R.failure
         out["measured_but_invalid_Mpixels_per_s"] = round(value, 1)
@@ -948,6 +981,7 @@ def main(argv=None):
     preflight(R)
     run_timed(R)
     verify(R)
+    R.longer_run = time_longer_run(R) if R.rank == 0 and not R.failure else None
     R.with_rebuild = time_with_rebuild(R) if R.rank == 0 and not R.failure else None
     if R.rank == 0:
         report(R)

@@ -714,13 +714,19 @@ int sah_ipc_reset(sah_ctx* ctx);
 
 /* ---- the row-sharded frame as a loop of this library (no reference counterpart: north_star's "shard by screen-tile rows, all-gather the
  * final image"; the reference records one frame at a time on one queue, render_backend.cpp:135-153) ---------------------------------------
- * One rank's share of the whole chain — Lighting of its rows (LightingPhase::render), "Copy scene" + bloom mip 0 over its band
- * (scene_renderer.cpp:502-527, bloomer.cpp:50-72), its rows of bloom mip 1, [exchange of mip 1], mips 2.. (bloomer.cpp:74-262), the
- * composite of its rows (ui_phase.cpp:98-113), [exchange of the R8G8B8A8 rows, reversed rank order] — with two frames in flight, so that
- * both exchanges travel beside compute: frame i is cut at its first exchange into A(i) (up to mip 1) and B(i) (the rest);
- * sah_chain_submit enqueues A(i), the mip-1 gather, then B(i - 1) and its final gather.  Everything a frame writes exists twice
- * (`frames[2]`, used alternately).  With a post stream B(i - 1) runs there, beside A(i) on the work stream; the exchanges run on the
- * context's side stream if one is set (sah_comm_set_stream), through RCCL or the direct exchange as sah_allgather_rows would.
+ * One rank's share of the whole chain, two frames in flight, so that both exchanges travel beside compute.  A frame has three parts:
+ *     L(i)  Lighting of the rank's rows (LightingPhase::render)                                                          work stream
+ *     R(i)  "Copy scene" + bloom mip 0 over its band (scene_renderer.cpp:502-527, bloomer.cpp:50-72), its rows of mip 1   reduce stream
+ *           -> exchange of mip 1
+ *     B(i)  mips 2.. (bloomer.cpp:74-262), the composite of its rows (ui_phase.cpp:98-113)                                post stream
+ *           -> exchange of the R8G8B8A8 rows, reversed rank order
+ * sah_chain_submit enqueues L(i), R(i), the mip-1 gather, then B(i - 1) and its final gather.  Everything a frame writes exists twice
+ * (`frames[2]`, used alternately); a part starts behind the last reader (a part of frame i - 2) of what it overwrites.  The three streams
+ * may coincide (reduce_stream NULL = the work stream, post_stream NULL = the reduce stream): on one stream the order is the stream's;
+ * with a post stream B(i - 1) runs beside L(i) and R(i); with a reduce stream as well the lighting of frame i + 1 starts when that of
+ * frame i ends instead of behind its copy and mip rows — the shape that pays on a rank of eight, whose parts are each too small to fill the
+ * chip by themselves.  The exchanges run on the context's side stream if one is set (sah_comm_set_stream), through RCCL or the direct
+ * exchange as sah_allgather_rows would.
  * The row arithmetic is the caller's (androidrenderer_amd/shard.py: chain_plan; include/sah_host.hpp); this object only keeps the order
  * and the events, which is what cost the host 72 us per frame when every call crossed a language boundary.
  * All descriptors are copied (pointers into HOST memory need not outlive sah_chain_create); device memory must outlive the chain. */
@@ -739,12 +745,13 @@ typedef struct sah_chain_frame {
     sah_mipchain bloom;
     sah_plane out; /* R8G8B8A8 */
 } sah_chain_frame;
-/* work_stream: the stream of the A halves (the context is left on it after every call); post_stream: the stream of the B halves, or NULL
- * for the work stream.  tonemap_flags as for sah_tonemap_ex.  chain_flags: SAH_CHAIN_NO_EXCHANGE = both gathers are left out (one rank's
- * compute of an N-rank plan on a context of another world size: rehearsals and measurements of a rank's share on one GPU). */
+/* work_stream / reduce_stream / post_stream: see above (the context is left on the work stream after every call).  tonemap_flags as for
+ * sah_tonemap_ex.  chain_flags: SAH_CHAIN_NO_EXCHANGE = both gathers are left out (one rank's compute of an N-rank plan on a context of
+ * another world size: rehearsals and measurements of a rank's share on one GPU). */
 #define SAH_CHAIN_NO_EXCHANGE (1u << 0)
-/* SAH_CHAIN_CAPTURE: the two halves of a frame (the launches between two exchanges) are captured into HIP graphs the second time a buffer set
- * is used and replayed afterwards — one graph launch instead of three to five kernel launches per half.  A replay enqueues exactly what
+/* SAH_CHAIN_CAPTURE: the parts of a frame are captured into HIP graphs the second time a buffer set is used and replayed afterwards — one
+ * graph launch instead of one to three kernel launches per part (less host time per frame, MORE device time: a replay has a start-up of
+ * its own; measured in tools/experiments/r5/README.md — off by default).  A replay enqueues exactly what
  * the captured calls enqueued, so it is only used while nothing those calls depend on has changed (context buffers and tables, the gather
  * copies' state: the context counts such changes) — any other use of the context in between sends the chain back to direct calls and a new
  * capture — and not for a submit that asks for the Lighting pass's events.  Frame descriptors are fixed at sah_chain_create either way; what
@@ -752,7 +759,7 @@ typedef struct sah_chain_frame {
  * caller-kept change counter in a fixed descriptor could not change). */
 #define SAH_CHAIN_CAPTURE (1u << 1)
 int sah_chain_create(sah_ctx* ctx, const sah_chain_plan* plan, const sah_chain_frame frames[2], uint32_t tonemap_flags, uint32_t chain_flags,
-                     void* work_stream, void* post_stream, sah_chain** out);
+                     void* work_stream, void* reduce_stream, void* post_stream, sah_chain** out);
 /* lighting_begin / lighting_end: optional hipEvent_t recorded on the work stream around the frame's sah_lighting calls (NULL: none) */
 int sah_chain_submit(sah_chain* chain, void* lighting_begin, void* lighting_end);
 /* Completes every submitted frame; the work stream then waits for the last gathers and B halves. */

@@ -204,7 +204,7 @@ def main():
             frames[k].lit, frames[k].antialiased, frames[k].out = f.plane(rgba16, s), f.plane(rgba16, s), f.plane(_abi.FORMAT_R8G8B8A8_SRGB, s)
             frames[k].bloom = f.mipchain(s)
         out = C.c_void_p()
-        rc = L.sah_chain_create(ctx(), opt(plan), frames if f.g.random() < 0.9 else None, f.u32(), f.u32(), None, None, C.byref(out) if f.g.random() < 0.95 else None)
+        rc = L.sah_chain_create(ctx(), opt(plan), frames if f.g.random() < 0.9 else None, f.u32(), f.u32(), None, None, None, C.byref(out) if f.g.random() < 0.95 else None)
         if rc == 0 and out.value:  # (cannot happen without a device; kept honest anyway)
             L.sah_chain_destroy(out)
         return rc

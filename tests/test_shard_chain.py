@@ -238,13 +238,14 @@ def test_hip_chain_through_a_one_rank_communicator():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native", [False, True, "graphs"], ids=["python-loop", "library-loop", "library-loop-graphs"])
+@pytest.mark.parametrize("native", [False, True, "graphs", "three-streams", "three-streams-graphs"],
+                         ids=["python-loop", "library-loop", "library-loop-graphs", "library-loop-3-streams", "library-loop-3-streams-graphs"])
 @pytest.mark.parametrize("no_split,two_streams", [(False, False), (True, False), (False, True), (True, True), (None, True), (None, False)])
 def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_streams, native):
     """Two frames in flight (chain.PipelinedChain: both exchanges on the side stream of a one-rank communicator), a different AO plane
     per frame, warm-up / flush / more frames as bench.py drives it: every frame's final image equals the unpipelined chain's.
     `two_streams`: the B halves (mips 1.., tonemap, final exchange) on a second work stream beside the next frame's lighting.
-    `native`: the same loop inside the library (sah_chain_create / _submit / _flush through chain.NativePipelinedChain); "graphs": with its
+    `native`: the same loop inside the library ("three-streams": lighting, copy + mip rows and mips 2.. + composite each on a stream of its own) (sah_chain_create / _submit / _flush through chain.NativePipelinedChain); "graphs": with its
     halves captured into HIP graphs and replayed (SAH_CHAIN_CAPTURE) — the AO plane still changes every frame, the descriptors do not."""
     import torch
     from androidrenderer_amd import chain, lib
@@ -254,7 +255,7 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
     # (no_split None: no communicator at all — bench.py --frames-in-flight 2 on one GPU; the exchanges are no-ops)
     ctx = lib.Context(device=0, rank=0, world=1, comm_id=None if no_split is None else lib.comm_unique_id())
     previous_stream = torch.cuda.current_stream()
-    if native == "graphs":
+    if native in ("graphs", "three-streams-graphs"):
         torch.cuda.set_stream(torch.cuda.Stream())  # a work stream of its own: the null stream cannot be captured
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     side = torch.cuda.Stream()
@@ -272,7 +273,9 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
             want.append(plain.out.cpu().numpy().copy())
         assert not np.array_equal(want[0], want[1])
         if native:
-            pc = chain.NativePipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None, capture=native == "graphs")
+            three = isinstance(native, str) and native.startswith("three-streams")
+            pc = chain.NativePipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if (two_streams or three) else None, capture=isinstance(native, str) and native.endswith("graphs"),
+                                            reduce_stream=torch.cuda.Stream() if three else None)
         else:
             pc = chain.PipelinedChain(ctx, f, dev, 0, 1, side, torch.cuda.Stream() if two_streams else None)
         got = {}
@@ -292,7 +295,7 @@ def test_hip_pipelined_chain_keeps_its_frames_apart(monkeypatch, no_split, two_s
         for i, img in sorted(got.items()):
             assert np.array_equal(img, want[i]), f"frame {i}"
         assert pc.submitted == 7 and (native or pc.finished == 7)
-        if native == "graphs":  # seven frames over two buffer sets: each half direct once, captured once, replayed afterwards
+        if isinstance(native, str) and native.endswith("graphs"):  # seven frames over two buffer sets: each part direct once, captured once, replayed afterwards
             replays, captures, failed = pc.graphs()
             assert not failed and captures >= 4 and replays >= 4, (replays, captures, failed)
         if native:

@@ -76,8 +76,41 @@ def two_streams():
     ctx.set_stream(s1.cuda_stream)
 
 
-def library_loop(second, capture=False):
-    pc = chain.NativePipelinedChain(ctx, fr, dev, rank, world, None, second, tonemap_flags=tm, exchange=False, capture=capture)
+s3 = torch.cuda.Stream()
+
+
+def three_streams():
+    """lighting | copy + mip 0 + mip 1 | mips 2-5 + composite, each on a stream of its own: the lighting of frame i + 1 starts when that of frame i
+    ends (not behind its copy and mip rows), ordered by events against the last readers of the buffer set it overwrites"""
+    l_done, r_done, c_done = [None, None], [None, None], [None, None]
+    for i in range(N + 2):
+        if i < N:
+            k = i % 2
+            ctx.set_stream(s1.cuda_stream)
+            if r_done[k] is not None:
+                s1.wait_event(r_done[k])  # `lit` of this set was last read by the copy of frame i - 2
+            maintain()
+            sets[k].lighting()
+            l_done[k] = s1.record_event()
+            ctx.set_stream(s2.cuda_stream)
+            s2.wait_event(l_done[k])
+            if c_done[k] is not None:
+                s2.wait_event(c_done[k])  # antialiased / mip 0 / mip 1 of this set were last read by the composite of frame i - 2
+            with torch.cuda.stream(s2):
+                sets[k].reduce()
+            r_done[k] = s2.record_event()
+        if 1 <= i <= N:
+            j = (i - 1) % 2
+            ctx.set_stream(s3.cuda_stream)
+            s3.wait_event(r_done[j])
+            with torch.cuda.stream(s3):
+                sets[j].composite()
+            c_done[j] = s3.record_event()
+    ctx.set_stream(s1.cuda_stream)
+
+
+def library_loop(second, capture=False, reduce=None):
+    pc = chain.NativePipelinedChain(ctx, fr, dev, rank, world, None, second, tonemap_flags=tm, exchange=False, capture=capture, reduce_stream=reduce)
 
     def run():
         for _ in range(N):
@@ -88,8 +121,10 @@ def library_loop(second, capture=False):
 
 
 lib_one, lib_two, graph_one, graph_two = library_loop(None), library_loop(s2), library_loop(None, True), library_loop(s2, True)
-for name, fn in (("python, one stream", one_stream), ("python, two streams", two_streams), ("library loop, one stream", lib_one), ("library loop, two streams", lib_two),
-                 ("library loop + graphs, one", graph_one), ("library loop + graphs, two", graph_two)) * 2:
+lib_three, graph_three = library_loop(s3, False, s2), library_loop(s3, True, s2)
+for name, fn in (("python, one stream", one_stream), ("python, two streams", two_streams), ("python, three streams", three_streams), ("library loop, one stream", lib_one), ("library loop, two streams", lib_two),
+                 ("library loop, three streams", lib_three), ("library loop + graphs, one", graph_one), ("library loop + graphs, two", graph_two),
+                 ("library loop + graphs, three", graph_three)) * 2:
     fn()
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -97,4 +132,4 @@ for name, fn in (("python, one stream", one_stream), ("python, two streams", two
     host = (time.perf_counter() - t) / N
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / N
-    print(f"world {world} rank {rank}: {name:26s} {dt * 1e3:.4f} ms per frame (host enqueue {host * 1e3:.4f} ms)", flush=True)
+    print(f"world {world} rank {rank}: {name:28s} {dt * 1e3:.4f} ms per frame (host enqueue {host * 1e3:.4f} ms)", flush=True)

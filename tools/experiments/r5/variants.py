@@ -123,6 +123,27 @@ VARIANTS["both_xcd"] = (["lighting.hip", "lighting_tiled.hip"], VARIANTS["fast_x
 # the tolerance composite on a row band: 32-row tiles whatever the band's height (the product picks 16-row tiles when 32-row ones would not
 # fill the chip's 768 slots twice)
 VARIANTS["tm_band32"] = (["tonemap_tol.hip"], [("tonemap_tol.hip", "    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL", "    if (true) hipLaunchKernelGGL")])
+# Timing-only probe of the composite's occupancy (its images are wrong on purpose): what would a fourth workgroup per CU buy the 32-row shape?
+# G in three planes (the third read from the second), staged texels as 8-byte fp16 cells converted at the read, __launch_bounds__(256, 4):
+# 38.9 KB of LDS and at most 128 VGPRs.  If this does not move the time, the real restructuring (derive G2 = G1 + G3 at the read, fp16 cells)
+# is not worth writing.
+VARIANTS["tm_occ4"] = (["tonemap_tol.hip"], [
+    ("tonemap_tol.hip", "    static constexpr int kMaxRows = 21, kWaves = 3;", "    static constexpr int kMaxRows = 21, kWaves = 4;"),
+    ("tonemap_tol.hip", "    __shared__ __attribute__((aligned(16))) float4 s_src[kMaxRows * kPitch];", "    __shared__ __attribute__((aligned(16))) uint2 s_src[kMaxRows * kPitch];"),
+    ("tonemap_tol.hip", "    __shared__ __attribute__((aligned(16))) float s_g[4 * kPlane];", "    __shared__ __attribute__((aligned(16))) float s_g[3 * kPlane];"),
+    ("tonemap_tol.hip", "                s_src[rr * kPitch + tx] = make_float4(h2f((uint16_t)(staged[j].x & 0xffffu)), h2f((uint16_t)(staged[j].x >> 16)),\n"
+                        "                                                       h2f((uint16_t)(staged[j].y & 0xffffu)), 0.f);",
+     "                s_src[rr * kPitch + tx] = staged[j];"),
+    ("tonemap_tol.hip", "                const float4* srow = s_src + r * kPitch;", "                const uint2* srow = s_src + r * kPitch;"),
+    ("tonemap_tol.hip", "                        tp[k] = lds_read16(srow + xa[c][k].o);\n                        tq[k] = lds_read16(srow + xa[c][k].o + 1);",
+     "                        { const float2 a_ = lds_read8(reinterpret_cast<const float*>(srow + xa[c][k].o)); const uint32_t ax_ = __builtin_bit_cast(uint32_t, a_.x), ay_ = __builtin_bit_cast(uint32_t, a_.y);\n"
+     "                          tp[k] = make_float4(h2f((uint16_t)(ax_ & 0xffffu)), h2f((uint16_t)(ax_ >> 16)), h2f((uint16_t)(ay_ & 0xffffu)), 0.f);\n"
+     "                          const float2 b_ = lds_read8(reinterpret_cast<const float*>(srow + xa[c][k].o + 1)); const uint32_t bx_ = __builtin_bit_cast(uint32_t, b_.x), by_ = __builtin_bit_cast(uint32_t, b_.y);\n"
+     "                          tq[k] = make_float4(h2f((uint16_t)(bx_ & 0xffffu)), h2f((uint16_t)(bx_ >> 16)), h2f((uint16_t)(by_ & 0xffffu)), 0.f); }"),
+    ("tonemap_tol.hip", "                for (int p = 0; p < 4; p++) {\n                    float2* d2 = reinterpret_cast<float2*>(dst + p * kPlane);  // 24-byte stride: 8-byte aligned",
+     "                for (int p = 0; p < 4; p++) {\n                    if (p == 2) continue;\n                    float2* d2 = reinterpret_cast<float2*>(dst + (p == 3 ? 2 : p) * kPlane);  // 24-byte stride: 8-byte aligned"),
+    ("tonemap_tol.hip", "                        const float* g0 = s_g + yv * kPlane + ey[a][yv].o + 6 * (int)cp;", "                        const float* g0 = s_g + (yv == 3 ? 2 : (yv == 2 ? 1 : yv)) * kPlane + ey[a][yv].o + 6 * (int)cp;"),
+])
 for _k, _v in list(VARIANTS.items()):  # (the patch texts above are written with escaped newlines for readability)
     VARIANTS[_k] = (_v[0], [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n")) for f, o, n in _v[1]])
 
