@@ -1254,4 +1254,77 @@ inline void evaluate_antialiasing_none(RenderGraph& graph, TextureHandle lit_sce
                     }));
 }
 
+// ---- the row-sharded frame (no reference counterpart: north_star's "frames shard by screen-tile rows across the 8 GPUs") ------------------
+// Which rows a rank shades, copies, reduces and composites so that the two exchanges of sah_chain_submit — the quarter-resolution bloom
+// mip 1, the final R8G8B8A8 image — reassemble exactly what one GPU computes.  Dependencies, in rows (include/sah_hip.h; the same integer
+// arithmetic as androidrenderer_amd/shard.py: chain_plan, and tests/test_shard_chain.py holds the two against each other):
+//   final image row y     samples the scene upside down (scene_upsample.frag, fullscreen.vert: v = 1 - (y + 0.5) / H): antialiased rows
+//                         H - 1 - y +- 1, bloom mip 0 rows within 3 of (1 - (y + 0.5) / H) * H0 - 0.5, every smaller mip (global);
+//   antialiased row j     "Copy scene": lit rows j - 1 .. j + 1, and its sampler REPEATS (row 0 taps row H - 1 and the other way round);
+//   bloom mip m row j     the rows of its source that sah_bloom_source_rows names.
+// Rank r owns mip 1 rows [r q, (r + 1) q) and the final rows of slot N - 1 - r (the vertical flip: those are the rows whose scene rows it has).
+struct ShardPlan {
+    sah_chain_plan chain{};          // what sah_chain_create takes (allocations: mip1_rows_per_rank * world and rows_per_rank * world rows)
+    uint32_t lit_rows[2]{};          // rows this rank's sah_lighting shades (sah_lighting_desc::row_begin / row_end) ...
+    uint32_t lit_wrap_rows[2]{};     // ... plus the row on the opposite edge that the REPEAT sampler taps ((0, 0): none): a second sah_lighting call
+    uint32_t mip0_height = 0, mip1_height = 0;
+};
+inline ShardPlan shard_chain_plan(uint32_t height, uint32_t world, uint32_t rank) {
+    auto clip = [](int64_t a, int64_t b, int64_t n, uint32_t out[2]) {
+        a = std::max<int64_t>(0, std::min(a, n));
+        b = std::max<int64_t>(0, std::min(b, n));
+        out[0] = (uint32_t)a;
+        out[1] = (uint32_t)std::max(a, b);
+    };
+    auto floordiv = [](int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    auto hull = [](bool& any, int64_t& lo, int64_t& hi, int64_t a, int64_t b) {
+        if (b <= a) return;
+        lo = any ? std::min(lo, a) : a;
+        hi = any ? std::max(hi, b) : b;
+        any = true;
+    };
+    ShardPlan p;
+    const int64_t H = height, N = world, per = (H + N - 1) / N;
+    const int64_t h0 = std::max<int64_t>(1, H / 2), h1 = std::max<int64_t>(1, h0 / 2), q = (h1 + N - 1) / N, slot = N - 1 - (int64_t)rank;
+    p.mip0_height = (uint32_t)h0;
+    p.mip1_height = (uint32_t)h1;
+    p.chain.rows_per_rank = (uint32_t)per;
+    p.chain.out_allocated_rows = (uint32_t)(per * N);
+    p.chain.mip1_rows_per_rank = (uint32_t)q;
+    p.chain.mip1_allocated_rows = (uint32_t)(q * N);
+    clip(slot * per, (slot + 1) * per, H, p.chain.out_rows);
+    clip((int64_t)rank * q, ((int64_t)rank + 1) * q, h1, p.chain.mip1_rows);
+    bool any0 = false, any_aa = false;
+    int64_t lo0 = 0, hi0 = 0, lo_aa = 0, hi_aa = 0;
+    const uint32_t* out = p.chain.out_rows;
+    if (out[1] > out[0]) {
+        hull(any_aa, lo_aa, hi_aa, H - out[1] - 1, H - out[0] + 1);
+        const int64_t slack = (H == 2 * h0) ? 0 : 1;
+        const int64_t p_lo = floordiv((2 * (H - ((int64_t)out[1] - 1)) - 1) * h0 - H, 2 * H), p_hi = floordiv((2 * (H - (int64_t)out[0]) - 1) * h0 - H, 2 * H);
+        hull(any0, lo0, hi0, p_lo - 1 - slack, p_hi + 2 + slack + 1);
+    }
+    if (p.chain.mip1_rows[1] > p.chain.mip1_rows[0]) {
+        // (the unclipped window: the plan takes the hull of its needs before it clips; sah_bloom_source_rows returns the clipped one)
+        const int64_t j0 = p.chain.mip1_rows[0], j1 = p.chain.mip1_rows[1], s1 = (h0 == 2 * h1) ? 0 : 1;
+        hull(any0, lo0, hi0, floordiv((2 * j0 + 1) * h0 - h1 - 4 * h1, 2 * h1) - s1, floordiv((2 * (j1 - 1) + 1) * h0 - h1 + 4 * h1, 2 * h1) + 1 + s1 + 1);
+    }
+    if (any0) clip(lo0, hi0, h0, p.chain.mip0_rows);
+    if (p.chain.mip0_rows[1] > p.chain.mip0_rows[0]) {
+        const int64_t j0 = p.chain.mip0_rows[0], j1 = p.chain.mip0_rows[1], s0 = (H == 2 * h0) ? 0 : 1;
+        hull(any_aa, lo_aa, hi_aa, floordiv((2 * j0 + 1) * H - h0 - 4 * h0, 2 * h0) - s0, floordiv((2 * (j1 - 1) + 1) * H - h0 + 4 * h0, 2 * h0) + 1 + s0 + 1);
+    }
+    if (any_aa) {
+        clip(lo_aa, hi_aa, H, p.chain.aa_rows);
+        clip((int64_t)p.chain.aa_rows[0] - 1, (int64_t)p.chain.aa_rows[1] + 1, H, p.lit_rows);
+        if (p.chain.aa_rows[0] == 0 && p.lit_rows[1] < height) {
+            p.lit_wrap_rows[0] = height - 1;
+            p.lit_wrap_rows[1] = height;
+        } else if (p.chain.aa_rows[1] == height && p.lit_rows[0] > 0) {
+            p.lit_wrap_rows[0] = 0;
+            p.lit_wrap_rows[1] = 1;
+        }
+    }
+    return p;
+}
+
 }  // namespace sah

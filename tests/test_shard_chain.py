@@ -323,3 +323,23 @@ def test_library_source_row_rule_is_the_plans():
                 assert (out[0], out[1]) == shard._clip(lo, hi, hs), (hs, hd, j0, j1)
     assert L.sah_bloom_source_rows(10, 5, 3, 3, out) == 0 and (out[0], out[1]) == (0, 0)  # an empty band reads nothing
     assert L.sah_bloom_source_rows(10, 5, 4, 3, out) != 0 and L.sah_bloom_source_rows(10, 5, 0, 6, out) != 0 and L.sah_bloom_source_rows(0, 5, 0, 1, out) != 0
+
+
+def test_cpp_facade_plan_is_the_python_plan(tmp_path):
+    """include/sah_host.hpp: sah::shard_chain_plan — what a C++ host hands to sah_chain_create — restates shard.chain_plan; every field of every
+    rank's plan must agree, on 4K and 8K and on the odd heights whose mips are not exactly half as high (tests/cpp/shard_plan.cpp, CPU only)."""
+    import subprocess
+    from androidrenderer_amd import shard
+    exe = str(tmp_path / "shard_plan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "shard_plan.cpp"), "-o", exe])
+    cases = [(2160, 8), (2160, 4), (2160, 2), (2160, 1), (4320, 8), (1080, 6), (720, 16), (97, 2), (150, 3), (37, 3), (149, 4), (75, 8), (9, 4), (5, 7), (2, 2), (1, 3)]
+    out = subprocess.check_output([exe] + [str(v) for c in cases for v in c], text=True)
+    lines = iter(out.strip().splitlines())
+    for height, world in cases:
+        for r in range(world):
+            got = [int(v) for v in next(lines).split()]
+            p = shard.chain_plan(height, world, r)
+            want = [height, world, r, *p.out_rows, *p.mip1_rows, *p.mip0_rows, *p.aa_rows, *p.lit_rows, *p.lit_wrap_rows, p.rows_per_rank, p.mip1_rows_per_rank,
+                    p.rows_per_rank * world, p.mip1_rows_per_rank * world, p.mip0_height, p.mip1_height]
+            assert got == want, (height, world, r, got, want)

@@ -42,6 +42,6 @@ print("copied; workloads:", list(old))
 X = "gpurun_out/refresh_extras"
 for src, dst in (("pmc_rt.txt", "pmc_rt_kernels.txt"), ("ktrace_traced/kt_kernel_stats.csv", "kernel_stats_4k_probe_gi_chain_traced.csv"),
                  ("stress_rt.txt", "stress_rt.txt"), ("stress_parity.txt", "stress_parity.txt"), ("stress_post.txt", "stress_post.txt"),
-                 ("stress_raster.txt", "stress_raster.txt")):
+                 ("stress_raster.txt", "stress_raster.txt"), ("segv_fixed.txt", "segv_fixed.txt")):
     if os.path.exists(f"{X}/{src}"):
         shutil.copy(f"{X}/{src}", f"{DST}/{R}_{dst}")

@@ -11,9 +11,5 @@ for cfg in "SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE|4320|7680
   rm -rf gpurun_out/r4_segv_h2d$i
   i=$((i+1))
 done
-# and the real thing once more, for the record of how often it faults: the bench's own synthesis, 4 counters, three times
-for k in 1 2 3; do
-  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d gpurun_out/r4_segv_again -o pmc --output-format csv -- python3 tools/experiments/r4/segv/segv_probe.py gpurun_out/r4_segv_again_report$k.txt --workload 8k_deferred_gi --no-cpu-baseline --steps 2 --warmup 1 --ramp-ms 0 > gpurun_out/r4_segv_again$k.log 2>&1
-  echo "bench 8k_deferred_gi, GPU synthesis, 4 counters, run $k: rc=$? $(grep -a -m1 'fault address' gpurun_out/r4_segv_again_report$k.txt 2>/dev/null | cut -c1-120) $(grep -a -m1 -o 'gpu_kernel_impl[^(]*<[^>]*>' gpurun_out/r4_segv_again_report$k.txt 2>/dev/null | head -1 | cut -c1-120)"
-  rm -rf gpurun_out/r4_segv_again
-done
+# (round 5: the loop that re-ran the faulting command three times 'for the record of how often it faults' is gone — the cause is known:
+#  profiles/README.md "8K under --pmc"; tools/experiments/r4/r4_segv_fixed.sh runs the fixed command once)

@@ -144,6 +144,14 @@ VARIANTS["tm_occ4"] = (["tonemap_tol.hip"], [
      "                for (int p = 0; p < 4; p++) {\n                    if (p == 2) continue;\n                    float2* d2 = reinterpret_cast<float2*>(dst + (p == 3 ? 2 : p) * kPlane);  // 24-byte stride: 8-byte aligned"),
     ("tonemap_tol.hip", "                        const float* g0 = s_g + yv * kPlane + ey[a][yv].o + 6 * (int)cp;", "                        const float* g0 = s_g + (yv == 3 ? 2 : (yv == 2 ? 1 : yv)) * kPlane + ey[a][yv].o + 6 * (int)cp;"),
 ])
+# Timing-only upper bound of the "wave-uniform probe cell" idea: every lane takes lane 0's probe cell, so the cell's
+# indices, validity bytes, atlas origins and layers become scalar work (images wrong wherever a wave straddles a cell).  What this build
+# gains over the product is the most a two-path kernel could gain on waves that really share their cell.
+VARIANTS["tiled_uniform_cell"] = (["lighting_tiled.hip"], [
+    ("lighting_gi_ext.hpp", "        const Fn mp = Fn(__builtin_floorf(psa[k].v));\n        const Fn alpha = nclamp(psa[k] - mp, Fn(0.f), Fn(1.f));",
+     "        const Fn mp = Fn(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_floorf(psa[k].v)))));\n"
+     "        const Fn alpha = nclamp(psa[k] - mp, Fn(0.f), Fn(1.f));"),
+])
 for _k, _v in list(VARIANTS.items()):  # (the patch texts above are written with escaped newlines for readability)
     VARIANTS[_k] = (_v[0], [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n")) for f, o, n in _v[1]])
 

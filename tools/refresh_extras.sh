@@ -15,3 +15,5 @@ timeout -k 10 400 python3 tools/stress_rt.py --cases 40 > $O/stress_rt.txt 2>&1 
 timeout -k 10 400 python3 tools/stress_parity.py --seeds 12 > $O/stress_parity.txt 2>&1 && echo "stress parity ok"
 timeout -k 10 400 python3 tools/stress_post.py > $O/stress_post.txt 2>&1 && echo "stress post ok"
 timeout -k 10 400 python3 tools/stress_raster.py > $O/stress_raster.txt 2>&1 && echo "stress raster ok"
+# the 8K command that used to die under --pmc (light_stats' 16,384 outstanding dispatches), once, after the fix: its one result line
+bash tools/experiments/r4/r4_segv_fixed.sh > $O/segv_fixed.txt 2>&1 && echo "segv fixed: $(cat $O/segv_fixed.txt)"
