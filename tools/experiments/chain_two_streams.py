@@ -1,7 +1,7 @@
 """One rank's compute of the sharded chain at N ranks, emulated on one GPU without exchanges: one stream against two streams
 (A(i+1) = lighting + copy + mip-0 and mip-1 rows beside B(i) = mips 2-5 + tonemap rows), enqueued call by call from Python against the
 library's own loop (sah_chain_submit, round 5).
-usage: chain_two_streams.py [world] [rank] [--strict-tonemap] [--rebuild-copies] [--no-probe-updates]
+usage: chain_two_streams.py [world] [rank] [--strict-tonemap] [--rebuild-copies] [--no-probe-updates] [--priorities]
   the tonemap runs in tolerance mode, as bench.py's chain workloads do, unless --strict-tonemap is given;
   the context tracks its fp32 copy of the irradiance atlas (sah_gi::probe_generation = SAH_GENERATION_TRACKED) and every frame re-widens
   the blocks of 1024 probes — the reference's r.GI.Cache.UpdatesPerFrame — through sah_probe_notify_updated, unless --no-probe-updates;
@@ -27,7 +27,8 @@ fr = frame.LightingInputs(W, H, seed=2, sun_mode=_abi.SHADOW_MODE_RT, gi=_abi.GI
 fr.probe_generation = 0 if rebuild else _abi.GENERATION_TRACKED
 dev = fr.device_arrays("cuda")
 ctx = lib.Context(0)
-torch.cuda.set_stream(torch.cuda.Stream())  # a work stream of its own: the null stream cannot be captured into a graph
+prio = "--priorities" in sys.argv  # the lighting stream above the two others (hipStreamCreateWithPriority through torch)
+torch.cuda.set_stream(torch.cuda.Stream(priority=-1) if prio else torch.cuda.Stream())  # a work stream of its own: the null stream cannot be captured into a graph
 s1 = torch.cuda.current_stream()
 s2 = torch.cuda.Stream()
 ctx.set_stream(s1.cuda_stream)

@@ -152,6 +152,15 @@ VARIANTS["tiled_uniform_cell"] = (["lighting_tiled.hip"], [
      "        const Fn mp = Fn(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_floorf(psa[k].v)))));\n"
      "        const Fn alpha = nclamp(psa[k] - mp, Fn(0.f), Fn(1.f));"),
 ])
+# Beside the lighting of the next frame (three work streams) the band composite is not on the critical path, but its latency-bound waves
+# hold registers the VALU-bound lighting waves could use: what if it may keep only two (one) workgroups per CU resident?  LDS padding, same images.
+for _n, _pad in (("tm_band_2wg", 10000), ("tm_band_1wg", 24000)):
+    VARIANTS[_n] = (["tonemap_tol.hip"], [
+        ("tonemap_tol.hip", "    __shared__ int s_bad[2][kStageMips];  // the mip cannot be staged: strict evaluation from global memory",
+         "    __shared__ int s_bad[2][kStageMips];  // the mip cannot be staged: strict evaluation from global memory\n"
+         "    __shared__ float s_pad_[kTileH == 16 ? %d : 1];\n    if (t.out_w == 0xffffffffu) s_pad_[threadIdx.x & 0] = 1.f;" % _pad),
+        ("tonemap_tol.hip", "    const float4* code_tab = reinterpret_cast<const float4*>(t.code_table);", "    const float4* code_tab = reinterpret_cast<const float4*>(t.code_table);\n    if (t.out_w == 0xfffffffeu) bloom[0][0].r += s_pad_[0];"),
+    ])
 for _k, _v in list(VARIANTS.items()):  # (the patch texts above are written with escaped newlines for readability)
     VARIANTS[_k] = (_v[0], [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n")) for f, o, n in _v[1]])
 
