@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_lpv_pack(const VolumeArg r, const Volum
         dst[1] = t[1];
         dst[2] = t[2];
     }
-    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicMax(&state->nonfinite, 1u);
+    if (wave_any(bad != 0) && (threadIdx.x & 63) == 0) atomicMax(&state->nonfinite, 1u);
 }
 
 // per-column numerator of the view-space x (inverse_projection separable: vs.x = p0 * ndc.x + p12), with the two texcoord conventions:
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
         uint32_t any_e = 0;
 #pragma unroll
         for (int i = 0; i < PPT; i++) any_e |= we[i];
-        emissive_wave = __any(active && (any_e & 0xffffffu) != 0u);
+        emissive_wave = wave_any(active && (any_e & 0xffffffu) != 0u);
     }
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
     const uint32_t seg = gid >> 6, lane = threadIdx.x & 63u;
     uint32_t front = 0;
     const uint32_t listed = SKY ? deferred_mask & ~sky_mask : deferred_mask;
-    if (__any(listed != 0u)) {  // (a wave of a coherent frame lists nothing: one vote instead of PPT ballots)
+    if (wave_any(listed != 0u)) {  // (a wave of a coherent frame lists nothing: one vote instead of PPT ballots)
         uint8_t* seg_codes = f.seg_list + (size_t)seg * f.seg_stride;
 #pragma unroll
         for (int i = 0; i < PPT; i++) {

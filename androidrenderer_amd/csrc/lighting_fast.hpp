@@ -79,10 +79,11 @@ SAH_DEV FastGeom fast_geometry(const LightingArgs& a, const FastArgs& f, float c
 // colour) * shadow is exactly 0 (or NaN, which the shader's guard turns into 0) whenever ndotl == 0 or shadow == 0, so both the PCF
 // lookup and the BRDF are skipped when no lane of the wave needs them (wave-uniform votes: no divergent branches).
 SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float* tab, const F3& N, const F3& ws, const Fn vsz, const F3& V, const F3& L,
-                          const Surface<Fn>& s, const SurfIn& si, bool sky_px, bool& ok, Fn (&sc)[3]) {
+                          const Surface<Fn>& s, const SurfIn& si, lanemask act, bool& ok, Fn (&sc)[3]) {
     const Fn ndotl_sun = nclamp(dot(N, L), Fn(0.f), Fn(1.f));
     sc[0] = sc[1] = sc[2] = Fn(0.f);
-    if (__any(ok && !sky_px && ndotl_sun.v > 0.f)) {
+    const lanemask lit_m = lanes(ndotl_sun.v > 0.f) & act;  // (`act`: the lanes whose sun term is used — surface pixels inside the hot form's domain)
+    if (lit_m) {
         uint32_t cascade = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) cascade = (vsz.v < csm.splits[i]) ? i + 1u : cascade;
@@ -133,7 +134,7 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
         float shadow = sp_inside ? pcf : 1.0f;
         shadow = cascade > 3u ? 0.0f : shadow;
         shadow = ndotl_sun.v > 0.f ? shadow : 1.0f;
-        if (__any(ok && !sky_px && ndotl_sun.v > 0.f && shadow != 0.0f)) {
+        if (lit_m & lanes(shadow != 0.0f)) {
             bool brdf_out_of_domain;
             const F3 b = brdf_fast(s, L, V, brdf_out_of_domain);
             const F3 direct = ndotl_sun * b * F3{Fn(a.sun_color[0]), Fn(a.sun_color[1]), Fn(a.sun_color[2])} * Fn(shadow);
@@ -181,6 +182,9 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     s.normal = N;
     s.roughness = Fn(si.rough);
     s.metalness = Fn(si.metal);
+    // lanes whose surface terms are used: the votes below are scalar algebra on this mask and the masks of single compares (numerics.hpp,
+    // lanes()).  `ok` only shrinks from here on, so a vote on this mask never skips what a pixel needs.
+    const lanemask act = lanes(ok && !sky_px);
 
     const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
     // LPV: cascade selection and the gather coordinate
@@ -191,6 +195,7 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         // Cascade 0 is tested first: when every lane of the wave is inside it (coherent near-field pixels) the other
         // cascades cannot change the answer and are skipped.  Scale / translate rows come from the LDS table (uniform
         // addresses: broadcast reads) so that they do not occupy SGPRs.
+        lanemask out_m = 0;  // lanes outside the box last tested
         auto inside = [&](uint32_t i) {
             const float4 cs_ = *reinterpret_cast<const float4*>(tab + TAB_LPV + i * 8u);
             const float4 ct_ = *reinterpret_cast<const float4*>(tab + TAB_LPV + i * 8u + 4u);
@@ -201,11 +206,12 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
             // finite for every pixel that is not deferred (finite ws, |scale|, |translate| <= 2^40: host check), so the
             // NaN-dropping behaviour of v_min3 / v_max3 cannot matter
             const float mn = __builtin_fminf(__builtin_fminf(cx.v, cy.v), cz.v), mxv = __builtin_fmaxf(__builtin_fmaxf(cx.v, cy.v), cz.v);
+            out_m = lanes(!(mn > 0.f)) | lanes(!(mxv < 1.f));
             return mn > 0.f && mxv < 1.f;
         };
         uint32_t selected = 0;
         const bool in0 = inside(0u);
-        if (!__all(in0 || !ok || sky_px)) {
+        if (out_m & act) {
 #pragma unroll
             for (int i = 3; i >= 1; i--) {
                 if (i < (int)lpv.num_cascades) selected = inside((uint32_t)i) ? (uint32_t)i : selected;
@@ -234,7 +240,7 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
     // The votes are wave-uniform: the body stays free of divergent branches.
     if constexpr (SUN == SAH_SHADOW_MODE_CSM) {
         Fn sc[3];
-        fast_csm_sun(a, csm, tab, N, ws, vsz, V, L, s, si, sky_px, ok, sc);
+        fast_csm_sun(a, csm, tab, N, ws, vsz, V, L, s, si, act, ok, sc);
         const bool quirk = (a.flags & SAH_LIGHTING_QUIRK_SUN_BLEND) != 0;
         // quirk: dst is the cleared target, s*s + 0*0 == s*s, alpha 1*0 + 0*0 == 0; otherwise plain additive
         float x1[3];

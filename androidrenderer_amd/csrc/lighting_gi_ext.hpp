@@ -477,7 +477,7 @@ SAH_DEV void gi_cache_frag(const LightingArgs& a, const CacheArgs& c, const Slan
     };
     uint32_t cascade_index = 0;
     const bool in0 = inside(0u);
-    if (!__all(in0)) {
+    if (!wave_all(in0)) {
         cascade_index = 5;
 #pragma unroll
         for (int i = 3; i >= 1; i--) cascade_index = inside((uint32_t)i) ? (uint32_t)i : cascade_index;
@@ -567,6 +567,23 @@ SAH_DEV void gi_rtgi_frag(const LightingArgs& a, const RtgiArgs& r, uint32_t x, 
 struct PointLightDev {
     float px, py, pz, radius, cr, cg, cb, intensity;
 };
+// The light as the kernel loads it (wave-uniform: eight scalar registers): the bit patterns beside the values, so that the
+// preconditions of the hot form are integer compares of scalars — they run on the scalar unit, where float compares were six VALU
+// instructions per light and wave.  (Tests written on a bit_cast of the FLOAT are recognised by the compiler and turned back into
+// v_cmp_class_f32; a word that was loaded as an integer is not.)
+struct PointLightWords {
+    uint32_t w[8];
+};
+SAH_DEV PointLightDev point_light_values(const PointLightWords& b) {
+    auto f = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    return {f(b.w[0]), f(b.w[1]), f(b.w[2]), f(b.w[3]), f(b.w[4]), f(b.w[5]), f(b.w[6]), f(b.w[7])};
+}
+SAH_DEV bool point_light_hot_ok(const PointLightWords& b) {
+    auto bits = [](float f) { return __builtin_bit_cast(uint32_t, f); };
+    auto finite = [&](uint32_t u) { return (~u & 0x7f800000u) != 0u; };
+    // kDivLo <= radius <= kDivHi: unsigned distance from the lower bound (negative, NaN and infinite patterns wrap past the upper one)
+    return b.w[3] - bits(kDivLo) <= bits(kDivHi) - bits(kDivLo) && finite(b.w[4]) && finite(b.w[5]) && finite(b.w[6]) && finite(b.w[7]);
+}
 SAH_DEV F3 point_light_contribution(const Surface<Fn>& s, F3 ws, F3 V, const PointLightDev& pl) {
     const F3 lv = F3{Fn(pl.px), Fn(pl.py), Fn(pl.pz)} - ws;
     const Fn d2 = dot(lv, lv);
@@ -584,25 +601,28 @@ SAH_DEV F3 point_light_contribution(const Surface<Fn>& s, F3 ws, F3 V, const Poi
     return c;
 }
 
-// Hot form of point_light_contribution() for a light with 2^-40 <= radius <= 2^40 and finite fields (checked by the caller, per
+// Hot form of point_light_contribution() for a light with 2^-40 <= radius <= 2^40 and finite fields (point_light_hot_ok(), per
 // light, uniformly): restricted-range sqrt / reciprocal / divide (numerics.hpp) and the shared-subexpression BRDF of the fast
-// path.  `bad` is set when an operand leaves a domain or the result holds a NaN (the spec turns that into 0): the caller then
+// path.  `bad` (a lane mask: numerics.hpp, lanes()) is set when an operand leaves a domain or the result holds a NaN (the spec turns that into 0): the caller then
 // evaluates the general form for the pixel.
-SAH_DEV F3 point_light_contribution_fast(const Surface<Fn>& s, const BrdfPixel& bp, F3 lv, Fn d2, F3 V, const PointLightDev& pl, bool& bad) {
+// `inv_radius` = div_nr_refine(pl.radius): the part of dist / radius that depends on the light only.  `d2_out`, `away`: the masks of
+// "d2 outside [2^-80, 2^40]" and "N.L <= 0" the caller's votes have built (a ballot of a compare from another basic block is not free).
+SAH_DEV F3 point_light_contribution_fast(const Surface<Fn>& s, const BrdfPixel& bp, F3 lv, Fn d2, F3 V, const PointLightDev& pl, float inv_radius, lanemask d2_out,
+                                         lanemask away, lanemask& bad) {
     const Fn dist = Fn(sqrt_nr(d2.v));
     const F3 L = lv * Fn(rcp_nr(dist.v));
     const Fn ndotl = nclamp(dot(s.normal, L), Fn(0.f), Fn(1.f));
-    const Fn xr = Fn(div_nr(dist.v, pl.radius));
+    const Fn xr = Fn(div_nr_y1(dist.v, pl.radius, inv_radius));
     const Fn x2 = xr * xr;
     const Fn x4 = x2 * x2;
     const Fn w = nclamp(Fn(1.f) - x4, Fn(0.f), Fn(1.f));
     const Fn ww = w * w;
-    const Fn att = Fn(div_nr(ww.v, __builtin_fmaxf(d2.v, 1e-4f)));
-    bool brdf_bad;
-    const F3 b = brdf_fast_light(s, bp, L, V, brdf_bad);
+    const Fn att = Fn(div_nr(ww.v, vmax_f32(d2.v, 1e-4f)));  // (d2 is a sum of products: never a signalling NaN)
+    lanemask brdf_bad;
+    const F3 b = brdf_fast_light(s, bp, L, V, away, brdf_bad);
     const F3 c = ndotl * b * F3{Fn(pl.cr), Fn(pl.cg), Fn(pl.cb)} * (Fn(pl.intensity) * att);
     const float nan_probe = (c.x + c.y + c.z).v;
-    bad = brdf_bad | !((d2.v >= 0x1p-80f) & (d2.v <= 0x1p+40f)) | !((ww.v == 0.f) | (ww.v >= kDivLo)) | !(nan_probe == nan_probe);
+    bad = brdf_bad | d2_out | (lanes(ww.v != 0.f) & lanes(!(ww.v >= kDivLo))) | lanes(nan_probe != nan_probe);
     return c;
 }
 

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     __shared__ float s_box[4][6];
     __shared__ uint32_t s_wave_count[4];
     __shared__ uint16_t s_list[kMaxTileLights];
+    __shared__ float2 s_lconst[LIGHTS ? kMaxTileLights : 1u];  // per kept light: far2, refined 1 / radius (see the shading loop)
     s_lut[threadIdx.x] = a.luts[threadIdx.x];
     s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
     __syncthreads();
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         s.normal = g.N;
         s.roughness = Fn(si.rough);
         s.metalness = Fn(si.metal);
-        if (__any(surface && !geom_ok)) {  // general restatement of the same quantities (IEEE operators) for the pixels that need it
+        if (wave_any(surface && !geom_ok)) {  // general restatement of the same quantities (IEEE operators) for the pixels that need it
             if (surface && !geom_ok) {
                 s.normal = normalize(F3{Fn(si.normal[0]), Fn(si.normal[1]), Fn(si.normal[2])});
                 const F3 vs = viewspace_position_glsl(a, x, y, p.depth);
@@ -136,10 +137,10 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         if (fast_geom) {
             const F3 L = {Fn(a.sun_L[0]), Fn(a.sun_L[1]), Fn(a.sun_L[2])};
             Fn sc3[3];
-            fast_csm_sun(a, csm, s_lut, g.N, g.ws, g.vsz, g.V, L, s, si, !surface, sun_ok, sc3);
+            fast_csm_sun(a, csm, s_lut, g.N, g.ws, g.vsz, g.V, L, s, si, lanes(sun_ok && surface), sun_ok, sc3);
             sc[0] = sc3[0]; sc[1] = sc3[1]; sc[2] = sc3[2];
         }
-        if (__any(surface && !sun_ok)) {
+        if (wave_any(surface && !sun_ok)) {
             if (surface && !sun_ok) sun_frag(a, csm, x, y, p, si, sc);
         }
         if (surface) {
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     if constexpr (LIGHTS) {
         // shading inputs as the a9 spec builds them: the sun fragment's fp32 surface, N, V and position (above)
         const F3 ws = g.ws, V = g.V;
-        const PointLightDev* lights = reinterpret_cast<const PointLightDev*>(a.lights);
+        const PointLightWords* light_words = reinterpret_cast<const PointLightWords*>(a.lights);
 
         // tile bound: box of the positions of the surface pixels (non-finite positions get 0 from every light anyway)
         const float inf = __builtin_inff();
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
         }
 
         F3 sum = F3(Fn(0.f));
+        const lanemask surface_m = lanes(surface);
         const BrdfPixel bp = brdf_fast_pixel(s, V);  // the light-independent half of the BRDF, once per pixel
         for (uint32_t batch = 0; batch < a.num_lights; batch += kMaxTileLights) {
             const uint32_t batch_n = min(kMaxTileLights, a.num_lights - batch);
@@ -195,16 +197,18 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
                 for (uint32_t base = 0; base < batch_n; base += 256u) {
                     const uint32_t i = base + threadIdx.x;
                     bool keep = false;
+                    float radius = 0.f;
                     if (i < batch_n) {
-                        const PointLightDev pl = lights[batch + i];
-                        const float c[3] = {pl.px, pl.py, pl.pz};
+                        const float4 pr = *reinterpret_cast<const float4*>(&light_words[batch + i]);  // position, radius
+                        radius = pr.w;
+                        const float c[3] = {pr.x, pr.y, pr.z};
                         float d2 = 0.f;
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
                             const float d = __builtin_fmaxf(__builtin_fmaxf(lo[k] - c[k], c[k] - hi[k]), 0.f);
                             d2 += d * d;
                         }
-                        const float rr = pl.radius * 1.0001f + 1e-6f;
+                        const float rr = radius * 1.0001f + 1e-6f;
                         keep = d2 <= rr * rr;  // empty box (lo = +inf) gives d2 = inf: nothing kept; NaN light data: kept
                         keep = keep || !(d2 == d2) || !(rr == rr);
                     }
@@ -220,38 +224,55 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
                         offset += w < wave ? c : 0u;
                         total += c;
                     }
-                    if (keep) s_list[offset + before] = (uint16_t)i;
+                    if (keep) {  // (few lights of a batch: what the shading loop needs of the light alone is worked out for those only)
+                        const PointLightWords plw = light_words[batch + i];
+                        const float far_r = radius * 1.001f;
+                        s_list[offset + before] = (uint16_t)(i | (point_light_hot_ok(plw) ? 0x8000u : 0u));  // index in the batch | hot form allowed << 15
+                        s_lconst[offset + before] = {far_r * far_r, div_nr_refine(radius)};
+                    }
                     count += total;
                     __syncthreads();
                 }
             }
             // shade the (ordered) list
             for (uint32_t j = 0; j < count; j++) {
-                const uint32_t idx = batch + (brute_force ? j : (uint32_t)s_list[j]);
-                const PointLightDev pl = lights[idx];
-                // A pixel farther than 1.001 r from the light has xr >= 1.0009, so w = clamp(1 - xr^4, 0, 1) = 0 and its term is +-0
-                // (or NaN -> 0): adding it cannot change `sum`.  Waves in which no pixel is nearer skip the light (uniform branch).
-                const float far_r = pl.radius * 1.001f, far2 = far_r * far_r;
+                // the light and what depends on it alone (uniform): from the culling pass where there was one — computed here they are VALU
+                // instructions of every wave and light.  A pixel farther than 1.001 r from the light has xr >= 1.0009, so
+                // w = clamp(1 - xr^4, 0, 1) = 0 and its term is +-0 (or NaN -> 0): adding it cannot change `sum`; waves in which no pixel is
+                // nearer skip the light (uniform branch).  `light_ok`: the preconditions of the hot form; anything else takes the general one.
+                const uint32_t entry = brute_force ? j : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[j]);  // (scalar: its flag is tested on the scalar unit)
+                const PointLightWords plw = light_words[batch + (entry & 0x7fffu)];
+                const PointLightDev pl = point_light_values(plw);
+                float far2, inv_radius;
+                bool light_ok;
+                if (brute_force) {
+                    const float far_r = pl.radius * 1.001f;
+                    far2 = far_r * far_r;
+                    inv_radius = div_nr_refine(pl.radius);
+                    light_ok = point_light_hot_ok(plw);
+                } else {
+                    const float2 lc = s_lconst[j];
+                    far2 = lc.x;
+                    inv_radius = lc.y;
+                    light_ok = (entry & 0x8000u) != 0u;
+                }
                 const F3 lv = F3{Fn(pl.px), Fn(pl.py), Fn(pl.pz)} - ws;
                 const Fn d2 = dot(lv, lv);
                 const bool near = surface && d2.v <= far2;
-                if (!__any(near)) continue;
+                const lanemask near_m = lanes(d2.v <= far2) & surface_m;  // (votes as scalar mask algebra: numerics.hpp, lanes())
+                if (!near_m) continue;
                 // A light behind the surface (N.L <= 0) contributes ndotl * (...) with ndotl = +0: +-0, or NaN -> 0 — nothing, in the hot
                 // form and in the general one alike (both evaluate L = lv / |lv| with the same bits while d2 is inside the domain of
                 // the restricted-range root and reciprocal).  Waves whose reachable pixels all face away skip the light.
-                {
-                    const bool d2_ok = d2.v >= 0x1p-80f && d2.v <= 0x1p+40f;
-                    const F3 Le = lv * Fn(rcp_nr(sqrt_nr(d2.v)));
-                    const bool facing = !(d2_ok && dot(s.normal, Le).v <= 0.f);
-                    if (!__any(near && facing)) continue;
-                }
-                // per-light (uniform) precondition of the hot form; anything else takes the general form
-                const bool light_ok = pl.radius >= kDivLo && pl.radius <= kDivHi && __builtin_fabsf(pl.cr) < inf && __builtin_fabsf(pl.cg) < inf &&
-                                      __builtin_fabsf(pl.cb) < inf && __builtin_fabsf(pl.intensity) < inf;
+                const lanemask d2_out = lanes(!(d2.v >= 0x1p-80f)) | lanes(!(d2.v <= 0x1p+40f));
+                const F3 Le = lv * Fn(rcp_nr(sqrt_nr(d2.v)));
+                const lanemask away = lanes(dot(s.normal, Le).v <= 0.f);
+                if (!(near_m & (d2_out | ~away))) continue;
                 F3 c = F3(Fn(0.f));
-                bool redo = !light_ok;
-                if (light_ok) c = point_light_contribution_fast(s, bp, lv, d2, V, pl, redo);
-                if (__any(near && redo)) {
+                lanemask redo_m = ~0ull;
+                if (light_ok) c = point_light_contribution_fast(s, bp, lv, d2, V, pl, inv_radius, d2_out, away, redo_m);
+                if (near_m & redo_m) {
+                    const bool redo = (redo_m >> lane) & 1ull;
                     const F3 cg = point_light_contribution(s, ws, V, pl);
                     // (component by component: `c = redo ? cg : c` on the struct goes through scratch memory, 28 bytes a lane, in every iteration)
                     c.x = redo ? cg.x : c.x;
@@ -301,7 +322,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
             sg.V = to_h(fg.V);
             sg.bv = brdf_sl_view(sg.s, sg.V);
         }
-        if (__any(surface && !hot)) {
+        if (wave_any(surface && !hot)) {
             if (surface && !hot) sg = slang_geometry(a, x, y, p, si);
         }
     }
@@ -332,7 +353,7 @@ __global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, co
     // exactly what one fp16 add of +0 does (fp16 -> fp32 is exact, a NaN keeps its bits), so the look-ups, products and fp32 blends become
     // three v_add_f16
     {
-        if (__any((p.emission & 0xffffffu) != 0u)) {
+        if (wave_any((p.emission & 0xffffffu) != 0u)) {
             const Fn e = Fn(3.1415927f);
             lit[0] = Hn(tof(lit[0]) + (Fn(s_lut[p.emission & 0xffu]) * e).v);
             lit[1] = Hn(tof(lit[1]) + (Fn(s_lut[(p.emission >> 8) & 0xffu]) * e).v);

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_lpv_propagate(PropArgs a) {
         *reinterpret_cast<uint2*>(a.packed + (size_t)(z + kLpvPackBorder) * a.pk_slice_pitch + (size_t)(y + kLpvPackBorder) * a.pk_row_pitch +
                                   (size_t)(x + kLpvPackBorder) * kLpvPackTexel + 8u * c) = q;
         const bool bad = ((q.x & 0x7c00u) == 0x7c00u) | ((q.x & 0x7c000000u) == 0x7c000000u) | ((q.y & 0x7c00u) == 0x7c00u) | ((q.y & 0x7c000000u) == 0x7c000000u);
-        if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicMax(&a.state->nonfinite, 1u);
+        if (wave_any(bad) && (threadIdx.x & 63u) == 0u) atomicMax(&a.state->nonfinite, 1u);
     }
 }
 

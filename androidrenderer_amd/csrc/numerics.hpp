@@ -12,6 +12,16 @@ namespace sah {
 
 #define SAH_DEV __device__ __forceinline__
 
+// ---- wave votes ---------------------------------------------------------------------------------
+// A ballot of a COMPARE is the compare itself, written to a scalar register pair; a ballot of anything else (a conjunction, a bool that
+// crossed a basic block) — and HIP's __any / __all, which take an int — first materialises the predicate in a vector register
+// (v_cndmask 0 / 1) and compares it again: two VALU instructions per vote in kernels that are bound by VALU issue.  Hot loops therefore
+// combine the masks of their elementary compares with scalar and / or (lanes(a) & lanes(b)) instead of voting on a && b.
+using lanemask = unsigned long long;
+SAH_DEV lanemask lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+SAH_DEV bool wave_any(bool p) { return lanes(p) != 0ull; }
+SAH_DEV bool wave_all(bool p) { return lanes(!p) == 0ull; }
+
 // ---- fp16 storage <-> fp32 ----------------------------------------------------------------------
 SAH_DEV float h2f(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
 SAH_DEV uint16_t f2h(float f) {  // v_cvt_f16_f32, RNE; the asm keeps LLVM from fusing the producer into v_fma_mixlo_f16
@@ -105,6 +115,29 @@ SAH_DEV float div_nr(float a, float b) {
     const float q1 = __builtin_fmaf(r0, y1, q0);
     const float r1 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(r1, y1, q1);
+}
+
+// |b| in [2^-40, 2^40] -> RN(0.5 / b) = RN(1 / b) / 2: halving is exact (no result below 2^-41), and so is the order of the two roundings
+SAH_DEV float half_over_nr(float b) { return 0.5f * rcp_nr(b); }
+// a / b as div_nr(a, b) with the refined reciprocal y1 of b — div_nr's first three instructions — supplied by the caller (a divisor that is
+// uniform over a loop's lanes or iterations): the same operations on the same operands, so the same bits
+SAH_DEV float div_nr_y1(float a, float b, float y1) {
+    const float q0 = a * y1;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y1, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y1, q1);
+}
+SAH_DEV float div_nr_refine(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+}
+// max(a, b) as one v_max_f32 for an operand a that is not a signalling NaN (a result of arithmetic) and a uniform b (a constant: scalar
+// register): __builtin_fmaxf on a value from another basic block is preceded by a canonicalising v_max_f32 x, x
+SAH_DEV float vmax_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(b), "v"(a));
+    return r;
 }
 
 // float -> uint as the hardware converts (GLSL / Slang uint(float) on this path): truncation, negatives and NaN -> 0, 2^32 and above ->
@@ -390,14 +423,13 @@ SAH_DEV F3 brdf_fast(const Surface<Fn>& s, F3 l, F3 v, bool& out_of_domain) {
     const Fn GGXL = NoV * Fn(sqrt_nr(argL.v));
     const Fn GGXV = NoL * Fn(sqrt_nr(argV.v));
     const Fn vden = GGXV + GGXL;
-    const Fn Vis = Fn(div_nr(0.5f, vden.v));
+    const Fn Vis = Fn(half_over_nr(vden.v));
     const F3 fr = (D * Vis) * Fv;
     const F3 sum = fd + fr;
-    // lower bounds: one min3 / min per class, then one compare each.  Upper bounds: dh <= 4, NoV <= 1.00002, a <= 1, so every
-    // operand above is <= 4.
+    // lower bounds: one min3 for the roots, one compare per divisor (a min of values that come from another basic block costs a
+    // canonicalising v_max per operand).  Upper bounds: dh <= 4, NoV <= 1.00002, a <= 1, so every operand above is <= 4.
     const float lo_sqrt = __builtin_fminf(__builtin_fminf(dh.v, argL.v), argV.v);
-    const float lo_div = __builtin_fminf(dden.v, vden.v);
-    out_of_domain = !dark && !(lo_sqrt >= 0x1p-80f && lo_div >= kDivLo);
+    out_of_domain = !dark && !((lo_sqrt >= 0x1p-80f) & (dden.v >= kDivLo) & (vden.v >= kDivLo));
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
 
@@ -422,7 +454,8 @@ SAH_DEV BrdfPixel brdf_fast_pixel(const Surface<Fn>& s, F3 v) {
     p.powV = npow5(nclamp(one - p.NoV, zero, one));
     return p;
 }
-SAH_DEV F3 brdf_fast_light(const Surface<Fn>& s, const BrdfPixel& p, F3 l, F3 v, bool& out_of_domain) {
+// `dark_m`: lanes(dot(s.normal, l) <= 0), which the caller has voted on already (a ballot of a compare from another basic block is not free).
+SAH_DEV F3 brdf_fast_light(const Surface<Fn>& s, const BrdfPixel& p, F3 l, F3 v, lanemask dark_m, lanemask& out_of_domain) {
     const Fn one = Fn(1.0f), zero = Fn(0.0f);
     const F3 vl = v + l;
     const Fn dh = dot(vl, vl);  // <= 4 + eps
@@ -450,12 +483,12 @@ SAH_DEV F3 brdf_fast_light(const Surface<Fn>& s, const BrdfPixel& p, F3 l, F3 v,
     const Fn GGXL = p.NoV * Fn(sqrt_nr(argL.v));
     const Fn GGXV = NoL * p.sqrtV;
     const Fn vden = GGXV + GGXL;
-    const Fn Vis = Fn(div_nr(0.5f, vden.v));
+    const Fn Vis = Fn(half_over_nr(vden.v));
     const F3 fr = (D * Vis) * Fv;
     const F3 sum = fd + fr;
     const float lo_sqrt = __builtin_fminf(__builtin_fminf(dh.v, argL.v), p.argV.v);
-    const float lo_div = __builtin_fminf(dden.v, vden.v);
-    out_of_domain = !dark && !(lo_sqrt >= 0x1p-80f && lo_div >= kDivLo);
+    // (as a lane mask, from the masks of the elementary compares: the caller votes on it — see lanes())
+    out_of_domain = ~dark_m & (lanes(!(lo_sqrt >= 0x1p-80f)) | lanes(!(dden.v >= kDivLo)) | lanes(!(vden.v >= kDivLo)));
     return {dark ? zero : sum.x, dark ? zero : sum.y, dark ? zero : sum.z};
 }
 
