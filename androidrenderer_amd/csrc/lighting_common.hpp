@@ -48,6 +48,15 @@ struct Px {  // one pixel's G-buffer texels, still packed
 };
 
 SAH_DEV int clamp_to_int(float f) { return (int)__builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f); }
+// min(max(clamp_to_int(f), 0), hi) for a wave-uniform hi in [0, 10^9] (an extent from the kernel arguments: it is bound to a scalar
+// register) as two instructions for four: v_cvt_i32_f32 saturates by itself (NaN -> 0, which the clamp above also ends at), and the
+// two-sided clamp is one v_med3_i32.
+SAH_DEV int clamp_index(float f, int hi) {
+    int i, r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "s"(hi));
+    return r;
+}
 SAH_DEV _Float16 hbits(uint32_t b) { return __builtin_bit_cast(_Float16, (uint16_t)b); }
 
 // ---- samplers: Vulkan weighted-sum formula, fma chain in tap order (DESIGN.md "Sampling") -----------------

@@ -108,10 +108,11 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
         const float px = spx.v * (float)sm.width - 0.5f, py = spy.v * (float)sm.height - 0.5f;
         const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
         const float pcf_fx = px - fx0, pcf_fy = py - fy0;
-        const int x0 = clamp_to_int(fx0), y0 = clamp_to_int(fy0);
+        // texel indices clamped into the map (CLAMP_TO_EDGE; a coordinate far outside — its taps are not used: sp_inside — or not finite
+        // still addresses the map): clamp_index(f, n) = min(max(int(f), 0), n), and fx0 + 1 is exact below 2^24
         const int wm1 = (int)sm.width - 1, hm1 = (int)sm.height - 1;
-        const uint32_t xa = (uint32_t)min(max(x0, 0), wm1) * 2u, xb = (uint32_t)min(max(x0 + 1, 0), wm1) * 2u;
-        const uint32_t ra = (uint32_t)min(max(y0, 0), hm1) * sm.row_pitch, rb = (uint32_t)min(max(y0 + 1, 0), hm1) * sm.row_pitch;
+        const uint32_t xa = (uint32_t)clamp_index(fx0, wm1) * 2u, xb = (uint32_t)clamp_index(fx0 + 1.0f, wm1) * 2u;
+        const uint32_t ra = (uint32_t)clamp_index(fy0, hm1) * sm.row_pitch, rb = (uint32_t)clamp_index(fy0 + 1.0f, hm1) * sm.row_pitch;
         const uint32_t lo = cc * sm.slice_pitch;  // host guarantees the shadow map is < 4 GiB for the fast path
         const uint32_t pcf_off[4] = {lo + ra + xa, lo + ra + xb, lo + rb + xa, lo + rb + xb};
         // PCF taps (compare LESS, then filter); the fast path is D16_UNORM only (anything else: general kernel)

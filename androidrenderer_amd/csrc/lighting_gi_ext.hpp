@@ -193,7 +193,7 @@ SAH_DEV BilinearTaps bilinear_setup_probe(const VolumeArg& v, float u, float vv,
     const float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
     const float fx = px - fx0, fy = py - fy0;
     const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    const int x0 = min(max(clamp_to_int(fx0), 0), (int)v.width - 2), y0 = min(max(clamp_to_int(fy0), 0), (int)v.height - 2);
+    const int x0 = clamp_index(fx0, (int)v.width - 2), y0 = clamp_index(fy0, (int)v.height - 2);
     BilinearTaps t;
     t.row0 = (uint32_t)layer * v.slice_pitch + (uint32_t)y0 * v.row_pitch + (uint32_t)x0 * 4u;  // atlases are < 4 GiB (host check)
     t.row1 = t.row0 + v.row_pitch;
@@ -238,7 +238,7 @@ SAH_DEV ProbeAxis probe_axis(float u, uint32_t size, uint32_t stride) {
     const float p = u * (float)size - 0.5f;
     const float f0 = __builtin_floorf(p);
     const float f = p - f0;
-    const int i0 = min(max(clamp_to_int(f0), 0), (int)size - 2);
+    const int i0 = clamp_index(f0, (int)size - 2);
     return {(uint32_t)i0 * stride, 1.0f - f, f};
 }
 
@@ -306,19 +306,21 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
     // the address is clamped into the atlas and the range test applied to the result): read where they are used, each probe's byte is a
     // memory round trip the rest of its iteration waits for — eight in a row per pixel.  Only `validity == 0` is used, and
     // (half)(b / 255) is zero for b = 0 alone
-    uint32_t voff[3][2];
-    bool vin[3][2];
+    // The range test as a byte mask per axis corner (all ones / zero), so that "byte != 0 and all three indices in range" is one
+    // three-input AND and one compare per probe (as bools the compiler builds 0 / 1 words and combines those: eight instructions)
+    uint32_t voff[3][2], vmask[3][2];
     {
         const uint32_t vext[3] = {c.validity.width, c.validity.height, c.validity.depth}, vpitch[3] = {1u, c.validity.row_pitch, c.validity.slice_pitch};
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                vin[k][j] = pidx[k][j] < vext[k];
+                vmask[k][j] = pidx[k][j] < vext[k] ? 0xffu : 0u;
                 voff[k][j] = min(pidx[k][j], vext[k] - 1u) * vpitch[k];
             }
     }
-    uint8_t vbyte[8];
+    const uint32_t vmask_yz[2][2] = {{vmask[1][0] & vmask[2][0], vmask[1][1] & vmask[2][0]}, {vmask[1][0] & vmask[2][1], vmask[1][1] & vmask[2][1]}};  // [jz][jy]
+    uint32_t vbyte[8];
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++) vbyte[i] = c.validity.ptr[voff[2][(i >> 2) & 1u] + voff[1][(i >> 1) & 1u] + voff[0][i & 1u]];
 
@@ -327,7 +329,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++) {
         const int jx = i & 1u, jy = (i >> 1) & 1u, jz = (i >> 2) & 1u;
-        if (!((vbyte[i] != 0) & vin[0][jx] & vin[1][jy] & vin[2][jz])) continue;
+        if ((vbyte[i] & vmask[0][jx] & vmask_yz[jz][jy]) == 0u) continue;
         // a valid probe index is < 32 per axis (validity atlas extent, host check <= 64), which bounds every texcoord below
         const F3 dir_to_probe = {dp[0][jx], dp[1][jy], dp[2][jz]};
         const Fn d2 = sq[0][jx] + sq[1][jy] + sq[2][jz];
@@ -354,7 +356,8 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
         }
         const float du = div_const((dbase[0][jx] + depth_oct.x * (Fn(10.f) * Fn(0.5f))).v, 384.0f, 1.0f / 384.0f);
         const float dv = div_const((dbase[1][jy] + depth_oct.y * (Fn(10.f) * Fn(0.5f))).v, 384.0f, 1.0f / 384.0f);
-        const ProbeAxis dxa = probe_axis(du, c.depth.width, 4u), dya = probe_axis(dv, c.depth.height, c.depth.row_pitch);
+        // (the depth atlas is 384 x 384 texels in the hot form — CacheArgs::hot_ok —, as the 384 of the two quotients above says already)
+        const ProbeAxis dxa = probe_axis(du, 384u, 4u), dya = probe_axis(dv, 384u, c.depth.row_pitch);
         const uint32_t drow0 = dlayer[jz] + dya.off + dxa.off;
         const uint2 d0 = load_pair(c.depth.ptr, drow0), d1 = load_pair(c.depth.ptr, drow0 + c.depth.row_pitch);
         const uint32_t dw[4] = {d0.x, d0.y, d1.x, d1.y};  // tap order (x0,y0) (x1,y0) (x0,y1) (x1,y1)
@@ -400,7 +403,7 @@ SAH_DEV F3 sample_cascade_fast(const CacheArgs& c, F3 location, F3 direction, ui
             ib = __builtin_fmaf(iwt[k], it[k].z, ib);
         }
         const H3 pi = {Hn(ir), Hn(ig), Hn(ib)};  // Sampler2DArray<half3>
-        irradiance = irradiance + to_f(pi) * probe_weight;
+        irradiance = irradiance + F3{Fn(mul_mix(probe_weight.v, pi.x)), Fn(mul_mix(probe_weight.v, pi.y)), Fn(mul_mix(probe_weight.v, pi.z))};  // to_f(pi) * probe_weight
         weight = weight + probe_weight;
         bad = bad | pbad;
     }
