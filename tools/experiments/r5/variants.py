@@ -148,10 +148,18 @@ VARIANTS["tm_occ4"] = (["tonemap_tol.hip"], [
 # indices, validity bytes, atlas origins and layers become scalar work (images wrong wherever a wave straddles a cell).  What this build
 # gains over the product is the most a two-path kernel could gain on waves that really share their cell.
 VARIANTS["tiled_uniform_cell"] = (["lighting_tiled.hip"], [
+    # TIMING ONLY (wrong image): every wave takes its first lane's probe cell, and nothing is re-evaluated — the upper bound of what a
+    # wave-uniform cell path can save (the compiler moves what then depends on uniform values alone to the scalar unit)
     ("lighting_gi_ext.hpp", "        const Fn mp = Fn(__builtin_floorf(psa[k].v));\n        const Fn alpha = nclamp(psa[k] - mp, Fn(0.f), Fn(1.f));",
      "        const Fn mp = Fn(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_floorf(psa[k].v)))));\n"
      "        const Fn alpha = nclamp(psa[k] - mp, Fn(0.f), Fn(1.f));"),
+    ("lighting_gi_ext.hpp", "    if (weight.v == 0.f) return F3(Fn(0.f));\n    // the three quotients through one refined reciprocal",
+     "    bad = false;\n    if (weight.v == 0.f) return F3(Fn(0.f));\n    // the three quotients through one refined reciprocal"),
+    ("lighting_gi_ext.hpp", "        bad = bad | !((mn >= __builtin_bit_cast(uint32_t, kDivLo) - 1u) & (mx <= __builtin_bit_cast(uint32_t, kDivHi)));",
+     "        bad = false;"),
 ])
+# the same with nothing re-evaluated but every lane's own cell: the reference point of the timing probe above
+VARIANTS["tiled_no_redo"] = (["lighting_tiled.hip"], VARIANTS["tiled_uniform_cell"][1][1:])
 # Beside the lighting of the next frame (three work streams) the band composite is not on the critical path, but its latency-bound waves
 # hold registers the VALU-bound lighting waves could use: what if it may keep only two (one) workgroups per CU resident?  LDS padding, same images.
 for _n, _pad in (("tm_band_2wg", 10000), ("tm_band_1wg", 24000)):
@@ -161,6 +169,45 @@ for _n, _pad in (("tm_band_2wg", 10000), ("tm_band_1wg", 24000)):
          "    __shared__ float s_pad_[kTileH == 16 ? %d : 1];\n    if (t.out_w == 0xffffffffu) s_pad_[threadIdx.x & 0] = 1.f;" % _pad),
         ("tonemap_tol.hip", "    const float4* code_tab = reinterpret_cast<const float4*>(t.code_table);", "    const float4* code_tab = reinterpret_cast<const float4*>(t.code_table);\n    if (t.out_w == 0xfffffffeu) bloom[0][0].r += s_pad_[0];"),
     ])
+# Counter build of the cache-GI gather ("wave-uniform probe-cell path"): how many waves hold one probe cell only, and how many
+# of a pixel's eight probes are evaluated.  tools/experiments/r5/cell_fractions.py reads the counters.
+VARIANTS["tiled_cell_stats"] = (["lighting_tiled.hip"], [
+    ("lighting_tiled.hip", '#include "lighting_gi_ext.hpp"', 'namespace sah { __device__ unsigned long long g_cell_stats[16]; }\n#include "lighting_gi_ext.hpp"'),
+    ("lighting_gi_ext.hpp", "    F3 irradiance = F3(Fn(0.f));\n    Fn weight = Fn(0.f);\n#pragma unroll\n    for (uint32_t i = 0; i < 8; i++) {\n        const int jx = i & 1u",
+     "    {\n"
+     "        const uint32_t cell = pidx[0][0] | (pidx[1][0] << 8) | (pidx[2][0] << 16) | (cascade_index << 24);\n"
+     "        const bool same = cell == (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);\n"
+     "        const uint32_t first = (uint32_t)__builtin_ctzll(lanes(true));\n"
+     "        uint32_t nvalid = 0;\n"
+     "        for (uint32_t i = 0; i < 8; i++) nvalid += (vbyte[i] & vmask[0][i & 1u] & vmask_yz[(i >> 2) & 1u][(i >> 1) & 1u]) != 0u ? 1u : 0u;\n"
+     "        const uint32_t active = (uint32_t)__builtin_popcountll(lanes(true)), same_n = (uint32_t)__builtin_popcountll(lanes(same));\n"
+     "        uint32_t nv_wave = nvalid;\n"
+     "        for (int o = 32; o >= 1; o >>= 1) nv_wave += (uint32_t)__shfl_xor((int)nv_wave, o);\n"
+     "        const uint32_t row_same = __builtin_popcountll(lanes(same) & 0xffffffffull), any_valid_m = (uint32_t)__builtin_popcountll(lanes(nvalid != 0u));\n"
+     "        if ((threadIdx.x & 63u) == first) {\n"
+     "            atomicAdd(&g_cell_stats[0], 1ull);                              // waves that gather\n"
+     "            atomicAdd(&g_cell_stats[1], (unsigned long long)active);       // pixels that gather\n"
+     "            atomicAdd(&g_cell_stats[2], same_n == active ? 1ull : 0ull);    // waves whose pixels share one cell (and cascade)\n"
+     "            atomicAdd(&g_cell_stats[3], (unsigned long long)same_n);       // pixels in the cell of their wave's first pixel\n"
+     "            atomicAdd(&g_cell_stats[4], (unsigned long long)nv_wave);      // probes evaluated (sum over pixels)\n"
+     "            atomicAdd(&g_cell_stats[5], active == 64u ? 1ull : 0ull);       // full waves\n"
+     "            atomicAdd(&g_cell_stats[6], (unsigned long long)any_valid_m);  // pixels with at least one probe\n"
+     "        }\n"
+     "    }\n"
+     "    F3 irradiance = F3(Fn(0.f));\n    Fn weight = Fn(0.f);\n#pragma unroll\n    for (uint32_t i = 0; i < 8; i++) {\n        const int jx = i & 1u"),
+    ("lighting_tiled.hip", "}  // namespace sah\n",
+     "}  // namespace sah\n"
+     "extern \"C\" __attribute__((visibility(\"default\"))) int sah_debug_cell_stats(unsigned long long* out, int reset) {\n"
+     "    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sah::g_cell_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;\n"
+     "    if (reset) {\n        unsigned long long z[16] = {};\n        if (hipMemcpyToSymbol(HIP_SYMBOL(sah::g_cell_stats), z, sizeof(z)) != hipSuccess) return -1;\n    }\n"
+     "    return 0;\n}\n"),
+])
+# The general sample_cascade() — the inline re-evaluation of pixels outside the hot form's domains — as a real function call instead of 1,400
+# inlined instructions in the middle of the kernel (tiled_no_redo above says what its mere presence costs: 2 %)
+VARIANTS["tiled_redo_call"] = (["lighting_tiled.hip"], [
+    ("lighting_gi_ext.hpp", "SAH_DEV F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index) {",
+     "__device__ __attribute__((noinline)) F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index) {"),
+])
 for _k, _v in list(VARIANTS.items()):  # (the patch texts above are written with escaped newlines for readability)
     VARIANTS[_k] = (_v[0], [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n")) for f, o, n in _v[1]])
 
