@@ -722,19 +722,31 @@ def preflight(R):
     R.preflight["fallback_ok"] = bool(ok2)
 
 
+def clock_ramp(R, step, drain, synchronize, clock=time.perf_counter):
+    """args.ramp_ms of untimed steps before the warm-up (clocks up, caches and tables made), eight at a time.  WHEN TO STOP IS ONE DECISION
+    FOR THE WHOLE JOB: every step holds the exchanges of the sharded loop, so every rank must make the same number of them — a rank that
+    read its own clock alone would stop one round before or after a peer whose ramp began a millisecond apart, and the extra gathers
+    would wait for partners that never come (RCCL: for ever; the direct exchange: its two seconds, found by a four-rank rehearsal in
+    round 5).  The ranks stop together as soon as any of them has had its time.  Returns the number of steps made."""
+    if R.args.ramp_ms <= 0:
+        return 0
+    t_ramp = clock()
+    k = 0
+    while True:
+        for _ in range(8):
+            step(k)
+            k += 1
+        drain()
+        synchronize()
+        if not all_ranks_min(R, int((clock() - t_ramp) * 1e3 < R.args.ramp_ms)):
+            return k
+
+
 def run_timed(R):
     """Clock ramp, W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides.  Adds: elapsed (max over ranks),
     kernel_ms_mean, kernel_ms_min, kernel_scope."""
     args, torch, dist, step, drain = R.args, R.torch, R.dist, R.step, R.drain
-    if args.ramp_ms > 0:
-        t_ramp = time.perf_counter()
-        k = 0
-        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-            for _ in range(8):
-                step(k)
-                k += 1
-            drain()
-            torch.cuda.synchronize()
+    clock_ramp(R, step, drain, torch.cuda.synchronize)
     R.beat("warm-up")
     for i in range(args.warmup):
         step(i)

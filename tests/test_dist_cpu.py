@@ -66,3 +66,53 @@ def test_shard_rows_partition():
             assert rows[0][0] == 0 and rows[-1][1] == h
             assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
             assert all(0 <= b - a <= -(-h // w) for a, b in rows)
+
+
+def _ramp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import types
+
+    import torch
+    import torch.distributed as dist
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R = types.SimpleNamespace(args=types.SimpleNamespace(ramp_ms=200.0), torch=torch, dist=dist, torch_pg=True, red_dev=torch.device("cpu"), world=world, rank=rank)
+    # a clock of its own per rank: rank 1's ramp begins 30 ms "later" and its steps are a little faster, so that each rank, reading its own
+    # clock alone, would stop after a different number of rounds (rank 0: 3 rounds of 8 x 10 ms, rank 1: 4 rounds of 8 x 7.5 ms)
+    now = [0.0 if rank == 0 else 0.030]
+    per_step = 0.010 if rank == 0 else 0.0075
+    steps = []
+
+    def step(k):
+        now[0] += per_step
+        t = torch.tensor([k], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the exchange inside a step: a collective every rank must join, or it never returns
+        assert int(t.item()) == k, "the ranks are not at the same step"
+        steps.append(k)
+
+    n = bench.clock_ramp(R, step, lambda: None, lambda: None, clock=lambda: now[0])
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64))
+    with open(os.path.join(out_dir, f"ramp{rank}.txt"), "w") as f:
+        f.write(" ".join(str(int(c.item())) for c in counts) + f" {len(steps)}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_clock_ramp_stops_on_every_rank_after_the_same_step(tmp_path):
+    """bench.py's clock ramp runs for a TIME; its steps hold collectives.  Two ranks whose clocks disagree about when the time is up must
+    still make the same number of steps (round 5: a four-rank rehearsal left one rank's last gathers without partners)."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ramp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    seen = [open(tmp_path / f"ramp{r}.txt").read().split() for r in range(world)]
+    assert seen[0] == seen[1], seen
+    n0, n1, made = (int(v) for v in seen[0])
+    assert n0 == n1 == made and made % 8 == 0 and 0 < made <= 32, seen
