@@ -548,6 +548,11 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
     // pixels per thread: 4 (16 B/lane plane loads) whenever pitches and width allow (measured on MI355X, DESIGN.md §7: with the
     // packed LPV gather the 4-pixel body fits 106 VGPRs without spills and beats 2 px/thread by ~4 %)
     int ppt = vec4ok ? 4 : 1;
+    // ... unless the launch would then be too few workgroups to keep the chip's 1,024 workgroup slots (256 CUs x 4) busy for more than a
+    // round and a half: a 1280 x 720 frame, or one rank's 270 rows of a 4K frame, is ~900 workgroups of 1,024 pixels, and the kernel then takes
+    // as long as one workgroup lives.  Fewer pixels per thread: more and shorter workgroups (1280 x 720, RT sun only: 0.0356 ms at 4, 0.0233 at
+    // 2, 0.0222 at 1; 1920 x 1080 is equal at all three; at 4K 4 wins by 20 %).  The three bodies produce the same bits (tests/test_lighting_gpu.py).
+    while (ppt > 1 && (uint64_t)(W / (uint32_t)ppt) * (r1 - r0) < 1536ull * 256ull) ppt /= 2;
     if (ctx->force_ppt == 1 || ctx->force_ppt == 2 || ctx->force_ppt == 4) {
         if (ctx->force_ppt == 1 || (vec4ok && W % ctx->force_ppt == 0)) ppt = ctx->force_ppt;
     }

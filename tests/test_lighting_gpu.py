@@ -16,15 +16,18 @@ def _check(frame, hip_ctx, name):
     ref = frame.run_oracle()
     dev = frame.device_arrays()
     outs = {}
-    for path, general in (("fast", False), ("general", True)):
-        hip_ctx.debug_set(force_general=general)
+    # (the fast kernel has three bodies — 4, 2 and 1 pixels per thread — and picks one by the size of the launch: frames of this size
+    # get 1, so the other two are asked for by name; widths they cannot take fall back by themselves)
+    for path, general, ppt in (("fast", False, 0), ("fast, 4 px per thread", False, 4), ("fast, 2 px per thread", False, 2), ("general", True, 0)):
+        hip_ctx.debug_set(force_general=general, force_ppt=ppt)
         got = frame.run_hip(hip_ctx, dev)
         outs[path] = got
         d = util.f16_ulp_diff(got, ref)
         print(util.report_ulp(f"{name} [{path}]", d))
         assert d.max() <= MAX_ULP, util.report_ulp(f"{name} [{path}]", d)
-    hip_ctx.debug_set(force_general=False)
-    assert np.array_equal(outs["fast"], outs["general"]), "fast and general kernels disagree"
+    hip_ctx.debug_set(force_general=False, force_ppt=0)
+    for path in outs:
+        assert np.array_equal(outs[path], outs["general"]), f"the {path} kernel and the general kernel disagree"
 
 
 @pytest.mark.parametrize("sun_mode", [_abi.SHADOW_MODE_OFF, _abi.SHADOW_MODE_CSM, _abi.SHADOW_MODE_RT])
