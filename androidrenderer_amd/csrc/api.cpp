@@ -618,6 +618,8 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             fast.row_magic = (gpr >= 2 && threads * gpr < (1ull << 32)) ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u;
         }
         fast.state = ctx->state;
+        fast.hint_slot = ctx->hint_slot;  // (FrameState::deferred_hint: consecutive calls take the two words in turn)
+        ctx->hint_slot ^= 1u;
     }
     // per-column numerators of the view-space x and per-row ones of y (IEEE divides per thread / per pixel otherwise; the tiled kernel reads
     // them too): a function of the extent, the render resolution

@@ -58,6 +58,7 @@ struct sah_ctx {
     // reallocated, a table is rebuilt for other extents, a gather copy that calls were re-using is dropped or has to be rebuilt.  While it
     // stands, the same call enqueues the same kernels with the same kernel arguments — what sah_chain's captured graphs rely on (api_chain.cpp).
     uint64_t cache_epoch = 0;
+    uint32_t hint_slot = 0;  // FrameState::deferred_hint word of the next fast-path Lighting call (the calls of a context are serialised: guard_lighting)
     uint32_t dbg_lpv_packs = 0, dbg_irr_unpacks = 0;  // full rebuilds of the two gather copies by sah_lighting (debug hook sah_debug_copy_rebuilds)
     const uint16_t* last_seg_count = nullptr;  // debug hook (sah_debug_deferred_pixels)
     uint32_t last_num_segments = 0;

@@ -79,11 +79,25 @@ __global__ void __launch_bounds__(256) k_lighting_general(const LightingArgs a, 
 // stay busy whether a segment holds one stray pixel or is all sky.  No atomics, no list clearing: every wave of the fast kernel
 // rewrites its count.
 constexpr uint32_t kFixupSegs = 16;
+// (at most this many workgroups, striding over the groups of segments: 512 leave an empty list 0.7 us sooner than 2,048, but take
+//  3.7 % longer over a frame that lists 29 K pixels — tools/experiments/r5/ab_fixup_grid.sh)
+#ifndef SAH_FIXUP_MAX_WGS
+#define SAH_FIXUP_MAX_WGS 2048
+#endif
+constexpr uint32_t kFixupMaxWorkgroups = SAH_FIXUP_MAX_WGS;
 template <int SUN, int GI, int PPT>
 __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
                                                         const FastArgs f) {
+    // nothing listed by any wave (FrameState::deferred_hint): every workgroup leaves here
+    if (__hip_atomic_load(&f.state->deferred_hint[f.hint_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ uint32_t s_pref[kFixupSegs + 1];
-    const uint32_t seg0 = blockIdx.x * kFixupSegs;
+    __shared__ float s_lut[512];
+    s_lut[threadIdx.x] = a.luts[threadIdx.x];
+    s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
+    const uint32_t ngroups = (f.num_segments + kFixupSegs - 1u) / kFixupSegs;
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    __syncthreads();  // (s_pref of the previous group is read no more; the LUT is in place)
+    const uint32_t seg0 = grp * kFixupSegs;
     if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         const uint32_t c = (lane < kFixupSegs && seg0 + lane < f.num_segments) ? (uint32_t)f.seg_count[seg0 + lane] : 0u;
@@ -98,11 +112,7 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
     }
     __syncthreads();
     const uint32_t total = s_pref[kFixupSegs];
-    if (total == 0) return;
-    __shared__ float s_lut[512];
-    s_lut[threadIdx.x] = a.luts[threadIdx.x];
-    s_lut[threadIdx.x + 256] = a.luts[threadIdx.x + 256];
-    __syncthreads();
+    if (total == 0) continue;
     const uint32_t groups_per_row = a.width / PPT;
     for (uint32_t i = threadIdx.x; i < total; i += 256u) {
         uint32_t s = 0;  // last segment whose prefix is <= i (counts are small: a 4-step search over 16 LDS words)
@@ -127,6 +137,7 @@ __global__ void __launch_bounds__(256) k_lighting_fixup(const LightingArgs a, co
                      : 1.0f;
         const uint2 r = shade_pixel_general<SUN, GI>(a, csm, lpv, sky, x, y, p, s_lut);
         *reinterpret_cast<uint2*>(const_cast<uint8_t*>(a.lit.ptr) + (size_t)y * a.lit.pitch + (size_t)x * 8) = r;
+    }
     }
 }
 
@@ -366,7 +377,11 @@ __global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fas
             }
         }
     }
-    if (lane == 0 && seg < f.num_segments) f.seg_count[seg] = (uint16_t)front;
+    if (lane == 0 && seg < f.num_segments) {
+        f.seg_count[seg] = (uint16_t)front;
+        if (front != 0u) f.state->deferred_hint[f.hint_slot] = 1u;  // (see FrameState: the fix-up kernel's workgroups leave at once without it)
+    }
+    if (gid == 0u) f.state->deferred_hint[f.hint_slot ^ 1u] = 0u;  // the next call's word
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------
@@ -405,7 +420,9 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     if (ppt == 4) launch(std::integral_constant<int, 4>{});
     else if (ppt == 2) launch(std::integral_constant<int, 2>{});
     else launch(std::integral_constant<int, 1>{});
-    const dim3 fgrid((f.num_segments + kFixupSegs - 1) / kFixupSegs);
+    // (a grid-stride loop over the groups of segments)
+    const uint32_t fgroups = (f.num_segments + kFixupSegs - 1) / kFixupSegs;
+    const dim3 fgrid(fgroups < kFixupMaxWorkgroups ? fgroups : kFixupMaxWorkgroups);
     if (ppt == 4) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 4>), fgrid, block, 0, st, a, csm, lpv, sky, f);
     else if (ppt == 2) hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 2>), fgrid, block, 0, st, a, csm, lpv, sky, f);
     else hipLaunchKernelGGL((k_lighting_fixup<SUN, GI, 1>), fgrid, block, 0, st, a, csm, lpv, sky, f);

@@ -79,7 +79,14 @@ struct SkyArgs {
 // Per-context device state shared by consecutive Lighting calls (double-buffered by call parity so that no memset
 // is needed between calls: the fix-up kernel of call k zeroes the slots call k+1 will use).
 struct FrameState {
-    uint32_t unused[3];
+    // "some wave of the fast kernel has listed a pixel for the fix-up kernel": raised (a plain store of 1) by such a wave, read first thing by
+    // every workgroup of k_lighting_fixup — the frames a renderer produces list nothing, and the fix-up launch is then a few hundred
+    // workgroups that return at once instead of a scan of 32,400 segment counts.  Two words, used in turn by consecutive Lighting calls
+    // (FastArgs::hint_slot): the fast kernel of a call clears the word of the NEXT call (which nobody reads or raises before that call),
+    // so no memset, no atomic and no "last workgroup" ticket is needed (2,025 tickets on one address cost 0.1 ms).  A captured launch that
+    // is replayed by itself keeps its slot: its word is then never cleared, which costs the early exit, not correctness.
+    uint32_t deferred_hint[2];
+    uint32_t unused;
     // 1 when the gather copy of the LPV volumes holds an inf / NaN texel: cleared (a 4-byte memset in front of the kernel) and raised by whatever
     // writes the copy — k_lpv_pack, or the emitting step of the propagation — and read by the Lighting kernels; a copy that is kept over several
     // Lighting calls keeps its verdict.  (Rounds 2-4 compared a tag with the copy's serial number, a KERNEL ARGUMENT: a captured launch replays
@@ -110,6 +117,7 @@ struct FastArgs {
     uint8_t* seg_list;
     uint16_t* seg_count;
     uint32_t num_segments, seg_stride;
+    uint32_t hint_slot;  // which word of FrameState::deferred_hint this call uses (0 / 1, alternating per Lighting call of the context)
     // LPV gather copy (k_lpv_pack): texel (x,y,z) of the three volumes interleaved as 24 bytes {R[4], G[4], B[4]} (fp16) at
     // ((z+2) * pk_slice_pitch + (y+2) * pk_row_pitch + (x+2) * 24), inside a two-texel border of zeros (= CLAMP_TO_BORDER)
     const uint8_t* lpv_packed;
