@@ -788,6 +788,9 @@ def run_timed(R):
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     R.rebuilds_in_timed_region = {"lpv": R.ctx.copy_rebuilds()[0] - rebuilds0[0], "irradiance_atlas": R.ctx.copy_rebuilds()[1] - rebuilds0[1]}
+    # how many pixels of the last pass the fast kernel handed to its fix-up launch (0 for the frames a renderer produces: the launch then
+    # returns at once; the tiled kernel re-evaluates inline and has no such list)
+    R.fixup_pixels_last_step = R.ctx.deferred_pixels() if not R.chain and not R.n_lights and R.gi_kind in (0, 1) else None
     loop_ms = g0.elapsed_time(g1) / args.steps
     if R.chain:
         per_step = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
@@ -932,6 +935,7 @@ def report(R):
                 "rebuilt inside every step (lpv_generation 0: k_lpv_pack + the pass — a frame whose volumes somebody else's propagation rewrites)"
                 if args.lpv_copy == "rebuild" else "kept across steps (lpv_generation 1: the LPV volumes of this benchmark never change)"),
             "gather_copy_rebuilds_in_timed_region": R.rebuilds_in_timed_region,
+            "fixup_pixels_last_step": R.fixup_pixels_last_step,
             "probe_gather_copy": None if R.gi_kind != _abi.GI_CACHE else (
                 "tracked by the context (SAH_GENERATION_TRACKED): sah_probe_update re-widens the blocks of the 1024 probes it folds every step" if (wl.get("traced") and args.probe_copy == "patched") else
                 "tracked by the context (SAH_GENERATION_TRACKED): every step re-widens the blocks of 1024 probes (sah_probe_notify_updated: r.GI.Cache.UpdatesPerFrame)" if args.probe_copy == "patched" else
