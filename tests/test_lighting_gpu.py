@@ -236,3 +236,25 @@ def test_probe_generation_keeps_and_drops_the_irradiance_copy(hip_ctx):
     f.arrays["probe_irr"] = synth.probe_atlases(1000)["irradiance"]
     dev["probe_irr"].copy_(util.to_torch(f.arrays["probe_irr"]))
     assert np.array_equal(f.run_hip(hip_ctx, dev), f.run_oracle())
+
+
+def test_fixup_hint_across_calls(hip_ctx):
+    """The fix-up launch returns at once unless a wave of the fast kernel raised the context's hint word; the two words are used in turn by
+    consecutive calls and cleared by the call before.  A frame that lists pixels (random G-buffer: roughness 0 under the LPV) and one that lists
+    none (atrium), in every order of succession, each against the general kernel's image of the same frame."""
+    a = util.LightingFrame(256, 144, seed=31, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="random")
+    b = util.LightingFrame(256, 144, seed=32, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    dev = {id(f): f.device_arrays() for f in (a, b)}
+    want = {}
+    hip_ctx.debug_set(force_general=True)
+    for f in (a, b):
+        want[id(f)] = f.run_hip(hip_ctx, dev[id(f)])
+    listed = {}
+    for ppt in (0, 4):
+        hip_ctx.debug_set(force_general=False, force_ppt=ppt)
+        for k, f in enumerate((a, b, b, a, a, b, a, b, b, b, a)):
+            got = f.run_hip(hip_ctx, dev[id(f)])
+            listed[id(f)] = hip_ctx.deferred_pixels()
+            assert np.array_equal(got, want[id(f)]), f"call {k} (pixels per thread {ppt or 'auto'}): the fast path's image differs from the general kernel's"
+    hip_ctx.debug_set(force_general=False, force_ppt=0)
+    assert listed[id(a)] > 0 and listed[id(b)] == 0, listed  # (the two frames are what the test takes them for)
