@@ -208,6 +208,21 @@ VARIANTS["tiled_redo_call"] = (["lighting_tiled.hip"], [
     ("lighting_gi_ext.hpp", "SAH_DEV F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index) {",
      "__device__ __attribute__((noinline)) F3 sample_cascade(const CacheArgs& c, F3 location, F3 direction, uint32_t cascade_index) {"),
 ])
+# The sky workgroups of the fast kernel at the END of the grid instead of interleaved 1 : 4 — would their work fill the tail of the surface
+# workgroups (the launch's last ~6 us run at falling occupancy)?  Same images.
+VARIANTS["fast_sky_last"] = (["lighting.hip"], [
+    ("lighting.hip", "        if (blockIdx.x % (kSkyRatio + 1u) == kSkyRatio) {", "        const uint32_t nsurf_ = gridDim.x / (kSkyRatio + 1u) * kSkyRatio;\n        if (blockIdx.x >= nsurf_) {"),
+    ("lighting.hip", "                const uint32_t gid = ((blockIdx.x / (kSkyRatio + 1u)) * kSkyRatio + k) * 256u + threadIdx.x;",
+     "                const uint32_t gid = ((blockIdx.x - nsurf_) * kSkyRatio + k) * 256u + threadIdx.x;"),
+    ("lighting.hip", "        block_id = blockIdx.x - blockIdx.x / (kSkyRatio + 1u);", "        block_id = blockIdx.x;"),
+])
+# ... and at the START (their depth reads warm nothing, but their arithmetic runs beside the surface workgroups' first loads)
+VARIANTS["fast_sky_first"] = (["lighting.hip"], [
+    ("lighting.hip", "        if (blockIdx.x % (kSkyRatio + 1u) == kSkyRatio) {", "        const uint32_t nsky_ = gridDim.x / (kSkyRatio + 1u);\n        if (blockIdx.x < nsky_) {"),
+    ("lighting.hip", "                const uint32_t gid = ((blockIdx.x / (kSkyRatio + 1u)) * kSkyRatio + k) * 256u + threadIdx.x;",
+     "                const uint32_t gid = (blockIdx.x * kSkyRatio + k) * 256u + threadIdx.x;"),
+    ("lighting.hip", "        block_id = blockIdx.x - blockIdx.x / (kSkyRatio + 1u);", "        block_id = blockIdx.x - nsky_;"),
+])
 for _k, _v in list(VARIANTS.items()):  # (the patch texts above are written with escaped newlines for readability)
     VARIANTS[_k] = (_v[0], [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n")) for f, o, n in _v[1]])
 
