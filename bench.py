@@ -224,6 +224,39 @@ def parse_args(argv=None):
     return args
 
 
+def self_launch(args, argv=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks as a CHILD process —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` —
+    relay its one JSON line to stdout (everything else it wrote there goes to stderr) and return its exit code.  Never exec: this process
+    has not touched the GPU (nothing before this point imports torch; tests/test_bench_host.py holds it to that), and it stays the parent
+    until the ranks have gone."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")  # (torch.distributed.run would set it, with a warning on stdout's neighbour)
+    print("[bench] no launcher around --gpus %d: starting the ranks as a child process: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    line = None
+    for text in child.stdout:
+        if text.startswith('{"metric"'):
+            line = text.rstrip("\n")
+        else:
+            sys.stderr.write(text)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("[bench] the ranks exited with code 0 but printed no result line", file=sys.stderr, flush=True)
+        rc = 4
+    return rc
+
+
 def setup_distributed(args):
     """torch, the process group, this rank's device and the stdout discipline.  Adds: torch, dist, world, rank, local_rank, dev, red_dev, rehearsal,
     exchange, torch_pg, saved_stdout, beat."""
@@ -234,8 +267,9 @@ def setup_distributed(args):
     R.world = int(os.environ.get("WORLD_SIZE", "1"))
     R.rank = int(os.environ.get("RANK", "0"))
     R.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if R.world != args.gpus and R.world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if R.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {R.world}: launch as `python bench.py --gpus N ...` (the file starts its own ranks) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     R.rehearsal = args.rehearse_on_one_gpu and R.world > 1
@@ -884,6 +918,18 @@ def time_with_rebuild(R):
             "note": "the same pass with lpv_generation 0 (k_lpv_pack + the pass in every step), GPU time between two events, after the timed region"}
 
 
+def metric_name(workload, chain, W, H):
+    """`metric` names what the line's `value` counts.  The headline workload carries BASELINE.json's metric verbatim; every other workload says
+    which pass or frame its pixels went through, so that two lines of different workloads are not read as one curve (at N > 1 the default
+    workload is the configs[3] frame, not the N = 1 headline pass)."""
+    if workload == "4k_deferred_gi":
+        return "lit Mpixels/sec (deferred+GI pass) at 4K"
+    res = {(3840, 2160): "4K", (7680, 4320): "8K", (1920, 1080): "1080p", (1280, 720): "720p"}.get((W, H), f"{W}x{H}")
+    if chain:
+        return f"final-image Mpixels/sec ({workload}: lighting + copy scene + bloom + tonemap frame) at {res}"
+    return f"lit Mpixels/sec ({workload} lighting pass) at {res}"
+
+
 def report(R):
     """Rank 0 prints the ONE JSON line."""
     from androidrenderer_amd import _abi
@@ -911,7 +957,7 @@ def report(R):
         par = f"row-shard x{world} + RCCL all-gather of the lit rows"
     gather, lib_gather = R.gather, R.lib_gather
     out = {
-        "metric": "lit Mpixels/sec (deferred+GI pass) at 4K",
+        "metric": metric_name(args.workload, R.chain, W, H),
         "value": None if R.failure else round(value, 1),
         "unit": "Mpixels/s",
         "n_gpus": world,
@@ -961,6 +1007,11 @@ def report(R):
         "roofline": roofline(args.workload, world, achieved, R.kernel_ms_mean, R.kernel_ms_min, R.kernel_scope, R.bytes_per_pixel * R.my_px, R.my_px,
                              "sah::k_lighting_tiled" if (R.n_lights or R.gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),
     }
+    if world > 1:
+        # what a scaling curve of THIS line has to be read against: the same workload unsharded on one of these GPUs, timed by this run (the
+        # N = 1 run of this file measures the headline lighting pass — another workload; value(N) / value(1) across the two is not a speed-up)
+        out["same_workload_on_one_gpu"] = R.single_gpu
+        out["speedup_vs_same_workload_on_one_gpu"] = out["config"]["speedup_vs_same_workload_on_one_gpu"]
     if R.with_rebuild is not None:
         out["config"]["lpv_gather_copy_rebuilt_every_step"] = R.with_rebuild
     if R.longer_run is not None:
@@ -982,6 +1033,8 @@ def report(R):
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
     R = setup_distributed(args)
     make_inputs(R)
     make_context(R)

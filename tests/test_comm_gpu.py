@@ -231,3 +231,21 @@ def test_bench_reports_a_failed_verification_as_a_failure(tmp_path):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["value"] is None and "differ" in d["error"] and d["config"]["sharded_equals_unsharded"] is False
     assert d["config"]["speedup_vs_same_workload_on_one_gpu"] is None
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with no torch.distributed.run around it (the shape of the driver's one-GPU command): the file starts its ranks as
+    a child process and relays their one line and exit code.  The line names the chain's metric and carries the one-GPU reference at its top level."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--rehearse-on-one-gpu", "--ramp-ms", "0"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] is not None and d["config"]["sharded_equals_unsharded"] is True
+    assert "final-image" in d["metric"] and "4k_probe_gi_chain" in d["metric"]
+    assert d["same_workload_on_one_gpu"]["value"] > 0 and "speedup_vs_same_workload_on_one_gpu" in d
