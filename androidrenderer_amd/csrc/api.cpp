@@ -610,6 +610,7 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
                 ctx->dbg_lpv_packs++;
                 ctx->lpv_pack_generation = gen;
                 for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = src[i];
+                sah_lpv_pack_written_by_pack(ctx, lpv.red.width, lpv.red.height, lpv.red.depth);
             }
         }
         fast.sky_enabled = sky.enabled;

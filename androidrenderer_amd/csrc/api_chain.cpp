@@ -104,15 +104,23 @@ struct sah_chain {
 static bool rows_nonempty(const uint32_t r[2]) { return r[1] > r[0]; }
 
 // `body`: the direct calls of one half, enqueued on `st` (the context's current stream).  See HalfGraph.
-template <class Body> static int run_half(sah_chain* c, HalfGraph& g, hipStream_t st, bool may_replay, Body body) {
+// `guard`: the guarded context state the half's calls touch (ctx.hpp: SahCacheGuard), or null.  A replay enqueues the half's kernels without
+// going through the entry points that would mark the guard, so it is marked here: a later user of that state on another stream is then
+// ordered behind the replay by sah_set_stream's event like behind direct calls.
+// An executable graph is destroyed only behind a synchronisation of the stream it was launched on: whether the runtime keeps an exec alive
+// while a launch of it is in flight is not documented for HIP, and the two paths that retire one (a stale capture, a capture whose calls
+// rebuilt something) are rare.
+template <class Body> static int run_half(sah_chain* c, HalfGraph& g, hipStream_t st, bool may_replay, SahCacheGuard* guard, Body body) {
     sah_ctx* ctx = c->ctx;
     if (!c->capture || c->capture_failed || !may_replay || st == nullptr) return body();  // (the null stream cannot be captured)
     if (g.exec && g.epoch == ctx->cache_epoch) {
+        if (guard) HIP_TRY(ctx, sah_guard_touch(ctx, *guard));
         HIP_TRY(ctx, hipGraphLaunch(g.exec, st));
         c->replays++;
         return SAH_OK;
     }
     if (g.exec) {  // stale: something the launches depend on has changed since the capture
+        (void)hipStreamSynchronize(st);  // (earlier replays of it may still be running)
         (void)hipGraphExecDestroy(g.exec);
         g.exec = nullptr;
         g.direct_runs = 0;
@@ -122,6 +130,7 @@ template <class Body> static int run_half(sah_chain* c, HalfGraph& g, hipStream_
         return body();
     }
     const uint64_t epoch_before = ctx->cache_epoch;
+    const uint32_t hint_before = ctx->hint_slot;  // (host state a captured-but-never-run Lighting call has advanced: put back before the half is run directly)
     if (const hipError_t eb = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed); eb != hipSuccess) {
         (void)hipGetLastError();
         c->capture_failed = true;
@@ -141,12 +150,14 @@ template <class Body> static int run_half(sah_chain* c, HalfGraph& g, hipStream_
         c->capture_failed = true;
         c->capture_note = rc != SAH_OK ? "a captured call failed: " + body_error
                                        : (e != hipSuccess ? std::string("hipStreamEndCapture: ") + hipGetErrorString(e) : std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        ctx->hint_slot = hint_before;
         return body();
     }
     (void)hipGraphDestroy(graph);
     HIP_TRY(ctx, hipGraphLaunch(exec, st));
     c->captures++;
     if (ctx->cache_epoch != epoch_before) {  // the captured calls (re)built something: a replay would rebuild it every time.  Used once; captured again next time
+        (void)hipStreamSynchronize(st);
         (void)hipGraphExecDestroy(exec);
         return SAH_OK;
     }
@@ -181,7 +192,7 @@ static int chain_finish(sah_chain* c, uint64_t j) {
     // mips 2.. read every rank's rows of mip 1 (the gather ran behind R(j)); the final gather of frame j - 2 still reads this set's image
     if (s.mip_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.mip_done, 0));
     if (s.final_valid) HIP_TRY(ctx, hipStreamWaitEvent(st, s.final_done, 0));
-    CHAIN_TRY(run_half(c, s.graph_b, st, true, [&]() -> int {
+    CHAIN_TRY(run_half(c, s.graph_b, st, true, &ctx->guard_tonemap, [&]() -> int {
         CHAIN_TRY(sah_bloom_from_mip(ctx, &s.antialiased, &s.bloom, 1));
         if (rows_nonempty(c->plan.out_rows)) CHAIN_TRY(sah_tonemap_ex(ctx, &s.antialiased, &s.bloom, &s.out, c->plan.out_rows[0], c->plan.out_rows[1], c->tonemap_flags));
         return SAH_OK;
@@ -262,7 +273,7 @@ int sah_chain_submit(sah_chain* c, void* lighting_begin, void* lighting_end) {
     CHAIN_TRY(sah_set_stream(ctx, (void*)c->work));
     if (c->reduce != c->work && s.r_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->work, s.r_done, 0));  // lit of this set: last read by R(i - 2)
     // (a caller that wants the Lighting pass timed gets it call by call: its events are not part of a captured graph)
-    CHAIN_TRY(run_half(c, s.graph_l, c->work, !lighting_begin && !lighting_end, [&]() -> int {
+    CHAIN_TRY(run_half(c, s.graph_l, c->work, !lighting_begin && !lighting_end, &ctx->guard_lighting, [&]() -> int {
         if (lighting_begin) HIP_TRY(ctx, hipEventRecord((hipEvent_t)lighting_begin, c->work));
         for (OwnedLighting& l : s.lighting)
             if (l.used) CHAIN_TRY(sah_lighting(ctx, &l.d));
@@ -276,7 +287,7 @@ int sah_chain_submit(sah_chain* c, void* lighting_begin, void* lighting_end) {
         HIP_TRY(ctx, hipStreamWaitEvent(c->reduce, s.l_done, 0));
     }
     if (c->post != c->reduce && s.b_valid) HIP_TRY(ctx, hipStreamWaitEvent(c->reduce, s.b_done, 0));  // antialiased / mips of this set: last read by B(i - 2)
-    CHAIN_TRY(run_half(c, s.graph_r, c->reduce, true, [&]() -> int {
+    CHAIN_TRY(run_half(c, s.graph_r, c->reduce, true, nullptr, [&]() -> int {
         if (rows_nonempty(p.aa_rows) && rows_nonempty(p.mip0_rows)) {  // one pass over lit: antialiased rows + mip 0 rows
             CHAIN_TRY(sah_copy_scene_bloom_mip0_rows(ctx, &s.lit, &s.antialiased, &s.bloom, p.aa_rows[0], p.aa_rows[1], p.mip0_rows[0], p.mip0_rows[1]));
         } else {
@@ -336,6 +347,13 @@ int sah_debug_chain_graphs(const sah_chain* c, uint64_t out[3]) {
 
 void sah_chain_destroy(sah_chain* c) {
     if (!c) return;
+    bool graphs = false;
+    for (FrameSet& s : c->sets) graphs = graphs || s.graph_l.exec || s.graph_r.exec || s.graph_b.exec;
+    if (graphs) {  // replays may still be running: an exec is destroyed behind its streams (see run_half)
+        if (c->ctx) (void)hipSetDevice(c->ctx->device);
+        for (hipStream_t st : {c->work, c->reduce, c->post})
+            if (st) (void)hipStreamSynchronize(st);
+    }
     for (FrameSet& s : c->sets) {
         for (hipEvent_t e : {s.l_done, s.r_done, s.mip_done, s.final_done, s.b_done})
             if (e) (void)hipEventDestroy(e);

@@ -222,7 +222,7 @@ int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all
         if (hs[p].magic != kMagic || (int)hs[p].rank != p || hs[p].bytes != bytes)
             return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "handle %d does not describe rank %d's copy of a %llu-byte buffer", p, p, (unsigned long long)bytes);
     auto& b = s.buffers[id];
-    const uint32_t seq = b.seq;  // counters of a mailbox slot only ever grow: a re-used index goes on counting where the last user stopped
+    const uint32_t seq = b.seq;  // counters of a mailbox slot only grow between resets: a re-used index goes on counting where the last user stopped
     b = {};
     b.seq = seq;
     b.local = (uint8_t*)buffer;
@@ -244,9 +244,12 @@ int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all
 }
 
 // After a gather has given up (SAH_ERR_COMM): the collective way back.  Every rank drains its streams (sah_sync, whatever it returns),
-// all ranks meet (the caller's barrier), every rank calls this, all ranks meet again, and the exchange works as before.  A gather that
-// one rank made and another skipped leaves their sequence numbers apart: each buffer's number is raised to the highest one anybody has
-// signalled — every rank sees the same maximum, because every counter a peer ever stored has landed by the time of the first barrier.
+// all ranks meet (the caller's barrier), every rank calls this, all ranks meet again, and the exchange works as before.
+// Between the two barriers nothing of anybody is in flight, so the exchange starts over from zero: every rank clears its WHOLE mailbox
+// (arrival counters, give-up notes, abort word) and the sequence number of every registration slot.  (Rounds 4-5 raised each number to
+// the highest counter a peer had stored here; a rank that went on enqueueing gathers behind the one that gave up — the ordinary pipelined
+// case: the host notices *timed_out two seconds later — has counted them without ever signalling them, so no rank could see that number
+// and the ranks came back apart: ADVICE r5.)
 int sah_ipc_reset(sah_ctx* ctx) {
     if (!ctx) return SAH_ERR_INVALID_ARGUMENT;
     auto& s = ctx->ipc;
@@ -254,18 +257,8 @@ int sah_ipc_reset(sah_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     (void)hipStreamSynchronize(ctx->stream);
-    std::vector<uint32_t> host(kMailboxWords);
-    HIP_TRY(ctx, hipMemcpy(host.data(), s.mailbox, kMailboxWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (uint32_t id = 0; id < SAH_IPC_MAX_BUFFERS; id++) {
-        uint32_t m = s.buffers[id].seq;
-        for (int p = 0; p < ctx->world; p++) {
-            if (p == ctx->rank) continue;
-            for (uint32_t v : {host[id * SAH_IPC_MAX_WORLD + p], host[(SAH_IPC_MAX_BUFFERS + id) * SAH_IPC_MAX_WORLD + p]})
-                if ((int32_t)(v - m) > 0) m = v;
-        }
-        s.buffers[id].seq = m;
-    }
-    HIP_TRY(ctx, hipMemset(s.mailbox + kNotesBase, 0, (kMailboxAlloc - kNotesBase) * sizeof(uint32_t)));  // the peers' notes and the abort word
+    HIP_TRY(ctx, hipMemset(s.mailbox, 0, kMailboxAlloc * sizeof(uint32_t)));
+    for (auto& b : s.buffers) b.seq = 0;
     *s.timed_out = 0;
     ctx->comm_pending = false;
     return SAH_OK;

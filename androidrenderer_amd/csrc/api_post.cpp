@@ -400,11 +400,14 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         a[i] = varg(a_rgb[i]);
         b[i] = varg(b_rgb[i]);
     }
-    // (arguments are in order: from here on the volumes change, and the Lighting pass's gather copy of them is stale — the epoch follows at the end)
+    // (arguments are in order: from here on the volumes change, and the Lighting pass's gather copy of them is stale.  The epoch moves WITH the
+    // drop: an early return below — a failed launch, a failed reserve — leaves a dropped or half-written copy, and a captured Lighting half that
+    // reads it must not be replayed: ADVICE r5.  Only the success path that ends where it began takes the move back, at the end.)
     const uint32_t prev_gen = ctx->lpv_pack_generation;
+    const uint64_t epoch_in = ctx->cache_epoch;
     sah::VolumeArg prev_src[3];
     for (int i = 0; i < 3; i++) prev_src[i] = ctx->lpv_pack_source[i];
-    ctx->lpv_pack_generation = 0;
+    sah_drop_lpv_copy(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->lpv_tables_built) {  // the 30 direction pairs' SH / lobe vectors, into this device's constant memory, once per context
         HIP_TRY(ctx, sah::launch_lpv_build_tables(ctx->stream));
@@ -425,6 +428,7 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
         HIP_TRY(ctx, sah_guard_touch(ctx, ctx->guard_lighting));
         HIP_TRY(ctx, sah_lpv_pack_reserve(ctx, pk.total));
         if (!ctx->state) emits = false;  // (made by sah_create; a context without it has no fast Lighting path either)
+        if (emits) HIP_TRY(ctx, sah_lpv_pack_borders_for(ctx, last[0].width, last[0].height, last[0].depth, pk.total));
         emit = {ctx->lpv_packed, pk.row_pitch, pk.slice_pitch, ctx->state};
     }
     for (uint32_t s = 0; s < steps; s++) {
@@ -440,7 +444,8 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
     // the Lighting pass that follows enqueues what it enqueued the frame before.  Anything else is a change.
     bool same = emits && prev_gen == SAH_GENERATION_TRACKED;
     for (int i = 0; i < 3 && same; i++) same = same_volume(prev_src[i], last[i]);
-    if (!same && (prev_gen != 0 || emits)) ctx->cache_epoch++;
+    if (same && ctx->cache_epoch == epoch_in + 1) ctx->cache_epoch = epoch_in;  // (nothing but the drop above has moved it: no reallocation, no other layout)
+    else if (!same && emits && prev_gen == 0) ctx->cache_epoch++;               // a copy came into being
     return SAH_OK;
 }
 

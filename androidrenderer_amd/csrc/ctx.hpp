@@ -51,6 +51,11 @@ struct sah_ctx {
     size_t lpv_packed_bytes = 0;
     uint32_t lpv_pack_generation = 0;  // sah_gi::lpv_generation the gather copy was built for (0: not reusable)
     sah::VolumeArg lpv_pack_source[3] = {};
+    // the volume extent whose two-texel border of the gather copy holds zeros ({0,0,0} + lpv_pack_all_zero: a new allocation, zero everywhere).
+    // The buffer is grow-only and shared by every extent it is asked for: k_lpv_pack writes the border itself, the emitting propagation step
+    // writes interior texels only and needs the border of ITS extent to be zero already (sah_lpv_pack_borders_for)
+    uint32_t lpv_pack_extent[3] = {0, 0, 0};
+    bool lpv_pack_all_zero = false;
     float* colx_table = nullptr;       // device: per-column view-space x numerators of the fast kernel, two flavours (lighting.hip: k_colx_table)
     uint32_t colx_capacity = 0, colx_width = 0;
     float colx_key[7] = {};            // render_resolution, p0, p12, p5, p13, height the tables were built for
@@ -206,7 +211,26 @@ inline hipError_t sah_lpv_pack_reserve(sah_ctx* ctx, uint64_t total) {
     e = hipMalloc((void**)&ctx->lpv_packed, total);
     if (e != hipSuccess) return e;
     ctx->lpv_packed_bytes = total;
+    ctx->lpv_pack_extent[0] = ctx->lpv_pack_extent[1] = ctx->lpv_pack_extent[2] = 0;
+    ctx->lpv_pack_all_zero = true;
     return hipMemsetAsync(ctx->lpv_packed, 0, total, ctx->stream);
+}
+// k_lpv_pack has been enqueued for a w x h x d volume: interior and border of that layout are its own
+inline void sah_lpv_pack_written_by_pack(sah_ctx* ctx, uint32_t w, uint32_t h, uint32_t d) {
+    ctx->lpv_pack_extent[0] = w, ctx->lpv_pack_extent[1] = h, ctx->lpv_pack_extent[2] = d;
+    ctx->lpv_pack_all_zero = false;
+}
+// The emitting propagation step is about to store the interior texels of a w x h x d layout: the border texels of THAT layout must hold zeros.
+// They do in a new allocation and after any writer of the same extent; a buffer last laid out for another extent (a context that lit a
+// 128 x 32 x 32 volume and now propagates three cascades: the grow-only buffer is not reallocated) holds old interior texels where the new
+// border lies — cleared here, on ctx->stream, ahead of the steps.
+inline hipError_t sah_lpv_pack_borders_for(sah_ctx* ctx, uint32_t w, uint32_t h, uint32_t d, uint64_t total) {
+    const bool same = ctx->lpv_pack_extent[0] == w && ctx->lpv_pack_extent[1] == h && ctx->lpv_pack_extent[2] == d;
+    hipError_t e = hipSuccess;
+    if (!same && !ctx->lpv_pack_all_zero) e = hipMemsetAsync(ctx->lpv_packed, 0, total, ctx->stream);
+    ctx->lpv_pack_extent[0] = w, ctx->lpv_pack_extent[1] = h, ctx->lpv_pack_extent[2] = d;
+    ctx->lpv_pack_all_zero = false;
+    return e;
 }
 
 // Uniform sub-expressions of sky_unified.slang:80-135 for a sun direction as get_sky_color() receives it (`sun_dir`): the Lighting pass's sky

@@ -214,12 +214,24 @@ __global__ void __launch_bounds__(256) k_colx_table(const LightingArgs a, const 
 constexpr uint32_t kSkyRatio = 4;  // surface workgroups per sky workgroup (1, 2, 8, 16 measured worse: DESIGN.md §5 "Deferred pixels ... and the sky")
 
 // ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
+// Waves per SIMD the SKY = true body is held to (its 256-thread workgroup is one wave per SIMD, so this is __launch_bounds__' second argument).
+// The sky path needs 126-137 VGPRs (two fp64 transcendentals per pixel) whatever the surface path next to it needs; left alone, the allocator gives
+// the WHOLE kernel that count: 3-4 waves per SIMD where the surface path by itself (SKY = false) runs 5-8 — and the small launches these bodies serve
+// (a 1280 x 720 frame, a rank's row band: api.cpp's launch-size rule) have nothing but occupancy to hide latency with.  The bound is the sky-less
+// body's own occupancy less one (never below four); what the sky path does not fit it spills, and only sky waves run that code
+// (tools/kernel_resources.py: profiles/r6_fast_resources.txt).
+template <int SUN, int GI, int PPT> constexpr int fast_sky_waves() {
+    // VGPRs of k_lighting_fast<SUN, GI, PPT, false> (gfx950, ROCm 7.2): rows SUN = off / CSM / RT, columns (GI none | LPV) x PPT (4, 2, 1)
+    constexpr int vgprs[3][2][3] = {{{45, 24, 15}, {104, 87, 57}}, {{66, 51, 41}, {108, 93, 65}}, {{70, 49, 42}, {119, 98, 80}}};
+    constexpr int v = vgprs[SUN][GI][PPT == 4 ? 0 : (PPT == 2 ? 1 : 2)];
+    constexpr int own = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : v <= 128 ? 4 : 3;  // 512 registers per lane and SIMD, granule 8
+    return own - 1 < 4 ? 4 : own - 1;
+}
+
 template <int SUN, int GI, int PPT, bool SKY>
 // (106 VGPRs at 4 px/thread = 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 36-44 bytes per lane and is 12-20 %
 // slower, measured.)
-// (With the sky path in the kernel the allocator would take 137 VGPRs = 3 waves per SIMD for every wave; the bound keeps the surface
-// path's 4 — the sky path, 4 % of the frame, spills the difference.)
-__global__ void __launch_bounds__(256, (SKY && PPT == 4) ? 4 : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
+__global__ void __launch_bounds__(256, (SKY ? fast_sky_waves<SUN, GI, PPT>() : 1)) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
                                                                                  const FastArgs f) {
     // Sky.  ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206): those pixels need their
     // coordinates and two fp64 transcendentals each, nothing of the surface code.  With a sky bound, one workgroup in kSkyRatio + 1

@@ -115,7 +115,7 @@ class LightingInputs:
                 gi.lpv_green = images.volume(arrays["lpv_g"], _abi.FORMAT_R16G16B16A16_SFLOAT)
                 gi.lpv_blue = images.volume(arrays["lpv_b"], _abi.FORMAT_R16G16B16A16_SFLOAT)
                 gi.lpv_cascades = C.cast(self.lpv.matrices, C.POINTER(_abi.LpvCascadeMatrices))
-                gi.lpv_num_cascades = 4
+                gi.lpv_num_cascades = getattr(self, "lpv_num_cascades", 4)  # (volumes are (32 * cascades) x 32 x 32)
                 gi.lpv_exposure = float(np.float32(math.pi) * np.float32(10.0))
                 gi.lpv_generation = getattr(self, "lpv_generation", 0)  # 0: the library rebuilds its gather copy of the volumes on every call
             elif self.gi_kind == _abi.GI_CACHE:

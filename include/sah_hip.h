@@ -707,9 +707,10 @@ int sah_ipc_unregister(sah_ctx* ctx, const void* buffer);
  * before it copies).  What the caller must NOT do on the error is free or unregister a gathered buffer at once: a peer that saw no
  * error yet may be in the middle of its copy into it.  The order out of the state, on EVERY rank:
  *     sah_sync (drain; it reports the error once more)  ->  barrier over the caller's own channel  ->  sah_ipc_reset  ->  barrier
- * after which gathers work again (a gather one rank made and another skipped has left their sequence numbers apart: sah_ipc_reset
- * raises every buffer's number to the highest one any rank has signalled, which every rank reads identically after the first barrier)
- * and buffers may be unregistered and freed as usual.  A no-op on a context that has not opened the exchange. */
+ * after which gathers work again and buffers may be unregistered and freed as usual.  Gathers that one rank made (or merely enqueued
+ * behind the one that gave up) and another skipped have left their sequence numbers apart; nothing is in flight between the two barriers,
+ * so sah_ipc_reset starts the exchange over from zero: it clears this rank's whole mailbox (arrival counters, give-up notes, abort word) and
+ * the sequence number of every registration slot.  A no-op on a context that has not opened the exchange. */
 int sah_ipc_reset(sah_ctx* ctx);
 
 /* ---- the row-sharded frame as a loop of this library (no reference counterpart: north_star's "shard by screen-tile rows, all-gather the

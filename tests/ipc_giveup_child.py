@@ -3,7 +3,9 @@ through the direct exchange (sah_ipc_*).  Gather 1 works.  Gather 2 is made by r
 (include/sah_hip.h, sah_ipc_reset): rank 0's sah_sync returns SAH_ERR_COMM after about two seconds, its next gather fails at once, and it
 has copied nothing into rank 1's buffer; rank 1, arriving late, finds its own ready-wait satisfied, does NOT copy into rank 0 (which has
 posted its give-up note), and gives up on the done-wait in turn.  Then the documented way out — sync, barrier, sah_ipc_reset, barrier —
-and gather 3 works on both.  Results go to <out_dir>/rank<r>.json."""
+and gather 3 works on both.  With a fourth argument "pipelined" rank 0 enqueues THREE gathers before it looks (the ordinary pipelined
+case: the host learns of the give-up two seconds late; the later gathers are counted on rank 0 and never signalled — ADVICE r5), and two
+gathers must work after the reset.  Results go to <out_dir>/rank<r>.json."""
 import json
 import os
 import sys
@@ -15,6 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, out_dir, port = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+    pipelined = len(sys.argv) > 4 and sys.argv[4] == "pipelined"
     world = 2
     import torch
     import torch.distributed as dist
@@ -57,7 +60,8 @@ def main():
     if rank == 1:
         time.sleep(3.0)
     t0 = time.perf_counter()
-    ctx.allgather_bytes(buf.data_ptr(), n)
+    for _ in range(3 if (pipelined and rank == 0) else 1):
+        ctx.allgather_bytes(buf.data_ptr(), n)
     try:
         ctx.sync()
         res["gather2_status"] = 0
@@ -87,6 +91,12 @@ def main():
     ctx.allgather_bytes(buf.data_ptr(), n)
     ctx.sync()
     res["gather3_ok"] = gathered_ok(30)
+    dist.barrier()
+    fill(40)
+    dist.barrier()
+    ctx.allgather_bytes(buf.data_ptr(), n)
+    ctx.sync()
+    res["gather4_ok"] = gathered_ok(40)
     dist.barrier()
     ctx.ipc_unregister(buf.data_ptr())
     json.dump(res, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))

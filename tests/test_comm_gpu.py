@@ -120,19 +120,23 @@ def test_two_rank_chain_direct_exchange_across_devices(tmp_path):
     _check_chain_children(tmp_path, 97)
 
 
-def test_direct_exchange_gives_up_and_recovers(tmp_path):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_direct_exchange_gives_up_and_recovers(tmp_path, pipelined):
     """The give-up path of the direct exchange: one rank skips a gather for three seconds.  The other's sah_sync must report
     SAH_ERR_COMM after about two, stay failed, and have copied nothing into the late peer; the late peer must not copy into the rank that
-    gave up; and sync -> barrier -> sah_ipc_reset -> barrier must bring both back (tests/ipc_giveup_child.py, two processes on GPU 0)."""
+    gave up; and sync -> barrier -> sah_ipc_reset -> barrier must bring both back (tests/ipc_giveup_child.py, two processes on GPU 0).
+    `pipelined`: the rank that is alone has three gathers enqueued before it looks (the reset must not depend on counters nobody signalled)."""
     import json
     port = 29800 + (os.getpid() % 150)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_giveup_child.py"), str(r), str(tmp_path), str(port)], env=env) for r in range(2)]
+    port += 11 if pipelined else 0
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_giveup_child.py"), str(r), str(tmp_path), str(port)] + (["pipelined"] if pipelined else []),
+                              env=env) for r in range(2)]
     rcs = [p.wait(timeout=120) for p in procs]
     assert rcs == [0, 0], rcs
     r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
     for r in (r0, r1):
-        assert r["gather1_ok"] and r["gather3_ok"], r
+        assert r["gather1_ok"] and r["gather3_ok"] and r["gather4_ok"], r
         assert r["gather2_status"] == _abi.SAH_ERR_COMM and r["gather_after_giveup_status"] == _abi.SAH_ERR_COMM, r
         assert r["peer_slot_untouched"], r
         assert r["gather_after_giveup_seconds"] < 0.5, r

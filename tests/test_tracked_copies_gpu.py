@@ -29,11 +29,11 @@ def _volumes(arrs):
     return [images.volume(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in arrs]
 
 
-def _oracle_propagate(a_np, b_np, steps):
+def _oracle_propagate(a_np, b_np, steps, num_cascades=4):
     o = util.oracle()
     a = (_abi.Volume * 3)(*_volumes(a_np))
     b = (_abi.Volume * 3)(*_volumes(b_np))
-    assert o.orc_lpv_propagate(a, b, 4, steps) == 0
+    assert o.orc_lpv_propagate(a, b, num_cascades, steps) == 0
 
 
 @pytest.mark.parametrize("steps", [1, 2, 5])
@@ -90,6 +90,51 @@ def test_tracked_copy_is_dropped_by_the_other_writers_and_by_other_volumes(ctx):
     for k in keys:
         f.arrays[k] = np.zeros_like(f.arrays[k])
     assert int(util.f16_ulp_diff(got_clear, f.run_oracle()).max()) == 0
+
+
+def test_emitted_copy_after_the_buffer_held_another_extent(ctx):
+    """The gather copy's buffer is grow-only and shared by every extent: a context that has lit a four-cascade volume (128 x 32 x 32:
+    k_lpv_pack fills the layout of THAT extent) and then propagates three cascades (96 x 32 x 32) emits interior texels into a layout whose border
+    positions hold the old interior — the emitting step must find them cleared, or CLAMP_TO_BORDER taps at the volume's edges read old light."""
+    import torch
+    keys = ("lpv_r", "lpv_g", "lpv_b")
+    f4 = util.LightingFrame(160, 96, seed=66, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    for k in keys:  # dense, bright volumes: every texel of the 128-wide layout non-zero
+        f4.arrays[k] = (np.abs(f4.arrays[k].astype(np.float32)) + 1.0).astype(np.float16)
+    assert int(util.f16_ulp_diff(f4.run_hip(ctx), f4.run_oracle()).max()) == 0 and ctx.copy_rebuilds()[0] == 1
+    f3 = util.LightingFrame(160, 96, seed=66, sun_mode=_abi.SHADOW_MODE_CSM, gi=_abi.GI_LPV, flavour="atrium")
+    f3.lpv_num_cascades = 3
+    for k in keys:
+        f3.arrays[k] = np.ascontiguousarray(f3.arrays[k][:, :, :96, :])
+    a_np = [f3.arrays[k].view(np.uint16).copy() for k in keys]
+    b_np = [np.zeros_like(a) for a in a_np]
+    _oracle_propagate(a_np, b_np, 1, num_cascades=3)
+    dev = f3.device_arrays()
+    a_t = [dev[k] for k in keys]
+    b_t = [torch.zeros_like(t) for t in a_t]
+    ctx.lpv_propagate(_volumes(a_t), _volumes(b_t), 3, 1)
+    for k, t, ref in zip(keys, b_t, b_np):
+        assert np.array_equal(util.from_torch(t, np.uint16).reshape(ref.shape), ref), k
+        dev[k] = t
+        f3.arrays[k] = ref.view(np.float16)
+    f3.lpv_generation = _abi.GENERATION_TRACKED
+    got = f3.run_hip(ctx, dev)
+    assert ctx.copy_rebuilds()[0] == 1, "the Lighting pass rebuilt the copy the propagation had just written"
+    assert int(util.f16_ulp_diff(got, f3.run_oracle()).max()) == 0
+    # ... and back to four cascades through the emitting step, over the three-cascade layout
+    a4 = [util.to_torch(f4.arrays[k].view(np.uint16)) for k in keys]
+    b4 = [torch.zeros_like(t) for t in a4]
+    a4_np = [f4.arrays[k].view(np.uint16).copy() for k in keys]
+    b4_np = [np.zeros_like(a) for a in a4_np]
+    _oracle_propagate(a4_np, b4_np, 1)
+    ctx.lpv_propagate(_volumes(a4), _volumes(b4), 4, 1)
+    dev4 = f4.device_arrays()
+    for k, t, ref in zip(keys, b4, b4_np):
+        dev4[k] = t
+        f4.arrays[k] = ref.view(np.float16)
+    f4.lpv_generation = _abi.GENERATION_TRACKED
+    got4 = f4.run_hip(ctx, dev4)
+    assert ctx.copy_rebuilds()[0] == 1 and int(util.f16_ulp_diff(got4, f4.run_oracle()).max()) == 0
 
 
 def test_emitted_copy_flags_non_finite_texels_like_the_pack_kernel(ctx):
