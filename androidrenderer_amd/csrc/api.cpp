@@ -614,6 +614,22 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
             }
         }
         fast.sky_enabled = sky.enabled;
+        {   // The sky workgroups of the fast kernel (lighting.hip): they LEAD the grid, one per `sky_ratio` surface workgroups.  Leading: a thread
+            // of a sky workgroup walks sky_ratio * ppt pixels one after the other (~900 instructions per sky pixel), and a walk that starts with the
+            // launch's last workgroups is the launch's tail (the atrium's sky is its last rows: 1280 x 720 22.8 -> 17.8 us, 1920 x 1080 55.5 -> 50.6,
+            // 4K CSM only 121.7 -> 113.8 leading instead of interleaved 1 : 4).  How many: about 512 of them — half a round of the chip's 1,024
+            // workgroup slots, two sky waves on every SIMD of a sky-heavy frame; more only hold slots in front of the surface workgroups to find
+            // nothing (4K: 2,025 sky workgroups 0.1649 ms, 506 0.1615), fewer make the walk the critical path of a short launch (1920 x 1080: 127
+            // sky workgroups 0.058 ms against 0.0507 with 506).  tools/experiments/r6/README.md §2.
+            static const int env_ratio = getenv("SAH_SKY_RATIO") ? atoi(getenv("SAH_SKY_RATIO")) : 0;  // experiments (tools/experiments/r6)
+            static const int env_interleaved = getenv("SAH_SKY_INTERLEAVED") ? atoi(getenv("SAH_SKY_INTERLEAVED")) : 0;
+            const uint64_t blocks = ((uint64_t)(W / (uint32_t)ppt) * (r1 - r0) + 255) / 256;
+            const uint64_t want = (blocks + 511) / 512;
+            fast.sky_ratio = (uint32_t)(want < 4 ? 4 : (want > 32 ? 32 : want));
+            if (env_ratio > 0) fast.sky_ratio = (uint32_t)env_ratio;
+            fast.sky_first = env_interleaved ? 0u : 1u;  // (lighting.hip's launcher turns the flag into the number of sky workgroups)
+            if (env_interleaved && env_ratio <= 0) fast.sky_ratio = 4;  // (rounds 2-5: every fifth workgroup)
+        }
         {  // thread index -> (row, group in row) by a multiply-high: exact while gid * groups_per_row < 2^32 (magic = floor(2^32 / d) + 1)
             const uint64_t gpr = W / (uint32_t)ppt, threads = (gpr * (r1 - r0) + 255) / 256 * 256;
             fast.row_magic = (gpr >= 2 && threads * gpr < (1ull << 32)) ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u;

@@ -211,40 +211,34 @@ __global__ void __launch_bounds__(256) k_colx_table(const LightingArgs a, const 
     }
 }
 
-constexpr uint32_t kSkyRatio = 4;  // surface workgroups per sky workgroup (1, 2, 8, 16 measured worse: DESIGN.md §5 "Deferred pixels ... and the sky")
+// surface workgroups per sky workgroup: FastArgs::sky_ratio, chosen by the host with the launch (api.cpp: a whole 4K frame 4 — 1, 2, 8, 16 measured
+// worse: DESIGN.md §5 "Deferred pixels ... and the sky" —; small launches fewer, so that a thread of a sky workgroup over an all-sky stretch walks
+// fewer pixels one after the other: that walk is the launch's critical path when the launch is short)
 
 // ---- fast kernel (per-pixel body: lighting_fast.hpp) ----------------------------------------------------------------------
-// Waves per SIMD the SKY = true body is held to (its 256-thread workgroup is one wave per SIMD, so this is __launch_bounds__' second argument).
-// The sky path needs 126-137 VGPRs (two fp64 transcendentals per pixel) whatever the surface path next to it needs; left alone, the allocator gives
-// the WHOLE kernel that count: 3-4 waves per SIMD where the surface path by itself (SKY = false) runs 5-8 — and the small launches these bodies serve
-// (a 1280 x 720 frame, a rank's row band: api.cpp's launch-size rule) have nothing but occupancy to hide latency with.  The bound is the sky-less
-// body's own occupancy less one (never below four); what the sky path does not fit it spills, and only sky waves run that code
-// (tools/kernel_resources.py: profiles/r6_fast_resources.txt).
-template <int SUN, int GI, int PPT> constexpr int fast_sky_waves() {
-    // VGPRs of k_lighting_fast<SUN, GI, PPT, false> (gfx950, ROCm 7.2): rows SUN = off / CSM / RT, columns (GI none | LPV) x PPT (4, 2, 1)
-    constexpr int vgprs[3][2][3] = {{{45, 24, 15}, {104, 87, 57}}, {{66, 51, 41}, {108, 93, 65}}, {{70, 49, 42}, {119, 98, 80}}};
-    constexpr int v = vgprs[SUN][GI][PPT == 4 ? 0 : (PPT == 2 ? 1 : 2)];
-    constexpr int own = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : v <= 128 ? 4 : 3;  // 512 registers per lane and SIMD, granule 8
-    return own - 1 < 4 ? 4 : own - 1;
-}
-
 template <int SUN, int GI, int PPT, bool SKY>
 // (106 VGPRs at 4 px/thread = 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 36-44 bytes per lane and is 12-20 %
 // slower, measured.)
-__global__ void __launch_bounds__(256, (SKY ? fast_sky_waves<SUN, GI, PPT>() : 1)) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
+// (The sky path — two fp64 transcendentals per pixel — wants 126-137 VGPRs whatever stands next to it, and a kernel has ONE register count: left
+// alone the allocator takes 133-137 = 3 waves per SIMD for every wave of the 4- and 2-pixel bodies.  The bound holds every SKY body at four waves
+// per SIMD: the 4-pixel body spills 12 bytes of the sky path, the others nothing.  Holding the SKY bodies at their sky-less twins' occupancy (5-8
+// waves: 72-96 VGPRs) was built and measured in round 6: the sky path then spills 160-236 bytes per lane and its waves become the launch's tail —
+// 1280 x 720 0.0222 -> 0.0380 ms, 4K CSM only 0.118 -> 0.151: tools/experiments/r6/README.md §2.)
+__global__ void __launch_bounds__(256, SKY ? 4 : 1) k_lighting_fast(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const SkyArgs sky,
                                                                                  const FastArgs f) {
     // Sky.  ProceduralSky::render_sky overwrites lit_scene where depth == 0 (sky_unified.slang:185-206): those pixels need their
-    // coordinates and two fp64 transcendentals each, nothing of the surface code.  With a sky bound, one workgroup in kSkyRatio + 1
-    // is a sky workgroup: it reads the depth of the pixels of the kSkyRatio surface workgroups before it and shades the sky among them;
+    // coordinates and two fp64 transcendentals each, nothing of the surface code.  With a sky bound, one workgroup in sky_ratio + 1
+    // is a sky workgroup: it reads the depth of the pixels of the sky_ratio surface workgroups before it and shades the sky among them;
     // surface workgroups leave those pixels alone.  Interleaved like this the sky's arithmetic fills issue slots the surface waves leave
     // idle (as a kernel of its own behind this one it cost 20 us on the 4 % of sky in the atrium frame: one busy wave per SIMD, in series).
     uint32_t block_id = blockIdx.x;
     if (SKY) {
-        if (blockIdx.x % (kSkyRatio + 1u) == kSkyRatio) {
+        const uint32_t ratio = f.sky_ratio, period = ratio + 1u, turn = f.sky_first ? blockIdx.x : blockIdx.x / period;
+        if (f.sky_first ? blockIdx.x < f.sky_first : blockIdx.x - turn * period == ratio) {
             const uint32_t groups_per_row = a.width / PPT, total = groups_per_row * (a.row_end - a.row_begin);
 #pragma unroll 1
-            for (uint32_t k = 0; k < kSkyRatio; k++) {
-                const uint32_t gid = ((blockIdx.x / (kSkyRatio + 1u)) * kSkyRatio + k) * 256u + threadIdx.x;
+            for (uint32_t k = 0; k < ratio; k++) {
+                const uint32_t gid = (turn * ratio + k) * 256u + threadIdx.x;
                 if (gid >= total) break;
                 const uint32_t ry = gid / groups_per_row, y = a.row_begin + ry, x0 = (gid - ry * groups_per_row) * PPT;
                 uint32_t wz[PPT];
@@ -259,7 +253,7 @@ __global__ void __launch_bounds__(256, (SKY ? fast_sky_waves<SUN, GI, PPT>() : 1
             }
             return;
         }
-        block_id = blockIdx.x - blockIdx.x / (kSkyRatio + 1u);
+        block_id = f.sky_first ? blockIdx.x - f.sky_first : blockIdx.x - turn;
     }
     // the thread's plane loads are requested first: the LUT staging and its barrier below then overlap their latency
     const uint32_t groups_per_row = a.width / PPT;
@@ -426,7 +420,11 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     const dim3 block(256);
     auto launch = [&](auto ppt_c) {
         constexpr int P = decltype(ppt_c)::value;
-        if (sky.enabled) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, true>), dim3((kSkyRatio + 1u) * ((blocks + kSkyRatio - 1u) / kSkyRatio)), block, 0, st, a, csm, lpv, sky, f);
+        if (sky.enabled && f.sky_first) {
+            FastArgs g = f;
+            g.sky_first = (blocks + f.sky_ratio - 1u) / f.sky_ratio;
+            hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, true>), dim3(g.sky_first + blocks), block, 0, st, a, csm, lpv, sky, g);
+        } else if (sky.enabled) hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, true>), dim3((f.sky_ratio + 1u) * ((blocks + f.sky_ratio - 1u) / f.sky_ratio)), block, 0, st, a, csm, lpv, sky, f);
         else hipLaunchKernelGGL((k_lighting_fast<SUN, GI, P, false>), dim3(blocks), block, 0, st, a, csm, lpv, sky, f);
     };
     if (ppt == 4) launch(std::integral_constant<int, 4>{});

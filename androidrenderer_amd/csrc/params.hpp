@@ -104,6 +104,8 @@ struct FastArgs {
     uint32_t ncasc_pow2;
     uint32_t pos_div_nr;  // view-space position quotients may use the shared-reciprocal divide (lighting_fast.hpp)
     uint32_t sky_enabled;
+    uint32_t sky_ratio;  // surface workgroups per sky workgroup of k_lighting_fast's grid (lighting.hip); >= 1
+    uint32_t sky_first;  // 0: every (sky_ratio + 1)-th workgroup of the grid is a sky workgroup; else the number of sky workgroups, which lead the grid
     uint32_t row_magic;  // floor(2^32 / groups per row) + 1 when mulhi(gid, row_magic) == gid / groups_per_row for every thread of the call, else 0
     uint32_t repack;       // 1: this call rebuilds the gather copy first
     const float* colx_tab; // per-column view-space x numerators (k_colx_table): [0, width) the GLSL flavour, [colx_stride, ..) the Slang one; or null
