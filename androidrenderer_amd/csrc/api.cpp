@@ -28,7 +28,6 @@ hipError_t launch_bloom_downsample(const PlaneArg& src, uint32_t sw, uint32_t sh
 struct TonemapArgs;
 hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
-hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, hipStream_t st);
 }  // namespace sah
 
 #include "ctx.hpp"

@@ -24,8 +24,8 @@ hipError_t launch_tonemap(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st);
 hipError_t launch_tonemap_axis_tables(const TonemapArgs& t, TmAxis* out, hipStream_t st);
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st);
-hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, const LpvPackEmit* emit, hipStream_t st);
-hipError_t launch_lpv_build_tables(hipStream_t st);
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, const LpvPackEmit* emit, int mode, hipStream_t st);
+hipError_t launch_lpv_build_tables(hipStream_t st, bool* hot_structure);
 hipError_t launch_sky_luts(const PlaneArg& transmittance, const PlaneArg& multiscattering, const PlaneArg& sky_view, const float light_vector[3], hipStream_t st);
 hipError_t launch_fill_r32f(const PlaneArg& dst, uint32_t w, uint32_t h, float value, hipStream_t st);
 hipError_t launch_probe_copy(const ProbeAtlasArgs& src, const ProbeAtlasArgs& dst, const float movement[4][3], hipStream_t st);
@@ -410,9 +410,16 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
     sah_drop_lpv_copy(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->lpv_tables_built) {  // the 30 direction pairs' SH / lobe vectors, into this device's constant memory, once per context
-        HIP_TRY(ctx, sah::launch_lpv_build_tables(ctx->stream));
+        HIP_TRY(ctx, sah::launch_lpv_build_tables(ctx->stream, &ctx->lpv_hot_structure));
         ctx->lpv_tables_built = true;
     }
+    // lpv.hip: the hot form of the 30 direction pairs (finite coefficients; the three colours of a cell in one thread) when the tables the device
+    // built have the structure it relies on; the general form for a context under sah_debug_set(force_general) — the tests' cross-check
+    static const int env_mode = getenv("SAH_LPV_MODE") ? atoi(getenv("SAH_LPV_MODE")) : -1;  // experiments: 0 general, 1 hot, 3 hot + three colours per thread
+    bool offsets32 = true;  // (the hot kernels address a volume by 32-bit byte offsets)
+    for (int i = 0; i < 3; i++)
+        offsets32 = offsets32 && (uint64_t)a[i].slice_pitch * a[i].depth < (1ull << 32) && (uint64_t)b[i].slice_pitch * b[i].depth < (1ull << 32);
+    const int mode = (!ctx->lpv_hot_structure || ctx->force_general || !offsets32) ? 0 : ((env_mode == 0 || env_mode == 1 || env_mode == 3) ? env_mode : 1);
     // light_propagation_volume.cpp:1016-1034: `steps` dispatches ping-ponging A -> B -> A ...  (Two steps per launch — 8^3 bricks with
     // their halo in LDS, bit-identical — were measured: 28 us per pair against 2 x 9.3 us, 1.5x the arithmetic in longer dependency
     // chains; not kept.)
@@ -433,8 +440,8 @@ int sah_lpv_propagate(sah_ctx* ctx, const sah_volume a_rgb[3], const sah_volume 
     }
     for (uint32_t s = 0; s < steps; s++) {
         const sah::LpvPackEmit* e = (emits && s + 1 == steps) ? &emit : nullptr;
-        if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, e, ctx->stream));
-        else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, e, ctx->stream));
+        if ((s & 1) == 0) HIP_TRY(ctx, sah::launch_lpv_propagate(a, b, num_cascades, e, mode, ctx->stream));
+        else HIP_TRY(ctx, sah::launch_lpv_propagate(b, a, num_cascades, e, mode, ctx->stream));
     }
     if (emits) {
         ctx->lpv_pack_generation = SAH_GENERATION_TRACKED;

@@ -32,6 +32,7 @@ struct sah_ctx {
     hipEvent_t probe_done = nullptr;  // behind the last sah_probe_update (its clear pass leaves probe_slots all zero again)
     hipStream_t probe_stream = nullptr;  // the stream that update ran on: an update on another stream waits for probe_done first
     bool lpv_tables_built = false;  // lpv.hip: c_prop_tables of this device filled (first sah_lpv_propagate)
+    bool lpv_hot_structure = false;  // ... and, read back, they have the structure the hot form of the propagation relies on (lpv.hip)
     void* comm = nullptr;   // ncclComm_t
     void* comm_reversed = nullptr;  // ncclComm_t with rank world - 1 - rank (sah_allgather_rows_reversed), made on first use
     void* rccl = nullptr;   // dlopen handle

@@ -5,6 +5,8 @@
 // One thread per cell; the three colour volumes are 1 MiB each and stay in the per-XCD L2 between steps.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/sah_hip.h"
 #include "numerics.hpp"
 #include "params.hpp"
@@ -80,6 +82,7 @@ struct PropArgs {
     uint8_t* packed;
     uint32_t pk_row_pitch, pk_slice_pitch;
     FrameState* state;
+    uint32_t hot;  // the tables have the structure propagate_from_hot relies on: waves with finite coefficients take it
 };
 
 // tables of the 30 direction pairs: built once per context into device memory (k_build_prop_tables) and read by the propagate kernels
@@ -124,9 +127,205 @@ SAH_DEV H4 propagate_from(const PropTables& T, const H4 (&coef)[6]) {
     return acc;
 }
 
+// ---- the same 30 direction pairs for FINITE coefficients, at half the arithmetic (round 6) ------------------------------------------------
+// Of the 4 + 4 table entries of a direction pair most are zeros BY CONSTRUCTION: kOrient[n] is a signed permutation, so the evaluation
+// direction of side s of neighbour n is +-0.894 along one world axis (w: the same for all four sides), +-0.447 along a second (u for s = 0, 2;
+// v for s = 1, 3) and 0 along the third, its re-projection direction is +-1 along u or v alone, and the neighbour's own direction +-1 along w
+// alone.  With the SH / lobe layouts (c0, -k y, k z, -k x) a pair therefore has three non-zero SH entries and two non-zero lobe entries; the
+// first SH entry is one constant for all 30 pairs, the w entry one value for a neighbour's four sides, and sides s and s + 2 hold negated
+// u / v entries.  For finite coefficients
+//   * a product with a zero entry is +-0, and  x + (+-0) == x  for every x but a zero, whose SIGN may change: a dot product evaluated
+//     without those terms differs from the shader's at most in the sign of a zero result;
+//   * max(0, +-0) is a zero either way, (sa * +-0) * lobe a vector of zeros, and  acc + (+-0) == acc  because acc is never -0 (it starts at +0,
+//     and a sum is -0 only if both operands are): the sign of that zero never reaches acc;
+//   * no dot product overflows (|dot| <= 0.94 max|c| < 65504), so sa * m is finite and its products with zero lobe entries are zeros, not NaN;
+//   * c * (-S) == -(c * S) bit for bit.
+// So the accumulated vector is the shader's bit for bit from 44 instead of 85 fp16 operations per neighbour.  A wave with an inf / NaN among its
+// coefficients takes propagate_from above.  The structure is not taken on faith: launch_lpv_build_tables reads the tables back and checks every
+// identity used here (prop_tables_have_hot_structure); a context whose tables fail it propagates with the general form only.
+constexpr int8_t kOrientC[6][9] = {
+    {1, 0, 0, 0, 1, 0, 0, 0, 1},  {-1, 0, 0, 0, 1, 0, 0, 0, -1}, {0, 0, 1, 0, 1, 0, -1, 0, 0},
+    {0, 0, -1, 0, 1, 0, 1, 0, 0}, {1, 0, 0, 0, 0, 1, 0, -1, 0},  {1, 0, 0, 0, 0, -1, 0, 1, 0},
+};
+// SH / lobe component that carries world axis i (x -> 3, y -> 1, z -> 2), and the component of column j (0: u, 1: v, 2: w) of kOrient[n]
+constexpr int sh_comp_of_axis(int i) { return i == 0 ? 3 : (i == 1 ? 1 : 2); }
+constexpr int sh_comp_of_col(int n, int j) {
+    for (int i = 0; i < 3; i++)
+        if (kOrientC[n][i * 3 + j] != 0) return sh_comp_of_axis(i);
+    return 0;
+}
+template <int K> SAH_DEV Hn h4_get(const H4& a) {
+    if constexpr (K == 0) return a.x;
+    else if constexpr (K == 1) return a.y;
+    else if constexpr (K == 2) return a.z;
+    else return a.w;
+}
+template <int K> SAH_DEV void h4_add(H4& a, Hn t) {
+    if constexpr (K == 0) a.x = a.x + t;
+    else if constexpr (K == 1) a.y = a.y + t;
+    else if constexpr (K == 2) a.z = a.z + t;
+    else a.w = a.w + t;
+}
+SAH_DEV Hn hneg(Hn a) { return Hn::raw(-a.v); }
+
+template <int N> SAH_DEV void propagate_from_neighbour_hot(const PropTables& T, const H4& c, H4& acc) {
+    constexpr int CU = sh_comp_of_col(N, 0), CV = sh_comp_of_col(N, 1), CW = sh_comp_of_col(N, 2);
+    const Hn direct_sa = Hn(tof(Hn::lit(0.4006696846f)) / 3.1415927f);
+    const Hn side_sa = Hn(tof(Hn::lit(0.4234413544f)) / 3.1415927f);
+    const Hn zero = Hn::lit(0.f);
+    const H4 sh0 = from_q(T.eval_sh[N][0]), sh1 = from_q(T.eval_sh[N][1]), shd = from_q(T.cur_sh[N]);
+    const Hn p0 = c.x * shd.x;
+    const Hn pw = h4_get<CW>(c) * h4_get<CW>(sh0);
+    const Hn pu = h4_get<CU>(c) * h4_get<CU>(sh0);
+    const Hn pv = h4_get<CV>(c) * h4_get<CV>(sh1);
+    const Hn pd = h4_get<CW>(c) * h4_get<CW>(shd);
+    auto side = [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        constexpr int CS = (S & 1) ? CV : CU;
+        const Hn ps = S == 0 ? pu : (S == 2 ? hneg(pu) : (S == 1 ? pv : hneg(pv)));
+        Hn dot = p0;  // components in the order of dot4h: 1, 2, 3 (the zero one dropped)
+#pragma unroll
+        for (int k = 1; k <= 3; k++) {
+            if (k == CW) dot = dot + pw;
+            else if (k == CS) dot = dot + ps;
+        }
+        const Hn t = side_sa * nmax(zero, dot);
+        const H4 lobe = from_q(T.reproj_lobe[N][S]);
+        acc.x = acc.x + t * lobe.x;
+        h4_add<CS>(acc, t * h4_get<CS>(lobe));
+    };
+    side(std::integral_constant<int, 0>{});
+    side(std::integral_constant<int, 1>{});
+    side(std::integral_constant<int, 2>{});
+    side(std::integral_constant<int, 3>{});
+    const Hn t = direct_sa * nmax(zero, p0 + pd);
+    const H4 lobe = from_q(T.cur_lobe[N]);
+    acc.x = acc.x + t * lobe.x;
+    h4_add<CW>(acc, t * h4_get<CW>(lobe));
+}
+SAH_DEV H4 propagate_from_hot(const PropTables& T, const H4 (&coef)[6]) {
+    const Hn zero = Hn::lit(0.f);
+    H4 acc = {zero, zero, zero, zero};
+    propagate_from_neighbour_hot<0>(T, coef[0], acc);
+    propagate_from_neighbour_hot<1>(T, coef[1], acc);
+    propagate_from_neighbour_hot<2>(T, coef[2], acc);
+    propagate_from_neighbour_hot<3>(T, coef[3], acc);
+    propagate_from_neighbour_hot<4>(T, coef[4], acc);
+    propagate_from_neighbour_hot<5>(T, coef[5], acc);
+    return acc;
+}
+
+// the identities propagate_from_hot relies on, checked on the tables the device built (bit patterns; host side)
+static bool prop_tables_have_hot_structure(const PropTables& T) {
+    auto bits = [](const Q4& q, int k) { return __builtin_bit_cast(uint16_t, q.v[k]); };
+    auto is_zero = [&](const Q4& q, int k) { return (bits(q, k) & 0x7fffu) == 0u; };
+    auto finite_nonzero = [&](const Q4& q, int k) { return !is_zero(q, k) && (bits(q, k) & 0x7c00u) != 0x7c00u; };
+    bool ok = true;
+    for (int n = 0; n < 6; n++) {
+        const int cu = sh_comp_of_col(n, 0), cv = sh_comp_of_col(n, 1), cw = sh_comp_of_col(n, 2);
+        ok = ok && cu != cv && cv != cw && cu != cw && cu >= 1 && cv >= 1 && cw >= 1;
+        for (int s = 0; s < 4; s++) {
+            const int cs = (s & 1) ? cv : cu;
+            for (int k = 0; k < 4; k++) {
+                const bool sh_nz = k == 0 || k == cw || k == cs, lobe_nz = k == 0 || k == cs;
+                ok = ok && (sh_nz ? finite_nonzero(T.eval_sh[n][s], k) : is_zero(T.eval_sh[n][s], k));
+                ok = ok && (lobe_nz ? finite_nonzero(T.reproj_lobe[n][s], k) : is_zero(T.reproj_lobe[n][s], k));
+            }
+            ok = ok && bits(T.eval_sh[n][s], 0) == bits(T.cur_sh[n], 0) && bits(T.eval_sh[n][s], cw) == bits(T.eval_sh[n][0], cw);
+        }
+        ok = ok && bits(T.eval_sh[n][2], cu) == (bits(T.eval_sh[n][0], cu) ^ 0x8000u) && bits(T.eval_sh[n][3], cv) == (bits(T.eval_sh[n][1], cv) ^ 0x8000u);
+        for (int k = 0; k < 4; k++) {
+            const bool nz = k == 0 || k == cw;
+            ok = ok && (nz ? finite_nonzero(T.cur_sh[n], k) : is_zero(T.cur_sh[n], k)) && (nz ? finite_nonzero(T.cur_lobe[n], k) : is_zero(T.cur_lobe[n], k));
+        }
+    }
+    return ok;
+}
+
 // one propagation step of one cell: lpv_propagate.comp.slang:76-156
 // (one colour volume per call: the three channels are independent and run as separate workgroups, blockIdx.y, which triples the
 // number of waves in flight — with one thread per cell doing all three the step was bound by its own dependency chains)
+SAH_DEV uint2 load_q(const VolumeArg& v, int x, int y, int z) {
+    if ((unsigned)x < v.width && (unsigned)y < v.height && (unsigned)z < v.depth)
+        return *reinterpret_cast<const uint2*>(v.ptr + (size_t)z * v.slice_pitch + (size_t)y * v.row_pitch + (size_t)x * 8);
+    return make_uint2(0u, 0u);
+}
+SAH_DEV H4 h4_of(uint2 q) {
+    H4 r;
+    r.x = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.x & 0xffffu)));
+    r.y = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.x >> 16)));
+    r.z = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.y & 0xffffu)));
+    r.w = Hn::raw(__builtin_bit_cast(_Float16, (uint16_t)(q.y >> 16)));
+    return r;
+}
+// bit 15 / bit 31 set <=> the low / high half of w has an all-ones exponent (inf or NaN): 0x7c00 + 0x0400 carries into the sign position
+SAH_DEV uint32_t nonfinite_halves(uint32_t w) { return (w & 0x7c007c00u) + 0x04000400u; }
+
+// NC colour volumes per thread (1: blockIdx.y picks the colour; 3: all of them — the neighbour tests, addresses and the scalar table reads are
+// shared, a third as many waves each three times as long).
+// The neighbour of direction n is the cell at c - kDir[n]; which of them exist is one compare each, because c is in [0, 32)^3 and the host has
+// checked the extents ((32 * cascades) x 32 x 32 at least, api_post.cpp):  c - 1 is outside the volume only below 0 — for x that is x == 0 of
+// cascade 0: a cell of column 0 of a later cascade reads the last column of the cascade before it, the shader's own quirk —, and c + 1 is the
+// shader's skipped neighbour exactly when c == 31 (the asymmetric [-1, 31] test: column 31 never reads the next cascade).  Offsets are 32-bit
+// (host-checked) from the centre cell's: one add per neighbour, no 64-bit multiply-adds; directions are compile-time constants — as
+// __constant__ data (rounds 1-5) every neighbour's address waited for a load of its direction, and the waits (vmcnt counts in order) also
+// waited for the neighbour texels requested before: six round trips in series, most of a step's 9.3 us.
+constexpr int8_t kDirC[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+template <int NC, bool EMIT>
+SAH_DEV void propagate_cell_hot(const PropTables& T, const PropArgs& a, uint32_t idx, uint32_t c0) {
+    const uint32_t cx = idx & 31u, cy = (idx >> 5) & 31u, cz = (idx >> 10) & 31u, x = cx + (idx >> 15) * 32u;
+    uint2 q[NC][6];
+    uint32_t off_c[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const VolumeArg& v = a.src[c0 + c];
+        off_c[c] = cz * v.slice_pitch + cy * v.row_pitch + x * 8u;
+    }
+#pragma unroll
+    for (int n = 0; n < 6; n++) {
+        constexpr int8_t zero8 = 0;
+        const int axis = kDirC[n][0] != zero8 ? 0 : (kDirC[n][1] != zero8 ? 1 : 2);
+        const bool minus = kDirC[n][axis] > 0;  // the neighbour at c - 1 along the axis
+        const uint32_t ca = axis == 0 ? cx : (axis == 1 ? cy : cz);
+        const bool valid = minus ? (axis == 0 ? x >= 1u : ca >= 1u) : ca <= 30u;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const VolumeArg& v = a.src[c0 + c];
+            const uint32_t step = axis == 0 ? 8u : (axis == 1 ? v.row_pitch : v.slice_pitch);
+            const uint32_t off = minus ? off_c[c] - step : off_c[c] + step;
+            q[c][n] = make_uint2(0u, 0u);
+            if (valid) q[c][n] = *reinterpret_cast<const uint2*>(v.ptr + off);
+        }
+    }
+    uint32_t bad = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int n = 0; n < 6; n++) bad |= nonfinite_halves(q[c][n].x) | nonfinite_halves(q[c][n].y);
+    const bool general = !a.hot || wave_any((bad & 0x80008000u) != 0u);
+    uint32_t bad_out = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        H4 coef[6];
+#pragma unroll
+        for (int n = 0; n < 6; n++) coef[n] = h4_of(q[c][n]);
+        const H4 out = general ? propagate_from(T, coef) : propagate_from_hot(T, coef);
+        uint2 o;
+        o.x = (uint32_t)__builtin_bit_cast(uint16_t, out.x.v) | ((uint32_t)__builtin_bit_cast(uint16_t, out.y.v) << 16);
+        o.y = (uint32_t)__builtin_bit_cast(uint16_t, out.z.v) | ((uint32_t)__builtin_bit_cast(uint16_t, out.w.v) << 16);
+        const VolumeArg& d = a.dst[c0 + c];
+        *reinterpret_cast<uint2*>(const_cast<uint8_t*>(d.ptr) + (cz * d.slice_pitch + cy * d.row_pitch + x * 8u)) = o;
+        if constexpr (EMIT) {
+            *reinterpret_cast<uint2*>(a.packed + ((cz + kLpvPackBorder) * a.pk_slice_pitch + (cy + kLpvPackBorder) * a.pk_row_pitch +
+                                                  (x + kLpvPackBorder) * kLpvPackTexel + 8u * (c0 + (uint32_t)c))) = o;
+            bad_out |= nonfinite_halves(o.x) | nonfinite_halves(o.y);
+        }
+    }
+    if constexpr (EMIT) {
+        if (wave_any((bad_out & 0x80008000u) != 0u) && (threadIdx.x & 63u) == 0u) atomicMax(&a.state->nonfinite, 1u);
+    }
+}
+
 SAH_DEV H4 propagate_cell(const PropTables& T, const VolumeArg& src, const VolumeArg& dst, uint32_t idx) {
     const int cx = idx & 31, cy = (idx >> 5) & 31, cz = (idx >> 10) & 31, cascade = idx >> 15;
     const int xoff = cascade * 32;
@@ -182,6 +381,13 @@ __global__ void __launch_bounds__(256) k_lpv_clear(ClearArgs a) {
     }
 }
 
+template <int NC, bool EMIT>
+__global__ void __launch_bounds__(256) k_lpv_propagate_hot(PropArgs a) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.num_cascades * 32768u) return;
+    propagate_cell_hot<NC, EMIT>(c_prop_tables, a, idx, NC == 1 ? blockIdx.y : 0u);
+}
+
 hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades, hipStream_t st) {
     ClearArgs a;
     a.n = n;
@@ -191,19 +397,48 @@ hipError_t launch_lpv_clear(const VolumeArg* vols, int n, uint32_t num_cascades,
     return hipGetLastError();
 }
 
-hipError_t launch_lpv_build_tables(hipStream_t st) {  // on the current device
+// on the current device.  `hot_structure`: the tables as built have the structure propagate_from_hot relies on (read back once and checked)
+hipError_t launch_lpv_build_tables(hipStream_t st, bool* hot_structure) {
     void* sym = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(c_prop_tables));
+    hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(c_prop_tables));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_build_prop_tables, dim3(1), dim3(64), 0, st, (PropTables*)sym);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    PropTables host;
+    if ((e = hipMemcpyAsync(&host, sym, sizeof(host), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    *hot_structure = prop_tables_have_hot_structure(host);
+    return hipSuccess;
 }
 
 // `emit` (or null): where the step also writes the Lighting pass's gather copy of `dst` (PropArgs)
-hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, const LpvPackEmit* emit, hipStream_t st) {
+// `mode`: 0 the general form only (rounds 1-5's kernel), 1 hot form, one colour volume per thread, 3 hot form, the three colours of a cell in one thread
+hipError_t launch_lpv_propagate(const VolumeArg src[3], const VolumeArg dst[3], uint32_t num_cascades, const LpvPackEmit* emit, int mode, hipStream_t st) {
     PropArgs a = {};
     for (int i = 0; i < 3; i++) { a.src[i] = src[i]; a.dst[i] = dst[i]; }
     a.num_cascades = num_cascades;
+    a.hot = mode != 0 ? 1u : 0u;
+    if (emit) {
+        a.packed = emit->packed;
+        a.pk_row_pitch = emit->row_pitch;
+        a.pk_slice_pitch = emit->slice_pitch;
+        a.state = emit->state;
+    }
+    if (mode != 0) {
+        if (emit) {
+            const hipError_t me = hipMemsetAsync(&emit->state->nonfinite, 0, sizeof(uint32_t), st);  // the copy's verdict starts at "finite"
+            if (me != hipSuccess) return me;
+        }
+        const dim3 grid(num_cascades * 128, mode == 3 ? 1 : 3);
+        if (mode == 3) {
+            if (emit) hipLaunchKernelGGL((k_lpv_propagate_hot<3, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_lpv_propagate_hot<3, false>), grid, dim3(256), 0, st, a);
+        } else {
+            if (emit) hipLaunchKernelGGL((k_lpv_propagate_hot<1, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_lpv_propagate_hot<1, false>), grid, dim3(256), 0, st, a);
+        }
+        return hipGetLastError();
+    }
     if (emit) {
         a.packed = emit->packed;
         a.pk_row_pitch = emit->row_pitch;

@@ -26,7 +26,11 @@ def test_every_workload_has_a_static_counter_record():
 
 def test_roofline_names_a_bound_only_with_a_record():
     with_rec = bench.roofline("4k_deferred_gi", 1, 1750.0, 0.17, None, "x", 298598400, 3840 * 2160, "k")
-    assert with_rec["bound"] in ("valu", "hbm", "fp32") and with_rec["traffic"] and with_rec["valu_issue"]["frac"] <= 1.0
+    assert with_rec["bound"] in ("valu", "hbm", "fp32", "latency") and with_rec["traffic"] and with_rec["valu_issue"]["frac"] <= 1.0
+    assert with_rec["traffic_over_algorithmic"] > 1.0 and 0 < with_rec["traffic_frac_of_peak"] < 1
+    # a launch that takes three times as long with the same instructions and bytes is bound by neither roofline
+    slow = bench.roofline("4k_deferred_gi", 1, 1750.0 / 3, 0.17 * 3, None, "x", 298598400, 3840 * 2160, "k")
+    assert slow["bound"] == "latency" and slow["bound_by_fraction"] in ("valu", "hbm") and "latency" in slow["bound_note"]
     without = bench.roofline("no_such_workload", 1, 1750.0, 0.17, None, "x", 298598400, 3840 * 2160, "k")
     assert without["bound"] is None and "bound_note" in without and without["traffic"] is None
 

@@ -123,6 +123,63 @@ def test_lpv_propagate_and_clear(hip_ctx, steps):
     assert all(int(t.abs().max()) == 0 for t in a_t) and int(b_t[0].abs().max()) == 0
 
 
+@pytest.mark.parametrize("case", ["extremes", "nonfinite", "three_cascades_padded"])
+def test_lpv_propagate_hot_form_equals_general_form_and_oracle(hip_ctx, case):
+    """The propagation's hot form (csrc/lpv.hip: zero table entries dropped, shared products — exact for finite coefficients) against the general
+    form of the same library (sah_debug_set(force_general)) and the oracle, on volumes made to break it: magnitudes up to the largest half (sums
+    that overflow), denormals, negative zeros, exact cancellations; waves that hold an inf / NaN (they must take the general form); three cascades
+    in volumes larger than the propagated cells, with pitches that are not the tight ones."""
+    import torch
+    o = util.oracle()
+    rng = np.random.default_rng({"extremes": 71, "nonfinite": 72, "three_cascades_padded": 73}[case])
+    nc = 3 if case == "three_cascades_padded" else 4
+    w, h, d = (32 * nc + 5, 34, 33) if case == "three_cascades_padded" else (32 * nc, 32, 32)
+    vols = []
+    for c in range(3):
+        kind = rng.integers(0, 8, (d, h, w, 4))
+        v = rng.uniform(-2.0, 2.0, (d, h, w, 4)).astype(np.float16)
+        v = np.where(kind == 0, np.float16(0.0), v)
+        v = np.where(kind == 1, np.float16(-0.0), v)
+        v = np.where(kind == 2, (rng.uniform(-1, 1, v.shape) * 6.0e-6).astype(np.float16), v)       # denormals
+        v = np.where(kind == 3, (rng.choice([-1.0, 1.0], v.shape) * rng.uniform(3.0e4, 65504.0, v.shape)).astype(np.float16), v)
+        v = np.where(kind == 4, np.float16(0.5), v)                                                   # equal magnitudes: exact cancellations
+        v = np.where(kind == 5, np.float16(-0.5), v)
+        if case == "nonfinite":
+            zz, yy, xx = rng.integers(0, d, 40), rng.integers(0, h, 40), rng.integers(0, w, 40)
+            v[zz[:15], yy[:15], xx[:15], 0] = np.float16(np.inf)
+            v[zz[15:30], yy[15:30], xx[15:30], 2] = np.float16(-np.inf)
+            v[zz[30:], yy[30:], xx[30:], 3] = np.float16(np.nan)
+        vols.append(np.ascontiguousarray(v))
+    steps = 3
+
+    def desc(arrs):
+        return [images.volume(a, _abi.FORMAT_R16G16B16A16_SFLOAT) for a in arrs]
+    a_np = [v.view(np.uint16).copy() for v in vols]
+    b_np = [np.full_like(v, 0x3C00) for v in a_np]
+    assert o.orc_lpv_propagate((_abi.Volume * 3)(*desc(a_np)), (_abi.Volume * 3)(*desc(b_np)), nc, steps) == 0
+    results = []
+    for force_general in (False, True):
+        hip_ctx.debug_set(force_general=force_general)
+        try:
+            a_t = [util.to_torch(v.view(np.uint16).copy()) for v in vols]
+            b_t = [torch.full_like(t, 0x3C00) for t in a_t]
+            hip_ctx.lpv_propagate(desc(a_t), desc(b_t), nc, steps)
+            torch.cuda.synchronize()
+            results.append([util.from_torch(t, np.uint16).reshape(a_np[0].shape) for t in a_t + b_t])
+        finally:
+            hip_ctx.debug_set(force_general=False)
+    want = a_np + b_np
+
+    def same(x, y):  # bit for bit, except that a NaN is a NaN whatever its payload (numerics contract: DESIGN.md section 3)
+        xn, yn = (x & 0x7FFF) > 0x7C00, (y & 0x7FFF) > 0x7C00
+        return bool(np.all((x == y) | (xn & yn)))
+    for i in range(6):
+        assert same(results[0][i], want[i]), f"hot form differs from the oracle in volume {i}: {int(np.sum(results[0][i] != want[i]))} halves"
+        assert same(results[1][i], want[i]), f"general form differs from the oracle in volume {i}"
+    if case != "nonfinite":
+        assert np.isfinite(vols[0].astype(np.float32)).all()
+
+
 @pytest.mark.parametrize("size", [(256, 144), (250, 130), (333, 187), (64, 36), (9, 5), (2048, 96), (97, 512), (1920, 1080)])
 def test_copy_scene_and_bloom_mip0_in_one_pass(hip_ctx, size):
     """sah_copy_scene_bloom_mip0_rows == sah_copy_scene_rows followed by sah_bloom_mip0_rows == the oracle, bit for bit: whole frames (odd
