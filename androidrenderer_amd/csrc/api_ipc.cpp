@@ -34,6 +34,24 @@ struct Handle {  // SAH_IPC_HANDLE_BYTES
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
 static_assert(sizeof(Handle) == SAH_IPC_HANDLE_BYTES, "handle layout");
 
+// The allocation kinds the exchange is defined for (include/sah_hip.h, "direct exchange"): ordinary device memory of the context's own device
+// (hipMalloc, or a caching allocator's block of it).  Host-pinned and managed memory are refused: their pages may live on, or migrate to,
+// another agent, and nothing in this protocol orders a peer's stores against that.
+int check_exchange_memory(sah_ctx* ctx, const void* ptr) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "direct exchange: %p is not memory HIP knows (gathered buffers must be device memory of device %d)", ptr, ctx->device);
+    }
+    if (at.type != hipMemoryTypeDevice || at.isManaged)
+        return fail(ctx, SAH_ERR_UNSUPPORTED, "direct exchange: the buffer is %s memory; the exchange is defined for device memory (hipMalloc) only",
+                    at.isManaged ? "managed" : (at.type == hipMemoryTypeHost ? "host" : "not device"));
+    if (at.device != ctx->device)
+        return fail(ctx, SAH_ERR_INVALID_ARGUMENT, "direct exchange: the buffer lives on device %d, the context on device %d", at.device, ctx->device);
+    return SAH_OK;
+}
+
 int export_range(sah_ctx* ctx, const void* ptr, uint64_t bytes, Handle* h) {
     void* base = nullptr;
     size_t size = 0;
@@ -193,6 +211,7 @@ int sah_ipc_connect(sah_ctx* ctx, const void* all_handles) {
 int sah_ipc_export(sah_ctx* ctx, const void* buffer, uint64_t bytes, void* out_handle) {
     if (!ctx || !buffer || !bytes || !out_handle) return SAH_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = check_exchange_memory(ctx, buffer); rc != SAH_OK) return rc;
     Handle h;
     if (int rc = export_range(ctx, buffer, bytes, &h); rc != SAH_OK) return rc;
     memcpy(out_handle, &h, sizeof(h));
@@ -217,6 +236,7 @@ int sah_ipc_register(sah_ctx* ctx, void* buffer, uint64_t bytes, const void* all
     }
     if (id < 0) return fail(ctx, SAH_ERR_UNSUPPORTED, "at most %d registered buffers", SAH_IPC_MAX_BUFFERS);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = check_exchange_memory(ctx, buffer); rc != SAH_OK) return rc;
     const Handle* hs = (const Handle*)all_handles;
     for (int p = 0; p < ctx->world; p++)
         if (hs[p].magic != kMagic || (int)hs[p].rank != p || hs[p].bytes != bytes)

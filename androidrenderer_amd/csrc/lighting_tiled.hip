@@ -34,8 +34,11 @@ SAH_DEV float wave_max(float v) {
     return v;
 }
 
+#ifndef SAH_EXP_CACHE_WAVES
+#define SAH_EXP_CACHE_WAVES 1  // experiments (tools/experiments/r6): waves per SIMD the cache-GI body without a light list is held to (1: the allocator's own 4)
+#endif
 template <int SUN, int GI, bool LIGHTS>
-__global__ void __launch_bounds__(256) k_lighting_tiled(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const CacheArgs cache,
+__global__ void __launch_bounds__(256, ((GI == SAH_GI_CACHE && !LIGHTS) ? SAH_EXP_CACHE_WAVES : 1)) k_lighting_tiled(const LightingArgs a, const CsmArgs csm, const LpvArgs lpv, const CacheArgs cache,
                                                         const RtgiArgs rtgi, const SkyArgs sky, const uint32_t brute_force, const FastArgs f,
                                                         const uint32_t fast_geom) {
     // `fast_geom`: the uniform blocks have the structure the fast kernel's geometry and CSM sun rely on (api.cpp: detect_fast_path);

@@ -692,7 +692,17 @@ int sah_allgather_bytes(sah_ctx* ctx, void* buffer, uint64_t bytes_per_rank);
  * sah_ipc_unregister(ctx, buffer) on every rank, in the same order as everything else of this protocol; it waits for the context's
  * streams, closes the peer mappings nobody else uses and frees the slot (the lowest free slot is taken by the next registration).
  * The context may be created with comm_id == NULL and world > 1 for this path.  buffer may lie inside a larger allocation (a caching
- * allocator's block): the handle carries the offset. */
+ * allocator's block): the handle carries the offset.
+ * WHICH MEMORY.  Gathered buffers must be ordinary device memory (hipMalloc) of the context's own device; sah_ipc_export and
+ * sah_ipc_register refuse host-pinned and managed memory (SAH_ERR_UNSUPPORTED) and memory of another device.  Only the mailbox is
+ * fine-grained; the rows a peer stores land in the home device's ordinary (coarse-grained) allocation, as the rows RCCL's kernels store
+ * into a user buffer do, and they are published the same way: the peer's copy kernel ENDS (release at system scope) before its "done" counter
+ * is stored, and the home device reads the rows only in kernels that START behind the kernel that saw that counter (stream order on the
+ * exchange stream, sah_comm_wait on the work stream) — a kernel boundary, whose acquire makes the home device's caches drop what they hold
+ * of memory a peer may have written.  A consumer that polls gathered rows from INSIDE a running kernel is outside this contract.
+ * STATUS: verified with several processes on ONE device (tests/test_comm_gpu.py); on two devices it has not run yet (no multi-GPU box
+ * was available to the builder): RCCL is the default exchange of every entry point and of bench.py, the direct exchange is opt-in, and
+ * tests/test_comm_gpu.py's two-GPU tests (skipped on one GPU) are the first thing to run on a node — README.md "On a multi-GPU node". */
 #define SAH_IPC_HANDLE_BYTES 128
 #define SAH_IPC_MAX_WORLD 16
 #define SAH_IPC_MAX_BUFFERS 16
