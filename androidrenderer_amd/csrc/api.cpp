@@ -570,6 +570,39 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
     // (its LPV overlay, if any, stays the general one: the LPV part of the check is skipped)
     static const bool no_tiled_fast_geom = getenv("SAH_TILED_GENERAL_GEOMETRY") != nullptr;  // A/B switch (tools/ab.sh)
     const bool tiled_fast_geom = !fast_kind && !ctx->force_general && !no_tiled_fast_geom && detect_fast_path(d, sun_mode, SAH_GI_NONE, csm, &fast);
+    // ... and, round 6, the fast kernel's LPV overlay (gather from the packed copy) where the LPV part of the check holds as well: a light list
+    // over an LPV frame (configs[4]) no longer pays the general overlay's nine trilinear fetches per pixel
+    static const bool no_tiled_fast_lpv = getenv("SAH_TILED_GENERAL_LPV") != nullptr;  // A/B switch
+    const bool tiled_fast_lpv = tiled_fast_geom && gi_kind == SAH_GI_LPV && !no_tiled_fast_lpv && ctx->state && detect_fast_path(d, sun_mode, SAH_GI_LPV, csm, &fast);
+    fast.lpv_fast = tiled_fast_lpv ? 1u : 0u;
+    // the gather copy of the LPV volumes for a kernel that reads it: rebuilt by k_lpv_pack (in front of the kernel: lighting.hip) unless the caller's
+    // change counter says it stands (SAH_GENERATION_TRACKED: the last step of sah_lpv_propagate has written it — api_post.cpp)
+    auto prepare_lpv_copy = [&]() -> int {
+        const SahLpvPackLayout pk = sah_lpv_pack_layout(lpv.red.width, lpv.red.height, lpv.red.depth);
+        if (pk.total >= (1ull << 32)) return fail(ctx, SAH_ERR_UNSUPPORTED, "LPV volumes too large for the packed gather copy");
+        HIP_TRY(ctx, sah_lpv_pack_reserve(ctx, pk.total));
+        fast.lpv_packed = ctx->lpv_packed;
+        fast.pk_row_pitch = pk.row_pitch;
+        fast.pk_slice_pitch = pk.slice_pitch;
+        // the copy of the previous call is kept when the caller's change counter says the volumes are the ones it was made from
+        const sah::VolumeArg src[3] = {lpv.red, lpv.green, lpv.blue};
+        const uint32_t gen = d->gi->lpv_generation;
+        const bool reuse = gen != 0 && gen == ctx->lpv_pack_generation && same_volume(src[0], ctx->lpv_pack_source[0]) &&
+                           same_volume(src[1], ctx->lpv_pack_source[1]) && same_volume(src[2], ctx->lpv_pack_source[2]);
+        fast.repack = reuse ? 0u : 1u;
+        if (!reuse) {
+            if (gen != 0) ctx->cache_epoch++;  // (with 0 every call rebuilds: the same launches every time)
+            ctx->dbg_lpv_packs++;
+            ctx->lpv_pack_generation = gen;
+            for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = src[i];
+            sah_lpv_pack_written_by_pack(ctx, lpv.red.width, lpv.red.height, lpv.red.depth);
+        }
+        return SAH_OK;
+    };
+    if (tiled_fast_lpv && r1 > r0) {
+        if (const int rc = prepare_lpv_copy(); rc != SAH_OK) return rc;
+        fast.state = ctx->state;
+    }
     if (use_fast) {
         // deferred-pixel segments (params.hpp): one per wave of the fast kernel, 64 * ppt byte codes + a 16-bit count each
         const uint64_t groups = (uint64_t)(W / (uint32_t)ppt) * (r1 - r0);
@@ -590,27 +623,8 @@ int sah_lighting(sah_ctx* ctx, const sah_lighting_desc* d) {
         fast.seg_count = (uint16_t*)((uint8_t*)ctx->list + codes_bytes);
         fast.num_segments = nseg;
         fast.seg_stride = seg_stride;
-        if (gi_kind == SAH_GI_LPV) {  // gather copy of the LPV volumes: rebuilt by k_lpv_pack unless the change counter says it stands
-            // (SAH_GENERATION_TRACKED: the last step of sah_lpv_propagate has written it — api_post.cpp)
-            const SahLpvPackLayout pk = sah_lpv_pack_layout(lpv.red.width, lpv.red.height, lpv.red.depth);
-            if (pk.total >= (1ull << 32)) return fail(ctx, SAH_ERR_UNSUPPORTED, "LPV volumes too large for the packed gather copy");
-            HIP_TRY(ctx, sah_lpv_pack_reserve(ctx, pk.total));
-            fast.lpv_packed = ctx->lpv_packed;
-            fast.pk_row_pitch = pk.row_pitch;
-            fast.pk_slice_pitch = pk.slice_pitch;
-            // the copy of the previous call is kept when the caller's change counter says the volumes are the ones it was made from
-            const sah::VolumeArg src[3] = {lpv.red, lpv.green, lpv.blue};
-            const uint32_t gen = d->gi->lpv_generation;
-            const bool reuse = gen != 0 && gen == ctx->lpv_pack_generation && same_volume(src[0], ctx->lpv_pack_source[0]) &&
-                               same_volume(src[1], ctx->lpv_pack_source[1]) && same_volume(src[2], ctx->lpv_pack_source[2]);
-            fast.repack = reuse ? 0u : 1u;
-            if (!reuse) {
-                if (gen != 0) ctx->cache_epoch++;  // (with 0 every call rebuilds: the same launches every time)
-                ctx->dbg_lpv_packs++;
-                ctx->lpv_pack_generation = gen;
-                for (int i = 0; i < 3; i++) ctx->lpv_pack_source[i] = src[i];
-                sah_lpv_pack_written_by_pack(ctx, lpv.red.width, lpv.red.height, lpv.red.depth);
-            }
+        if (gi_kind == SAH_GI_LPV) {
+            if (const int rc = prepare_lpv_copy(); rc != SAH_OK) return rc;
         }
         fast.sky_enabled = sky.enabled;
         {   // The sky workgroups of the fast kernel (lighting.hip): they LEAD the grid, one per `sky_ratio` surface workgroups.  Leading: a thread

@@ -391,6 +391,15 @@ __global__ void __launch_bounds__(256, SKY ? 4 : 1) k_lighting_fast(const Lighti
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------
+// (re)builds the gather copy of the LPV volumes in front of a Lighting kernel that gathers from it (the fast kernel; the tiled one with f.lpv_fast)
+static hipError_t launch_lpv_pack(const LpvArgs& lpv, const FastArgs& f, hipStream_t st) {
+    const uint32_t prows = (lpv.red.height + 2 * kLpvPackBorder) * (lpv.red.depth + 2 * kLpvPackBorder);
+    const hipError_t me = hipMemsetAsync(&f.state->nonfinite, 0, sizeof(uint32_t), st);  // the new copy's verdict starts at "finite"
+    if (me != hipSuccess) return me;
+    hipLaunchKernelGGL(k_lpv_pack, dim3(prows), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, const_cast<uint8_t*>(f.lpv_packed), f.pk_row_pitch,
+                       f.pk_slice_pitch, f.state);
+    return hipGetLastError();
+}
 template <int SUN, int GI>
 static hipError_t launch_general_ppt(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const SkyArgs& sky, int ppt, hipStream_t st) {
     const uint32_t rows = a.row_end - a.row_begin;
@@ -410,11 +419,8 @@ static hipError_t launch_fast_ppt(const LightingArgs& a, const CsmArgs& csm, con
     const uint64_t groups = (uint64_t)(a.width / ppt) * rows;
     if (groups == 0) return hipSuccess;
     if (GI == SAH_GI_LPV && f.repack) {
-        const uint32_t prows = (lpv.red.height + 2 * kLpvPackBorder) * (lpv.red.depth + 2 * kLpvPackBorder);
-        const hipError_t me = hipMemsetAsync(&f.state->nonfinite, 0, sizeof(uint32_t), st);  // the new copy's verdict starts at "finite"
-        if (me != hipSuccess) return me;
-        hipLaunchKernelGGL(k_lpv_pack, dim3(prows), dim3(256), 0, st, lpv.red, lpv.green, lpv.blue, const_cast<uint8_t*>(f.lpv_packed), f.pk_row_pitch,
-                           f.pk_slice_pitch, f.state);
+        const hipError_t pe = launch_lpv_pack(lpv, f, st);
+        if (pe != hipSuccess) return pe;
     }
     const uint32_t blocks = (uint32_t)((groups + 255) / 256);
     const dim3 block(256);
@@ -462,8 +468,13 @@ hipError_t launch_lighting_tiled(const LightingArgs& a, const CsmArgs& csm, cons
 hipError_t launch_lighting(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const CacheArgs& cache, const RtgiArgs& rtgi,
                            const SkyArgs& sky, const FastArgs* fast, int sun_mode, int gi, int ppt, bool brute_force_lights, hipStream_t st) {
     // point lights and the GI overlays without a fast path run in the 16x16-tile kernel (lighting_tiled.hip)
-    if (a.num_lights || gi == SAH_GI_CACHE || gi == SAH_GI_RTGI)
+    if (a.num_lights || gi == SAH_GI_CACHE || gi == SAH_GI_RTGI) {
+        if (gi == SAH_GI_LPV && fast && fast->lpv_fast && fast->repack && a.row_end > a.row_begin) {
+            const hipError_t pe = launch_lpv_pack(lpv, *fast, st);
+            if (pe != hipSuccess) return pe;
+        }
         return launch_lighting_tiled(a, csm, lpv, cache, rtgi, sky, sun_mode, gi, brute_force_lights, fast, st);
+    }
     switch (sun_mode) {
         case SAH_SHADOW_MODE_OFF: return launch_gi<SAH_SHADOW_MODE_OFF>(a, csm, lpv, sky, fast, gi, ppt, st);
         case SAH_SHADOW_MODE_CSM: return launch_gi<SAH_SHADOW_MODE_CSM>(a, csm, lpv, sky, fast, gi, ppt, st);

@@ -152,6 +152,62 @@ SAH_DEV void fast_csm_sun(const LightingArgs& a, const CsmArgs& csm, const float
     }
 }
 
+// The LPV overlay of shade_pixel_fast_sl() below as a function of its own, for the tiled kernel (a light list with an LPV: configs[4]) — the same
+// operators in the same order (cascade selection on the scale + translate rows of the LDS table, the gather from the packed copy, Fd == diffuse
+// colour / pi, the specular quirk's +-0 dropped: DESIGN.md "Fast path proofs"), kept apart from the headline kernel's body, whose schedule it
+// must not disturb.  Preconditions (the caller's `ok`): finite depth, a finite non-zero normal, fast_geometry()'s domain, a non-zero roughness
+// byte, finite volumes.  `add`: what is blended into lit.rgb (total * exposure; lit.a gets + 1); `ok` is cleared when a term is NaN (the general
+// form then zeroes the pixel's overlay: the caller re-evaluates it).
+SAH_DEV void fast_lpv_overlay(const LpvArgs& lpv, const FastArgs& f, const float* tab, F3 N, F3 ws, const SurfIn& si, float ao_px, lanemask act, bool& ok,
+                              float (&add)[3]) {
+    lanemask out_m = 0;
+    auto inside = [&](uint32_t i) {
+        const float4 cs_ = *reinterpret_cast<const float4*>(tab + TAB_LPV + i * 8u);
+        const float4 ct_ = *reinterpret_cast<const float4*>(tab + TAB_LPV + i * 8u + 4u);
+        const Fn cx = Fn(cs_.x) * ws.x + Fn(ct_.x);
+        const Fn cy = Fn(cs_.y) * ws.y + Fn(ct_.y);
+        const Fn cz = Fn(cs_.z) * ws.z + Fn(ct_.z);
+        const float mn = __builtin_fminf(__builtin_fminf(cx.v, cy.v), cz.v), mxv = __builtin_fmaxf(__builtin_fmaxf(cx.v, cy.v), cz.v);
+        out_m = lanes(!(mn > 0.f)) | lanes(!(mxv < 1.f));
+        return mn > 0.f && mxv < 1.f;
+    };
+    uint32_t selected = 0;
+    const bool in0 = inside(0u);
+    if (out_m & act) {
+#pragma unroll
+        for (int i = 3; i >= 1; i--) {
+            if (i < (int)lpv.num_cascades) selected = inside((uint32_t)i) ? (uint32_t)i : selected;
+        }
+        selected = in0 ? 0u : selected;
+    }
+    F3 lpv_normal = -N;
+    lpv_normal.x = lpv_normal.x * Fn(-1.0f);
+    Fn nc[4];
+    dir_to_sh(lpv_normal, nc);
+    const float4 cs = *reinterpret_cast<const float4*>(tab + TAB_LPV + selected * 8u);
+    const float4 ct = *reinterpret_cast<const float4*>(tab + TAB_LPV + selected * 8u + 4u);
+    Fn cpx = Fn(cs.x) * (ws.x + N.x) + Fn(ct.x);
+    const Fn cpy = Fn(cs.y) * (ws.y + N.y) + Fn(ct.y);
+    const Fn cpz = Fn(cs.z) * (ws.z + N.z) + Fn(ct.z);
+    cpx = cpx + Fn((float)selected);
+    cpx = f.ncasc_pow2 ? cpx * Fn(f.inv_ncasc) : cpx / Fn(lpv.num_cascades_f);
+    Fn indirect[3];
+    lpv_fetch_packed(lpv, f.lpv_packed, f.pk_row_pitch, f.pk_slice_pitch, cpx.v, cpy.v, cpz.v, nc, indirect);
+    const Fn dielectric_f0 = Fn(0.04f);
+    const F3 base_color = {Fn(si.color[0]), Fn(si.color[1]), Fn(si.color[2])};
+    const F3 diffuse_color = base_color * (Fn(1.0f) - dielectric_f0) * (Fn(1.0f) - Fn(si.metal));
+    const Fn inv_pi = (Fn(1.0f) * Fn(1.0f)) * (Fn(1.0f) / Fn(3.1415927f));
+    const F3 diffuse_factor = diffuse_color * inv_pi;
+    const Fn ao = Fn(ao_px);
+    const F3 total = {indirect[0] * diffuse_factor.x * ao, indirect[1] * diffuse_factor.y * ao, indirect[2] * diffuse_factor.z * ao};
+    const float nan_probe = (total.x + total.y + total.z).v;
+    ok = ok && nan_probe == nan_probe;
+    const Fn exposure = Fn(lpv.exposure);
+    add[0] = (total.x * exposure).v;
+    add[1] = (total.y * exposure).v;
+    add[2] = (total.z * exposure).v;
+}
+
 template <int SUN, int GI>
 SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& csm, const LpvArgs& lpv, const FastArgs& f, float colx_glsl,
                                          float rowy_glsl, float colx_slang, float rowy_slang, const Px& p, const float* tab,

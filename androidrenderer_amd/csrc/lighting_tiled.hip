@@ -53,6 +53,10 @@ __global__ void __launch_bounds__(256, ((GI == SAH_GI_CACHE && !LIGHTS) ? SAH_EX
         const uint32_t t = threadIdx.x - 128u;
         s_lut[TAB_VIEW + t] = a.inv_view[(t & 3u) * 4u + (t >> 2)];
     }
+    if (GI == SAH_GI_LPV && threadIdx.x >= 64 && threadIdx.x < 96) {  // [cascade][sx sy sz - tx ty tz -] (meaningful when f.lpv_fast)
+        const uint32_t t = threadIdx.x - 64u, c = t >> 3, j = t & 7u;
+        s_lut[TAB_LPV + t] = (j & 3u) == 3u ? 0.f : (j < 4u ? f.lpv_s[c][j] : f.lpv_t[c][j - 4u]);
+    }
     __shared__ float s_box[4][6];
     __shared__ uint32_t s_wave_count[4];
     __shared__ uint16_t s_list[kMaxTileLights];
@@ -332,10 +336,27 @@ __global__ void __launch_bounds__(256, ((GI == SAH_GI_CACHE && !LIGHTS) ? SAH_EX
     // (3) GI overlay
     if (surface) {
         if constexpr (GI == SAH_GI_LPV) {
-            Fn s[4];
-            gi_lpv_frag(a, lpv, x, y, p, si, s);
+            // round 6: the fast kernel's overlay (gather from the packed copy, three of the nine trilinear fetches) where its proofs hold — the
+            // uniform blocks (f.lpv_fast: api.cpp), fast_geometry()'s domain, a non-zero roughness byte, finite volumes —, the general
+            // restatement for every other pixel.  (Inside `if (surface)`: the votes below are on masks that include `surface`.)
+            bool lpv_ok = false;
+            float add[3] = {0.f, 0.f, 0.f};
+            if constexpr (kNeedsGeom) {
+                if (f.lpv_fast) {
+                    lpv_ok = geom_ok && ((p.data >> 8) & 0xffu) != 0u && f.state->nonfinite == 0u;
+                    fast_lpv_overlay(lpv, f, s_lut, g.N, g.ws, si, p.ao, lanes(lpv_ok), lpv_ok, add);
+                }
+            }
+            if (lpv_ok) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
+                for (int i = 0; i < 3; i++) lit[i] = Hn(tof(lit[i]) + add[i]);
+                lit[3] = lit[3] + Hn::lit(1.0f);  // (the fp16 sum, as in the fast kernel)
+            } else {
+                Fn s[4];
+                gi_lpv_frag(a, lpv, x, y, p, si, s);
+#pragma unroll
+                for (int i = 0; i < 4; i++) lit[i] = Hn(tof(lit[i]) + s[i].v);
+            }
         } else if constexpr (GI == SAH_GI_CACHE || GI == SAH_GI_RTGI) {
             Hn s[4];
             if constexpr (GI == SAH_GI_CACHE) {

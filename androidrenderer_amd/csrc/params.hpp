@@ -124,6 +124,7 @@ struct FastArgs {
     // ((z+2) * pk_slice_pitch + (y+2) * pk_row_pitch + (x+2) * 24), inside a two-texel border of zeros (= CLAMP_TO_BORDER)
     const uint8_t* lpv_packed;
     uint32_t pk_row_pitch, pk_slice_pitch;
+    uint32_t lpv_fast;  // tiled kernel: the LPV part of the fast-path check holds too and the gather copy is there (lpv_s / lpv_t, lpv_packed, state valid)
 };
 // (an fp32 copy — 48-byte texels, plain v_fma_f32 taps — was measured and loses 67 %: profiles/r3_lpv_pack32_experiment.txt)
 constexpr uint32_t kLpvPackTexel = 24, kLpvPackBorder = 2;

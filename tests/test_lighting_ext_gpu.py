@@ -132,3 +132,39 @@ def test_tiled_kernel_adversarial_surface_inputs(hip_ctx, sun_mode, gi, extra):
     got = _vs_oracle(f, hip_ctx, f"tiled adversarial sun={sun_mode} gi={gi}", max_ulp=0)
     nan = (got & 0x7FFF) > 0x7C00
     print(f"NaN channels in the image: {int(nan.sum())}")
+
+
+@pytest.mark.parametrize("volumes", ["finite", "nonfinite"])
+@pytest.mark.parametrize("sun_mode", [_abi.SHADOW_MODE_CSM, _abi.SHADOW_MODE_RT])
+def test_point_lights_over_lpv_fast_overlay_adversarial(hip_ctx, sun_mode, volumes):
+    """Round 6: with a light list the LPV overlay of the tiled kernel is the fast kernel's (gather from the packed copy) wherever its proofs hold.
+    Poisoned surface inputs (zero / NaN / infinite / denormal normals and depths, roughness 0), NaN and infinite AO texels and — `nonfinite` — an
+    inf and a NaN in the volumes (every pixel must then take the general overlay) against the oracle, against the context forced onto the
+    general kernels, and with the gather copy kept across calls (lpv_generation != 0: no rebuild on the second call)."""
+    from tests.test_lighting_gpu import _poison
+    g = synth.random_gbuffer(160, 96, seed=93)
+    _poison(g, np.random.default_rng(9))
+    base = util.LightingFrame(160, 96, gbuffer=g, seed=94, sun_mode=sun_mode, gi=_abi.GI_LPV)
+    lights = synth.point_lights(base.view, 40, 8.0, seed=95)
+    f = util.LightingFrame(160, 96, gbuffer=g, seed=94, sun_mode=sun_mode, gi=_abi.GI_LPV, lights=lights)
+    f.arrays["ao"][3, 5] = np.nan
+    f.arrays["ao"][8, 13] = np.inf
+    f.arrays["ao"][20, 40] = -1.0
+    if volumes == "nonfinite":
+        f.arrays["lpv_g"] = f.arrays["lpv_g"].copy()
+        f.arrays["lpv_g"][5, 6, 7, 1] = np.float16(np.inf)
+        f.arrays["lpv_b"] = f.arrays["lpv_b"].copy()
+        f.arrays["lpv_b"][9, 3, 50, 0] = np.float16(np.nan)
+    got = _vs_oracle(f, hip_ctx, f"lights + LPV (tiled, fast overlay) sun={sun_mode} {volumes}", max_ulp=0)
+    hip_ctx.debug_set(force_general=True)
+    try:
+        general = f.run_hip(hip_ctx)
+    finally:
+        hip_ctx.debug_set(force_general=False)
+    assert int(util.f16_ulp_diff(got, general).max()) == 0
+    before = hip_ctx.copy_rebuilds()[0]
+    f.lpv_generation = 7
+    dev = f.device_arrays()
+    first, second = f.run_hip(hip_ctx, dev), f.run_hip(hip_ctx, dev)
+    assert hip_ctx.copy_rebuilds()[0] == before + 1, "the kept gather copy was rebuilt (or never built) by the tiled kernel's Lighting calls"
+    assert np.array_equal(first, got) and np.array_equal(second, got)
