@@ -5,7 +5,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r5"
+R = sys.argv[1] if len(sys.argv) > 1 else "r6"
 SRC, DST = "gpurun_out/refresh", "profiles"
 shutil.copy(f"{SRC}/bench.json", f"{DST}/{R}_bench_4k_deferred_gi.json")
 shutil.copy(f"{SRC}/ktrace/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_deferred_gi.csv")
@@ -13,6 +13,8 @@ shutil.copy(f"{SRC}/pmc.txt", f"{DST}/{R}_pmc_4k_deferred_gi.txt")
 if os.path.exists(f"{SRC}/ktrace_chain/kt_kernel_stats.csv"):
     shutil.copy(f"{SRC}/ktrace_chain/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_probe_gi_chain.csv")
 shutil.copy(f"{SRC}/passes.txt", f"{DST}/{R}_passes_4k.txt")
+if os.path.exists(f"{SRC}/ktrace_lpv_frame/kt_kernel_stats.csv"):
+    shutil.copy(f"{SRC}/ktrace_lpv_frame/kt_kernel_stats.csv", f"{DST}/{R}_kernel_stats_4k_lpv_gi_frame.csv")
 if os.path.exists(f"{SRC}/roofline_static.json"):
     shutil.copy(f"{SRC}/roofline_static.json", f"{DST}/roofline_static.json")
 for src, dst in (("pmc_rt_cache_tiled.txt", "pmc_rt_cache_tiled.txt"), ("pmc_tonemap.txt", "pmc_tonemap.txt"), ("cpu_baselines.txt", "cpu_baselines.txt"),
