@@ -17,3 +17,6 @@ timeout -k 10 400 python3 tools/stress_post.py > $O/stress_post.txt 2>&1 && echo
 timeout -k 10 400 python3 tools/stress_raster.py > $O/stress_raster.txt 2>&1 && echo "stress raster ok"
 # the 8K command that used to die under --pmc (light_stats' 16,384 outstanding dispatches), once, after the fix: its one result line
 bash tools/experiments/r4/r4_segv_fixed.sh > $O/segv_fixed.txt 2>&1 && echo "segv fixed: $(cat $O/segv_fixed.txt)"
+# what travels back from the GPU box is limited (64 MiB): the raw counter and trace CSVs have been summarised above
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -path "*/g[0-9]*" -name "*.csv" -delete
+du -sh $O | tail -1

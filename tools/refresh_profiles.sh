@@ -30,3 +30,6 @@ python3 tools/cpu_baselines.py --seconds 5 > $O/cpu_baselines.txt 2>> $O/bench.e
 # (round 6: no launcher around it — bench.py starts its own ranks)
 timeout -k 10 200 python3 bench.py --gpus 2 --steps 20 --warmup 5 --rehearse-on-one-gpu > $O/rehearse_n2.json 2> $O/rehearse_n2.err && echo "rehearsal ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ktrace_lpv_frame -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --workload 4k_lpv_gi_frame --steps 30 --warmup 5 > $O/ktrace_lpv_frame.log 2>&1 && echo "ktrace lpv frame ok"
+# what travels back from the GPU box is limited (64 MiB): the raw counter and trace CSVs have been summarised above
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -path "*/g[0-9]*" -name "*.csv" -delete
+du -sh $O | tail -1
