@@ -29,6 +29,8 @@
 // LDS per workgroup: G 32.3 KB + texels 10.8 KB + tables 9 KB = 52.3 KB, 3 workgroups per CU.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "post_common.hpp"
 
 namespace sah {
@@ -122,11 +124,20 @@ __global__ void __launch_bounds__(256) k_tonemap_axis_tables(TonemapArgs t, TmAx
     out[(size_t)blockIdx.y * t.axis_stride + i] = e;
 }
 
-template <int kTileH>
-__global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(TonemapArgs t) {
+// kThreads: 256 (the product: a thread owns two adjacent columns of kTileH / 16 rows) or 512 — round 6's experiment (SAH_TM_THREADS=512; VERDICT r5 item 3:
+// "512- or 1,024-thread workgroups, so a SIMD has another wave to run while one waits at a barrier"): the same tile, rectangles, stages and LDS with twice
+// the waves, each thread one row of the 32-row tile; 114 VGPRs, so TWO such workgroups per CU = four waves per SIMD where three 256-thread workgroups are
+// three.  Same codes (tests, tools/stress_post.py) and SLOWER: 0.2073 ms against 0.1794 for the 4K frame (two tiles in flight per CU instead of three
+// outweigh the second wave per SIMD); held to six waves per SIMD (80 VGPRs, 144 B of scratch) 0.352.  tools/experiments/r6/README.md §8.
+template <int kTileH, int kThreads>
+__global__ void __launch_bounds__(kThreads, (kThreads == 512 ? 4 : TmShape<kTileH>::kWaves)) k_tonemap_tol(TonemapArgs t) {
     using Shape = TmShape<kTileH>;
-    constexpr int kMaxRows = Shape::kMaxRows, kPlane = kMaxRows * kTile * 3, kStageIters = (kMaxRows + 7) / 8;
-    constexpr int kA = kTileH / 16;  // pixel rows per thread: tile rows tr + 16 a
+    constexpr int kRowStep = kThreads / 16;  // pixel rows (and pass-1 items) a sweep of the workgroup covers
+    constexpr int kStageRowStep = kThreads / 32;  // staged rows a sweep of the staging loads covers
+    constexpr int kMaxRows = Shape::kMaxRows, kPlane = kMaxRows * kTile * 3, kStageIters = (kMaxRows + kStageRowStep - 1) / kStageRowStep;
+    constexpr int kA = kTileH / kRowStep;  // pixel rows per thread: tile rows tr + kRowStep a
+    static_assert(kA >= 1 && kTileH % kRowStep == 0, "tile height / threads");
+    const uint32_t tid8 = threadIdx.x & 255u;  // the 256 table entries of a mip are fetched and stored by every 256-thread half alike (same values)
     // (s_src and s_xt are read by pass 1 only, which every thread has left before anybody commits the next stage: single buffers; s_yt is
     // read by pass 2, which overlaps the next commit: double buffer)
     __shared__ __attribute__((aligned(16))) float4 s_src[kMaxRows * kPitch];  // staged texels, fp32 rgb (w unused), edge replication applied
@@ -157,8 +168,8 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
     auto stage_count = [&](uint32_t s) __attribute__((always_inline)) { return min(Shape::first(s + 1u), nmips) - Shape::first(s); };
 
     // the thread's table entry of a mip: (axis, variant, column / row) = (tid / 128, tid / 32 % 4, tid % 32)
-    const uint32_t entry_off = (((threadIdx.x >> 7) * 4u + ((threadIdx.x >> 5) & 3u)) * t.axis_stride) +
-                               ((threadIdx.x >> 7) == 0 ? min(bx + (threadIdx.x & 31u), x_last) : min(by + (threadIdx.x & 31u), y_last));  // past the edge: the last valid one
+    const uint32_t entry_off = (((tid8 >> 7) * 4u + ((tid8 >> 5) & 3u)) * t.axis_stride) +
+                               ((tid8 >> 7) == 0 ? min(bx + (tid8 & 31u), x_last) : min(by + (tid8 & 31u), y_last));  // past the edge: the last valid one
     uint2 staged[kStageIters];
     TmAxis entry0 = {0, 0.f}, entry1 = entry0, entry2 = entry0;
     // rows of the stage's mips as they lie in s_src / s_g: rb_j = first row of mip j of the stage (rb3: one past the last); a mip that is bad
@@ -192,7 +203,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
         const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
 #pragma unroll
         for (int j = 0; j < kStageIters; j++) {
-            const int rr = ty0 + 8 * j;  // row of the stage
+            const int rr = ty0 + kStageRowStep * j;  // row of the stage
             const int mj = (rr >= rb1 ? 1 : 0) + (rr >= rb2 ? 1 : 0);
             const uint32_t m = min(first + (uint32_t)mj, nmips - 1u);
             const uint4 mi = s_mip[m];
@@ -218,12 +229,12 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
         const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
 #pragma unroll
         for (int j = 0; j < kStageIters; j++) {
-            const int rr = ty0 + 8 * j;
+            const int rr = ty0 + kStageRowStep * j;
             if (rr < rb3)
                 s_src[rr * kPitch + tx] = make_float4(h2f((uint16_t)(staged[j].x & 0xffffu)), h2f((uint16_t)(staged[j].x >> 16)),
                                                        h2f((uint16_t)(staged[j].y & 0xffffu)), 0.f);
         }
-        const uint32_t te = threadIdx.x & (kTile - 1), tk = (threadIdx.x >> 5) & 3u, taxis = threadIdx.x >> 7;
+        const uint32_t te = tid8 & (kTile - 1), tk = (tid8 >> 5) & 3u, taxis = tid8 >> 7;
         auto put_entry = [&](uint32_t q, const TmAxis& en, const Rect& r, int rbase) __attribute__((always_inline)) {
             if (q < cnt && r.w > 0) {
                 if (taxis == 0) {
@@ -248,7 +259,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
     const bool live_col[2] = {x0p < t.out_w, x0p + 1u < t.out_w};
     bool live_row[kA];
 #pragma unroll
-    for (int a = 0; a < kA; a++) live_row[a] = by + tr + 16u * (uint32_t)a < t.row_end;
+    for (int a = 0; a < kA; a++) live_row[a] = by + tr + (uint32_t)kRowStep * (uint32_t)a < t.row_end;
 
     // the scene texels of the thread's pixels are sampled at the END (hoisted to the start, their twelve registers spilled across the whole
     // stage loop: 0.202 against 0.193 ms); one texel per pixel row is touched here so that the lines are in L2 by then
@@ -256,7 +267,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
     auto sample_scene = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < kA; a++) {
-        const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1u);
+        const uint32_t y = min(by + tr + (uint32_t)kRowStep * (uint32_t)a, t.row_end - 1u);
         const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -269,7 +280,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
     {
 #pragma unroll
         for (int a = 0; a < kA; a++) {
-            const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1u), x = min(x0p, t.out_w - 1);
+            const uint32_t y = min(by + tr + (uint32_t)kRowStep * (uint32_t)a, t.row_end - 1u), x = min(x0p, t.out_w - 1);
             const float v = 1.0f - ((float)y + 0.5f) / (float)t.out_h;
             const int sy = min(max((int)(v * (float)t.scene_h), 0), (int)t.scene_h - 1), sx = min(max((int)(((float)x + 0.5f) / (float)t.out_w * (float)t.scene_w), 0), (int)t.scene_w - 1);
             uint32_t w = *reinterpret_cast<const uint32_t*>(t.scene.ptr + (size_t)sy * t.scene.pitch + (size_t)sx * 8);
@@ -290,7 +301,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
                    bad2 = cnt > 2u && __builtin_amdgcn_readfirstlane(s_bad[b][2]) != 0;
         {
             // pass 1: items (column pair, staged row of the stage): column pair = tid % 16, rows tid / 16 + 16 j
-            for (int r = (int)tr; r < total_rows; r += 16) {
+            for (int r = (int)tr; r < total_rows; r += kRowStep) {
                 const int mj = (r >= mr1 ? 1 : 0) + (r >= mr2 ? 1 : 0);
                 if (mj == 0 ? bad0 : (mj == 1 ? bad1 : bad2)) continue;  // (its rows hold nothing: rc.h == 0, or the tables are not inside)
                 const float4* srow = s_src + r * kPitch;
@@ -349,7 +360,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
                 AxisS ey[kA][4];
 #pragma unroll
                 for (int a = 0; a < kA; a++) {
-                    const uint32_t pr = min(tr + 16u * (uint32_t)a, y_last - by);  // rows past the band: the last valid one (dropped later)
+                    const uint32_t pr = min(tr + (uint32_t)kRowStep * (uint32_t)a, y_last - by);  // rows past the band: the last valid one (dropped later)
 #pragma unroll
                     for (int yv = 0; yv < 4; yv++) ey[a][yv] = lds_axis(&s_yt[b][j][yv][pr]);
                 }
@@ -385,7 +396,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
                 for (int a = 0; a < kA; a++)
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
-                        const uint32_t y = min(by + tr + 16u * (uint32_t)a, t.row_end - 1), x = min(x0p + (uint32_t)c, t.out_w - 1);
+                        const uint32_t y = min(by + tr + (uint32_t)kRowStep * (uint32_t)a, t.row_end - 1), x = min(x0p + (uint32_t)c, t.out_w - 1);
                         bloom[a][c] = bloom[a][c] + tent_blur(mp, t.mip_w[m], t.mip_h[m], ((float)x + 0.5f) / (float)t.out_w, 1.0f - ((float)y + 0.5f) / (float)t.out_h);
                     }
             }
@@ -396,7 +407,7 @@ __global__ void __launch_bounds__(256, TmShape<kTileH>::kWaves) k_tonemap_tol(To
 #pragma unroll
     for (int a = 0; a < kA; a++) {
         if (!live_row[a]) continue;
-        const uint32_t y = by + tr + 16u * (uint32_t)a;
+        const uint32_t y = by + tr + (uint32_t)kRowStep * (uint32_t)a;
         uint32_t px[2] = {0u, 0u};
         if (a == 0) sample_scene();
 #pragma unroll
@@ -443,8 +454,13 @@ hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st) {
     const uint32_t cols = (t.out_w + kTile - 1) / kTile;
     // 32-row tiles unless they would not fill the chip's 768 workgroup slots twice (a rank's band of a row-sharded frame: its last,
     // partly filled round would be half the pass): then 16-row tiles, four per CU
-    if ((uint64_t)cols * ((rows + 31) / 32) >= 2 * 768) hipLaunchKernelGGL(k_tonemap_tol<32>, dim3(cols, (rows + 31) / 32), dim3(256), 0, st, t);
-    else hipLaunchKernelGGL(k_tonemap_tol<16>, dim3(cols, (rows + 15) / 16), dim3(256), 0, st, t);
+    static const int env_threads = getenv("SAH_TM_THREADS") ? atoi(getenv("SAH_TM_THREADS")) : 0;  // experiments (tools/experiments/r6): 256 / 512
+    static const int env_band32 = getenv("SAH_TM_BAND32") ? atoi(getenv("SAH_TM_BAND32")) : 0;
+    const bool big = (uint64_t)cols * ((rows + 31) / 32) >= 2 * 768;
+    if (big || env_band32) {
+        if (env_threads == 512) hipLaunchKernelGGL((k_tonemap_tol<32, 512>), dim3(cols, (rows + 31) / 32), dim3(512), 0, st, t);
+        else hipLaunchKernelGGL((k_tonemap_tol<32, 256>), dim3(cols, (rows + 31) / 32), dim3(256), 0, st, t);
+    } else hipLaunchKernelGGL((k_tonemap_tol<16, 256>), dim3(cols, (rows + 15) / 16), dim3(256), 0, st, t);
     return hipGetLastError();
 }
 
