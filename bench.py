@@ -293,6 +293,9 @@ def setup_distributed(args):
     if R.rehearsal:
         R.local_rank = 0
         args.exchange = "ipc"
+    elif R.local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {R.rank} (local rank {R.local_rank}) has no GPU — this box shows {torch.cuda.device_count()}; --gpus N needs N GPUs "
+                         "(to rehearse the N-rank control flow on one GPU: --rehearse-on-one-gpu)")
     torch.cuda.set_device(R.local_rank)
     R.dev = torch.device("cuda", R.local_rank)
     R.red_dev = torch.device("cpu") if R.rehearsal else R.dev  # where the small all-reduces of this file live (gloo has no GPU tensors here)
