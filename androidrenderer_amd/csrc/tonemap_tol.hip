@@ -452,12 +452,16 @@ hipError_t launch_tonemap_tol(const TonemapArgs& t, hipStream_t st) {
     const uint32_t rows = t.row_end - t.row_begin;
     if (rows == 0) return hipSuccess;
     const uint32_t cols = (t.out_w + kTile - 1) / kTile;
-    // 32-row tiles unless they would not fill the chip's 768 workgroup slots twice (a rank's band of a row-sharded frame: its last,
-    // partly filled round would be half the pass): then 16-row tiles, four per CU
+    // 32-row tiles for every launch (round 6).  Rounds 4-5 gave row bands that would not fill the chip's 768 workgroup slots twice (a rank's rows of a
+    // sharded frame) 16-row tiles, four per CU, for the band's latency BY ITSELF — where the two shapes are level at 270 rows (43.6 against 45.6 us) and the
+    // 32-row one ahead below (72 / 144 rows: 16.0 / 18.5 against 19.0 / 27.3).  But a band never runs by itself: in the rank's three-stream frame loop the
+    // chip is shared with the lighting and reduction of the next frame, what counts is the composite's WORK, and the 16-row shape stages a third more rows
+    // per pixel row (whole frame 0.238 against 0.179 ms): one rank of eight 0.1058 -> 0.0930 ms per frame with 32-row tiles on its band
+    // (tools/experiments/r6/README.md §9).  SAH_TM_BAND16=1 brings the old rule back (A/B).
     static const int env_threads = getenv("SAH_TM_THREADS") ? atoi(getenv("SAH_TM_THREADS")) : 0;  // experiments (tools/experiments/r6): 256 / 512
-    static const int env_band32 = getenv("SAH_TM_BAND32") ? atoi(getenv("SAH_TM_BAND32")) : 0;
+    static const int env_band16 = getenv("SAH_TM_BAND16") ? atoi(getenv("SAH_TM_BAND16")) : 0;
     const bool big = (uint64_t)cols * ((rows + 31) / 32) >= 2 * 768;
-    if (big || env_band32) {
+    if (big || !env_band16) {
         if (env_threads == 512) hipLaunchKernelGGL((k_tonemap_tol<32, 512>), dim3(cols, (rows + 31) / 32), dim3(512), 0, st, t);
         else hipLaunchKernelGGL((k_tonemap_tol<32, 256>), dim3(cols, (rows + 31) / 32), dim3(256), 0, st, t);
     } else hipLaunchKernelGGL((k_tonemap_tol<16, 256>), dim3(cols, (rows + 15) / 16), dim3(256), 0, st, t);
