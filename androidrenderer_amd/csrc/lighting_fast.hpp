@@ -290,6 +290,23 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
         lpv_v = cpy.v;
         lpv_w = cpz.v;
     }
+#ifdef SAH_EXP_LPV_TOUCH
+    // experiment (tools/experiments/r6): one dword of each of the four (y, z) rows of the LPV footprint requested BEFORE the sun's arithmetic, consumed
+    // behind it: the twelve 16-byte loads of lpv_fetch_packed() then find their lines in the vector cache
+    uint32_t lpv_touch[4] = {0u, 0u, 0u, 0u};
+    if constexpr (GI == SAH_GI_LPV && SUN == SAH_SHADOW_MODE_CSM) {
+        const int W = (int)lpv.red.width, H = (int)lpv.red.height, Dd = (int)lpv.red.depth;
+        const float px = lpv_u * (float)W - 0.5f, py = lpv_v * (float)H - 0.5f, pz = lpv_w * (float)Dd - 0.5f;
+        const int b = (int)kLpvPackBorder;
+        const uint32_t x0 = (uint32_t)(min(max(clamp_to_int(__builtin_floorf(px)), -b), W) + b), y0 = (uint32_t)(min(max(clamp_to_int(__builtin_floorf(py)), -b), H) + b),
+                       z0 = (uint32_t)(min(max(clamp_to_int(__builtin_floorf(pz)), -b), Dd) + b);
+        const uint32_t base = z0 * f.pk_slice_pitch + y0 * f.pk_row_pitch + x0 * kLpvPackTexel;
+        lpv_touch[0] = *reinterpret_cast<const uint32_t*>(f.lpv_packed + base);
+        lpv_touch[1] = *reinterpret_cast<const uint32_t*>(f.lpv_packed + base + f.pk_row_pitch);
+        lpv_touch[2] = *reinterpret_cast<const uint32_t*>(f.lpv_packed + base + f.pk_slice_pitch);
+        lpv_touch[3] = *reinterpret_cast<const uint32_t*>(f.lpv_packed + base + f.pk_slice_pitch + f.pk_row_pitch);
+    }
+#endif
 
     // ---------------- a1: sun, CSM mode ----------------
     // direct = ((ndotl * brdf) * colour) * shadow is exactly 0 (or NaN, which the shader's guard turns into 0) whenever
@@ -310,6 +327,9 @@ SAH_DEV FastPixelOut shade_pixel_fast_sl(const LightingArgs& a, const CsmArgs& c
 
     // ---------------- a3: LPV overlay ----------------
     if constexpr (GI == SAH_GI_LPV) {
+#ifdef SAH_EXP_LPV_TOUCH
+        asm volatile("" ::"v"(lpv_touch[0]), "v"(lpv_touch[1]), "v"(lpv_touch[2]), "v"(lpv_touch[3]));
+#endif
         Fn indirect[3];
         lpv_fetch_packed(lpv, f.lpv_packed, f.pk_row_pitch, f.pk_slice_pitch, lpv_u, lpv_v, lpv_w, nc, indirect);
         // Fd(surface, N, N) == diffuse_color * (1/pi) exactly when N is a finite normalised vector, and the specular term
