@@ -1,10 +1,10 @@
 #!/bin/bash
 # AddressSanitizer + UndefinedBehaviorSanitizer over everything that runs on the CPU: the oracle (oracle/Makefile target
 # `asan`, loaded by the whole CPU test suite through SAH_ORACLE_SO) and the host-only C++ test programs of tests/cpp.  Never the GPU build.
-#   tools/sanitize.sh [log]     (default log: profiles/r5_sanitizers.txt)
+#   tools/sanitize.sh [log]     (default log: profiles/r6_sanitizers.txt)
 set -o pipefail
 cd "$(dirname "$0")/.."
-LOG=${1:-profiles/r5_sanitizers.txt}
+LOG=${1:-profiles/r6_sanitizers.txt}
 ASAN_RT=$(gcc -print-file-name=libasan.so)
 UBSAN_RT=$(gcc -print-file-name=libubsan.so)
 {
