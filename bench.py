@@ -977,6 +977,46 @@ def time_longer_run(R):
             "note": "the same loop over 200 steps, GPU time between two events, after the timed region"}
 
 
+def time_exchange_only(R):
+    """N > 1, chain workloads through the library's exchange: the frame's two gathers (bloom mip 1, the final RGBA8 rows) by themselves, with no
+    compute beside them — what the frame rate cannot exceed whatever the kernels do (the sharded loop overlaps them with compute: frame time =
+    max(compute, exchange)).  EVERY rank runs it (the gathers are collective), the same fixed number of times; outside the timed region.
+    Returns the report's dict or None."""
+    if not (R.world > 1 and R.pipelined and R.gather and R.lib_gather and R.pc is not None and not R.failure):
+        return None
+    torch, ctx = R.torch, R.ctx
+    sc = R.pc.sets[0]
+    n = 20
+    R.beat("exchange-only timing")
+    try:
+        R.drain()
+        torch.cuda.synchronize()
+        R.dist.barrier()
+        for _ in range(3):
+            sc.exchange_mip()
+            sc.exchange_final()
+        ctx.comm_wait()
+        torch.cuda.synchronize()
+        R.dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            sc.exchange_mip()
+            sc.exchange_final()
+        ctx.comm_wait()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        R.dist.barrier()
+    except Exception as e:  # (a diagnostic must not cost the run its line)
+        return {"error": str(e)[:200]}
+    p = sc.plan
+    mip_bytes = p.mip1_rows_per_rank * sc.mip1_alloc.shape[1] * 8 * (R.world - 1)
+    out_bytes = p.rows_per_rank * R.W * 4 * (R.world - 1)
+    return {"ms_per_frame": round(ms, 5), "bytes_arriving_per_rank": int(mip_bytes + out_bytes),
+            "arriving_GB_per_s_per_rank": round((mip_bytes + out_bytes) / (ms * 1e-3) / 1e9, 1),
+            "note": "the frame's two gathers alone, 20 frames back to back behind 3 untimed ones, host clock of rank 0 around a synchronise; the sharded loop "
+                    "runs them beside compute, so ms_per_step >= this"}
+
+
 def time_with_rebuild(R):
     """One GPU, LPV lighting workloads under --lpv-copy propagate: the same pass with lpv_generation 0 — k_lpv_pack inside every step, what the
     frame pays when its volumes are rewritten by a pass that is not the library's.  Outside the timed region; returns the report's dict or None."""
@@ -1098,6 +1138,8 @@ def report(R):
         "roofline": roofline(args.workload, world, achieved, R.kernel_ms_mean, R.kernel_ms_min, R.kernel_scope, R.bytes_per_pixel * R.my_px, R.my_px,
                              "sah::k_lighting_tiled" if (R.n_lights or R.gi_kind in (_abi.GI_CACHE, _abi.GI_RTGI)) else "sah::k_lighting_fast"),
     }
+    if getattr(R, "exchange_only", None) is not None:
+        out["config"]["exchange_only"] = R.exchange_only
     if world > 1:
         # what a scaling curve of THIS line has to be read against: the same workload unsharded on one of these GPUs, timed by this run (the
         # N = 1 run of this file measures the headline lighting pass — another workload; value(N) / value(1) across the two is not a speed-up)
@@ -1144,6 +1186,7 @@ def main(argv=None):
     preflight(R)
     run_timed(R)
     verify(R)
+    R.exchange_only = time_exchange_only(R)
     R.longer_run = time_longer_run(R) if R.rank == 0 and not R.failure else None
     R.with_rebuild = time_with_rebuild(R) if R.rank == 0 and not R.failure else None
     if R.rank == 0:
